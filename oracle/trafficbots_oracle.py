@@ -1,0 +1,538 @@
+"""ORACLE -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+CPU restatement (PyTorch-CPU tensor ops, fp32 or fp64) of the reference's scene-encoder +
+closed-loop rollout hot path for the default config, written from SURVEY.md Appendix A and the
+reference sources cited per function.  It exists to check the HIP path: only `tests/`,
+`__graft_entry__.smoke()` and `bench.py`'s `cpu_baseline` leg may import it; the package
+`trafficbots_amd` never does (and fails loudly without its HIP library).
+
+Parity pin: validated against the reference itself, imported in the build container, through
+the committed fixtures `tests/golden/*.npz` (generator: `tools/gen_golden.py`); see
+`tests/test_oracle_golden.py`.
+
+It works on a flat dict of weights in the reference's `state_dict` naming and is purely
+functional (no nn.Module), operation order follows the reference so that fp32 results agree
+with it to rounding.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+from torch import Tensor
+
+H = 128
+N_HEAD = 4
+D_HEAD = 32
+LN_EPS = 1e-5
+
+
+def _t(x, dtype):
+    if isinstance(x, np.ndarray):
+        x = torch.from_numpy(np.ascontiguousarray(x))
+    if x.is_floating_point():
+        x = x.to(dtype)
+    return x
+
+
+class Oracle:
+    def __init__(self, state_dict: Dict[str, np.ndarray], cfg: dict, dtype=torch.float32, hoist: bool = False):
+        """`hoist=False` recomputes the loop-invariant map/TL K,V projections and the goal/latent
+        `mlp_in` every step exactly as the reference does; `hoist=True` computes them
+        once (same values) -- used where only the result matters."""
+        self.dtype = dtype
+        self.cfg = cfg
+        self.w = {k: _t(v, dtype) for k, v in state_dict.items()}
+        self.hoist = hoist
+        dyn = cfg["dynamics"]
+        # type order veh=0, ped=1, cyc=2 (`dynamics.py:23-27`: instantiate(veh), (ped), (cyc))
+        self.max_acc = torch.tensor([dyn["veh"]["max_acc"], dyn["ped"]["max_acc"], dyn["cyc"]["max_acc"]], dtype=dtype)
+        self.max_yr = torch.tensor(
+            [dyn["veh"]["max_yaw_rate"], dyn["ped"]["max_yaw_rate"], dyn["cyc"]["max_yaw_rate"]], dtype=dtype
+        )
+        self.dt = 0.1
+        self.t_cur = cfg["time_step_current"]
+        self.n_hist = self.t_cur + 1
+
+    # ------------------------------------------------------------------ building blocks
+    def _ln(self, x: Tensor, prefix: str) -> Tensor:
+        return F.layer_norm(x, (x.shape[-1],), self.w[prefix + ".weight"], self.w[prefix + ".bias"], LN_EPS)
+
+    def _lin(self, x: Tensor, prefix: str) -> Tensor:
+        return F.linear(x, self.w[prefix + ".weight"], self.w[prefix + ".bias"])
+
+    def pose_pe(self, xy: Tensor, yaw: Tensor, who: str = "agent") -> Tensor:
+        """`PosePE.forward` mode pe_xy_yaw (`src/utils/pose_pe.py:57-62`) with
+        `PositionalEmbedding` / `PositionalEmbeddingRad` (`src/utils/pos_emb.py:24-25,54-55`)."""
+        f_xy = self.w[f"pre_processing.input.pose_pe_{who}.pe_xy.freqs"]
+        f_yaw = self.w[f"pre_processing.input.pose_pe_{who}.pe_yaw.freqs"]
+
+        def emb(v: Tensor, freqs: Tensor) -> Tensor:
+            e = v.unsqueeze(-1) * freqs
+            return torch.cat([torch.cos(e[..., ::2]), torch.sin(e[..., 1::2])], dim=-1)
+
+        return torch.cat([emb(xy[..., 0], f_xy), emb(xy[..., 1], f_xy), emb(yaw, f_yaw)], dim=-1)
+
+    def input_pe_encoder(self, prefix: str, valid: Tensor, attr: Tensor, pe: Tensor) -> Tensor:
+        """`InputPeEncoder.forward`, pe_mode=cat (`input_pe_encoder.py:52-59`)."""
+        x = self._lin(torch.relu(self._lin(attr, prefix + ".mlp.fc_layers.0")), prefix + ".mlp.fc_layers.3")
+        x = torch.cat([x, pe], dim=-1)
+        return x.masked_fill(~valid.unsqueeze(-1), 0)
+
+    def kv_project(self, prefix: str, tgt: Tensor):
+        """LN_tgt + packed K,V projection of one layer (`transformer.py:189-192`, `attention.py:81-87`)."""
+        w_in = self.w[prefix + ".attn.in_proj_weight"]
+        b_in = self.w[prefix + ".attn.in_proj_bias"]
+        t = self._ln(tgt, prefix + ".norm_tgt")
+        kv = F.linear(t, w_in[H:], b_in[H:])
+        return kv[..., :H], kv[..., H:]
+
+    def tf_layer(self, prefix: str, src: Tensor, src_invalid: Tensor, tgt: Optional[Tensor], tgt_invalid: Tensor,
+                 attn_mask: Optional[Tensor] = None, kv=None) -> Tensor:
+        """One pre-LN `TransformerCrossAttention` layer incl. `Attention` (`transformer.py:189-239`,
+        `attention.py:81-146`), eval mode.  src [n, ns, H]; tgt [n, nt, H]; masks True = invalid."""
+        n, ns, _ = src.shape
+        w_in = self.w[prefix + ".attn.in_proj_weight"]
+        b_in = self.w[prefix + ".attn.in_proj_bias"]
+        s = self._ln(src, prefix + ".norm1")
+        q = F.linear(s, w_in[:H], b_in[:H])
+        k, v = kv if kv is not None else self.kv_project(prefix, tgt)
+        nt = k.shape[-2]
+        inv = tgt_invalid.unsqueeze(1).expand(-1, ns, -1)
+        if attn_mask is not None:
+            inv = inv | attn_mask
+        no_tgt = inv.all(-1)  # [n, ns]
+        inv = inv & (~no_tgt.unsqueeze(-1))
+        q = q.view(n, ns, N_HEAD, D_HEAD).transpose(1, 2)
+        k = k.reshape(n, nt, N_HEAD, D_HEAD).transpose(1, 2)
+        v = v.reshape(n, nt, N_HEAD, D_HEAD).transpose(1, 2)
+        attn = torch.matmul(q, k.transpose(-2, -1))
+        attn = attn.masked_fill(inv.unsqueeze(1), float("-inf"))
+        attn = torch.softmax(attn / math.sqrt(D_HEAD), dim=-1)
+        out = torch.matmul(attn, v).transpose(1, 2).flatten(2, 3)
+        out = F.linear(out, self.w[prefix + ".attn.out_proj_weight"], self.w[prefix + ".attn.out_proj_bias"])
+        out = out.masked_fill(no_tgt.unsqueeze(-1), 0)
+        src = src + out
+        s2 = self._ln(src, prefix + ".norm2")
+        s2 = self._lin(torch.relu(self._lin(s2, prefix + ".linear1")), prefix + ".linear2")
+        src = src + s2
+        return src.masked_fill(src_invalid.unsqueeze(-1), 0.0)
+
+    def tf_block(self, prefix: str, n_layer: int, src, src_invalid, tgt, tgt_invalid, attn_mask=None, kvs=None):
+        """`TransformerBlock.forward` (`transformer.py:82-92`): tgt is NOT updated between layers."""
+        for i in range(n_layer):
+            src = self.tf_layer(f"{prefix}.layers.{i}", src, src_invalid, tgt, tgt_invalid, attn_mask,
+                                kv=None if kvs is None else kvs[i])
+        return src
+
+    def interaction(self, prefix: str, x: Tensor, valid: Tensor) -> Tensor:
+        """`MultiAgentTF.forward` (`agent_interaction.py:51-93`): tgt = block input, eye mask,
+        groups with exactly one valid agent pass through unchanged."""
+        n, a, _ = x.shape
+        eye = torch.eye(a, dtype=torch.bool).unsqueeze(0).expand(n, -1, -1)
+        single = valid.sum(-1) == 1
+        y = self.tf_block(prefix + ".transformer", 3, x, ~valid, x, ~valid, attn_mask=eye)
+        return torch.where(single[:, None, None], x, y)
+
+    def gru_step(self, prefix: str, x: Tensor, h: Tensor):
+        """One time step of `nn.GRU(128,128,3)` (gate order r,z,n).  x [M,H], h [3,M,H]."""
+        h_new = []
+        inp = x
+        for l in range(3):
+            gi = F.linear(inp, self.w[f"{prefix}.weight_ih_l{l}"], self.w[f"{prefix}.bias_ih_l{l}"])
+            gh = F.linear(h[l], self.w[f"{prefix}.weight_hh_l{l}"], self.w[f"{prefix}.bias_hh_l{l}"])
+            i_r, i_z, i_n = gi.chunk(3, -1)
+            h_r, h_z, h_n = gh.chunk(3, -1)
+            r = torch.sigmoid(i_r + h_r)
+            z = torch.sigmoid(i_z + h_z)
+            nn_ = torch.tanh(i_n + r * h_n)
+            hl = (1 - z) * nn_ + z * h[l]
+            h_new.append(hl)
+            inp = hl
+        return inp, torch.stack(h_new, 0)
+
+    def gru_scan(self, prefix: str, x: Tensor, valid: Tensor) -> Tensor:
+        """`MultiAgentGRULoop.forward`, 3-D valid branch (`agent_temporal.py:133-146`).
+        x [B,S,A,H], valid [B,S,A] -> [B,S,A,H]."""
+        b, s, a, _ = x.shape
+        h = torch.zeros(3, b * a, H, dtype=x.dtype)
+        outs = []
+        for k in range(s):
+            o, h = self.gru_step(prefix, x[:, k].reshape(b * a, H), h)
+            inv = ~valid[:, k].reshape(b * a, 1)
+            h = h.masked_fill(inv.unsqueeze(0), 0.0)
+            outs.append(o.masked_fill(inv, 0.0).view(b, a, H))
+        return torch.stack(outs, 1)
+
+    # ------------------------------------------------------------------ scene encoders
+    def preprocess(self, batch: Dict[str, np.ndarray]) -> Dict[str, Tensor]:
+        """`SceneCentricPreProcessing` (eval) + `SceneCentricInput.forward`
+        (`scene_centric.py:103-133`, `sc_input.py:100-140`)."""
+        d = self.dtype
+        nh = self.n_hist
+        g = {k: _t(v, d) for k, v in batch.items()}
+        out: Dict[str, Tensor] = {}
+        av = g["history/agent/valid"][:, :nh]
+        out["agent_valid"] = av
+        a_type = g["history/agent/type"]
+        a_size = g["history/agent/size"]
+        n_agent = av.shape[-1]
+        out["agent_attr"] = torch.cat(
+            [
+                g["history/agent/vel"][:, :nh], g["history/agent/spd"][:, :nh], g["history/agent/yaw_rate"][:, :nh],
+                g["history/agent/acc"][:, :nh],
+                a_size.unsqueeze(1).expand(-1, nh, -1, -1), a_type.unsqueeze(1).expand(-1, nh, -1, -1).to(d),
+            ], dim=-1)
+        out["agent_pe"] = self.pose_pe(g["history/agent/pos"][:, :nh], g["history/agent/yaw_bbox"][:, :nh, :, 0], "agent")
+        out["agent_state"] = torch.cat(
+            [g["history/agent/pos"][:, :nh], g["history/agent/yaw_bbox"][:, :nh], g["history/agent/spd"][:, :nh]], -1)
+        out["agent_vel"] = g["history/agent/vel"][:, :nh]
+        out["agent_acc"] = g["history/agent/acc"][:, :nh]
+        out["agent_yaw_rate"] = g["history/agent/yaw_rate"][:, :nh]
+        out["agent_type"] = a_type
+        out["agent_size"] = a_size
+        mv = g["map/valid"]
+        b, p, nn_ = mv.shape
+        out["map_valid"] = mv
+        out["map_attr"] = torch.cat(
+            [g["map/type"].unsqueeze(-2).expand(-1, -1, nn_, -1).to(d),
+             torch.eye(nn_, dtype=d)[None, None].expand(b, p, -1, -1)], dim=-1)
+        map_yaw = torch.atan2(g["map/dir"][..., 1], g["map/dir"][..., 0])
+        out["map_pe"] = self.pose_pe(g["map/pos"], map_yaw, "map")
+        out["map_type"] = g["map/type"]
+        out["map_pos"] = g["map/pos"]
+        out["map_dir"] = g["map/dir"]
+        out["map_boundary"] = g["map/boundary"]
+        out["tl_valid"] = g["history/tl_stop/valid"][:, :nh]
+        out["tl_attr"] = g["history/tl_stop/state"][:, :nh].to(d)
+        tl_dir = g["history/tl_stop/dir"][:, :nh]
+        out["tl_pe"] = self.pose_pe(g["history/tl_stop/pos"][:, :nh], torch.atan2(tl_dir[..., 1], tl_dir[..., 0]), "tl")
+        return out
+
+    def map_encoder(self, inp: Dict[str, Tensor]):
+        """`MapEncoder.forward` (`map_encoder.py:72-114`), densetnt_vectornet + max pool."""
+        mv = inp["map_valid"]
+        b, p, nn_ = mv.shape
+        x = self.input_pe_encoder("model.map_encoder.input_pe_encoder", mv, inp["map_attr"], inp["map_pe"])
+        x = x.flatten(0, 1)
+        v = mv.flatten(0, 1)
+        x = self.tf_block("model.map_encoder.transformer_densetnt", 3, x, ~v, x, ~v)
+        x = x.view(b, p, nn_, H).masked_fill(~mv.unsqueeze(-1), float("-inf")).amax(dim=2)
+        pl_valid = mv.any(-1)
+        x = x.masked_fill(~pl_valid.unsqueeze(-1), 0)
+        x = self.tf_block("model.map_encoder.transformer_self_attn", 1, x, ~pl_valid, x, ~pl_valid)
+        return x, pl_valid
+
+    def encode_scene(self, inp: Dict[str, Tensor]) -> Dict[str, Tensor]:
+        """`TrafficBots.encode_input_features` (`traffic_bots.py:147-151`)."""
+        f: Dict[str, Tensor] = {}
+        f["map_feature"], f["map_valid"] = self.map_encoder(inp)
+        f["agent_feature"] = self.input_pe_encoder("model.agent_encoder", inp["agent_valid"], inp["agent_attr"], inp["agent_pe"])
+        f["agent_valid"] = inp["agent_valid"]
+        f["tl_feature"] = self.input_pe_encoder("model.tl_encoder", inp["tl_valid"], inp["tl_attr"], inp["tl_pe"])
+        f["tl_valid"] = inp["tl_valid"]
+        return f
+
+    def latent_prior(self, f: Dict[str, Tensor]):
+        """`LatentEncoder.forward` prior branch (`latent_encoder.py:98-147`) + `DistEncoder` diag_gaus."""
+        r = self.cfg["model"]["latent_encoder"]["temporal_down_sample_rate"]
+        av = f["agent_valid"][:, ::r]
+        x = f["agent_feature"][:, ::r]
+        tv = f["tl_valid"][:, ::r]
+        tf_ = f["tl_feature"][:, ::r]
+        b, s, a, _ = x.shape
+        y = self.tf_block("model.transformer_as2pl", 3, x.flatten(1, 2), ~av.flatten(1, 2), f["map_feature"], ~f["map_valid"])
+        y = y.view(b, s, a, H)
+        y = self.tf_block("model.transformer_as2tl", 3, y.flatten(0, 1), ~av.flatten(0, 1), tf_.flatten(0, 1), ~tv.flatten(0, 1))
+        y = self.interaction("model.latent_encoder.agent_interaction_prior", y, av.flatten(0, 1)).view(b, s, a, H)
+        y = self.gru_scan("model.latent_encoder.agent_temporal_prior.rnn", y, av)
+        agg = y.masked_fill(~av.unsqueeze(-1), -1e3).amax(1)
+        valid = av.any(1)
+        agg = agg.masked_fill(~valid.unsqueeze(-1), 0)
+        pre = "model.latent_encoder.latent_prior_dist"
+        mean = self._lin(torch.relu(self._lin(agg, pre + ".mlp_mean.fc_layers.0")), pre + ".mlp_mean.fc_layers.2")
+        mean = mean.masked_fill(~valid.unsqueeze(-1), 0)
+        return mean, self.w[pre + ".log_std"], valid
+
+    def dest_logits(self, f: Dict[str, Tensor], inp: Dict[str, Tensor]) -> Tensor:
+        """`DestPredictor.forward`, mode mlp (`goal_manager.py:229-247,294-307,329-332`).  Returns the
+        masked, un-normalised logits [B,A,P]."""
+        af, av = f["agent_feature"], f["agent_valid"]
+        b, s, a, _ = af.shape
+        mtype, atype = inp["map_type"], inp["agent_type"]
+        map_type_mask = ~(f["map_valid"] & mtype[:, :, :5].any(-1))
+        m_veh = atype[:, :, [0]] & mtype[:, :, 3].unsqueeze(1)
+        m_ped = atype[:, :, [1]] & mtype[:, :, :4].any(-1).unsqueeze(1)
+        m_cyc = atype[:, :, [2]] & mtype[:, :, :3].any(-1).unsqueeze(1)
+        attn_mask = m_veh | m_ped | m_cyc
+        dist_valid = av.any(1)
+        pre = "model.goal_manager.goal_predictor"
+        t = self.gru_scan(pre + ".gru_as.rnn", af, av) + af
+        idx_last = s - 1 - torch.max(av.flip(1).to(torch.uint8), dim=1)[1]
+        t = t[torch.arange(b).unsqueeze(1), idx_last, torch.arange(a).unsqueeze(0)]
+        t = t.masked_fill(~dist_valid.unsqueeze(-1), 0)
+        p = f["map_feature"].shape[1]
+        pair = torch.cat([f["map_feature"].unsqueeze(1).expand(-1, a, -1, -1), t.unsqueeze(2).expand(-1, -1, p, -1)], -1)
+        y = torch.relu(self._ln(self._lin(pair, pre + ".mlp.fc_layers.0"), pre + ".mlp.fc_layers.1"))
+        y = torch.relu(self._ln(self._lin(y, pre + ".mlp.fc_layers.3"), pre + ".mlp.fc_layers.4"))
+        logits = self._lin(y, pre + ".mlp.fc_layers.6").squeeze(-1)
+        logits = logits.masked_fill(map_type_mask.unsqueeze(1), float("-inf"))
+        logits = logits.masked_fill(attn_mask, float("-inf"))
+        logits = logits.masked_fill(~dist_valid.unsqueeze(-1), 0)
+        logits = logits.masked_fill((logits == float("-inf")).all(-1).unsqueeze(-1), 0)
+        return logits
+
+    @staticmethod
+    def dest_distribution(logits: Tensor, k: int):
+        """`DestCategorical` after `repeat_interleave_` (`distributions.py:163-171,197-201`):
+        returns (probs [N,A,P], log-prob table [N,A,P]) exactly as torch's Categorical(probs=...) holds them."""
+        probs = torch.softmax(logits, -1)  # Categorical(logits).probs
+        probs = probs.repeat_interleave(k, 0)
+        probs = probs / probs.sum(-1, keepdim=True)
+        eps = torch.finfo(probs.dtype).eps
+        return probs, torch.log(probs.clamp(min=eps, max=1 - eps))
+
+    # ------------------------------------------------------------------ rollout
+    def teacher_forcing_mask(self, valid: Tensor, tf_cfg: dict) -> Tensor:
+        """`TeacherForcing.get` (`teacher_forcing.py:45-54`), schedule terms are zero by default."""
+        m = torch.zeros_like(valid)
+        m[:, 0] |= valid[:, 0]
+        ssa = tf_cfg.get("step_spawn_agent", 10)
+        if ssa > 0:
+            sp = (~valid[:, :-1]) & valid[:, 1:]
+            sp[:, ssa:] = False
+            m[:, 1:] |= sp
+        sws = tf_cfg.get("step_warm_start", 10)
+        if sws >= 0:
+            m[:, : sws + 1] |= valid[:, : sws + 1]
+        return m
+
+    def policy_step(self, x, valid, map_f, map_inv, tl_f, tl_inv, goal_f, goal_valid, z, h, hoisted=None):
+        """`TrafficBots.forward` (`traffic_bots.py:205-241`) for one sim step."""
+        w = self.w
+        kv_pl = hoisted["kv_pl"] if hoisted else None
+        kv_tl = hoisted["kv_tl"] if hoisted else None
+        x = self.tf_block("model.transformer_as2pl", 3, x, ~valid, map_f, map_inv, kvs=kv_pl)
+        x = self.tf_block("model.transformer_as2tl", 3, x, ~valid, tl_f, tl_inv, kvs=kv_tl)
+        x = self.interaction("model.agent_interaction", x, valid)
+        n, a, _ = x.shape
+        o, h = self.gru_step("model.agent_temporal.rnn", x.reshape(n * a, H), h)
+        inv = ~valid.reshape(n * a, 1)
+        h = h.masked_fill(inv.unsqueeze(0), 0.0)
+        x = o.masked_fill(inv, 0.0).view(n, a, H)
+        # add_goal (`add_latent_goal.py:57-77`; MLP masks before the trailing in-place ReLU, `mlp.py:80-84`)
+        if hoisted:
+            g_pre = hoisted["goal_pre"]
+        else:
+            g_pre = self.goal_mlp_in(goal_f)
+        u = torch.relu(g_pre.masked_fill(~goal_valid.unsqueeze(-1), 0))
+        hh = torch.relu(self._lin(torch.cat([x, u], -1), "model.add_goal.mlp_out.fc_layers.0"))
+        hh = torch.relu(self._lin(hh, "model.add_goal.mlp_out.fc_layers.3"))
+        hh = hh.masked_fill(~goal_valid.unsqueeze(-1), 0) + x
+        x = hh.masked_fill(~valid.unsqueeze(-1), 0)
+        # add_latent
+        z_pre = hoisted["latent_pre"] if hoisted else self.latent_mlp_in(z)
+        u = torch.relu(z_pre.masked_fill(~valid.unsqueeze(-1), 0))
+        hh = torch.relu(self._lin(torch.cat([x, u], -1), "model.add_latent.mlp_out.fc_layers.0"))
+        hh = torch.relu(self._lin(hh, "model.add_latent.mlp_out.fc_layers.3"))
+        hh = hh.masked_fill(~valid.unsqueeze(-1), 0) + x
+        x = hh.masked_fill(~valid.unsqueeze(-1), 0)
+        return x, h
+
+    def goal_mlp_in(self, goal_f: Tensor) -> Tensor:
+        p = "model.add_goal.mlp_in.fc_layers"
+        y = torch.relu(self._ln(self._lin(goal_f, p + ".0"), p + ".1"))
+        y = torch.relu(self._ln(self._lin(y, p + ".4"), p + ".5"))
+        return self._ln(self._lin(y, p + ".8"), p + ".9")
+
+    def latent_mlp_in(self, z: Tensor) -> Tensor:
+        p = "model.add_latent.mlp_in.fc_layers"
+        return self._lin(torch.relu(self._lin(z, p + ".0")), p + ".3")
+
+    def action_mean(self, x: Tensor, valid: Tensor, a_type: Tensor) -> Tensor:
+        """`ActionHead.forward`, branch_type (`action_head.py:69-75`)."""
+        mean = 0
+        for i in range(3):
+            y = self._lin(torch.relu(self._lin(x, f"action_head.mlp_mean.{i}.fc_layers.0")), f"action_head.mlp_mean.{i}.fc_layers.2")
+            mean = mean + y.masked_fill(~(a_type[:, :, i] & valid).unsqueeze(-1), 0)
+        return mean
+
+    def rollout(self, inp: Dict[str, Tensor], f: Dict[str, Tensor], z: Tensor, latent_mean: Tensor, dest: Tensor,
+                goal_valid: Tensor, k: int, step_end: int, tap_steps=()) -> Dict[str, Tensor]:
+        """`WaymoMotion.rollout` + `forward` + `Dynamics` + always-on `TrafficRuleChecker` + buffer
+        (`waymo_motion.py:205-354,108-203`, `dynamics.py:50-167,187-228`,
+        `traffic_rule_checker.py:77-98,101-119,364-410`), driven as `joint_future_pred` does
+        (`waymo_motion.py:516-562`): every scene tensor repeated K times (instance n = b*K + k)."""
+        d = self.dtype
+        rep = lambda t: t.repeat_interleave(k, 0)  # noqa: E731
+        map_f, map_inv = rep(f["map_feature"]), ~rep(f["map_valid"])
+        tl_f, tl_v = rep(f["tl_feature"]), rep(f["tl_valid"])
+        hv = rep(inp["agent_valid"])
+        hs, hvel, hacc, hyr = rep(inp["agent_state"]), rep(inp["agent_vel"]), rep(inp["agent_acc"]), rep(inp["agent_yaw_rate"])
+        a_type, a_size = rep(inp["agent_type"]), rep(inp["agent_size"])
+        n, a = dest.shape
+        mask_tf = self.teacher_forcing_mask(hv, self.cfg["teacher_forcing_joint_future_pred"])
+        n_gt = hv.shape[1]
+        # rule-checker geometry gathered once (`traffic_rule_checker.py:85-98`)
+        bidx = torch.arange(n).unsqueeze(1)
+        mvalid, mtype, mpos, mdir = rep(inp["map_valid"]), rep(inp["map_type"]), rep(inp["map_pos"]), rep(inp["map_dir"])
+        bound = rep(inp["map_boundary"])
+        dest_valid = mvalid[bidx, dest]
+        dest_type = mtype[bidx, dest]
+        dest_pos = mpos[bidx, dest]
+        dest_dir = mdir[bidx, dest]
+        dest_dir = dest_dir / torch.norm(dest_dir, dim=-1, keepdim=True)
+        thresh_rot_cos = np.cos(np.deg2rad(30))
+        thresh_pos = torch.ones_like(a_size[:, :, 0]) * 50
+        thresh_pos = thresh_pos * (1 - dest_type[:, :, 4] * 0.8)
+        mask_lane = dest_type[:, :, :4].any(-1)
+        mask_edge = dest_type[:, :, 4]
+        # latent log-prob (`distributions.py:11-15`, Independent(Normal))
+        log_std = self.w["model.latent_encoder.latent_prior_dist.log_std"]
+        std = log_std.exp()
+        lm = rep(latent_mean)
+        latent_logp = (-((z - lm) ** 2) / (2 * std ** 2) - std.log() - math.log(math.sqrt(2 * math.pi))).sum(-1)
+        goal_f = map_f[bidx, dest]
+        hoisted = None
+        if self.hoist:
+            hoisted = {
+                "kv_pl": [self.kv_project(f"model.transformer_as2pl.layers.{i}", map_f) for i in range(3)],
+                "goal_pre": self.goal_mlp_in(goal_f),
+                "latent_pre": self.latent_mlp_in(z),
+            }
+            kv_tl_all = [[self.kv_project(f"model.transformer_as2tl.layers.{i}", tl_f[:, s]) for i in range(3)]
+                         for s in range(tl_f.shape[1])]
+        # dynamics init (`dynamics.py:29-48`)
+        valid = hv[:, 0].clone()
+        killed = torch.zeros_like(valid)
+        state = hs[:, 0].clone()
+        vel, acc, yr = hvel[:, 0].clone(), hacc[:, 0].clone(), hyr[:, 0].clone()
+        h = torch.zeros(3, n * a, H, dtype=d)
+        outside = torch.zeros_like(valid)
+        dest_reached = torch.zeros_like(valid)
+        act_std_logp = 2 * (2.0 - math.log(math.sqrt(2 * math.pi)))  # Normal(mu, e^-2).log_prob(mu), 2 dims
+        atype_idx = a_type.to(torch.int64).argmax(-1)
+        max_acc = self.max_acc[atype_idx]
+        max_yr = self.max_yr[atype_idx]
+        has_type = a_type.any(-1)
+        out = {k_: [] for k_ in ("preds", "valid", "override_masks", "outside_map", "outside_map_this_step",
+                                 "dest_reached", "dest_reached_this_step", "action_log_probs")}
+        taps: Dict[str, Tensor] = {}
+        for t in range(self.cfg["time_step_sim_start"], step_end + 1):
+            m_ovr = mask_tf[:, t] if t < n_gt else torch.zeros_like(valid)
+            step_tl = min(t - 1, tl_v.shape[1] - 1)
+            # ---- WaymoMotion.forward ----
+            attr = torch.cat([vel, state[:, :, 3:4], yr, acc, a_size, a_type.to(d)], -1)
+            pe = self.pose_pe(state[:, :, :2], state[:, :, 2], "agent")
+            x = self.input_pe_encoder("model.agent_encoder", valid, attr, pe)
+            if t in tap_steps:
+                taps[f"tap{t}/agent_feature"] = x.clone()
+                taps[f"tap{t}/state_in"] = state.clone()
+                taps[f"tap{t}/agent_valid"] = valid.clone()
+                taps[f"tap{t}/goal_valid"] = goal_valid.clone()
+            if hoisted is not None:
+                hoisted["kv_tl"] = kv_tl_all[step_tl]
+            x, h = self.policy_step(x, valid, map_f, map_inv, tl_f[:, step_tl], ~tl_v[:, step_tl], goal_f, goal_valid, z, h, hoisted)
+            if t in tap_steps:
+                taps[f"tap{t}/policy_feature"] = x.clone()
+                taps[f"tap{t}/hidden"] = h.clone()
+            u = self.action_mean(x, valid, a_type)
+            alp = torch.full_like(state[:, :, 0], act_std_logp).masked_fill(~valid, 0)
+            act = torch.tanh(u)
+            act = torch.stack([act[..., 0] * max_acc, act[..., 1] * max_yr], -1)
+            act = act.masked_fill(~(has_type & valid).unsqueeze(-1), 0)
+            # MultiPathPP.update (`dynamics.py:208-221`)
+            a_, w_ = act[:, :, 0], act[:, :, 1]
+            v_t = state[:, :, 3] + 0.5 * self.dt * a_
+            th_t = state[:, :, 2] + 0.5 * self.dt * w_
+            delta = torch.stack([v_t * torch.cos(th_t), v_t * torch.sin(th_t), w_, a_], -1)
+            new_state = (state + self.dt * delta).masked_fill(~(has_type & valid).unsqueeze(-1), 0)
+            pred_state, pred_valid = new_state, valid
+            state = new_state
+            # override_states (`dynamics.py:132-149`)
+            m = m_ovr & (~killed)
+            if m.any():
+                valid = valid | m
+                m3 = m.unsqueeze(-1)
+                state = torch.where(m3, hs[:, t], state)
+                vel = torch.where(m3, hvel[:, t], vel)
+                acc = torch.where(m3, hacc[:, t], acc)
+                yr = torch.where(m3, hyr[:, t], yr)
+            # rule check (`traffic_rule_checker.py:101-119,364-410`)
+            xs, ys = state[:, :, 0], state[:, :, 1]
+            out_this = ((xs > bound[:, [1]]) | (xs < bound[:, [0]]) | (ys > bound[:, [3]]) | (ys < bound[:, [2]])) & valid
+            outside = outside | out_this
+            dist = torch.norm(state[..., :2].unsqueeze(2) - dest_pos, dim=-1).masked_fill(~dest_valid, 1e4)
+            pos_reached = (dist < thresh_pos.unsqueeze(-1)).any(-1)
+            head = torch.stack([torch.cos(state[..., 2]), torch.sin(state[..., 2])], -1)
+            rot = (head.unsqueeze(2) * dest_dir).sum(-1).masked_fill(~dest_valid, 0)
+            rot_reached = (rot > thresh_rot_cos).any(-1)
+            dr_this = (~dest_reached) & valid & ((mask_lane & pos_reached & rot_reached) | (mask_edge & pos_reached))
+            dest_reached = dest_reached | dr_this
+            # kill (`dynamics.py:161-167`)
+            mk = out_this & (~hv[:, t]) if t < n_gt else out_this
+            killed = killed | mk
+            valid = valid & (~mk)
+            # navigator (`goal_manager.py:155-162`)
+            goal_valid = goal_valid & valid & (~dest_reached)
+            out["preds"].append(pred_state)
+            out["valid"].append(pred_valid)
+            out["override_masks"].append(m_ovr)
+            out["outside_map"].append(outside)
+            out["outside_map_this_step"].append(out_this)
+            out["dest_reached"].append(dest_reached)
+            out["dest_reached_this_step"].append(dr_this)
+            out["action_log_probs"].append(alp)
+        res = {k_: torch.stack(v, 2) for k_, v in out.items()}
+        s = res["valid"].shape[2]
+        res["latent_log_probs"] = latent_logp.unsqueeze(-1).expand(-1, -1, s)
+        res["final_state"], res["final_valid"], res["final_hidden"] = state, valid, h
+        res["final_goal_valid"] = goal_valid
+        res.update(taps)
+        return res
+
+    # ------------------------------------------------------------------ end to end
+    def joint_future_pred(self, batch: Dict[str, np.ndarray], k: int, eps: Optional[np.ndarray], step_end: int,
+                          dest_override: Optional[np.ndarray] = None, tap_steps=()) -> Dict[str, Tensor]:
+        """Prologue of `WaymoMotion.test_step` + `joint_future_pred` (`waymo_motion.py:902-933,478-572`).
+        `eps` [N,A,16] are the standard-normal draws of the latent sample; `dest_override` [N,A]
+        replaces the destination sample (instances k>0 are multinomial draws in the reference)."""
+        inp = self.preprocess(batch)
+        f = self.encode_scene(inp)
+        mean, log_std, lvalid = self.latent_prior(f)
+        logits = self.dest_logits(f, inp)
+        probs, logp_table = self.dest_distribution(logits, k)
+        b, a = mean.shape[:2]
+        n = b * k
+        det = torch.zeros(n, a, dtype=torch.bool)
+        det[::k] = True
+        mean_r = mean.repeat_interleave(k, 0)
+        if eps is None:
+            z = mean_r.clone()
+        else:
+            rnd = mean_r + _t(eps, self.dtype) * log_std.exp()
+            z = mean_r.masked_fill(~det.unsqueeze(-1), 0) + rnd.masked_fill(det.unsqueeze(-1), 0)
+        dest = probs.argmax(-1)
+        if dest_override is not None:
+            dest = _t(dest_override, self.dtype).to(torch.int64).reshape(n, a)
+        goal_logp = logp_table.gather(-1, dest.unsqueeze(-1)).squeeze(-1)
+        goal_valid = inp["agent_valid"].any(1).repeat_interleave(k, 0)
+        res = self.rollout(inp, f, z, mean, dest, goal_valid, k, step_end, tap_steps)
+        # RolloutBuffer.flatten_repeat (`buffer.py:92-123`): [N,A,S,..] -> [B,A,K,S,..]
+        for key in ("preds", "valid", "override_masks", "outside_map", "outside_map_this_step", "dest_reached",
+                    "dest_reached_this_step", "action_log_probs", "latent_log_probs"):
+            v = res[key]
+            res[key] = v.reshape(b, k, *v.shape[1:]).transpose(1, 2)
+        res["goal_sample"] = dest.view(b, k, a).transpose(1, 2)
+        res["goal_log_probs"] = goal_logp.view(b, k, a).transpose(1, 2)
+        res["dest_logits_raw"] = logits
+        res["dest_logits"] = torch.log_softmax(logits, -1)
+        res["latent_mean"], res["latent_valid"], res["latent_sample"] = mean, lvalid, z
+        res["map_feature"], res["map_feature_valid"] = f["map_feature"], f["map_valid"]
+        res["agent_feature_cur"], res["agent_feature_0"] = f["agent_feature"][:, -1], f["agent_feature"][:, 0]
+        res["tl_feature_cur"] = f["tl_feature"][:, -1]
+        res["_inp"], res["_feats"] = inp, f
+        return res

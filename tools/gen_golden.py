@@ -1,0 +1,214 @@
+"""Generate the committed golden fixtures under tests/golden/ by running THE REFERENCE
+(`/root/reference/src`, imported through tools/ref_shim.py) on synthetic scenes.
+
+Run here only (the reference does not travel):  python tools/gen_golden.py
+Inputs and weights are NOT stored: both are regenerated from seeds by
+`trafficbots_amd.synth` (PCG64 raw stream), so each fixture holds only the seeds/sizes, the
+stochastic draws that the reference took from torch's RNG (latent eps, sampled destinations)
+and the reference's outputs.  The driving sequence mirrors `WaymoMotion.test_step`
+(`src/pl_modules/waymo_motion.py:902-933`).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+import ref_shim  # noqa: E402
+from trafficbots_amd import synth  # noqa: E402
+from trafficbots_amd.config import load_model_config  # noqa: E402
+
+GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
+
+# name -> fixture definition.  `scene` are make_scene kwargs.
+CASES = {
+    # BASELINE.json configs[0]: 1 scene, 8 agents, 32 polylines, 10-step open-loop decode
+    "c1_plumbing": dict(
+        base_seed=1000, n_scene=1, k=1, weight_seed=7, time_step_end=10,
+        scene=dict(n_agent=8, n_pl=32, n_tl=40), tap_steps=[1, 5, 10], fp64=True, store_feats=True,
+    ),
+    # small closed-loop case with full taps
+    "small_k1": dict(
+        base_seed=2000, n_scene=2, k=1, weight_seed=7, time_step_end=90,
+        scene=dict(n_agent=8, n_pl=32, n_tl=40), tap_steps=[1, 10, 11, 12, 50], fp64=True, store_feats=True,
+    ),
+    # mask coverage: invalid agents / polylines / nodes, late spawns, early exits; K=3 with
+    # stochastic latents and sampled destinations
+    "masks_k3": dict(
+        base_seed=3000, n_scene=3, k=3, weight_seed=8, time_step_end=90,
+        scene=dict(n_agent=16, n_pl=48, n_tl=40, p_invalid_agent=0.3, p_late_spawn=0.3, p_early_exit=0.2,
+                   p_invalid_pl=0.2, p_invalid_node=0.5, pos_range=140.0),
+        tap_steps=[1, 11, 30], fp64=False, store_feats=True,
+    ),
+    # degenerate scenes: a single valid agent (interaction bypass), no valid TL, few polylines
+    "degenerate": dict(
+        base_seed=4000, n_scene=2, k=2, weight_seed=8, time_step_end=40,
+        scene=dict(n_agent=16, n_pl=16, n_tl=40, p_invalid_agent=0.97, p_tl_valid=0.0, p_invalid_pl=0.5),
+        tap_steps=[1, 11], fp64=False, store_feats=True,
+    ),
+    # BASELINE.json configs[1] shape (headline), 2 scenes of it
+    "headline_2": dict(
+        base_seed=5000, n_scene=2, k=1, weight_seed=7, time_step_end=90,
+        scene=dict(n_agent=64, n_pl=256, n_tl=40), tap_steps=[], fp64=True, store_feats=True,
+    ),
+    # configs[3] shape: K=6 multi-modal, one scene
+    "headline_k6": dict(
+        base_seed=6000, n_scene=1, k=6, weight_seed=7, time_step_end=90,
+        scene=dict(n_agent=64, n_pl=256, n_tl=40), tap_steps=[], fp64=False, store_feats=False,
+    ),
+}
+
+
+def run_reference(case: dict, dtype=torch.float32) -> dict:
+    cfg = load_model_config(overrides={"time_step_end": case["time_step_end"], "n_joint_future": case["k"]})
+    sc = case["scene"]
+    torch.set_default_dtype(torch.float32)
+    model = ref_shim.build_reference(cfg, n_agent=sc["n_agent"], n_pl=sc["n_pl"], n_tl=sc.get("n_tl", 40))
+    sd = synth.make_state_dict(case["weight_seed"])
+    missing = model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()}, strict=True)
+    assert not missing.missing_keys and not missing.unexpected_keys
+    batch_np = synth.make_batch(case["base_seed"], case["n_scene"], **sc)
+    batch = {k: torch.from_numpy(v.copy()) for k, v in batch_np.items()}
+    if dtype == torch.float64:
+        model = model.double()
+        batch = {k: (v.double() if v.dtype == torch.float32 else v) for k, v in batch.items()}
+        torch.set_default_dtype(torch.float64)  # GRU zero state uses the default dtype (agent_temporal.py:131)
+    n_inst = case["n_scene"] * case["k"]
+    eps = torch.from_numpy(synth.make_latent_noise(case["base_seed"] + 99, n_inst, sc["n_agent"])).to(dtype)
+
+    import torch.distributions.normal as tdn
+
+    orig_std_normal = tdn._standard_normal
+
+    def fake_std_normal(shape, dtype, device):
+        if tuple(shape) == tuple(eps.shape):
+            return eps.to(dtype)
+        raise RuntimeError(f"unexpected rsample of shape {tuple(shape)}")
+
+    taps = {}
+    out = {}
+    try:
+        tdn._standard_normal = fake_std_normal
+        torch.manual_seed(case["base_seed"])  # multinomial destination draws (captured below)
+        with torch.no_grad():
+            batch = model.pre_processing(batch)
+            input_dict = {k.split("input/")[-1]: v for k, v in batch.items() if "input/" in k}
+            latent_prior_dict = {k.split("latent_prior/")[-1]: v for k, v in batch.items() if "latent_prior/" in k}
+            feats = model.model.encode_input_features(**input_dict)
+            feats_prior = model.model.encode_input_features(**latent_prior_dict)
+            goal_valid = input_dict["agent_valid"].any(1)
+            goal_pred = model.model.goal_manager.pred_goal(
+                agent_type=batch["ref/agent_type"], map_type=batch["ref/map_type"],
+                agent_state=batch["ref/agent_state"], **feats,
+            )
+            dest_logits = goal_pred.distribution.logits.clone()  # normalised log-probs
+            dest_probs = goal_pred.probs.clone()
+            latent_prior = model.model.latent_encoder(**feats_prior)
+            out["latent_mean"] = latent_prior.mean.clone()
+            out["latent_valid"] = latent_prior.valid.clone()
+            for k in ["valid", "vel", "acc", "yaw_rate", "pos", "yaw_bbox", "spd", "size"]:
+                batch[f"agent/{k}"] = batch[f"history/agent/{k}"]
+
+            step_counter = {"i": cfg["time_step_sim_start"] - 1}
+
+            def hook(mod, args, kwargs, output):
+                step_counter["i"] += 1
+                if step_counter["i"] in case["tap_steps"]:
+                    s = step_counter["i"]
+                    taps[f"tap{s}/agent_feature"] = kwargs["agent_feature"].clone()
+                    taps[f"tap{s}/agent_valid"] = kwargs["agent_valid"].clone()
+                    taps[f"tap{s}/goal_valid"] = kwargs["goal_valid"].clone()
+                    taps[f"tap{s}/policy_feature"] = output[0].clone()
+                    taps[f"tap{s}/hidden"] = mod.hidden.clone()
+                    taps[f"tap{s}/state_in"] = model.dynamics.agent_state.clone()
+
+            h = model.model.register_forward_hook(hook, with_kwargs=True)
+            buf, goal_sample, goal_log_probs = model.joint_future_pred(
+                batch=batch, input_feature_dict=feats, latent=latent_prior, goal=goal_pred,
+                goal_valid=goal_valid, require_vis_dict=False,
+            )
+            h.remove()
+    finally:
+        tdn._standard_normal = orig_std_normal
+        torch.set_default_dtype(torch.float32)
+
+    out.update(
+        map_feature=feats["map_feature"], map_feature_valid=feats["map_feature_valid"],
+        agent_feature_cur=feats["agent_feature"][:, -1], tl_feature_cur=feats["tl_feature"][:, -1],
+        agent_feature_0=feats["agent_feature"][:, 0],
+        dest_logits=dest_logits, dest_probs=dest_probs,
+        preds=buf.preds, valid=buf.valid, override_masks=buf.override_masks,
+        dest_reached=buf.violations["dest_reached"], outside_map=buf.violations["outside_map"],
+        outside_map_this_step=buf.violations["outside_map_this_step"],
+        dest_reached_this_step=buf.violations["dest_reached_this_step"],
+        latent_log_probs=buf.latent_log_probs, action_log_probs=buf.action_log_probs,
+        goal_sample=goal_sample, goal_log_probs=goal_log_probs, eps=eps,
+        latent_sample=model.model.latent_sample,
+        final_state=model.dynamics.agent_state, final_valid=model.dynamics.agent_valid,
+        final_hidden=model.model.hidden,
+    )
+    out.update(taps)
+    return {k: (v.detach().cpu().numpy() if torch.is_tensor(v) else v) for k, v in out.items()}
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", nargs="*", default=None)
+    args = ap.parse_args()
+    os.makedirs(GOLDEN_DIR, exist_ok=True)
+    torch.set_num_threads(os.cpu_count())
+
+    # reference state_dict key/shape list (pins trafficbots_amd.synth.state_dict_spec)
+    cfg = load_model_config()
+    model = ref_shim.build_reference(cfg, n_agent=8, n_pl=32)
+    keys = {k: list(v.shape) for k, v in model.state_dict().items()}
+    with open(os.path.join(GOLDEN_DIR, "state_dict_keys.json"), "w") as f:
+        json.dump(keys, f, indent=0, sort_keys=True)
+
+    for name, case in CASES.items():
+        if args.only and name not in args.only:
+            continue
+        r32 = run_reference(case, torch.float32)
+        save = {}
+        small = ["preds", "valid", "override_masks", "dest_reached", "outside_map", "outside_map_this_step",
+                 "dest_reached_this_step", "latent_log_probs", "action_log_probs", "goal_sample",
+                 "goal_log_probs", "latent_mean", "latent_valid", "latent_sample", "final_state",
+                 "final_valid"]
+        feats = ["map_feature", "map_feature_valid", "agent_feature_cur", "agent_feature_0", "tl_feature_cur",
+                 "dest_logits", "final_hidden"]
+        for k in small:
+            save[k] = r32[k]
+        if case["store_feats"]:
+            for k in feats:
+                save[k] = r32[k]
+        for k, v in r32.items():
+            if k.startswith("tap"):
+                save[k] = v
+        if case["fp64"]:
+            r64 = run_reference(case, torch.float64)
+            save["preds_fp64"] = r64["preds"]
+            save["valid_fp64"] = r64["valid"]
+            save["goal_sample_fp64"] = r64["goal_sample"]
+            d = np.abs(r64["preds"][..., :2] - r32["preds"][..., :2].astype(np.float64))
+            m = (r64["valid"] & r32["valid"])[..., None]
+            print(f"[{name}] reference fp32 vs fp64 max|dxy| = {float((d * m).max()):.3e}; "
+                  f"goal_sample equal: {bool((r64['goal_sample'] == r32['goal_sample']).all())}")
+        meta = {k: v for k, v in case.items()}
+        save["meta_json"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+        path = os.path.join(GOLDEN_DIR, f"{name}.npz")
+        np.savez_compressed(path, **save)
+        print(f"[{name}] wrote {path} ({os.path.getsize(path) / 1024:.0f} KiB); valid steps frac "
+              f"{r32['valid'].mean():.3f}; dest_reached {r32['dest_reached'][..., -1].mean():.3f}; "
+              f"outside {r32['outside_map'][..., -1].mean():.3f}")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,353 @@
+"""Synthetic WOMD-shaped scenes and version-stable random weights.
+
+Keys, shapes and dtypes follow the reference's packed-h5 test split
+(`src/data_modules/data_h5_womd.py:119-157`).  Everything is derived from the RAW
+uint64 stream of `numpy.random.PCG64(seed)` (`random_raw` is stable across numpy
+versions, `Generator.random/normal` are not guaranteed to be), mapped to floats
+explicitly, so the golden generator (this container, with the reference imported), the CPU
+tests and the GPU box regenerate bit-identical inputs and weights from a seed and nothing
+large has to be committed.
+"""
+from __future__ import annotations
+
+import math
+from collections import OrderedDict
+from typing import Dict, Tuple
+
+import numpy as np
+
+N_PL_NODE = 20
+N_STEP_HIST = 11
+N_PL_TYPE = 11
+N_TL_STATE = 5
+DT = 0.1
+
+
+class RawStream:
+    """Explicit float/int draws from the PCG64 raw stream."""
+
+    def __init__(self, seed: int) -> None:
+        self._bg = np.random.PCG64(int(seed))
+
+    def u01(self, shape) -> np.ndarray:
+        n = int(np.prod(shape)) if np.ndim(shape) else int(shape)
+        raw = self._bg.random_raw(n).astype(np.uint64)
+        return ((raw >> np.uint64(11)).astype(np.float64) * (2.0 ** -53)).reshape(shape)
+
+    def uniform(self, lo: float, hi: float, shape) -> np.ndarray:
+        return lo + (hi - lo) * self.u01(shape)
+
+    def integers(self, n: int, shape) -> np.ndarray:
+        return np.minimum((self.u01(shape) * n).astype(np.int64), n - 1)
+
+    def bernoulli(self, p: float, shape) -> np.ndarray:
+        return self.u01(shape) < p
+
+    def normal(self, shape) -> np.ndarray:
+        """Box-Muller in float64 (always draws two uniforms per sample)."""
+        u1 = 1.0 - self.u01(shape)  # (0, 1]
+        u2 = self.u01(shape)
+        return np.sqrt(-2.0 * np.log(u1)) * np.cos(2.0 * math.pi * u2)
+
+
+def make_scene(
+    seed: int,
+    n_agent: int,
+    n_pl: int,
+    n_tl: int = 40,
+    p_invalid_agent: float = 0.0,
+    p_late_spawn: float = 0.0,
+    p_early_exit: float = 0.0,
+    p_invalid_pl: float = 0.0,
+    p_invalid_node: float = 0.0,
+    p_tl_valid: float = 0.3,
+    pos_range: float = 100.0,
+    boundary: float = 150.0,
+) -> Dict[str, np.ndarray]:
+    """One scene (no batch dim) in the reference's test-split layout."""
+    rs = RawStream(seed)
+    f32 = np.float32
+    out: Dict[str, np.ndarray] = {}
+
+    # ---- map polylines: straight, 1 m node spacing ----
+    start = rs.uniform(-pos_range, pos_range, (n_pl, 2))
+    heading = rs.uniform(-math.pi, math.pi, (n_pl,))
+    d = np.stack([np.cos(heading), np.sin(heading)], -1)  # [P,2]
+    node = np.arange(N_PL_NODE, dtype=np.float64)[None, :, None]
+    map_pos = start[:, None, :] + node * d[:, None, :]
+    map_dir = np.broadcast_to(d[:, None, :], (n_pl, N_PL_NODE, 2)).copy()
+    pl_type = rs.integers(N_PL_TYPE, (n_pl,))
+    pl_type[0] = 1  # at least one lane-like polyline (dest candidates need type <= 4)
+    pl_type[min(1, n_pl - 1)] = 4  # and one road edge (ped candidates), unless n_pl == 1
+    map_type = np.zeros((n_pl, N_PL_TYPE), dtype=bool)
+    map_type[np.arange(n_pl), pl_type] = True
+    n_valid_node = np.where(rs.bernoulli(p_invalid_node, (n_pl,)), rs.integers(N_PL_NODE, (n_pl,)) + 1, N_PL_NODE)
+    map_valid = np.arange(N_PL_NODE)[None, :] < n_valid_node[:, None]
+    pl_ok = ~rs.bernoulli(p_invalid_pl, (n_pl,))
+    pl_ok[:2] = True
+    map_valid &= pl_ok[:, None]
+    out["map/valid"] = map_valid
+    out["map/type"] = map_type
+    out["map/pos"] = map_pos.astype(f32)
+    out["map/dir"] = map_dir.astype(f32)
+    out["map/boundary"] = np.array([-boundary, boundary, -boundary, boundary], dtype=f32)
+
+    # ---- traffic-light stop points ----
+    tl_valid0 = rs.bernoulli(p_tl_valid, (n_tl,))
+    flick = rs.bernoulli(0.05, (N_STEP_HIST, n_tl))
+    tl_valid = tl_valid0[None, :] ^ (flick & tl_valid0[None, :])
+    tl_state_idx = rs.integers(N_TL_STATE, (N_STEP_HIST, n_tl))
+    tl_state = np.zeros((N_STEP_HIST, n_tl, N_TL_STATE), dtype=bool)
+    tl_state[np.arange(N_STEP_HIST)[:, None], np.arange(n_tl)[None, :], tl_state_idx] = True
+    tl_pos = rs.uniform(-pos_range, pos_range, (n_tl, 2))
+    tl_head = rs.uniform(-math.pi, math.pi, (n_tl,))
+    out["history/tl_stop/valid"] = tl_valid
+    out["history/tl_stop/state"] = tl_state
+    out["history/tl_stop/pos"] = np.broadcast_to(tl_pos[None], (N_STEP_HIST, n_tl, 2)).astype(f32).copy()
+    out["history/tl_stop/dir"] = (
+        np.broadcast_to(np.stack([np.cos(tl_head), np.sin(tl_head)], -1)[None], (N_STEP_HIST, n_tl, 2)).astype(f32).copy()
+    )
+
+    # ---- agents: smooth histories with constant acc / yaw-rate ----
+    p0 = rs.uniform(-0.8 * pos_range, 0.8 * pos_range, (n_agent, 2))
+    yaw0 = rs.uniform(-math.pi, math.pi, (n_agent,))
+    spd0 = rs.uniform(0.0, 15.0, (n_agent,))
+    acc0 = rs.uniform(-1.0, 1.0, (n_agent,))
+    yr0 = rs.uniform(-0.2, 0.2, (n_agent,))
+    a_type = rs.integers(3, (n_agent,))
+    t = np.arange(N_STEP_HIST, dtype=np.float64)[:, None] * DT
+    spd = spd0[None] + acc0[None] * t
+    yaw = yaw0[None] + yr0[None] * t
+    vel = np.stack([spd * np.cos(yaw), spd * np.sin(yaw)], -1)  # [11,A,2]
+    pos = p0[None] + np.concatenate([np.zeros((1, n_agent, 2)), np.cumsum(vel[:-1] * DT, 0)], 0)
+    size = np.stack(
+        [rs.uniform(3.5, 5.5, (n_agent,)), rs.uniform(1.6, 2.2, (n_agent,)), rs.uniform(1.4, 1.9, (n_agent,))], -1
+    )
+    size[a_type == 1] *= np.array([0.2, 0.4, 1.1])  # pedestrians are small
+    agent_type = np.zeros((n_agent, 3), dtype=bool)
+    agent_type[np.arange(n_agent), a_type] = True
+    valid = np.ones((N_STEP_HIST, n_agent), dtype=bool)
+    never = rs.bernoulli(p_invalid_agent, (n_agent,))
+    late = rs.bernoulli(p_late_spawn, (n_agent,))
+    t_spawn = rs.integers(N_STEP_HIST - 1, (n_agent,)) + 1
+    early = rs.bernoulli(p_early_exit, (n_agent,))
+    t_exit = rs.integers(N_STEP_HIST - 1, (n_agent,)) + 1
+    steps = np.arange(N_STEP_HIST)[:, None]
+    valid &= ~(late[None] & (steps < t_spawn[None]))
+    valid &= ~(early[None] & ~late[None] & (steps >= t_exit[None]))
+    valid &= ~never[None]
+    valid[:, 0] = True  # agent 0 (the SDC slot) is always there
+    role = np.zeros((n_agent, 3), dtype=bool)
+    role[0, 0] = True
+    role[: max(1, n_agent // 8), 2] = True
+    out["history/agent/valid"] = valid
+    out["history/agent/pos"] = pos.astype(f32)
+    out["history/agent/z"] = np.zeros((N_STEP_HIST, n_agent, 1), dtype=f32)
+    out["history/agent/vel"] = vel.astype(f32)
+    out["history/agent/spd"] = spd[..., None].astype(f32)
+    out["history/agent/acc"] = np.broadcast_to(acc0[None, :, None], (N_STEP_HIST, n_agent, 1)).astype(f32).copy()
+    out["history/agent/yaw_bbox"] = yaw[..., None].astype(f32)
+    out["history/agent/yaw_rate"] = np.broadcast_to(yr0[None, :, None], (N_STEP_HIST, n_agent, 1)).astype(f32).copy()
+    out["history/agent/type"] = agent_type
+    out["history/agent/role"] = role
+    out["history/agent/size"] = size.astype(f32)
+    out["history/agent/object_id"] = np.arange(n_agent, dtype=np.int64)
+    # required-but-unused keys of the eval-mode scene-centric pre-processing
+    # (`src/data_modules/scene_centric.py:121-125`)
+    n_ns = 4
+    out["history/agent_no_sim/valid"] = np.zeros((N_STEP_HIST, n_ns), dtype=bool)
+    out["history/agent_no_sim/pos"] = np.zeros((N_STEP_HIST, n_ns, 2), dtype=f32)
+    out["history/agent_no_sim/z"] = np.zeros((N_STEP_HIST, n_ns, 1), dtype=f32)
+    out["history/agent_no_sim/vel"] = np.zeros((N_STEP_HIST, n_ns, 2), dtype=f32)
+    out["history/agent_no_sim/spd"] = np.zeros((N_STEP_HIST, n_ns, 1), dtype=f32)
+    out["history/agent_no_sim/yaw_bbox"] = np.zeros((N_STEP_HIST, n_ns, 1), dtype=f32)
+    out["history/agent_no_sim/type"] = np.zeros((n_ns, 3), dtype=bool)
+    out["history/agent_no_sim/size"] = np.zeros((n_ns, 3), dtype=f32)
+    return out
+
+
+def make_batch(base_seed: int, n_scene: int, scene_offset: int = 0, **kw) -> Dict[str, np.ndarray]:
+    """Batch-stacked scenes; scene i uses seed base_seed + scene_offset + i (so a rank's shard
+    of a global batch is `make_batch(base, n_local, scene_offset=rank * n_local)`)."""
+    scenes = [make_scene(base_seed + scene_offset + i, **kw) for i in range(n_scene)]
+    return {k: np.stack([s[k] for s in scenes], 0) for k in scenes[0].keys()}
+
+
+def make_latent_noise(seed: int, n_inst: int, n_agent: int, latent_dim: int = 16) -> np.ndarray:
+    """Standard-normal draws eps[N, A, latent_dim] for the CVAE personality samples (the reference
+    draws them from torch's CPU stream, `distributions.py:26-31`; goldens pass them explicitly)."""
+    return RawStream(seed).normal((n_inst, n_agent, latent_dim)).astype(np.float32)
+
+
+# --------------------------------------------------------------------------------------
+# state_dict of the reference model for the default config, in the
+# reference's parameter naming, so a reference checkpoint's state_dict loads unchanged.
+# --------------------------------------------------------------------------------------
+def _tf_layer(prefix: str, spec: "OrderedDict[str, Tuple[int, ...]]", h: int = 128, d_ff: int = 128) -> None:
+    spec[f"{prefix}.norm1.weight"] = (h,)
+    spec[f"{prefix}.norm1.bias"] = (h,)
+    spec[f"{prefix}.norm_tgt.weight"] = (h,)
+    spec[f"{prefix}.norm_tgt.bias"] = (h,)
+    spec[f"{prefix}.attn.in_proj_weight"] = (3 * h, h)
+    spec[f"{prefix}.attn.out_proj_weight"] = (h, h)
+    spec[f"{prefix}.attn.in_proj_bias"] = (3 * h,)
+    spec[f"{prefix}.attn.out_proj_bias"] = (h,)
+    spec[f"{prefix}.linear1.weight"] = (d_ff, h)
+    spec[f"{prefix}.linear1.bias"] = (d_ff,)
+    spec[f"{prefix}.linear2.weight"] = (h, d_ff)
+    spec[f"{prefix}.linear2.bias"] = (h,)
+    spec[f"{prefix}.norm2.weight"] = (h,)
+    spec[f"{prefix}.norm2.bias"] = (h,)
+
+
+def _tf_block(prefix: str, n_layer: int, spec) -> None:
+    for i in range(n_layer):
+        _tf_layer(f"{prefix}.layers.{i}", spec)
+
+
+def _gru(prefix: str, n_layer: int, spec, h: int = 128) -> None:
+    for i in range(n_layer):
+        spec[f"{prefix}.weight_ih_l{i}"] = (3 * h, h)
+        spec[f"{prefix}.weight_hh_l{i}"] = (3 * h, h)
+        spec[f"{prefix}.bias_ih_l{i}"] = (3 * h,)
+        spec[f"{prefix}.bias_hh_l{i}"] = (3 * h,)
+
+
+def _linear(prefix: str, n_out: int, n_in: int, spec) -> None:
+    spec[f"{prefix}.weight"] = (n_out, n_in)
+    spec[f"{prefix}.bias"] = (n_out,)
+
+
+def _ln(prefix: str, n: int, spec) -> None:
+    spec[f"{prefix}.weight"] = (n,)
+    spec[f"{prefix}.bias"] = (n,)
+
+
+def state_dict_spec(h: int = 128, latent_dim: int = 16, pe_dim: int = 96) -> "OrderedDict[str, Tuple[int, ...]]":
+    """Parameter (and buffer) names -> shapes of `WaymoMotion.state_dict()` for the default
+    config.  Buffers are listed too (they are part of the reference state_dict) but are not
+    randomised by :func:`make_state_dict`."""
+    spec: "OrderedDict[str, Tuple[int, ...]]" = OrderedDict()
+    enc_out = h - pe_dim  # 32
+    for name in ("input", "latent"):
+        spec[f"pre_processing.{name}.pl_node_ohe"] = (N_PL_NODE, N_PL_NODE)
+        for who in ("agent", "map", "tl"):
+            spec[f"pre_processing.{name}.pose_pe_{who}.pe_xy.freqs"] = (pe_dim // 4,)
+            spec[f"pre_processing.{name}.pose_pe_{who}.pe_yaw.freqs"] = (pe_dim // 2,)
+    # map encoder
+    _linear("model.map_encoder.input_pe_encoder.mlp.fc_layers.0", enc_out, N_PL_TYPE + N_PL_NODE, spec)
+    _linear("model.map_encoder.input_pe_encoder.mlp.fc_layers.3", enc_out, enc_out, spec)
+    _tf_block("model.map_encoder.transformer_densetnt", 3, spec)
+    _tf_block("model.map_encoder.transformer_self_attn", 1, spec)
+    _linear("model.tl_encoder.mlp.fc_layers.0", enc_out, N_TL_STATE, spec)
+    _linear("model.tl_encoder.mlp.fc_layers.3", enc_out, enc_out, spec)
+    _linear("model.agent_encoder.mlp.fc_layers.0", enc_out, 11, spec)
+    _linear("model.agent_encoder.mlp.fc_layers.3", enc_out, enc_out, spec)
+    _tf_block("model.transformer_as2pl", 3, spec)
+    _tf_block("model.transformer_as2tl", 3, spec)
+    # destination predictor
+    _gru("model.goal_manager.goal_predictor.gru_as.rnn", 3, spec)
+    _linear("model.goal_manager.goal_predictor.mlp.fc_layers.0", h, 2 * h, spec)
+    _ln("model.goal_manager.goal_predictor.mlp.fc_layers.1", h, spec)
+    _linear("model.goal_manager.goal_predictor.mlp.fc_layers.3", h, h, spec)
+    _ln("model.goal_manager.goal_predictor.mlp.fc_layers.4", h, spec)
+    _linear("model.goal_manager.goal_predictor.mlp.fc_layers.6", 1, h, spec)
+    # latent encoder (as2pl/as2tl are aliases of the policy's blocks)
+    _tf_block("model.latent_encoder.transformer_as2pl", 3, spec)
+    _tf_block("model.latent_encoder.transformer_as2tl", 3, spec)
+    for which in ("prior", "post"):
+        _linear(f"model.latent_encoder.latent_{which}_dist.mlp_mean.fc_layers.0", h, h, spec)
+        _linear(f"model.latent_encoder.latent_{which}_dist.mlp_mean.fc_layers.2", latent_dim, h, spec)
+        spec[f"model.latent_encoder.latent_{which}_dist.log_std"] = (latent_dim,)
+    for which in ("post", "prior"):
+        _gru(f"model.latent_encoder.agent_temporal_{which}.rnn", 3, spec)
+        _tf_block(f"model.latent_encoder.agent_interaction_{which}.transformer", 3, spec)
+    # policy
+    _gru("model.agent_temporal.rnn", 3, spec)
+    _tf_block("model.agent_interaction.transformer", 3, spec)
+    _linear("model.add_goal.mlp_in.fc_layers.0", h, h, spec)
+    _ln("model.add_goal.mlp_in.fc_layers.1", h, spec)
+    _linear("model.add_goal.mlp_in.fc_layers.4", h, h, spec)
+    _ln("model.add_goal.mlp_in.fc_layers.5", h, spec)
+    _linear("model.add_goal.mlp_in.fc_layers.8", h, h, spec)
+    _ln("model.add_goal.mlp_in.fc_layers.9", h, spec)
+    _linear("model.add_goal.mlp_out.fc_layers.0", h, 2 * h, spec)
+    _linear("model.add_goal.mlp_out.fc_layers.3", h, h, spec)
+    _linear("model.add_latent.mlp_in.fc_layers.0", h, latent_dim, spec)
+    _linear("model.add_latent.mlp_in.fc_layers.3", h, h, spec)
+    _linear("model.add_latent.mlp_out.fc_layers.0", h, 2 * h, spec)
+    _linear("model.add_latent.mlp_out.fc_layers.3", h, h, spec)
+    for i in range(3):
+        _linear(f"action_head.mlp_mean.{i}.fc_layers.0", h, h, spec)
+        _linear(f"action_head.mlp_mean.{i}.fc_layers.2", 2, h, spec)
+    for i in range(3):
+        spec[f"action_head.log_std.{i}"] = (2,)
+    return spec
+
+
+ALIASES = {
+    # shared storage in the reference (`latent_encoder.py:41-43`, shared_transformer_as=True)
+    "model.latent_encoder.transformer_as2pl.": "model.transformer_as2pl.",
+    "model.latent_encoder.transformer_as2tl.": "model.transformer_as2tl.",
+}
+
+
+def _is_buffer(name: str) -> bool:
+    return name.endswith(".freqs") or name.endswith("pl_node_ohe")
+
+
+def _buffer_value(name: str, shape) -> np.ndarray:
+    if name.endswith("pl_node_ohe"):
+        return np.eye(shape[0], dtype=np.float32)
+    dim = shape[0]
+    if ".pe_xy." in name:  # `src/utils/pos_emb.py:11-14`, theta = 1e3; float64 then rounded once
+        k = np.arange(0, dim, 2, dtype=np.float64) / float(dim)
+        freqs = (1.0 / (1e3 ** k)).astype(np.float32)
+    else:  # `src/utils/pos_emb.py:42-44`
+        freqs = np.arange(0, dim // 2, dtype=np.float32) + np.float32(1.0)
+    return np.repeat(freqs, 2).astype(np.float32)
+
+
+def make_state_dict(seed: int, gain: float = 1.0, h: int = 128) -> "OrderedDict[str, np.ndarray]":
+    """Random fp32 weights in reference naming.  Matrices/biases ~ U(+-gain/sqrt(fan_in)),
+    LayerNorm gamma = 1 + 0.1 u, beta = 0.1 u (so LN affine paths are exercised), GRU tensors
+    U(+-1/sqrt(hidden)); `log_std` parameters keep their config values; buffers keep their
+    defined values.  Filled in sorted-key order from one PCG64 raw stream."""
+    spec = state_dict_spec(h=h)
+    rs = RawStream(seed)
+    sd: "OrderedDict[str, np.ndarray]" = OrderedDict()
+    for name in sorted(spec.keys()):
+        shape = spec[name]
+        alias = next((a for a in ALIASES if name.startswith(a)), None)
+        if alias is not None:
+            continue
+        if _is_buffer(name):
+            sd[name] = _buffer_value(name, shape)
+            continue
+        if name.endswith("log_std") or ".log_std." in name:
+            sd[name] = np.full(shape, -2.0 if name.startswith("action_head") else -1.0, dtype=np.float32)
+            continue
+        u = rs.uniform(-1.0, 1.0, shape)
+        is_ln = (
+            ".norm" in name
+            or (".mlp_in.fc_layers." in name and name.split(".")[-2] in ("1", "5", "9") and "add_goal" in name)
+            or ("goal_predictor.mlp.fc_layers." in name and name.split(".")[-2] in ("1", "4"))
+        )
+        if is_ln:
+            val = (1.0 + 0.1 * u) if name.endswith("weight") else 0.1 * u
+        elif ".rnn." in name:
+            val = u / math.sqrt(h)
+        elif len(shape) == 2:
+            val = u * gain / math.sqrt(shape[1])
+        else:
+            # bias: fan_in of the matching weight
+            wname = name.replace("in_proj_bias", "in_proj_weight").replace("out_proj_bias", "out_proj_weight")
+            wname = wname[: -len("bias")] + "weight" if wname.endswith(".bias") else wname
+            fan_in = spec[wname][1]
+            val = u * gain / math.sqrt(fan_in)
+        sd[name] = val.astype(np.float32)
+    for name in spec.keys():
+        for a, tgt in ALIASES.items():
+            if name.startswith(a):
+                sd[name] = sd[tgt + name[len(a):]]
+    return OrderedDict((k, sd[k]) for k in spec.keys())
