@@ -1,0 +1,156 @@
+/*
+ * trafficbots_hip.h -- C ABI of the MI355X (gfx950) scene-encoder + closed-loop rollout hot path.
+ *
+ * The reference (zhejz/TrafficBots) has no FFI: its seam is Python (`src/pl_modules/waymo_motion.py`,
+ * `src/models/traffic_bots.py`).  Each entry point below names the reference interface it replaces;
+ * `trafficbots_amd/` binds them with ctypes (see INTEGRATION.md for the stub a maintainer would add).
+ *
+ * Conventions
+ *  - Every buffer in the *_io structs is a BORROWED DEVICE pointer (caller's allocator, e.g. PyTorch-ROCm),
+ *    valid until the work queued on `stream` completes.  The library owns only its weight arena and scratch.
+ *  - No hidden synchronisation: calls enqueue on `stream` and return.
+ *  - Return 0 on success, non-zero on error (message via tb_last_error).  One tb_ctx per (device, stream user);
+ *    not thread-safe.
+ *  - Floats are fp32, masks are uint8 (0/1), indices int32, row-major, shapes in comments.
+ *    B = scenes, K = futures per scene, N = B*K rollout instances (instance n uses scene n / K),
+ *    A = agents, P = polylines, T = traffic-light stop points, NH = history steps (11), S = executed steps.
+ */
+#ifndef TRAFFICBOTS_HIP_H
+#define TRAFFICBOTS_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct tb_ctx tb_ctx;
+typedef void* tb_stream; /* hipStream_t */
+
+/* Scalar config the kernels need (defaults = configs/model/traffic_bots.yaml of the reference). */
+typedef struct tb_config {
+    int32_t time_step_current;   /* 10  (traffic_bots.yaml:5)  */
+    int32_t time_step_sim_start; /* 1   (traffic_bots.yaml:8)  */
+    float dt;                    /* 0.1 (src/utils/dynamics.py:13) */
+    float max_acc[3];            /* per type veh,ped,cyc (traffic_bots.yaml:142-155) */
+    float max_yaw_rate[3];
+    float action_log_std;        /* -2 (traffic_bots.yaml:138) */
+    float latent_log_std;        /* -1 (traffic_bots.yaml:76); overwritten by the loaded parameter */
+} tb_config;
+
+/* -- lifecycle ----------------------------------------------------------------------------------- */
+/* Replaces: WaymoMotion.__init__ / hydra.utils.instantiate (waymo_motion.py:28-106). */
+int tb_create(const tb_config* cfg, tb_ctx** out);
+void tb_destroy(tb_ctx* ctx);
+const char* tb_last_error(tb_ctx* ctx);
+/* Version / build info string (static storage). */
+const char* tb_version(void);
+
+/* -- weights ------------------------------------------------------------------------------------- */
+/* Replaces: LightningModule.load_from_checkpoint / load_state_dict (src/run.py:42-44).
+ * `name` is the reference state_dict key, `data` a HOST fp32 array of `numel`.
+ * After all tensors are staged, tb_finalize_weights packs them into MFMA fragment order and uploads. */
+int tb_load_weight(tb_ctx* ctx, const char* name, const float* host_data, int64_t numel);
+int tb_finalize_weights(tb_ctx* ctx, tb_stream stream);
+
+/* -- hot path: closed-loop rollout ------------------------------------------------------------------ */
+typedef struct tb_rollout_io {
+    /* sizes */
+    int32_t n_scene, k_futures, n_agent, n_pl, n_tl, n_hist, step_end;
+    /* encoded scene (outputs of encode_input_features, traffic_bots.py:109-151) */
+    const float* map_feature;      /* [B,P,128] */
+    const uint8_t* map_feature_valid; /* [B,P] */
+    const float* tl_feature;       /* [B,NH,T,128] */
+    const uint8_t* tl_feature_valid;  /* [B,NH,T] */
+    /* history used for init / teacher forcing (features{} of joint_future_pred, waymo_motion.py:533-546) */
+    const uint8_t* agent_valid;    /* [B,NH,A] */
+    const float* agent_state;      /* [B,NH,A,4] x,y,yaw,spd */
+    const float* agent_vel;        /* [B,NH,A,2] */
+    const float* agent_acc;        /* [B,NH,A] */
+    const float* agent_yaw_rate;   /* [B,NH,A] */
+    const uint8_t* mask_teacher_forcing; /* [B,NH,A] (TeacherForcing.get, teacher_forcing.py:33-74) */
+    const int32_t* agent_type;     /* [B,A] 0 veh / 1 ped / 2 cyc / -1 none */
+    const float* agent_size;       /* [B,A,3] */
+    /* rule-checker geometry (TrafficRuleChecker.__init__, traffic_rule_checker.py:77-98) */
+    const float* map_boundary;     /* [B,4] xmin,xmax,ymin,ymax */
+    const uint8_t* map_valid;      /* [B,P,20] */
+    const int32_t* map_type;       /* [B,P] index of the one-hot */
+    const float* map_pos;          /* [B,P,20,2] */
+    const float* map_dir;          /* [B,P,20,2] */
+    /* per instance */
+    const float* latent_sample;    /* [N,A,16] z (MyDist.sample, distributions.py:18-38) */
+    const float* latent_mean;      /* [B,A,16] prior mean, for latent_log_prob */
+    const int32_t* dest;           /* [N,A] destination polyline index (goal_sample) */
+    const uint8_t* goal_valid;     /* [N,A] */
+    /* outputs = RolloutBuffer fields after finish() (buffer.py:72-90), step axis S = step_end - sim_start + 1 */
+    float* preds;                  /* [N,A,S,4] */
+    uint8_t* valid;                /* [N,A,S] */
+    uint8_t* override_masks;       /* [N,A,S] */
+    uint8_t* outside_map;          /* [N,A,S] */
+    uint8_t* outside_map_this_step;/* [N,A,S] */
+    uint8_t* dest_reached;         /* [N,A,S] */
+    uint8_t* dest_reached_this_step; /* [N,A,S] */
+    float* action_log_probs;       /* [N,A,S] */
+    float* latent_log_prob;        /* [N,A]   (constant over steps, traffic_bots.py:196-199) */
+    /* final simulator state (Dynamics.agent_state/agent_valid, TrafficBots.hidden) -- may be NULL */
+    float* final_state;            /* [N,A,4] */
+    uint8_t* final_valid;          /* [N,A] */
+    float* final_hidden;           /* [3,N,A,128] */
+    /* optional debug taps (NULL to skip): policy feature of one step */
+    int32_t tap_step;              /* absolute step whose policy feature to capture, or -1 */
+    float* tap_policy_feature;     /* [N,A,128] */
+    float* tap_agent_feature;      /* [N,A,128] */
+} tb_rollout_io;
+
+/* Replaces: WaymoMotion.rollout (+ per-step WaymoMotion.forward, TrafficBots.forward, ActionHead,
+ * Dynamics.update/override_states/kill, TrafficRuleChecker.check, GoalManager.get_goal_feature /
+ * disable_goal_reached, RolloutBuffer) -- waymo_motion.py:108-354. */
+int tb_rollout(tb_ctx* ctx, const tb_rollout_io* io, tb_stream stream);
+
+/* -- hot path: scene encoders ------------------------------------------------------------------------ */
+typedef struct tb_encode_io {
+    int32_t n_scene, n_agent, n_pl, n_tl, n_hist;
+    /* raw scene (packed-h5 test split, data_h5_womd.py:119-157; bool tensors as uint8) */
+    const uint8_t* agent_valid;    /* [B,NH,A] */
+    const float* agent_pos;        /* [B,NH,A,2] */
+    const float* agent_yaw;        /* [B,NH,A] */
+    const float* agent_vel;        /* [B,NH,A,2] */
+    const float* agent_spd;        /* [B,NH,A] */
+    const float* agent_acc;        /* [B,NH,A] */
+    const float* agent_yaw_rate;   /* [B,NH,A] */
+    const int32_t* agent_type;     /* [B,A] */
+    const float* agent_size;       /* [B,A,3] */
+    const uint8_t* map_valid;      /* [B,P,20] */
+    const int32_t* map_type;       /* [B,P] */
+    const float* map_pos;          /* [B,P,20,2] */
+    const float* map_dir;          /* [B,P,20,2] */
+    const uint8_t* tl_valid;       /* [B,NH,T] */
+    const int32_t* tl_state;       /* [B,NH,T] index of the one-hot */
+    const float* tl_pos;           /* [B,NH,T,2] */
+    const float* tl_dir;           /* [B,NH,T,2] */
+    /* outputs */
+    float* map_feature;            /* [B,P,128] */
+    uint8_t* map_feature_valid;    /* [B,P] */
+    float* agent_feature;          /* [B,NH,A,128] */
+    float* tl_feature;             /* [B,NH,T,128] */
+    float* latent_mean;            /* [B,A,16]  prior mean (LatentEncoder.forward, latent_encoder.py:70-147) */
+    uint8_t* latent_valid;         /* [B,A] */
+    float* dest_logits;            /* [B,A,P] masked, un-normalised (DestPredictor.forward, goal_manager.py:202-333) */
+} tb_encode_io;
+
+/* Replaces: SceneCentricInput.forward (sc_input.py:50-140) + TrafficBots.encode_input_features
+ * (traffic_bots.py:109-151) + LatentEncoder.forward prior + GoalManager.pred_goal. */
+int tb_encode_scene(tb_ctx* ctx, const tb_encode_io* io, tb_stream stream);
+
+/* -- instrumentation ---------------------------------------------------------------------------------- */
+/* Time (ms, HIP events on `stream`) spent in the per-step kernels of the LAST tb_rollout when timing was
+ * enabled with tb_set_timing(ctx, 1): out[0] = sum over steps of kernel A (encode+as2pl+as2tl+kv), out[1] =
+ * kernel C (interaction..dynamics), out[2] = prologue (hoists), out[3] = number of steps.  Timing inserts event
+ * records only (no host sync until this query, which synchronises the events). */
+int tb_set_timing(tb_ctx* ctx, int enable);
+int tb_get_timing(tb_ctx* ctx, float* out4);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TRAFFICBOTS_HIP_H */

@@ -1,0 +1,529 @@
+// C ABI (include/trafficbots_hip.h): context, weight staging + MFMA-fragment packing, workspace, rollout driver.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/trafficbots_hip.h"
+#include "tb_encode.hpp"
+#include "tb_rollout.hpp"
+
+namespace tb {
+size_t step_lds_bytes();
+void launch_kv_hoist(const float* W, const XLayerW* L3, const float* feat, const uint8_t* fvalid, int G, int n_tok, int n_pad,
+                     float* K, float* VT, uint8_t* kvalid, hipStream_t s);
+void launch_rollout_init(const RolloutP& p, hipStream_t s);
+void launch_step_a(const RolloutP& p, int t, hipStream_t s);
+void launch_step_c(const RolloutP& p, int t, hipStream_t s);
+int run_encode(struct ::tb_ctx* ctx, const tb_encode_io* io, hipStream_t s);
+}  // namespace tb
+
+struct tb_ctx {
+    tb_config cfg;
+    std::string err;
+    std::map<std::string, std::vector<float>> staged;
+    float* d_arena = nullptr;
+    size_t arena_floats = 0;
+    tb::PolicyW pw;
+    tb::EncoderW ew;
+    bool finalized = false;
+    // workspace
+    char* d_ws = nullptr;
+    size_t ws_bytes = 0;
+    // timing
+    bool timing = false;
+    std::vector<hipEvent_t> ev;
+    int n_timed_steps = 0;
+};
+
+static int fail(tb_ctx* ctx, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (ctx) ctx->err = buf;
+    return 1;
+}
+
+#define TB_HIP(ctx, call)                                                                  \
+    do {                                                                                   \
+        hipError_t e_ = (call);                                                            \
+        if (e_ != hipSuccess) return fail(ctx, "%s failed: %s", #call, hipGetErrorString(e_)); \
+    } while (0)
+
+// ---------------------------------------------------------------------------------------------------
+// weight arena builder
+// ---------------------------------------------------------------------------------------------------
+namespace {
+
+struct Arena {
+    std::vector<float> h;
+    uint32_t add(const float* src, size_t n) {
+        while (h.size() % 64) h.push_back(0.f);
+        uint32_t off = (uint32_t)h.size();
+        h.insert(h.end(), src, src + n);
+        return off;
+    }
+    uint32_t add(const std::vector<float>& v) { return add(v.data(), v.size()); }
+};
+
+// W [n_out][k] row-major -> [n_out/16][kp/16][64][4] with lane = kq*16 + m, k = kq*(kp/4) + 4*j + i
+std::vector<float> pack_mfma(const float* w, int n_out, int k, int kp) {
+    const int n_tiles = n_out / 16, kj = kp / 16;
+    std::vector<float> out((size_t)n_tiles * kj * 64 * 4, 0.f);
+    for (int t = 0; t < n_tiles; ++t)
+        for (int j = 0; j < kj; ++j)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int i = 0; i < 4; ++i) {
+                    const int kq = lane >> 4, m = lane & 15;
+                    const int kk = kq * (kp / 4) + 4 * j + i;
+                    out[(((size_t)t * kj + j) * 64 + lane) * 4 + i] = kk < k ? w[(size_t)(t * 16 + m) * k + kk] : 0.f;
+                }
+    return out;
+}
+
+struct Stage {
+    tb_ctx* ctx;
+    bool ok = true;
+    const std::vector<float>* get(const std::string& name, size_t numel) {
+        auto it = ctx->staged.find(name);
+        if (it == ctx->staged.end()) {
+            if (ok) fail(ctx, "weight '%s' was not loaded", name.c_str());
+            ok = false;
+            return nullptr;
+        }
+        if (it->second.size() != numel) {
+            if (ok) fail(ctx, "weight '%s': expected %zu elements, got %zu", name.c_str(), numel, it->second.size());
+            ok = false;
+            return nullptr;
+        }
+        return &it->second;
+    }
+};
+
+uint32_t add_plain(Arena& a, Stage& s, const std::string& name, size_t numel) {
+    auto v = s.get(name, numel);
+    return v ? a.add(*v) : 0;
+}
+
+uint32_t add_packed(Arena& a, Stage& s, const std::string& name, int n_out, int k, int kp, int row0 = 0, int rows_total = -1) {
+    if (rows_total < 0) rows_total = n_out;
+    auto v = s.get(name, (size_t)rows_total * k);
+    if (!v) return 0;
+    return a.add(pack_mfma(v->data() + (size_t)row0 * k, n_out, k, kp));
+}
+
+tb::XLayerW add_xlayer(Arena& a, Stage& s, const std::string& p) {
+    tb::XLayerW L;
+    L.ln1_g = add_plain(a, s, p + ".norm1.weight", 128);
+    L.ln1_b = add_plain(a, s, p + ".norm1.bias", 128);
+    L.lnt_g = add_plain(a, s, p + ".norm_tgt.weight", 128);
+    L.lnt_b = add_plain(a, s, p + ".norm_tgt.bias", 128);
+    L.ln2_g = add_plain(a, s, p + ".norm2.weight", 128);
+    L.ln2_b = add_plain(a, s, p + ".norm2.bias", 128);
+    L.wq = add_packed(a, s, p + ".attn.in_proj_weight", 128, 128, 128, 0, 384);
+    L.wkv = add_packed(a, s, p + ".attn.in_proj_weight", 256, 128, 128, 128, 384);
+    auto bin = s.get(p + ".attn.in_proj_bias", 384);
+    if (bin) {
+        L.bq = a.add(bin->data(), 128);
+        L.bkv = a.add(bin->data() + 128, 256);
+    }
+    L.wo = add_packed(a, s, p + ".attn.out_proj_weight", 128, 128, 128);
+    L.bo = add_plain(a, s, p + ".attn.out_proj_bias", 128);
+    L.w1 = add_packed(a, s, p + ".linear1.weight", 128, 128, 128);
+    L.b1 = add_plain(a, s, p + ".linear1.bias", 128);
+    L.w2 = add_packed(a, s, p + ".linear2.weight", 128, 128, 128);
+    L.b2 = add_plain(a, s, p + ".linear2.bias", 128);
+    return L;
+}
+
+tb::GruLayerW add_gru(Arena& a, Stage& s, const std::string& p, int l) {
+    tb::GruLayerW G;
+    const std::string sl = std::to_string(l);
+    G.wih = add_packed(a, s, p + ".weight_ih_l" + sl, 384, 128, 128);
+    G.whh = add_packed(a, s, p + ".weight_hh_l" + sl, 384, 128, 128);
+    G.bih = add_plain(a, s, p + ".bias_ih_l" + sl, 384);
+    G.bhh = add_plain(a, s, p + ".bias_hh_l" + sl, 384);
+    return G;
+}
+
+uint32_t add_freqs(Arena& a, Stage& s, const std::string& name, int n_full) {
+    auto v = s.get(name, n_full);
+    if (!v) return 0;
+    std::vector<float> f(n_full / 2);
+    for (int i = 0; i < n_full / 2; ++i) f[i] = (*v)[2 * i];  // repeat_interleave(2) table (pos_emb.py:13,43)
+    return a.add(f);
+}
+
+tb::EncMlpW add_enc(Arena& a, Stage& s, const std::string& p, int attr_dim) {
+    tb::EncMlpW e;
+    e.w1 = add_plain(a, s, p + ".mlp.fc_layers.0.weight", (size_t)32 * attr_dim);
+    e.b1 = add_plain(a, s, p + ".mlp.fc_layers.0.bias", 32);
+    e.w2 = add_plain(a, s, p + ".mlp.fc_layers.3.weight", 32 * 32);
+    e.b2 = add_plain(a, s, p + ".mlp.fc_layers.3.bias", 32);
+    return e;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------
+extern "C" {
+
+const char* tb_version(void) { return "trafficbots_hip 0.1 (gfx950, fp32 MFMA 16x16x4)"; }
+
+int tb_create(const tb_config* cfg, tb_ctx** out) {
+    if (!cfg || !out) return 1;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+        fprintf(stderr, "trafficbots_hip: no HIP device visible -- this library has no CPU fallback\n");
+        return 2;
+    }
+    tb_ctx* c = new tb_ctx();
+    c->cfg = *cfg;
+    *out = c;
+    return 0;
+}
+
+void tb_destroy(tb_ctx* ctx) {
+    if (!ctx) return;
+    if (ctx->d_arena) (void)hipFree(ctx->d_arena);
+    if (ctx->d_ws) (void)hipFree(ctx->d_ws);
+    for (auto e : ctx->ev) (void)hipEventDestroy(e);
+    delete ctx;
+}
+
+const char* tb_last_error(tb_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int tb_load_weight(tb_ctx* ctx, const char* name, const float* host_data, int64_t numel) {
+    if (!ctx || !name || !host_data || numel <= 0) return fail(ctx, "tb_load_weight: bad argument");
+    ctx->staged[name] = std::vector<float>(host_data, host_data + numel);
+    ctx->finalized = false;
+    return 0;
+}
+
+int tb_finalize_weights(tb_ctx* ctx, tb_stream stream) {
+    if (!ctx) return 1;
+    Arena a;
+    Stage s{ctx};
+    tb::PolicyW& pw = ctx->pw;
+    for (int i = 0; i < 3; ++i) {
+        const std::string si = std::to_string(i);
+        pw.as2pl[i] = add_xlayer(a, s, "model.transformer_as2pl.layers." + si);
+        pw.as2tl[i] = add_xlayer(a, s, "model.transformer_as2tl.layers." + si);
+        pw.inter[i] = add_xlayer(a, s, "model.agent_interaction.transformer.layers." + si);
+        pw.gru[i] = add_gru(a, s, "model.agent_temporal.rnn", i);
+    }
+    {
+        tb::EncMlpW e = add_enc(a, s, "model.agent_encoder", 11);
+        pw.enc_w1 = e.w1; pw.enc_b1 = e.b1; pw.enc_w2 = e.w2; pw.enc_b2 = e.b2;
+    }
+    pw.pe_fxy = add_freqs(a, s, "pre_processing.input.pose_pe_agent.pe_xy.freqs", 24);
+    pw.pe_fyaw = add_freqs(a, s, "pre_processing.input.pose_pe_agent.pe_yaw.freqs", 48);
+    const int gl[3] = {0, 4, 8};
+    for (int i = 0; i < 3; ++i) {
+        const std::string p = "model.add_goal.mlp_in.fc_layers.";
+        pw.goal_in_w[i] = add_packed(a, s, p + std::to_string(gl[i]) + ".weight", 128, 128, 128);
+        pw.goal_in_b[i] = add_plain(a, s, p + std::to_string(gl[i]) + ".bias", 128);
+        pw.goal_in_g[i] = add_plain(a, s, p + std::to_string(gl[i] + 1) + ".weight", 128);
+        pw.goal_in_be[i] = add_plain(a, s, p + std::to_string(gl[i] + 1) + ".bias", 128);
+    }
+    pw.goal_out_w1 = add_packed(a, s, "model.add_goal.mlp_out.fc_layers.0.weight", 128, 256, 256);
+    pw.goal_out_b1 = add_plain(a, s, "model.add_goal.mlp_out.fc_layers.0.bias", 128);
+    pw.goal_out_w2 = add_packed(a, s, "model.add_goal.mlp_out.fc_layers.3.weight", 128, 128, 128);
+    pw.goal_out_b2 = add_plain(a, s, "model.add_goal.mlp_out.fc_layers.3.bias", 128);
+    pw.lat_in_w1 = add_packed(a, s, "model.add_latent.mlp_in.fc_layers.0.weight", 128, 16, 16);
+    pw.lat_in_b1 = add_plain(a, s, "model.add_latent.mlp_in.fc_layers.0.bias", 128);
+    pw.lat_in_w2 = add_packed(a, s, "model.add_latent.mlp_in.fc_layers.3.weight", 128, 128, 128);
+    pw.lat_in_b2 = add_plain(a, s, "model.add_latent.mlp_in.fc_layers.3.bias", 128);
+    pw.lat_out_w1 = add_packed(a, s, "model.add_latent.mlp_out.fc_layers.0.weight", 128, 256, 256);
+    pw.lat_out_b1 = add_plain(a, s, "model.add_latent.mlp_out.fc_layers.0.bias", 128);
+    pw.lat_out_w2 = add_packed(a, s, "model.add_latent.mlp_out.fc_layers.3.weight", 128, 128, 128);
+    pw.lat_out_b2 = add_plain(a, s, "model.add_latent.mlp_out.fc_layers.3.bias", 128);
+    for (int i = 0; i < 3; ++i) {
+        const std::string p = "action_head.mlp_mean." + std::to_string(i) + ".fc_layers.";
+        pw.head_w1[i] = add_packed(a, s, p + "0.weight", 128, 128, 128);
+        pw.head_b1[i] = add_plain(a, s, p + "0.bias", 128);
+        pw.head_w2[i] = add_plain(a, s, p + "2.weight", 2 * 128);
+        pw.head_b2[i] = add_plain(a, s, p + "2.bias", 2);
+        pw.head_log_std[i] = add_plain(a, s, "action_head.log_std." + std::to_string(i), 2);
+    }
+    pw.latent_log_std = add_plain(a, s, "model.latent_encoder.latent_prior_dist.log_std", 16);
+    for (int i = 0; i < 3; ++i) {
+        pw.max_acc[i] = ctx->cfg.max_acc[i];
+        pw.max_yaw_rate[i] = ctx->cfg.max_yaw_rate[i];
+    }
+    pw.dt = ctx->cfg.dt;
+
+    // ---- scene-encoder weights
+    tb::EncoderW& ew = ctx->ew;
+    ew.map_enc = add_enc(a, s, "model.map_encoder.input_pe_encoder", 31);
+    ew.tl_enc = add_enc(a, s, "model.tl_encoder", 5);
+    ew.agent_enc = add_enc(a, s, "model.agent_encoder", 11);
+    ew.pe_fxy = pw.pe_fxy;
+    ew.pe_fyaw = pw.pe_fyaw;
+    for (int i = 0; i < 3; ++i) {
+        const std::string si = std::to_string(i);
+        ew.densetnt[i] = add_xlayer(a, s, "model.map_encoder.transformer_densetnt.layers." + si);
+        ew.inter_prior[i] = add_xlayer(a, s, "model.latent_encoder.agent_interaction_prior.transformer.layers." + si);
+        ew.gru_prior[i] = add_gru(a, s, "model.latent_encoder.agent_temporal_prior.rnn", i);
+        ew.gru_dest[i] = add_gru(a, s, "model.goal_manager.goal_predictor.gru_as.rnn", i);
+        ew.as2pl[i] = pw.as2pl[i];
+        ew.as2tl[i] = pw.as2tl[i];
+    }
+    ew.map_self = add_xlayer(a, s, "model.map_encoder.transformer_self_attn.layers.0");
+    ew.lat_w1 = add_packed(a, s, "model.latent_encoder.latent_prior_dist.mlp_mean.fc_layers.0.weight", 128, 128, 128);
+    ew.lat_b1 = add_plain(a, s, "model.latent_encoder.latent_prior_dist.mlp_mean.fc_layers.0.bias", 128);
+    ew.lat_w2 = add_plain(a, s, "model.latent_encoder.latent_prior_dist.mlp_mean.fc_layers.2.weight", 16 * 128);
+    ew.lat_b2 = add_plain(a, s, "model.latent_encoder.latent_prior_dist.mlp_mean.fc_layers.2.bias", 16);
+    {
+        // dest predictor first layer [128][256] split into the map half (cols 0:128) and the agent half (128:256)
+        const std::string p = "model.goal_manager.goal_predictor.mlp.fc_layers.";
+        auto w0 = s.get(p + "0.weight", 128 * 256);
+        if (w0) {
+            std::vector<float> wm(128 * 128), wa(128 * 128);
+            for (int o = 0; o < 128; ++o)
+                for (int k = 0; k < 128; ++k) {
+                    wm[o * 128 + k] = (*w0)[o * 256 + k];
+                    wa[o * 128 + k] = (*w0)[o * 256 + 128 + k];
+                }
+            ew.dest_w0_map = a.add(pack_mfma(wm.data(), 128, 128, 128));
+            ew.dest_w0_agent = a.add(pack_mfma(wa.data(), 128, 128, 128));
+        }
+        ew.dest_b0 = add_plain(a, s, p + "0.bias", 128);
+        ew.dest_ln0_g = add_plain(a, s, p + "1.weight", 128);
+        ew.dest_ln0_b = add_plain(a, s, p + "1.bias", 128);
+        ew.dest_w1 = add_packed(a, s, p + "3.weight", 128, 128, 128);
+        ew.dest_b1 = add_plain(a, s, p + "3.bias", 128);
+        ew.dest_ln1_g = add_plain(a, s, p + "4.weight", 128);
+        ew.dest_ln1_b = add_plain(a, s, p + "4.bias", 128);
+        ew.dest_w2 = add_plain(a, s, p + "6.weight", 128);
+        ew.dest_b2 = add_plain(a, s, p + "6.bias", 1);
+    }
+    if (!s.ok) return 1;
+
+    if (ctx->d_arena) {
+        TB_HIP(ctx, hipFree(ctx->d_arena));
+        ctx->d_arena = nullptr;
+    }
+    ctx->arena_floats = a.h.size();
+    TB_HIP(ctx, hipMalloc((void**)&ctx->d_arena, a.h.size() * sizeof(float)));
+    TB_HIP(ctx, hipMemcpyAsync(ctx->d_arena, a.h.data(), a.h.size() * sizeof(float), hipMemcpyHostToDevice, (hipStream_t)stream));
+    TB_HIP(ctx, hipStreamSynchronize((hipStream_t)stream));  // host staging buffer `a` dies at return
+    ctx->staged.clear();
+    ctx->finalized = true;
+    return 0;
+}
+
+int tb_set_timing(tb_ctx* ctx, int enable) {
+    if (!ctx) return 1;
+    ctx->timing = enable != 0;
+    return 0;
+}
+
+int tb_get_timing(tb_ctx* ctx, float* out4) {
+    if (!ctx || !out4) return 1;
+    out4[0] = out4[1] = out4[2] = 0.f;
+    out4[3] = (float)ctx->n_timed_steps;
+    if (ctx->n_timed_steps == 0) return 0;
+    const int n = ctx->n_timed_steps;
+    TB_HIP(ctx, hipEventSynchronize(ctx->ev[2 + 3 * n - 1]));
+    float ms = 0.f;
+    TB_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));
+    out4[2] = ms;
+    for (int i = 0; i < n; ++i) {
+        TB_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev[2 + 3 * i], ctx->ev[2 + 3 * i + 1]));
+        out4[0] += ms;
+        TB_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev[2 + 3 * i + 1], ctx->ev[2 + 3 * i + 2]));
+        out4[1] += ms;
+    }
+    return 0;
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------
+// workspace
+// ---------------------------------------------------------------------------------------------------
+struct Carver {
+    char* base;
+    size_t off = 0;
+    template <typename T>
+    T* take(size_t n) {
+        off = (off + 255) & ~(size_t)255;
+        T* p = base ? reinterpret_cast<T*>(base + off) : nullptr;
+        off += n * sizeof(T);
+        return p;
+    }
+};
+
+int tb_ensure_workspace(tb_ctx* ctx, size_t bytes) {
+    if (bytes <= ctx->ws_bytes) return 0;
+    if (ctx->d_ws) {
+        TB_HIP(ctx, hipDeviceSynchronize());
+        TB_HIP(ctx, hipFree(ctx->d_ws));
+        ctx->d_ws = nullptr;
+        ctx->ws_bytes = 0;
+    }
+    bytes += bytes / 8;
+    TB_HIP(ctx, hipMalloc((void**)&ctx->d_ws, bytes));
+    ctx->ws_bytes = bytes;
+    return 0;
+}
+
+static inline int pad16(int x) { return (x + 15) / 16 * 16; }
+
+static void carve_rollout(tb::RolloutP& p, Carver& c) {
+    const size_t B = p.n_scene, N = p.n_inst, NH = p.n_hist;
+    p.kpl = c.take<float>(B * 3 * p.p_pad * 128);
+    p.vtpl = c.take<float>(B * 3 * 128 * p.p_pad);
+    p.kvalid_pl = c.take<uint8_t>(B * p.p_pad);
+    p.ktl = c.take<float>(B * NH * 3 * p.t_pad * 128);
+    p.vttl = c.take<float>(B * NH * 3 * 128 * p.t_pad);
+    p.kvalid_tl = c.take<uint8_t>(B * NH * p.t_pad);
+    p.state = c.take<float>(N * p.a_pad * 4);
+    p.aux = c.take<float>(N * p.a_pad * 4);
+    p.valid = c.take<uint8_t>(N * p.a_pad);
+    p.killed = c.take<uint8_t>(N * p.a_pad);
+    p.goal_valid = c.take<uint8_t>(N * p.a_pad);
+    p.dest_reached = c.take<uint8_t>(N * p.a_pad);
+    p.outside = c.take<uint8_t>(N * p.a_pad);
+    p.hidden = c.take<float>(3 * N * p.a_pad * 128);
+    p.x_mid = c.take<float>(N * p.a_pad * 128);
+    p.kin = c.take<float>(N * 3 * p.a_pad * 128);
+    p.vtin = c.take<float>(N * 3 * 128 * p.a_pad);
+    p.goal_pre = c.take<float>(N * p.a_pad * 128);
+    p.lat_pre = c.take<float>(N * p.a_pad * 128);
+}
+
+extern "C" int tb_rollout(tb_ctx* ctx, const tb_rollout_io* io, tb_stream stream_) {
+    if (!ctx || !io) return 1;
+    if (!ctx->finalized) return fail(ctx, "tb_rollout: weights not finalized");
+    hipStream_t s = (hipStream_t)stream_;
+    if (io->n_scene <= 0 || io->k_futures <= 0 || io->n_agent <= 0 || io->n_pl <= 0 || io->n_tl <= 0)
+        return fail(ctx, "tb_rollout: empty dimension (B=%d K=%d A=%d P=%d T=%d)", io->n_scene, io->k_futures, io->n_agent,
+                    io->n_pl, io->n_tl);
+    if (io->n_agent > 256) return fail(ctx, "tb_rollout: n_agent %d > 256 not supported", io->n_agent);
+    if (io->n_hist != ctx->cfg.time_step_current + 1)
+        return fail(ctx, "tb_rollout: n_hist %d != time_step_current+1", io->n_hist);
+    const int step_start = ctx->cfg.time_step_sim_start;
+    if (io->step_end < step_start) return fail(ctx, "tb_rollout: step_end < time_step_sim_start");
+    tb::RolloutP p;
+    memset(&p, 0, sizeof(p));
+    p.W = ctx->d_arena;
+    p.pw = ctx->pw;
+    p.n_scene = io->n_scene;
+    p.k_rep = io->k_futures;
+    p.n_inst = io->n_scene * io->k_futures;
+    p.n_agent = io->n_agent;
+    p.a_pad = pad16(io->n_agent);
+    p.n_pl = io->n_pl;
+    p.p_pad = pad16(io->n_pl);
+    p.n_tl = io->n_tl;
+    p.t_pad = pad16(io->n_tl);
+    p.n_hist = io->n_hist;
+    p.step_start = step_start;
+    p.n_step_out = io->step_end - step_start + 1;
+    p.map_feature = io->map_feature;
+    p.tl_feature = io->tl_feature;
+    p.hist_valid = io->agent_valid;
+    p.hist_state = io->agent_state;
+    p.hist_vel = io->agent_vel;
+    p.hist_acc = io->agent_acc;
+    p.hist_yaw_rate = io->agent_yaw_rate;
+    p.tf_mask = io->mask_teacher_forcing;
+    p.agent_type = io->agent_type;
+    p.agent_size = io->agent_size;
+    p.map_boundary = io->map_boundary;
+    p.map_valid = io->map_valid;
+    p.map_type = io->map_type;
+    p.map_pos = io->map_pos;
+    p.map_dir = io->map_dir;
+    p.latent_z = io->latent_sample;
+    p.latent_mean = io->latent_mean;
+    p.dest = io->dest;
+    p.goal_valid0 = io->goal_valid;
+    p.preds = io->preds;
+    p.o_valid = io->valid;
+    p.o_override = io->override_masks;
+    p.o_outside = io->outside_map;
+    p.o_outside_this = io->outside_map_this_step;
+    p.o_dest_reached = io->dest_reached;
+    p.o_dest_reached_this = io->dest_reached_this_step;
+    p.o_action_logp = io->action_log_probs;
+    p.o_latent_logp = io->latent_log_prob;
+    p.tap_step = io->tap_step;
+    p.tap_policy_feature = io->tap_policy_feature;
+    p.tap_agent_feature = io->tap_agent_feature;
+    const void* required[] = {p.map_feature, io->map_feature_valid, p.tl_feature, io->tl_feature_valid, p.hist_valid, p.hist_state,
+                              p.hist_vel, p.hist_acc, p.hist_yaw_rate, p.tf_mask, p.agent_type, p.agent_size, p.map_boundary,
+                              p.map_valid, p.map_type, p.map_pos, p.map_dir, p.latent_z, p.latent_mean, p.dest, p.goal_valid0,
+                              p.preds, p.o_valid, p.o_override, p.o_outside, p.o_outside_this, p.o_dest_reached,
+                              p.o_dest_reached_this, p.o_action_logp, p.o_latent_logp};
+    for (const void* q : required)
+        if (!q) return fail(ctx, "tb_rollout: a required buffer pointer is NULL");
+
+    Carver sizing{nullptr};
+    carve_rollout(p, sizing);
+    if (tb_ensure_workspace(ctx, sizing.off + 256)) return 1;
+    Carver c{ctx->d_ws};
+    carve_rollout(p, c);
+
+    const int n_steps = p.n_step_out;
+    if (ctx->timing) {
+        const size_t need = 2 + 3 * (size_t)n_steps;
+        while (ctx->ev.size() < need) {
+            hipEvent_t e;
+            TB_HIP(ctx, hipEventCreate(&e));
+            ctx->ev.push_back(e);
+        }
+        TB_HIP(ctx, hipEventRecord(ctx->ev[0], s));
+    }
+    // ---- prologue: hoisted K/V of the map and of every history step's traffic lights; simulator init
+    tb::launch_kv_hoist(p.W, p.pw.as2pl, p.map_feature, io->map_feature_valid, p.n_scene, p.n_pl, p.p_pad, p.kpl, p.vtpl,
+                        p.kvalid_pl, s);
+    tb::launch_kv_hoist(p.W, p.pw.as2tl, p.tl_feature, io->tl_feature_valid, p.n_scene * p.n_hist, p.n_tl, p.t_pad, p.ktl,
+                        p.vttl, p.kvalid_tl, s);
+    tb::launch_rollout_init(p, s);
+    if (ctx->timing) TB_HIP(ctx, hipEventRecord(ctx->ev[1], s));
+    // ---- the sequential loop (waymo_motion.py:269): two launches per step, no host sync
+    for (int i = 0; i < n_steps; ++i) {
+        const int t = step_start + i;
+        if (ctx->timing) TB_HIP(ctx, hipEventRecord(ctx->ev[2 + 3 * i], s));
+        tb::launch_step_a(p, t, s);
+        if (ctx->timing) TB_HIP(ctx, hipEventRecord(ctx->ev[2 + 3 * i + 1], s));
+        tb::launch_step_c(p, t, s);
+        if (ctx->timing) TB_HIP(ctx, hipEventRecord(ctx->ev[2 + 3 * i + 2], s));
+    }
+    ctx->n_timed_steps = ctx->timing ? n_steps : 0;
+    // ---- final simulator state
+    if (io->final_state || io->final_valid) {
+        for (int n = 0; n < p.n_inst; ++n) {
+            if (io->final_state)
+                TB_HIP(ctx, hipMemcpyAsync(io->final_state + (size_t)n * p.n_agent * 4, p.state + (size_t)n * p.a_pad * 4,
+                                           (size_t)p.n_agent * 4 * sizeof(float), hipMemcpyDeviceToDevice, s));
+            if (io->final_valid)
+                TB_HIP(ctx, hipMemcpyAsync(io->final_valid + (size_t)n * p.n_agent, p.valid + (size_t)n * p.a_pad,
+                                           (size_t)p.n_agent, hipMemcpyDeviceToDevice, s));
+        }
+    }
+    if (io->final_hidden) {
+        for (int l = 0; l < 3; ++l)
+            for (int n = 0; n < p.n_inst; ++n)
+                TB_HIP(ctx, hipMemcpyAsync(io->final_hidden + ((size_t)l * p.n_inst + n) * p.n_agent * 128,
+                                           p.hidden + ((size_t)l * p.n_inst + n) * p.a_pad * 128,
+                                           (size_t)p.n_agent * 128 * sizeof(float), hipMemcpyDeviceToDevice, s));
+    }
+    TB_HIP(ctx, hipGetLastError());
+    return 0;
+}
+
+extern "C" int tb_encode_scene(tb_ctx* ctx, const tb_encode_io* io, tb_stream stream) {
+    if (!ctx || !io) return 1;
+    if (!ctx->finalized) return fail(ctx, "tb_encode_scene: weights not finalized");
+    return tb::run_encode(ctx, io, (hipStream_t)stream);
+}

@@ -1,0 +1,92 @@
+// Kernel-side parameter blocks of the rollout path (passed by value as kernel arguments).
+#pragma once
+#include "tb_device.hpp"
+
+namespace tb {
+
+struct PolicyW {
+    XLayerW as2pl[3], as2tl[3], inter[3];
+    GruLayerW gru[3];
+    // agent InputPeEncoder (plain row-major, VALU): W1 [32][11], W2 [32][32]
+    uint32_t enc_w1, enc_b1, enc_w2, enc_b2;
+    uint32_t pe_fxy;   // 12 distinct xy frequencies
+    uint32_t pe_fyaw;  // 24 distinct yaw multipliers
+    // add_goal: mlp_in 3x(Linear128 + LN), mlp_out Linear(256->128), Linear(128->128)
+    uint32_t goal_in_w[3], goal_in_b[3], goal_in_g[3], goal_in_be[3];
+    uint32_t goal_out_w1, goal_out_b1, goal_out_w2, goal_out_b2;
+    // add_latent: mlp_in Linear(16->128), Linear(128->128); mlp_out as above
+    uint32_t lat_in_w1, lat_in_b1, lat_in_w2, lat_in_b2;
+    uint32_t lat_out_w1, lat_out_b1, lat_out_w2, lat_out_b2;
+    // action head per type: Linear(128->128) packed, Linear(128->2) plain [2][128]
+    uint32_t head_w1[3], head_b1[3], head_w2[3], head_b2[3];
+    uint32_t head_log_std[3];  // [2] each
+    uint32_t latent_log_std;   // [16]
+    float max_acc[3], max_yaw_rate[3];
+    float dt;
+};
+
+struct RolloutP {
+    const float* W;  // weight arena
+    PolicyW pw;
+    // sizes
+    int n_scene, k_rep, n_inst, n_agent, a_pad, n_pl, p_pad, n_tl, t_pad, n_hist, step_start, n_step_out;
+    // encoded scene
+    const float* map_feature;     // [B,P,128]
+    const float* tl_feature;      // [B,NH,T,128]
+    // hoisted keys/values
+    float* kpl;                   // [B,3,p_pad,128]
+    float* vtpl;                  // [B,3,128,p_pad]
+    uint8_t* kvalid_pl;           // [B,p_pad]
+    float* ktl;                   // [B*NH,3,t_pad,128]
+    float* vttl;                  // [B*NH,3,128,t_pad]
+    uint8_t* kvalid_tl;           // [B*NH,t_pad]
+    // history / teacher forcing
+    const uint8_t* hist_valid;    // [B,NH,A]
+    const float* hist_state;      // [B,NH,A,4]
+    const float* hist_vel;        // [B,NH,A,2]
+    const float* hist_acc;        // [B,NH,A]
+    const float* hist_yaw_rate;   // [B,NH,A]
+    const uint8_t* tf_mask;       // [B,NH,A]
+    const int32_t* agent_type;    // [B,A]
+    const float* agent_size;      // [B,A,3]
+    // rule checker geometry
+    const float* map_boundary;    // [B,4]
+    const uint8_t* map_valid;     // [B,P,20]
+    const int32_t* map_type;      // [B,P]
+    const float* map_pos;         // [B,P,20,2]
+    const float* map_dir;         // [B,P,20,2]
+    // per instance inputs
+    const float* latent_z;        // [N,A,16]
+    const float* latent_mean;     // [B,A,16]
+    const int32_t* dest;          // [N,A]
+    const uint8_t* goal_valid0;   // [N,A]
+    // simulator state (workspace)
+    float* state;                 // [N,a_pad,4]
+    float* aux;                   // [N,a_pad,4]  vel_x, vel_y, acc, yaw_rate as last teacher-forced
+    uint8_t* valid;               // [N,a_pad]
+    uint8_t* killed;
+    uint8_t* goal_valid;
+    uint8_t* dest_reached;
+    uint8_t* outside;
+    float* hidden;                // [3,N,a_pad,128]
+    float* x_mid;                 // [N,a_pad,128]
+    float* kin;                   // [N,3,a_pad,128]
+    float* vtin;                  // [N,3,128,a_pad]
+    float* goal_pre;              // [N,a_pad,128]
+    float* lat_pre;               // [N,a_pad,128]
+    // outputs
+    float* preds;                 // [N,A,S,4]
+    uint8_t* o_valid;
+    uint8_t* o_override;
+    uint8_t* o_outside;
+    uint8_t* o_outside_this;
+    uint8_t* o_dest_reached;
+    uint8_t* o_dest_reached_this;
+    float* o_action_logp;         // [N,A,S]
+    float* o_latent_logp;         // [N,A]
+    int tap_step;
+    float* tap_policy_feature;    // [N,A,128]
+    float* tap_agent_feature;     // [N,A,128]
+};
+
+}  // namespace tb

@@ -1,0 +1,127 @@
+"""ctypes binding of `libtrafficbots_hip.so` (C ABI: include/trafficbots_hip.h).
+
+There is NO CPU fallback: importing this module without the built library, or creating a
+context without a visible HIP device, raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Dict, Optional
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libtrafficbots_hip.so")
+
+c_f32p = C.POINTER(C.c_float)
+c_u8p = C.POINTER(C.c_uint8)
+c_i32p = C.POINTER(C.c_int32)
+
+
+class TbConfig(C.Structure):
+    _fields_ = [
+        ("time_step_current", C.c_int32),
+        ("time_step_sim_start", C.c_int32),
+        ("dt", C.c_float),
+        ("max_acc", C.c_float * 3),
+        ("max_yaw_rate", C.c_float * 3),
+        ("action_log_std", C.c_float),
+        ("latent_log_std", C.c_float),
+    ]
+
+
+class TbRolloutIO(C.Structure):
+    _fields_ = [
+        ("n_scene", C.c_int32), ("k_futures", C.c_int32), ("n_agent", C.c_int32), ("n_pl", C.c_int32),
+        ("n_tl", C.c_int32), ("n_hist", C.c_int32), ("step_end", C.c_int32),
+        ("map_feature", c_f32p), ("map_feature_valid", c_u8p), ("tl_feature", c_f32p), ("tl_feature_valid", c_u8p),
+        ("agent_valid", c_u8p), ("agent_state", c_f32p), ("agent_vel", c_f32p), ("agent_acc", c_f32p),
+        ("agent_yaw_rate", c_f32p), ("mask_teacher_forcing", c_u8p), ("agent_type", c_i32p), ("agent_size", c_f32p),
+        ("map_boundary", c_f32p), ("map_valid", c_u8p), ("map_type", c_i32p), ("map_pos", c_f32p), ("map_dir", c_f32p),
+        ("latent_sample", c_f32p), ("latent_mean", c_f32p), ("dest", c_i32p), ("goal_valid", c_u8p),
+        ("preds", c_f32p), ("valid", c_u8p), ("override_masks", c_u8p), ("outside_map", c_u8p),
+        ("outside_map_this_step", c_u8p), ("dest_reached", c_u8p), ("dest_reached_this_step", c_u8p),
+        ("action_log_probs", c_f32p), ("latent_log_prob", c_f32p),
+        ("final_state", c_f32p), ("final_valid", c_u8p), ("final_hidden", c_f32p),
+        ("tap_step", C.c_int32), ("tap_policy_feature", c_f32p), ("tap_agent_feature", c_f32p),
+    ]
+
+
+class TbEncodeIO(C.Structure):
+    _fields_ = [
+        ("n_scene", C.c_int32), ("n_agent", C.c_int32), ("n_pl", C.c_int32), ("n_tl", C.c_int32), ("n_hist", C.c_int32),
+        ("agent_valid", c_u8p), ("agent_pos", c_f32p), ("agent_yaw", c_f32p), ("agent_vel", c_f32p), ("agent_spd", c_f32p),
+        ("agent_acc", c_f32p), ("agent_yaw_rate", c_f32p), ("agent_type", c_i32p), ("agent_size", c_f32p),
+        ("map_valid", c_u8p), ("map_type", c_i32p), ("map_pos", c_f32p), ("map_dir", c_f32p),
+        ("tl_valid", c_u8p), ("tl_state", c_i32p), ("tl_pos", c_f32p), ("tl_dir", c_f32p),
+        ("map_feature", c_f32p), ("map_feature_valid", c_u8p), ("agent_feature", c_f32p), ("tl_feature", c_f32p),
+        ("latent_mean", c_f32p), ("latent_valid", c_u8p), ("dest_logits", c_f32p),
+    ]
+
+
+EXPORTS = (
+    "tb_create", "tb_destroy", "tb_last_error", "tb_version", "tb_load_weight", "tb_finalize_weights",
+    "tb_rollout", "tb_encode_scene", "tb_set_timing", "tb_get_timing",
+)
+
+_lib: Optional[C.CDLL] = None
+
+
+def lib_path() -> str:
+    return _LIB_PATH
+
+
+def load() -> C.CDLL:
+    """dlopen the HIP library (raises if it has not been built: run `python -c 'import
+    __graft_entry__ as g; g.build()'` or `make -C trafficbots_amd/csrc`)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB_PATH):
+        raise RuntimeError(
+            f"trafficbots_amd: HIP library not built ({_LIB_PATH} missing). There is no CPU fallback; "
+            "build it with __graft_entry__.build()."
+        )
+    lib = C.CDLL(_LIB_PATH)
+    lib.tb_create.argtypes = [C.POINTER(TbConfig), C.POINTER(C.c_void_p)]
+    lib.tb_create.restype = C.c_int
+    lib.tb_destroy.argtypes = [C.c_void_p]
+    lib.tb_destroy.restype = None
+    lib.tb_last_error.argtypes = [C.c_void_p]
+    lib.tb_last_error.restype = C.c_char_p
+    lib.tb_version.argtypes = []
+    lib.tb_version.restype = C.c_char_p
+    lib.tb_load_weight.argtypes = [C.c_void_p, C.c_char_p, c_f32p, C.c_int64]
+    lib.tb_load_weight.restype = C.c_int
+    lib.tb_finalize_weights.argtypes = [C.c_void_p, C.c_void_p]
+    lib.tb_finalize_weights.restype = C.c_int
+    lib.tb_rollout.argtypes = [C.c_void_p, C.POINTER(TbRolloutIO), C.c_void_p]
+    lib.tb_rollout.restype = C.c_int
+    lib.tb_encode_scene.argtypes = [C.c_void_p, C.POINTER(TbEncodeIO), C.c_void_p]
+    lib.tb_encode_scene.restype = C.c_int
+    lib.tb_set_timing.argtypes = [C.c_void_p, C.c_int]
+    lib.tb_set_timing.restype = C.c_int
+    lib.tb_get_timing.argtypes = [C.c_void_p, c_f32p]
+    lib.tb_get_timing.restype = C.c_int
+    _lib = lib
+    return lib
+
+
+def ptr(t, ctype):
+    """Device pointer of a contiguous torch tensor (or NULL for None) as a ctypes pointer."""
+    if t is None:
+        return C.cast(None, ctype)
+    assert t.is_contiguous(), "tensor handed to the C ABI must be contiguous"
+    return C.cast(C.c_void_p(t.data_ptr()), ctype)
+
+
+def make_config(cfg: Dict) -> TbConfig:
+    c = TbConfig()
+    c.time_step_current = int(cfg["time_step_current"])
+    c.time_step_sim_start = int(cfg["time_step_sim_start"])
+    c.dt = 0.1  # Dynamics default dt (src/utils/dynamics.py:13)
+    dyn = cfg["dynamics"]
+    for i, k in enumerate(("veh", "ped", "cyc")):  # type order of `Dynamics.agent_dynamics` (dynamics.py:23-27)
+        c.max_acc[i] = float(dyn[k]["max_acc"])
+        c.max_yaw_rate[i] = float(dyn[k]["max_yaw_rate"])
+    c.action_log_std = float(cfg["action_head"]["log_std"])
+    c.latent_log_std = float(cfg["model"]["latent_encoder"]["latent_prior"]["log_std"])
+    return c

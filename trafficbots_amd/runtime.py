@@ -1,0 +1,253 @@
+"""Host side of the HIP hot path: owns a `tb_ctx`, feeds it borrowed PyTorch-ROCm buffers.
+
+PyTorch is plumbing here (device memory, the current HIP stream); all arithmetic of the path
+runs in `libtrafficbots_hip.so`.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+from torch import Tensor
+
+from . import hip
+
+N_PL_NODE = 20
+
+
+def _onehot_to_index(x: Tensor) -> Tensor:
+    """bool one-hot [..., C] -> int32 index, -1 where no class is set."""
+    idx = x.to(torch.int32).argmax(-1).to(torch.int32)
+    return torch.where(x.any(-1), idx, torch.full_like(idx, -1)).contiguous()
+
+
+def teacher_forcing_mask(valid: Tensor, step_spawn_agent: int = 10, step_warm_start: int = 10) -> Tensor:
+    """Mask of `TeacherForcing.get` (`src/utils/teacher_forcing.py:33-74`) with the schedule terms
+    (step_horizon, prob_forcing_agent) at their default 0: always spawn at step 0, spawn on
+    invalid->valid transitions up to `step_spawn_agent`, force every valid agent up to `step_warm_start`.
+    valid: [B, S, A] bool."""
+    m = torch.zeros_like(valid)
+    m[:, 0] |= valid[:, 0]
+    if step_spawn_agent > 0:
+        sp = (~valid[:, :-1]) & valid[:, 1:]
+        sp[:, step_spawn_agent:] = False
+        m[:, 1:] |= sp
+    if step_warm_start >= 0:
+        m[:, : step_warm_start + 1] |= valid[:, : step_warm_start + 1]
+    return m
+
+
+def scene_from_batch(batch: Dict[str, Tensor], device, n_hist: int = 11) -> Dict[str, Tensor]:
+    """Reference test-split batch (`data_h5_womd.py:119-157`, bool tensors, history/ prefix) ->
+    the C ABI's device layout (uint8 masks, int32 class indices, yaw/spd/acc as [B,NH,A])."""
+
+    def g(k):
+        v = batch[k]
+        if isinstance(v, np.ndarray):
+            v = torch.from_numpy(v)
+        return v.to(device)
+
+    f32, u8 = torch.float32, torch.uint8
+    s: Dict[str, Tensor] = {}
+    av = g("history/agent/valid")[:, :n_hist]
+    s["agent_valid"] = av.to(u8).contiguous()
+    pos = g("history/agent/pos")[:, :n_hist].to(f32)
+    yaw = g("history/agent/yaw_bbox")[:, :n_hist].to(f32)
+    spd = g("history/agent/spd")[:, :n_hist].to(f32)
+    s["agent_pos"] = pos.contiguous()
+    s["agent_yaw"] = yaw[..., 0].contiguous()
+    s["agent_spd"] = spd[..., 0].contiguous()
+    s["agent_state"] = torch.cat([pos, yaw, spd], -1).contiguous()
+    s["agent_vel"] = g("history/agent/vel")[:, :n_hist].to(f32).contiguous()
+    s["agent_acc"] = g("history/agent/acc")[:, :n_hist, :, 0].to(f32).contiguous()
+    s["agent_yaw_rate"] = g("history/agent/yaw_rate")[:, :n_hist, :, 0].to(f32).contiguous()
+    s["agent_type"] = _onehot_to_index(g("history/agent/type"))
+    s["agent_size"] = g("history/agent/size").to(f32).contiguous()
+    s["map_valid"] = g("map/valid").to(u8).contiguous()
+    s["map_type"] = _onehot_to_index(g("map/type"))
+    s["map_pos"] = g("map/pos").to(f32).contiguous()
+    s["map_dir"] = g("map/dir").to(f32).contiguous()
+    s["map_boundary"] = g("map/boundary").to(f32).contiguous()
+    s["tl_valid"] = g("history/tl_stop/valid")[:, :n_hist].to(u8).contiguous()
+    s["tl_state"] = _onehot_to_index(g("history/tl_stop/state")[:, :n_hist])
+    s["tl_pos"] = g("history/tl_stop/pos")[:, :n_hist].to(f32).contiguous()
+    s["tl_dir"] = g("history/tl_stop/dir")[:, :n_hist].to(f32).contiguous()
+    return s
+
+
+class HipEngine:
+    """One `tb_ctx` on one device."""
+
+    def __init__(self, cfg: Dict, device: str = "cuda:0") -> None:
+        if not torch.cuda.is_available():
+            raise RuntimeError("trafficbots_amd: no HIP device visible to PyTorch-ROCm (no CPU fallback)")
+        self.lib = hip.load()
+        self.cfg = cfg
+        self.device = torch.device(device)
+        torch.cuda.set_device(self.device)
+        self._ctx = C.c_void_p()
+        c = hip.make_config(cfg)
+        rc = self.lib.tb_create(C.byref(c), C.byref(self._ctx))
+        if rc != 0:
+            raise RuntimeError(f"tb_create failed ({rc})")
+        self.n_hist = cfg["time_step_current"] + 1
+        self._weights_loaded = False
+
+    def __del__(self):
+        try:
+            if getattr(self, "_ctx", None) and self._ctx.value:
+                self.lib.tb_destroy(self._ctx)
+                self._ctx = C.c_void_p()
+        except Exception:
+            pass
+
+    def _check(self, rc: int, what: str) -> None:
+        if rc != 0:
+            raise RuntimeError(f"{what} failed: {self.lib.tb_last_error(self._ctx).decode()}")
+
+    def _stream(self) -> C.c_void_p:
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    # -------------------------------------------------------------------------------- weights
+    def load_state_dict(self, state_dict: Dict) -> None:
+        """Reference-format `state_dict` (numpy or torch values, SURVEY Appendix B names)."""
+        for k, v in state_dict.items():
+            if isinstance(v, Tensor):
+                v = v.detach().cpu().numpy()
+            v = np.ascontiguousarray(v, dtype=np.float32)
+            self._check(
+                self.lib.tb_load_weight(self._ctx, k.encode(), v.ctypes.data_as(hip.c_f32p), v.size), f"tb_load_weight({k})"
+            )
+        self._check(self.lib.tb_finalize_weights(self._ctx, self._stream()), "tb_finalize_weights")
+        self._weights_loaded = True
+
+    # -------------------------------------------------------------------------------- encoders
+    def encode_scene(self, s: Dict[str, Tensor]) -> Dict[str, Tensor]:
+        b, nh, a = s["agent_valid"].shape
+        p = s["map_valid"].shape[1]
+        t = s["tl_valid"].shape[2]
+        dev, f32, u8 = self.device, torch.float32, torch.uint8
+        out = {
+            "map_feature": torch.empty(b, p, 128, device=dev, dtype=f32),
+            "map_feature_valid": torch.empty(b, p, device=dev, dtype=u8),
+            "agent_feature": torch.empty(b, nh, a, 128, device=dev, dtype=f32),
+            "tl_feature": torch.empty(b, nh, t, 128, device=dev, dtype=f32),
+            "latent_mean": torch.empty(b, a, 16, device=dev, dtype=f32),
+            "latent_valid": torch.empty(b, a, device=dev, dtype=u8),
+            "dest_logits": torch.empty(b, a, p, device=dev, dtype=f32),
+        }
+        io = hip.TbEncodeIO()
+        io.n_scene, io.n_agent, io.n_pl, io.n_tl, io.n_hist = b, a, p, t, nh
+        for name in ("agent_valid", "map_valid", "tl_valid"):
+            setattr(io, name, hip.ptr(s[name], hip.c_u8p))
+        for name in ("agent_pos", "agent_yaw", "agent_vel", "agent_spd", "agent_acc", "agent_yaw_rate", "agent_size",
+                     "map_pos", "map_dir", "tl_pos", "tl_dir"):
+            setattr(io, name, hip.ptr(s[name], hip.c_f32p))
+        for name in ("agent_type", "map_type", "tl_state"):
+            setattr(io, name, hip.ptr(s[name], hip.c_i32p))
+        for name in ("map_feature", "agent_feature", "tl_feature", "latent_mean", "dest_logits"):
+            setattr(io, name, hip.ptr(out[name], hip.c_f32p))
+        io.map_feature_valid = hip.ptr(out["map_feature_valid"], hip.c_u8p)
+        io.latent_valid = hip.ptr(out["latent_valid"], hip.c_u8p)
+        self._check(self.lib.tb_encode_scene(self._ctx, C.byref(io), self._stream()), "tb_encode_scene")
+        return out
+
+    # -------------------------------------------------------------------------------- rollout
+    def rollout(
+        self,
+        s: Dict[str, Tensor],
+        feats: Dict[str, Tensor],
+        latent_sample: Tensor,
+        latent_mean: Tensor,
+        dest: Tensor,
+        goal_valid: Tensor,
+        k_futures: int,
+        step_end: int,
+        mask_teacher_forcing: Optional[Tensor] = None,
+        tap_step: int = -1,
+        out: Optional[Dict[str, Tensor]] = None,
+    ) -> Dict[str, Tensor]:
+        """Closed-loop rollout of N = B*K instances (instance n uses scene n // K).  Returns the
+        `RolloutBuffer` fields as [N, A, S, ...] tensors (`buffer.py:72-90`)."""
+        b, nh, a = s["agent_valid"].shape
+        p = s["map_valid"].shape[1]
+        t = s["tl_valid"].shape[2]
+        n = b * k_futures
+        n_step = step_end - self.cfg["time_step_sim_start"] + 1
+        dev, f32, u8 = self.device, torch.float32, torch.uint8
+        if mask_teacher_forcing is None:
+            tf = self.cfg["teacher_forcing_joint_future_pred"]
+            mask_teacher_forcing = teacher_forcing_mask(
+                s["agent_valid"].bool(), tf.get("step_spawn_agent", 10), tf.get("step_warm_start", 10)
+            ).to(u8).contiguous()
+        if out is None:
+            out = {
+                "preds": torch.empty(n, a, n_step, 4, device=dev, dtype=f32),
+                "action_log_probs": torch.empty(n, a, n_step, device=dev, dtype=f32),
+                "latent_log_prob": torch.empty(n, a, device=dev, dtype=f32),
+                "final_state": torch.empty(n, a, 4, device=dev, dtype=f32),
+                "final_valid": torch.empty(n, a, device=dev, dtype=u8),
+                "final_hidden": torch.empty(3, n, a, 128, device=dev, dtype=f32),
+            }
+            for name in ("valid", "override_masks", "outside_map", "outside_map_this_step", "dest_reached",
+                         "dest_reached_this_step"):
+                out[name] = torch.empty(n, a, n_step, device=dev, dtype=u8)
+            if tap_step >= 0:
+                out["tap_policy_feature"] = torch.zeros(n, a, 128, device=dev, dtype=f32)
+                out["tap_agent_feature"] = torch.zeros(n, a, 128, device=dev, dtype=f32)
+        io = hip.TbRolloutIO()
+        io.n_scene, io.k_futures, io.n_agent, io.n_pl, io.n_tl, io.n_hist, io.step_end = b, k_futures, a, p, t, nh, step_end
+        io.map_feature = hip.ptr(feats["map_feature"], hip.c_f32p)
+        io.map_feature_valid = hip.ptr(feats["map_feature_valid"], hip.c_u8p)
+        io.tl_feature = hip.ptr(feats["tl_feature"], hip.c_f32p)
+        io.tl_feature_valid = hip.ptr(s["tl_valid"], hip.c_u8p)
+        io.agent_valid = hip.ptr(s["agent_valid"], hip.c_u8p)
+        io.agent_state = hip.ptr(s["agent_state"], hip.c_f32p)
+        io.agent_vel = hip.ptr(s["agent_vel"], hip.c_f32p)
+        io.agent_acc = hip.ptr(s["agent_acc"], hip.c_f32p)
+        io.agent_yaw_rate = hip.ptr(s["agent_yaw_rate"], hip.c_f32p)
+        io.mask_teacher_forcing = hip.ptr(mask_teacher_forcing, hip.c_u8p)
+        io.agent_type = hip.ptr(s["agent_type"], hip.c_i32p)
+        io.agent_size = hip.ptr(s["agent_size"], hip.c_f32p)
+        io.map_boundary = hip.ptr(s["map_boundary"], hip.c_f32p)
+        io.map_valid = hip.ptr(s["map_valid"], hip.c_u8p)
+        io.map_type = hip.ptr(s["map_type"], hip.c_i32p)
+        io.map_pos = hip.ptr(s["map_pos"], hip.c_f32p)
+        io.map_dir = hip.ptr(s["map_dir"], hip.c_f32p)
+        latent_sample = latent_sample.to(f32).contiguous()
+        latent_mean = latent_mean.to(f32).contiguous()
+        dest = dest.to(torch.int32).contiguous()
+        goal_valid = goal_valid.to(u8).contiguous()
+        assert latent_sample.shape == (n, a, 16) and dest.shape == (n, a) and goal_valid.shape == (n, a)
+        assert latent_mean.shape == (b, a, 16)
+        io.latent_sample = hip.ptr(latent_sample, hip.c_f32p)
+        io.latent_mean = hip.ptr(latent_mean, hip.c_f32p)
+        io.dest = hip.ptr(dest, hip.c_i32p)
+        io.goal_valid = hip.ptr(goal_valid, hip.c_u8p)
+        io.preds = hip.ptr(out["preds"], hip.c_f32p)
+        for name in ("valid", "override_masks", "outside_map", "outside_map_this_step", "dest_reached",
+                     "dest_reached_this_step"):
+            setattr(io, name, hip.ptr(out[name], hip.c_u8p))
+        io.action_log_probs = hip.ptr(out["action_log_probs"], hip.c_f32p)
+        io.latent_log_prob = hip.ptr(out["latent_log_prob"], hip.c_f32p)
+        io.final_state = hip.ptr(out.get("final_state"), hip.c_f32p)
+        io.final_valid = hip.ptr(out.get("final_valid"), hip.c_u8p)
+        io.final_hidden = hip.ptr(out.get("final_hidden"), hip.c_f32p)
+        io.tap_step = tap_step
+        io.tap_policy_feature = hip.ptr(out.get("tap_policy_feature"), hip.c_f32p)
+        io.tap_agent_feature = hip.ptr(out.get("tap_agent_feature"), hip.c_f32p)
+        self._check(self.lib.tb_rollout(self._ctx, C.byref(io), self._stream()), "tb_rollout")
+        # keep the borrowed inputs alive until the stream work is done
+        out["_keepalive"] = (latent_sample, latent_mean, dest, goal_valid, mask_teacher_forcing)
+        return out
+
+    # -------------------------------------------------------------------------------- timing
+    def set_timing(self, enable: bool) -> None:
+        self._check(self.lib.tb_set_timing(self._ctx, int(enable)), "tb_set_timing")
+
+    def get_timing(self) -> Dict[str, float]:
+        buf = (C.c_float * 4)()
+        self._check(self.lib.tb_get_timing(self._ctx, buf), "tb_get_timing")
+        return {"step_a_ms": buf[0], "step_c_ms": buf[1], "prologue_ms": buf[2], "n_steps": int(buf[3])}
