@@ -1,0 +1,175 @@
+"""Headline benchmark: closed-loop rollout throughput (scene-steps/s) on BASELINE.json configs[1]
+(B=32 scenes x 64 agents x 256 polylines, 90 executed steps = 10 teacher-forced + 80 free, fp32),
+scene-parallel over N GPUs (one process per GPU, one RCCL all-reduce of metric partials per pass).
+
+One "step" of this bench = one pass of the hot path (tb_rollout: K/V hoists + the 90-step closed loop) over
+one batch of 32 synthetic scenes per GPU whose encoded features are already resident in HBM; the one-time
+scene encoders are timed separately (`encode_ms`).  Prints ONE JSON line (rank 0).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from trafficbots_amd import synth  # noqa: E402
+from trafficbots_amd.config import load_model_config  # noqa: E402
+
+B_PER_GPU, N_AGENT, N_PL, N_TL, STEP_END = 32, 64, 256, 40, 90
+H = 128
+PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak
+
+
+def flops_step_a(a, p, t):  # SURVEY 8(d) split: as2pl + as2tl + interaction K/V projections + agent encoder
+    return 60 * a * H * H + 12 * a * H * (p + t) + 2 * a * (11 * 32 + 32 * 32)
+
+
+def flops_step_c(a):  # interaction attention/FFN + GRU + add_goal + add_latent + one action-head branch
+    return 74 * a * H * H + 12 * a * H * a + 4 * a * H
+
+
+def cpu_baseline(cfg, sd, budget_s=20.0):
+    """The oracle (CPU port of the reference path, un-hoisted = the reference's op sequence) on a bounded sample."""
+    from oracle.trafficbots_oracle import Oracle
+
+    n_threads = os.cpu_count() or 1
+    torch.set_num_threads(n_threads)
+    b = 8
+    batch = synth.make_batch(5000, b, n_agent=N_AGENT, n_pl=N_PL, n_tl=N_TL)
+    orc = Oracle(sd, cfg, torch.float32, hoist=False)
+    with torch.no_grad():
+        inp = orc.preprocess(batch)
+        f = orc.encode_scene(inp)
+        mean, _, _ = orc.latent_prior(f)
+        dest = orc.dest_logits(f, inp).argmax(-1)
+        gv = inp["agent_valid"].any(1)
+        orc.rollout(inp, f, mean, mean, dest, gv, 1, 12)  # warm-up (12 steps)
+        times = []
+        t_begin = time.time()
+        while len(times) < 3 and (time.time() - t_begin) < budget_s:
+            t0 = time.time()
+            orc.rollout(inp, f, mean, mean, dest, gv, 1, STEP_END)
+            times.append(time.time() - t0)
+    best = min(times)
+    return {
+        "value": b * STEP_END / best, "unit": "scene-steps/s", "cores": int(torch.get_num_threads()), "kind": "port",
+        "sample": f"oracle rollout (reference op sequence, PyTorch-CPU fp32) of {b} scenes x {N_AGENT} agents x {N_PL} polylines x "
+                  f"{STEP_END} steps, best of {len(times)} ({best:.2f} s)",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    from trafficbots_amd.runtime import HipEngine, scene_from_batch
+
+    cfg = load_model_config(overrides={"time_step_end": STEP_END, "n_joint_future": 1})
+    sd = synth.make_state_dict(7)
+    eng = HipEngine(cfg, f"cuda:{local_rank}")
+    eng.load_state_dict(sd)
+    # this rank's shard of the global batch: scenes [rank*32, rank*32+32) of the seeded stream (configs[2] layout)
+    batch = synth.make_batch(5000, B_PER_GPU, scene_offset=rank * B_PER_GPU, n_agent=N_AGENT, n_pl=N_PL, n_tl=N_TL)
+    scene = scene_from_batch(batch, dev)
+
+    # ---- one-time encoders (timed separately)
+    enc = eng.encode_scene(scene)
+    torch.cuda.synchronize()
+    t0 = time.time()
+    enc = eng.encode_scene(scene)
+    torch.cuda.synchronize()
+    encode_ms = (time.time() - t0) * 1e3
+    feats = {"map_feature": enc["map_feature"], "map_feature_valid": enc["map_feature_valid"], "tl_feature": enc["tl_feature"]}
+    z = enc["latent_mean"].clone()  # deterministic personality (K = 1)
+    dest = enc["dest_logits"].argmax(-1).to(torch.int32)
+    gv = scene["agent_valid"].bool().any(1).to(torch.uint8)
+
+    out = None
+    eng.set_timing(True)  # hipEventRecord markers around the per-step kernels (no host sync)
+    for _ in range(args.warmup):
+        out = eng.rollout(scene, feats, z, enc["latent_mean"], dest, gv, 1, STEP_END, out=out)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ka = kc = 0.0
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = eng.rollout(scene, feats, z, enc["latent_mean"], dest, gv, 1, STEP_END, out=out)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    tm = eng.get_timing()  # HIP-event durations of the LAST pass of the timed region
+    ka, kc = tm["step_a_ms"] / tm["n_steps"], tm["step_c_ms"] / tm["n_steps"]
+
+    # ---- metric partials + the one collective of the path (torchmetrics dist_reduce_fx="sum" states in the reference)
+    from trafficbots_amd.shard import all_reduce_partials, metric_partials
+
+    part = metric_partials(out["preds"], out["valid"], out["outside_map"], out["dest_reached"], B_PER_GPU, STEP_END)
+    red, elapsed = all_reduce_partials(part, elapsed)
+    finite = bool(torch.isfinite(out["preds"]).all())
+
+    if rank == 0:
+        total_scene_steps = world * B_PER_GPU * STEP_END * args.steps
+        value = total_scene_steps / elapsed
+        n_inst = B_PER_GPU
+        fa, fc = flops_step_a(N_AGENT, N_PL, N_TL) * n_inst, flops_step_c(N_AGENT) * n_inst
+        dom, dur_ms, fl = ("k_step_a", ka, fa) if ka >= kc else ("k_step_c", kc, fc)
+        achieved = fl / (dur_ms * 1e-3) / 1e12
+        line = {
+            "metric": "rollout scene-steps/sec (64 agents, 90 executed = 10 teacher-forced + 80 free steps)",
+            "value": value, "unit": "scene-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE.json configs[1]: 32 synthetic WOMD-shaped scenes per GPU, 64 agents, 256 polylines, "
+                                   "40 TL stop points, K=1, 90-step closed-loop rollout, fp32, random-init weights",
+                       "scenes_per_gpu": B_PER_GPU, "n_agent": N_AGENT, "n_pl": N_PL, "n_tl": N_TL, "sim_steps": STEP_END,
+                       "parallelism": f"scene-parallel x{world}"},
+            "agent_steps_per_s": value * N_AGENT,
+            "encode_ms": encode_ms,
+            "kernel_us": {"k_step_a": ka * 1e3, "k_step_c": kc * 1e3, "prologue_ms": tm["prologue_ms"]},
+            "roofline": {"bound": "mfma", "kernel": dom, "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                         "flops_per_launch": fl, "avg_launch_us": dur_ms * 1e3,
+                         "other": {"kernel": "k_step_c" if dom == "k_step_a" else "k_step_a",
+                                   "achieved": (fc if dom == "k_step_a" else fa) / ((kc if dom == "k_step_a" else ka) * 1e-3) / 1e12}},
+            "checks": dict(finite=finite, **red),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(cfg, sd)
+            line["gpu_over_cpu"] = value / line["cpu_baseline"]["value"]
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,40 @@
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def load_golden(name):
+    g = np.load(os.path.join(GOLDEN_DIR, f"{name}.npz"))
+    meta = json.loads(bytes(g["meta_json"]).decode())
+    return g, meta
+
+
+def golden_inputs(meta):
+    """Regenerate the exact inputs / weights / latent noise of a golden case from its seeds."""
+    from trafficbots_amd import synth
+    from trafficbots_amd.config import load_model_config
+
+    cfg = load_model_config(overrides={"time_step_end": meta["time_step_end"], "n_joint_future": meta["k"]})
+    sd = synth.make_state_dict(meta["weight_seed"])
+    batch = synth.make_batch(meta["base_seed"], meta["n_scene"], **meta["scene"])
+    n = meta["n_scene"] * meta["k"]
+    eps = synth.make_latent_noise(meta["base_seed"] + 99, n, meta["scene"]["n_agent"])
+    return cfg, sd, batch, eps
+
+
+@pytest.fixture(scope="session")
+def golden_names():
+    return ["c1_plumbing", "small_k1", "masks_k3", "degenerate", "headline_2", "headline_k6"]

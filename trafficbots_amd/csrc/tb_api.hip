@@ -9,8 +9,7 @@
 #include <vector>
 
 #include "../../include/trafficbots_hip.h"
-#include "tb_encode.hpp"
-#include "tb_rollout.hpp"
+#include "tb_internal.hpp"
 
 namespace tb {
 size_t step_lds_bytes();
@@ -21,40 +20,6 @@ void launch_step_a(const RolloutP& p, int t, hipStream_t s);
 void launch_step_c(const RolloutP& p, int t, hipStream_t s);
 int run_encode(struct ::tb_ctx* ctx, const tb_encode_io* io, hipStream_t s);
 }  // namespace tb
-
-struct tb_ctx {
-    tb_config cfg;
-    std::string err;
-    std::map<std::string, std::vector<float>> staged;
-    float* d_arena = nullptr;
-    size_t arena_floats = 0;
-    tb::PolicyW pw;
-    tb::EncoderW ew;
-    bool finalized = false;
-    // workspace
-    char* d_ws = nullptr;
-    size_t ws_bytes = 0;
-    // timing
-    bool timing = false;
-    std::vector<hipEvent_t> ev;
-    int n_timed_steps = 0;
-};
-
-static int fail(tb_ctx* ctx, const char* fmt, ...) {
-    char buf[512];
-    va_list ap;
-    va_start(ap, fmt);
-    vsnprintf(buf, sizeof(buf), fmt, ap);
-    va_end(ap);
-    if (ctx) ctx->err = buf;
-    return 1;
-}
-
-#define TB_HIP(ctx, call)                                                                  \
-    do {                                                                                   \
-        hipError_t e_ = (call);                                                            \
-        if (e_ != hipSuccess) return fail(ctx, "%s failed: %s", #call, hipGetErrorString(e_)); \
-    } while (0)
 
 // ---------------------------------------------------------------------------------------------------
 // weight arena builder
@@ -93,12 +58,12 @@ struct Stage {
     const std::vector<float>* get(const std::string& name, size_t numel) {
         auto it = ctx->staged.find(name);
         if (it == ctx->staged.end()) {
-            if (ok) fail(ctx, "weight '%s' was not loaded", name.c_str());
+            if (ok) tb_fail(ctx, "weight '%s' was not loaded", name.c_str());
             ok = false;
             return nullptr;
         }
         if (it->second.size() != numel) {
-            if (ok) fail(ctx, "weight '%s': expected %zu elements, got %zu", name.c_str(), numel, it->second.size());
+            if (ok) tb_fail(ctx, "weight '%s': expected %zu elements, got %zu", name.c_str(), numel, it->second.size());
             ok = false;
             return nullptr;
         }
@@ -200,7 +165,7 @@ void tb_destroy(tb_ctx* ctx) {
 const char* tb_last_error(tb_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 
 int tb_load_weight(tb_ctx* ctx, const char* name, const float* host_data, int64_t numel) {
-    if (!ctx || !name || !host_data || numel <= 0) return fail(ctx, "tb_load_weight: bad argument");
+    if (!ctx || !name || !host_data || numel <= 0) return tb_fail(ctx, "tb_load_weight: bad argument");
     ctx->staged[name] = std::vector<float>(host_data, host_data + numel);
     ctx->finalized = false;
     return 0;
@@ -349,18 +314,6 @@ int tb_get_timing(tb_ctx* ctx, float* out4) {
 // ---------------------------------------------------------------------------------------------------
 // workspace
 // ---------------------------------------------------------------------------------------------------
-struct Carver {
-    char* base;
-    size_t off = 0;
-    template <typename T>
-    T* take(size_t n) {
-        off = (off + 255) & ~(size_t)255;
-        T* p = base ? reinterpret_cast<T*>(base + off) : nullptr;
-        off += n * sizeof(T);
-        return p;
-    }
-};
-
 int tb_ensure_workspace(tb_ctx* ctx, size_t bytes) {
     if (bytes <= ctx->ws_bytes) return 0;
     if (ctx->d_ws) {
@@ -374,8 +327,6 @@ int tb_ensure_workspace(tb_ctx* ctx, size_t bytes) {
     ctx->ws_bytes = bytes;
     return 0;
 }
-
-static inline int pad16(int x) { return (x + 15) / 16 * 16; }
 
 static void carve_rollout(tb::RolloutP& p, Carver& c) {
     const size_t B = p.n_scene, N = p.n_inst, NH = p.n_hist;
@@ -402,16 +353,16 @@ static void carve_rollout(tb::RolloutP& p, Carver& c) {
 
 extern "C" int tb_rollout(tb_ctx* ctx, const tb_rollout_io* io, tb_stream stream_) {
     if (!ctx || !io) return 1;
-    if (!ctx->finalized) return fail(ctx, "tb_rollout: weights not finalized");
+    if (!ctx->finalized) return tb_fail(ctx, "tb_rollout: weights not finalized");
     hipStream_t s = (hipStream_t)stream_;
     if (io->n_scene <= 0 || io->k_futures <= 0 || io->n_agent <= 0 || io->n_pl <= 0 || io->n_tl <= 0)
-        return fail(ctx, "tb_rollout: empty dimension (B=%d K=%d A=%d P=%d T=%d)", io->n_scene, io->k_futures, io->n_agent,
+        return tb_fail(ctx, "tb_rollout: empty dimension (B=%d K=%d A=%d P=%d T=%d)", io->n_scene, io->k_futures, io->n_agent,
                     io->n_pl, io->n_tl);
-    if (io->n_agent > 256) return fail(ctx, "tb_rollout: n_agent %d > 256 not supported", io->n_agent);
+    if (io->n_agent > 256) return tb_fail(ctx, "tb_rollout: n_agent %d > 256 not supported", io->n_agent);
     if (io->n_hist != ctx->cfg.time_step_current + 1)
-        return fail(ctx, "tb_rollout: n_hist %d != time_step_current+1", io->n_hist);
+        return tb_fail(ctx, "tb_rollout: n_hist %d != time_step_current+1", io->n_hist);
     const int step_start = ctx->cfg.time_step_sim_start;
-    if (io->step_end < step_start) return fail(ctx, "tb_rollout: step_end < time_step_sim_start");
+    if (io->step_end < step_start) return tb_fail(ctx, "tb_rollout: step_end < time_step_sim_start");
     tb::RolloutP p;
     memset(&p, 0, sizeof(p));
     p.W = ctx->d_arena;
@@ -465,7 +416,7 @@ extern "C" int tb_rollout(tb_ctx* ctx, const tb_rollout_io* io, tb_stream stream
                               p.preds, p.o_valid, p.o_override, p.o_outside, p.o_outside_this, p.o_dest_reached,
                               p.o_dest_reached_this, p.o_action_logp, p.o_latent_logp};
     for (const void* q : required)
-        if (!q) return fail(ctx, "tb_rollout: a required buffer pointer is NULL");
+        if (!q) return tb_fail(ctx, "tb_rollout: a required buffer pointer is NULL");
 
     Carver sizing{nullptr};
     carve_rollout(p, sizing);
@@ -524,6 +475,6 @@ extern "C" int tb_rollout(tb_ctx* ctx, const tb_rollout_io* io, tb_stream stream
 
 extern "C" int tb_encode_scene(tb_ctx* ctx, const tb_encode_io* io, tb_stream stream) {
     if (!ctx || !io) return 1;
-    if (!ctx->finalized) return fail(ctx, "tb_encode_scene: weights not finalized");
+    if (!ctx->finalized) return tb_fail(ctx, "tb_encode_scene: weights not finalized");
     return tb::run_encode(ctx, io, (hipStream_t)stream);
 }

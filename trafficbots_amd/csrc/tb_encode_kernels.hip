@@ -1,6 +1,621 @@
-#include "../../include/trafficbots_hip.h"
-#include "tb_encode.hpp"
-struct tb_ctx;
+// One-time scene encoders on the GPU (tb_encode_scene):
+//   input features  : SceneCentricInput + InputPeEncoder for agent history, TL stop points and map nodes
+//   map encoder     : 3-layer transformer over the 20 nodes of each polyline (tgt = original node features),
+//                     masked max-pool, 1-layer self-attention over polylines           (map_encoder.py:72-114)
+//   personality prior: as2pl / as2tl / interaction_prior over history steps {0,5,10}, 3-step GRU scan, masked
+//                     max over time, MLP -> mean                                         (latent_encoder.py:98-147)
+//   destination predictor: 11-step GRU scan + residual, last-valid, pairwise MLP over (agent, polyline)
+//                                                                                        (goal_manager.py:229-333)
+// All of it is composed from the same 16-row-tile device functions as the rollout step kernels.
+#include "tb_internal.hpp"
+
 namespace tb {
-int run_encode(struct ::tb_ctx* ctx, const tb_encode_io* io, hipStream_t s) { return 77; }
+
+void launch_kv_hoist_n(const float* W, const XLayerW* L, int n_layer, const float* feat, const uint8_t* fvalid, int G,
+                       int n_tok, int n_pad, float* K, float* VT, uint8_t* kvalid, hipStream_t s);
+
+// ------------------------------------------------------------------------------------------------
+// token feature encoder: attr + pose PE -> MLP(attr,32,32) || PE(96)
+// ------------------------------------------------------------------------------------------------
+struct TokP {
+    const float* W;
+    EncMlpW mlp;
+    uint32_t pe_fxy, pe_fyaw;
+    int kind;     // 0 agent history, 1 traffic light, 2 map node
+    int n_tok;    // total tokens
+    int per_scene;  // tokens per scene (NH*A, NH*T, P*20)
+    int inner;      // A, T or 20
+    const uint8_t* valid;
+    const float* pos;   // [n_tok][2]
+    const float* yaw;   // agent: [n_tok]
+    const float* dir;   // tl / map: [n_tok][2]
+    // agent attributes
+    const float* vel; const float* spd; const float* acc; const float* yaw_rate;
+    const int32_t* cls;   // agent: type [B][A]; tl: state [n_tok]; map: type [B][P]
+    const float* size;    // [B][A][3]
+    float* out;           // [n_tok][128]
+};
+
+__global__ __launch_bounds__(NTHREADS) void k_encode_tokens(TokP p) {
+    __shared__ __attribute__((aligned(16))) float attr[TM][32];
+    __shared__ __attribute__((aligned(16))) float hid[TM][32];
+    __shared__ __attribute__((aligned(16))) float outt[TM][LDT];
+    __shared__ float pose[TM][4];
+    __shared__ uint8_t rv[TM];
+    const int tid = threadIdx.x;
+    const int tok0 = blockIdx.x * TM;
+    const int attr_dim = p.kind == 0 ? 11 : (p.kind == 1 ? 5 : 31);
+    if (tid < TM) {
+        const int tk = tok0 + tid;
+        float* a = attr[tid];
+        for (int k = 0; k < 32; ++k) a[k] = 0.f;
+        float x = 0.f, y = 0.f, yw = 0.f;
+        uint8_t v = 0;
+        if (tk < p.n_tok) {
+            v = p.valid[tk];
+            x = p.pos[(size_t)tk * 2];
+            y = p.pos[(size_t)tk * 2 + 1];
+            const int b = tk / p.per_scene, r = tk % p.inner;
+            if (p.kind == 0) {
+                yw = p.yaw[tk];
+                const int A = p.inner;
+                a[0] = p.vel[(size_t)tk * 2]; a[1] = p.vel[(size_t)tk * 2 + 1]; a[2] = p.spd[tk];
+                a[3] = p.yaw_rate[tk]; a[4] = p.acc[tk];
+                const float* sz = p.size + ((size_t)b * A + r) * 3;
+                a[5] = sz[0]; a[6] = sz[1]; a[7] = sz[2];
+                const int ty = p.cls[(size_t)b * A + r];
+                if (ty >= 0 && ty < 3) a[8 + ty] = 1.f;
+            } else {
+                yw = (float)atan2((double)p.dir[(size_t)tk * 2 + 1], (double)p.dir[(size_t)tk * 2]);  // pose_pe.py:61
+                if (p.kind == 1) {
+                    const int st = p.cls[tk];
+                    if (st >= 0 && st < 5) a[st] = 1.f;
+                } else {
+                    const int pl = tk / 20;  // global polyline index
+                    const int ty = p.cls[pl];
+                    if (ty >= 0 && ty < 11) a[ty] = 1.f;
+                    a[11 + r] = 1.f;  // node one-hot (sc_input.py:127-133)
+                }
+            }
+        }
+        pose[tid][0] = x; pose[tid][1] = y; pose[tid][2] = yw;
+        rv[tid] = v;
+    }
+    __syncthreads();
+    {
+        const int row = tid >> 4, i = tid & 15;
+        const float px = pose[row][0], py = pose[row][1], pyaw = pose[row][2];
+        float* xr = outt[row] + 32;
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            const int j = i * 3 + u;
+            float arg;
+            int c_cos, c_sin;
+            if (j < 12) {
+                arg = px * p.W[p.pe_fxy + j]; c_cos = j; c_sin = 12 + j;
+            } else if (j < 24) {
+                arg = py * p.W[p.pe_fxy + j - 12]; c_cos = 24 + (j - 12); c_sin = 36 + (j - 12);
+            } else {
+                arg = pyaw * p.W[p.pe_fyaw + j - 24]; c_cos = 48 + (j - 24); c_sin = 72 + (j - 24);
+            }
+            // fp64 sin/cos of the fp32 argument, rounded once: within 0.5 ulp of exact, i.e. as close as
+            // possible to whatever libm the reference's host uses (48 per agent, negligible)
+            double sv, cv;
+            sincos((double)arg, &sv, &cv);
+            xr[c_cos] = (float)cv;
+            xr[c_sin] = (float)sv;
+        }
+        const int o0 = i * 2;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int o = o0 + u;
+            float s = p.W[p.mlp.b1 + o];
+            for (int k = 0; k < attr_dim; ++k) s = fmaf(attr[row][k], p.W[p.mlp.w1 + o * attr_dim + k], s);
+            hid[row][o] = fmaxf(s, 0.f);
+        }
+    }
+    __syncthreads();
+    {
+        const int row = tid >> 4, o0 = (tid & 15) * 2;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int o = o0 + u;
+            float s = p.W[p.mlp.b2 + o];
+            for (int k = 0; k < 32; ++k) s = fmaf(hid[row][k], p.W[p.mlp.w2 + o * 32 + k], s);
+            outt[row][o] = s;
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < TM * 32; i += NTHREADS) {
+        const int r = i >> 5, c4 = (i & 31) * 4;
+        if (tok0 + r < p.n_tok) st4(p.out + (size_t)(tok0 + r) * H + c4, rv[r] ? lds4(&outt[r][c4]) : splat(0.f));
+    }
 }
+
+// ------------------------------------------------------------------------------------------------
+// generic cross-attention block over groups: n_layer x xattn_layer on 16-row tiles
+// ------------------------------------------------------------------------------------------------
+struct XBlockP {
+    const float* W;
+    XLayerW L[3];
+    int n_layer;
+    const float* src;          // [G][n_rows][128]
+    const uint8_t* src_valid;  // [G][n_rows]
+    float* dst;                // [G][n_rows][128]
+    const float* K;            // [G][n_layer][n_pad][128]
+    const float* VT;           // [G][n_layer][128][n_pad]
+    const uint8_t* kvalid;     // [G][n_pad]
+    int n_rows, n_pad;
+    int eye;                   // MultiAgentTF: self key masked; groups with exactly one valid row pass through
+};
+
+__global__ __launch_bounds__(NTHREADS) void k_xattn_block(XBlockP p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* X = smem;
+    float* S1 = X + TM * LDT;
+    float* S2 = S1 + TM * LDT;
+    uint8_t* rowvalid = reinterpret_cast<uint8_t*>(S2 + TM * LDT);
+    uint8_t* novalid_s = rowvalid + 16;
+    const int tid = threadIdx.x, g = blockIdx.y, row0 = blockIdx.x * TM;
+    const int n_real = min(TM, p.n_rows - row0);
+    load_tile(X, LDT, p.src + ((size_t)g * p.n_rows + row0) * H, n_real, tid);
+    if (tid < TM) rowvalid[tid] = tid < n_real ? p.src_valid[(size_t)g * p.n_rows + row0 + tid] : 0;
+    bool bypass = false;
+    if (p.eye) {
+        const int cnt = __syncthreads_count(tid < p.n_rows && p.src_valid[(size_t)g * p.n_rows + tid]);
+        bypass = cnt == 1;
+    } else {
+        __syncthreads();
+    }
+    if (!bypass) {
+#pragma unroll 1
+        for (int l = 0; l < p.n_layer; ++l) {
+            xattn_layer(p.W, p.L[l], X, S1, S2, p.K + ((size_t)g * p.n_layer + l) * p.n_pad * H,
+                        p.VT + ((size_t)g * p.n_layer + l) * H * p.n_pad, p.kvalid + (size_t)g * p.n_pad, p.n_pad,
+                        p.eye ? row0 : -1, rowvalid, novalid_s, tid);
+        }
+    }
+    store_tile(p.dst + ((size_t)g * p.n_rows + row0) * H, X, LDT, n_real, tid);
+}
+
+// K/V hoist for 1..3 layers (same as rollout's k_kv_hoist but with a layer count)
+__global__ __launch_bounds__(NTHREADS) void k_kv_hoist_n(const float* __restrict__ W, XLayerW l0, XLayerW l1, XLayerW l2, int n_layer,
+                                                        const float* __restrict__ feat, const uint8_t* __restrict__ fvalid, int n_tok,
+                                                        int n_pad, float* __restrict__ Kout, float* __restrict__ VTout,
+                                                        uint8_t* __restrict__ kvalid) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* T = smem;
+    float* S1 = smem + TM * LDT;
+    const int tid = threadIdx.x, g = blockIdx.y, tok0 = blockIdx.x * TM;
+    const int n_real = max(0, min(TM, n_tok - tok0));
+    load_tile(T, LDT, feat + ((size_t)g * n_tok + tok0) * H, n_real, tid);
+    if (tid < TM) kvalid[(size_t)g * n_pad + tok0 + tid] = (tid < n_real) ? fvalid[(size_t)g * n_tok + tok0 + tid] : 0;
+    __syncthreads();
+    const XLayerW* Ls[3] = {&l0, &l1, &l2};
+    for (int l = 0; l < n_layer; ++l) {
+        kv_project_tile(W, *Ls[l], T, S1, Kout + ((size_t)g * n_layer + l) * n_pad * H, VTout + ((size_t)g * n_layer + l) * H * n_pad,
+                        n_pad, tok0, n_real, tid);
+    }
+}
+
+void launch_kv_hoist_n(const float* W, const XLayerW* L, int n_layer, const float* feat, const uint8_t* fvalid, int G, int n_tok,
+                       int n_pad, float* K, float* VT, uint8_t* kvalid, hipStream_t s) {
+    dim3 grid(n_pad / TM, G);
+    hipLaunchKernelGGL(k_kv_hoist_n, grid, dim3(NTHREADS), 2 * TM * LDT * sizeof(float), s, W, L[0], L[n_layer > 1 ? 1 : 0],
+                       L[n_layer > 2 ? 2 : 0], n_layer, feat, fvalid, n_tok, n_pad, K, VT, kvalid);
+}
+
+// ------------------------------------------------------------------------------------------------
+// masked max-pool over the nodes of each polyline (map_encoder.py:95-106): one thread per (polyline, 4 features)
+// ------------------------------------------------------------------------------------------------
+__global__ void k_pool_nodes(const float* __restrict__ x /*[n_pl][20][128]*/, const uint8_t* __restrict__ v /*[n_pl][20]*/,
+                             int n_pl, float* __restrict__ out /*[n_pl][128]*/, uint8_t* __restrict__ out_valid) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int pl = idx >> 5, c4 = (idx & 31) * 4;
+    if (pl >= n_pl) return;
+    f32x4 m = splat(-INFINITY);
+    bool any = false;
+    for (int k = 0; k < 20; ++k) {
+        if (!v[(size_t)pl * 20 + k]) continue;
+        any = true;
+        const f32x4 a = ldg4(x + ((size_t)pl * 20 + k) * H + c4);
+        m = f32x4{fmaxf(m.x, a.x), fmaxf(m.y, a.y), fmaxf(m.z, a.z), fmaxf(m.w, a.w)};
+    }
+    st4(out + (size_t)pl * H + c4, any ? m : splat(0.f));
+    if (c4 == 0) out_valid[pl] = any;
+}
+
+// gather history steps {0, stride, 2*stride, ..} : dst[b][s'][r][C] = src[b][s'*stride][r][C]
+__global__ void k_gather_steps_f(const float* __restrict__ src, float* __restrict__ dst, int B, int S, int S2, int stride, int RC4) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t total = (size_t)B * S2 * RC4;
+    if (idx >= total) return;
+    const int c = idx % RC4;
+    const int s2 = (idx / RC4) % S2;
+    const int b = idx / ((size_t)RC4 * S2);
+    st4(dst + idx * 4, ldg4(src + (((size_t)b * S + (size_t)s2 * stride) * RC4 + c) * 4));
+}
+__global__ void k_gather_steps_u8(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, int B, int S, int S2, int stride, int R) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t total = (size_t)B * S2 * R;
+    if (idx >= total) return;
+    const int r = idx % R;
+    const int s2 = (idx / R) % S2;
+    const int b = idx / ((size_t)R * S2);
+    dst[idx] = src[((size_t)b * S + (size_t)s2 * stride) * R + r];
+}
+
+// ------------------------------------------------------------------------------------------------
+// GRU scan over S steps for 16-agent tiles (agent_temporal.py:133-146) with fused temporal aggregate
+//   mode 0: masked max over time (fill -1e3), then latent mean head  (agent_temporal.py:28-29, latent_encoder.py:194-198)
+//   mode 1: + residual, last valid step                              (goal_manager.py:295-300, agent_temporal.py:30-33)
+// ------------------------------------------------------------------------------------------------
+struct ScanP {
+    const float* W;
+    GruLayerW gru[3];
+    uint32_t head_w1, head_b1, head_w2, head_b2;  // mode 0
+    int mode, B, S, A;
+    const float* x;        // [B][S][A][128]
+    const uint8_t* valid;  // [B][S][A]
+    float* out_feat;       // mode 1: [B][A][128]
+    float* out_mean;       // mode 0: [B][A][16]
+    uint8_t* out_valid;    // [B][A]
+};
+
+__global__ __launch_bounds__(NTHREADS) void k_gru_scan(ScanP p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* X = smem;                 // step input
+    float* Y0 = X + TM * LDT;
+    float* Y1 = Y0 + TM * LDT;
+    float* HS = Y1 + TM * LDT;       // 3 hidden tiles [3][16][LDT]
+    float* AGG = HS + 3 * TM * LDT;  // aggregate
+    uint8_t* rowvalid = reinterpret_cast<uint8_t*>(AGG + TM * LDT);
+    uint8_t* anyvalid = rowvalid + 16;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, kq = lane >> 4, m = lane & 15;
+    const int b = blockIdx.y, row0 = blockIdx.x * TM;
+    const int n_real = min(TM, p.A - row0);
+    for (int i = tid; i < 3 * TM * LDT; i += NTHREADS) HS[i] = 0.f;
+    for (int i = tid; i < TM * LDT; i += NTHREADS) AGG[i] = p.mode == 0 ? -INFINITY : 0.f;
+    if (tid < TM) anyvalid[tid] = 0;
+    __syncthreads();
+    float* scratch_g = nullptr;
+    for (int s = 0; s < p.S; ++s) {
+        load_tile(X, LDT, p.x + (((size_t)b * p.S + s) * p.A + row0) * H, n_real, tid);
+        if (tid < TM) {
+            const uint8_t v = tid < n_real ? p.valid[((size_t)b * p.S + s) * p.A + row0 + tid] : 0;
+            rowvalid[tid] = v;
+            if (v) anyvalid[tid] = 1;
+        }
+        __syncthreads();
+        // three layers; each layer's new hidden replaces HS[l] (copy after the layer's barrier)
+        float* in = X;
+        float* outs[3] = {Y0, Y1, Y0};
+        for (int l = 0; l < 3; ++l) {
+            float* hs = HS + l * TM * LDT;
+            // gru_layer writes hidden to a global pointer too; route that to a dummy by n_real_rows = 0
+            gru_layer(p.W, p.gru[l], in, hs, outs[l], rowvalid, scratch_g, 0, tid);
+            for (int i = tid; i < TM * 32; i += NTHREADS) {
+                const int r = i >> 5, c4 = (i & 31) * 4;
+                st4(hs + r * LDT + c4, lds4(outs[l] + r * LDT + c4));
+            }
+            __syncthreads();
+            in = outs[l];
+        }
+        // aggregate (outputs of invalid rows are already zero; hidden reset to zero likewise)
+        for (int i = tid; i < TM * 32; i += NTHREADS) {
+            const int r = i >> 5, c4 = (i & 31) * 4;
+            if (p.mode == 0) {
+                // x.masked_fill(~valid, -1e3).amax(1)
+                const f32x4 o = rowvalid[r] ? lds4(in + r * LDT + c4) : splat(-1e3f);
+                const f32x4 a = lds4(AGG + r * LDT + c4);
+                st4(AGG + r * LDT + c4, f32x4{fmaxf(a.x, o.x), fmaxf(a.y, o.y), fmaxf(a.z, o.z), fmaxf(a.w, o.w)});
+            } else if (rowvalid[r]) {
+                st4(AGG + r * LDT + c4, lds4(in + r * LDT + c4) + lds4(X + r * LDT + c4));
+            }
+        }
+        __syncthreads();
+    }
+    // rows that were never valid -> 0
+    for (int i = tid; i < TM * 32; i += NTHREADS) {
+        const int r = i >> 5, c4 = (i & 31) * 4;
+        if (!anyvalid[r]) st4(AGG + r * LDT + c4, splat(0.f));
+    }
+    __syncthreads();
+    if (tid < n_real) p.out_valid[(size_t)b * p.A + row0 + tid] = anyvalid[tid];
+    if (p.mode == 1) {
+        store_tile(p.out_feat + ((size_t)b * p.A + row0) * H, AGG, LDT, n_real, tid);
+        return;
+    }
+    // latent mean = W2 relu(W1 agg + b1) + b2, masked (latent_encoder.py:168-178; MLP mask, mlp.py:80-82)
+    {
+        f32x4 acc[2];
+        linear128<128>(acc, p.W + p.head_w1, p.W + p.head_b1, AGG + m * LDT + kq * 32, wave, lane);
+        st4(cptr(Y0, LDT, 2 * wave, lane), relu4(acc[0]));
+        st4(cptr(Y0, LDT, 2 * wave + 1, lane), relu4(acc[1]));
+    }
+    __syncthreads();
+    {
+        const int r = tid >> 4, o = tid & 15;
+        float s = p.W[p.head_b2 + o];
+        const float* w2 = p.W + p.head_w2 + o * H;
+        for (int k = 0; k < H; ++k) s = fmaf(Y0[r * LDT + k], w2[k], s);
+        if (r < n_real) p.out_mean[((size_t)b * p.A + row0 + r) * 16 + o] = anyvalid[r] ? s : 0.f;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// rows x Linear(128->128) (+ optional bias): out = x W^T + b        grid = ceil(n_rows/16)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(NTHREADS) void k_linear_rows(const float* __restrict__ W, uint32_t w, uint32_t bias, int has_bias,
+                                                         const float* __restrict__ x, int n_rows, float* __restrict__ out) {
+    __shared__ __attribute__((aligned(16))) float X[TM * LDT];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, kq = lane >> 4, m = lane & 15;
+    const int row0 = blockIdx.x * TM, n_real = min(TM, n_rows - row0);
+    load_tile(X, LDT, x + (size_t)row0 * H, n_real, tid);
+    __syncthreads();
+    const int tiles[2] = {2 * wave, 2 * wave + 1};
+    f32x4 acc[2];
+    acc[0] = has_bias ? bias4(W + bias, tiles[0], lane) : splat(0.f);
+    acc[1] = has_bias ? bias4(W + bias, tiles[1], lane) : splat(0.f);
+    gemm_acc<128, 2>(acc, W + w, tiles, X + m * LDT + kq * 32, lane);
+    if (m < n_real) {
+        st4(out + (size_t)(row0 + m) * H + tiles[0] * 16 + kq * 4, acc[0]);
+        st4(out + (size_t)(row0 + m) * H + tiles[1] * 16 + kq * 4, acc[1]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// destination logits: for agent a and 16 polylines  (goal_manager.py:235-244,304-307,329-332)
+//   y = relu(LN(U[p] + V[a])) ; y = relu(LN(W1 y + b1)) ; logit = w2.y + b2 ; masks
+// grid = (p_tiles, A, B)
+// ------------------------------------------------------------------------------------------------
+struct DestP {
+    const float* W;
+    uint32_t ln0_g, ln0_b, w1, b1, ln1_g, ln1_b, w2, b2;
+    int B, A, P;
+    const float* U;            // [B][P][128]  = W0[:, :128] map_feature + b0
+    const float* V;            // [B][A][128]  = W0[:, 128:] agent
+    const uint8_t* map_fvalid; // [B][P]
+    const int32_t* map_type;   // [B][P]
+    const int32_t* agent_type; // [B][A]
+    const uint8_t* dist_valid; // [B][A]
+    float* logits;             // [B][A][P]
+};
+
+__device__ __forceinline__ bool dest_candidate(int mtype, bool mvalid, int atype) {
+    // map_type_mask (goal_manager.py:235) and the per-class exclusions (:237-244)
+    if (!(mvalid && mtype >= 0 && mtype < 5)) return false;
+    if (atype == 0 && mtype == 3) return false;
+    if (atype == 1 && mtype < 4) return false;
+    if (atype == 2 && mtype < 3) return false;
+    return true;
+}
+
+__global__ __launch_bounds__(NTHREADS) void k_dest_pairs(DestP p) {
+    __shared__ __attribute__((aligned(16))) float X[TM * LDT];
+    __shared__ __attribute__((aligned(16))) float Y[TM * LDT];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, kq = lane >> 4, m = lane & 15;
+    const int p0 = blockIdx.x * TM, a = blockIdx.y, b = blockIdx.z;
+    const int n_real = min(TM, p.P - p0);
+    const int atype = p.agent_type[(size_t)b * p.A + a];
+    const bool dvalid = p.dist_valid[(size_t)b * p.A + a] != 0;
+    // does this agent have any candidate polyline at all? (rows that are all -inf become 0, :331-332)
+    bool mine = false;
+    for (int q = tid; q < p.P; q += NTHREADS)
+        mine |= dest_candidate(p.map_type[(size_t)b * p.P + q], p.map_fvalid[(size_t)b * p.P + q] != 0, atype);
+    const bool any_cand = __syncthreads_or(mine);
+    for (int i = tid; i < TM * 32; i += NTHREADS) {
+        const int r = i >> 5, c4 = (i & 31) * 4;
+        f32x4 v = splat(0.f);
+        if (r < n_real) v = ldg4(p.U + ((size_t)b * p.P + p0 + r) * H + c4) + ldg4(p.V + ((size_t)b * p.A + a) * H + c4);
+        st4(X + r * LDT + c4, v);
+    }
+    __syncthreads();
+    layernorm_tile(X, LDT, Y, LDT, p.W + p.ln0_g, p.W + p.ln0_b, tid);
+    __syncthreads();
+    for (int i = tid; i < TM * 32; i += NTHREADS) {
+        float* q = Y + (i >> 5) * LDT + (i & 31) * 4;
+        st4(q, relu4(lds4(q)));
+    }
+    __syncthreads();
+    {
+        f32x4 acc[2];
+        linear128<128>(acc, p.W + p.w1, p.W + p.b1, Y + m * LDT + kq * 32, wave, lane);
+        st4(cptr(X, LDT, 2 * wave, lane), acc[0]);
+        st4(cptr(X, LDT, 2 * wave + 1, lane), acc[1]);
+    }
+    __syncthreads();
+    layernorm_tile(X, LDT, Y, LDT, p.W + p.ln1_g, p.W + p.ln1_b, tid);
+    __syncthreads();
+    {
+        // 16 lanes per row: dot(relu(Y[row]), w2)
+        const int row = tid >> 4, c0 = (tid & 15) * 8;
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s = fmaf(fmaxf(Y[row * LDT + c0 + k], 0.f), p.W[p.w2 + c0 + k], s);
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) s += __shfl_xor(s, o);
+        if ((tid & 15) == 0 && row < n_real) {
+            const int q = p0 + row;
+            float lg = s + p.W[p.b2];
+            const bool cand = dest_candidate(p.map_type[(size_t)b * p.P + q], p.map_fvalid[(size_t)b * p.P + q] != 0, atype);
+            if (!cand) lg = -INFINITY;
+            if (!dvalid || !any_cand) lg = 0.f;
+            p.logits[((size_t)b * p.A + a) * p.P + q] = lg;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// driver
+// ------------------------------------------------------------------------------------------------
+static void launch_xblock(const XBlockP& p, int G, hipStream_t s) {
+    dim3 grid((p.n_rows + TM - 1) / TM, G);
+    hipLaunchKernelGGL(k_xattn_block, grid, dim3(NTHREADS), (3 * TM * LDT + 16) * sizeof(float), s, p);
+}
+
+int run_encode(struct ::tb_ctx* ctx, const tb_encode_io* io, hipStream_t s) {
+    const int B = io->n_scene, A = io->n_agent, P = io->n_pl, T = io->n_tl, NH = io->n_hist;
+    if (B <= 0 || A <= 0 || P <= 0 || T <= 0) return tb_fail(ctx, "tb_encode_scene: empty dimension");
+    if (A > 256) return tb_fail(ctx, "tb_encode_scene: n_agent %d > 256 not supported", A);
+    if (NH != ctx->cfg.time_step_current + 1 || (NH - 1) % 5 != 0)
+        return tb_fail(ctx, "tb_encode_scene: n_hist %d does not match the config", NH);
+    const void* req[] = {io->agent_valid, io->agent_pos, io->agent_yaw, io->agent_vel, io->agent_spd, io->agent_acc,
+                         io->agent_yaw_rate, io->agent_type, io->agent_size, io->map_valid, io->map_type, io->map_pos,
+                         io->map_dir, io->tl_valid, io->tl_state, io->tl_pos, io->tl_dir, io->map_feature,
+                         io->map_feature_valid, io->agent_feature, io->tl_feature, io->latent_mean, io->latent_valid,
+                         io->dest_logits};
+    for (const void* q : req)
+        if (!q) return tb_fail(ctx, "tb_encode_scene: a required buffer pointer is NULL");
+    const float* W = ctx->d_arena;
+    const EncoderW& ew = ctx->ew;
+    const int a_pad = pad16(A), p_pad = pad16(P), t_pad = pad16(T);
+    const int S3 = (NH - 1) / 5 + 1;  // steps {0,5,10} (latent_encoder.py:98-103)
+    // map-encoder chunking bounds the per-polyline K/V scratch (3 layers x 32 keys x 128 x 2 x 4 B = 96 KiB / polyline)
+    const int scenes_per_chunk = std::max(1, std::min(B, (int)(((size_t)512 << 20) / ((size_t)P * 98304))));
+
+    auto carve = [&](Carver& c, float*& nodef, float*& nodeo, float*& kn, float*& vtn, uint8_t*& kvn, float*& plf, float*& kps,
+                     float*& vtps, uint8_t*& kvps, float*& kpl, float*& vtpl, uint8_t*& kvpl, float*& x0, uint8_t*& v0, float*& x1,
+                     float*& x2, float*& x3, float*& tl3, uint8_t*& tlv3, float*& ktl, float*& vttl, uint8_t*& kvtl, float*& kin,
+                     float*& vtin, uint8_t*& kvin, float*& tgt, uint8_t*& tgtv, float*& U, float*& V) {
+        nodef = c.take<float>((size_t)B * P * 20 * 128);
+        nodeo = c.take<float>((size_t)scenes_per_chunk * P * 20 * 128);
+        kn = c.take<float>((size_t)scenes_per_chunk * P * 3 * 32 * 128);
+        vtn = c.take<float>((size_t)scenes_per_chunk * P * 3 * 128 * 32);
+        kvn = c.take<uint8_t>((size_t)scenes_per_chunk * P * 32);
+        plf = c.take<float>((size_t)B * P * 128);
+        kps = c.take<float>((size_t)B * p_pad * 128);
+        vtps = c.take<float>((size_t)B * 128 * p_pad);
+        kvps = c.take<uint8_t>((size_t)B * p_pad);
+        kpl = c.take<float>((size_t)B * 3 * p_pad * 128);
+        vtpl = c.take<float>((size_t)B * 3 * 128 * p_pad);
+        kvpl = c.take<uint8_t>((size_t)B * p_pad);
+        x0 = c.take<float>((size_t)B * S3 * A * 128);
+        v0 = c.take<uint8_t>((size_t)B * S3 * A);
+        x1 = c.take<float>((size_t)B * S3 * A * 128);
+        x2 = c.take<float>((size_t)B * S3 * A * 128);
+        x3 = c.take<float>((size_t)B * S3 * A * 128);
+        tl3 = c.take<float>((size_t)B * S3 * T * 128);
+        tlv3 = c.take<uint8_t>((size_t)B * S3 * T);
+        ktl = c.take<float>((size_t)B * S3 * 3 * t_pad * 128);
+        vttl = c.take<float>((size_t)B * S3 * 3 * 128 * t_pad);
+        kvtl = c.take<uint8_t>((size_t)B * S3 * t_pad);
+        kin = c.take<float>((size_t)B * S3 * 3 * a_pad * 128);
+        vtin = c.take<float>((size_t)B * S3 * 3 * 128 * a_pad);
+        kvin = c.take<uint8_t>((size_t)B * S3 * a_pad);
+        tgt = c.take<float>((size_t)B * A * 128);
+        tgtv = c.take<uint8_t>((size_t)B * A);
+        U = c.take<float>((size_t)B * P * 128);
+        V = c.take<float>((size_t)B * A * 128);
+    };
+    float *nodef, *nodeo, *kn, *vtn, *plf, *kps, *vtps, *kpl, *vtpl, *x0, *x1, *x2, *x3, *tl3, *ktl, *vttl, *kin, *vtin, *tgt, *U, *V;
+    uint8_t *kvn, *kvps, *kvpl, *v0, *tlv3, *kvtl, *kvin, *tgtv;
+    Carver sz{nullptr};
+    carve(sz, nodef, nodeo, kn, vtn, kvn, plf, kps, vtps, kvps, kpl, vtpl, kvpl, x0, v0, x1, x2, x3, tl3, tlv3, ktl, vttl, kvtl, kin,
+          vtin, kvin, tgt, tgtv, U, V);
+    if (tb_ensure_workspace(ctx, sz.off + 256)) return 1;
+    Carver c{ctx->d_ws};
+    carve(c, nodef, nodeo, kn, vtn, kvn, plf, kps, vtps, kvps, kpl, vtpl, kvpl, x0, v0, x1, x2, x3, tl3, tlv3, ktl, vttl, kvtl, kin,
+          vtin, kvin, tgt, tgtv, U, V);
+
+    // ---- input features (sc_input.py:100-140 + input_pe_encoder.py:52-59)
+    {
+        TokP t{};
+        t.W = W; t.pe_fxy = ew.pe_fxy; t.pe_fyaw = ew.pe_fyaw;
+        t.kind = 0; t.mlp = ew.agent_enc; t.n_tok = B * NH * A; t.per_scene = NH * A; t.inner = A;
+        t.valid = io->agent_valid; t.pos = io->agent_pos; t.yaw = io->agent_yaw; t.vel = io->agent_vel; t.spd = io->agent_spd;
+        t.acc = io->agent_acc; t.yaw_rate = io->agent_yaw_rate; t.cls = io->agent_type; t.size = io->agent_size;
+        t.out = io->agent_feature;
+        hipLaunchKernelGGL(k_encode_tokens, dim3((t.n_tok + TM - 1) / TM), dim3(NTHREADS), 0, s, t);
+        TokP l{};
+        l.W = W; l.pe_fxy = ew.pe_fxy; l.pe_fyaw = ew.pe_fyaw;
+        l.kind = 1; l.mlp = ew.tl_enc; l.n_tok = B * NH * T; l.per_scene = NH * T; l.inner = T;
+        l.valid = io->tl_valid; l.pos = io->tl_pos; l.dir = io->tl_dir; l.cls = io->tl_state; l.out = io->tl_feature;
+        hipLaunchKernelGGL(k_encode_tokens, dim3((l.n_tok + TM - 1) / TM), dim3(NTHREADS), 0, s, l);
+        TokP m{};
+        m.W = W; m.pe_fxy = ew.pe_fxy; m.pe_fyaw = ew.pe_fyaw;
+        m.kind = 2; m.mlp = ew.map_enc; m.n_tok = B * P * 20; m.per_scene = P * 20; m.inner = 20;
+        m.valid = io->map_valid; m.pos = io->map_pos; m.dir = io->map_dir; m.cls = io->map_type; m.out = nodef;
+        hipLaunchKernelGGL(k_encode_tokens, dim3((m.n_tok + TM - 1) / TM), dim3(NTHREADS), 0, s, m);
+    }
+    // ---- map encoder
+    for (int b0 = 0; b0 < B; b0 += scenes_per_chunk) {
+        const int nb = std::min(scenes_per_chunk, B - b0);
+        const int G = nb * P;
+        const float* src = nodef + (size_t)b0 * P * 20 * 128;
+        const uint8_t* sv = io->map_valid + (size_t)b0 * P * 20;
+        launch_kv_hoist_n(W, ew.densetnt, 3, src, sv, G, 20, 32, kn, vtn, kvn, s);
+        XBlockP x{};
+        x.W = W; x.n_layer = 3;
+        for (int l = 0; l < 3; ++l) x.L[l] = ew.densetnt[l];
+        x.src = src; x.src_valid = sv; x.dst = nodeo; x.K = kn; x.VT = vtn; x.kvalid = kvn; x.n_rows = 20; x.n_pad = 32; x.eye = 0;
+        launch_xblock(x, G, s);
+        const int nthr = G * 32;
+        hipLaunchKernelGGL(k_pool_nodes, dim3((nthr + 255) / 256), dim3(256), 0, s, nodeo, sv, G, plf + (size_t)b0 * P * 128,
+                           io->map_feature_valid + (size_t)b0 * P);
+    }
+    {
+        launch_kv_hoist_n(W, &ew.map_self, 1, plf, io->map_feature_valid, B, P, p_pad, kps, vtps, kvps, s);
+        XBlockP x{};
+        x.W = W; x.n_layer = 1; x.L[0] = ew.map_self;
+        x.src = plf; x.src_valid = io->map_feature_valid; x.dst = io->map_feature; x.K = kps; x.VT = vtps; x.kvalid = kvps;
+        x.n_rows = P; x.n_pad = p_pad; x.eye = 0;
+        launch_xblock(x, B, s);
+    }
+    // ---- personality prior
+    {
+        const int RC4 = A * 32;
+        size_t total = (size_t)B * S3 * RC4;
+        hipLaunchKernelGGL(k_gather_steps_f, dim3((total + 255) / 256), dim3(256), 0, s, io->agent_feature, x0, B, NH, S3, 5, RC4);
+        total = (size_t)B * S3 * A;
+        hipLaunchKernelGGL(k_gather_steps_u8, dim3((total + 255) / 256), dim3(256), 0, s, io->agent_valid, v0, B, NH, S3, 5, A);
+        total = (size_t)B * S3 * T * 32;
+        hipLaunchKernelGGL(k_gather_steps_f, dim3((total + 255) / 256), dim3(256), 0, s, io->tl_feature, tl3, B, NH, S3, 5, T * 32);
+        total = (size_t)B * S3 * T;
+        hipLaunchKernelGGL(k_gather_steps_u8, dim3((total + 255) / 256), dim3(256), 0, s, io->tl_valid, tlv3, B, NH, S3, 5, T);
+        // agent -> map over the 3*A tokens of each scene (shared as2pl weights)
+        launch_kv_hoist_n(W, ew.as2pl, 3, io->map_feature, io->map_feature_valid, B, P, p_pad, kpl, vtpl, kvpl, s);
+        XBlockP x{};
+        x.W = W; x.n_layer = 3;
+        for (int l = 0; l < 3; ++l) x.L[l] = ew.as2pl[l];
+        x.src = x0; x.src_valid = v0; x.dst = x1; x.K = kpl; x.VT = vtpl; x.kvalid = kvpl; x.n_rows = S3 * A; x.n_pad = p_pad; x.eye = 0;
+        launch_xblock(x, B, s);
+        // agent -> traffic lights, per step
+        launch_kv_hoist_n(W, ew.as2tl, 3, tl3, tlv3, B * S3, T, t_pad, ktl, vttl, kvtl, s);
+        for (int l = 0; l < 3; ++l) x.L[l] = ew.as2tl[l];
+        x.src = x1; x.dst = x2; x.K = ktl; x.VT = vttl; x.kvalid = kvtl; x.n_rows = A; x.n_pad = t_pad;
+        launch_xblock(x, B * S3, s);
+        // interaction (own weights), tgt = block input
+        launch_kv_hoist_n(W, ew.inter_prior, 3, x2, v0, B * S3, A, a_pad, kin, vtin, kvin, s);
+        for (int l = 0; l < 3; ++l) x.L[l] = ew.inter_prior[l];
+        x.src = x2; x.dst = x3; x.K = kin; x.VT = vtin; x.kvalid = kvin; x.n_rows = A; x.n_pad = a_pad; x.eye = 1;
+        launch_xblock(x, B * S3, s);
+        ScanP sp{};
+        sp.W = W;
+        for (int l = 0; l < 3; ++l) sp.gru[l] = ew.gru_prior[l];
+        sp.head_w1 = ew.lat_w1; sp.head_b1 = ew.lat_b1; sp.head_w2 = ew.lat_w2; sp.head_b2 = ew.lat_b2;
+        sp.mode = 0; sp.B = B; sp.S = S3; sp.A = A; sp.x = x3; sp.valid = v0; sp.out_mean = io->latent_mean; sp.out_valid = io->latent_valid;
+        hipLaunchKernelGGL(k_gru_scan, dim3(a_pad / TM, B), dim3(NTHREADS), (8 * TM * LDT + 16) * sizeof(float), s, sp);
+    }
+    // ---- destination predictor
+    {
+        ScanP sp{};
+        sp.W = W;
+        for (int l = 0; l < 3; ++l) sp.gru[l] = ew.gru_dest[l];
+        sp.mode = 1; sp.B = B; sp.S = NH; sp.A = A; sp.x = io->agent_feature; sp.valid = io->agent_valid; sp.out_feat = tgt; sp.out_valid = tgtv;
+        hipLaunchKernelGGL(k_gru_scan, dim3(a_pad / TM, B), dim3(NTHREADS), (8 * TM * LDT + 16) * sizeof(float), s, sp);
+        hipLaunchKernelGGL(k_linear_rows, dim3((B * P + TM - 1) / TM), dim3(NTHREADS), 0, s, W, ew.dest_w0_map, ew.dest_b0, 1,
+                           io->map_feature, B * P, U);
+        hipLaunchKernelGGL(k_linear_rows, dim3((B * A + TM - 1) / TM), dim3(NTHREADS), 0, s, W, ew.dest_w0_agent, 0u, 0, tgt, B * A, V);
+        DestP d{};
+        d.W = W; d.ln0_g = ew.dest_ln0_g; d.ln0_b = ew.dest_ln0_b; d.w1 = ew.dest_w1; d.b1 = ew.dest_b1; d.ln1_g = ew.dest_ln1_g;
+        d.ln1_b = ew.dest_ln1_b; d.w2 = ew.dest_w2; d.b2 = ew.dest_b2;
+        d.B = B; d.A = A; d.P = P; d.U = U; d.V = V; d.map_fvalid = io->map_feature_valid; d.map_type = io->map_type;
+        d.agent_type = io->agent_type; d.dist_valid = tgtv; d.logits = io->dest_logits;
+        hipLaunchKernelGGL(k_dest_pairs, dim3((P + TM - 1) / TM, A, B), dim3(NTHREADS), 0, s, d);
+    }
+    TB_HIP(ctx, hipGetLastError());
+    return 0;
+}
+
+}  // namespace tb

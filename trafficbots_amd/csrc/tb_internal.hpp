@@ -1,0 +1,65 @@
+// Internal (not part of the C ABI): context layout shared by the translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/trafficbots_hip.h"
+#include "tb_encode.hpp"
+#include "tb_rollout.hpp"
+
+struct tb_ctx {
+    tb_config cfg;
+    std::string err;
+    std::map<std::string, std::vector<float>> staged;
+    float* d_arena = nullptr;
+    size_t arena_floats = 0;
+    tb::PolicyW pw;
+    tb::EncoderW ew;
+    bool finalized = false;
+    // workspace
+    char* d_ws = nullptr;
+    size_t ws_bytes = 0;
+    // timing
+    bool timing = false;
+    std::vector<hipEvent_t> ev;
+    int n_timed_steps = 0;
+};
+
+
+inline int tb_fail(tb_ctx* ctx, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (ctx) ctx->err = buf;
+    return 1;
+}
+
+#define TB_HIP(ctx, call)                                                                     \
+    do {                                                                                      \
+        hipError_t e_ = (call);                                                               \
+        if (e_ != hipSuccess) return tb_fail(ctx, "%s failed: %s", #call, hipGetErrorString(e_)); \
+    } while (0)
+
+// bump allocator over the context workspace (pass base = nullptr to size)
+struct Carver {
+    char* base;
+    size_t off = 0;
+    template <typename T>
+    T* take(size_t n) {
+        off = (off + 255) & ~(size_t)255;
+        T* p = base ? reinterpret_cast<T*>(base + off) : nullptr;
+        off += n * sizeof(T);
+        return p;
+    }
+};
+
+int tb_ensure_workspace(tb_ctx* ctx, size_t bytes);
+inline int pad16(int x) { return (x + 15) / 16 * 16; }

@@ -216,10 +216,12 @@ __global__ __launch_bounds__(NTHREADS) void k_step_a(RolloutP p, int t) {
             } else {
                 arg = pyaw * W[pw.pe_fyaw + j - 24]; c_cos = 48 + (j - 24); c_sin = 72 + (j - 24);
             }
-            float sv, cv;
-            sincosf(arg, &sv, &cv);
-            xr[c_cos] = cv;
-            xr[c_sin] = sv;
+            // fp64 sin/cos of the fp32 argument, rounded once: within 0.5 ulp of exact, i.e. as close as
+            // possible to whatever libm the reference's host uses (48 per agent, negligible)
+            double sv, cv;
+            sincos((double)arg, &sv, &cv);
+            xr[c_cos] = (float)cv;
+            xr[c_sin] = (float)sv;
         }
     }
     // ---- InputPeEncoder MLP 11 -> 32 -> 32 (input_pe_encoder.py:52-54), 2 outputs per thread
