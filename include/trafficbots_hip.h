@@ -143,10 +143,11 @@ typedef struct tb_encode_io {
 int tb_encode_scene(tb_ctx* ctx, const tb_encode_io* io, tb_stream stream);
 
 /* -- instrumentation ---------------------------------------------------------------------------------- */
-/* Time (ms, HIP events on `stream`) spent in the per-step kernels of the LAST tb_rollout when timing was
- * enabled with tb_set_timing(ctx, 1): out[0] = sum over steps of kernel A (encode+as2pl+as2tl+kv), out[1] =
- * kernel C (interaction..dynamics), out[2] = prologue (hoists), out[3] = number of steps.  Timing inserts event
- * records only (no host sync until this query, which synchronises the events). */
+/* Per-launch durations (ms, HIP events recorded on `stream`) of the LAST tb_rollout when timing was enabled with
+ * tb_set_timing(ctx, 1).  A rollout of S steps issues S+1 step launches: A(1) alone, S-1 fused launches
+ * C(t)+A(t+1), C(S) alone.  out[0] = sum over the fused launches, out[1] = the two edge launches, out[2] = prologue
+ * (K/V hoists + init), out[3] = number of fused launches.  Timing inserts event records only (no host sync until
+ * this query, which synchronises on the last event). */
 int tb_set_timing(tb_ctx* ctx, int enable);
 int tb_get_timing(tb_ctx* ctx, float* out4);
 

@@ -97,7 +97,7 @@ def timing():
         dt_ = time.time() - t0
         tm = eng.get_timing()
         print(f"[timing] rollout B=32 A=64 P=256 90 steps: {dt_ * 1e3:.2f} ms -> {32 * 90 / dt_:.0f} scene-steps/s; "
-              f"step_a {tm['step_a_ms'] / 90 * 1e3:.1f} us  step_c {tm['step_c_ms'] / 90 * 1e3:.1f} us  prologue {tm['prologue_ms']:.3f} ms")
+              f"fused k_step {tm['fused_ms'] / max(1, tm['n_fused']) * 1e3:.1f} us  edge {tm['edge_ms']:.3f} ms  prologue {tm['prologue_ms']:.3f} ms")
     print("   finite:", bool(torch.isfinite(out["preds"]).all()), " valid frac:", out["valid"].float().mean().item())
 
 

@@ -1,0 +1,69 @@
+"""Development probe: per-stage cycle breakdown of one fused k_step launch from the -DTB_PROFILE build
+(s_memtime stamps written by thread 0 of every workgroup).  Run on the GPU box:
+    TB_HIP_LIB=trafficbots_amd/lib/libtrafficbots_hip_prof.so python tools/gpu_stage_profile.py"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from trafficbots_amd import synth  # noqa: E402
+from trafficbots_amd.config import load_model_config  # noqa: E402
+from trafficbots_amd.runtime import HipEngine, scene_from_batch  # noqa: E402
+
+NAMES = ["C: tile/geometry loads", "C: interaction x3", "C: GRU x3", "C: add_goal", "C: add_latent", "C: action head",
+         "C: epilogue", "A: attr+PE+encoder", "A: as2pl x3", "A: as2tl x3", "A: interaction K/V proj x3"]
+
+cfg = load_model_config()
+sd = synth.make_state_dict(7)
+b, a, p, t = 32, 64, 256, 40
+batch = synth.make_batch(5000, b, n_agent=a, n_pl=p, n_tl=t)
+dev = torch.device("cuda:0")
+eng = HipEngine(cfg)
+eng.load_state_dict(sd)
+s = scene_from_batch(batch, dev)
+enc = eng.encode_scene(s)
+feats = {"map_feature": enc["map_feature"], "map_feature_valid": enc["map_feature_valid"], "tl_feature": enc["tl_feature"]}
+z = enc["latent_mean"].clone()
+dest = enc["dest_logits"].argmax(-1).to(torch.int32)
+gv = s["agent_valid"].bool().any(1).to(torch.uint8)
+out = None
+for step_end in (90, 50):  # the stamps kept are those of the LAST launch that ran both halves: use step_end-1 ... see below
+    out = eng.rollout(s, feats, z, enc["latent_mean"], dest, gv, 1, step_end)
+torch.cuda.synchronize()
+# last launch = C(S) only; stamps 0..7 of it are overwritten, stamps 8..11 are those of the previous (fused) launch
+n_blocks = b * (a // 16)
+buf = (C.c_longlong * (32 * n_blocks))()
+eng.lib.tb_debug_read_prof.argtypes = [C.c_void_p, C.POINTER(C.c_longlong), C.c_int]
+rc = eng.lib.tb_debug_read_prof(eng._ctx, buf, n_blocks)
+assert rc == 0
+st = np.frombuffer(buf, dtype=np.int64).reshape(n_blocks, 32)
+d_c = np.diff(st[:, 0:8], axis=1)     # C half of the last launch
+d_a = np.diff(st[:, 7:12], axis=1)    # NOTE: stamp 7 is from the last launch, 8.. from the previous one -> use 8..11 only
+d_a = np.diff(st[:, 8:12], axis=1)
+print(f"workgroups: {n_blocks}; cycles are s_memtime ticks (median over workgroups [min..max])")
+tot = 0
+for i in range(7):
+    v = d_c[:, i]
+    print(f"  {NAMES[i]:32s} {np.median(v):9.0f}  [{v.min():8.0f} .. {v.max():8.0f}]")
+    tot += np.median(v)
+for i in range(3):
+    v = d_a[:, i]
+    print(f"  {NAMES[8 + i]:32s} {np.median(v):9.0f}  [{v.min():8.0f} .. {v.max():8.0f}]")
+    tot += np.median(v)
+print(f"  sum of medians (without A front-end) {tot:9.0f}")
+# finer stamps inside add_goal: 3 = stage start, 12 = CAT built (barrier), 13 = first unit's MFMAs done, 14 = second unit done,
+# 15 = after the barrier, 4 = stage end
+seq = [3, 12, 13, 14, 15, 4]
+lab = ["CAT build + barrier", "unit 1 (64 MFMA)", "wload + unit 2 (64 MFMA)", "relu/store + barrier", "unit 3 + residual + barrier"]
+for i in range(5):
+    v = st[:, seq[i + 1]] - st[:, seq[i]]
+    print(f"    add_goal/{lab[i]:30s} {np.median(v):8.0f}  [{v.min():7.0f} .. {v.max():7.0f}]")
+lab = ["LN1 + barrier", "wload + Q proj (64 MFMA)", "attention 256 keys (8 x 32 MFMA)", "store + barrier", "wload + out proj + residual + barrier",
+       "LN2 + barrier", "wload + FFN1 + relu + barrier", "wload + FFN2 + residual + barrier"]
+for i in range(8):
+    v = st[:, 17 + i] - st[:, 16 + i]
+    print(f"    as2pl[0]/{lab[i]:40s} {np.median(v):8.0f}  [{v.min():7.0f} .. {v.max():7.0f}]")

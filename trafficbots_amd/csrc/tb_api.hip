@@ -16,8 +16,8 @@ size_t step_lds_bytes();
 void launch_kv_hoist(const float* W, const XLayerW* L3, const float* feat, const uint8_t* fvalid, int G, int n_tok, int n_pad,
                      float* K, float* VT, uint8_t* kvalid, hipStream_t s);
 void launch_rollout_init(const RolloutP& p, hipStream_t s);
-void launch_step_a(const RolloutP& p, int t, hipStream_t s);
-void launch_step_c(const RolloutP& p, int t, hipStream_t s);
+void launch_step(const RolloutP& p, int t, int do_c, int do_a, hipStream_t s);
+void launch_rollout_final(const RolloutP& p, float* f_state, uint8_t* f_valid, float* f_hidden, hipStream_t s);
 int run_encode(struct ::tb_ctx* ctx, const tb_encode_io* io, hipStream_t s);
 }  // namespace tb
 
@@ -293,19 +293,23 @@ int tb_set_timing(tb_ctx* ctx, int enable) {
 int tb_get_timing(tb_ctx* ctx, float* out4) {
     if (!ctx || !out4) return 1;
     out4[0] = out4[1] = out4[2] = 0.f;
-    out4[3] = (float)ctx->n_timed_steps;
-    if (ctx->n_timed_steps == 0) return 0;
-    const int n = ctx->n_timed_steps;
-    TB_HIP(ctx, hipEventSynchronize(ctx->ev[2 + 3 * n - 1]));
+    out4[3] = 0.f;
+    const int n = ctx->n_timed_steps;  // number of step launches of the last rollout (S + 1)
+    if (n < 2) return 0;
+    TB_HIP(ctx, hipEventSynchronize(ctx->ev[1 + n]));
     float ms = 0.f;
     TB_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));
     out4[2] = ms;
-    for (int i = 0; i < n; ++i) {
-        TB_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev[2 + 3 * i], ctx->ev[2 + 3 * i + 1]));
+    // launch 0 = A(1) alone, launches 1..n-2 = fused C(t)+A(t+1), launch n-1 = C(S) alone
+    TB_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev[1], ctx->ev[2]));
+    out4[1] += ms;
+    TB_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev[n], ctx->ev[n + 1]));
+    out4[1] += ms;
+    for (int i = 1; i + 1 < n; ++i) {
+        TB_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev[1 + i], ctx->ev[2 + i]));
         out4[0] += ms;
-        TB_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev[2 + 3 * i + 1], ctx->ev[2 + 3 * i + 2]));
-        out4[1] += ms;
     }
+    out4[3] = (float)(n - 2);
     return 0;
 }
 
@@ -349,6 +353,9 @@ static void carve_rollout(tb::RolloutP& p, Carver& c) {
     p.vtin = c.take<float>(N * 3 * 128 * p.a_pad);
     p.goal_pre = c.take<float>(N * p.a_pad * 128);
     p.lat_pre = c.take<float>(N * p.a_pad * 128);
+    p.dest_geo = c.take<float>(N * p.a_pad * 80);
+    p.dest_flag = c.take<int>(N * p.a_pad);
+    p.prof = c.take<long long>(N * (p.a_pad / 16) * 32);
 }
 
 extern "C" int tb_rollout(tb_ctx* ctx, const tb_rollout_io* io, tb_stream stream_) {
@@ -371,11 +378,11 @@ extern "C" int tb_rollout(tb_ctx* ctx, const tb_rollout_io* io, tb_stream stream
     p.k_rep = io->k_futures;
     p.n_inst = io->n_scene * io->k_futures;
     p.n_agent = io->n_agent;
-    p.a_pad = pad16(io->n_agent);
+    p.a_pad = padk(io->n_agent);
     p.n_pl = io->n_pl;
-    p.p_pad = pad16(io->n_pl);
+    p.p_pad = padk(io->n_pl);
     p.n_tl = io->n_tl;
-    p.t_pad = pad16(io->n_tl);
+    p.t_pad = padk(io->n_tl);
     p.n_hist = io->n_hist;
     p.step_start = step_start;
     p.n_step_out = io->step_end - step_start + 1;
@@ -424,9 +431,11 @@ extern "C" int tb_rollout(tb_ctx* ctx, const tb_rollout_io* io, tb_stream stream
     Carver c{ctx->d_ws};
     carve_rollout(p, c);
 
+    ctx->last_prof = p.prof;
     const int n_steps = p.n_step_out;
+    const int n_launch = n_steps + 1;
     if (ctx->timing) {
-        const size_t need = 2 + 3 * (size_t)n_steps;
+        const size_t need = 2 + (size_t)n_launch;
         while (ctx->ev.size() < need) {
             hipEvent_t e;
             TB_HIP(ctx, hipEventCreate(&e));
@@ -441,35 +450,25 @@ extern "C" int tb_rollout(tb_ctx* ctx, const tb_rollout_io* io, tb_stream stream
                         p.vttl, p.kvalid_tl, s);
     tb::launch_rollout_init(p, s);
     if (ctx->timing) TB_HIP(ctx, hipEventRecord(ctx->ev[1], s));
-    // ---- the sequential loop (waymo_motion.py:269): two launches per step, no host sync
-    for (int i = 0; i < n_steps; ++i) {
-        const int t = step_start + i;
-        if (ctx->timing) TB_HIP(ctx, hipEventRecord(ctx->ev[2 + 3 * i], s));
-        tb::launch_step_a(p, t, s);
-        if (ctx->timing) TB_HIP(ctx, hipEventRecord(ctx->ev[2 + 3 * i + 1], s));
-        tb::launch_step_c(p, t, s);
-        if (ctx->timing) TB_HIP(ctx, hipEventRecord(ctx->ev[2 + 3 * i + 2], s));
+    // ---- the sequential loop (waymo_motion.py:269): launch i runs C(start+i-1) then A(start+i); no host sync
+    for (int i = 0; i < n_launch; ++i) {
+        const int t = step_start + i - 1;
+        tb::launch_step(p, t, /*do_c=*/i > 0, /*do_a=*/i < n_steps, s);
+        if (ctx->timing) TB_HIP(ctx, hipEventRecord(ctx->ev[2 + i], s));
     }
-    ctx->n_timed_steps = ctx->timing ? n_steps : 0;
+    ctx->n_timed_steps = ctx->timing ? n_launch : 0;
     // ---- final simulator state
-    if (io->final_state || io->final_valid) {
-        for (int n = 0; n < p.n_inst; ++n) {
-            if (io->final_state)
-                TB_HIP(ctx, hipMemcpyAsync(io->final_state + (size_t)n * p.n_agent * 4, p.state + (size_t)n * p.a_pad * 4,
-                                           (size_t)p.n_agent * 4 * sizeof(float), hipMemcpyDeviceToDevice, s));
-            if (io->final_valid)
-                TB_HIP(ctx, hipMemcpyAsync(io->final_valid + (size_t)n * p.n_agent, p.valid + (size_t)n * p.a_pad,
-                                           (size_t)p.n_agent, hipMemcpyDeviceToDevice, s));
-        }
-    }
-    if (io->final_hidden) {
-        for (int l = 0; l < 3; ++l)
-            for (int n = 0; n < p.n_inst; ++n)
-                TB_HIP(ctx, hipMemcpyAsync(io->final_hidden + ((size_t)l * p.n_inst + n) * p.n_agent * 128,
-                                           p.hidden + ((size_t)l * p.n_inst + n) * p.a_pad * 128,
-                                           (size_t)p.n_agent * 128 * sizeof(float), hipMemcpyDeviceToDevice, s));
-    }
+    if (io->final_state || io->final_valid || io->final_hidden)
+        tb::launch_rollout_final(p, io->final_state, io->final_valid, io->final_hidden, s);
     TB_HIP(ctx, hipGetLastError());
+    return 0;
+}
+
+// development aid (not in the public header): copy the stage time stamps of the last launch of a -DTB_PROFILE build
+extern "C" int tb_debug_read_prof(tb_ctx* ctx, long long* host_out, int n_blocks) {
+    if (!ctx || !ctx->last_prof) return 1;
+    TB_HIP(ctx, hipDeviceSynchronize());
+    TB_HIP(ctx, hipMemcpy(host_out, ctx->last_prof, sizeof(long long) * 32 * n_blocks, hipMemcpyDeviceToHost));
     return 0;
 }
 

@@ -1,6 +1,6 @@
 // Device building blocks for the gfx950 rollout kernels (wave64, fp32 MFMA 16x16x4).
 //
-// Geometry used everywhere: one workgroup = 256 threads = 4 waves owns a tile of TM = 16 rows
+// Geometry used everywhere: one workgroup = 256 threads = 4 waves (one per SIMD) owns a tile of TM = 16 rows
 // (agents / tokens).  Activations of the tile live in LDS as row-major [16][ld] fp32; every Linear
 // is computed in TRANSPOSED form  Y^T = W . X^T  with v_mfma_f32_16x16x4_f32:
 //     A operand = W   (lane l: W[n0 + (l&15)][k(l>>4, step)])          -- pre-packed, 16 B / lane / 4 steps
@@ -11,6 +11,12 @@
 // next MFMA wants as its B operand (attention never round-trips through LDS).
 // The k index consumed by MFMA step (j, i) in lane group kq = l>>4 is  k = kq*(K/4) + 4*j + i  (any bijection
 // works as long as A and B agree; this one makes both operands float4-contiguous).
+//
+// Latency: with one wave per SIMD nothing hides a load, so weights move as UNITS (2 output tiles x 128 k =
+// 16 float4 = 64 VGPRs per lane, 64 MFMAs of work) that are fetched one unit AHEAD of their use: every stage
+// function receives its first unit already in registers and leaves the next stage's first unit loading
+// (`WNext`), so the ~2k cycles of MFMA of one unit cover the L2 / Infinity-Cache latency of the next.
+// Attention K/V tiles are double-buffered the same way.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -26,6 +32,7 @@ constexpr int TM = 16;       // rows per workgroup tile
 constexpr int LDT = 132;     // LDS row stride (floats) of a [16][128] tile (16-B aligned rows)
 constexpr int LDC = 260;     // LDS row stride of a [16][256] concat tile
 constexpr int NTHREADS = 256;
+constexpr int KEYPAD = 32;   // key counts are padded to a multiple of 32 (attention loop is unrolled by two tiles)
 constexpr float LN_EPS = 1e-5f;
 constexpr float ATTN_SCALE = 0.17677669529663687f;  // 1/sqrt(32)
 
@@ -43,10 +50,101 @@ __device__ __forceinline__ f32x4 relu4(f32x4 v) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// acc[t] += Wpk(tile t) . X^T      K = reduction length (multiple of 16), NT = tiles this wave owns.
-// wpk: packed weight [n_tiles][K/16][64 lanes][4]; tiles[t] = tile index (16 output features each);
-// xrow: THIS LANE's pointer to X[agent][kq*(K/4)] in LDS (caller resolves concat buffers).
+// weight units
 // ---------------------------------------------------------------------------------------------
+struct WUnit {
+    f32x4 w[2][8];  // [tile][k-step group]
+    f32x4 b[2];     // bias of the two tiles for this lane's 4 features (zero when the unit continues a reduction)
+};
+
+// Where the next unit lives: packed matrix, the two 16-feature tiles, and the k-window (kj_total = K/16,
+// j0 = first k-step group of this unit; K = 256 matrices are two units with j0 = 0 and 8).
+struct WNext {
+    const float* wpk;
+    const float* bias;  // bias vector indexed by output feature, or nullptr
+    int tile_a, tile_b, kj_total, j0;
+};
+
+__device__ __forceinline__ WNext wnext(const float* wpk, const float* bias, int tile_a, int tile_b, int kj_total = 8, int j0 = 0) {
+    return WNext{wpk, bias, tile_a, tile_b, kj_total, j0};
+}
+// the standard Linear(128 -> 128) unit of wave `wave`: tiles {2w, 2w+1}
+__device__ __forceinline__ WNext wstd(const float* wpk, const float* bias, int wave) {
+    return WNext{wpk, bias, 2 * wave, 2 * wave + 1, 8, 0};
+}
+
+// The scheduler must not sink these loads below the MFMAs that follow (it would: their results are needed late),
+// nor hoist later loads above them (s_waitcnt vmcnt counts in issue order: anything needed EARLY -- biases --
+// has to be requested BEFORE a wload).  sched_barrier(0) pins both sides.
+#define TB_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+
+__device__ __forceinline__ void wload(WUnit& u, const WNext& n, int lane) {
+    const float* pa_ = n.wpk + ((size_t)(n.tile_a * n.kj_total + n.j0) * 64 + lane) * 4;
+    const float* pb_ = n.wpk + ((size_t)(n.tile_b * n.kj_total + n.j0) * 64 + lane) * 4;
+#ifdef TB_FAKE_W  // timing experiment only: every unit reads the same 16 KiB (L1-resident) -> results are wrong
+    const float* pa = n.wpk + (size_t)lane * 4;
+    const float* pb = pa + 64 * 4;
+    (void)pa_; (void)pb_;
+#else
+    const float* pa = pa_;
+    const float* pb = pb_;
+#endif
+    TB_SCHED_FENCE();
+    if (n.bias) {
+        u.b[0] = ldg4(n.bias + n.tile_a * 16 + (lane >> 4) * 4);
+        u.b[1] = ldg4(n.bias + n.tile_b * 16 + (lane >> 4) * 4);
+    } else {
+        u.b[0] = f32x4{0.f, 0.f, 0.f, 0.f};
+        u.b[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        u.w[0][j] = ldg4(pa + j * 256);
+        u.w[1][j] = ldg4(pb + j * 256);
+    }
+    TB_SCHED_FENCE();
+}
+
+// acc_a / acc_b += unit . X^T ; xrow = this lane's pointer to X[agent][kq*(K/4) + 4*j0].  The two accumulators are
+// interleaved so consecutive MFMAs never depend on each other (16x16x4 f32: 32-cycle issue, 40-cycle dependent).
+__device__ __forceinline__ void wmma(f32x4& acc_a, f32x4& acc_b, const WUnit& u, const float* xrow) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const f32x4 xv = lds4(xrow + 4 * j);
+        acc_a = mfma4(u.w[0][j].x, xv.x, acc_a);
+        acc_b = mfma4(u.w[1][j].x, xv.x, acc_b);
+        acc_a = mfma4(u.w[0][j].y, xv.y, acc_a);
+        acc_b = mfma4(u.w[1][j].y, xv.y, acc_b);
+        acc_a = mfma4(u.w[0][j].z, xv.z, acc_a);
+        acc_b = mfma4(u.w[1][j].z, xv.z, acc_b);
+        acc_a = mfma4(u.w[0][j].w, xv.w, acc_a);
+        acc_b = mfma4(u.w[1][j].w, xv.w, acc_b);
+    }
+}
+
+// bias for the 4 features a lane holds of tile `tile`
+__device__ __forceinline__ f32x4 bias4(const float* __restrict__ b, int tile, int lane) {
+    return ldg4(b + tile * 16 + (lane >> 4) * 4);
+}
+
+// pointer into a row-major LDS tile for the 4 features this lane holds of tile `tile`
+__device__ __forceinline__ float* cptr(float* base, int ld, int tile, int lane) {
+    return base + (lane & 15) * ld + tile * 16 + (lane >> 4) * 4;
+}
+
+// Un-pipelined Linear 128 -> 128 (used by one-time encoder kernels where latency does not matter).
+template <int K>
+__device__ __forceinline__ void linear128(f32x4 (&acc)[2], const float* __restrict__ wpk, const float* __restrict__ bias,
+                                          const float* xrow, int wave, int lane) {
+    static_assert(K == 128, "linear128 is the K = 128 form");
+    WUnit u;
+    wload(u, wstd(wpk, bias, wave), lane);
+    acc[0] = u.b[0];
+    acc[1] = u.b[1];
+    wmma(acc[0], acc[1], u, xrow);
+}
+
+// generic (un-pipelined) accumulate for odd shapes: K multiple of 16, NT tiles
 template <int K, int NT>
 __device__ __forceinline__ void gemm_acc(f32x4 (&acc)[NT], const float* __restrict__ wpk, const int (&tiles)[NT],
                                          const float* xrow, int lane) {
@@ -65,24 +163,14 @@ __device__ __forceinline__ void gemm_acc(f32x4 (&acc)[NT], const float* __restri
     }
 }
 
-// bias for the 4 features a lane holds of tile `tile`
-__device__ __forceinline__ f32x4 bias4(const float* __restrict__ b, int tile, int lane) {
-    return ldg4(b + tile * 16 + (lane >> 4) * 4);
-}
-
-// pointer into a row-major LDS tile for the 4 features this lane holds of tile `tile`
-__device__ __forceinline__ float* cptr(float* base, int ld, int tile, int lane) {
-    return base + (lane & 15) * ld + tile * 16 + (lane >> 4) * 4;
-}
-
-// Standard Linear 128 -> 128 of the 16-row tile: wave w owns tiles {2w, 2w+1}.
-template <int K>
-__device__ __forceinline__ void linear128(f32x4 (&acc)[2], const float* __restrict__ wpk, const float* __restrict__ bias,
-                                          const float* xrow, int wave, int lane) {
-    const int tiles[2] = {2 * wave, 2 * wave + 1};
-    acc[0] = bias4(bias, tiles[0], lane);
-    acc[1] = bias4(bias, tiles[1], lane);
-    gemm_acc<K, 2>(acc, wpk, tiles, xrow, lane);
+// sum over the 16 lanes of a DPP row (lanes 16r .. 16r+15); every lane gets the total.  quad xor 1, quad xor 2,
+// row_half_mirror, row_mirror -- four VALU+DPP ops instead of four ds_bpermute round trips.
+__device__ __forceinline__ float row16_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, true));
+    return v;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -92,29 +180,97 @@ __device__ __forceinline__ void layernorm_tile(const float* src, int lds_, float
                                                const float* __restrict__ g, const float* __restrict__ b, int tid) {
     const int row = tid >> 4, c0 = (tid & 15) * 8;
     const f32x4 a = lds4(src + row * lds_ + c0), c = lds4(src + row * lds_ + c0 + 4);
-    float s = (a.x + a.y) + (a.z + a.w) + (c.x + c.y) + (c.z + c.w);
-#pragma unroll
-    for (int o = 1; o < 16; o <<= 1) s += __shfl_xor(s, o);
+    const f32x4 g0 = ldg4(g + c0), g1 = ldg4(g + c0 + 4), b0 = ldg4(b + c0), b1 = ldg4(b + c0 + 4);
+    const float s = row16_sum((a.x + a.y) + (a.z + a.w) + (c.x + c.y) + (c.z + c.w));
     const float mean = s * (1.0f / 128.0f);
     const f32x4 da = a - splat(mean), dc = c - splat(mean);
-    float v = (da.x * da.x + da.y * da.y) + (da.z * da.z + da.w * da.w) + (dc.x * dc.x + dc.y * dc.y) + (dc.z * dc.z + dc.w * dc.w);
-#pragma unroll
-    for (int o = 1; o < 16; o <<= 1) v += __shfl_xor(v, o);
+    const float v = row16_sum((da.x * da.x + da.y * da.y) + (da.z * da.z + da.w * da.w) + (dc.x * dc.x + dc.y * dc.y) +
+                              (dc.z * dc.z + dc.w * dc.w));
     const float rstd = 1.0f / sqrtf(v * (1.0f / 128.0f) + LN_EPS);
-    const f32x4 g0 = ldg4(g + c0), g1 = ldg4(g + c0 + 4), b0 = ldg4(b + c0), b1 = ldg4(b + c0 + 4);
     st4(dst + row * ldd + c0, da * splat(rstd) * g0 + b0);
     st4(dst + row * ldd + c0 + 4, dc * splat(rstd) * g1 + b1);
 }
 
 // ---------------------------------------------------------------------------------------------
-// One attention head (this wave's) over n_key_pad keys with online softmax.
+// One attention head (this wave's) over n_key_pad keys (multiple of 32) with online softmax.
 //   q[tt][r]  = Q^T[h*32 + tt*16 + kq*4 + r][agent]  (this wave's Q-projection accumulators, bias added)
 //   Kmat      = [n_key_pad][128] row-major, VT = [128][n_key_pad] (keys contiguous), both in global (L2)
 //   keyvalid  = uint8 [n_key_pad] (0 for padding keys)
 //   self_key  = key index that equals THIS LANE's agent (eye mask of MultiAgentTF), or -1
 // Returns o[dt][r] = O^T[h*32 + dt*16 + kq*4 + r][agent] (already divided by the softmax sum) and
 // whether the agent row had no valid key at all (attention.py:101-107: its output is zeroed after out-proj).
+// K/V fragments of key tile t+2 are requested while tile t is being reduced (two register buffers).
 // ---------------------------------------------------------------------------------------------
+struct KVFrag {  // K / V^T fragments of 32 keys (two 16-key tiles) for one head
+    f32x4 ka[2][2], va[2][2];  // [tile][half of the 32 features]
+    uint32_t kv4[2];
+};
+
+__device__ __forceinline__ void kv_load(KVFrag& f, const float* __restrict__ kbase, const float* __restrict__ vbase,
+                                        const uint8_t* __restrict__ keyvalid, int n_key_pad, int k0, int kq) {
+    TB_SCHED_FENCE();
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        f.ka[t][0] = ldg4(kbase + (size_t)(k0 + 16 * t) * H);
+        f.ka[t][1] = ldg4(kbase + (size_t)(k0 + 16 * t) * H + 16);
+        f.va[t][0] = ldg4(vbase + k0 + 16 * t);
+        f.va[t][1] = ldg4(vbase + (size_t)16 * n_key_pad + k0 + 16 * t);
+        f.kv4[t] = *reinterpret_cast<const uint32_t*>(keyvalid + k0 + 16 * t + kq * 4);
+    }
+    TB_SCHED_FENCE();
+}
+
+// one online-softmax update over 32 keys: the two tiles' MFMA chains are interleaved (independent accumulators),
+// one running-max update / rescale per 32 keys
+__device__ __forceinline__ void attn_tile32(const KVFrag& f, const f32x4 (&q)[2], int kb, int self_key, float& run_max,
+                                            float& run_sum, f32x4 (&o)[2]) {
+    f32x4 s0 = splat(0.f), s1 = splat(0.f);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        s0 = mfma4(f.ka[0][h].x, q[h].x, s0);
+        s1 = mfma4(f.ka[1][h].x, q[h].x, s1);
+        s0 = mfma4(f.ka[0][h].y, q[h].y, s0);
+        s1 = mfma4(f.ka[1][h].y, q[h].y, s1);
+        s0 = mfma4(f.ka[0][h].z, q[h].z, s0);
+        s1 = mfma4(f.ka[1][h].z, q[h].z, s1);
+        s0 = mfma4(f.ka[0][h].w, q[h].w, s0);
+        s1 = mfma4(f.ka[1][h].w, q[h].w, s1);
+    }
+    // sv[t][r] = logit(key kb + 16 t + r, agent m)
+    float sv[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const bool ok = ((f.kv4[t] >> (8 * r)) & 0xffu) != 0 && (kb + 16 * t + r) != self_key;
+            sv[4 * t + r] = ok ? sv[4 * t + r] * ATTN_SCALE : -INFINITY;
+        }
+    float tmax = fmaxf(fmaxf(fmaxf(sv[0], sv[1]), fmaxf(sv[2], sv[3])), fmaxf(fmaxf(sv[4], sv[5]), fmaxf(sv[6], sv[7])));
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 16));
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+    const float new_max = fmaxf(run_max, tmax);
+    const bool dead = (new_max == -INFINITY);
+    const float alpha = dead ? 1.0f : expf(run_max - new_max);
+    float p[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) p[r] = dead ? 0.f : expf(sv[r] - new_max);
+    run_sum = run_sum * alpha + (((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7])));
+    run_max = new_max;
+    o[0] *= splat(alpha);
+    o[1] *= splat(alpha);
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        o[0] = mfma4(f.va[t][0].x, p[4 * t + 0], o[0]);
+        o[1] = mfma4(f.va[t][1].x, p[4 * t + 0], o[1]);
+        o[0] = mfma4(f.va[t][0].y, p[4 * t + 1], o[0]);
+        o[1] = mfma4(f.va[t][1].y, p[4 * t + 1], o[1]);
+        o[0] = mfma4(f.va[t][0].z, p[4 * t + 2], o[0]);
+        o[1] = mfma4(f.va[t][1].z, p[4 * t + 2], o[1]);
+        o[0] = mfma4(f.va[t][0].w, p[4 * t + 3], o[0]);
+        o[1] = mfma4(f.va[t][1].w, p[4 * t + 3], o[1]);
+    }
+}
+
 __device__ __forceinline__ bool attention_head(const f32x4 (&q)[2], const float* __restrict__ Kmat,
                                                const float* __restrict__ VT, const uint8_t* __restrict__ keyvalid,
                                                int n_key_pad, int head, int lane, int self_key, f32x4 (&o)[2]) {
@@ -124,48 +280,18 @@ __device__ __forceinline__ bool attention_head(const f32x4 (&q)[2], const float*
     o[1] = splat(0.f);
     const float* kbase = Kmat + (size_t)m * H + head * DHEAD + kq * 4;
     const float* vbase = VT + (size_t)(head * DHEAD + m) * n_key_pad + kq * 4;
-    for (int k0 = 0; k0 < n_key_pad; k0 += 16) {
-        const f32x4 ka0 = ldg4(kbase + (size_t)k0 * H), ka1 = ldg4(kbase + (size_t)k0 * H + 16);
-        const f32x4 va0 = ldg4(vbase + k0), va1 = ldg4(vbase + (size_t)16 * n_key_pad + k0);
-        const uint32_t kv4 = *reinterpret_cast<const uint32_t*>(keyvalid + k0 + kq * 4);
-        f32x4 s = splat(0.f);
-        s = mfma4(ka0.x, q[0].x, s);
-        s = mfma4(ka0.y, q[0].y, s);
-        s = mfma4(ka0.z, q[0].z, s);
-        s = mfma4(ka0.w, q[0].w, s);
-        s = mfma4(ka1.x, q[1].x, s);
-        s = mfma4(ka1.y, q[1].y, s);
-        s = mfma4(ka1.z, q[1].z, s);
-        s = mfma4(ka1.w, q[1].w, s);
-        // s[r] = logit(key k0 + kq*4 + r, agent m)
-        const int kb = k0 + kq * 4;
-        float sv[4] = {s.x, s.y, s.z, s.w};
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const bool ok = ((kv4 >> (8 * r)) & 0xffu) != 0 && (kb + r) != self_key;
-            sv[r] = ok ? sv[r] * ATTN_SCALE : -INFINITY;
+    KVFrag fa, fb;
+    kv_load(fa, kbase, vbase, keyvalid, n_key_pad, 0, kq);
+    // two register buffers: while one 32-key block is reduced the next is in flight
+    for (int k0 = 0; k0 < n_key_pad; k0 += 64) {
+        const int k1 = (k0 + 32 < n_key_pad) ? k0 + 32 : k0;
+        kv_load(fb, kbase, vbase, keyvalid, n_key_pad, k1, kq);
+        attn_tile32(fa, q, k0 + kq * 4, self_key, run_max, run_sum, o);
+        if (k0 + 32 < n_key_pad) {
+            const int k2 = (k0 + 64 < n_key_pad) ? k0 + 64 : k0;
+            kv_load(fa, kbase, vbase, keyvalid, n_key_pad, k2, kq);
+            attn_tile32(fb, q, k1 + kq * 4, self_key, run_max, run_sum, o);
         }
-        float tmax = fmaxf(fmaxf(sv[0], sv[1]), fmaxf(sv[2], sv[3]));
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 16));
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
-        const float new_max = fmaxf(run_max, tmax);
-        const bool dead = (new_max == -INFINITY);
-        const float alpha = dead ? 1.0f : expf(run_max - new_max);
-        float p[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) p[r] = dead ? 0.f : expf(sv[r] - new_max);
-        run_sum = run_sum * alpha + ((p[0] + p[1]) + (p[2] + p[3]));
-        run_max = new_max;
-        o[0] *= splat(alpha);
-        o[1] *= splat(alpha);
-        o[0] = mfma4(va0.x, p[0], o[0]);
-        o[0] = mfma4(va0.y, p[1], o[0]);
-        o[0] = mfma4(va0.z, p[2], o[0]);
-        o[0] = mfma4(va0.w, p[3], o[0]);
-        o[1] = mfma4(va1.x, p[0], o[1]);
-        o[1] = mfma4(va1.y, p[1], o[1]);
-        o[1] = mfma4(va1.z, p[2], o[1]);
-        o[1] = mfma4(va1.w, p[3], o[1]);
     }
     run_sum += __shfl_xor(run_sum, 16);
     run_sum += __shfl_xor(run_sum, 32);
@@ -192,33 +318,48 @@ struct GruLayerW {
 // One pre-LN cross-attention layer (transformer.py:189-239 + attention.py:81-146) on the LDS tile X.
 //   X    : [16][LDT] residual stream (in/out)         S1, S2 : [16][LDT] scratch
 //   Kmat/VT/keyvalid : projected keys / values of the tile's group for THIS layer
-//   row_invalid(row) comes from rowvalid[] (LDS uint8[16]); invalid rows are zeroed at the end.
-//   novalid_s : LDS uint8[16] scratch.   self_key0: key index of row 0 for the eye mask, or -1 for none.
+//   rowvalid : LDS uint8[16]; invalid rows are zeroed at the end.   novalid_s : LDS uint8[16] scratch.
+//   self_key0: key index of row 0 for the eye mask, or -1 for none.
+//   u : in = this layer's Wq unit (already requested), out = `nxt` requested.
 // All 256 threads must call.  Ends with a barrier.
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ void xattn_layer(const float* __restrict__ W, const XLayerW& L, float* X, float* S1, float* S2,
                                             const float* __restrict__ Kmat, const float* __restrict__ VT,
                                             const uint8_t* __restrict__ keyvalid, int n_key_pad, int self_key0,
-                                            const uint8_t* rowvalid, uint8_t* novalid_s, int tid) {
+                                            const uint8_t* rowvalid, uint8_t* novalid_s, int tid, WUnit& u, const WNext& nxt,
+                                            long long* prof = nullptr) {
     const int wave = tid >> 6, lane = tid & 63;
     const int kq = lane >> 4, m = lane & 15;
+#ifdef TB_PROFILE
+#define TB_XSTAMP(i) do { if (prof && threadIdx.x == 0) prof[i] = clock64(); } while (0)
+#else
+#define TB_XSTAMP(i) do { } while (0)
+#endif
+    TB_XSTAMP(16);
     // s = LN1(x)
     layernorm_tile(X, LDT, S1, LDT, W + L.ln1_g, W + L.ln1_b, tid);
     __syncthreads();
+    TB_XSTAMP(17);
+    WUnit u2;
     // q (this wave = head `wave`)
-    f32x4 q[2];
-    linear128<128>(q, W + L.wq, W + L.bq, S1 + m * LDT + kq * 32, wave, lane);
+    f32x4 q[2] = {u.b[0], u.b[1]};
+    wload(u2, wstd(W + L.wo, W + L.bo, wave), lane);
+    wmma(q[0], q[1], u, S1 + m * LDT + kq * 32);
+    TB_XSTAMP(18);
     f32x4 o[2];
     const bool novalid = attention_head(q, Kmat, VT, keyvalid, n_key_pad, wave, lane,
                                         self_key0 >= 0 ? self_key0 + m : -1, o);
+    TB_XSTAMP(19);
     st4(cptr(S2, LDT, 2 * wave, lane), o[0]);
     st4(cptr(S2, LDT, 2 * wave + 1, lane), o[1]);
     if (wave == 0 && kq == 0) novalid_s[m] = novalid ? 1 : 0;
     __syncthreads();
+    TB_XSTAMP(20);
     // out-proj + residual
     {
-        f32x4 acc[2];
-        linear128<128>(acc, W + L.wo, W + L.bo, S2 + m * LDT + kq * 32, wave, lane);
+        f32x4 acc[2] = {u2.b[0], u2.b[1]};
+        wload(u, wstd(W + L.w1, W + L.b1, wave), lane);
+        wmma(acc[0], acc[1], u2, S2 + m * LDT + kq * 32);
         const bool nv = novalid_s[m] != 0;
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
@@ -228,19 +369,24 @@ __device__ __forceinline__ void xattn_layer(const float* __restrict__ W, const X
         }
     }
     __syncthreads();
+    TB_XSTAMP(21);
     // FFN
     layernorm_tile(X, LDT, S1, LDT, W + L.ln2_g, W + L.ln2_b, tid);
     __syncthreads();
+    TB_XSTAMP(22);
     {
-        f32x4 acc[2];
-        linear128<128>(acc, W + L.w1, W + L.b1, S1 + m * LDT + kq * 32, wave, lane);
+        f32x4 acc[2] = {u.b[0], u.b[1]};
+        wload(u2, wstd(W + L.w2, W + L.b2, wave), lane);
+        wmma(acc[0], acc[1], u, S1 + m * LDT + kq * 32);
         st4(cptr(S2, LDT, 2 * wave, lane), relu4(acc[0]));
         st4(cptr(S2, LDT, 2 * wave + 1, lane), relu4(acc[1]));
     }
     __syncthreads();
+    TB_XSTAMP(23);
     {
-        f32x4 acc[2];
-        linear128<128>(acc, W + L.w2, W + L.b2, S2 + m * LDT + kq * 32, wave, lane);
+        f32x4 acc[2] = {u2.b[0], u2.b[1]};
+        wload(u, nxt, lane);
+        wmma(acc[0], acc[1], u2, S2 + m * LDT + kq * 32);
         const bool rv = rowvalid[m] != 0;
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
@@ -250,26 +396,39 @@ __device__ __forceinline__ void xattn_layer(const float* __restrict__ W, const X
         }
     }
     __syncthreads();
+    TB_XSTAMP(24);
 }
+
+// first unit of a cross-attention layer / of a K-V projection for wave `wave`
+__device__ __forceinline__ WNext xlayer_first(const float* W, const XLayerW& L, int wave) { return wstd(W + L.wq, W + L.bq, wave); }
+__device__ __forceinline__ WNext kvproj_first(const float* W, const XLayerW& L, int wave) { return wstd(W + L.wkv, W + L.bkv, wave); }
 
 // ---------------------------------------------------------------------------------------------
 // K/V projection of a 16-token tile for one layer: LN_tgt -> in_proj rows 128:384.
 //   T : [16][LDT] token features (LDS), S1 scratch.  Writes Kmat rows [tok0, tok0+16) and VT columns.
-//   Rows >= n_tok_valid_rows (padding tokens) are written as zeros.
-// Wave w produces K tiles {2w,2w+1} and V tiles {8+2w, 8+2w+1} (head w).  Ends with a barrier.
+//   Rows >= n_real_rows (padding tokens) are written as zeros.
+// Wave w produces K tiles {2w,2w+1} and V tiles {8+2w, 8+2w+1} (head w).
+//   u : in = the K unit (tiles 2w, 2w+1 of wkv), out = `nxt`.   Ends with a barrier.
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ void kv_project_tile(const float* __restrict__ W, const XLayerW& L, const float* T, float* S1,
                                                 float* __restrict__ Kmat, float* __restrict__ VT, int n_key_pad, int tok0,
-                                                int n_real_rows, int tid) {
+                                                int n_real_rows, int tid, WUnit& u, const WNext& nxt) {
     const int wave = tid >> 6, lane = tid & 63;
     const int kq = lane >> 4, m = lane & 15;
     layernorm_tile(T, LDT, S1, LDT, W + L.lnt_g, W + L.lnt_b, tid);
     __syncthreads();
     const int tiles[4] = {2 * wave, 2 * wave + 1, 8 + 2 * wave, 8 + 2 * wave + 1};
+    WUnit u2;
     f32x4 acc[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) acc[t] = bias4(W + L.bkv, tiles[t], lane);
-    gemm_acc<128, 4>(acc, W + L.wkv, tiles, S1 + m * LDT + kq * 32, lane);
+    acc[0] = u.b[0];
+    acc[1] = u.b[1];
+    wload(u2, wnext(W + L.wkv, W + L.bkv, tiles[2], tiles[3]), lane);
+    const float* xr = S1 + m * LDT + kq * 32;
+    wmma(acc[0], acc[1], u, xr);
+    acc[2] = u2.b[0];
+    acc[3] = u2.b[1];
+    wload(u, nxt, lane);
+    wmma(acc[2], acc[3], u2, xr);
     const bool real = m < n_real_rows;
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
@@ -291,40 +450,52 @@ __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf
 // ---------------------------------------------------------------------------------------------
 // One GRU layer step (PyTorch gate order r,z,n; agent_temporal.py:147-152 -> nn.GRU):
 //   Xin : [16][LDT] layer input, Hs : [16][LDT] previous hidden of this layer, Out : [16][LDT] new hidden
-// Wave w owns features [32w, 32w+32) of every gate.  Caller barriers before (inputs ready) -- ends with a barrier.
+// Wave w owns features [32w, 32w+32) of every gate; six weight units stream through two register buffers.
+//   u : in = W_ih r-unit (tiles 2w, 2w+1), out = `nxt`.
+// Caller barriers before (inputs ready) -- ends with a barrier.
 // ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ WNext gru_first(const float* W, const GruLayerW& G, int wave) { return wstd(W + G.wih, W + G.bih, wave); }
+
 __device__ __forceinline__ void gru_layer(const float* __restrict__ W, const GruLayerW& G, const float* Xin, const float* Hs,
                                           float* Out, const uint8_t* rowvalid, float* __restrict__ h_global /*[rows][128]*/,
-                                          int n_real_rows, int tid) {
+                                          int n_real_rows, int tid, WUnit& u, const WNext& nxt) {
     const int wave = tid >> 6, lane = tid & 63;
     const int kq = lane >> 4, m = lane & 15;
-    const int t_rz[4] = {2 * wave, 2 * wave + 1, 8 + 2 * wave, 8 + 2 * wave + 1};
-    const int t_n[2] = {16 + 2 * wave, 16 + 2 * wave + 1};
-    f32x4 rz[4], gin[2], ghn[2];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) rz[t] = bias4(W + G.bih, t_rz[t], lane) + bias4(W + G.bhh, t_rz[t], lane);
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        gin[t] = bias4(W + G.bih, t_n[t], lane);
-        ghn[t] = bias4(W + G.bhh, t_n[t], lane);
-    }
+    const int tr0 = 2 * wave, tz0 = 8 + 2 * wave, tn0 = 16 + 2 * wave;
     const float* xr = Xin + m * LDT + kq * 32;
     const float* hr = Hs + m * LDT + kq * 32;
-    gemm_acc<128, 4>(rz, W + G.wih, t_rz, xr, lane);
-    gemm_acc<128, 4>(rz, W + G.whh, t_rz, hr, lane);
-    gemm_acc<128, 2>(gin, W + G.wih, t_n, xr, lane);
-    gemm_acc<128, 2>(ghn, W + G.whh, t_n, hr, lane);
+    WUnit u2;
+    f32x4 r[2], z[2], gin[2], ghn[2];
+    const float* wih = W + G.wih; const float* whh = W + G.whh; const float* bih = W + G.bih; const float* bhh = W + G.bhh;
+    r[0] = u.b[0]; r[1] = u.b[1];
+    wload(u2, wnext(whh, bhh, tr0, tr0 + 1), lane);
+    wmma(r[0], r[1], u, xr);
+    r[0] += u2.b[0]; r[1] += u2.b[1];
+    wload(u, wnext(wih, bih, tz0, tz0 + 1), lane);
+    wmma(r[0], r[1], u2, hr);
+    z[0] = u.b[0]; z[1] = u.b[1];
+    wload(u2, wnext(whh, bhh, tz0, tz0 + 1), lane);
+    wmma(z[0], z[1], u, xr);
+    z[0] += u2.b[0]; z[1] += u2.b[1];
+    wload(u, wnext(wih, bih, tn0, tn0 + 1), lane);
+    wmma(z[0], z[1], u2, hr);
+    gin[0] = u.b[0]; gin[1] = u.b[1];
+    wload(u2, wnext(whh, bhh, tn0, tn0 + 1), lane);
+    wmma(gin[0], gin[1], u, xr);
+    ghn[0] = u2.b[0]; ghn[1] = u2.b[1];
+    wload(u, nxt, lane);
+    wmma(ghn[0], ghn[1], u2, hr);
     const bool rv = rowvalid[m] != 0;
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
         const f32x4 hold = lds4(Hs + m * LDT + (2 * wave + t) * 16 + kq * 4);
         f32x4 hn;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float rg = sigmoidf_(rz[t][r]);
-            const float zg = sigmoidf_(rz[2 + t][r]);
-            const float ng = tanhf(gin[t][r] + rg * ghn[t][r]);
-            hn[r] = rv ? (1.0f - zg) * ng + zg * hold[r] : 0.f;
+        for (int q = 0; q < 4; ++q) {
+            const float rg = sigmoidf_(r[t][q]);
+            const float zg = sigmoidf_(z[t][q]);
+            const float ng = tanhf(gin[t][q] + rg * ghn[t][q]);
+            hn[q] = rv ? (1.0f - zg) * ng + zg * hold[q] : 0.f;
         }
         st4(cptr(Out, LDT, 2 * wave + t, lane), hn);
         if (m < n_real_rows) st4(h_global + (size_t)m * H + (2 * wave + t) * 16 + kq * 4, hn);

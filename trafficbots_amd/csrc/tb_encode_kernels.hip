@@ -168,11 +168,15 @@ __global__ __launch_bounds__(NTHREADS) void k_xattn_block(XBlockP p) {
         __syncthreads();
     }
     if (!bypass) {
+        const int wave = tid >> 6, lane = tid & 63;
+        WUnit u;
+        wload(u, xlayer_first(p.W, p.L[0], wave), lane);
 #pragma unroll 1
         for (int l = 0; l < p.n_layer; ++l) {
+            const WNext nxt = xlayer_first(p.W, p.L[l + 1 < p.n_layer ? l + 1 : l], wave);
             xattn_layer(p.W, p.L[l], X, S1, S2, p.K + ((size_t)g * p.n_layer + l) * p.n_pad * H,
                         p.VT + ((size_t)g * p.n_layer + l) * H * p.n_pad, p.kvalid + (size_t)g * p.n_pad, p.n_pad,
-                        p.eye ? row0 : -1, rowvalid, novalid_s, tid);
+                        p.eye ? row0 : -1, rowvalid, novalid_s, tid, u, nxt);
         }
     }
     store_tile(p.dst + ((size_t)g * p.n_rows + row0) * H, X, LDT, n_real, tid);
@@ -192,9 +196,14 @@ __global__ __launch_bounds__(NTHREADS) void k_kv_hoist_n(const float* __restrict
     if (tid < TM) kvalid[(size_t)g * n_pad + tok0 + tid] = (tid < n_real) ? fvalid[(size_t)g * n_tok + tok0 + tid] : 0;
     __syncthreads();
     const XLayerW* Ls[3] = {&l0, &l1, &l2};
+    const int wave = tid >> 6, lane = tid & 63;
+    WUnit u;
+    wload(u, kvproj_first(W, l0, wave), lane);
+#pragma unroll 1
     for (int l = 0; l < n_layer; ++l) {
+        const WNext nxt = kvproj_first(W, *Ls[l + 1 < n_layer ? l + 1 : l], wave);
         kv_project_tile(W, *Ls[l], T, S1, Kout + ((size_t)g * n_layer + l) * n_pad * H, VTout + ((size_t)g * n_layer + l) * H * n_pad,
-                        n_pad, tok0, n_real, tid);
+                        n_pad, tok0, n_real, tid, u, nxt);
     }
 }
 
@@ -279,6 +288,9 @@ __global__ __launch_bounds__(NTHREADS) void k_gru_scan(ScanP p) {
     if (tid < TM) anyvalid[tid] = 0;
     __syncthreads();
     float* scratch_g = nullptr;
+    WUnit u;
+    wload(u, gru_first(p.W, p.gru[0], wave), lane);
+#pragma unroll 1
     for (int s = 0; s < p.S; ++s) {
         load_tile(X, LDT, p.x + (((size_t)b * p.S + s) * p.A + row0) * H, n_real, tid);
         if (tid < TM) {
@@ -290,10 +302,11 @@ __global__ __launch_bounds__(NTHREADS) void k_gru_scan(ScanP p) {
         // three layers; each layer's new hidden replaces HS[l] (copy after the layer's barrier)
         float* in = X;
         float* outs[3] = {Y0, Y1, Y0};
+#pragma unroll 1
         for (int l = 0; l < 3; ++l) {
             float* hs = HS + l * TM * LDT;
             // gru_layer writes hidden to a global pointer too; route that to a dummy by n_real_rows = 0
-            gru_layer(p.W, p.gru[l], in, hs, outs[l], rowvalid, scratch_g, 0, tid);
+            gru_layer(p.W, p.gru[l], in, hs, outs[l], rowvalid, scratch_g, 0, tid, u, gru_first(p.W, p.gru[(l + 1) % 3], wave));
             for (int i = tid; i < TM * 32; i += NTHREADS) {
                 const int r = i >> 5, c4 = (i & 31) * 4;
                 st4(hs + r * LDT + c4, lds4(outs[l] + r * LDT + c4));
@@ -469,7 +482,7 @@ int run_encode(struct ::tb_ctx* ctx, const tb_encode_io* io, hipStream_t s) {
         if (!q) return tb_fail(ctx, "tb_encode_scene: a required buffer pointer is NULL");
     const float* W = ctx->d_arena;
     const EncoderW& ew = ctx->ew;
-    const int a_pad = pad16(A), p_pad = pad16(P), t_pad = pad16(T);
+    const int a_pad = padk(A), p_pad = padk(P), t_pad = padk(T);
     const int S3 = (NH - 1) / 5 + 1;  // steps {0,5,10} (latent_encoder.py:98-103)
     // map-encoder chunking bounds the per-polyline K/V scratch (3 layers x 32 keys x 128 x 2 x 4 B = 96 KiB / polyline)
     const int scenes_per_chunk = std::max(1, std::min(B, (int)(((size_t)512 << 20) / ((size_t)P * 98304))));

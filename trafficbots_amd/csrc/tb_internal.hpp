@@ -25,6 +25,7 @@ struct tb_ctx {
     // workspace
     char* d_ws = nullptr;
     size_t ws_bytes = 0;
+    long long* last_prof = nullptr;
     // timing
     bool timing = false;
     std::vector<hipEvent_t> ev;
@@ -62,4 +63,4 @@ struct Carver {
 };
 
 int tb_ensure_workspace(tb_ctx* ctx, size_t bytes);
-inline int pad16(int x) { return (x + 15) / 16 * 16; }
+inline int padk(int x) { return (x + 31) / 32 * 32; }  // key counts / row counts are padded to 32 (tb::KEYPAD)

@@ -74,6 +74,9 @@ struct RolloutP {
     float* vtin;                  // [N,3,128,a_pad]
     float* goal_pre;              // [N,a_pad,128]
     float* lat_pre;               // [N,a_pad,128]
+    float* dest_geo;              // [N,a_pad,20,4] destination polyline nodes: px, py, unit dir x, unit dir y
+    int* dest_flag;               // [N,a_pad] bit0: lane-type destination, bit1: road-edge destination
+    long long* prof;              // [n_blocks][32] stage time stamps (only written by -DTB_PROFILE builds)
     // outputs
     float* preds;                 // [N,A,S,4]
     uint8_t* o_valid;

@@ -1,10 +1,16 @@
-// Rollout kernels (gfx950).  Per simulation step two launches, cut at the only all-to-all seam of the
-// step (every agent's interaction layer needs K/V of all agents of its scene):
-//   step_a : agent attr + pose PE + InputPeEncoder -> 3x agent->map attn -> 3x agent->TL attn
-//            -> x_mid and the 3 interaction layers' K/V of the tile's agents          (rows independent)
-//   step_c : 3x agent<->agent attn -> 3-layer GRU -> add_goal -> add_latent -> action head ->
-//            unicycle dynamics -> teacher forcing -> rule check / kill / navigator -> buffer writes
-// One workgroup (4 waves) owns 16 agents of one rollout instance; grid = (a_pad/16, N).
+// Rollout kernels (gfx950).  The only all-to-all seam of a simulation step is the agent<->agent interaction
+// (every agent needs K/V of all agents of its scene); everything else is independent per agent.  So a step is
+// cut there and the two halves of CONSECUTIVE steps are fused into one launch:
+//
+//   k_step(t) :  [C(t)]  3x agent<->agent attn -> 3-layer GRU -> add_goal -> add_latent -> action head ->
+//                        unicycle dynamics -> teacher forcing -> rule check / kill / navigator -> buffer writes
+//                [A(t+1)] agent attr + pose PE + InputPeEncoder -> 3x agent->map attn -> 3x agent->TL attn
+//                        -> x_mid and the three interaction layers' K/V of the tile's agents
+//
+// One workgroup (4 waves) owns 16 agents of one rollout instance for the whole launch; grid = (a_pad/16, N);
+// S+1 launches per rollout (A(1) alone, S-1 fused, C(S) alone), no host synchronisation.
+// Weights stream as register units one unit ahead of the MFMAs (tb_device.hpp); the unit chain runs straight
+// through all stages of the launch.
 #include "tb_rollout.hpp"
 
 namespace tb {
@@ -16,8 +22,25 @@ constexpr int OFF_S2 = OFF_S1 + TM * LDT;  // [16][LDT]
 constexpr int OFF_H = OFF_S2 + TM * LDT;   // [16][LDT] GRU previous hidden
 constexpr int OFF_Y = OFF_H + TM * LDT;    // [16][LDT] GRU out ping
 constexpr int OFF_CAT = OFF_Y + TM * LDT;  // [16][LDC] concat tile
-constexpr int OFF_SMALL = OFF_CAT + TM * LDC;
-constexpr int STEP_LDS_FLOATS = OFF_SMALL + 16 * 16 /*attr*/ + 16 * 32 /*enc hidden*/ + 64 /*u*/ + 64;
+constexpr int OFF_H1 = OFF_CAT + TM * LDC; // [16][LDT] GRU hidden layer 1
+constexpr int OFF_H2 = OFF_H1 + TM * LDT;  // [16][LDT] GRU hidden layer 2
+constexpr int OFF_GP = OFF_H2 + TM * LDT;  // [16][LDT] add_goal.mlp_in output of the tile's agents
+constexpr int OFF_LP = OFF_GP + TM * LDT;  // [16][LDT] add_latent.mlp_in output
+constexpr int OFF_DG = OFF_LP + TM * LDT;  // [16][80]  destination polyline geometry (20 nodes x px,py,dx,dy)
+constexpr int OFF_SMALL = OFF_DG + TM * 80;
+constexpr int SMALL_FLOATS = 16 * 16 /*attr*/ + 16 * 32 /*enc hidden*/ + 16 * 8 /*row state*/ + 32 /*u*/ + 64 /*flags,types*/;
+constexpr int STEP_LDS_FLOATS = OFF_SMALL + SMALL_FLOATS;
+
+#ifdef TB_PROFILE
+#define TB_STAMP(i)                                                                                        \
+    do {                                                                                                   \
+        if (threadIdx.x == 0) p.prof[(size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 32 + (i)] = clock64(); \
+    } while (0)
+#else
+#define TB_STAMP(i) \
+    do {            \
+    } while (0)
+#endif
 
 __device__ __forceinline__ float fmul_(float a, float b) { return __fmul_rn(a, b); }
 __device__ __forceinline__ float fadd_(float a, float b) { return __fadd_rn(a, b); }
@@ -37,17 +60,19 @@ __global__ __launch_bounds__(NTHREADS) void k_kv_hoist(const float* __restrict__
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* T = smem;
     float* S1 = smem + TM * LDT;
-    const int tid = threadIdx.x, g = blockIdx.y, tok0 = blockIdx.x * TM;
-    const int n_real = min(TM, n_tok - tok0);
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, g = blockIdx.y, tok0 = blockIdx.x * TM;
+    const int n_real = max(0, min(TM, n_tok - tok0));
+    WUnit u;
+    wload(u, kvproj_first(W, l0, wave), lane);
     load_tile(T, LDT, feat + ((size_t)g * n_tok + tok0) * H, n_real, tid);
     if (tid < TM) kvalid[(size_t)g * n_pad + tok0 + tid] = (tid < n_real) ? fvalid[(size_t)g * n_tok + tok0 + tid] : 0;
     __syncthreads();
-    const XLayerW* Ls[3] = {&l0, &l1, &l2};
-#pragma unroll
-    for (int l = 0; l < 3; ++l) {
-        kv_project_tile(W, *Ls[l], T, S1, Kout + ((size_t)g * 3 + l) * n_pad * H, VTout + ((size_t)g * 3 + l) * H * n_pad,
-                        n_pad, tok0, n_real, tid);
-    }
+    kv_project_tile(W, l0, T, S1, Kout + ((size_t)g * 3 + 0) * n_pad * H, VTout + ((size_t)g * 3 + 0) * H * n_pad, n_pad, tok0,
+                    n_real, tid, u, kvproj_first(W, l1, wave));
+    kv_project_tile(W, l1, T, S1, Kout + ((size_t)g * 3 + 1) * n_pad * H, VTout + ((size_t)g * 3 + 1) * H * n_pad, n_pad, tok0,
+                    n_real, tid, u, kvproj_first(W, l2, wave));
+    kv_project_tile(W, l2, T, S1, Kout + ((size_t)g * 3 + 2) * n_pad * H, VTout + ((size_t)g * 3 + 2) * H * n_pad, n_pad, tok0,
+                    n_real, tid, u, kvproj_first(W, l2, wave));
 }
 
 // simulator init (Dynamics.init, dynamics.py:29-48; TrafficBots.init, traffic_bots.py:153-161) +
@@ -61,7 +86,7 @@ __global__ __launch_bounds__(NTHREADS) void k_rollout_init(RolloutP p) {
     float* Z = smem + OFF_H;  // [16][20]
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, kq = lane >> 4, m = lane & 15;
     const int n = blockIdx.y, b = n / p.k_rep, row0 = blockIdx.x * TM;
-    const int n_real = min(TM, p.n_agent - row0);
+    const int n_real = max(0, min(TM, p.n_agent - row0));
     const float* W = p.W;
     const PolicyW& pw = p.pw;
     // ---- state init from history frame 0
@@ -117,6 +142,31 @@ __global__ __launch_bounds__(NTHREADS) void k_rollout_init(RolloutP p) {
         }
         p.o_latent_logp[(size_t)n * p.n_agent + row] = lp;
     }
+    // ---- destination polyline geometry per agent, gathered once (traffic_rule_checker.py:85-98): node position,
+    // unit direction (dir / |dir|); invalid nodes get a far position and a zero direction so both tests fail
+    for (int i = tid; i < TM * 20; i += NTHREADS) {
+        const int r = i / 20, k = i % 20;
+        f32x4 g = f32x4{1e30f, 1e30f, 0.f, 0.f};
+        if (r < n_real) {
+            const int d = p.dest[(size_t)n * p.n_agent + row0 + r];
+            const size_t nb = ((size_t)b * p.n_pl + d) * 20 + k;
+            if (p.map_valid[nb]) {
+                const float ddx = p.map_dir[nb * 2], ddy = p.map_dir[nb * 2 + 1];
+                const float nrm = sqrtf(fadd_(fmul_(ddx, ddx), fmul_(ddy, ddy)));
+                g = f32x4{p.map_pos[nb * 2], p.map_pos[nb * 2 + 1], ddx / nrm, ddy / nrm};
+            }
+        }
+        st4(p.dest_geo + (((size_t)n * p.a_pad + row0 + r) * 20 + k) * 4, g);
+    }
+    if (tid < TM) {
+        int fl = 0;
+        if (tid < n_real) {
+            const int d = p.dest[(size_t)n * p.n_agent + row0 + tid];
+            const int dty = p.map_type[(size_t)b * p.n_pl + d];
+            fl = (dty >= 0 && dty < 4 ? 1 : 0) | (dty == 4 ? 2 : 0);
+        }
+        p.dest_flag[(size_t)n * p.a_pad + row0 + tid] = fl;
+    }
     // ---- add_goal.mlp_in : 3 x (Linear128 -> LN [-> ReLU]) ; last LN output is stored un-masked, the mask and
     // the trailing ReLU (mlp.py:80-84) are applied per step because goal_valid changes.
     float* cur = X;
@@ -145,7 +195,7 @@ __global__ __launch_bounds__(NTHREADS) void k_rollout_init(RolloutP p) {
         const int tiles[2] = {2 * wave, 2 * wave + 1};
         f32x4 acc[2] = {bias4(W + pw.lat_in_b1, tiles[0], lane), bias4(W + pw.lat_in_b1, tiles[1], lane)};
         gemm_acc<16, 2>(acc, W + pw.lat_in_w1, tiles, Z + m * 20 + kq * 4, lane);
-        __syncthreads();  // goal tile stores above read `cur`; S2 is free again after this barrier
+        __syncthreads();
         st4(cptr(S2, LDT, tiles[0], lane), relu4(acc[0]));
         st4(cptr(S2, LDT, tiles[1], lane), relu4(acc[1]));
         __syncthreads();
@@ -157,56 +207,359 @@ __global__ __launch_bounds__(NTHREADS) void k_rollout_init(RolloutP p) {
     }
 }
 
+// final simulator state -> caller buffers (Dynamics.agent_state / agent_valid, TrafficBots.hidden)
+__global__ void k_rollout_final(RolloutP p, float* __restrict__ f_state, uint8_t* __restrict__ f_valid, float* __restrict__ f_hidden) {
+    const int n = blockIdx.x;
+    for (int a = threadIdx.x; a < p.n_agent; a += blockDim.x) {
+        const size_t si = (size_t)n * p.a_pad + a, di = (size_t)n * p.n_agent + a;
+        if (f_state) st4(f_state + di * 4, ldg4(p.state + si * 4));
+        if (f_valid) f_valid[di] = p.valid[si];
+    }
+    if (f_hidden) {
+        for (int l = 0; l < 3; ++l)
+            for (int i = threadIdx.x; i < p.n_agent * 32; i += blockDim.x) {
+                const int a = i >> 5, c4 = (i & 31) * 4;
+                st4(f_hidden + (((size_t)l * p.n_inst + n) * p.n_agent + a) * H + c4,
+                    ldg4(p.hidden + (((size_t)l * p.n_inst + n) * p.a_pad + a) * H + c4));
+            }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
-// step kernel A
+// h = relu(W2 relu(W1 [x ; u] + b1) + b2); h = zvalid ? h : 0; x = rowvalid ? h + x : 0   (add_latent_goal.py:57-77)
+//   PRE : [16][LDT] LDS copy of mlp_in's (un-masked) output for the tile's agents
+//   uw : in = first half (k 0..127) of W1 (carries b1), out = `nxt`
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(NTHREADS) void k_step_a(RolloutP p, int t) {
+__device__ __forceinline__ void fuse_latent_goal(const float* __restrict__ W, uint32_t w1, uint32_t w2, uint32_t b2, float* X, float* CAT,
+                                                 float* S2, const float* PRE, const uint8_t* zvalid, const uint8_t* rowvalid, int tid,
+                                                 WUnit& uw, const WNext& nxt, long long* prof = nullptr) {
+    const int wave = tid >> 6, lane = tid & 63, kq = lane >> 4, m = lane & 15;
+    // CAT = [x ; relu(mask(pre))]
+    for (int i = tid; i < TM * 32; i += NTHREADS) {
+        const int r = i >> 5, c4 = (i & 31) * 4;
+        st4(CAT + r * LDC + c4, lds4(X + r * LDT + c4));
+        st4(CAT + r * LDC + 128 + c4, zvalid[r] ? relu4(lds4(PRE + r * LDT + c4)) : splat(0.f));
+    }
+    __syncthreads();
+#ifdef TB_PROFILE
+    if (prof && threadIdx.x == 0) prof[12] = clock64();
+#endif
+    WUnit u2;
+    {
+        const int ta = 2 * wave, tb_ = 2 * wave + 1;
+        f32x4 acc[2] = {uw.b[0], uw.b[1]};
+        wload(u2, wnext(W + w1, nullptr, ta, tb_, 16, 8), lane);
+        const float* xr = CAT + m * LDC + kq * 64;
+        wmma(acc[0], acc[1], uw, xr);
+#ifdef TB_PROFILE
+        if (prof && threadIdx.x == 0) prof[13] = clock64();
+#endif
+        wload(uw, wstd(W + w2, W + b2, wave), lane);
+        wmma(acc[0], acc[1], u2, xr + 32);
+#ifdef TB_PROFILE
+        if (prof && threadIdx.x == 0) prof[14] = clock64();
+#endif
+        st4(cptr(S2, LDT, ta, lane), relu4(acc[0]));
+        st4(cptr(S2, LDT, tb_, lane), relu4(acc[1]));
+    }
+    __syncthreads();
+#ifdef TB_PROFILE
+    if (prof && threadIdx.x == 0) prof[15] = clock64();
+#endif
+    {
+        f32x4 acc[2] = {uw.b[0], uw.b[1]};
+        wload(u2, nxt, lane);
+        wmma(acc[0], acc[1], uw, S2 + m * LDT + kq * 32);
+        const bool zv = zvalid[m] != 0, rv = rowvalid[m] != 0;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            float* px = cptr(X, LDT, 2 * wave + t, lane);
+            const f32x4 h = zv ? relu4(acc[t]) : splat(0.f);
+            st4(px, rv ? h + lds4(px) : splat(0.f));
+        }
+        uw = u2;
+    }
+    __syncthreads();
+}
+
+// per-row simulator state carried in LDS between the C and the A half of a launch
+struct RowSt {
+    float st[4];   // x, y, yaw, spd
+    float aux[4];  // vel_x, vel_y, acc, yaw_rate as last teacher-forced
+};
+
+// ------------------------------------------------------------------------------------------------
+// the step kernel
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(NTHREADS) void k_step(RolloutP p, int t, int do_c, int do_a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* X = smem + OFF_X;
     float* S1 = smem + OFF_S1;
     float* S2 = smem + OFF_S2;
-    float* attr = smem + OFF_SMALL;          // [16][16]
-    float* ench = attr + 16 * 16;            // [16][32]
-    uint8_t* rowvalid = reinterpret_cast<uint8_t*>(ench + 16 * 32);  // [16]
-    uint8_t* novalid_s = rowvalid + 16;                              // [16]
-    float* pose = reinterpret_cast<float*>(rowvalid + 32);           // [16][4]  x,y,yaw,-
+    float* Hs = smem + OFF_H;
+    float* Y = smem + OFF_Y;
+    float* CAT = smem + OFF_CAT;
+    float* H1 = smem + OFF_H1;
+    float* H2 = smem + OFF_H2;
+    float* GP = smem + OFF_GP;
+    float* LP = smem + OFF_LP;
+    float* DG = smem + OFF_DG;
+    float* attr = smem + OFF_SMALL;                         // [16][16]
+    float* ench = attr + 16 * 16;                           // [16][32]
+    RowSt* rst = reinterpret_cast<RowSt*>(ench + 16 * 32);  // [16]
+    float* ubuf = reinterpret_cast<float*>(rst + 16);       // [16][2] action means
+    uint8_t* rowvalid = reinterpret_cast<uint8_t*>(ubuf + 32);
+    uint8_t* novalid_s = rowvalid + 16;
+    uint8_t* gvalid = rowvalid + 32;
+    int* rtype = reinterpret_cast<int*>(rowvalid + 48);     // [16]
+    int* dflag = rtype + 16;                                // [16] bit0 lane-type destination, bit1 road-edge destination
 
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, kq = lane >> 4, m = lane & 15;
     const int n = blockIdx.y, b = n / p.k_rep, row0 = blockIdx.x * TM;
-    const int n_real = min(TM, p.n_agent - row0);
+    const int n_real = max(0, min(TM, p.n_agent - row0));
     const float* W = p.W;
     const PolicyW& pw = p.pw;
+    const size_t base_row = (size_t)n * p.a_pad + row0;
 
+    WUnit u;
+    TB_STAMP(0);
+    if (tid < TM) {
+        rtype[tid] = (tid < n_real) ? p.agent_type[(size_t)b * p.n_agent + row0 + tid] : -1;
+        const size_t si = base_row + tid;
+        const f32x4 st = ldg4(p.state + si * 4), ax = ldg4(p.aux + si * 4);
+        rst[tid].st[0] = st.x; rst[tid].st[1] = st.y; rst[tid].st[2] = st.z; rst[tid].st[3] = st.w;
+        rst[tid].aux[0] = ax.x; rst[tid].aux[1] = ax.y; rst[tid].aux[2] = ax.z; rst[tid].aux[3] = ax.w;
+        rowvalid[tid] = p.valid[si];
+        gvalid[tid] = p.goal_valid[si];
+    }
+
+    if (do_c) {
+        // =================================== C(t) ===================================
+        // number of valid agents of the instance (agent_interaction.py:61: exactly one -> bypass the block)
+        const int n_valid = __syncthreads_count(tid < p.a_pad && p.valid[(size_t)n * p.a_pad + tid]);
+        const bool bypass = n_valid == 1;
+        wload(u, bypass ? gru_first(W, pw.gru[0], wave) : xlayer_first(W, pw.inter[0], wave), lane);
+        // one burst of per-tile inputs for the whole C half (a single exposed global latency)
+        load_tile(X, LDT, p.x_mid + base_row * H, TM, tid);
+        load_tile(Hs, LDT, p.hidden + (((size_t)0 * p.n_inst + n) * p.a_pad + row0) * H, TM, tid);
+        load_tile(H1, LDT, p.hidden + (((size_t)1 * p.n_inst + n) * p.a_pad + row0) * H, TM, tid);
+        load_tile(H2, LDT, p.hidden + (((size_t)2 * p.n_inst + n) * p.a_pad + row0) * H, TM, tid);
+        load_tile(GP, LDT, p.goal_pre + base_row * H, TM, tid);
+        load_tile(LP, LDT, p.lat_pre + base_row * H, TM, tid);
+        for (int i = tid; i < TM * 20; i += NTHREADS) st4(DG + i * 4, ldg4(p.dest_geo + (base_row * 20 + i) * 4));
+        if (tid < TM) dflag[tid] = p.dest_flag[base_row + tid];
+        __syncthreads();
+        TB_STAMP(1);
+        if (!bypass) {
+            const uint8_t* kvd = p.valid + (size_t)n * p.a_pad;
+            const size_t ls = (size_t)p.a_pad * H;
+            const float* K0 = p.kin + ((size_t)n * 3) * ls;
+            const float* V0 = p.vtin + ((size_t)n * 3) * ls;
+            xattn_layer(W, pw.inter[0], X, S1, S2, K0, V0, kvd, p.a_pad, row0, rowvalid, novalid_s, tid, u,
+                        xlayer_first(W, pw.inter[1], wave));
+            xattn_layer(W, pw.inter[1], X, S1, S2, K0 + ls, V0 + ls, kvd, p.a_pad, row0, rowvalid, novalid_s, tid, u,
+                        xlayer_first(W, pw.inter[2], wave));
+            xattn_layer(W, pw.inter[2], X, S1, S2, K0 + 2 * ls, V0 + 2 * ls, kvd, p.a_pad, row0, rowvalid, novalid_s, tid, u,
+                        gru_first(W, pw.gru[0], wave));
+        }
+        TB_STAMP(2);
+        // ---- 3-layer GRU, one step (agent_temporal.py:147-152): X -> Y -> S1 -> X
+        {
+            float* hg0 = p.hidden + (((size_t)0 * p.n_inst + n) * p.a_pad + row0) * H;
+            float* hg1 = p.hidden + (((size_t)1 * p.n_inst + n) * p.a_pad + row0) * H;
+            float* hg2 = p.hidden + (((size_t)2 * p.n_inst + n) * p.a_pad + row0) * H;
+            gru_layer(W, pw.gru[0], X, Hs, Y, rowvalid, hg0, TM, tid, u, gru_first(W, pw.gru[1], wave));
+            gru_layer(W, pw.gru[1], Y, H1, S1, rowvalid, hg1, TM, tid, u, gru_first(W, pw.gru[2], wave));
+            gru_layer(W, pw.gru[2], S1, H2, X, rowvalid, hg2, TM, tid, u,
+                      wnext(W + pw.goal_out_w1, W + pw.goal_out_b1, 2 * wave, 2 * wave + 1, 16, 0));
+        }
+        TB_STAMP(3);
+        // ---- add_goal, add_latent (traffic_bots.py:240-241)
+        fuse_latent_goal(W, pw.goal_out_w1, pw.goal_out_w2, pw.goal_out_b2, X, CAT, S2, GP, gvalid, rowvalid, tid, u,
+                         wnext(W + pw.lat_out_w1, W + pw.lat_out_b1, 2 * wave, 2 * wave + 1, 16, 0),
+                         p.prof + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 32);
+        // action-head branches needed by this tile (action_head.py:69-75): one per agent type present
+        const bool has0 = __syncthreads_or(tid < TM && rtype[tid] == 0 && rowvalid[tid]);
+        const bool has1 = __syncthreads_or(tid < TM && rtype[tid] == 1 && rowvalid[tid]);
+        const bool has2 = __syncthreads_or(tid < TM && rtype[tid] == 2 && rowvalid[tid]);
+        const WNext after_head = do_a ? xlayer_first(W, pw.as2pl[0], wave) : wstd(W + pw.head_w1[0], W + pw.head_b1[0], wave);
+        const WNext h2 = has2 ? wstd(W + pw.head_w1[2], W + pw.head_b1[2], wave) : after_head;
+        const WNext h1 = has1 ? wstd(W + pw.head_w1[1], W + pw.head_b1[1], wave) : h2;
+        const WNext h0 = has0 ? wstd(W + pw.head_w1[0], W + pw.head_b1[0], wave) : h1;
+        TB_STAMP(4);
+        fuse_latent_goal(W, pw.lat_out_w1, pw.lat_out_w2, pw.lat_out_b2, X, CAT, S2, LP, rowvalid, rowvalid, tid, u, h0);
+        TB_STAMP(5);
+        if (t == p.tap_step && p.tap_policy_feature)
+            store_tile(p.tap_policy_feature + ((size_t)n * p.n_agent + row0) * H, X, LDT, n_real, tid);
+
+        if (tid < 32) ubuf[tid] = 0.f;
+#pragma unroll
+        for (int ty = 0; ty < 3; ++ty) {
+            const bool present = ty == 0 ? has0 : (ty == 1 ? has1 : has2);
+            if (!present) continue;
+            WUnit uh = u;
+            f32x4 acc[2] = {uh.b[0], uh.b[1]};
+            wload(u, ty == 0 ? h1 : (ty == 1 ? h2 : after_head), lane);
+            wmma(acc[0], acc[1], uh, X + m * LDT + kq * 32);
+            st4(cptr(S2, LDT, 2 * wave, lane), relu4(acc[0]));
+            st4(cptr(S2, LDT, 2 * wave + 1, lane), relu4(acc[1]));
+            __syncthreads();
+            {
+                // Linear(128 -> 2): 32 (row, output) pairs x 8 lanes, 16 k each, quad + half-row DPP reduction
+                const int pair = tid >> 3, sub = tid & 7, r = pair >> 1, o = pair & 1;
+                const float* w2 = W + pw.head_w2[ty] + o * H + sub * 16;
+                const float* xs = S2 + r * LDT + sub * 16;
+                float sacc = 0.f;
+#pragma unroll
+                for (int k4 = 0; k4 < 4; ++k4) {
+                    const f32x4 a4 = lds4(xs + 4 * k4), w4 = ldg4(w2 + 4 * k4);
+                    sacc = fmaf(a4.x, w4.x, sacc); sacc = fmaf(a4.y, w4.y, sacc);
+                    sacc = fmaf(a4.z, w4.z, sacc); sacc = fmaf(a4.w, w4.w, sacc);
+                }
+                sacc += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sacc), 0xB1, 0xf, 0xf, true));
+                sacc += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sacc), 0x4E, 0xf, 0xf, true));
+                sacc += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sacc), 0x141, 0xf, 0xf, true));
+                if (sub == 0 && rtype[r] == ty && rowvalid[r]) ubuf[pair] = sacc + W[pw.head_b2[ty] + o];
+            }
+            __syncthreads();
+        }
+        __syncthreads();
+        TB_STAMP(6);
+
+        // ---- per-agent epilogue
+        if (tid < n_real) {
+            const int row = row0 + tid;
+            const size_t si = base_row + tid;
+            const int ty = rtype[tid];
+            const bool valid_old = rowvalid[tid] != 0;
+            const bool have = valid_old && ty >= 0;
+            const f32x4 st = f32x4{rst[tid].st[0], rst[tid].st[1], rst[tid].st[2], rst[tid].st[3]};
+            // Dynamics.update + MultiPathPP (dynamics.py:74-119,194-228); tanh-bounded action, midpoint unicycle
+            float acc_ = 0.f, yr_ = 0.f;
+            if (have) {
+                acc_ = fmul_(tanhf(ubuf[tid * 2 + 0]), pw.max_acc[ty]);
+                yr_ = fmul_(tanhf(ubuf[tid * 2 + 1]), pw.max_yaw_rate[ty]);
+            }
+            const float half_dt = 0.5f * pw.dt;  // python: 0.5 * self.dt, then cast with the tensor op
+            const float v_t = fadd_(st.w, fmul_(half_dt, acc_));
+            const float th_t = fadd_(st.z, fmul_(half_dt, yr_));
+            float sn, cs;
+            sincosf(th_t, &sn, &cs);
+            f32x4 pred;
+            pred.x = fadd_(st.x, fmul_(pw.dt, fmul_(v_t, cs)));
+            pred.y = fadd_(st.y, fmul_(pw.dt, fmul_(v_t, sn)));
+            pred.z = fadd_(st.z, fmul_(pw.dt, yr_));
+            pred.w = fadd_(st.w, fmul_(pw.dt, acc_));
+            if (!have) pred = splat(0.f);
+            float alp = 0.f;
+            if (valid_old) {
+                for (int d = 0; d < 2; ++d) {
+                    const float ls = (ty >= 0) ? W[pw.head_log_std[ty] + d] : 0.f;
+                    alp += -logf(expf(ls)) - 0.9189385332046727f;
+                }
+            }
+            // teacher forcing / spawn (dynamics.py:132-149)
+            f32x4 cur = pred;
+            bool valid = valid_old;
+            bool killed = p.killed[si] != 0;
+            uint8_t ovr = 0;
+            bool gt_valid = false;
+            if (t < p.n_hist) {
+                const size_t hi = ((size_t)b * p.n_hist + t) * p.n_agent + row;
+                ovr = p.tf_mask[hi];
+                gt_valid = p.hist_valid[hi] != 0;
+                if (ovr && !killed) {
+                    valid = true;
+                    cur = ldg4(p.hist_state + hi * 4);
+                    const f32x4 ax = f32x4{p.hist_vel[hi * 2], p.hist_vel[hi * 2 + 1], p.hist_acc[hi], p.hist_yaw_rate[hi]};
+                    st4(p.aux + si * 4, ax);
+                    rst[tid].aux[0] = ax.x; rst[tid].aux[1] = ax.y; rst[tid].aux[2] = ax.z; rst[tid].aux[3] = ax.w;
+                }
+            }
+            // rule checks on the post-override state (traffic_rule_checker.py:101-119,364-410)
+            const float* bd = p.map_boundary + (size_t)b * 4;
+            const bool out_this = valid && ((cur.x > bd[1]) || (cur.x < bd[0]) || (cur.y > bd[3]) || (cur.y < bd[2]));
+            const bool outside = (p.outside[si] != 0) || out_this;
+            bool dreached = p.dest_reached[si] != 0;
+            bool dr_this = false;
+            {
+                const bool is_lane = (dflag[tid] & 1) != 0, is_edge = (dflag[tid] & 2) != 0;
+                const float thresh = is_edge ? fmul_(50.f, fadd_(1.f, -0.8f)) : 50.f;
+                float hs, hc;
+                sincosf(cur.z, &hs, &hc);
+                bool pos_r = false, rot_r = false;
+#pragma unroll 4
+                for (int k = 0; k < 20; ++k) {
+                    const f32x4 g = lds4(DG + (tid * 20 + k) * 4);
+                    const float dx = fadd_(cur.x, -g.x), dy = fadd_(cur.y, -g.y);
+                    const float dist = sqrtf(fadd_(fmul_(dx, dx), fmul_(dy, dy)));
+                    pos_r |= dist < thresh;
+                    const float rot = fadd_(fmul_(hc, g.z), fmul_(hs, g.w));
+                    rot_r |= rot > 0.8660254037844387f;
+                }
+                dr_this = !dreached && valid && ((is_lane && pos_r && rot_r) || (is_edge && pos_r));
+                dreached |= dr_this;
+            }
+            // kill agents that left the map unless ground truth is still valid (dynamics.py:161-167)
+            const bool mk = out_this && !gt_valid;
+            killed |= mk;
+            valid = valid && !mk;
+            // navigator (goal_manager.py:155-162)
+            const bool gv = (gvalid[tid] != 0) && valid && !dreached;
+            // simulator state: global (the next launch's interaction reads `valid` of every agent) + LDS (A half below)
+            st4(p.state + si * 4, cur);
+            p.valid[si] = valid;
+            p.killed[si] = killed;
+            p.goal_valid[si] = gv;
+            p.dest_reached[si] = dreached;
+            p.outside[si] = outside;
+            rst[tid].st[0] = cur.x; rst[tid].st[1] = cur.y; rst[tid].st[2] = cur.z; rst[tid].st[3] = cur.w;
+            rowvalid[tid] = valid;
+            // RolloutBuffer.add (buffer.py:39-70)
+            const int s = t - p.step_start;
+            const size_t oi = ((size_t)n * p.n_agent + row) * p.n_step_out + s;
+            st4(p.preds + oi * 4, pred);
+            p.o_valid[oi] = valid_old;
+            p.o_override[oi] = ovr;
+            p.o_outside[oi] = outside;
+            p.o_outside_this[oi] = out_this;
+            p.o_dest_reached[oi] = dreached;
+            p.o_dest_reached_this[oi] = dr_this;
+            p.o_action_logp[oi] = alp;
+        }
+        __syncthreads();
+    } else {
+        wload(u, xlayer_first(W, pw.as2pl[0], wave), lane);
+        __syncthreads();
+    }
+    TB_STAMP(7);
+    if (!do_a) return;
+
+    // =================================== A(t+1) ===================================
+    const int t1 = t + 1;
     // ---- agent attributes (sc_input.py:142-165): vel2, spd, yaw_rate, acc, size3, type one-hot3
     if (tid < TM) {
         const int row = row0 + tid;
-        const size_t si = (size_t)n * p.a_pad + row;
-        const f32x4 st = ldg4(p.state + si * 4);
-        const f32x4 ax = ldg4(p.aux + si * 4);
-        const uint8_t v = p.valid[si];
-        rowvalid[tid] = v;
         float* a = attr + tid * 16;
-        int ty = -1;
+        const int ty = rtype[tid];
         f32x4 sz = splat(0.f);
         if (tid < n_real) {
-            ty = p.agent_type[(size_t)b * p.n_agent + row];
             const float* s = p.agent_size + ((size_t)b * p.n_agent + row) * 3;
             sz = f32x4{s[0], s[1], s[2], 0.f};
         }
-        a[0] = ax.x; a[1] = ax.y; a[2] = st.w; a[3] = ax.w; a[4] = ax.z;
+        a[0] = rst[tid].aux[0]; a[1] = rst[tid].aux[1]; a[2] = rst[tid].st[3]; a[3] = rst[tid].aux[3]; a[4] = rst[tid].aux[2];
         a[5] = sz.x; a[6] = sz.y; a[7] = sz.z;
         a[8] = ty == 0 ? 1.f : 0.f; a[9] = ty == 1 ? 1.f : 0.f; a[10] = ty == 2 ? 1.f : 0.f;
-        pose[tid * 4 + 0] = st.x; pose[tid * 4 + 1] = st.y; pose[tid * 4 + 2] = st.z;
     }
     __syncthreads();
     // ---- pose PE (pose_pe.py:57-62, pos_emb.py:24-25,54-55): 48 sincos per row, 3 per thread
     {
         const int row = tid >> 4, i = tid & 15;
-        const float px = pose[row * 4], py = pose[row * 4 + 1], pyaw = pose[row * 4 + 2];
+        const float px = rst[row].st[0], py = rst[row].st[1], pyaw = rst[row].st[2];
         float* xr = X + row * LDT + 32;
 #pragma unroll
-        for (int u = 0; u < 3; ++u) {
-            const int j = i * 3 + u;
+        for (int uu = 0; uu < 3; ++uu) {
+            const int j = i * 3 + uu;
             float arg;
             int c_cos, c_sin;
             if (j < 12) {
@@ -228,8 +581,8 @@ __global__ __launch_bounds__(NTHREADS) void k_step_a(RolloutP p, int t) {
     {
         const int row = tid >> 4, o0 = (tid & 15) * 2;
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int o = o0 + u;
+        for (int uu = 0; uu < 2; ++uu) {
+            const int o = o0 + uu;
             float s = W[pw.enc_b1 + o];
             for (int k = 0; k < 11; ++k) s = fmaf(attr[row * 16 + k], W[pw.enc_w1 + o * 11 + k], s);
             ench[row * 32 + o] = fmaxf(s, 0.f);
@@ -239,8 +592,8 @@ __global__ __launch_bounds__(NTHREADS) void k_step_a(RolloutP p, int t) {
     {
         const int row = tid >> 4, o0 = (tid & 15) * 2;
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int o = o0 + u;
+        for (int uu = 0; uu < 2; ++uu) {
+            const int o = o0 + uu;
             float s = W[pw.enc_b2 + o];
             for (int k = 0; k < 32; ++k) s = fmaf(ench[row * 32 + k], W[pw.enc_w2 + o * 32 + k], s);
             X[row * LDT + o] = s;
@@ -253,263 +606,50 @@ __global__ __launch_bounds__(NTHREADS) void k_step_a(RolloutP p, int t) {
         if (!rowvalid[r]) st4(X + r * LDT + (i & 31) * 4, splat(0.f));
     }
     __syncthreads();
-    if (t == p.tap_step && p.tap_agent_feature)
+    if (t1 == p.tap_step && p.tap_agent_feature)
         store_tile(p.tap_agent_feature + ((size_t)n * p.n_agent + row0) * H, X, LDT, n_real, tid);
 
+    TB_STAMP(8);
     // ---- agent -> map polylines (traffic_bots.py:205-211)
-#pragma unroll 1
-    for (int l = 0; l < 3; ++l) {
-        xattn_layer(W, pw.as2pl[l], X, S1, S2, p.kpl + ((size_t)b * 3 + l) * p.p_pad * H,
-                    p.vtpl + ((size_t)b * 3 + l) * H * p.p_pad, p.kvalid_pl + (size_t)b * p.p_pad, p.p_pad, -1, rowvalid,
-                    novalid_s, tid);
-    }
-    // ---- agent -> traffic lights of step min(t-1, n_hist-1) (waymo_motion.py:287, traffic_bots.py:213-219)
-    const int g_tl = b * p.n_hist + min(t - 1, p.n_hist - 1);
-#pragma unroll 1
-    for (int l = 0; l < 3; ++l) {
-        xattn_layer(W, pw.as2tl[l], X, S1, S2, p.ktl + ((size_t)g_tl * 3 + l) * p.t_pad * H,
-                    p.vttl + ((size_t)g_tl * 3 + l) * H * p.t_pad, p.kvalid_tl + (size_t)g_tl * p.t_pad, p.t_pad, -1, rowvalid,
-                    novalid_s, tid);
-    }
-    // ---- hand-off to step_c: x_mid and the interaction K/V of this tile's agents (tgt = block input for all
-    // three layers, agent_interaction.py:51-52 + transformer.py:82-92)
-    store_tile(p.x_mid + ((size_t)n * p.a_pad + row0) * H, X, LDT, TM, tid);
-#pragma unroll 1
-    for (int l = 0; l < 3; ++l) {
-        kv_project_tile(W, pw.inter[l], X, S1, p.kin + ((size_t)n * 3 + l) * p.a_pad * H,
-                        p.vtin + ((size_t)n * 3 + l) * H * p.a_pad, p.a_pad, row0, TM, tid);
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// step kernel C
-// ------------------------------------------------------------------------------------------------
-// h = relu(W2 relu(W1 [x ; u] + b1) + b2); h = zvalid ? h : 0; x = rowvalid ? h + x : 0   (add_latent_goal.py:57-77)
-__device__ __forceinline__ void fuse_latent_goal(const float* __restrict__ W, uint32_t w1, uint32_t b1, uint32_t w2, uint32_t b2,
-                                                 float* X, float* CAT, float* S2, const float* __restrict__ pre_rows /*[16][128] global*/,
-                                                 const uint8_t* zvalid, const uint8_t* rowvalid, int tid) {
-    const int wave = tid >> 6, lane = tid & 63, kq = lane >> 4, m = lane & 15;
-    // CAT = [x ; relu(mask(pre))]
-    for (int i = tid; i < TM * 32; i += NTHREADS) {
-        const int r = i >> 5, c4 = (i & 31) * 4;
-        st4(CAT + r * LDC + c4, lds4(X + r * LDT + c4));
-        const f32x4 u = zvalid[r] ? relu4(ldg4(pre_rows + (size_t)r * H + c4)) : splat(0.f);
-        st4(CAT + r * LDC + 128 + c4, u);
-    }
-    __syncthreads();
     {
-        const int tiles[2] = {2 * wave, 2 * wave + 1};
-        f32x4 acc[2] = {bias4(W + b1, tiles[0], lane), bias4(W + b1, tiles[1], lane)};
-        gemm_acc<256, 2>(acc, W + w1, tiles, CAT + m * LDC + kq * 64, lane);
-        st4(cptr(S2, LDT, tiles[0], lane), relu4(acc[0]));
-        st4(cptr(S2, LDT, tiles[1], lane), relu4(acc[1]));
+        const uint8_t* kvd = p.kvalid_pl + (size_t)b * p.p_pad;
+        const size_t ls = (size_t)p.p_pad * H;
+        const float* K0 = p.kpl + ((size_t)b * 3) * ls;
+        const float* V0 = p.vtpl + ((size_t)b * 3) * ls;
+        xattn_layer(W, pw.as2pl[0], X, S1, S2, K0, V0, kvd, p.p_pad, -1, rowvalid, novalid_s, tid, u, xlayer_first(W, pw.as2pl[1], wave),
+                    p.prof + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 32);
+        xattn_layer(W, pw.as2pl[1], X, S1, S2, K0 + ls, V0 + ls, kvd, p.p_pad, -1, rowvalid, novalid_s, tid, u,
+                    xlayer_first(W, pw.as2pl[2], wave));
+        xattn_layer(W, pw.as2pl[2], X, S1, S2, K0 + 2 * ls, V0 + 2 * ls, kvd, p.p_pad, -1, rowvalid, novalid_s, tid, u,
+                    xlayer_first(W, pw.as2tl[0], wave));
     }
-    __syncthreads();
+    TB_STAMP(9);
+    // ---- agent -> traffic lights of step min(t1-1, n_hist-1) (waymo_motion.py:287, traffic_bots.py:213-219)
     {
-        f32x4 acc[2];
-        linear128<128>(acc, W + w2, W + b2, S2 + m * LDT + kq * 32, wave, lane);
-        const bool zv = zvalid[m] != 0, rv = rowvalid[m] != 0;
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            float* px = cptr(X, LDT, 2 * wave + t, lane);
-            const f32x4 h = zv ? relu4(acc[t]) : splat(0.f);
-            st4(px, rv ? h + lds4(px) : splat(0.f));
-        }
+        const int g_tl = b * p.n_hist + min(t1 - 1, p.n_hist - 1);
+        const uint8_t* kvd = p.kvalid_tl + (size_t)g_tl * p.t_pad;
+        const size_t ls = (size_t)p.t_pad * H;
+        const float* K0 = p.ktl + ((size_t)g_tl * 3) * ls;
+        const float* V0 = p.vttl + ((size_t)g_tl * 3) * ls;
+        xattn_layer(W, pw.as2tl[0], X, S1, S2, K0, V0, kvd, p.t_pad, -1, rowvalid, novalid_s, tid, u, xlayer_first(W, pw.as2tl[1], wave));
+        xattn_layer(W, pw.as2tl[1], X, S1, S2, K0 + ls, V0 + ls, kvd, p.t_pad, -1, rowvalid, novalid_s, tid, u,
+                    xlayer_first(W, pw.as2tl[2], wave));
+        xattn_layer(W, pw.as2tl[2], X, S1, S2, K0 + 2 * ls, V0 + 2 * ls, kvd, p.t_pad, -1, rowvalid, novalid_s, tid, u,
+                    kvproj_first(W, pw.inter[0], wave));
     }
-    __syncthreads();
-}
-
-__global__ __launch_bounds__(NTHREADS) void k_step_c(RolloutP p, int t) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* X = smem + OFF_X;
-    float* S1 = smem + OFF_S1;
-    float* S2 = smem + OFF_S2;
-    float* Hs = smem + OFF_H;
-    float* Y = smem + OFF_Y;
-    float* CAT = smem + OFF_CAT;
-    float* ubuf = smem + OFF_SMALL;  // [16][2] action means
-    uint8_t* rowvalid = reinterpret_cast<uint8_t*>(ubuf + 32);
-    uint8_t* novalid_s = rowvalid + 16;
-    uint8_t* gvalid = rowvalid + 32;
-    int* rtype = reinterpret_cast<int*>(rowvalid + 48);  // [16]
-
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, kq = lane >> 4, m = lane & 15;
-    const int n = blockIdx.y, b = n / p.k_rep, row0 = blockIdx.x * TM;
-    const int n_real = min(TM, p.n_agent - row0);
-    const float* W = p.W;
-    const PolicyW& pw = p.pw;
-    const size_t base_row = (size_t)n * p.a_pad + row0;
-
-    load_tile(X, LDT, p.x_mid + base_row * H, TM, tid);
-    if (tid < TM) {
-        rowvalid[tid] = p.valid[base_row + tid];
-        gvalid[tid] = p.goal_valid[base_row + tid];
-        rtype[tid] = (tid < n_real) ? p.agent_type[(size_t)b * p.n_agent + row0 + tid] : -1;
-    }
-    // number of valid agents of the instance (agent_interaction.py:61: exactly one -> bypass the block)
-    const int n_valid = __syncthreads_count(tid < p.a_pad && p.valid[(size_t)n * p.a_pad + tid]);
-    if (n_valid != 1) {
-#pragma unroll 1
-        for (int l = 0; l < 3; ++l) {
-            xattn_layer(W, pw.inter[l], X, S1, S2, p.kin + ((size_t)n * 3 + l) * p.a_pad * H,
-                        p.vtin + ((size_t)n * 3 + l) * H * p.a_pad, p.valid + (size_t)n * p.a_pad, p.a_pad, row0, rowvalid,
-                        novalid_s, tid);
-        }
-    }
-    // ---- 3-layer GRU, one step (agent_temporal.py:147-152)
+    TB_STAMP(10);
+    // ---- hand-off to the next launch: x_mid and the interaction K/V of this tile's agents (tgt = block input for
+    // all three layers, agent_interaction.py:51-52 + transformer.py:82-92)
+    store_tile(p.x_mid + base_row * H, X, LDT, TM, tid);
     {
-        float* in = X;
-        float* out = Y;
-#pragma unroll 1
-        for (int l = 0; l < 3; ++l) {
-            float* hg = p.hidden + (((size_t)l * p.n_inst + n) * p.a_pad + row0) * H;
-            load_tile(Hs, LDT, hg, TM, tid);
-            __syncthreads();
-            gru_layer(W, pw.gru[l], in, Hs, out, rowvalid, hg, TM, tid);
-            float* tmp = in; in = out; out = (tmp == X) ? S1 : tmp;  // ping-pong X -> Y -> S1 -> Y
-        }
-        // result of layer 2 sits in `in`; move to X if needed
-        if (in != X) {
-            for (int i = tid; i < TM * 32; i += NTHREADS) {
-                const int r = i >> 5, c4 = (i & 31) * 4;
-                st4(X + r * LDT + c4, lds4(in + r * LDT + c4));
-            }
-            __syncthreads();
-        }
+        const size_t ls = (size_t)p.a_pad * H;
+        float* K0 = p.kin + ((size_t)n * 3) * ls;
+        float* V0 = p.vtin + ((size_t)n * 3) * ls;
+        kv_project_tile(W, pw.inter[0], X, S1, K0, V0, p.a_pad, row0, TM, tid, u, kvproj_first(W, pw.inter[1], wave));
+        kv_project_tile(W, pw.inter[1], X, S1, K0 + ls, V0 + ls, p.a_pad, row0, TM, tid, u, kvproj_first(W, pw.inter[2], wave));
+        kv_project_tile(W, pw.inter[2], X, S1, K0 + 2 * ls, V0 + 2 * ls, p.a_pad, row0, TM, tid, u, kvproj_first(W, pw.inter[2], wave));
     }
-    // ---- add_goal, add_latent (traffic_bots.py:240-241)
-    fuse_latent_goal(W, pw.goal_out_w1, pw.goal_out_b1, pw.goal_out_w2, pw.goal_out_b2, X, CAT, S2,
-                     p.goal_pre + base_row * H, gvalid, rowvalid, tid);
-    fuse_latent_goal(W, pw.lat_out_w1, pw.lat_out_b1, pw.lat_out_w2, pw.lat_out_b2, X, CAT, S2,
-                     p.lat_pre + base_row * H, rowvalid, rowvalid, tid);
-    if (t == p.tap_step && p.tap_policy_feature)
-        store_tile(p.tap_policy_feature + ((size_t)n * p.n_agent + row0) * H, X, LDT, n_real, tid);
-
-    // ---- action head per agent type (action_head.py:69-75); branches without an agent in the tile are skipped
-    if (tid < 32) ubuf[tid] = 0.f;
-#pragma unroll 1
-    for (int ty = 0; ty < 3; ++ty) {
-        const int present = __syncthreads_or(tid < TM && rtype[tid] == ty && rowvalid[tid]);
-        if (!present) continue;
-        f32x4 acc[2];
-        linear128<128>(acc, W + pw.head_w1[ty], W + pw.head_b1[ty], X + m * LDT + kq * 32, wave, lane);
-        st4(cptr(S2, LDT, 2 * wave, lane), relu4(acc[0]));
-        st4(cptr(S2, LDT, 2 * wave + 1, lane), relu4(acc[1]));
-        __syncthreads();
-        if (tid < 32) {
-            const int r = tid >> 1, o = tid & 1;
-            if (rtype[r] == ty && rowvalid[r]) {
-                float s = W[pw.head_b2[ty] + o];
-                const float* w2 = W + pw.head_w2[ty] + o * H;
-                for (int k = 0; k < H; ++k) s = fmaf(S2[r * LDT + k], w2[k], s);
-                ubuf[tid] = s;
-            }
-        }
-        __syncthreads();
-    }
-    __syncthreads();
-
-    // ---- per-agent epilogue
-    if (tid < n_real) {
-        const int row = row0 + tid;
-        const size_t si = base_row + tid;
-        const int ty = rtype[tid];
-        const bool valid_old = rowvalid[tid] != 0;
-        const bool have = valid_old && ty >= 0;
-        f32x4 st = ldg4(p.state + si * 4);
-        // Dynamics.update + MultiPathPP (dynamics.py:74-119,194-228); tanh-bounded action, midpoint unicycle
-        float acc_ = 0.f, yr_ = 0.f;
-        if (have) {
-            acc_ = fmul_(tanhf(ubuf[tid * 2 + 0]), pw.max_acc[ty]);
-            yr_ = fmul_(tanhf(ubuf[tid * 2 + 1]), pw.max_yaw_rate[ty]);
-        }
-        const float half_dt = 0.5f * pw.dt;  // python: 0.5 * self.dt, then cast with the tensor op
-        const float v_t = fadd_(st.w, fmul_(half_dt, acc_));
-        const float th_t = fadd_(st.z, fmul_(half_dt, yr_));
-        float sn, cs;
-        sincosf(th_t, &sn, &cs);
-        f32x4 pred;
-        pred.x = fadd_(st.x, fmul_(pw.dt, fmul_(v_t, cs)));
-        pred.y = fadd_(st.y, fmul_(pw.dt, fmul_(v_t, sn)));
-        pred.z = fadd_(st.z, fmul_(pw.dt, yr_));
-        pred.w = fadd_(st.w, fmul_(pw.dt, acc_));
-        if (!have) pred = splat(0.f);
-        float alp = 0.f;
-        if (valid_old) {
-            for (int d = 0; d < 2; ++d) {
-                const float ls = (ty >= 0) ? W[pw.head_log_std[ty] + d] : 0.f;
-                alp += -logf(expf(ls)) - 0.9189385332046727f;
-            }
-        }
-        // teacher forcing / spawn (dynamics.py:132-149)
-        f32x4 cur = pred;
-        bool valid = valid_old;
-        bool killed = p.killed[si] != 0;
-        uint8_t ovr = 0;
-        bool gt_valid = false;
-        if (t < p.n_hist) {
-            const size_t hi = ((size_t)b * p.n_hist + t) * p.n_agent + row;
-            ovr = p.tf_mask[hi];
-            gt_valid = p.hist_valid[hi] != 0;
-            if (ovr && !killed) {
-                valid = true;
-                cur = ldg4(p.hist_state + hi * 4);
-                st4(p.aux + si * 4, f32x4{p.hist_vel[hi * 2], p.hist_vel[hi * 2 + 1], p.hist_acc[hi], p.hist_yaw_rate[hi]});
-            }
-        }
-        // rule checks on the post-override state (traffic_rule_checker.py:101-119,364-410)
-        const float* bd = p.map_boundary + (size_t)b * 4;
-        const bool out_this = valid && ((cur.x > bd[1]) || (cur.x < bd[0]) || (cur.y > bd[3]) || (cur.y < bd[2]));
-        bool outside = (p.outside[si] != 0) || out_this;
-        bool dreached = p.dest_reached[si] != 0;
-        bool dr_this = false;
-        {
-            const int d = p.dest[(size_t)n * p.n_agent + row];
-            const int dty = p.map_type[(size_t)b * p.n_pl + d];
-            const bool is_edge = dty == 4, is_lane = dty >= 0 && dty < 4;
-            const float thresh = is_edge ? fmul_(50.f, fadd_(1.f, -0.8f)) : 50.f;
-            float hs, hc;
-            sincosf(cur.z, &hs, &hc);
-            bool pos_r = false, rot_r = false;
-            const size_t nb = ((size_t)b * p.n_pl + d) * 20;
-            for (int k = 0; k < 20; ++k) {
-                if (!p.map_valid[nb + k]) continue;
-                const float dx = fadd_(cur.x, -p.map_pos[(nb + k) * 2]), dy = fadd_(cur.y, -p.map_pos[(nb + k) * 2 + 1]);
-                const float dist = sqrtf(fadd_(fmul_(dx, dx), fmul_(dy, dy)));
-                pos_r |= dist < thresh;
-                const float ddx = p.map_dir[(nb + k) * 2], ddy = p.map_dir[(nb + k) * 2 + 1];
-                const float nrm = sqrtf(fadd_(fmul_(ddx, ddx), fmul_(ddy, ddy)));
-                const float rot = fadd_(fmul_(hc, ddx / nrm), fmul_(hs, ddy / nrm));
-                rot_r |= rot > 0.8660254037844387f;
-            }
-            dr_this = !dreached && valid && ((is_lane && pos_r && rot_r) || (is_edge && pos_r));
-            dreached |= dr_this;
-        }
-        // kill agents that left the map unless ground truth is still valid (dynamics.py:161-167)
-        const bool mk = out_this && !gt_valid;
-        killed |= mk;
-        valid = valid && !mk;
-        // navigator (goal_manager.py:155-162)
-        const bool gv = (gvalid[tid] != 0) && valid && !dreached;
-        // write simulator state
-        st4(p.state + si * 4, cur);
-        p.valid[si] = valid;
-        p.killed[si] = killed;
-        p.goal_valid[si] = gv;
-        p.dest_reached[si] = dreached;
-        p.outside[si] = outside;
-        // RolloutBuffer.add (buffer.py:39-70)
-        const int s = t - p.step_start;
-        const size_t oi = ((size_t)n * p.n_agent + row) * p.n_step_out + s;
-        st4(p.preds + oi * 4, pred);
-        p.o_valid[oi] = valid_old;
-        p.o_override[oi] = ovr;
-        p.o_outside[oi] = outside;
-        p.o_outside_this[oi] = out_this;
-        p.o_dest_reached[oi] = dreached;
-        p.o_dest_reached_this[oi] = dr_this;
-        p.o_action_logp[oi] = alp;
-    }
+    TB_STAMP(11);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -525,18 +665,26 @@ void launch_kv_hoist(const float* W, const XLayerW* L3, const float* feat, const
 }
 
 void launch_rollout_init(const RolloutP& p, hipStream_t s) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_rollout_init), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)step_lds_bytes());
     dim3 grid(p.a_pad / TM, p.n_inst);
     hipLaunchKernelGGL(k_rollout_init, grid, dim3(NTHREADS), step_lds_bytes(), s, p);
 }
 
-void launch_step_a(const RolloutP& p, int t, hipStream_t s) {
+void launch_step(const RolloutP& p, int t, int do_c, int do_a, hipStream_t s) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_step), hipFuncAttributeMaxDynamicSharedMemorySize, (int)step_lds_bytes());
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_rollout_init), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)step_lds_bytes());
+        attr_set = true;
+    }
     dim3 grid(p.a_pad / TM, p.n_inst);
-    hipLaunchKernelGGL(k_step_a, grid, dim3(NTHREADS), step_lds_bytes(), s, p, t);
+    hipLaunchKernelGGL(k_step, grid, dim3(NTHREADS), step_lds_bytes(), s, p, t, do_c, do_a);
 }
 
-void launch_step_c(const RolloutP& p, int t, hipStream_t s) {
-    dim3 grid(p.a_pad / TM, p.n_inst);
-    hipLaunchKernelGGL(k_step_c, grid, dim3(NTHREADS), step_lds_bytes(), s, p, t);
+void launch_rollout_final(const RolloutP& p, float* f_state, uint8_t* f_valid, float* f_hidden, hipStream_t s) {
+    hipLaunchKernelGGL(k_rollout_final, dim3(p.n_inst), dim3(256), 0, s, p, f_state, f_valid, f_hidden);
 }
 
 }  // namespace tb

@@ -9,7 +9,8 @@ import ctypes as C
 import os
 from typing import Dict, Optional
 
-_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libtrafficbots_hip.so")
+# TB_HIP_LIB selects an alternative build of the same library (e.g. the -DTB_PROFILE one used by tools/)
+_LIB_PATH = os.environ.get("TB_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libtrafficbots_hip.so")
 
 c_f32p = C.POINTER(C.c_float)
 c_u8p = C.POINTER(C.c_uint8)

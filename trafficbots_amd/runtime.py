@@ -250,4 +250,5 @@ class HipEngine:
     def get_timing(self) -> Dict[str, float]:
         buf = (C.c_float * 4)()
         self._check(self.lib.tb_get_timing(self._ctx, buf), "tb_get_timing")
-        return {"step_a_ms": buf[0], "step_c_ms": buf[1], "prologue_ms": buf[2], "n_steps": int(buf[3])}
+        # fused launches = C(t)+A(t+1) (S-1 of them); edge launches = A(1) alone + C(S) alone
+        return {"fused_ms": buf[0], "edge_ms": buf[1], "prologue_ms": buf[2], "n_fused": int(buf[3])}
