@@ -67,3 +67,7 @@ lab = ["LN1 + barrier", "wload + Q proj (64 MFMA)", "attention 256 keys (8 x 32 
 for i in range(8):
     v = st[:, 17 + i] - st[:, 16 + i]
     print(f"    as2pl[0]/{lab[i]:40s} {np.median(v):8.0f}  [{v.min():7.0f} .. {v.max():7.0f}]")
+for nm, a_, b_ in (("blk0 phase A (QK next || exp)", 25, 26), ("blk0 phase B (PV || stats next)", 26, 27), ("blk1 phase A", 27, 28), ("blk1 phase B", 28, 29)):
+    v = st[:, b_] - st[:, a_]
+    print(f"    as2pl[0]/attention {nm:34s} {np.median(v):8.0f}  [{v.min():7.0f} .. {v.max():7.0f}]")
+print(f"    as2pl[0]/attention prologue (loads + first QK + stats) {np.median(st[:, 25] - st[:, 18]):8.0f}")

@@ -14,7 +14,7 @@
 namespace tb {
 size_t step_lds_bytes();
 void launch_kv_hoist(const float* W, const XLayerW* L3, const float* feat, const uint8_t* fvalid, int G, int n_tok, int n_pad,
-                     float* K, float* VT, uint8_t* kvalid, hipStream_t s);
+                     float* K, float* VT, float* kbias, hipStream_t s);
 void launch_rollout_init(const RolloutP& p, hipStream_t s);
 void launch_step(const RolloutP& p, int t, int do_c, int do_a, hipStream_t s);
 void launch_rollout_final(const RolloutP& p, float* f_state, uint8_t* f_valid, float* f_hidden, hipStream_t s);
@@ -336,13 +336,14 @@ static void carve_rollout(tb::RolloutP& p, Carver& c) {
     const size_t B = p.n_scene, N = p.n_inst, NH = p.n_hist;
     p.kpl = c.take<float>(B * 3 * p.p_pad * 128);
     p.vtpl = c.take<float>(B * 3 * 128 * p.p_pad);
-    p.kvalid_pl = c.take<uint8_t>(B * p.p_pad);
+    p.kbias_pl = c.take<float>(B * p.p_pad);
     p.ktl = c.take<float>(B * NH * 3 * p.t_pad * 128);
     p.vttl = c.take<float>(B * NH * 3 * 128 * p.t_pad);
-    p.kvalid_tl = c.take<uint8_t>(B * NH * p.t_pad);
+    p.kbias_tl = c.take<float>(B * NH * p.t_pad);
     p.state = c.take<float>(N * p.a_pad * 4);
     p.aux = c.take<float>(N * p.a_pad * 4);
     p.valid = c.take<uint8_t>(N * p.a_pad);
+    p.vbias = c.take<float>(N * p.a_pad);
     p.killed = c.take<uint8_t>(N * p.a_pad);
     p.goal_valid = c.take<uint8_t>(N * p.a_pad);
     p.dest_reached = c.take<uint8_t>(N * p.a_pad);
@@ -445,9 +446,9 @@ extern "C" int tb_rollout(tb_ctx* ctx, const tb_rollout_io* io, tb_stream stream
     }
     // ---- prologue: hoisted K/V of the map and of every history step's traffic lights; simulator init
     tb::launch_kv_hoist(p.W, p.pw.as2pl, p.map_feature, io->map_feature_valid, p.n_scene, p.n_pl, p.p_pad, p.kpl, p.vtpl,
-                        p.kvalid_pl, s);
+                        p.kbias_pl, s);
     tb::launch_kv_hoist(p.W, p.pw.as2tl, p.tl_feature, io->tl_feature_valid, p.n_scene * p.n_hist, p.n_tl, p.t_pad, p.ktl,
-                        p.vttl, p.kvalid_tl, s);
+                        p.vttl, p.kbias_tl, s);
     tb::launch_rollout_init(p, s);
     if (ctx->timing) TB_HIP(ctx, hipEventRecord(ctx->ev[1], s));
     // ---- the sequential loop (waymo_motion.py:269): launch i runs C(start+i-1) then A(start+i); no host sync

@@ -122,6 +122,49 @@ __device__ __forceinline__ void wmma(f32x4& acc_a, f32x4& acc_b, const WUnit& u,
     }
 }
 
+// Same MFMA block with the NEXT unit's 18 loads issued in the shadow of the MFMAs (one VMEM per 4 MFMAs): a
+// global_load_dwordx4 costs ~30 issue cycles that would otherwise sit in front of the chain.
+__device__ __forceinline__ void wmma_pf(f32x4& acc_a, f32x4& acc_b, const WUnit& u, const float* xrow, WUnit& un, const WNext& n,
+                                        int lane) {
+    const float* pa = n.wpk + ((size_t)(n.tile_a * n.kj_total + n.j0) * 64 + lane) * 4;
+    const float* pb = n.wpk + ((size_t)(n.tile_b * n.kj_total + n.j0) * 64 + lane) * 4;
+    const float* ba = n.bias ? n.bias + n.tile_a * 16 + (lane >> 4) * 4 : n.wpk;
+    const float* bb = n.bias ? n.bias + n.tile_b * 16 + (lane >> 4) * 4 : n.wpk;
+    TB_SCHED_FENCE();
+    un.b[0] = ldg4(ba);
+    un.b[1] = ldg4(bb);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        un.w[0][j] = ldg4(pa + j * 256);
+        un.w[1][j] = ldg4(pb + j * 256);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const f32x4 xv = lds4(xrow + 4 * j);
+        acc_a = mfma4(u.w[0][j].x, xv.x, acc_a);
+        acc_b = mfma4(u.w[1][j].x, xv.x, acc_b);
+        acc_a = mfma4(u.w[0][j].y, xv.y, acc_a);
+        acc_b = mfma4(u.w[1][j].y, xv.y, acc_b);
+        acc_a = mfma4(u.w[0][j].z, xv.z, acc_a);
+        acc_b = mfma4(u.w[1][j].z, xv.z, acc_b);
+        acc_a = mfma4(u.w[0][j].w, xv.w, acc_a);
+        acc_b = mfma4(u.w[1][j].w, xv.w, acc_b);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);  // 2 DS reads to prime
+    __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);  // bias loads
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        if ((g & 1) == 0 && g < 12) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    }
+    TB_SCHED_FENCE();
+    if (!n.bias) {
+        un.b[0] = f32x4{0.f, 0.f, 0.f, 0.f};
+        un.b[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+}
+
 // bias for the 4 features a lane holds of tile `tile`
 __device__ __forceinline__ f32x4 bias4(const float* __restrict__ b, int tile, int lane) {
     return ldg4(b + tile * 16 + (lane >> 4) * 4);
@@ -176,11 +219,24 @@ __device__ __forceinline__ float row16_sum(float v) {
 // ---------------------------------------------------------------------------------------------
 // LayerNorm of a [16][128] LDS tile: 16 threads per row, 8 elements each (two float4).
 // ---------------------------------------------------------------------------------------------
+// explicit LDS load: a generic pointer that may or may not be LDS makes the compiler emit FLAT loads, whose completion can
+// only be awaited with vmcnt(0) -- that would drain every prefetched weight / K / V load in flight
+typedef __attribute__((address_space(3))) const f32x4 lds_f32x4;
+__device__ __forceinline__ f32x4 lds4_explicit(const float* p) {
+    return *reinterpret_cast<lds_f32x4*>((__attribute__((address_space(3))) const char*)p);
+}
+
+template <bool PARAMS_IN_LDS = false>
 __device__ __forceinline__ void layernorm_tile(const float* src, int lds_, float* dst, int ldd,
                                                const float* __restrict__ g, const float* __restrict__ b, int tid) {
     const int row = tid >> 4, c0 = (tid & 15) * 8;
     const f32x4 a = lds4(src + row * lds_ + c0), c = lds4(src + row * lds_ + c0 + 4);
-    const f32x4 g0 = ldg4(g + c0), g1 = ldg4(g + c0 + 4), b0 = ldg4(b + c0), b1 = ldg4(b + c0 + 4);
+    f32x4 g0, g1, b0, b1;
+    if (PARAMS_IN_LDS) {
+        g0 = lds4_explicit(g + c0); g1 = lds4_explicit(g + c0 + 4); b0 = lds4_explicit(b + c0); b1 = lds4_explicit(b + c0 + 4);
+    } else {
+        g0 = ldg4(g + c0); g1 = ldg4(g + c0 + 4); b0 = ldg4(b + c0); b1 = ldg4(b + c0 + 4);
+    }
     const float s = row16_sum((a.x + a.y) + (a.z + a.w) + (c.x + c.y) + (c.z + c.w));
     const float mean = s * (1.0f / 128.0f);
     const f32x4 da = a - splat(mean), dc = c - splat(mean);
@@ -201,30 +257,80 @@ __device__ __forceinline__ void layernorm_tile(const float* src, int lds_, float
 // whether the agent row had no valid key at all (attention.py:101-107: its output is zeroed after out-proj).
 // K/V fragments of key tile t+2 are requested while tile t is being reduced (two register buffers).
 // ---------------------------------------------------------------------------------------------
-struct KVFrag {  // K / V^T fragments of 32 keys (two 16-key tiles) for one head
-    f32x4 ka[2][2], va[2][2];  // [tile][half of the 32 features]
-    uint32_t kv4[2];
+// exp(x) for x <= 0 as one v_exp_f32 with a compensated argument: t = rn(x*log2e), e = x*log2e - t (exact via fma + the
+// low word of log2e), exp(x) = 2^t * (1 + e*ln2).  Max relative error 1.2e-7 on [-100, 0] (tools/microtests); no
+// denormal / overflow handling is needed for softmax arguments.
+__device__ __forceinline__ float exp_neg(float x) {
+    const float L2E_HI = 1.44269502162933349609375f, L2E_LO = 1.925963033500011e-08f, LN2 = 0.693147182464599609375f;
+    x = fmaxf(x, -110.0f);  // 2^(-110 log2 e) underflows to exactly 0; keeps -inf (masked keys) away from inf - inf
+    const float t = x * L2E_HI;
+    float e = fmaf(x, L2E_HI, -t);
+    e = fmaf(x, L2E_LO, e);
+    const float r = __builtin_amdgcn_exp2f(t);
+    return fmaf(r, e * LN2, r);
+}
+
+// all-reduce over the four 16-lane rows of the wave (lanes l, l^16, l^32, l^48) with the gfx950 row swaps:
+// permlane16_swap(x, x) = {[x0,x0,x2,x2], [x1,x1,x3,x3]}, permlane32_swap(y, y) = {[y0,y1,y0,y1], [y2,y3,y2,y3]}
+// Written as inline asm with both registers as read-write operands: the instruction swaps rows between its two
+// registers in place (the clang builtin mis-tracks the second result when both inputs hold the same value).
+// hipcc pads nothing inside an asm statement, hence the s_nop's (VALU write -> permlane read, permlane -> VALU).
+__device__ __forceinline__ void rows_pair16(float v, float& lo, float& hi) {
+    float a = v, b = v;
+    asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+    lo = a;
+    hi = b;
+}
+__device__ __forceinline__ void rows_pair32(float v, float& lo, float& hi) {
+    float a = v, b = v;
+    asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+    lo = a;
+    hi = b;
+}
+__device__ __forceinline__ float rows_max(float v) {
+    float x, y;
+    rows_pair16(v, x, y);
+    v = fmaxf(x, y);
+    rows_pair32(v, x, y);
+    return fmaxf(x, y);
+}
+__device__ __forceinline__ float rows_sum(float v) {
+    float x, y;
+    rows_pair16(v, x, y);
+    v = x + y;
+    rows_pair32(v, x, y);
+    return x + y;
+}
+
+// K / V^T fragments of 32 keys (two 16-key tiles) for one head
+struct KFrag {
+    f32x4 ka[2][2];  // [tile][half of the 32 features]
+    f32x4 kb[2];     // additive key bias (0 valid / -inf invalid or padding) of this lane's 4 keys per tile
+};
+struct VFrag {
+    f32x4 va[2][2];
 };
 
-__device__ __forceinline__ void kv_load(KVFrag& f, const float* __restrict__ kbase, const float* __restrict__ vbase,
-                                        const uint8_t* __restrict__ keyvalid, int n_key_pad, int k0, int kq) {
-    TB_SCHED_FENCE();
+__device__ __forceinline__ void k_load(KFrag& f, const float* __restrict__ kbase, const float* __restrict__ bbase, int k0) {
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
         f.ka[t][0] = ldg4(kbase + (size_t)(k0 + 16 * t) * H);
         f.ka[t][1] = ldg4(kbase + (size_t)(k0 + 16 * t) * H + 16);
+        f.kb[t] = ldg4(bbase + k0 + 16 * t);
+    }
+}
+__device__ __forceinline__ void v_load(VFrag& f, const float* __restrict__ vbase, int n_key_pad, int k0) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
         f.va[t][0] = ldg4(vbase + k0 + 16 * t);
         f.va[t][1] = ldg4(vbase + (size_t)16 * n_key_pad + k0 + 16 * t);
-        f.kv4[t] = *reinterpret_cast<const uint32_t*>(keyvalid + k0 + 16 * t + kq * 4);
     }
-    TB_SCHED_FENCE();
 }
 
-// one online-softmax update over 32 keys: the two tiles' MFMA chains are interleaved (independent accumulators),
-// one running-max update / rescale per 32 keys
-__device__ __forceinline__ void attn_tile32(const KVFrag& f, const f32x4 (&q)[2], int kb, int self_key, float& run_max,
-                                            float& run_sum, f32x4 (&o)[2]) {
-    f32x4 s0 = splat(0.f), s1 = splat(0.f);
+// S^T tiles of 32 keys: s0 / s1[r] = logit(key k0 + 16 t + kq*4 + r, agent m), two interleaved MFMA chains
+__device__ __forceinline__ void attn_qk(const KFrag& f, const f32x4 (&q)[2], f32x4& s0, f32x4& s1) {
+    s0 = splat(0.f);
+    s1 = splat(0.f);
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         s0 = mfma4(f.ka[0][h].x, q[h].x, s0);
@@ -236,65 +342,145 @@ __device__ __forceinline__ void attn_tile32(const KVFrag& f, const f32x4 (&q)[2]
         s0 = mfma4(f.ka[0][h].w, q[h].w, s0);
         s1 = mfma4(f.ka[1][h].w, q[h].w, s1);
     }
-    // sv[t][r] = logit(key kb + 16 t + r, agent m)
-    float sv[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const bool ok = ((f.kv4[t] >> (8 * r)) & 0xffu) != 0 && (kb + 16 * t + r) != self_key;
-            sv[4 * t + r] = ok ? sv[4 * t + r] * ATTN_SCALE : -INFINITY;
-        }
-    float tmax = fmaxf(fmaxf(fmaxf(sv[0], sv[1]), fmaxf(sv[2], sv[3])), fmaxf(fmaxf(sv[4], sv[5]), fmaxf(sv[6], sv[7])));
-    tmax = fmaxf(tmax, __shfl_xor(tmax, 16));
-    tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
-    const float new_max = fmaxf(run_max, tmax);
-    const bool dead = (new_max == -INFINITY);
-    const float alpha = dead ? 1.0f : expf(run_max - new_max);
-    float p[8];
-#pragma unroll
-    for (int r = 0; r < 8; ++r) p[r] = dead ? 0.f : expf(sv[r] - new_max);
-    run_sum = run_sum * alpha + (((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7])));
-    run_max = new_max;
-    o[0] *= splat(alpha);
-    o[1] *= splat(alpha);
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        o[0] = mfma4(f.va[t][0].x, p[4 * t + 0], o[0]);
-        o[1] = mfma4(f.va[t][1].x, p[4 * t + 0], o[1]);
-        o[0] = mfma4(f.va[t][0].y, p[4 * t + 1], o[0]);
-        o[1] = mfma4(f.va[t][1].y, p[4 * t + 1], o[1]);
-        o[0] = mfma4(f.va[t][0].z, p[4 * t + 2], o[0]);
-        o[1] = mfma4(f.va[t][1].z, p[4 * t + 2], o[1]);
-        o[0] = mfma4(f.va[t][0].w, p[4 * t + 3], o[0]);
-        o[1] = mfma4(f.va[t][1].w, p[4 * t + 3], o[1]);
-    }
 }
 
-__device__ __forceinline__ bool attention_head(const f32x4 (&q)[2], const float* __restrict__ Kmat,
-                                               const float* __restrict__ VT, const uint8_t* __restrict__ keyvalid,
-                                               int n_key_pad, int head, int lane, int self_key, f32x4 (&o)[2]) {
+// scale + mask the 8 logits of a lane and fold them into the running max: sv = logits/sqrt(d) + bias,
+// new_max = max(run_max, max over the 32 keys), alpha = exp(run_max - new_max) (1 when nothing is valid yet)
+__device__ __forceinline__ void attn_stats(const f32x4& s0, const f32x4& s1, const f32x4 (&kb)[2], int kb0, int self_key,
+                                           float run_max, float (&sv)[8], float& new_max, float& alpha) {
+    const float raw[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+    const float bias[8] = {kb[0].x, kb[0].y, kb[0].z, kb[0].w, kb[1].x, kb[1].y, kb[1].z, kb[1].w};
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const float v = fmaf(raw[r], ATTN_SCALE, bias[r]);
+        sv[r] = (kb0 + 16 * (r >> 2) + (r & 3) == self_key) ? -INFINITY : v;  // self_key = -1 never matches
+    }
+    float tmax = fmaxf(fmaxf(fmaxf(sv[0], sv[1]), fmaxf(sv[2], sv[3])), fmaxf(fmaxf(sv[4], sv[5]), fmaxf(sv[6], sv[7])));
+    tmax = rows_max(tmax);
+    new_max = fmaxf(run_max, tmax);
+    // branch-free: (-inf) - (-inf) = NaN is clamped inside exp_neg (v_max drops the NaN) and yields 0, which is
+    // harmless because the running sum and the accumulators are still 0 in that case
+    alpha = exp_neg(run_max - new_max);
+}
+
+// One attention head (this wave's) over n_key_pad keys (multiple of 32) with online softmax.
+//   q[tt][r]  = Q^T[h*32 + tt*16 + kq*4 + r][agent]  (this wave's Q-projection accumulators, bias added)
+//   Kmat      = [n_key_pad][128] row-major, VT = [128][n_key_pad] (keys contiguous), both in global (L2)
+//   keybias   = float [n_key_pad]: 0 for valid keys, -inf for invalid / padding keys
+//   self_key  = key index that equals THIS LANE's agent (eye mask of MultiAgentTF), or -1
+// Returns o[dt][r] = O^T[h*32 + dt*16 + kq*4 + r][agent] (already divided by the softmax sum) and
+// whether the agent row had no valid key at all (attention.py:101-107: its output is zeroed after out-proj).
+//
+// Software pipeline per 32-key block i (one wave per SIMD issues in order, so VALU only overlaps MFMA when it sits
+// BETWEEN MFMAs in program order): phase A = QK MFMAs of block i+1 interleaved with the exponentials of block i,
+// phase B = PV MFMAs of block i interleaved with scale / mask / running-max of block i+1; K fragments are requested
+// two blocks ahead, V fragments one block ahead.
+struct AttnPre {  // first fragments of a head's K / V stream, requested before the Q projection so they land under it
+    KFrag k0f, kn;
+    VFrag vc;
+};
+
+__device__ __forceinline__ void attention_prefetch(AttnPre& a, const float* __restrict__ Kmat, const float* __restrict__ VT,
+                                                   const float* __restrict__ keybias, int n_key_pad, int head, int lane) {
     const int kq = lane >> 4, m = lane & 15;
-    float run_max = -INFINITY, run_sum = 0.f;
+    const float* kbase = Kmat + (size_t)m * H + head * DHEAD + kq * 4;
+    const float* vbase = VT + (size_t)(head * DHEAD + m) * n_key_pad + kq * 4;
+    const float* bbase = keybias + kq * 4;
+    TB_SCHED_FENCE();
+    k_load(a.k0f, kbase, bbase, 0);
+    v_load(a.vc, vbase, n_key_pad, 0);
+    k_load(a.kn, kbase, bbase, n_key_pad > 32 ? 32 : 0);
+    TB_SCHED_FENCE();
+}
+
+// keep a value in a VGPR (MFMA results otherwise live in AGPRs and every VALU touch costs v_accvgpr moves)
+__device__ __forceinline__ void in_vgpr(f32x4& v) { asm("" : "+v"(v)); }
+
+__device__ __forceinline__ bool attention_head(const f32x4 (&q)[2], AttnPre& pre, const float* __restrict__ Kmat,
+                                               const float* __restrict__ VT, const float* __restrict__ keybias,
+                                               int n_key_pad, int head, int lane, int self_key, f32x4 (&o)[2],
+                                               long long* prof = nullptr) {
+    const int kq = lane >> 4, m = lane & 15;
     o[0] = splat(0.f);
     o[1] = splat(0.f);
     const float* kbase = Kmat + (size_t)m * H + head * DHEAD + kq * 4;
     const float* vbase = VT + (size_t)(head * DHEAD + m) * n_key_pad + kq * 4;
-    KVFrag fa, fb;
-    kv_load(fa, kbase, vbase, keyvalid, n_key_pad, 0, kq);
-    // two register buffers: while one 32-key block is reduced the next is in flight
-    for (int k0 = 0; k0 < n_key_pad; k0 += 64) {
-        const int k1 = (k0 + 32 < n_key_pad) ? k0 + 32 : k0;
-        kv_load(fb, kbase, vbase, keyvalid, n_key_pad, k1, kq);
-        attn_tile32(fa, q, k0 + kq * 4, self_key, run_max, run_sum, o);
-        if (k0 + 32 < n_key_pad) {
-            const int k2 = (k0 + 64 < n_key_pad) ? k0 + 64 : k0;
-            kv_load(fa, kbase, vbase, keyvalid, n_key_pad, k2, kq);
-            attn_tile32(fb, q, k1 + kq * 4, self_key, run_max, run_sum, o);
-        }
+    const float* bbase = keybias + kq * 4;
+    KFrag kn = pre.kn;
+    VFrag vc = pre.vc;
+    float run_max = -INFINITY, run_sum = 0.f, new_max, alpha, sv[8];
+    {
+        f32x4 s0, s1;
+        attn_qk(pre.k0f, q, s0, s1);
+        in_vgpr(s0);
+        in_vgpr(s1);
+        attn_stats(s0, s1, pre.k0f.kb, kq * 4, self_key, run_max, sv, new_max, alpha);
     }
-    run_sum += __shfl_xor(run_sum, 16);
-    run_sum += __shfl_xor(run_sum, 32);
+    for (int k0 = 0; k0 < n_key_pad; k0 += 32) {
+        const bool has_next = k0 + 32 < n_key_pad;
+        const int k2 = (k0 + 64 < n_key_pad) ? k0 + 64 : k0;   // clamped re-reads on the tail are harmless
+        const int k1 = has_next ? k0 + 32 : k0;
+        // ---------------- phase A: QK(i+1) || exp(i), issue K(i+2) / V(i+1)
+#ifdef TB_PROFILE
+        if (prof && threadIdx.x == 0 && k0 < 64) prof[25 + (k0 >> 5) * 2] = clock64();
+#endif
+        TB_SCHED_FENCE();
+        f32x4 t0, t1;
+        in_vgpr(o[0]);
+        in_vgpr(o[1]);
+        attn_qk(kn, q, t0, t1);
+        f32x4 nb[2] = {kn.kb[0], kn.kb[1]};
+        KFrag k2f;
+        VFrag v1f;
+        k_load(k2f, kbase, bbase, k2);
+        v_load(v1f, vbase, n_key_pad, k1);
+        float p[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) p[r] = exp_neg(sv[r] - new_max);  // masked keys: -inf (or NaN) -> clamp -> exactly 0
+        run_sum = run_sum * alpha + (((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7])));
+        run_max = new_max;
+        o[0] *= splat(alpha);
+        o[1] *= splat(alpha);
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
+            __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);  // up to 5 VALU in its shadow
+            if (g < 11) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // 1 VMEM read
+        }
+        TB_SCHED_FENCE();
+        in_vgpr(t0);
+        in_vgpr(t1);
+        in_vgpr(o[0]);
+        in_vgpr(o[1]);
+#ifdef TB_PROFILE
+        if (prof && threadIdx.x == 0 && k0 < 64) prof[26 + (k0 >> 5) * 2] = clock64();
+#endif
+        // ---------------- phase B: PV(i) || stats(i+1)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            o[0] = mfma4(vc.va[t][0].x, p[4 * t + 0], o[0]);
+            o[1] = mfma4(vc.va[t][1].x, p[4 * t + 0], o[1]);
+            o[0] = mfma4(vc.va[t][0].y, p[4 * t + 1], o[0]);
+            o[1] = mfma4(vc.va[t][1].y, p[4 * t + 1], o[1]);
+            o[0] = mfma4(vc.va[t][0].z, p[4 * t + 2], o[0]);
+            o[1] = mfma4(vc.va[t][1].z, p[4 * t + 2], o[1]);
+            o[0] = mfma4(vc.va[t][0].w, p[4 * t + 3], o[0]);
+            o[1] = mfma4(vc.va[t][1].w, p[4 * t + 3], o[1]);
+        }
+        attn_stats(t0, t1, nb, k1 + kq * 4, self_key, run_max, sv, new_max, alpha);  // (unused after the last block)
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+        }
+        TB_SCHED_FENCE();
+        kn = k2f;
+        vc = v1f;
+#ifdef TB_PROFILE
+        if (prof && threadIdx.x == 0 && k0 == 32) prof[29] = clock64();
+#endif
+    }
+    run_sum = rows_sum(run_sum);
     const bool novalid = !(run_sum > 0.f);
     const float inv = novalid ? 0.f : 1.0f / run_sum;
     o[0] *= splat(inv);
@@ -317,17 +503,21 @@ struct GruLayerW {
 // ---------------------------------------------------------------------------------------------
 // One pre-LN cross-attention layer (transformer.py:189-239 + attention.py:81-146) on the LDS tile X.
 //   X    : [16][LDT] residual stream (in/out)         S1, S2 : [16][LDT] scratch
-//   Kmat/VT/keyvalid : projected keys / values of the tile's group for THIS layer
+//   Kmat/VT/keybias : projected keys / values (+ additive 0 / -inf key mask) of the tile's group for THIS layer
 //   rowvalid : LDS uint8[16]; invalid rows are zeroed at the end.   novalid_s : LDS uint8[16] scratch.
 //   self_key0: key index of row 0 for the eye mask, or -1 for none.
 //   u : in = this layer's Wq unit (already requested), out = `nxt` requested.
 // All 256 threads must call.  Ends with a barrier.
 // ---------------------------------------------------------------------------------------------
+template <bool LNLDS = false>
 __device__ __forceinline__ void xattn_layer(const float* __restrict__ W, const XLayerW& L, float* X, float* S1, float* S2,
                                             const float* __restrict__ Kmat, const float* __restrict__ VT,
-                                            const uint8_t* __restrict__ keyvalid, int n_key_pad, int self_key0,
+                                            const float* __restrict__ keybias, int n_key_pad, int self_key0,
                                             const uint8_t* rowvalid, uint8_t* novalid_s, int tid, WUnit& u, const WNext& nxt,
-                                            long long* prof = nullptr) {
+                                            const float* lnblk = nullptr, long long* prof = nullptr) {
+    // LayerNorm parameters: the six 128-vectors [ln1_g, ln1_b, lnt_g, lnt_b, ln2_g, ln2_b] are contiguous in the arena
+    // (tb_api.hip add_xlayer); `lnblk` may point at an LDS copy of that block (no VMEM in front of the K/V prefetch)
+    if (!LNLDS) lnblk = W + L.ln1_g;
     const int wave = tid >> 6, lane = tid & 63;
     const int kq = lane >> 4, m = lane & 15;
 #ifdef TB_PROFILE
@@ -336,19 +526,25 @@ __device__ __forceinline__ void xattn_layer(const float* __restrict__ W, const X
 #define TB_XSTAMP(i) do { } while (0)
 #endif
     TB_XSTAMP(16);
+    AttnPre apre;
+#ifndef TB_LATE_KV_PREFETCH
+    attention_prefetch(apre, Kmat, VT, keybias, n_key_pad, wave, lane);
+#endif
     // s = LN1(x)
-    layernorm_tile(X, LDT, S1, LDT, W + L.ln1_g, W + L.ln1_b, tid);
+    layernorm_tile<LNLDS>(X, LDT, S1, LDT, lnblk, lnblk + 128, tid);
     __syncthreads();
     TB_XSTAMP(17);
     WUnit u2;
     // q (this wave = head `wave`)
     f32x4 q[2] = {u.b[0], u.b[1]};
-    wload(u2, wstd(W + L.wo, W + L.bo, wave), lane);
-    wmma(q[0], q[1], u, S1 + m * LDT + kq * 32);
+    wmma_pf(q[0], q[1], u, S1 + m * LDT + kq * 32, u2, wstd(W + L.wo, W + L.bo, wave), lane);
     TB_XSTAMP(18);
+#ifdef TB_LATE_KV_PREFETCH
+    attention_prefetch(apre, Kmat, VT, keybias, n_key_pad, wave, lane);
+#endif
     f32x4 o[2];
-    const bool novalid = attention_head(q, Kmat, VT, keyvalid, n_key_pad, wave, lane,
-                                        self_key0 >= 0 ? self_key0 + m : -1, o);
+    const bool novalid = attention_head(q, apre, Kmat, VT, keybias, n_key_pad, wave, lane,
+                                        self_key0 >= 0 ? self_key0 + m : -1, o, prof);
     TB_XSTAMP(19);
     st4(cptr(S2, LDT, 2 * wave, lane), o[0]);
     st4(cptr(S2, LDT, 2 * wave + 1, lane), o[1]);
@@ -358,8 +554,7 @@ __device__ __forceinline__ void xattn_layer(const float* __restrict__ W, const X
     // out-proj + residual
     {
         f32x4 acc[2] = {u2.b[0], u2.b[1]};
-        wload(u, wstd(W + L.w1, W + L.b1, wave), lane);
-        wmma(acc[0], acc[1], u2, S2 + m * LDT + kq * 32);
+        wmma_pf(acc[0], acc[1], u2, S2 + m * LDT + kq * 32, u, wstd(W + L.w1, W + L.b1, wave), lane);
         const bool nv = novalid_s[m] != 0;
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
@@ -371,13 +566,12 @@ __device__ __forceinline__ void xattn_layer(const float* __restrict__ W, const X
     __syncthreads();
     TB_XSTAMP(21);
     // FFN
-    layernorm_tile(X, LDT, S1, LDT, W + L.ln2_g, W + L.ln2_b, tid);
+    layernorm_tile<LNLDS>(X, LDT, S1, LDT, lnblk + 512, lnblk + 640, tid);
     __syncthreads();
     TB_XSTAMP(22);
     {
         f32x4 acc[2] = {u.b[0], u.b[1]};
-        wload(u2, wstd(W + L.w2, W + L.b2, wave), lane);
-        wmma(acc[0], acc[1], u, S1 + m * LDT + kq * 32);
+        wmma_pf(acc[0], acc[1], u, S1 + m * LDT + kq * 32, u2, wstd(W + L.w2, W + L.b2, wave), lane);
         st4(cptr(S2, LDT, 2 * wave, lane), relu4(acc[0]));
         st4(cptr(S2, LDT, 2 * wave + 1, lane), relu4(acc[1]));
     }
@@ -385,8 +579,7 @@ __device__ __forceinline__ void xattn_layer(const float* __restrict__ W, const X
     TB_XSTAMP(23);
     {
         f32x4 acc[2] = {u2.b[0], u2.b[1]};
-        wload(u, nxt, lane);
-        wmma(acc[0], acc[1], u2, S2 + m * LDT + kq * 32);
+        wmma_pf(acc[0], acc[1], u2, S2 + m * LDT + kq * 32, u, nxt, lane);
         const bool rv = rowvalid[m] != 0;
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
@@ -410,25 +603,25 @@ __device__ __forceinline__ WNext kvproj_first(const float* W, const XLayerW& L, 
 // Wave w produces K tiles {2w,2w+1} and V tiles {8+2w, 8+2w+1} (head w).
 //   u : in = the K unit (tiles 2w, 2w+1 of wkv), out = `nxt`.   Ends with a barrier.
 // ---------------------------------------------------------------------------------------------
+template <bool LNLDS = false>
 __device__ __forceinline__ void kv_project_tile(const float* __restrict__ W, const XLayerW& L, const float* T, float* S1,
                                                 float* __restrict__ Kmat, float* __restrict__ VT, int n_key_pad, int tok0,
-                                                int n_real_rows, int tid, WUnit& u, const WNext& nxt) {
+                                                int n_real_rows, int tid, WUnit& u, const WNext& nxt, const float* lnblk = nullptr) {
     const int wave = tid >> 6, lane = tid & 63;
     const int kq = lane >> 4, m = lane & 15;
-    layernorm_tile(T, LDT, S1, LDT, W + L.lnt_g, W + L.lnt_b, tid);
+    if (!LNLDS) lnblk = W + L.ln1_g;
+    layernorm_tile<LNLDS>(T, LDT, S1, LDT, lnblk + 256, lnblk + 384, tid);
     __syncthreads();
     const int tiles[4] = {2 * wave, 2 * wave + 1, 8 + 2 * wave, 8 + 2 * wave + 1};
     WUnit u2;
     f32x4 acc[4];
     acc[0] = u.b[0];
     acc[1] = u.b[1];
-    wload(u2, wnext(W + L.wkv, W + L.bkv, tiles[2], tiles[3]), lane);
     const float* xr = S1 + m * LDT + kq * 32;
-    wmma(acc[0], acc[1], u, xr);
+    wmma_pf(acc[0], acc[1], u, xr, u2, wnext(W + L.wkv, W + L.bkv, tiles[2], tiles[3]), lane);
     acc[2] = u2.b[0];
     acc[3] = u2.b[1];
-    wload(u, nxt, lane);
-    wmma(acc[2], acc[3], u2, xr);
+    wmma_pf(acc[2], acc[3], u2, xr, u, nxt, lane);
     const bool real = m < n_real_rows;
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
@@ -468,23 +661,17 @@ __device__ __forceinline__ void gru_layer(const float* __restrict__ W, const Gru
     f32x4 r[2], z[2], gin[2], ghn[2];
     const float* wih = W + G.wih; const float* whh = W + G.whh; const float* bih = W + G.bih; const float* bhh = W + G.bhh;
     r[0] = u.b[0]; r[1] = u.b[1];
-    wload(u2, wnext(whh, bhh, tr0, tr0 + 1), lane);
-    wmma(r[0], r[1], u, xr);
+    wmma_pf(r[0], r[1], u, xr, u2, wnext(whh, bhh, tr0, tr0 + 1), lane);
     r[0] += u2.b[0]; r[1] += u2.b[1];
-    wload(u, wnext(wih, bih, tz0, tz0 + 1), lane);
-    wmma(r[0], r[1], u2, hr);
+    wmma_pf(r[0], r[1], u2, hr, u, wnext(wih, bih, tz0, tz0 + 1), lane);
     z[0] = u.b[0]; z[1] = u.b[1];
-    wload(u2, wnext(whh, bhh, tz0, tz0 + 1), lane);
-    wmma(z[0], z[1], u, xr);
+    wmma_pf(z[0], z[1], u, xr, u2, wnext(whh, bhh, tz0, tz0 + 1), lane);
     z[0] += u2.b[0]; z[1] += u2.b[1];
-    wload(u, wnext(wih, bih, tn0, tn0 + 1), lane);
-    wmma(z[0], z[1], u2, hr);
+    wmma_pf(z[0], z[1], u2, hr, u, wnext(wih, bih, tn0, tn0 + 1), lane);
     gin[0] = u.b[0]; gin[1] = u.b[1];
-    wload(u2, wnext(whh, bhh, tn0, tn0 + 1), lane);
-    wmma(gin[0], gin[1], u, xr);
+    wmma_pf(gin[0], gin[1], u, xr, u2, wnext(whh, bhh, tn0, tn0 + 1), lane);
     ghn[0] = u2.b[0]; ghn[1] = u2.b[1];
-    wload(u, nxt, lane);
-    wmma(ghn[0], ghn[1], u2, hr);
+    wmma_pf(ghn[0], ghn[1], u2, hr, u, nxt, lane);
     const bool rv = rowvalid[m] != 0;
 #pragma unroll
     for (int t = 0; t < 2; ++t) {

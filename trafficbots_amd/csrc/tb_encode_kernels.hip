@@ -12,7 +12,7 @@
 namespace tb {
 
 void launch_kv_hoist_n(const float* W, const XLayerW* L, int n_layer, const float* feat, const uint8_t* fvalid, int G,
-                       int n_tok, int n_pad, float* K, float* VT, uint8_t* kvalid, hipStream_t s);
+                       int n_tok, int n_pad, float* K, float* VT, float* kbias, hipStream_t s);
 
 // ------------------------------------------------------------------------------------------------
 // token feature encoder: attr + pose PE -> MLP(attr,32,32) || PE(96)
@@ -144,7 +144,7 @@ struct XBlockP {
     float* dst;                // [G][n_rows][128]
     const float* K;            // [G][n_layer][n_pad][128]
     const float* VT;           // [G][n_layer][128][n_pad]
-    const uint8_t* kvalid;     // [G][n_pad]
+    const float* kbias;        // [G][n_pad] additive key mask
     int n_rows, n_pad;
     int eye;                   // MultiAgentTF: self key masked; groups with exactly one valid row pass through
 };
@@ -175,7 +175,7 @@ __global__ __launch_bounds__(NTHREADS) void k_xattn_block(XBlockP p) {
         for (int l = 0; l < p.n_layer; ++l) {
             const WNext nxt = xlayer_first(p.W, p.L[l + 1 < p.n_layer ? l + 1 : l], wave);
             xattn_layer(p.W, p.L[l], X, S1, S2, p.K + ((size_t)g * p.n_layer + l) * p.n_pad * H,
-                        p.VT + ((size_t)g * p.n_layer + l) * H * p.n_pad, p.kvalid + (size_t)g * p.n_pad, p.n_pad,
+                        p.VT + ((size_t)g * p.n_layer + l) * H * p.n_pad, p.kbias + (size_t)g * p.n_pad, p.n_pad,
                         p.eye ? row0 : -1, rowvalid, novalid_s, tid, u, nxt);
         }
     }
@@ -186,14 +186,15 @@ __global__ __launch_bounds__(NTHREADS) void k_xattn_block(XBlockP p) {
 __global__ __launch_bounds__(NTHREADS) void k_kv_hoist_n(const float* __restrict__ W, XLayerW l0, XLayerW l1, XLayerW l2, int n_layer,
                                                         const float* __restrict__ feat, const uint8_t* __restrict__ fvalid, int n_tok,
                                                         int n_pad, float* __restrict__ Kout, float* __restrict__ VTout,
-                                                        uint8_t* __restrict__ kvalid) {
+                                                        float* __restrict__ kbias) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* T = smem;
     float* S1 = smem + TM * LDT;
     const int tid = threadIdx.x, g = blockIdx.y, tok0 = blockIdx.x * TM;
     const int n_real = max(0, min(TM, n_tok - tok0));
     load_tile(T, LDT, feat + ((size_t)g * n_tok + tok0) * H, n_real, tid);
-    if (tid < TM) kvalid[(size_t)g * n_pad + tok0 + tid] = (tid < n_real) ? fvalid[(size_t)g * n_tok + tok0 + tid] : 0;
+    if (tid < TM)
+        kbias[(size_t)g * n_pad + tok0 + tid] = (tid < n_real && fvalid[(size_t)g * n_tok + tok0 + tid]) ? 0.f : -INFINITY;
     __syncthreads();
     const XLayerW* Ls[3] = {&l0, &l1, &l2};
     const int wave = tid >> 6, lane = tid & 63;
@@ -208,10 +209,10 @@ __global__ __launch_bounds__(NTHREADS) void k_kv_hoist_n(const float* __restrict
 }
 
 void launch_kv_hoist_n(const float* W, const XLayerW* L, int n_layer, const float* feat, const uint8_t* fvalid, int G, int n_tok,
-                       int n_pad, float* K, float* VT, uint8_t* kvalid, hipStream_t s) {
+                       int n_pad, float* K, float* VT, float* kbias, hipStream_t s) {
     dim3 grid(n_pad / TM, G);
     hipLaunchKernelGGL(k_kv_hoist_n, grid, dim3(NTHREADS), 2 * TM * LDT * sizeof(float), s, W, L[0], L[n_layer > 1 ? 1 : 0],
-                       L[n_layer > 2 ? 2 : 0], n_layer, feat, fvalid, n_tok, n_pad, K, VT, kvalid);
+                       L[n_layer > 2 ? 2 : 0], n_layer, feat, fvalid, n_tok, n_pad, K, VT, kbias);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -487,22 +488,22 @@ int run_encode(struct ::tb_ctx* ctx, const tb_encode_io* io, hipStream_t s) {
     // map-encoder chunking bounds the per-polyline K/V scratch (3 layers x 32 keys x 128 x 2 x 4 B = 96 KiB / polyline)
     const int scenes_per_chunk = std::max(1, std::min(B, (int)(((size_t)512 << 20) / ((size_t)P * 98304))));
 
-    auto carve = [&](Carver& c, float*& nodef, float*& nodeo, float*& kn, float*& vtn, uint8_t*& kvn, float*& plf, float*& kps,
-                     float*& vtps, uint8_t*& kvps, float*& kpl, float*& vtpl, uint8_t*& kvpl, float*& x0, uint8_t*& v0, float*& x1,
-                     float*& x2, float*& x3, float*& tl3, uint8_t*& tlv3, float*& ktl, float*& vttl, uint8_t*& kvtl, float*& kin,
-                     float*& vtin, uint8_t*& kvin, float*& tgt, uint8_t*& tgtv, float*& U, float*& V) {
+    auto carve = [&](Carver& c, float*& nodef, float*& nodeo, float*& kn, float*& vtn, float*& kvn, float*& plf, float*& kps,
+                     float*& vtps, float*& kvps, float*& kpl, float*& vtpl, float*& kvpl, float*& x0, uint8_t*& v0, float*& x1,
+                     float*& x2, float*& x3, float*& tl3, uint8_t*& tlv3, float*& ktl, float*& vttl, float*& kvtl, float*& kin,
+                     float*& vtin, float*& kvin, float*& tgt, uint8_t*& tgtv, float*& U, float*& V) {
         nodef = c.take<float>((size_t)B * P * 20 * 128);
         nodeo = c.take<float>((size_t)scenes_per_chunk * P * 20 * 128);
         kn = c.take<float>((size_t)scenes_per_chunk * P * 3 * 32 * 128);
         vtn = c.take<float>((size_t)scenes_per_chunk * P * 3 * 128 * 32);
-        kvn = c.take<uint8_t>((size_t)scenes_per_chunk * P * 32);
+        kvn = c.take<float>((size_t)scenes_per_chunk * P * 32);
         plf = c.take<float>((size_t)B * P * 128);
         kps = c.take<float>((size_t)B * p_pad * 128);
         vtps = c.take<float>((size_t)B * 128 * p_pad);
-        kvps = c.take<uint8_t>((size_t)B * p_pad);
+        kvps = c.take<float>((size_t)B * p_pad);
         kpl = c.take<float>((size_t)B * 3 * p_pad * 128);
         vtpl = c.take<float>((size_t)B * 3 * 128 * p_pad);
-        kvpl = c.take<uint8_t>((size_t)B * p_pad);
+        kvpl = c.take<float>((size_t)B * p_pad);
         x0 = c.take<float>((size_t)B * S3 * A * 128);
         v0 = c.take<uint8_t>((size_t)B * S3 * A);
         x1 = c.take<float>((size_t)B * S3 * A * 128);
@@ -512,17 +513,18 @@ int run_encode(struct ::tb_ctx* ctx, const tb_encode_io* io, hipStream_t s) {
         tlv3 = c.take<uint8_t>((size_t)B * S3 * T);
         ktl = c.take<float>((size_t)B * S3 * 3 * t_pad * 128);
         vttl = c.take<float>((size_t)B * S3 * 3 * 128 * t_pad);
-        kvtl = c.take<uint8_t>((size_t)B * S3 * t_pad);
+        kvtl = c.take<float>((size_t)B * S3 * t_pad);
         kin = c.take<float>((size_t)B * S3 * 3 * a_pad * 128);
         vtin = c.take<float>((size_t)B * S3 * 3 * 128 * a_pad);
-        kvin = c.take<uint8_t>((size_t)B * S3 * a_pad);
+        kvin = c.take<float>((size_t)B * S3 * a_pad);
         tgt = c.take<float>((size_t)B * A * 128);
         tgtv = c.take<uint8_t>((size_t)B * A);
         U = c.take<float>((size_t)B * P * 128);
         V = c.take<float>((size_t)B * A * 128);
     };
     float *nodef, *nodeo, *kn, *vtn, *plf, *kps, *vtps, *kpl, *vtpl, *x0, *x1, *x2, *x3, *tl3, *ktl, *vttl, *kin, *vtin, *tgt, *U, *V;
-    uint8_t *kvn, *kvps, *kvpl, *v0, *tlv3, *kvtl, *kvin, *tgtv;
+    uint8_t *v0, *tlv3, *tgtv;
+    float *kvn, *kvps, *kvpl, *kvtl, *kvin;
     Carver sz{nullptr};
     carve(sz, nodef, nodeo, kn, vtn, kvn, plf, kps, vtps, kvps, kpl, vtpl, kvpl, x0, v0, x1, x2, x3, tl3, tlv3, ktl, vttl, kvtl, kin,
           vtin, kvin, tgt, tgtv, U, V);
@@ -561,7 +563,7 @@ int run_encode(struct ::tb_ctx* ctx, const tb_encode_io* io, hipStream_t s) {
         XBlockP x{};
         x.W = W; x.n_layer = 3;
         for (int l = 0; l < 3; ++l) x.L[l] = ew.densetnt[l];
-        x.src = src; x.src_valid = sv; x.dst = nodeo; x.K = kn; x.VT = vtn; x.kvalid = kvn; x.n_rows = 20; x.n_pad = 32; x.eye = 0;
+        x.src = src; x.src_valid = sv; x.dst = nodeo; x.K = kn; x.VT = vtn; x.kbias = kvn; x.n_rows = 20; x.n_pad = 32; x.eye = 0;
         launch_xblock(x, G, s);
         const int nthr = G * 32;
         hipLaunchKernelGGL(k_pool_nodes, dim3((nthr + 255) / 256), dim3(256), 0, s, nodeo, sv, G, plf + (size_t)b0 * P * 128,
@@ -571,7 +573,7 @@ int run_encode(struct ::tb_ctx* ctx, const tb_encode_io* io, hipStream_t s) {
         launch_kv_hoist_n(W, &ew.map_self, 1, plf, io->map_feature_valid, B, P, p_pad, kps, vtps, kvps, s);
         XBlockP x{};
         x.W = W; x.n_layer = 1; x.L[0] = ew.map_self;
-        x.src = plf; x.src_valid = io->map_feature_valid; x.dst = io->map_feature; x.K = kps; x.VT = vtps; x.kvalid = kvps;
+        x.src = plf; x.src_valid = io->map_feature_valid; x.dst = io->map_feature; x.K = kps; x.VT = vtps; x.kbias = kvps;
         x.n_rows = P; x.n_pad = p_pad; x.eye = 0;
         launch_xblock(x, B, s);
     }
@@ -591,17 +593,17 @@ int run_encode(struct ::tb_ctx* ctx, const tb_encode_io* io, hipStream_t s) {
         XBlockP x{};
         x.W = W; x.n_layer = 3;
         for (int l = 0; l < 3; ++l) x.L[l] = ew.as2pl[l];
-        x.src = x0; x.src_valid = v0; x.dst = x1; x.K = kpl; x.VT = vtpl; x.kvalid = kvpl; x.n_rows = S3 * A; x.n_pad = p_pad; x.eye = 0;
+        x.src = x0; x.src_valid = v0; x.dst = x1; x.K = kpl; x.VT = vtpl; x.kbias = kvpl; x.n_rows = S3 * A; x.n_pad = p_pad; x.eye = 0;
         launch_xblock(x, B, s);
         // agent -> traffic lights, per step
         launch_kv_hoist_n(W, ew.as2tl, 3, tl3, tlv3, B * S3, T, t_pad, ktl, vttl, kvtl, s);
         for (int l = 0; l < 3; ++l) x.L[l] = ew.as2tl[l];
-        x.src = x1; x.dst = x2; x.K = ktl; x.VT = vttl; x.kvalid = kvtl; x.n_rows = A; x.n_pad = t_pad;
+        x.src = x1; x.dst = x2; x.K = ktl; x.VT = vttl; x.kbias = kvtl; x.n_rows = A; x.n_pad = t_pad;
         launch_xblock(x, B * S3, s);
         // interaction (own weights), tgt = block input
         launch_kv_hoist_n(W, ew.inter_prior, 3, x2, v0, B * S3, A, a_pad, kin, vtin, kvin, s);
         for (int l = 0; l < 3; ++l) x.L[l] = ew.inter_prior[l];
-        x.src = x2; x.dst = x3; x.K = kin; x.VT = vtin; x.kvalid = kvin; x.n_rows = A; x.n_pad = a_pad; x.eye = 1;
+        x.src = x2; x.dst = x3; x.K = kin; x.VT = vtin; x.kbias = kvin; x.n_rows = A; x.n_pad = a_pad; x.eye = 1;
         launch_xblock(x, B * S3, s);
         ScanP sp{};
         sp.W = W;

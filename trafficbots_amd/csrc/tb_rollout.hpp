@@ -36,10 +36,10 @@ struct RolloutP {
     // hoisted keys/values
     float* kpl;                   // [B,3,p_pad,128]
     float* vtpl;                  // [B,3,128,p_pad]
-    uint8_t* kvalid_pl;           // [B,p_pad]
+    float* kbias_pl;              // [B,p_pad]   additive key mask: 0 valid, -inf invalid / padding
     float* ktl;                   // [B*NH,3,t_pad,128]
     float* vttl;                  // [B*NH,3,128,t_pad]
-    uint8_t* kvalid_tl;           // [B*NH,t_pad]
+    float* kbias_tl;              // [B*NH,t_pad]
     // history / teacher forcing
     const uint8_t* hist_valid;    // [B,NH,A]
     const float* hist_state;      // [B,NH,A,4]
@@ -64,6 +64,7 @@ struct RolloutP {
     float* state;                 // [N,a_pad,4]
     float* aux;                   // [N,a_pad,4]  vel_x, vel_y, acc, yaw_rate as last teacher-forced
     uint8_t* valid;               // [N,a_pad]
+    float* vbias;                 // [N,a_pad]  same as `valid` as additive key mask for the interaction
     uint8_t* killed;
     uint8_t* goal_valid;
     uint8_t* dest_reached;

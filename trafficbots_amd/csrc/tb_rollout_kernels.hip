@@ -27,7 +27,8 @@ constexpr int OFF_H2 = OFF_H1 + TM * LDT;  // [16][LDT] GRU hidden layer 2
 constexpr int OFF_GP = OFF_H2 + TM * LDT;  // [16][LDT] add_goal.mlp_in output of the tile's agents
 constexpr int OFF_LP = OFF_GP + TM * LDT;  // [16][LDT] add_latent.mlp_in output
 constexpr int OFF_DG = OFF_LP + TM * LDT;  // [16][80]  destination polyline geometry (20 nodes x px,py,dx,dy)
-constexpr int OFF_SMALL = OFF_DG + TM * 80;
+constexpr int OFF_LN = OFF_DG + TM * 80;   // [9][768] LayerNorm parameter blocks of inter / as2pl / as2tl layers
+constexpr int OFF_SMALL = OFF_LN + 9 * 768;
 constexpr int SMALL_FLOATS = 16 * 16 /*attr*/ + 16 * 32 /*enc hidden*/ + 16 * 8 /*row state*/ + 32 /*u*/ + 64 /*flags,types*/;
 constexpr int STEP_LDS_FLOATS = OFF_SMALL + SMALL_FLOATS;
 
@@ -56,7 +57,7 @@ __global__ __launch_bounds__(NTHREADS) void k_kv_hoist(const float* __restrict__
                                                       const uint8_t* __restrict__ fvalid /*[G][n_tok]*/, int n_tok, int n_pad,
                                                       float* __restrict__ Kout /*[G][3][n_pad][128]*/,
                                                       float* __restrict__ VTout /*[G][3][128][n_pad]*/,
-                                                      uint8_t* __restrict__ kvalid /*[G][n_pad]*/) {
+                                                      float* __restrict__ kbias /*[G][n_pad] 0 valid / -inf*/) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* T = smem;
     float* S1 = smem + TM * LDT;
@@ -65,7 +66,8 @@ __global__ __launch_bounds__(NTHREADS) void k_kv_hoist(const float* __restrict__
     WUnit u;
     wload(u, kvproj_first(W, l0, wave), lane);
     load_tile(T, LDT, feat + ((size_t)g * n_tok + tok0) * H, n_real, tid);
-    if (tid < TM) kvalid[(size_t)g * n_pad + tok0 + tid] = (tid < n_real) ? fvalid[(size_t)g * n_tok + tok0 + tid] : 0;
+    if (tid < TM)
+        kbias[(size_t)g * n_pad + tok0 + tid] = (tid < n_real && fvalid[(size_t)g * n_tok + tok0 + tid]) ? 0.f : -INFINITY;
     __syncthreads();
     kv_project_tile(W, l0, T, S1, Kout + ((size_t)g * 3 + 0) * n_pad * H, VTout + ((size_t)g * 3 + 0) * H * n_pad, n_pad, tok0,
                     n_real, tid, u, kvproj_first(W, l1, wave));
@@ -105,6 +107,7 @@ __global__ __launch_bounds__(NTHREADS) void k_rollout_init(RolloutP p) {
         st4(p.state + si * 4, st);
         st4(p.aux + si * 4, ax);
         p.valid[si] = v;
+        p.vbias[si] = v ? 0.f : -INFINITY;
         p.killed[si] = 0;
         p.goal_valid[si] = gv;
         p.dest_reached[si] = 0;
@@ -248,14 +251,12 @@ __device__ __forceinline__ void fuse_latent_goal(const float* __restrict__ W, ui
     {
         const int ta = 2 * wave, tb_ = 2 * wave + 1;
         f32x4 acc[2] = {uw.b[0], uw.b[1]};
-        wload(u2, wnext(W + w1, nullptr, ta, tb_, 16, 8), lane);
         const float* xr = CAT + m * LDC + kq * 64;
-        wmma(acc[0], acc[1], uw, xr);
+        wmma_pf(acc[0], acc[1], uw, xr, u2, wnext(W + w1, nullptr, ta, tb_, 16, 8), lane);
 #ifdef TB_PROFILE
         if (prof && threadIdx.x == 0) prof[13] = clock64();
 #endif
-        wload(uw, wstd(W + w2, W + b2, wave), lane);
-        wmma(acc[0], acc[1], u2, xr + 32);
+        wmma_pf(acc[0], acc[1], u2, xr + 32, uw, wstd(W + w2, W + b2, wave), lane);
 #ifdef TB_PROFILE
         if (prof && threadIdx.x == 0) prof[14] = clock64();
 #endif
@@ -268,8 +269,7 @@ __device__ __forceinline__ void fuse_latent_goal(const float* __restrict__ W, ui
 #endif
     {
         f32x4 acc[2] = {uw.b[0], uw.b[1]};
-        wload(u2, nxt, lane);
-        wmma(acc[0], acc[1], uw, S2 + m * LDT + kq * 32);
+        wmma_pf(acc[0], acc[1], uw, S2 + m * LDT + kq * 32, u2, nxt, lane);
         const bool zv = zvalid[m] != 0, rv = rowvalid[m] != 0;
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
@@ -304,6 +304,7 @@ __global__ __launch_bounds__(NTHREADS) void k_step(RolloutP p, int t, int do_c, 
     float* GP = smem + OFF_GP;
     float* LP = smem + OFF_LP;
     float* DG = smem + OFF_DG;
+    float* LN = smem + OFF_LN;
     float* attr = smem + OFF_SMALL;                         // [16][16]
     float* ench = attr + 16 * 16;                           // [16][32]
     RowSt* rst = reinterpret_cast<RowSt*>(ench + 16 * 32);  // [16]
@@ -323,6 +324,14 @@ __global__ __launch_bounds__(NTHREADS) void k_step(RolloutP p, int t, int do_c, 
 
     WUnit u;
     TB_STAMP(0);
+    {
+        // LayerNorm parameter blocks -> LDS (slots 0..2 interaction, 3..5 as2pl, 6..8 as2tl)
+        const uint32_t base[9] = {pw.inter[0].ln1_g, pw.inter[1].ln1_g, pw.inter[2].ln1_g, pw.as2pl[0].ln1_g, pw.as2pl[1].ln1_g,
+                                  pw.as2pl[2].ln1_g, pw.as2tl[0].ln1_g, pw.as2tl[1].ln1_g, pw.as2tl[2].ln1_g};
+#pragma unroll
+        for (int sl = 0; sl < 9; ++sl)
+            if (tid < 192) st4(LN + sl * 768 + tid * 4, ldg4(W + base[sl] + tid * 4));
+    }
     if (tid < TM) {
         rtype[tid] = (tid < n_real) ? p.agent_type[(size_t)b * p.n_agent + row0 + tid] : -1;
         const size_t si = base_row + tid;
@@ -336,7 +345,9 @@ __global__ __launch_bounds__(NTHREADS) void k_step(RolloutP p, int t, int do_c, 
     if (do_c) {
         // =================================== C(t) ===================================
         // number of valid agents of the instance (agent_interaction.py:61: exactly one -> bypass the block)
-        const int n_valid = __syncthreads_count(tid < p.a_pad && p.valid[(size_t)n * p.a_pad + tid]);
+        int n_valid = 0;
+        for (int i0 = 0; i0 < p.a_pad; i0 += 64)  // every wave counts for itself: no LDS round trip
+            n_valid += __popcll(__ballot(i0 + lane < p.a_pad && p.valid[(size_t)n * p.a_pad + i0 + lane] != 0));
         const bool bypass = n_valid == 1;
         wload(u, bypass ? gru_first(W, pw.gru[0], wave) : xlayer_first(W, pw.inter[0], wave), lane);
         // one burst of per-tile inputs for the whole C half (a single exposed global latency)
@@ -351,16 +362,16 @@ __global__ __launch_bounds__(NTHREADS) void k_step(RolloutP p, int t, int do_c, 
         __syncthreads();
         TB_STAMP(1);
         if (!bypass) {
-            const uint8_t* kvd = p.valid + (size_t)n * p.a_pad;
+            const float* kvd = p.vbias + (size_t)n * p.a_pad;
             const size_t ls = (size_t)p.a_pad * H;
             const float* K0 = p.kin + ((size_t)n * 3) * ls;
             const float* V0 = p.vtin + ((size_t)n * 3) * ls;
-            xattn_layer(W, pw.inter[0], X, S1, S2, K0, V0, kvd, p.a_pad, row0, rowvalid, novalid_s, tid, u,
-                        xlayer_first(W, pw.inter[1], wave));
-            xattn_layer(W, pw.inter[1], X, S1, S2, K0 + ls, V0 + ls, kvd, p.a_pad, row0, rowvalid, novalid_s, tid, u,
-                        xlayer_first(W, pw.inter[2], wave));
-            xattn_layer(W, pw.inter[2], X, S1, S2, K0 + 2 * ls, V0 + 2 * ls, kvd, p.a_pad, row0, rowvalid, novalid_s, tid, u,
-                        gru_first(W, pw.gru[0], wave));
+            xattn_layer<true>(W, pw.inter[0], X, S1, S2, K0, V0, kvd, p.a_pad, row0, rowvalid, novalid_s, tid, u,
+                        xlayer_first(W, pw.inter[1], wave), LN + 0 * 768);
+            xattn_layer<true>(W, pw.inter[1], X, S1, S2, K0 + ls, V0 + ls, kvd, p.a_pad, row0, rowvalid, novalid_s, tid, u,
+                        xlayer_first(W, pw.inter[2], wave), LN + 1 * 768);
+            xattn_layer<true>(W, pw.inter[2], X, S1, S2, K0 + 2 * ls, V0 + 2 * ls, kvd, p.a_pad, row0, rowvalid, novalid_s, tid, u,
+                        gru_first(W, pw.gru[0], wave), LN + 2 * 768);
         }
         TB_STAMP(2);
         // ---- 3-layer GRU, one step (agent_temporal.py:147-152): X -> Y -> S1 -> X
@@ -379,9 +390,8 @@ __global__ __launch_bounds__(NTHREADS) void k_step(RolloutP p, int t, int do_c, 
                          wnext(W + pw.lat_out_w1, W + pw.lat_out_b1, 2 * wave, 2 * wave + 1, 16, 0),
                          p.prof + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 32);
         // action-head branches needed by this tile (action_head.py:69-75): one per agent type present
-        const bool has0 = __syncthreads_or(tid < TM && rtype[tid] == 0 && rowvalid[tid]);
-        const bool has1 = __syncthreads_or(tid < TM && rtype[tid] == 1 && rowvalid[tid]);
-        const bool has2 = __syncthreads_or(tid < TM && rtype[tid] == 2 && rowvalid[tid]);
+        const int my_ty = (lane < TM && rowvalid[lane]) ? rtype[lane] : -1;  // (rowvalid / rtype are stable since C start)
+        const bool has0 = __ballot(my_ty == 0) != 0, has1 = __ballot(my_ty == 1) != 0, has2 = __ballot(my_ty == 2) != 0;
         const WNext after_head = do_a ? xlayer_first(W, pw.as2pl[0], wave) : wstd(W + pw.head_w1[0], W + pw.head_b1[0], wave);
         const WNext h2 = has2 ? wstd(W + pw.head_w1[2], W + pw.head_b1[2], wave) : after_head;
         const WNext h1 = has1 ? wstd(W + pw.head_w1[1], W + pw.head_b1[1], wave) : h2;
@@ -399,8 +409,7 @@ __global__ __launch_bounds__(NTHREADS) void k_step(RolloutP p, int t, int do_c, 
             if (!present) continue;
             WUnit uh = u;
             f32x4 acc[2] = {uh.b[0], uh.b[1]};
-            wload(u, ty == 0 ? h1 : (ty == 1 ? h2 : after_head), lane);
-            wmma(acc[0], acc[1], uh, X + m * LDT + kq * 32);
+            wmma_pf(acc[0], acc[1], uh, X + m * LDT + kq * 32, u, ty == 0 ? h1 : (ty == 1 ? h2 : after_head), lane);
             st4(cptr(S2, LDT, 2 * wave, lane), relu4(acc[0]));
             st4(cptr(S2, LDT, 2 * wave + 1, lane), relu4(acc[1]));
             __syncthreads();
@@ -509,6 +518,7 @@ __global__ __launch_bounds__(NTHREADS) void k_step(RolloutP p, int t, int do_c, 
             // simulator state: global (the next launch's interaction reads `valid` of every agent) + LDS (A half below)
             st4(p.state + si * 4, cur);
             p.valid[si] = valid;
+            p.vbias[si] = valid ? 0.f : -INFINITY;
             p.killed[si] = killed;
             p.goal_valid[si] = gv;
             p.dest_reached[si] = dreached;
@@ -612,30 +622,31 @@ __global__ __launch_bounds__(NTHREADS) void k_step(RolloutP p, int t, int do_c, 
     TB_STAMP(8);
     // ---- agent -> map polylines (traffic_bots.py:205-211)
     {
-        const uint8_t* kvd = p.kvalid_pl + (size_t)b * p.p_pad;
+        const float* kvd = p.kbias_pl + (size_t)b * p.p_pad;
         const size_t ls = (size_t)p.p_pad * H;
         const float* K0 = p.kpl + ((size_t)b * 3) * ls;
         const float* V0 = p.vtpl + ((size_t)b * 3) * ls;
-        xattn_layer(W, pw.as2pl[0], X, S1, S2, K0, V0, kvd, p.p_pad, -1, rowvalid, novalid_s, tid, u, xlayer_first(W, pw.as2pl[1], wave),
-                    p.prof + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 32);
-        xattn_layer(W, pw.as2pl[1], X, S1, S2, K0 + ls, V0 + ls, kvd, p.p_pad, -1, rowvalid, novalid_s, tid, u,
-                    xlayer_first(W, pw.as2pl[2], wave));
-        xattn_layer(W, pw.as2pl[2], X, S1, S2, K0 + 2 * ls, V0 + 2 * ls, kvd, p.p_pad, -1, rowvalid, novalid_s, tid, u,
-                    xlayer_first(W, pw.as2tl[0], wave));
+        xattn_layer<true>(W, pw.as2pl[0], X, S1, S2, K0, V0, kvd, p.p_pad, -1, rowvalid, novalid_s, tid, u, xlayer_first(W, pw.as2pl[1], wave),
+                    LN + 3 * 768, p.prof + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 32);
+        xattn_layer<true>(W, pw.as2pl[1], X, S1, S2, K0 + ls, V0 + ls, kvd, p.p_pad, -1, rowvalid, novalid_s, tid, u,
+                    xlayer_first(W, pw.as2pl[2], wave), LN + 4 * 768);
+        xattn_layer<true>(W, pw.as2pl[2], X, S1, S2, K0 + 2 * ls, V0 + 2 * ls, kvd, p.p_pad, -1, rowvalid, novalid_s, tid, u,
+                    xlayer_first(W, pw.as2tl[0], wave), LN + 5 * 768);
     }
     TB_STAMP(9);
     // ---- agent -> traffic lights of step min(t1-1, n_hist-1) (waymo_motion.py:287, traffic_bots.py:213-219)
     {
         const int g_tl = b * p.n_hist + min(t1 - 1, p.n_hist - 1);
-        const uint8_t* kvd = p.kvalid_tl + (size_t)g_tl * p.t_pad;
+        const float* kvd = p.kbias_tl + (size_t)g_tl * p.t_pad;
         const size_t ls = (size_t)p.t_pad * H;
         const float* K0 = p.ktl + ((size_t)g_tl * 3) * ls;
         const float* V0 = p.vttl + ((size_t)g_tl * 3) * ls;
-        xattn_layer(W, pw.as2tl[0], X, S1, S2, K0, V0, kvd, p.t_pad, -1, rowvalid, novalid_s, tid, u, xlayer_first(W, pw.as2tl[1], wave));
-        xattn_layer(W, pw.as2tl[1], X, S1, S2, K0 + ls, V0 + ls, kvd, p.t_pad, -1, rowvalid, novalid_s, tid, u,
-                    xlayer_first(W, pw.as2tl[2], wave));
-        xattn_layer(W, pw.as2tl[2], X, S1, S2, K0 + 2 * ls, V0 + 2 * ls, kvd, p.t_pad, -1, rowvalid, novalid_s, tid, u,
-                    kvproj_first(W, pw.inter[0], wave));
+        xattn_layer<true>(W, pw.as2tl[0], X, S1, S2, K0, V0, kvd, p.t_pad, -1, rowvalid, novalid_s, tid, u, xlayer_first(W, pw.as2tl[1], wave),
+                    LN + 6 * 768);
+        xattn_layer<true>(W, pw.as2tl[1], X, S1, S2, K0 + ls, V0 + ls, kvd, p.t_pad, -1, rowvalid, novalid_s, tid, u,
+                    xlayer_first(W, pw.as2tl[2], wave), LN + 7 * 768);
+        xattn_layer<true>(W, pw.as2tl[2], X, S1, S2, K0 + 2 * ls, V0 + 2 * ls, kvd, p.t_pad, -1, rowvalid, novalid_s, tid, u,
+                    kvproj_first(W, pw.inter[0], wave), LN + 8 * 768);
     }
     TB_STAMP(10);
     // ---- hand-off to the next launch: x_mid and the interaction K/V of this tile's agents (tgt = block input for
@@ -645,9 +656,10 @@ __global__ __launch_bounds__(NTHREADS) void k_step(RolloutP p, int t, int do_c, 
         const size_t ls = (size_t)p.a_pad * H;
         float* K0 = p.kin + ((size_t)n * 3) * ls;
         float* V0 = p.vtin + ((size_t)n * 3) * ls;
-        kv_project_tile(W, pw.inter[0], X, S1, K0, V0, p.a_pad, row0, TM, tid, u, kvproj_first(W, pw.inter[1], wave));
-        kv_project_tile(W, pw.inter[1], X, S1, K0 + ls, V0 + ls, p.a_pad, row0, TM, tid, u, kvproj_first(W, pw.inter[2], wave));
-        kv_project_tile(W, pw.inter[2], X, S1, K0 + 2 * ls, V0 + 2 * ls, p.a_pad, row0, TM, tid, u, kvproj_first(W, pw.inter[2], wave));
+        kv_project_tile<true>(W, pw.inter[0], X, S1, K0, V0, p.a_pad, row0, TM, tid, u, kvproj_first(W, pw.inter[1], wave), LN + 0 * 768);
+        kv_project_tile<true>(W, pw.inter[1], X, S1, K0 + ls, V0 + ls, p.a_pad, row0, TM, tid, u, kvproj_first(W, pw.inter[2], wave), LN + 1 * 768);
+        kv_project_tile<true>(W, pw.inter[2], X, S1, K0 + 2 * ls, V0 + 2 * ls, p.a_pad, row0, TM, tid, u, kvproj_first(W, pw.inter[2], wave),
+                        LN + 2 * 768);
     }
     TB_STAMP(11);
 }
@@ -658,10 +670,10 @@ __global__ __launch_bounds__(NTHREADS) void k_step(RolloutP p, int t, int do_c, 
 size_t step_lds_bytes() { return (size_t)STEP_LDS_FLOATS * sizeof(float); }
 
 void launch_kv_hoist(const float* W, const XLayerW* L3, const float* feat, const uint8_t* fvalid, int G, int n_tok, int n_pad,
-                     float* K, float* VT, uint8_t* kvalid, hipStream_t s) {
+                     float* K, float* VT, float* kbias, hipStream_t s) {
     dim3 grid(n_pad / TM, G);
     hipLaunchKernelGGL(k_kv_hoist, grid, dim3(NTHREADS), 2 * TM * LDT * sizeof(float), s, W, L3[0], L3[1], L3[2], feat, fvalid,
-                       n_tok, n_pad, K, VT, kvalid);
+                       n_tok, n_pad, K, VT, kbias);
 }
 
 void launch_rollout_init(const RolloutP& p, hipStream_t s) {
