@@ -55,13 +55,11 @@ for i in range(3):
     print(f"  {NAMES[8 + i]:32s} {np.median(v):9.0f}  [{v.min():8.0f} .. {v.max():8.0f}]")
     tot += np.median(v)
 print(f"  sum of medians (without A front-end) {tot:9.0f}")
-# finer stamps inside add_goal: 3 = stage start, 12 = CAT built (barrier), 13 = first unit's MFMAs done, 14 = second unit done,
-# 15 = after the barrier, 4 = stage end
-seq = [3, 12, 13, 14, 15, 4]
-lab = ["CAT build + barrier", "unit 1 (64 MFMA)", "wload + unit 2 (64 MFMA)", "relu/store + barrier", "unit 3 + residual + barrier"]
+seq = [0, 12, 13, 14, 15, 1]
+lab = ["LN params -> LDS (issue+store)", "row state loads (16 thr)", "valid ballots", "wload + 6 tile loads + geometry issue", "barrier (wait for all)"]
 for i in range(5):
     v = st[:, seq[i + 1]] - st[:, seq[i]]
-    print(f"    add_goal/{lab[i]:30s} {np.median(v):8.0f}  [{v.min():7.0f} .. {v.max():7.0f}]")
+    print(f"    C-start/{lab[i]:40s} {np.median(v):8.0f}  [{v.min():7.0f} .. {v.max():7.0f}]")
 lab = ["LN1 + barrier", "wload + Q proj (64 MFMA)", "attention 256 keys (8 x 32 MFMA)", "store + barrier", "wload + out proj + residual + barrier",
        "LN2 + barrier", "wload + FFN1 + relu + barrier", "wload + FFN2 + residual + barrier"]
 for i in range(8):

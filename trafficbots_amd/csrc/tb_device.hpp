@@ -138,25 +138,26 @@ __device__ __forceinline__ void wmma_pf(f32x4& acc_a, f32x4& acc_b, const WUnit&
         un.w[0][j] = ldg4(pa + j * 256);
         un.w[1][j] = ldg4(pb + j * 256);
     }
+    f32x4 xv[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) xv[j] = lds4(xrow + 4 * j);  // all B operands up front: no LDS wait inside the chain
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        const f32x4 xv = lds4(xrow + 4 * j);
-        acc_a = mfma4(u.w[0][j].x, xv.x, acc_a);
-        acc_b = mfma4(u.w[1][j].x, xv.x, acc_b);
-        acc_a = mfma4(u.w[0][j].y, xv.y, acc_a);
-        acc_b = mfma4(u.w[1][j].y, xv.y, acc_b);
-        acc_a = mfma4(u.w[0][j].z, xv.z, acc_a);
-        acc_b = mfma4(u.w[1][j].z, xv.z, acc_b);
-        acc_a = mfma4(u.w[0][j].w, xv.w, acc_a);
-        acc_b = mfma4(u.w[1][j].w, xv.w, acc_b);
+        acc_a = mfma4(u.w[0][j].x, xv[j].x, acc_a);
+        acc_b = mfma4(u.w[1][j].x, xv[j].x, acc_b);
+        acc_a = mfma4(u.w[0][j].y, xv[j].y, acc_a);
+        acc_b = mfma4(u.w[1][j].y, xv[j].y, acc_b);
+        acc_a = mfma4(u.w[0][j].z, xv[j].z, acc_a);
+        acc_b = mfma4(u.w[1][j].z, xv[j].z, acc_b);
+        acc_a = mfma4(u.w[0][j].w, xv[j].w, acc_a);
+        acc_b = mfma4(u.w[1][j].w, xv[j].w, acc_b);
     }
-    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);  // 2 DS reads to prime
+    __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);  // the 8 DS reads first
     __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);  // bias loads
 #pragma unroll
     for (int g = 0; g < 16; ++g) {
         __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
         __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-        if ((g & 1) == 0 && g < 12) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
     }
     TB_SCHED_FENCE();
     if (!n.bias) {
@@ -638,7 +639,17 @@ __device__ __forceinline__ void kv_project_tile(const float* __restrict__ W, con
     __syncthreads();
 }
 
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+// sigmoid / tanh from one compensated v_exp_f32 of a non-positive argument and one v_rcp_f32 (absolute error ~1e-7)
+__device__ __forceinline__ float sigmoidf_(float x) {
+    const float e = exp_neg(-fabsf(x));              // in (0, 1]
+    const float r = __builtin_amdgcn_rcpf(1.0f + e);  // 1 / (1 + e^-|x|)
+    return x >= 0.f ? r : e * r;
+}
+__device__ __forceinline__ float tanhf_(float x) {
+    const float e = exp_neg(-2.0f * fabsf(x));
+    const float t = (1.0f - e) * __builtin_amdgcn_rcpf(1.0f + e);
+    return copysignf(t, x);
+}
 
 // ---------------------------------------------------------------------------------------------
 // One GRU layer step (PyTorch gate order r,z,n; agent_temporal.py:147-152 -> nn.GRU):
@@ -681,7 +692,7 @@ __device__ __forceinline__ void gru_layer(const float* __restrict__ W, const Gru
         for (int q = 0; q < 4; ++q) {
             const float rg = sigmoidf_(r[t][q]);
             const float zg = sigmoidf_(z[t][q]);
-            const float ng = tanhf(gin[t][q] + rg * ghn[t][q]);
+            const float ng = tanhf_(gin[t][q] + rg * ghn[t][q]);
             hn[q] = rv ? (1.0f - zg) * ng + zg * hold[q] : 0.f;
         }
         st4(cptr(Out, LDT, 2 * wave + t, lane), hn);

@@ -245,7 +245,7 @@ __device__ __forceinline__ void fuse_latent_goal(const float* __restrict__ W, ui
     }
     __syncthreads();
 #ifdef TB_PROFILE
-    if (prof && threadIdx.x == 0) prof[12] = clock64();
+    (void)prof;
 #endif
     WUnit u2;
     {
@@ -254,18 +254,18 @@ __device__ __forceinline__ void fuse_latent_goal(const float* __restrict__ W, ui
         const float* xr = CAT + m * LDC + kq * 64;
         wmma_pf(acc[0], acc[1], uw, xr, u2, wnext(W + w1, nullptr, ta, tb_, 16, 8), lane);
 #ifdef TB_PROFILE
-        if (prof && threadIdx.x == 0) prof[13] = clock64();
+        (void)prof;
 #endif
         wmma_pf(acc[0], acc[1], u2, xr + 32, uw, wstd(W + w2, W + b2, wave), lane);
 #ifdef TB_PROFILE
-        if (prof && threadIdx.x == 0) prof[14] = clock64();
+        (void)prof;
 #endif
         st4(cptr(S2, LDT, ta, lane), relu4(acc[0]));
         st4(cptr(S2, LDT, tb_, lane), relu4(acc[1]));
     }
     __syncthreads();
 #ifdef TB_PROFILE
-    if (prof && threadIdx.x == 0) prof[15] = clock64();
+    (void)prof;
 #endif
     {
         f32x4 acc[2] = {uw.b[0], uw.b[1]};
@@ -316,7 +316,21 @@ __global__ __launch_bounds__(NTHREADS) void k_step(RolloutP p, int t, int do_c, 
     int* dflag = rtype + 16;                                // [16] bit0 lane-type destination, bit1 road-edge destination
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, kq = lane >> 4, m = lane & 15;
-    const int n = blockIdx.y, b = n / p.k_rep, row0 = blockIdx.x * TM;
+    // XCD-aware tile -> workgroup map (speed only): the dispatcher places linear workgroup L on XCD L % 8; give all row
+    // tiles of an instance the same L % 8 so its map / TL / interaction K,V are fetched into ONE XCD's L2 instead of up to 4
+    int n, rt;
+    {
+        const int T = gridDim.x, N = gridDim.y, L = blockIdx.y * T + blockIdx.x;
+        if ((N & 7) == 0) {
+            const int q = L >> 3;
+            rt = q % T;
+            n = (L & 7) + 8 * (q / T);
+        } else {
+            rt = blockIdx.x;
+            n = blockIdx.y;
+        }
+    }
+    const int b = n / p.k_rep, row0 = rt * TM;
     const int n_real = max(0, min(TM, p.n_agent - row0));
     const float* W = p.W;
     const PolicyW& pw = p.pw;
@@ -332,6 +346,7 @@ __global__ __launch_bounds__(NTHREADS) void k_step(RolloutP p, int t, int do_c, 
         for (int sl = 0; sl < 9; ++sl)
             if (tid < 192) st4(LN + sl * 768 + tid * 4, ldg4(W + base[sl] + tid * 4));
     }
+    TB_STAMP(12);
     if (tid < TM) {
         rtype[tid] = (tid < n_real) ? p.agent_type[(size_t)b * p.n_agent + row0 + tid] : -1;
         const size_t si = base_row + tid;
@@ -341,6 +356,7 @@ __global__ __launch_bounds__(NTHREADS) void k_step(RolloutP p, int t, int do_c, 
         rowvalid[tid] = p.valid[si];
         gvalid[tid] = p.goal_valid[si];
     }
+    TB_STAMP(13);
 
     if (do_c) {
         // =================================== C(t) ===================================
@@ -349,6 +365,7 @@ __global__ __launch_bounds__(NTHREADS) void k_step(RolloutP p, int t, int do_c, 
         for (int i0 = 0; i0 < p.a_pad; i0 += 64)  // every wave counts for itself: no LDS round trip
             n_valid += __popcll(__ballot(i0 + lane < p.a_pad && p.valid[(size_t)n * p.a_pad + i0 + lane] != 0));
         const bool bypass = n_valid == 1;
+        TB_STAMP(14);
         wload(u, bypass ? gru_first(W, pw.gru[0], wave) : xlayer_first(W, pw.inter[0], wave), lane);
         // one burst of per-tile inputs for the whole C half (a single exposed global latency)
         load_tile(X, LDT, p.x_mid + base_row * H, TM, tid);
@@ -359,6 +376,7 @@ __global__ __launch_bounds__(NTHREADS) void k_step(RolloutP p, int t, int do_c, 
         load_tile(LP, LDT, p.lat_pre + base_row * H, TM, tid);
         for (int i = tid; i < TM * 20; i += NTHREADS) st4(DG + i * 4, ldg4(p.dest_geo + (base_row * 20 + i) * 4));
         if (tid < TM) dflag[tid] = p.dest_flag[base_row + tid];
+        TB_STAMP(15);
         __syncthreads();
         TB_STAMP(1);
         if (!bypass) {
