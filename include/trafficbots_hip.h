@@ -107,6 +107,18 @@ typedef struct tb_rollout_io {
  * disable_goal_reached, RolloutBuffer) -- waymo_motion.py:108-354. */
 int tb_rollout(tb_ctx* ctx, const tb_rollout_io* io, tb_stream stream);
 
+/* Stepwise form of the same rollout, for callers that drive the loop themselves the way the reference's rollout() drives
+ * the stateful WaymoMotion.forward (waymo_motion.py:108-203, 269-343):
+ *   tb_rollout_begin : prologue (K/V hoists, simulator init from history frame 0) and the first half-step; `io` as above
+ *                      (its buffers must stay valid until the last step has run; step_end bounds the number of steps);
+ *   tb_rollout_step  : one simulation step t = sim_start, sim_start+1, ...: writes slot t - sim_start of every output;
+ *   tb_rollout_state : copy of the CURRENT simulator state (Dynamics.agent_state / agent_valid, TrafficBots.hidden);
+ *                      any pointer may be NULL.
+ * tb_rollout(io) == tb_rollout_begin(io) + (step_end - sim_start + 1) x tb_rollout_step, fused into fewer launches. */
+int tb_rollout_begin(tb_ctx* ctx, const tb_rollout_io* io, tb_stream stream);
+int tb_rollout_step(tb_ctx* ctx, tb_stream stream);
+int tb_rollout_state(tb_ctx* ctx, float* state /*[N,A,4]*/, uint8_t* valid /*[N,A]*/, float* hidden /*[3,N,A,128]*/, tb_stream stream);
+
 /* -- hot path: scene encoders ------------------------------------------------------------------------ */
 typedef struct tb_encode_io {
     int32_t n_scene, n_agent, n_pl, n_tl, n_hist;

@@ -208,6 +208,46 @@ def test_full_size_properties():
     assert (d["rollout_buffer"].preds[:, :, 1] - d["rollout_buffer"].preds[:, :, 0]).abs().max() > 1e-3
 
 
+def test_stepwise_forward_equals_fused_rollout():
+    """`rollout(stepwise=True)` + repeated `forward()` (tb_rollout_begin / _step / _state) is bitwise the fused
+    `tb_rollout`, and the per-step return values are the buffer slices of that step."""
+    from trafficbots_amd import synth
+    from trafficbots_amd.runtime import teacher_forcing_mask
+
+    step_end, k = 25, 2
+    sd = synth.make_state_dict(5)
+    batch = synth.make_batch(7700, 3, n_agent=20, n_pl=50, n_tl=12, p_late_spawn=0.3, p_invalid_agent=0.2, pos_range=140.0)
+    wm = _engine({"time_step_end": step_end, "n_joint_future": k}, sd)
+    eps = torch.from_numpy(synth.make_latent_noise(5, 3 * k, 20)).cuda()
+    full = wm.test_step(batch, latent_eps=eps, generator=torch.Generator(device="cuda").manual_seed(9))
+    ref_buf = full["rollout_buffer"]
+    scene = wm.pre_processing(batch)
+    f = wm.model.encode_input_features(scene)
+    latent, goal = wm.model.latent_encoder(), wm.model.goal_manager.pred_goal()
+    latent.repeat_interleave_(k, 0)
+    det = torch.zeros(3 * k, 20, dtype=torch.bool, device="cuda")
+    det[::k] = True
+    feats = dict(scene, map_feature=f["map_feature"], map_feature_valid=f["map_feature_valid"].to(torch.uint8), tl_feature=f["tl_feature"])
+    gs = full["goal_sample"].transpose(1, 2).reshape(3 * k, 20)
+    gv = scene["agent_valid"].bool().any(1).repeat_interleave(k, 0)
+    buf = wm.rollout(feats, latent, gs, gv, teacher_forcing_mask(scene["agent_valid"].bool()), deterministic_latent=det,
+                     step_end=step_end, k_futures=k, latent_eps=eps, stepwise=True)
+    for t in range(1, step_end + 1):
+        state, valid, train, _ = wm.forward()
+        s = t - 1
+        assert torch.equal(train["pred_state"], buf.preds[:, :, s])
+        if t == 7:
+            assert valid.dtype == torch.bool and state.shape == (3 * k, 20, 4)
+    torch.cuda.synchronize()
+    buf = wm.finish_rollout()
+    buf.flatten_repeat(k)
+    assert torch.equal(buf.preds, ref_buf.preds)
+    assert torch.equal(buf.valid, ref_buf.valid)
+    assert torch.equal(buf.violations["dest_reached"], ref_buf.violations["dest_reached"])
+    with pytest.raises(RuntimeError):
+        wm.forward()  # past step_end
+
+
 def test_empty_and_bad_inputs_fail_loudly():
     from trafficbots_amd import synth
     from trafficbots_amd.waymo_motion import WaymoMotion

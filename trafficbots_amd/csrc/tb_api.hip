@@ -359,19 +359,17 @@ static void carve_rollout(tb::RolloutP& p, Carver& c) {
     p.prof = c.take<long long>(N * (p.a_pad / 16) * 32);
 }
 
-extern "C" int tb_rollout(tb_ctx* ctx, const tb_rollout_io* io, tb_stream stream_) {
+static int rollout_setup(tb_ctx* ctx, const tb_rollout_io* io, tb::RolloutP& p) {
     if (!ctx || !io) return 1;
     if (!ctx->finalized) return tb_fail(ctx, "tb_rollout: weights not finalized");
-    hipStream_t s = (hipStream_t)stream_;
     if (io->n_scene <= 0 || io->k_futures <= 0 || io->n_agent <= 0 || io->n_pl <= 0 || io->n_tl <= 0)
         return tb_fail(ctx, "tb_rollout: empty dimension (B=%d K=%d A=%d P=%d T=%d)", io->n_scene, io->k_futures, io->n_agent,
-                    io->n_pl, io->n_tl);
+                       io->n_pl, io->n_tl);
     if (io->n_agent > 256) return tb_fail(ctx, "tb_rollout: n_agent %d > 256 not supported", io->n_agent);
     if (io->n_hist != ctx->cfg.time_step_current + 1)
         return tb_fail(ctx, "tb_rollout: n_hist %d != time_step_current+1", io->n_hist);
     const int step_start = ctx->cfg.time_step_sim_start;
     if (io->step_end < step_start) return tb_fail(ctx, "tb_rollout: step_end < time_step_sim_start");
-    tb::RolloutP p;
     memset(&p, 0, sizeof(p));
     p.W = ctx->d_arena;
     p.pw = ctx->pw;
@@ -425,14 +423,30 @@ extern "C" int tb_rollout(tb_ctx* ctx, const tb_rollout_io* io, tb_stream stream
                               p.o_dest_reached_this, p.o_action_logp, p.o_latent_logp};
     for (const void* q : required)
         if (!q) return tb_fail(ctx, "tb_rollout: a required buffer pointer is NULL");
-
     Carver sizing{nullptr};
     carve_rollout(p, sizing);
     if (tb_ensure_workspace(ctx, sizing.off + 256)) return 1;
     Carver c{ctx->d_ws};
     carve_rollout(p, c);
-
     ctx->last_prof = p.prof;
+    return 0;
+}
+
+// prologue: hoisted K/V of the map and of every history step's traffic lights; simulator init
+static void rollout_prologue(const tb::RolloutP& p, const tb_rollout_io* io, hipStream_t s) {
+    tb::launch_kv_hoist(p.W, p.pw.as2pl, p.map_feature, io->map_feature_valid, p.n_scene, p.n_pl, p.p_pad, p.kpl, p.vtpl,
+                        p.kbias_pl, s);
+    tb::launch_kv_hoist(p.W, p.pw.as2tl, p.tl_feature, io->tl_feature_valid, p.n_scene * p.n_hist, p.n_tl, p.t_pad, p.ktl,
+                        p.vttl, p.kbias_tl, s);
+    tb::launch_rollout_init(p, s);
+}
+
+extern "C" int tb_rollout(tb_ctx* ctx, const tb_rollout_io* io, tb_stream stream_) {
+    tb::RolloutP p;
+    if (rollout_setup(ctx, io, p)) return 1;
+    hipStream_t s = (hipStream_t)stream_;
+    ctx->step_active = false;
+    const int step_start = p.step_start;
     const int n_steps = p.n_step_out;
     const int n_launch = n_steps + 1;
     if (ctx->timing) {
@@ -444,12 +458,7 @@ extern "C" int tb_rollout(tb_ctx* ctx, const tb_rollout_io* io, tb_stream stream
         }
         TB_HIP(ctx, hipEventRecord(ctx->ev[0], s));
     }
-    // ---- prologue: hoisted K/V of the map and of every history step's traffic lights; simulator init
-    tb::launch_kv_hoist(p.W, p.pw.as2pl, p.map_feature, io->map_feature_valid, p.n_scene, p.n_pl, p.p_pad, p.kpl, p.vtpl,
-                        p.kbias_pl, s);
-    tb::launch_kv_hoist(p.W, p.pw.as2tl, p.tl_feature, io->tl_feature_valid, p.n_scene * p.n_hist, p.n_tl, p.t_pad, p.ktl,
-                        p.vttl, p.kbias_tl, s);
-    tb::launch_rollout_init(p, s);
+    rollout_prologue(p, io, s);
     if (ctx->timing) TB_HIP(ctx, hipEventRecord(ctx->ev[1], s));
     // ---- the sequential loop (waymo_motion.py:269): launch i runs C(start+i-1) then A(start+i); no host sync
     for (int i = 0; i < n_launch; ++i) {
@@ -461,6 +470,40 @@ extern "C" int tb_rollout(tb_ctx* ctx, const tb_rollout_io* io, tb_stream stream
     // ---- final simulator state
     if (io->final_state || io->final_valid || io->final_hidden)
         tb::launch_rollout_final(p, io->final_state, io->final_valid, io->final_hidden, s);
+    TB_HIP(ctx, hipGetLastError());
+    return 0;
+}
+
+// ---- stepwise driving (the reference's stateful WaymoMotion.forward, waymo_motion.py:108-203) ------------------------
+extern "C" int tb_rollout_begin(tb_ctx* ctx, const tb_rollout_io* io, tb_stream stream_) {
+    tb::RolloutP p;
+    if (rollout_setup(ctx, io, p)) return 1;
+    hipStream_t s = (hipStream_t)stream_;
+    rollout_prologue(p, io, s);
+    tb::launch_step(p, p.step_start - 1, /*do_c=*/0, /*do_a=*/1, s);  // A(sim_start)
+    ctx->step_p = p;
+    ctx->step_next = p.step_start;
+    ctx->step_end = io->step_end;
+    ctx->step_active = true;
+    TB_HIP(ctx, hipGetLastError());
+    return 0;
+}
+
+extern "C" int tb_rollout_step(tb_ctx* ctx, tb_stream stream_) {
+    if (!ctx) return 1;
+    if (!ctx->step_active) return tb_fail(ctx, "tb_rollout_step: no rollout in progress (call tb_rollout_begin)");
+    if (ctx->step_next > ctx->step_end) return tb_fail(ctx, "tb_rollout_step: step %d is past step_end %d", ctx->step_next, ctx->step_end);
+    const int t = ctx->step_next;
+    tb::launch_step(ctx->step_p, t, /*do_c=*/1, /*do_a=*/t < ctx->step_end, (hipStream_t)stream_);
+    ctx->step_next = t + 1;
+    TB_HIP(ctx, hipGetLastError());
+    return 0;
+}
+
+extern "C" int tb_rollout_state(tb_ctx* ctx, float* state, uint8_t* valid, float* hidden, tb_stream stream_) {
+    if (!ctx) return 1;
+    if (!ctx->step_active) return tb_fail(ctx, "tb_rollout_state: no rollout in progress");
+    tb::launch_rollout_final(ctx->step_p, state, valid, hidden, (hipStream_t)stream_);
     TB_HIP(ctx, hipGetLastError());
     return 0;
 }

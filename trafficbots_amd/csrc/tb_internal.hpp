@@ -26,6 +26,10 @@ struct tb_ctx {
     char* d_ws = nullptr;
     size_t ws_bytes = 0;
     long long* last_prof = nullptr;
+    // stepwise rollout (tb_rollout_begin / _step / _state)
+    tb::RolloutP step_p;
+    int step_next = 0, step_end = -1;
+    bool step_active = false;
     // timing
     bool timing = false;
     std::vector<hipEvent_t> ev;

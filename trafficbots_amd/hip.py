@@ -60,7 +60,7 @@ class TbEncodeIO(C.Structure):
 
 EXPORTS = (
     "tb_create", "tb_destroy", "tb_last_error", "tb_version", "tb_load_weight", "tb_finalize_weights",
-    "tb_rollout", "tb_encode_scene", "tb_set_timing", "tb_get_timing",
+    "tb_rollout", "tb_rollout_begin", "tb_rollout_step", "tb_rollout_state", "tb_encode_scene", "tb_set_timing", "tb_get_timing",
 )
 
 _lib: Optional[C.CDLL] = None
@@ -96,6 +96,12 @@ def load() -> C.CDLL:
     lib.tb_finalize_weights.restype = C.c_int
     lib.tb_rollout.argtypes = [C.c_void_p, C.POINTER(TbRolloutIO), C.c_void_p]
     lib.tb_rollout.restype = C.c_int
+    lib.tb_rollout_begin.argtypes = [C.c_void_p, C.POINTER(TbRolloutIO), C.c_void_p]
+    lib.tb_rollout_begin.restype = C.c_int
+    lib.tb_rollout_step.argtypes = [C.c_void_p, C.c_void_p]
+    lib.tb_rollout_step.restype = C.c_int
+    lib.tb_rollout_state.argtypes = [C.c_void_p, c_f32p, c_u8p, c_f32p, C.c_void_p]
+    lib.tb_rollout_state.restype = C.c_int
     lib.tb_encode_scene.argtypes = [C.c_void_p, C.POINTER(TbEncodeIO), C.c_void_p]
     lib.tb_encode_scene.restype = C.c_int
     lib.tb_set_timing.argtypes = [C.c_void_p, C.c_int]

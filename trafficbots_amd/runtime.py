@@ -168,9 +168,11 @@ class HipEngine:
         mask_teacher_forcing: Optional[Tensor] = None,
         tap_step: int = -1,
         out: Optional[Dict[str, Tensor]] = None,
+        stepwise: bool = False,
     ) -> Dict[str, Tensor]:
         """Closed-loop rollout of N = B*K instances (instance n uses scene n // K).  Returns the
-        `RolloutBuffer` fields as [N, A, S, ...] tensors (`buffer.py:72-90`)."""
+        `RolloutBuffer` fields as [N, A, S, ...] tensors (`buffer.py:72-90`).  With `stepwise=True` only the
+        prologue runs (`tb_rollout_begin`); advance with :meth:`rollout_step`, inspect with :meth:`rollout_state`."""
         b, nh, a = s["agent_valid"].shape
         p = s["map_valid"].shape[1]
         t = s["tl_valid"].shape[2]
@@ -238,10 +240,32 @@ class HipEngine:
         io.tap_step = tap_step
         io.tap_policy_feature = hip.ptr(out.get("tap_policy_feature"), hip.c_f32p)
         io.tap_agent_feature = hip.ptr(out.get("tap_agent_feature"), hip.c_f32p)
-        self._check(self.lib.tb_rollout(self._ctx, C.byref(io), self._stream()), "tb_rollout")
         # keep the borrowed inputs alive until the stream work is done
-        out["_keepalive"] = (latent_sample, latent_mean, dest, goal_valid, mask_teacher_forcing)
+        out["_keepalive"] = (latent_sample, latent_mean, dest, goal_valid, mask_teacher_forcing, s, feats)
+        if stepwise:
+            self._check(self.lib.tb_rollout_begin(self._ctx, C.byref(io), self._stream()), "tb_rollout_begin")
+            self._step_out = out
+        else:
+            self._check(self.lib.tb_rollout(self._ctx, C.byref(io), self._stream()), "tb_rollout")
         return out
+
+    def rollout_step(self) -> None:
+        """One simulation step of the rollout opened with `rollout(..., stepwise=True)` (`tb_rollout_step`)."""
+        self._check(self.lib.tb_rollout_step(self._ctx, self._stream()), "tb_rollout_step")
+
+    def rollout_state(self) -> Dict[str, Tensor]:
+        """Current simulator state of the stepwise rollout: `Dynamics.agent_state / agent_valid`, `TrafficBots.hidden`."""
+        o = self._step_out
+        n, a = o["preds"].shape[:2]
+        st = {
+            "agent_state": torch.empty(n, a, 4, device=self.device, dtype=torch.float32),
+            "agent_valid": torch.empty(n, a, device=self.device, dtype=torch.uint8),
+            "hidden": torch.empty(3, n, a, 128, device=self.device, dtype=torch.float32),
+        }
+        self._check(
+            self.lib.tb_rollout_state(self._ctx, hip.ptr(st["agent_state"], hip.c_f32p), hip.ptr(st["agent_valid"], hip.c_u8p),
+                                      hip.ptr(st["hidden"], hip.c_f32p), self._stream()), "tb_rollout_state")
+        return st
 
     # -------------------------------------------------------------------------------- timing
     def set_timing(self, enable: bool) -> None:

@@ -136,8 +136,10 @@ class WaymoMotion:
         k_futures: int = 1,
         latent_eps: Optional[Tensor] = None,
         tap_step: int = -1,
+        stepwise: bool = False,
     ) -> RolloutBuffer:
-        """`WaymoMotion.rollout` (`waymo_motion.py:205-354`).  `features` is the pre-processed scene merged
+        """`WaymoMotion.rollout` (`waymo_motion.py:205-354`).  `stepwise=True` only initialises the simulator
+        (`model.init`, `dynamics.init`, goal features: `waymo_motion.py:246-266`); drive it with :meth:`forward`.  `features` is the pre-processed scene merged
         with the encoder outputs (un-repeated: K futures share scene tensors, instance n uses scene n // K);
         `latent` / `goal` / `goal_valid` are per instance [N, ...] as in the reference."""
         if not deterministic_action:
@@ -151,8 +153,14 @@ class WaymoMotion:
         mean_scene = latent.mean.reshape(b, k_futures, *latent.mean.shape[1:])[:, 0].contiguous()
         out = self.engine.rollout(
             features, features, z, mean_scene, goal, goal_valid, k_futures, step_end,
-            mask_teacher_forcing=mask_teacher_forcing.to(torch.uint8).contiguous(), tap_step=tap_step,
+            mask_teacher_forcing=mask_teacher_forcing.to(torch.uint8).contiguous(), tap_step=tap_step, stepwise=stepwise,
         )
+        self._step_t = step_start
+        self._rollout_meta = (step_start, step_end, z)
+        return self._buffer_from(out)
+
+    def _buffer_from(self, out: Dict[str, Tensor]) -> RolloutBuffer:
+        step_start, step_end, z = self._rollout_meta
         buf = RolloutBuffer(step_start, step_end, self.hparams["time_step_current"])
         buf.valid = out["valid"].bool()
         buf.preds = out["preds"]
@@ -166,6 +174,37 @@ class WaymoMotion:
         buf.taps = {k: out[k] for k in ("tap_policy_feature", "tap_agent_feature") if k in out}
         buf.latent_sample = z
         return buf
+
+    def finish_rollout(self) -> RolloutBuffer:
+        """`RolloutBuffer.finish()` for a stepwise rollout (`buffer.py:72-90`): the buffer over the steps taken so far
+        (slots of steps not yet simulated are undefined)."""
+        return self._buffer_from(self.engine._step_out)
+
+    def forward(self, *unused_feature_args, action_override=None, mask_action_override=None, state_override=None,
+                mask_state_override=None, deterministic_action: bool = True, require_train_dict: bool = True,
+                require_vis_dict: bool = False):
+        """One simulation step, the reference's stateful `WaymoMotion.forward` (`waymo_motion.py:108-203`): advances the
+        simulator opened by `rollout(..., stepwise=True)` and returns `(agent_state, agent_valid, train_dict, vis_dict)`.
+        The scene / goal features and the teacher-forcing overrides were bound when the rollout was opened (the reference's
+        `rollout()` passes exactly those per step, `waymo_motion.py:271-306`); custom per-call overrides are not built."""
+        if action_override is not None or state_override is not None or mask_state_override is not None or require_vis_dict:
+            raise NotImplementedError("per-call action/state overrides and vis dicts are outside the built path")
+        if not deterministic_action:
+            raise NotImplementedError("stochastic actions are outside the built path")
+        eng = self.engine
+        eng.rollout_step()
+        st = eng.rollout_state()
+        s_idx = self._step_t - self.hparams["time_step_sim_start"]
+        self._step_t += 1
+        o = eng._step_out
+        train_dict = {}
+        if require_train_dict:
+            train_dict = {
+                "latent_log_prob": o["latent_log_prob"], "action_log_prob": o["action_log_probs"][:, :, s_idx],
+                "pred_valid": o["valid"][:, :, s_idx].bool(), "pred_state": o["preds"][:, :, s_idx],
+            }
+        self.model.hidden = st["hidden"].flatten(1, 2)
+        return st["agent_state"], st["agent_valid"].bool(), train_dict, {}
 
     def joint_future_pred(
         self,
