@@ -18,6 +18,7 @@ void launch_kv_hoist(const float* W, const XLayerW* L3, const float* feat, const
 void launch_rollout_init(const RolloutP& p, hipStream_t s);
 void launch_step(const RolloutP& p, int t, int do_c, int do_a, hipStream_t s);
 void launch_rollout_final(const RolloutP& p, float* f_state, uint8_t* f_valid, float* f_hidden, hipStream_t s);
+hipError_t configure_rollout_kernels();
 int run_encode(struct ::tb_ctx* ctx, const tb_encode_io* io, hipStream_t s);
 }  // namespace tb
 
@@ -150,6 +151,10 @@ int tb_create(const tb_config* cfg, tb_ctx** out) {
     }
     tb_ctx* c = new tb_ctx();
     c->cfg = *cfg;
+    if (hipGetDevice(&c->device) != hipSuccess) {
+        delete c;
+        return 2;
+    }
     *out = c;
     return 0;
 }
@@ -173,6 +178,8 @@ int tb_load_weight(tb_ctx* ctx, const char* name, const float* host_data, int64_
 
 int tb_finalize_weights(tb_ctx* ctx, tb_stream stream) {
     if (!ctx) return 1;
+    TB_HIP(ctx, hipSetDevice(ctx->device));
+    TB_HIP(ctx, tb::configure_rollout_kernels());
     Arena a;
     Stage s{ctx};
     tb::PolicyW& pw = ctx->pw;
@@ -362,6 +369,7 @@ static void carve_rollout(tb::RolloutP& p, Carver& c) {
 static int rollout_setup(tb_ctx* ctx, const tb_rollout_io* io, tb::RolloutP& p) {
     if (!ctx || !io) return 1;
     if (!ctx->finalized) return tb_fail(ctx, "tb_rollout: weights not finalized");
+    TB_HIP(ctx, hipSetDevice(ctx->device));  // the context is bound to the device that was current at tb_create
     if (io->n_scene <= 0 || io->k_futures <= 0 || io->n_agent <= 0 || io->n_pl <= 0 || io->n_tl <= 0)
         return tb_fail(ctx, "tb_rollout: empty dimension (B=%d K=%d A=%d P=%d T=%d)", io->n_scene, io->k_futures, io->n_agent,
                        io->n_pl, io->n_tl);
@@ -519,5 +527,6 @@ extern "C" int tb_debug_read_prof(tb_ctx* ctx, long long* host_out, int n_blocks
 extern "C" int tb_encode_scene(tb_ctx* ctx, const tb_encode_io* io, tb_stream stream) {
     if (!ctx || !io) return 1;
     if (!ctx->finalized) return tb_fail(ctx, "tb_encode_scene: weights not finalized");
+    TB_HIP(ctx, hipSetDevice(ctx->device));
     return tb::run_encode(ctx, io, (hipStream_t)stream);
 }

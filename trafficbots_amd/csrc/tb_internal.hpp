@@ -15,6 +15,7 @@
 
 struct tb_ctx {
     tb_config cfg;
+    int device = 0;  // HIP device the context is bound to
     std::string err;
     std::map<std::string, std::vector<float>> staged;
     float* d_arena = nullptr;

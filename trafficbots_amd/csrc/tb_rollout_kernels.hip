@@ -694,21 +694,21 @@ void launch_kv_hoist(const float* W, const XLayerW* L3, const float* feat, const
                        n_tok, n_pad, K, VT, kbias);
 }
 
+// the step kernels carve > 64 KiB of dynamic LDS: raise the per-function limit (per device; called from tb_finalize_weights)
+hipError_t configure_rollout_kernels() {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_step), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)step_lds_bytes());
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(k_rollout_init), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)step_lds_bytes());
+}
+
 void launch_rollout_init(const RolloutP& p, hipStream_t s) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_rollout_init), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)step_lds_bytes());
     dim3 grid(p.a_pad / TM, p.n_inst);
     hipLaunchKernelGGL(k_rollout_init, grid, dim3(NTHREADS), step_lds_bytes(), s, p);
 }
 
 void launch_step(const RolloutP& p, int t, int do_c, int do_a, hipStream_t s) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_step), hipFuncAttributeMaxDynamicSharedMemorySize, (int)step_lds_bytes());
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_rollout_init), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)step_lds_bytes());
-        attr_set = true;
-    }
     dim3 grid(p.a_pad / TM, p.n_inst);
     hipLaunchKernelGGL(k_step, grid, dim3(NTHREADS), step_lds_bytes(), s, p, t, do_c, do_a);
 }
