@@ -3,6 +3,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -19,6 +20,8 @@ void launch_rollout_init(const RolloutP& p, hipStream_t s);
 void launch_step(const RolloutP& p, int t, int do_c, int do_a, hipStream_t s);
 void launch_rollout_final(const RolloutP& p, float* f_state, uint8_t* f_valid, float* f_hidden, hipStream_t s);
 hipError_t configure_rollout_kernels();
+void launch_step8(const RolloutP& p, int t, int do_c, int do_a, hipStream_t s);
+hipError_t configure_step8_kernel();
 int run_encode(struct ::tb_ctx* ctx, const tb_encode_io* io, hipStream_t s);
 }  // namespace tb
 
@@ -142,6 +145,13 @@ extern "C" {
 
 const char* tb_version(void) { return "trafficbots_hip 0.1 (gfx950, fp32 MFMA 16x16x4)"; }
 
+static void step_launch(const tb_ctx* ctx, const tb::RolloutP& p, int t, int do_c, int do_a, hipStream_t s) {
+    if (ctx->step_waves == 8)
+        tb::launch_step8(p, t, do_c, do_a, s);
+    else
+        tb::launch_step(p, t, do_c, do_a, s);
+}
+
 int tb_create(const tb_config* cfg, tb_ctx** out) {
     if (!cfg || !out) return 1;
     int ndev = 0;
@@ -151,6 +161,14 @@ int tb_create(const tb_config* cfg, tb_ctx** out) {
     }
     tb_ctx* c = new tb_ctx();
     c->cfg = *cfg;
+    if (const char* w = getenv("TB_STEP_WAVES")) {
+        c->step_waves = atoi(w);
+        if (c->step_waves != 4 && c->step_waves != 8) {
+            fprintf(stderr, "trafficbots_hip: TB_STEP_WAVES must be 4 or 8\n");
+            delete c;
+            return 1;
+        }
+    }
     if (hipGetDevice(&c->device) != hipSuccess) {
         delete c;
         return 2;
@@ -180,6 +198,7 @@ int tb_finalize_weights(tb_ctx* ctx, tb_stream stream) {
     if (!ctx) return 1;
     TB_HIP(ctx, hipSetDevice(ctx->device));
     TB_HIP(ctx, tb::configure_rollout_kernels());
+    TB_HIP(ctx, tb::configure_step8_kernel());
     Arena a;
     Stage s{ctx};
     tb::PolicyW& pw = ctx->pw;
@@ -471,7 +490,7 @@ extern "C" int tb_rollout(tb_ctx* ctx, const tb_rollout_io* io, tb_stream stream
     // ---- the sequential loop (waymo_motion.py:269): launch i runs C(start+i-1) then A(start+i); no host sync
     for (int i = 0; i < n_launch; ++i) {
         const int t = step_start + i - 1;
-        tb::launch_step(p, t, /*do_c=*/i > 0, /*do_a=*/i < n_steps, s);
+        step_launch(ctx, p, t, /*do_c=*/i > 0, /*do_a=*/i < n_steps, s);
         if (ctx->timing) TB_HIP(ctx, hipEventRecord(ctx->ev[2 + i], s));
     }
     ctx->n_timed_steps = ctx->timing ? n_launch : 0;
@@ -488,7 +507,7 @@ extern "C" int tb_rollout_begin(tb_ctx* ctx, const tb_rollout_io* io, tb_stream 
     if (rollout_setup(ctx, io, p)) return 1;
     hipStream_t s = (hipStream_t)stream_;
     rollout_prologue(p, io, s);
-    tb::launch_step(p, p.step_start - 1, /*do_c=*/0, /*do_a=*/1, s);  // A(sim_start)
+    step_launch(ctx, p, p.step_start - 1, /*do_c=*/0, /*do_a=*/1, s);  // A(sim_start)
     ctx->step_p = p;
     ctx->step_next = p.step_start;
     ctx->step_end = io->step_end;
@@ -502,7 +521,7 @@ extern "C" int tb_rollout_step(tb_ctx* ctx, tb_stream stream_) {
     if (!ctx->step_active) return tb_fail(ctx, "tb_rollout_step: no rollout in progress (call tb_rollout_begin)");
     if (ctx->step_next > ctx->step_end) return tb_fail(ctx, "tb_rollout_step: step %d is past step_end %d", ctx->step_next, ctx->step_end);
     const int t = ctx->step_next;
-    tb::launch_step(ctx->step_p, t, /*do_c=*/1, /*do_a=*/t < ctx->step_end, (hipStream_t)stream_);
+    step_launch(ctx, ctx->step_p, t, /*do_c=*/1, /*do_a=*/t < ctx->step_end, (hipStream_t)stream_);
     ctx->step_next = t + 1;
     TB_HIP(ctx, hipGetLastError());
     return 0;

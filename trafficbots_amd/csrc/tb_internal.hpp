@@ -23,6 +23,7 @@ struct tb_ctx {
     tb::PolicyW pw;
     tb::EncoderW ew;
     bool finalized = false;
+    int step_waves = 4;  // waves per workgroup of the step kernel: 4 (k_step) or 8 (k_step8); TB_STEP_WAVES overrides
     // workspace
     char* d_ws = nullptr;
     size_t ws_bytes = 0;

@@ -1,0 +1,280 @@
+// Pieces shared by the 4-wave (k_step) and the 8-wave (k_step8) step kernels: LDS carve, per-row state,
+// the per-agent simulator epilogue and the agent input encoding at the head of the A half.
+#pragma once
+#include "tb_rollout.hpp"
+
+namespace tb {
+
+// LDS carve for the step kernels (floats)
+constexpr int OFF_X = 0;                   // [16][LDT] residual stream
+constexpr int OFF_S1 = OFF_X + TM * LDT;   // [16][LDT]
+constexpr int OFF_S2 = OFF_S1 + TM * LDT;  // [16][LDT]
+constexpr int OFF_H = OFF_S2 + TM * LDT;   // [16][LDT] GRU previous hidden
+constexpr int OFF_Y = OFF_H + TM * LDT;    // [16][LDT] GRU out ping
+constexpr int OFF_CAT = OFF_Y + TM * LDT;  // [16][LDC] concat tile
+constexpr int OFF_H1 = OFF_CAT + TM * LDC; // [16][LDT] GRU hidden layer 1
+constexpr int OFF_H2 = OFF_H1 + TM * LDT;  // [16][LDT] GRU hidden layer 2
+constexpr int OFF_GP = OFF_H2 + TM * LDT;  // [16][LDT] add_goal.mlp_in output of the tile's agents
+constexpr int OFF_LP = OFF_GP + TM * LDT;  // [16][LDT] add_latent.mlp_in output
+constexpr int OFF_DG = OFF_LP + TM * LDT;  // [16][80]  destination polyline geometry (20 nodes x px,py,dx,dy)
+constexpr int OFF_LN = OFF_DG + TM * 80;   // [9][768] LayerNorm parameter blocks of inter / as2pl / as2tl layers
+constexpr int OFF_SMALL = OFF_LN + 9 * 768;
+constexpr int SMALL_FLOATS = 16 * 16 /*attr*/ + 16 * 32 /*enc hidden*/ + 16 * 8 /*row state*/ + 32 /*u*/ + 64 /*flags,types*/;
+constexpr int STEP_LDS_FLOATS = OFF_SMALL + SMALL_FLOATS;
+
+#ifdef TB_PROFILE
+#define TB_STAMP(i)                                                                                        \
+    do {                                                                                                   \
+        if (threadIdx.x == 0) p.prof[(size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 32 + (i)] = clock64(); \
+    } while (0)
+#else
+#define TB_STAMP(i) \
+    do {            \
+    } while (0)
+#endif
+
+__device__ __forceinline__ float fmul_(float a, float b) { return __fmul_rn(a, b); }
+__device__ __forceinline__ float fadd_(float a, float b) { return __fadd_rn(a, b); }
+
+// per-row simulator state carried in LDS between the C and the A half of a launch
+struct RowSt {
+    float st[4];   // x, y, yaw, spd
+    float aux[4];  // vel_x, vel_y, acc, yaw_rate as last teacher-forced
+};
+
+// pointers into the SMALL region of the LDS carve
+struct StepSmall {
+    float* attr;         // [16][16]
+    float* ench;         // [16][32]
+    RowSt* rst;          // [16]
+    float* ubuf;         // [16][2] action means
+    uint8_t* rowvalid;   // [16]
+    uint8_t* novalid_s;  // [16]
+    uint8_t* gvalid;     // [16]
+    int* rtype;          // [16]
+    int* dflag;          // [16] bit0 lane-type destination, bit1 road-edge destination
+};
+
+__device__ __forceinline__ StepSmall step_small(float* smem) {
+    StepSmall s;
+    s.attr = smem + OFF_SMALL;
+    s.ench = s.attr + 16 * 16;
+    s.rst = reinterpret_cast<RowSt*>(s.ench + 16 * 32);
+    s.ubuf = reinterpret_cast<float*>(s.rst + 16);
+    s.rowvalid = reinterpret_cast<uint8_t*>(s.ubuf + 32);
+    s.novalid_s = s.rowvalid + 16;
+    s.gvalid = s.rowvalid + 32;
+    s.rtype = reinterpret_cast<int*>(s.rowvalid + 48);
+    s.dflag = s.rtype + 16;
+    return s;
+}
+
+// XCD-aware tile -> workgroup map (speed only): the dispatcher places linear workgroup L on XCD L % 8; give all row
+// tiles of an instance the same L % 8 so its map / TL / interaction K,V are fetched into ONE XCD's L2 instead of up to 4
+__device__ __forceinline__ void step_tile_map(int& n, int& rt) {
+    const int T = gridDim.x, N = gridDim.y, L = blockIdx.y * T + blockIdx.x;
+    if ((N & 7) == 0) {
+        const int q = L >> 3;
+        rt = q % T;
+        n = (L & 7) + 8 * (q / T);
+    } else {
+        rt = blockIdx.x;
+        n = blockIdx.y;
+    }
+}
+
+// ---- per-agent simulator epilogue of C(t): dynamics, teacher forcing, rule checks, kill, navigator, buffer writes.
+// Thread `tid` < n_real handles row `tid` of the tile; the caller places barriers around it.
+__device__ __forceinline__ void step_epilogue(const RolloutP& p, int t, int n, int b, int row0, int n_real, int tid,
+                                              const StepSmall& sm, const float* DG) {
+    const PolicyW& pw = p.pw;
+    const float* W = p.W;
+    const size_t base_row = (size_t)n * p.a_pad + row0;
+    RowSt* rst = sm.rst; float* ubuf = sm.ubuf; uint8_t* rowvalid = sm.rowvalid; uint8_t* gvalid = sm.gvalid;
+    const int* rtype = sm.rtype; const int* dflag = sm.dflag;
+    if (tid < n_real) {
+        const int row = row0 + tid;
+        const size_t si = base_row + tid;
+        const int ty = rtype[tid];
+        const bool valid_old = rowvalid[tid] != 0;
+        const bool have = valid_old && ty >= 0;
+        const f32x4 st = f32x4{rst[tid].st[0], rst[tid].st[1], rst[tid].st[2], rst[tid].st[3]};
+        // Dynamics.update + MultiPathPP (dynamics.py:74-119,194-228); tanh-bounded action, midpoint unicycle
+        float acc_ = 0.f, yr_ = 0.f;
+        if (have) {
+            acc_ = fmul_(tanhf(ubuf[tid * 2 + 0]), pw.max_acc[ty]);
+            yr_ = fmul_(tanhf(ubuf[tid * 2 + 1]), pw.max_yaw_rate[ty]);
+        }
+        const float half_dt = 0.5f * pw.dt;  // python: 0.5 * self.dt, then cast with the tensor op
+        const float v_t = fadd_(st.w, fmul_(half_dt, acc_));
+        const float th_t = fadd_(st.z, fmul_(half_dt, yr_));
+        float sn, cs;
+        sincosf(th_t, &sn, &cs);
+        f32x4 pred;
+        pred.x = fadd_(st.x, fmul_(pw.dt, fmul_(v_t, cs)));
+        pred.y = fadd_(st.y, fmul_(pw.dt, fmul_(v_t, sn)));
+        pred.z = fadd_(st.z, fmul_(pw.dt, yr_));
+        pred.w = fadd_(st.w, fmul_(pw.dt, acc_));
+        if (!have) pred = splat(0.f);
+        float alp = 0.f;
+        if (valid_old) {
+            for (int d = 0; d < 2; ++d) {
+                const float ls = (ty >= 0) ? W[pw.head_log_std[ty] + d] : 0.f;
+                alp += -logf(expf(ls)) - 0.9189385332046727f;
+            }
+        }
+        // teacher forcing / spawn (dynamics.py:132-149)
+        f32x4 cur = pred;
+        bool valid = valid_old;
+        bool killed = p.killed[si] != 0;
+        uint8_t ovr = 0;
+        bool gt_valid = false;
+        if (t < p.n_hist) {
+            const size_t hi = ((size_t)b * p.n_hist + t) * p.n_agent + row;
+            ovr = p.tf_mask[hi];
+            gt_valid = p.hist_valid[hi] != 0;
+            if (ovr && !killed) {
+                valid = true;
+                cur = ldg4(p.hist_state + hi * 4);
+                const f32x4 ax = f32x4{p.hist_vel[hi * 2], p.hist_vel[hi * 2 + 1], p.hist_acc[hi], p.hist_yaw_rate[hi]};
+                st4(p.aux + si * 4, ax);
+                rst[tid].aux[0] = ax.x; rst[tid].aux[1] = ax.y; rst[tid].aux[2] = ax.z; rst[tid].aux[3] = ax.w;
+            }
+        }
+        // rule checks on the post-override state (traffic_rule_checker.py:101-119,364-410)
+        const float* bd = p.map_boundary + (size_t)b * 4;
+        const bool out_this = valid && ((cur.x > bd[1]) || (cur.x < bd[0]) || (cur.y > bd[3]) || (cur.y < bd[2]));
+        const bool outside = (p.outside[si] != 0) || out_this;
+        bool dreached = p.dest_reached[si] != 0;
+        bool dr_this = false;
+        {
+            const bool is_lane = (dflag[tid] & 1) != 0, is_edge = (dflag[tid] & 2) != 0;
+            const float thresh = is_edge ? fmul_(50.f, fadd_(1.f, -0.8f)) : 50.f;
+            float hs, hc;
+            sincosf(cur.z, &hs, &hc);
+            bool pos_r = false, rot_r = false;
+#pragma unroll 4
+            for (int k = 0; k < 20; ++k) {
+                const f32x4 g = lds4(DG + (tid * 20 + k) * 4);
+                const float dx = fadd_(cur.x, -g.x), dy = fadd_(cur.y, -g.y);
+                const float dist = sqrtf(fadd_(fmul_(dx, dx), fmul_(dy, dy)));
+                pos_r |= dist < thresh;
+                const float rot = fadd_(fmul_(hc, g.z), fmul_(hs, g.w));
+                rot_r |= rot > 0.8660254037844387f;
+            }
+            dr_this = !dreached && valid && ((is_lane && pos_r && rot_r) || (is_edge && pos_r));
+            dreached |= dr_this;
+        }
+        // kill agents that left the map unless ground truth is still valid (dynamics.py:161-167)
+        const bool mk = out_this && !gt_valid;
+        killed |= mk;
+        valid = valid && !mk;
+        // navigator (goal_manager.py:155-162)
+        const bool gv = (gvalid[tid] != 0) && valid && !dreached;
+        // simulator state: global (the next launch's interaction reads `valid` of every agent) + LDS (A half below)
+        st4(p.state + si * 4, cur);
+        p.valid[si] = valid;
+        p.vbias[si] = valid ? 0.f : -INFINITY;
+        p.killed[si] = killed;
+        p.goal_valid[si] = gv;
+        p.dest_reached[si] = dreached;
+        p.outside[si] = outside;
+        rst[tid].st[0] = cur.x; rst[tid].st[1] = cur.y; rst[tid].st[2] = cur.z; rst[tid].st[3] = cur.w;
+        rowvalid[tid] = valid;
+        // RolloutBuffer.add (buffer.py:39-70)
+        const int s = t - p.step_start;
+        const size_t oi = ((size_t)n * p.n_agent + row) * p.n_step_out + s;
+        st4(p.preds + oi * 4, pred);
+        p.o_valid[oi] = valid_old;
+        p.o_override[oi] = ovr;
+        p.o_outside[oi] = outside;
+        p.o_outside_this[oi] = out_this;
+        p.o_dest_reached[oi] = dreached;
+        p.o_dest_reached_this[oi] = dr_this;
+        p.o_action_logp[oi] = alp;
+    }
+}
+
+// ---- head of A(t+1): agent attributes + pose PE + InputPeEncoder -> X[:, 0:128] (invalid rows zeroed).
+// The row/column maps use 256 threads; extra threads of a wider workgroup only take part in the barriers.
+template <int NT>
+__device__ __forceinline__ void step_encode_inputs(const RolloutP& p, int t, int n, int b, int row0, int n_real, int tid,
+                                                   const StepSmall& sm, float* X) {
+    (void)t; (void)n;
+    const PolicyW& pw = p.pw;
+    const float* W = p.W;
+    float* attr = sm.attr; float* ench = sm.ench; const RowSt* rst = sm.rst; const uint8_t* rowvalid = sm.rowvalid;
+    const int* rtype = sm.rtype;
+    const bool act = (NT == 256) || tid < 256;
+    // ---- agent attributes (sc_input.py:142-165): vel2, spd, yaw_rate, acc, size3, type one-hot3
+    if (tid < TM) {
+        const int row = row0 + tid;
+        float* a = attr + tid * 16;
+        const int ty = rtype[tid];
+        f32x4 sz = splat(0.f);
+        if (tid < n_real) {
+            const float* s = p.agent_size + ((size_t)b * p.n_agent + row) * 3;
+            sz = f32x4{s[0], s[1], s[2], 0.f};
+        }
+        a[0] = rst[tid].aux[0]; a[1] = rst[tid].aux[1]; a[2] = rst[tid].st[3]; a[3] = rst[tid].aux[3]; a[4] = rst[tid].aux[2];
+        a[5] = sz.x; a[6] = sz.y; a[7] = sz.z;
+        a[8] = ty == 0 ? 1.f : 0.f; a[9] = ty == 1 ? 1.f : 0.f; a[10] = ty == 2 ? 1.f : 0.f;
+    }
+    __syncthreads();
+    // ---- pose PE (pose_pe.py:57-62, pos_emb.py:24-25,54-55): 48 sincos per row, 3 per thread
+    if (act) {
+        const int row = tid >> 4, i = tid & 15;
+        const float px = rst[row].st[0], py = rst[row].st[1], pyaw = rst[row].st[2];
+        float* xr = X + row * LDT + 32;
+#pragma unroll
+        for (int uu = 0; uu < 3; ++uu) {
+            const int j = i * 3 + uu;
+            float arg;
+            int c_cos, c_sin;
+            if (j < 12) {
+                arg = px * W[pw.pe_fxy + j]; c_cos = j; c_sin = 12 + j;
+            } else if (j < 24) {
+                arg = py * W[pw.pe_fxy + j - 12]; c_cos = 24 + (j - 12); c_sin = 36 + (j - 12);
+            } else {
+                arg = pyaw * W[pw.pe_fyaw + j - 24]; c_cos = 48 + (j - 24); c_sin = 72 + (j - 24);
+            }
+            // fp64 sin/cos of the fp32 argument, rounded once: within 0.5 ulp of exact, i.e. as close as
+            // possible to whatever libm the reference's host uses (48 per agent, negligible)
+            double sv, cv;
+            sincos((double)arg, &sv, &cv);
+            xr[c_cos] = (float)cv;
+            xr[c_sin] = (float)sv;
+        }
+    }
+    // ---- InputPeEncoder MLP 11 -> 32 -> 32 (input_pe_encoder.py:52-54), 2 outputs per thread
+    if (act) {
+        const int row = tid >> 4, o0 = (tid & 15) * 2;
+#pragma unroll
+        for (int uu = 0; uu < 2; ++uu) {
+            const int o = o0 + uu;
+            float s = W[pw.enc_b1 + o];
+            for (int k = 0; k < 11; ++k) s = fmaf(attr[row * 16 + k], W[pw.enc_w1 + o * 11 + k], s);
+            ench[row * 32 + o] = fmaxf(s, 0.f);
+        }
+    }
+    __syncthreads();
+    if (act) {
+        const int row = tid >> 4, o0 = (tid & 15) * 2;
+#pragma unroll
+        for (int uu = 0; uu < 2; ++uu) {
+            const int o = o0 + uu;
+            float s = W[pw.enc_b2 + o];
+            for (int k = 0; k < 32; ++k) s = fmaf(ench[row * 32 + k], W[pw.enc_w2 + o * 32 + k], s);
+            X[row * LDT + o] = s;
+        }
+    }
+    __syncthreads();
+    // zero invalid rows (input_pe_encoder.py:59)
+    for (int i = tid; i < TM * 32; i += NT) {
+        const int r = i >> 5;
+        if (!rowvalid[r]) st4(X + r * LDT + (i & 31) * 4, splat(0.f));
+    }
+    __syncthreads();
+}
+
+}  // namespace tb
