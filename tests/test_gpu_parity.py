@@ -249,7 +249,7 @@ def test_stepwise_forward_equals_fused_rollout():
 
 
 def test_eight_wave_step_kernel_matches_default(monkeypatch):
-    """`TB_STEP_WAVES=8` selects k_step8 (512-thread workgroups, tb_step8_kernels.hip): same arithmetic per agent,
+    """`TB_STEP_KERNEL=fp32w8` selects k_step8 (512-thread workgroups, tb_step8_kernels.hip): same arithmetic per agent,
     different split over waves (two partial softmaxes merged, two accumulator chains per tile) -> equal flags,
     trajectories within the closed-loop tolerance of the default kernel."""
     from trafficbots_amd import synth
@@ -259,8 +259,8 @@ def test_eight_wave_step_kernel_matches_default(monkeypatch):
     batch = synth.make_batch(9100, 3, n_agent=40, n_pl=96, n_tl=20, p_late_spawn=0.2, p_invalid_agent=0.2, pos_range=140.0)
     eps = torch.from_numpy(synth.make_latent_noise(11, 3 * k, 40)).cuda()
     outs = []
-    for waves in ("4", "8"):
-        monkeypatch.setenv("TB_STEP_WAVES", waves)
+    for waves in ("fp32", "fp32w8"):
+        monkeypatch.setenv("TB_STEP_KERNEL", waves)
         wm = _engine({"time_step_end": step_end, "n_joint_future": k}, sd)
         outs.append(wm.test_step(batch, latent_eps=eps, generator=torch.Generator(device="cuda").manual_seed(4))["rollout_buffer"])
     a, b = outs

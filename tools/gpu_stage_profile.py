@@ -60,7 +60,7 @@ lab = ["LN params -> LDS (issue+store)", "row state loads (16 thr)", "valid ball
 for i in range(5):
     v = st[:, seq[i + 1]] - st[:, seq[i]]
     print(f"    C-start/{lab[i]:40s} {np.median(v):8.0f}  [{v.min():7.0f} .. {v.max():7.0f}]")
-if os.environ.get("TB_STEP_WAVES") == "8":
+if os.environ.get("TB_STEP_KERNEL") == "fp32w8":
     lab = ["LN1 + barrier", "Q proj (32 MFMA) + LDS exchange + barrier", "attention half: 128 keys (4 x 32 MFMA)", "partial store + barrier",
            "softmax merge + barrier", "out proj + residual + barrier", "LN2 + barrier", "FFN1 + relu + barrier", "FFN2 + residual + barrier"]
     for i in range(9):

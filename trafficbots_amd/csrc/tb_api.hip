@@ -3,6 +3,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <map>
@@ -22,6 +23,8 @@ void launch_rollout_final(const RolloutP& p, float* f_state, uint8_t* f_valid, f
 hipError_t configure_rollout_kernels();
 void launch_step8(const RolloutP& p, int t, int do_c, int do_a, hipStream_t s);
 hipError_t configure_step8_kernel();
+void launch_step_x(const RolloutP& p, int t, int do_c, int do_a, hipStream_t s);
+hipError_t configure_stepx_kernel();
 int run_encode(struct ::tb_ctx* ctx, const tb_encode_io* io, hipStream_t s);
 }  // namespace tb
 
@@ -56,6 +59,65 @@ std::vector<float> pack_mfma(const float* w, int n_out, int k, int kp) {
     return out;
 }
 
+// fp16-pair packing for the XDL path (tb_device_xdl.hpp): W [n_out][k] row-major, k a multiple of 32 ->
+// [n_out/16][k/32][2 planes][64 lanes][8 fp16], lane = kq*16 + row holds W_plane[tile*16 + row][chunk*32 + kq*8 + 0..7];
+// w ~ w0 + 2^-11 w1 with w0 = fp16(w), w1 = fp16((w - w0) * 2^11), round-to-nearest-even.  Returned as raw floats (two
+// fp16 per float) so that it lives in the same arena.
+uint16_t f32_to_f16_rne(float f) {
+    uint32_t x;
+    memcpy(&x, &f, 4);
+    const uint32_t sign = (x >> 16) & 0x8000u;
+    x &= 0x7fffffffu;
+    if (x >= 0x47800000u) return (uint16_t)(sign | 0x7c00u);  // >= 65536 (or inf / nan): inf
+    if (x < 0x38800000u) {                                    // < 2^-14: fp16 subnormal (or zero)
+        if (x < 0x33000000u) return (uint16_t)sign;           // < 2^-25: rounds to zero
+        const int e = (int)(x >> 23);                         // biased fp32 exponent, 102..112
+        const uint32_t mant = (x & 0x7fffffu) | 0x800000u;    // 24-bit significand
+        const int shift = 126 - e;                            // result = mant >> shift, in units of 2^-24; shift in 14..24
+        uint32_t r = mant >> shift;
+        const uint32_t rem = mant & ((1u << shift) - 1u), half = 1u << (shift - 1);
+        if (rem > half || (rem == half && (r & 1u))) ++r;
+        return (uint16_t)(sign | r);
+    }
+    uint32_t r = ((x - 0x38000000u) >> 13);                   // rebias 127 -> 15, drop 13 mantissa bits
+    const uint32_t rem = x & 0x1fffu;
+    if (rem > 0x1000u || (rem == 0x1000u && (r & 1u))) ++r;   // may carry into the exponent (and to inf): correct
+    return (uint16_t)(sign | r);
+}
+float f16_to_f32(uint16_t h) {
+    const uint32_t sign = (uint32_t)(h & 0x8000u) << 16;
+    const uint32_t e = (h >> 10) & 0x1fu, m = h & 0x3ffu;
+    float out;
+    if (e == 0) {
+        out = ldexpf((float)m, -24);
+    } else if (e == 31) {
+        out = m ? NAN : INFINITY;
+    } else {
+        const uint32_t x = ((e + 112u) << 23) | (m << 13);
+        memcpy(&out, &x, 4);
+    }
+    return sign ? -out : out;
+}
+std::vector<float> pack_xdl(const float* w, int n_out, int k) {
+    const int n_tiles = n_out / 16, nch = k / 32;
+    std::vector<uint16_t> out((size_t)n_tiles * nch * 2 * 512);
+    for (int t = 0; t < n_tiles; ++t)
+        for (int c = 0; c < nch; ++c)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int e = 0; e < 8; ++e) {
+                    const float v = w[(size_t)(t * 16 + (lane & 15)) * k + c * 32 + (lane >> 4) * 8 + e];
+                    const uint16_t h0 = f32_to_f16_rne(v);
+                    const float r1 = (v - f16_to_f32(h0)) * 2048.0f;
+                    const uint16_t h1 = f32_to_f16_rne(r1);
+                    const size_t base = ((size_t)(t * nch + c) * 2) * 512 + (size_t)lane * 8 + e;
+                    out[base] = h0;
+                    out[base + 512] = h1;
+                }
+    std::vector<float> f(out.size() / 2);
+    memcpy(f.data(), out.data(), out.size() * 2);
+    return f;
+}
+
 struct Stage {
     tb_ctx* ctx;
     bool ok = true;
@@ -85,6 +147,23 @@ uint32_t add_packed(Arena& a, Stage& s, const std::string& name, int n_out, int 
     auto v = s.get(name, (size_t)rows_total * k);
     if (!v) return 0;
     return a.add(pack_mfma(v->data() + (size_t)row0 * k, n_out, k, kp));
+}
+
+uint32_t add_xdl(Arena& a, Stage& s, const std::string& name, int n_out, int k, int row0 = 0, int rows_total = -1) {
+    if (rows_total < 0) rows_total = n_out;
+    auto v = s.get(name, (size_t)rows_total * k);
+    if (!v) return 0;
+    return a.add(pack_xdl(v->data() + (size_t)row0 * k, n_out, k));
+}
+
+tb::XLayerX add_xlayer_x(Arena& a, Stage& s, const std::string& p) {
+    tb::XLayerX L;
+    L.wq = add_xdl(a, s, p + ".attn.in_proj_weight", 128, 128, 0, 384);
+    L.wkv = add_xdl(a, s, p + ".attn.in_proj_weight", 256, 128, 128, 384);
+    L.wo = add_xdl(a, s, p + ".attn.out_proj_weight", 128, 128);
+    L.w1 = add_xdl(a, s, p + ".linear1.weight", 128, 128);
+    L.w2 = add_xdl(a, s, p + ".linear2.weight", 128, 128);
+    return L;
 }
 
 tb::XLayerW add_xlayer(Arena& a, Stage& s, const std::string& p) {
@@ -146,7 +225,9 @@ extern "C" {
 const char* tb_version(void) { return "trafficbots_hip 0.1 (gfx950, fp32 MFMA 16x16x4)"; }
 
 static void step_launch(const tb_ctx* ctx, const tb::RolloutP& p, int t, int do_c, int do_a, hipStream_t s) {
-    if (ctx->step_waves == 8)
+    if (ctx->step_kernel == 2)
+        tb::launch_step_x(p, t, do_c, do_a, s);
+    else if (ctx->step_kernel == 1)
         tb::launch_step8(p, t, do_c, do_a, s);
     else
         tb::launch_step(p, t, do_c, do_a, s);
@@ -161,10 +242,16 @@ int tb_create(const tb_config* cfg, tb_ctx** out) {
     }
     tb_ctx* c = new tb_ctx();
     c->cfg = *cfg;
-    if (const char* w = getenv("TB_STEP_WAVES")) {
-        c->step_waves = atoi(w);
-        if (c->step_waves != 4 && c->step_waves != 8) {
-            fprintf(stderr, "trafficbots_hip: TB_STEP_WAVES must be 4 or 8\n");
+    if (const char* w = getenv("TB_STEP_KERNEL")) {  // development switch between the step-kernel implementations
+        const std::string k = w;
+        if (k == "fp32")
+            c->step_kernel = 0;
+        else if (k == "fp32w8")
+            c->step_kernel = 1;
+        else if (k == "xdl")
+            c->step_kernel = 2;
+        else {
+            fprintf(stderr, "trafficbots_hip: TB_STEP_KERNEL must be fp32, fp32w8 or xdl\n");
             delete c;
             return 1;
         }
@@ -199,6 +286,7 @@ int tb_finalize_weights(tb_ctx* ctx, tb_stream stream) {
     TB_HIP(ctx, hipSetDevice(ctx->device));
     TB_HIP(ctx, tb::configure_rollout_kernels());
     TB_HIP(ctx, tb::configure_step8_kernel());
+    TB_HIP(ctx, tb::configure_stepx_kernel());
     Arena a;
     Stage s{ctx};
     tb::PolicyW& pw = ctx->pw;
@@ -249,6 +337,23 @@ int tb_finalize_weights(tb_ctx* ctx, tb_stream stream) {
         pw.max_yaw_rate[i] = ctx->cfg.max_yaw_rate[i];
     }
     pw.dt = ctx->cfg.dt;
+    // ---- the same policy Linears once more as fp16 pairs for k_step_x
+    {
+        tb::PolicyWX& px = ctx->px;
+        for (int i = 0; i < 3; ++i) {
+            const std::string si = std::to_string(i);
+            px.as2pl[i] = add_xlayer_x(a, s, "model.transformer_as2pl.layers." + si);
+            px.as2tl[i] = add_xlayer_x(a, s, "model.transformer_as2tl.layers." + si);
+            px.inter[i] = add_xlayer_x(a, s, "model.agent_interaction.transformer.layers." + si);
+            px.gru[i].wih = add_xdl(a, s, "model.agent_temporal.rnn.weight_ih_l" + si, 384, 128);
+            px.gru[i].whh = add_xdl(a, s, "model.agent_temporal.rnn.weight_hh_l" + si, 384, 128);
+            px.head_w1[i] = add_xdl(a, s, "action_head.mlp_mean." + si + ".fc_layers.0.weight", 128, 128);
+        }
+        px.goal_out_w1 = add_xdl(a, s, "model.add_goal.mlp_out.fc_layers.0.weight", 128, 256);
+        px.goal_out_w2 = add_xdl(a, s, "model.add_goal.mlp_out.fc_layers.3.weight", 128, 128);
+        px.lat_out_w1 = add_xdl(a, s, "model.add_latent.mlp_out.fc_layers.0.weight", 128, 256);
+        px.lat_out_w2 = add_xdl(a, s, "model.add_latent.mlp_out.fc_layers.3.weight", 128, 128);
+    }
 
     // ---- scene-encoder weights
     tb::EncoderW& ew = ctx->ew;
@@ -400,6 +505,7 @@ static int rollout_setup(tb_ctx* ctx, const tb_rollout_io* io, tb::RolloutP& p) 
     memset(&p, 0, sizeof(p));
     p.W = ctx->d_arena;
     p.pw = ctx->pw;
+    p.px = ctx->px;
     p.n_scene = io->n_scene;
     p.k_rep = io->k_futures;
     p.n_inst = io->n_scene * io->k_futures;

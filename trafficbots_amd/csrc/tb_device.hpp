@@ -40,6 +40,9 @@ __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
+// wave index inside the workgroup as a wave-UNIFORM (SGPR) value: everything derived from it (weight tile offsets, head
+// offsets, K/V bases) then stays in scalar registers instead of per-lane 64-bit VALU address math
+__device__ __forceinline__ int wave_of(int tid) { return __builtin_amdgcn_readfirstlane(tid >> 6); }
 __device__ __forceinline__ f32x4 ldg4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 __device__ __forceinline__ f32x4 lds4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
@@ -519,7 +522,7 @@ __device__ __forceinline__ void xattn_layer(const float* __restrict__ W, const X
     // LayerNorm parameters: the six 128-vectors [ln1_g, ln1_b, lnt_g, lnt_b, ln2_g, ln2_b] are contiguous in the arena
     // (tb_api.hip add_xlayer); `lnblk` may point at an LDS copy of that block (no VMEM in front of the K/V prefetch)
     if (!LNLDS) lnblk = W + L.ln1_g;
-    const int wave = tid >> 6, lane = tid & 63;
+    const int wave = wave_of(tid), lane = tid & 63;
     const int kq = lane >> 4, m = lane & 15;
 #ifdef TB_PROFILE
 #define TB_XSTAMP(i) do { if (prof && threadIdx.x == 0) prof[i] = clock64(); } while (0)
@@ -608,7 +611,7 @@ template <bool LNLDS = false>
 __device__ __forceinline__ void kv_project_tile(const float* __restrict__ W, const XLayerW& L, const float* T, float* S1,
                                                 float* __restrict__ Kmat, float* __restrict__ VT, int n_key_pad, int tok0,
                                                 int n_real_rows, int tid, WUnit& u, const WNext& nxt, const float* lnblk = nullptr) {
-    const int wave = tid >> 6, lane = tid & 63;
+    const int wave = wave_of(tid), lane = tid & 63;
     const int kq = lane >> 4, m = lane & 15;
     if (!LNLDS) lnblk = W + L.ln1_g;
     layernorm_tile<LNLDS>(T, LDT, S1, LDT, lnblk + 256, lnblk + 384, tid);
@@ -663,7 +666,7 @@ __device__ __forceinline__ WNext gru_first(const float* W, const GruLayerW& G, i
 __device__ __forceinline__ void gru_layer(const float* __restrict__ W, const GruLayerW& G, const float* Xin, const float* Hs,
                                           float* Out, const uint8_t* rowvalid, float* __restrict__ h_global /*[rows][128]*/,
                                           int n_real_rows, int tid, WUnit& u, const WNext& nxt) {
-    const int wave = tid >> 6, lane = tid & 63;
+    const int wave = wave_of(tid), lane = tid & 63;
     const int kq = lane >> 4, m = lane & 15;
     const int tr0 = 2 * wave, tz0 = 8 + 2 * wave, tn0 = 16 + 2 * wave;
     const float* xr = Xin + m * LDT + kq * 32;

@@ -227,7 +227,7 @@ __device__ __forceinline__ void xattn_layer8(const float* __restrict__ W, const 
 #endif
     if (!LNLDS) lnblk = W + L.ln1_g;
     TB_X8STAMP(16);
-    const int wave = tid >> 6, lane = tid & 63;
+    const int wave = wave_of(tid), lane = tid & 63;
     const int kq = lane >> 4, m = lane & 15;
     const int head = wave >> 1, half = wave & 1;
     layernorm_tile8<LNLDS>(X, LDT, sc.S1, LDT, lnblk, lnblk + 128, tid);
@@ -313,7 +313,7 @@ template <bool LNLDS = false>
 __device__ __forceinline__ void kv_project_tile8(const float* __restrict__ W, const XLayerW& L, const float* T, float* S1,
                                                  float* __restrict__ Kmat, float* __restrict__ VT, int n_key_pad, int tok0,
                                                  int n_real_rows, int tid, WUnit1& u, const WNext1& nxt, const float* lnblk = nullptr) {
-    const int wave = tid >> 6, lane = tid & 63;
+    const int wave = wave_of(tid), lane = tid & 63;
     const int kq = lane >> 4, m = lane & 15;
     if (!LNLDS) lnblk = W + L.ln1_g;
     layernorm_tile8<LNLDS>(T, LDT, S1, LDT, lnblk + 256, lnblk + 384, tid);
@@ -341,7 +341,7 @@ __device__ __forceinline__ WNext1 gru_first8(const float* W, const GruLayerW& G,
 __device__ __forceinline__ void gru_layer8(const float* __restrict__ W, const GruLayerW& G, const float* Xin, const float* Hs, float* Out,
                                            const uint8_t* rowvalid, float* __restrict__ h_global, int n_real_rows, int tid,
                                            WUnit1& u, const WNext1& nxt) {
-    const int wave = tid >> 6, lane = tid & 63;
+    const int wave = wave_of(tid), lane = tid & 63;
     const int kq = lane >> 4, m = lane & 15;
     const int tr = wave, tz = 8 + wave, tn = 16 + wave;
     const float* xr = Xin + m * LDT + kq * 32;

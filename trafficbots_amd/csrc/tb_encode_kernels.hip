@@ -168,7 +168,7 @@ __global__ __launch_bounds__(NTHREADS) void k_xattn_block(XBlockP p) {
         __syncthreads();
     }
     if (!bypass) {
-        const int wave = tid >> 6, lane = tid & 63;
+        const int wave = wave_of(tid), lane = tid & 63;
         WUnit u;
         wload(u, xlayer_first(p.W, p.L[0], wave), lane);
 #pragma unroll 1
@@ -197,7 +197,7 @@ __global__ __launch_bounds__(NTHREADS) void k_kv_hoist_n(const float* __restrict
         kbias[(size_t)g * n_pad + tok0 + tid] = (tid < n_real && fvalid[(size_t)g * n_tok + tok0 + tid]) ? 0.f : -INFINITY;
     __syncthreads();
     const XLayerW* Ls[3] = {&l0, &l1, &l2};
-    const int wave = tid >> 6, lane = tid & 63;
+    const int wave = wave_of(tid), lane = tid & 63;
     WUnit u;
     wload(u, kvproj_first(W, l0, wave), lane);
 #pragma unroll 1
@@ -281,7 +281,7 @@ __global__ __launch_bounds__(NTHREADS) void k_gru_scan(ScanP p) {
     float* AGG = HS + 3 * TM * LDT;  // aggregate
     uint8_t* rowvalid = reinterpret_cast<uint8_t*>(AGG + TM * LDT);
     uint8_t* anyvalid = rowvalid + 16;
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, kq = lane >> 4, m = lane & 15;
+    const int tid = threadIdx.x, wave = wave_of(tid), lane = tid & 63, kq = lane >> 4, m = lane & 15;
     const int b = blockIdx.y, row0 = blockIdx.x * TM;
     const int n_real = min(TM, p.A - row0);
     for (int i = tid; i < 3 * TM * LDT; i += NTHREADS) HS[i] = 0.f;
@@ -363,7 +363,7 @@ __global__ __launch_bounds__(NTHREADS) void k_gru_scan(ScanP p) {
 __global__ __launch_bounds__(NTHREADS) void k_linear_rows(const float* __restrict__ W, uint32_t w, uint32_t bias, int has_bias,
                                                          const float* __restrict__ x, int n_rows, float* __restrict__ out) {
     __shared__ __attribute__((aligned(16))) float X[TM * LDT];
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, kq = lane >> 4, m = lane & 15;
+    const int tid = threadIdx.x, wave = wave_of(tid), lane = tid & 63, kq = lane >> 4, m = lane & 15;
     const int row0 = blockIdx.x * TM, n_real = min(TM, n_rows - row0);
     load_tile(X, LDT, x + (size_t)row0 * H, n_real, tid);
     __syncthreads();
@@ -408,7 +408,7 @@ __device__ __forceinline__ bool dest_candidate(int mtype, bool mvalid, int atype
 __global__ __launch_bounds__(NTHREADS) void k_dest_pairs(DestP p) {
     __shared__ __attribute__((aligned(16))) float X[TM * LDT];
     __shared__ __attribute__((aligned(16))) float Y[TM * LDT];
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, kq = lane >> 4, m = lane & 15;
+    const int tid = threadIdx.x, wave = wave_of(tid), lane = tid & 63, kq = lane >> 4, m = lane & 15;
     const int p0 = blockIdx.x * TM, a = blockIdx.y, b = blockIdx.z;
     const int n_real = min(TM, p.P - p0);
     const int atype = p.agent_type[(size_t)b * p.A + a];

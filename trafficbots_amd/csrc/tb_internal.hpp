@@ -21,9 +21,10 @@ struct tb_ctx {
     float* d_arena = nullptr;
     size_t arena_floats = 0;
     tb::PolicyW pw;
+    tb::PolicyWX px;
     tb::EncoderW ew;
     bool finalized = false;
-    int step_waves = 4;  // waves per workgroup of the step kernel: 4 (k_step) or 8 (k_step8); TB_STEP_WAVES overrides
+    int step_kernel = 0;  // 0: k_step (fp32 MFMA, 4 waves)  1: k_step8 (fp32 MFMA, 8 waves)  2: k_step_x (split-bf16 XDL GEMMs); TB_STEP_KERNEL overrides
     // workspace
     char* d_ws = nullptr;
     size_t ws_bytes = 0;

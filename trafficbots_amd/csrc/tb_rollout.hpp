@@ -1,6 +1,7 @@
 // Kernel-side parameter blocks of the rollout path (passed by value as kernel arguments).
 #pragma once
 #include "tb_device.hpp"
+#include "tb_device_xdl.hpp"
 
 namespace tb {
 
@@ -25,9 +26,18 @@ struct PolicyW {
     float dt;
 };
 
+// offsets of the split-bf16 (XDL) packings of the policy Linears (same arena; biases / LN parameters come from PolicyW)
+struct PolicyWX {
+    XLayerX as2pl[3], as2tl[3], inter[3];
+    GruLayerX gru[3];
+    uint32_t goal_out_w1, goal_out_w2, lat_out_w1, lat_out_w2;
+    uint32_t head_w1[3];
+};
+
 struct RolloutP {
     const float* W;  // weight arena
     PolicyW pw;
+    PolicyWX px;
     // sizes
     int n_scene, k_rep, n_inst, n_agent, a_pad, n_pl, p_pad, n_tl, t_pad, n_hist, step_start, n_step_out;
     // encoded scene

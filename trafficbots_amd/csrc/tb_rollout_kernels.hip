@@ -30,7 +30,7 @@ __global__ __launch_bounds__(NTHREADS) void k_kv_hoist(const float* __restrict__
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* T = smem;
     float* S1 = smem + TM * LDT;
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, g = blockIdx.y, tok0 = blockIdx.x * TM;
+    const int tid = threadIdx.x, wave = wave_of(tid), lane = tid & 63, g = blockIdx.y, tok0 = blockIdx.x * TM;
     const int n_real = max(0, min(TM, n_tok - tok0));
     WUnit u;
     wload(u, kvproj_first(W, l0, wave), lane);
@@ -55,7 +55,7 @@ __global__ __launch_bounds__(NTHREADS) void k_rollout_init(RolloutP p) {
     float* S1 = smem + OFF_S1;
     float* S2 = smem + OFF_S2;
     float* Z = smem + OFF_H;  // [16][20]
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, kq = lane >> 4, m = lane & 15;
+    const int tid = threadIdx.x, wave = wave_of(tid), lane = tid & 63, kq = lane >> 4, m = lane & 15;
     const int n = blockIdx.y, b = n / p.k_rep, row0 = blockIdx.x * TM;
     const int n_real = max(0, min(TM, p.n_agent - row0));
     const float* W = p.W;
@@ -205,7 +205,7 @@ __global__ void k_rollout_final(RolloutP p, float* __restrict__ f_state, uint8_t
 __device__ __forceinline__ void fuse_latent_goal(const float* __restrict__ W, uint32_t w1, uint32_t w2, uint32_t b2, float* X, float* CAT,
                                                  float* S2, const float* PRE, const uint8_t* zvalid, const uint8_t* rowvalid, int tid,
                                                  WUnit& uw, const WNext& nxt, long long* prof = nullptr) {
-    const int wave = tid >> 6, lane = tid & 63, kq = lane >> 4, m = lane & 15;
+    const int wave = wave_of(tid), lane = tid & 63, kq = lane >> 4, m = lane & 15;
     // CAT = [x ; relu(mask(pre))]
     for (int i = tid; i < TM * 32; i += NTHREADS) {
         const int r = i >> 5, c4 = (i & 31) * 4;
@@ -268,7 +268,7 @@ __global__ __launch_bounds__(NTHREADS) void k_step(RolloutP p, int t, int do_c, 
     float* LP = smem + OFF_LP;
     float* DG = smem + OFF_DG;
     float* LN = smem + OFF_LN;
-    const StepSmall sm = step_small(smem);
+    const StepSmall sm = step_small(smem + OFF_SMALL);
     RowSt* rst = sm.rst;
     float* ubuf = sm.ubuf;
     uint8_t* rowvalid = sm.rowvalid;
@@ -277,7 +277,7 @@ __global__ __launch_bounds__(NTHREADS) void k_step(RolloutP p, int t, int do_c, 
     int* rtype = sm.rtype;
     int* dflag = sm.dflag;
 
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, kq = lane >> 4, m = lane & 15;
+    const int tid = threadIdx.x, wave = wave_of(tid), lane = tid & 63, kq = lane >> 4, m = lane & 15;
     int n, rt;
     step_tile_map(n, rt);
     const int b = n / p.k_rep, row0 = rt * TM;
@@ -318,14 +318,7 @@ __global__ __launch_bounds__(NTHREADS) void k_step(RolloutP p, int t, int do_c, 
         TB_STAMP(14);
         wload(u, bypass ? gru_first(W, pw.gru[0], wave) : xlayer_first(W, pw.inter[0], wave), lane);
         // one burst of per-tile inputs for the whole C half (a single exposed global latency)
-        load_tile(X, LDT, p.x_mid + base_row * H, TM, tid);
-        load_tile(Hs, LDT, p.hidden + (((size_t)0 * p.n_inst + n) * p.a_pad + row0) * H, TM, tid);
-        load_tile(H1, LDT, p.hidden + (((size_t)1 * p.n_inst + n) * p.a_pad + row0) * H, TM, tid);
-        load_tile(H2, LDT, p.hidden + (((size_t)2 * p.n_inst + n) * p.a_pad + row0) * H, TM, tid);
-        load_tile(GP, LDT, p.goal_pre + base_row * H, TM, tid);
-        load_tile(LP, LDT, p.lat_pre + base_row * H, TM, tid);
-        for (int i = tid; i < TM * 20; i += NTHREADS) st4(DG + i * 4, ldg4(p.dest_geo + (base_row * 20 + i) * 4));
-        if (tid < TM) dflag[tid] = p.dest_flag[base_row + tid];
+        step_load_c_inputs<NTHREADS>(p, n, row0, tid, X, Hs, H1, H2, GP, LP, DG, dflag);
         TB_STAMP(15);
         __syncthreads();
         TB_STAMP(1);

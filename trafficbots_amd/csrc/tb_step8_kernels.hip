@@ -12,7 +12,7 @@ namespace tb {
 __device__ __forceinline__ void fuse_latent_goal8(const float* __restrict__ W, uint32_t w1, uint32_t w2, uint32_t b2, float* X, float* CAT,
                                                   float* S2, const float* PRE, const uint8_t* zvalid, const uint8_t* rowvalid, int tid,
                                                   WUnit1& uw, const WNext1& nxt) {
-    const int wave = tid >> 6, lane = tid & 63, kq = lane >> 4, m = lane & 15;
+    const int wave = wave_of(tid), lane = tid & 63, kq = lane >> 4, m = lane & 15;
     {
         const int r = tid >> 5, c4 = (tid & 31) * 4;  // 16 rows x 32 float4 = 512 threads
         st4(CAT + r * LDC + c4, lds4(X + r * LDT + c4));
@@ -54,7 +54,7 @@ __global__ __launch_bounds__(NTHREADS8) void k_step8(RolloutP p, int t, int do_c
     float* LP = smem + OFF_LP;
     float* DG = smem + OFF_DG;
     float* LN = smem + OFF_LN;
-    const StepSmall sm = step_small(smem);
+    const StepSmall sm = step_small(smem + OFF_SMALL);
     RowSt* rst = sm.rst;
     float* ubuf = sm.ubuf;
     uint8_t* rowvalid = sm.rowvalid;
@@ -66,7 +66,7 @@ __global__ __launch_bounds__(NTHREADS8) void k_step8(RolloutP p, int t, int do_c
     const X8Scratch xs{S1, S2, Y, CAT, CAT + TM * LDT};
     static_assert(TM * LDT + 2 * 4 * 16 * 2 <= TM * LDC, "attention merge scratch must fit the concat tile");
 
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, kq = lane >> 4, m = lane & 15;
+    const int tid = threadIdx.x, wave = wave_of(tid), lane = tid & 63, kq = lane >> 4, m = lane & 15;
     int n, rt;
     step_tile_map(n, rt);
     const int b = n / p.k_rep, row0 = rt * TM;
@@ -102,14 +102,7 @@ __global__ __launch_bounds__(NTHREADS8) void k_step8(RolloutP p, int t, int do_c
             n_valid += __popcll(__ballot(i0 + lane < p.a_pad && p.valid[(size_t)n * p.a_pad + i0 + lane] != 0));
         const bool bypass = n_valid == 1;  // agent_interaction.py:61
         wload1(u, bypass ? gru_first8(W, pw.gru[0], wave) : xlayer_first8(W, pw.inter[0], wave), lane);
-        load_tile8(X, LDT, p.x_mid + base_row * H, TM, tid);
-        load_tile8(Hs, LDT, p.hidden + (((size_t)0 * p.n_inst + n) * p.a_pad + row0) * H, TM, tid);
-        load_tile8(H1, LDT, p.hidden + (((size_t)1 * p.n_inst + n) * p.a_pad + row0) * H, TM, tid);
-        load_tile8(H2, LDT, p.hidden + (((size_t)2 * p.n_inst + n) * p.a_pad + row0) * H, TM, tid);
-        load_tile8(GP, LDT, p.goal_pre + base_row * H, TM, tid);
-        load_tile8(LP, LDT, p.lat_pre + base_row * H, TM, tid);
-        if (tid < TM * 20) st4(DG + tid * 4, ldg4(p.dest_geo + (base_row * 20 + tid) * 4));
-        if (tid < TM) dflag[tid] = p.dest_flag[base_row + tid];
+        step_load_c_inputs<NTHREADS8>(p, n, row0, tid, X, Hs, H1, H2, GP, LP, DG, dflag);
         __syncthreads();
         TB_STAMP(1);
         if (!bypass) {

@@ -55,9 +55,9 @@ struct StepSmall {
     int* dflag;          // [16] bit0 lane-type destination, bit1 road-edge destination
 };
 
-__device__ __forceinline__ StepSmall step_small(float* smem) {
+__device__ __forceinline__ StepSmall step_small(float* small_base) {
     StepSmall s;
-    s.attr = smem + OFF_SMALL;
+    s.attr = small_base;
     s.ench = s.attr + 16 * 16;
     s.rst = reinterpret_cast<RowSt*>(s.ench + 16 * 32);
     s.ubuf = reinterpret_cast<float*>(s.rst + 16);
@@ -81,6 +81,53 @@ __device__ __forceinline__ void step_tile_map(int& n, int& rt) {
         rt = blockIdx.x;
         n = blockIdx.y;
     }
+}
+
+// ---- the per-tile inputs of the C half (x_mid, three GRU hidden tiles, goal / latent pre-activations, destination
+// geometry + flags) as ONE burst: every global load is issued before the first LDS store, so the launch pays one cold
+// round trip here instead of one per tile (the compiler otherwise reuses one register quad and waits after each load).
+template <int NT>
+__device__ __forceinline__ void step_load_c_inputs(const RolloutP& p, int n, int row0, int tid, float* X, float* Hs, float* H1,
+                                                   float* H2, float* GP, float* LP, float* DG, int* dflag) {
+    const size_t base_row = (size_t)n * p.a_pad + row0;
+    const float* src[6] = {p.x_mid + base_row * H,
+                           p.hidden + (((size_t)0 * p.n_inst + n) * p.a_pad + row0) * H,
+                           p.hidden + (((size_t)1 * p.n_inst + n) * p.a_pad + row0) * H,
+                           p.hidden + (((size_t)2 * p.n_inst + n) * p.a_pad + row0) * H,
+                           p.goal_pre + base_row * H,
+                           p.lat_pre + base_row * H};
+    float* dst[6] = {X, Hs, H1, H2, GP, LP};
+    constexpr int PER = (TM * 32) / NT;  // float4 per thread per tile: 2 (256 threads) or 1 (512)
+    f32x4 v[6][PER], g[2];
+    int df = 0;
+    TB_SCHED_FENCE();
+#pragma unroll
+    for (int s = 0; s < 6; ++s)
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int idx = tid + i * NT;
+            v[s][i] = ldg4(src[s] + (size_t)(idx >> 5) * H + (idx & 31) * 4);
+        }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int idx = tid + i * NT;
+        g[i] = idx < TM * 20 ? ldg4(p.dest_geo + (base_row * 20 + idx) * 4) : splat(0.f);
+    }
+    if (tid < TM) df = p.dest_flag[base_row + tid];
+    TB_SCHED_FENCE();
+#pragma unroll
+    for (int s = 0; s < 6; ++s)
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int idx = tid + i * NT;
+            st4(dst[s] + (idx >> 5) * LDT + (idx & 31) * 4, v[s][i]);
+        }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int idx = tid + i * NT;
+        if (idx < TM * 20) st4(DG + idx * 4, g[i]);
+    }
+    if (tid < TM) dflag[tid] = df;
 }
 
 // ---- per-agent simulator epilogue of C(t): dynamics, teacher forcing, rule checks, kill, navigator, buffer writes.

@@ -1,0 +1,283 @@
+// k_step_x: the fused step launch C(t) + A(t+1) of tb_rollout_kernels.hip with every Linear on the XDL matrix pipe
+// (fp16-pair operands, fp32 accumulate, tb_device_xdl.hpp).  Tiling, global layouts, attention (fp32 MFMA QK / PV with
+// online softmax), LayerNorm, GRU gate math, dynamics and rule checks are those of k_step; GEMM inputs live in LDS as
+// two fp16 planes instead of one fp32 tile.
+#include "tb_rollout.hpp"
+#include "tb_step_common.hpp"
+
+namespace tb {
+
+// LDS carve (floats): seven fp32 tiles, geometry, LN parameters, small state, four plane buffers
+constexpr int XO_X = 0;
+constexpr int XO_H = XO_X + TM * LDT;
+constexpr int XO_H1 = XO_H + TM * LDT;
+constexpr int XO_H2 = XO_H1 + TM * LDT;
+constexpr int XO_GP = XO_H2 + TM * LDT;
+constexpr int XO_LP = XO_GP + TM * LDT;
+constexpr int XO_Y = XO_LP + TM * LDT;
+constexpr int XO_DG = XO_Y + TM * LDT;
+constexpr int XO_LN = XO_DG + TM * 80;
+constexpr int XO_SMALL = XO_LN + 9 * 768;
+constexpr int XO_PL = XO_SMALL + SMALL_FLOATS;  // 4 x [2][16][LDP] fp16
+constexpr int PLANES_FLOATS = PLANES_BYTES / 4;
+constexpr int STEPX_LDS_FLOATS = XO_PL + 4 * PLANES_FLOATS;
+static_assert(XO_PL % 4 == 0, "plane buffers must be 16-byte aligned");
+static_assert(NPL * PLANEC * 2 <= 2 * PLANES_BYTES, "concat planes must fit two plane buffers");
+static_assert(STEPX_LDS_FLOATS * 4 <= 160 * 1024, "LDS budget");
+
+// add_goal / add_latent fusion MLP (add_latent_goal.py:57-77): h = relu(W2 relu(W1 [x ; relu(mask(pre))] + b1) + b2) ...
+//   CP : concat planes [3][16][LDPC];  P2 : plane buffer for the hidden;  uw : in = first K half of W1 (carries b1)
+__device__ __forceinline__ void fuse_latent_goal_x(const float* __restrict__ W, uint32_t w1x, uint32_t w2x, uint32_t b2, float* X,
+                                                   xhalf* CP, xhalf* P2, const float* PRE, const uint8_t* zvalid,
+                                                   const uint8_t* rowvalid, int tid, WUnitX& uw, const WNextX& nxt) {
+    const int wave = wave_of(tid), lane = tid & 63, kq = lane >> 4, m = lane & 15;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int idx = tid + i * NTHREADS;
+        const int r = idx >> 5, c4 = (idx & 31) * 4;
+        planes_store4(CP, PLANEC, LDPC, r, c4, lds4(X + r * LDT + c4));
+        planes_store4(CP, PLANEC, LDPC, r, 128 + c4, zvalid[r] ? relu4(lds4(PRE + r * LDT + c4)) : splat(0.f));
+    }
+    __syncthreads();
+    WUnitX u2;
+    {
+        const int ta = 2 * wave, tb_ = 2 * wave + 1;
+        f32x4 acc[2] = {uw.b[0], uw.b[1]};
+        const xhalf* xr = CP + m * LDPC + kq * 8;
+        wmmax_pf(acc[0], acc[1], uw, xr, PLANEC, u2, wnextx(W, w1x, nullptr, ta, tb_, 8, 4), lane);
+        wmmax_pf(acc[0], acc[1], u2, xr + 128, PLANEC, uw, wstdx(W, w2x, W + b2, wave), lane);
+        planes_store_c(P2, ta, lane, relu4(acc[0]));
+        planes_store_c(P2, tb_, lane, relu4(acc[1]));
+    }
+    __syncthreads();
+    {
+        f32x4 acc[2] = {uw.b[0], uw.b[1]};
+        wmmax_pf(acc[0], acc[1], uw, P2 + m * LDP + kq * 8, PLANE, u2, nxt, lane);
+        const bool zv = zvalid[m] != 0, rv = rowvalid[m] != 0;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            float* px = cptr(X, LDT, 2 * wave + t, lane);
+            const f32x4 h = zv ? relu4(acc[t]) : splat(0.f);
+            st4(px, rv ? h + lds4(px) : splat(0.f));
+        }
+        uw = u2;
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(NTHREADS) void k_step_x(RolloutP p, int t, int do_c, int do_a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* X = smem + XO_X;
+    float* Hs = smem + XO_H;
+    float* H1 = smem + XO_H1;
+    float* H2 = smem + XO_H2;
+    float* GP = smem + XO_GP;
+    float* LP = smem + XO_LP;
+    float* DG = smem + XO_DG;
+    float* LN = smem + XO_LN;
+    xhalf* PA = reinterpret_cast<xhalf*>(smem + XO_PL);
+    xhalf* PB = PA + NPL * PLANE;
+    xhalf* PC = PB + NPL * PLANE;
+    xhalf* PD = PC + NPL * PLANE;
+    const StepSmall sm = step_small(smem + XO_SMALL);
+    RowSt* rst = sm.rst;
+    float* ubuf = sm.ubuf;
+    uint8_t* rowvalid = sm.rowvalid;
+    uint8_t* novalid_s = sm.novalid_s;
+    uint8_t* gvalid = sm.gvalid;
+    int* rtype = sm.rtype;
+    int* dflag = sm.dflag;
+
+    const int tid = threadIdx.x, wave = wave_of(tid), lane = tid & 63, kq = lane >> 4, m = lane & 15;
+    int n, rt;
+    step_tile_map(n, rt);
+    const int b = n / p.k_rep, row0 = rt * TM;
+    const int n_real = max(0, min(TM, p.n_agent - row0));
+    const float* W = p.W;
+    const PolicyW& pw = p.pw;
+    const PolicyWX& px = p.px;
+    const size_t base_row = (size_t)n * p.a_pad + row0;
+
+    WUnitX u;
+    TB_STAMP(0);
+    {
+        const uint32_t base[9] = {pw.inter[0].ln1_g, pw.inter[1].ln1_g, pw.inter[2].ln1_g, pw.as2pl[0].ln1_g, pw.as2pl[1].ln1_g,
+                                  pw.as2pl[2].ln1_g, pw.as2tl[0].ln1_g, pw.as2tl[1].ln1_g, pw.as2tl[2].ln1_g};
+#pragma unroll
+        for (int sl = 0; sl < 9; ++sl)
+            if (tid < 192) st4(LN + sl * 768 + tid * 4, ldg4(W + base[sl] + tid * 4));
+    }
+    if (tid < TM) {
+        rtype[tid] = (tid < n_real) ? p.agent_type[(size_t)b * p.n_agent + row0 + tid] : -1;
+        const size_t si = base_row + tid;
+        const f32x4 st = ldg4(p.state + si * 4), ax = ldg4(p.aux + si * 4);
+        rst[tid].st[0] = st.x; rst[tid].st[1] = st.y; rst[tid].st[2] = st.z; rst[tid].st[3] = st.w;
+        rst[tid].aux[0] = ax.x; rst[tid].aux[1] = ax.y; rst[tid].aux[2] = ax.z; rst[tid].aux[3] = ax.w;
+        rowvalid[tid] = p.valid[si];
+        gvalid[tid] = p.goal_valid[si];
+    }
+
+    if (do_c) {
+        // =================================== C(t) ===================================
+        int n_valid = 0;
+        for (int i0 = 0; i0 < p.a_pad; i0 += 64)
+            n_valid += __popcll(__ballot(i0 + lane < p.a_pad && p.valid[(size_t)n * p.a_pad + i0 + lane] != 0));
+        const bool bypass = n_valid == 1;  // agent_interaction.py:61
+        wloadx(u, bypass ? gru_first_x(W, pw.gru[0], px.gru[0], wave) : xlayer_first_x(W, pw.inter[0], px.inter[0], wave), lane);
+        step_load_c_inputs<NTHREADS>(p, n, row0, tid, X, Hs, H1, H2, GP, LP, DG, dflag);
+        __syncthreads();
+        TB_STAMP(1);
+        if (!bypass) {
+            const float* kvd = p.vbias + (size_t)n * p.a_pad;
+            const size_t ls = (size_t)p.a_pad * H;
+            const float* K0 = p.kin + ((size_t)n * 3) * ls;
+            const float* V0 = p.vtin + ((size_t)n * 3) * ls;
+            xattn_layer_x<true>(W, pw.inter[0], px.inter[0], X, PA, PB, K0, V0, kvd, p.a_pad, row0, rowvalid, novalid_s, tid, u,
+                                xlayer_first_x(W, pw.inter[1], px.inter[1], wave), LN + 0 * 768);
+            xattn_layer_x<true>(W, pw.inter[1], px.inter[1], X, PA, PB, K0 + ls, V0 + ls, kvd, p.a_pad, row0, rowvalid, novalid_s, tid,
+                                u, xlayer_first_x(W, pw.inter[2], px.inter[2], wave), LN + 1 * 768);
+            xattn_layer_x<true>(W, pw.inter[2], px.inter[2], X, PA, PB, K0 + 2 * ls, V0 + 2 * ls, kvd, p.a_pad, row0, rowvalid,
+                                novalid_s, tid, u, gru_first_x(W, pw.gru[0], px.gru[0], wave), LN + 2 * 768);
+        }
+        TB_STAMP(2);
+        // ---- 3-layer GRU, one step (agent_temporal.py:147-152).  planes: x0 = PA, h0 = PB, h1 = PD, out0 = PC, h2 -> PB, out1 = PA
+        {
+            float* hg0 = p.hidden + (((size_t)0 * p.n_inst + n) * p.a_pad + row0) * H;
+            float* hg1 = p.hidden + (((size_t)1 * p.n_inst + n) * p.a_pad + row0) * H;
+            float* hg2 = p.hidden + (((size_t)2 * p.n_inst + n) * p.a_pad + row0) * H;
+            tile_to_planes(X, LDT, PA, tid);
+            tile_to_planes(Hs, LDT, PB, tid);
+            tile_to_planes(H1, LDT, PD, tid);
+            __syncthreads();
+            gru_layer_x(W, pw.gru[0], px.gru[0], PA, PB, Hs, PC, nullptr, rowvalid, hg0, TM, tid, u, gru_first_x(W, pw.gru[1], px.gru[1], wave));
+            tile_to_planes(H2, LDT, PB, tid);  // (h0's planes are free after the barrier that closed layer 0)
+            gru_layer_x(W, pw.gru[1], px.gru[1], PC, PD, H1, PA, nullptr, rowvalid, hg1, TM, tid, u, gru_first_x(W, pw.gru[2], px.gru[2], wave));
+            gru_layer_x(W, pw.gru[2], px.gru[2], PA, PB, H2, nullptr, X, rowvalid, hg2, TM, tid, u,
+                        wnextx(W, px.goal_out_w1, W + pw.goal_out_b1, 2 * wave, 2 * wave + 1, 8, 0));
+        }
+        TB_STAMP(3);
+        // ---- add_goal, add_latent (traffic_bots.py:240-241); concat planes = PC..PD, hidden = PB
+        fuse_latent_goal_x(W, px.goal_out_w1, px.goal_out_w2, pw.goal_out_b2, X, PC, PB, GP, gvalid, rowvalid, tid, u,
+                           wnextx(W, px.lat_out_w1, W + pw.lat_out_b1, 2 * wave, 2 * wave + 1, 8, 0));
+        const int my_ty = (lane < TM && rowvalid[lane]) ? rtype[lane] : -1;
+        const bool has0 = __ballot(my_ty == 0) != 0, has1 = __ballot(my_ty == 1) != 0, has2 = __ballot(my_ty == 2) != 0;
+        const WNextX after_head = do_a ? xlayer_first_x(W, pw.as2pl[0], px.as2pl[0], wave) : wstdx(W, px.head_w1[0], W + pw.head_b1[0], wave);
+        const WNextX h2 = has2 ? wstdx(W, px.head_w1[2], W + pw.head_b1[2], wave) : after_head;
+        const WNextX h1 = has1 ? wstdx(W, px.head_w1[1], W + pw.head_b1[1], wave) : h2;
+        const WNextX h0 = has0 ? wstdx(W, px.head_w1[0], W + pw.head_b1[0], wave) : h1;
+        TB_STAMP(4);
+        fuse_latent_goal_x(W, px.lat_out_w1, px.lat_out_w2, pw.lat_out_b2, X, PC, PB, LP, rowvalid, rowvalid, tid, u, h0);
+        TB_STAMP(5);
+        if (t == p.tap_step && p.tap_policy_feature)
+            store_tile(p.tap_policy_feature + ((size_t)n * p.n_agent + row0) * H, X, LDT, n_real, tid);
+
+        // ---- action head (action_head.py:69-75): first Linear of every type present, hidden tiles -> Hs / H1 / H2
+        // (the GRU hidden copies are dead by now), then ONE reduction stage for the 128 -> 2 Linear of each row's own type
+        tile_to_planes(X, LDT, PA, tid);
+        if (tid < 32) ubuf[tid] = 0.f;
+        __syncthreads();
+#pragma unroll
+        for (int ty = 0; ty < 3; ++ty) {
+            const bool present = ty == 0 ? has0 : (ty == 1 ? has1 : has2);
+            if (!present) continue;
+            WUnitX uh = u;
+            f32x4 acc[2] = {uh.b[0], uh.b[1]};
+            wmmax_pf(acc[0], acc[1], uh, PA + m * LDP + kq * 8, PLANE, u, ty == 0 ? h1 : (ty == 1 ? h2 : after_head), lane);
+            float* hb = ty == 0 ? Hs : (ty == 1 ? H1 : H2);
+            st4(cptr(hb, LDT, 2 * wave, lane), relu4(acc[0]));
+            st4(cptr(hb, LDT, 2 * wave + 1, lane), relu4(acc[1]));
+        }
+        __syncthreads();
+        {
+            // Linear(128 -> 2): 32 (row, output) pairs x 8 lanes, 16 k each, quad + half-row DPP reduction
+            const int pair = tid >> 3, sub = tid & 7, r = pair >> 1, o = pair & 1;
+            const int ty = rtype[r];
+            const bool use = ty >= 0 && rowvalid[r];
+            const int tyc = ty < 0 ? 0 : ty;
+            const float* hb = tyc == 0 ? Hs : (tyc == 1 ? H1 : H2);
+            const uint32_t w2o = tyc == 0 ? pw.head_w2[0] : (tyc == 1 ? pw.head_w2[1] : pw.head_w2[2]);
+            const uint32_t b2o = tyc == 0 ? pw.head_b2[0] : (tyc == 1 ? pw.head_b2[1] : pw.head_b2[2]);
+            const float* w2 = W + w2o + o * H + sub * 16;
+            const float* xs = hb + r * LDT + sub * 16;
+            float sacc = 0.f;
+#pragma unroll
+            for (int k4 = 0; k4 < 4; ++k4) {
+                const f32x4 a4 = lds4(xs + 4 * k4), w4 = ldg4(w2 + 4 * k4);
+                sacc = fmaf(a4.x, w4.x, sacc); sacc = fmaf(a4.y, w4.y, sacc);
+                sacc = fmaf(a4.z, w4.z, sacc); sacc = fmaf(a4.w, w4.w, sacc);
+            }
+            sacc += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sacc), 0xB1, 0xf, 0xf, true));
+            sacc += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sacc), 0x4E, 0xf, 0xf, true));
+            sacc += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sacc), 0x141, 0xf, 0xf, true));
+            if (sub == 0 && use) ubuf[pair] = sacc + W[b2o + o];
+        }
+        __syncthreads();
+        TB_STAMP(6);
+        step_epilogue(p, t, n, b, row0, n_real, tid, sm, DG);
+        __syncthreads();
+    } else {
+        wloadx(u, xlayer_first_x(W, pw.as2pl[0], px.as2pl[0], wave), lane);
+        __syncthreads();
+    }
+    TB_STAMP(7);
+    if (!do_a) return;
+
+    // =================================== A(t+1) ===================================
+    const int t1 = t + 1;
+    step_encode_inputs<NTHREADS>(p, t, n, b, row0, n_real, tid, sm, X);
+    if (t1 == p.tap_step && p.tap_agent_feature)
+        store_tile(p.tap_agent_feature + ((size_t)n * p.n_agent + row0) * H, X, LDT, n_real, tid);
+    TB_STAMP(8);
+    {
+        const float* kvd = p.kbias_pl + (size_t)b * p.p_pad;
+        const size_t ls = (size_t)p.p_pad * H;
+        const float* K0 = p.kpl + ((size_t)b * 3) * ls;
+        const float* V0 = p.vtpl + ((size_t)b * 3) * ls;
+        xattn_layer_x<true>(W, pw.as2pl[0], px.as2pl[0], X, PA, PB, K0, V0, kvd, p.p_pad, -1, rowvalid, novalid_s, tid, u,
+                            xlayer_first_x(W, pw.as2pl[1], px.as2pl[1], wave), LN + 3 * 768);
+        xattn_layer_x<true>(W, pw.as2pl[1], px.as2pl[1], X, PA, PB, K0 + ls, V0 + ls, kvd, p.p_pad, -1, rowvalid, novalid_s, tid, u,
+                            xlayer_first_x(W, pw.as2pl[2], px.as2pl[2], wave), LN + 4 * 768);
+        xattn_layer_x<true>(W, pw.as2pl[2], px.as2pl[2], X, PA, PB, K0 + 2 * ls, V0 + 2 * ls, kvd, p.p_pad, -1, rowvalid, novalid_s, tid,
+                            u, xlayer_first_x(W, pw.as2tl[0], px.as2tl[0], wave), LN + 5 * 768);
+    }
+    TB_STAMP(9);
+    {
+        const int g_tl = b * p.n_hist + min(t1 - 1, p.n_hist - 1);
+        const float* kvd = p.kbias_tl + (size_t)g_tl * p.t_pad;
+        const size_t ls = (size_t)p.t_pad * H;
+        const float* K0 = p.ktl + ((size_t)g_tl * 3) * ls;
+        const float* V0 = p.vttl + ((size_t)g_tl * 3) * ls;
+        xattn_layer_x<true>(W, pw.as2tl[0], px.as2tl[0], X, PA, PB, K0, V0, kvd, p.t_pad, -1, rowvalid, novalid_s, tid, u,
+                            xlayer_first_x(W, pw.as2tl[1], px.as2tl[1], wave), LN + 6 * 768);
+        xattn_layer_x<true>(W, pw.as2tl[1], px.as2tl[1], X, PA, PB, K0 + ls, V0 + ls, kvd, p.t_pad, -1, rowvalid, novalid_s, tid, u,
+                            xlayer_first_x(W, pw.as2tl[2], px.as2tl[2], wave), LN + 7 * 768);
+        xattn_layer_x<true>(W, pw.as2tl[2], px.as2tl[2], X, PA, PB, K0 + 2 * ls, V0 + 2 * ls, kvd, p.t_pad, -1, rowvalid, novalid_s, tid,
+                            u, kvproj_first_x(W, pw.inter[0], px.inter[0], wave), LN + 8 * 768);
+    }
+    TB_STAMP(10);
+    store_tile(p.x_mid + base_row * H, X, LDT, TM, tid);
+    {
+        const size_t ls = (size_t)p.a_pad * H;
+        float* K0 = p.kin + ((size_t)n * 3) * ls;
+        float* V0 = p.vtin + ((size_t)n * 3) * ls;
+        kv_project_tile_x<true>(W, pw.inter[0], px.inter[0], X, PA, K0, V0, p.a_pad, row0, TM, tid, u,
+                                kvproj_first_x(W, pw.inter[1], px.inter[1], wave), LN + 0 * 768);
+        kv_project_tile_x<true>(W, pw.inter[1], px.inter[1], X, PA, K0 + ls, V0 + ls, p.a_pad, row0, TM, tid, u,
+                                kvproj_first_x(W, pw.inter[2], px.inter[2], wave), LN + 1 * 768);
+        kv_project_tile_x<true>(W, pw.inter[2], px.inter[2], X, PA, K0 + 2 * ls, V0 + 2 * ls, p.a_pad, row0, TM, tid, u,
+                                kvproj_first_x(W, pw.inter[2], px.inter[2], wave), LN + 2 * 768);
+    }
+    TB_STAMP(11);
+}
+
+hipError_t configure_stepx_kernel() {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(k_step_x), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)(STEPX_LDS_FLOATS * sizeof(float)));
+}
+
+void launch_step_x(const RolloutP& p, int t, int do_c, int do_a, hipStream_t s) {
+    dim3 grid(p.a_pad / TM, p.n_inst);
+    hipLaunchKernelGGL(k_step_x, grid, dim3(NTHREADS), STEPX_LDS_FLOATS * sizeof(float), s, p, t, do_c, do_a);
+}
+
+}  // namespace tb
