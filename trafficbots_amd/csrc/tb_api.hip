@@ -25,6 +25,8 @@ void launch_step8(const RolloutP& p, int t, int do_c, int do_a, hipStream_t s);
 hipError_t configure_step8_kernel();
 void launch_step_x(const RolloutP& p, int t, int do_c, int do_a, hipStream_t s);
 hipError_t configure_stepx_kernel();
+void launch_kv_hoist_x(const float* W, const XLayerW* L3, const XLayerX* X3, const float* feat, const uint8_t* fvalid, int G, int n_tok,
+                       int n_pad, float* K, float* VT, float* kbias, hipStream_t s);
 int run_encode(struct ::tb_ctx* ctx, const tb_encode_io* io, hipStream_t s);
 }  // namespace tb
 
@@ -566,7 +568,15 @@ static int rollout_setup(tb_ctx* ctx, const tb_rollout_io* io, tb::RolloutP& p) 
 }
 
 // prologue: hoisted K/V of the map and of every history step's traffic lights; simulator init
-static void rollout_prologue(const tb::RolloutP& p, const tb_rollout_io* io, hipStream_t s) {
+static void rollout_prologue(const tb_ctx* ctx, const tb::RolloutP& p, const tb_rollout_io* io, hipStream_t s) {
+    if (ctx->step_kernel == 2) {  // k_step_x reads K / V as fp16 pairs in XDL operand order
+        tb::launch_kv_hoist_x(p.W, p.pw.as2pl, p.px.as2pl, p.map_feature, io->map_feature_valid, p.n_scene, p.n_pl, p.p_pad, p.kpl,
+                              p.vtpl, p.kbias_pl, s);
+        tb::launch_kv_hoist_x(p.W, p.pw.as2tl, p.px.as2tl, p.tl_feature, io->tl_feature_valid, p.n_scene * p.n_hist, p.n_tl, p.t_pad,
+                              p.ktl, p.vttl, p.kbias_tl, s);
+        tb::launch_rollout_init(p, s);
+        return;
+    }
     tb::launch_kv_hoist(p.W, p.pw.as2pl, p.map_feature, io->map_feature_valid, p.n_scene, p.n_pl, p.p_pad, p.kpl, p.vtpl,
                         p.kbias_pl, s);
     tb::launch_kv_hoist(p.W, p.pw.as2tl, p.tl_feature, io->tl_feature_valid, p.n_scene * p.n_hist, p.n_tl, p.t_pad, p.ktl,
@@ -591,7 +601,7 @@ extern "C" int tb_rollout(tb_ctx* ctx, const tb_rollout_io* io, tb_stream stream
         }
         TB_HIP(ctx, hipEventRecord(ctx->ev[0], s));
     }
-    rollout_prologue(p, io, s);
+    rollout_prologue(ctx, p, io, s);
     if (ctx->timing) TB_HIP(ctx, hipEventRecord(ctx->ev[1], s));
     // ---- the sequential loop (waymo_motion.py:269): launch i runs C(start+i-1) then A(start+i); no host sync
     for (int i = 0; i < n_launch; ++i) {
@@ -612,7 +622,7 @@ extern "C" int tb_rollout_begin(tb_ctx* ctx, const tb_rollout_io* io, tb_stream 
     tb::RolloutP p;
     if (rollout_setup(ctx, io, p)) return 1;
     hipStream_t s = (hipStream_t)stream_;
-    rollout_prologue(p, io, s);
+    rollout_prologue(ctx, p, io, s);
     step_launch(ctx, p, p.step_start - 1, /*do_c=*/0, /*do_a=*/1, s);  // A(sim_start)
     ctx->step_p = p;
     ctx->step_next = p.step_start;

@@ -492,6 +492,12 @@ __device__ __forceinline__ bool attention_head(const f32x4 (&q)[2], AttnPre& pre
     return novalid;
 }
 
+#ifdef TB_PROFILE
+#define TB_XSTAMP(i) do { if (prof && threadIdx.x == 0) prof[i] = clock64(); } while (0)
+#else
+#define TB_XSTAMP(i) do { (void)prof; } while (0)
+#endif
+
 // Offsets (in floats) of one pre-LN cross-attention layer inside the weight arena.
 struct XLayerW {
     uint32_t ln1_g, ln1_b, lnt_g, lnt_b, ln2_g, ln2_b;
@@ -524,11 +530,6 @@ __device__ __forceinline__ void xattn_layer(const float* __restrict__ W, const X
     if (!LNLDS) lnblk = W + L.ln1_g;
     const int wave = wave_of(tid), lane = tid & 63;
     const int kq = lane >> 4, m = lane & 15;
-#ifdef TB_PROFILE
-#define TB_XSTAMP(i) do { if (prof && threadIdx.x == 0) prof[i] = clock64(); } while (0)
-#else
-#define TB_XSTAMP(i) do { } while (0)
-#endif
     TB_XSTAMP(16);
     AttnPre apre;
 #ifndef TB_LATE_KV_PREFETCH

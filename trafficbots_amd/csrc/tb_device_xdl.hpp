@@ -187,6 +187,27 @@ __device__ __forceinline__ void wmmax_pf(f32x4& acc_a, f32x4& acc_b, const WUnit
     }
 }
 
+// the same unit without a follow-up request (the caller issues the next unit itself, see attention_head_x)
+__device__ __forceinline__ void wmmax(f32x4& acc_a, f32x4& acc_b, const WUnitX& u, const xhalf* bp, int plane_stride) {
+    xh8 x[4][NPL];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int p = 0; p < NPL; ++p) x[c][p] = ldsb8(bp + p * plane_stride + c * 32);
+    f32x4 mid_a = splat(0.f), mid_b = splat(0.f);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        mid_a = mfma_h(u.w[0][c][0], x[c][1], mid_a);
+        mid_b = mfma_h(u.w[1][c][0], x[c][1], mid_b);
+        mid_a = mfma_h(u.w[0][c][1], x[c][0], mid_a);
+        mid_b = mfma_h(u.w[1][c][1], x[c][0], mid_b);
+        acc_a = mfma_h(u.w[0][c][0], x[c][0], acc_a);
+        acc_b = mfma_h(u.w[1][c][0], x[c][0], acc_b);
+    }
+    acc_a += mid_a * splat(SPLIT_INV);
+    acc_b += mid_b * splat(SPLIT_INV);
+}
+
 // offsets (in floats, into the same arena) of the fp16-pair packed Linears of one cross-attention layer / GRU layer
 struct XLayerX {
     uint32_t wq, wkv, wo, w1, w2;
@@ -206,32 +227,256 @@ __device__ __forceinline__ WNextX gru_first_x(const float* W, const GruLayerW& G
 }
 
 // ---------------------------------------------------------------------------------------------
-// One pre-LN cross-attention layer, GEMMs on XDL, attention (QK / PV) unchanged on the fp32 MFMA.
+// attention on the XDL pipe.  K and V of a group live in global memory as fp16 pairs, FRAGMENT-MAJOR: for every block of
+// 32 keys, head and plane the two operand fragments a wave loads are 2 x 1 KiB contiguous (one fully coalesced
+// global_load_dwordx4 each; a row-major layout makes every load touch 16 half-used cache lines and runs at ~1/3 the rate):
+//   Kf : [key block][head][plane][key tile t][lane = kq*16 + row][8]   key = blk*32 + 16 t + row,
+//                                                                       feature = head*32 + (e < 4 ? 4 kq + e : 16 + 4 kq + e - 4)
+//   Vf : [key block][head][plane][d tile dt][lane = kq*16 + row][8]    d = head*32 + 16 dt + row,
+//                                                                       key = blk*32 + (e < 4 ? 4 kq + e : 16 + 4 kq + e - 4)
+// With that element order the Q^T accumulators of the projection (lane (kq, m): features tt*16 + 4 kq + r) and the P^T values
+// of the softmax (lane (kq, m): keys t*16 + 4 kq + r) ARE the B operands of v_mfma_f32_16x16x32_f16 -- no data movement, as
+// in the fp32 path.  Per 32 keys: 6 MFMAs for S^T = K Q^T (2 key tiles x 3 products) and 6 for O^T += V^T P^T.
+// ---------------------------------------------------------------------------------------------
+struct KFragX {
+    xh8 ka[2][NPL];  // [key tile][plane]
+    f32x4 kb[2];     // additive key bias of this lane's 4 keys per tile
+};
+struct VFragX {
+    xh8 va[2][NPL];  // [d tile][plane]
+};
+
+constexpr int KV_BLOCK_HALFS = 4 * NPL * 2 * 512;  // fp16 per 32-key block (all heads): 8192
+
+// kfb / vfb : this lane's base = Kf / Vf + head*NPL*1024 + lane*8 ; k0 = first key of the block (multiple of 32)
+__device__ __forceinline__ void k_load_x(KFragX& f, const xhalf* __restrict__ kfb, const float* __restrict__ bbase, int k0) {
+#if defined(TB_FAKE_KV) || defined(TB_FAKE_K)  // timing experiment only: every block re-reads the first 32 keys -> results are wrong
+    k0 = 0;
+#endif
+    const xhalf* p = kfb + (size_t)(k0 >> 5) * KV_BLOCK_HALFS;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+#pragma unroll
+        for (int pl = 0; pl < NPL; ++pl) f.ka[t][pl] = *reinterpret_cast<const xh8*>(p + (pl * 2 + t) * 512);
+        f.kb[t] = ldg4(bbase + k0 + 16 * t);
+    }
+}
+__device__ __forceinline__ void v_load_x(VFragX& f, const xhalf* __restrict__ vfb, int k0) {
+#if defined(TB_FAKE_KV) || defined(TB_FAKE_V)
+    k0 = 0;
+#endif
+    const xhalf* p = vfb + (size_t)(k0 >> 5) * KV_BLOCK_HALFS;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int pl = 0; pl < NPL; ++pl) f.va[dt][pl] = *reinterpret_cast<const xh8*>(p + (pl * 2 + dt) * 512);
+}
+
+// eight floats of a lane -> fp16 pair (B operand)
+__device__ __forceinline__ void split8(const f32x4& a, const f32x4& b, xh8& h, xh8& l) {
+    xh4 h0, l0, h1, l1;
+    split2(a, h0, l0);
+    split2(b, h1, l1);
+    h = xh8{h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+    l = xh8{l0.x, l0.y, l0.z, l0.w, l1.x, l1.y, l1.z, l1.w};
+}
+
+// S^T of 32 keys: s = hi products, c = cross products (to be scaled by 2^-11)
+__device__ __forceinline__ void attn_qk_x(const KFragX& f, const xh8& qh, const xh8& ql, f32x4 (&s)[2], f32x4 (&c)[2]) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        c[t] = mfma_h(f.ka[t][0], ql, splat(0.f));
+        s[t] = mfma_h(f.ka[t][0], qh, splat(0.f));
+        c[t] = mfma_h(f.ka[t][1], qh, c[t]);
+    }
+}
+
+__device__ __forceinline__ void attn_stats_x(const f32x4 (&s)[2], const f32x4 (&c)[2], const f32x4 (&kb)[2], int kb0, int self_key,
+                                             float run_max, float (&sv)[8], float& new_max, float& alpha) {
+    const float raw[8] = {s[0].x, s[0].y, s[0].z, s[0].w, s[1].x, s[1].y, s[1].z, s[1].w};
+    const float crs[8] = {c[0].x, c[0].y, c[0].z, c[0].w, c[1].x, c[1].y, c[1].z, c[1].w};
+    const float bias[8] = {kb[0].x, kb[0].y, kb[0].z, kb[0].w, kb[1].x, kb[1].y, kb[1].z, kb[1].w};
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const float v = fmaf(raw[r] + crs[r] * SPLIT_INV, ATTN_SCALE, bias[r]);
+        sv[r] = (kb0 + 16 * (r >> 2) + (r & 3) == self_key) ? -INFINITY : v;
+    }
+    float tmax = fmaxf(fmaxf(fmaxf(sv[0], sv[1]), fmaxf(sv[2], sv[3])), fmaxf(fmaxf(sv[4], sv[5]), fmaxf(sv[6], sv[7])));
+    tmax = rows_max(tmax);
+    new_max = fmaxf(run_max, tmax);
+    alpha = exp_neg(run_max - new_max);
+}
+
+struct AttnPreX {
+    KFragX k0f, kn;
+    VFragX vc;
+};
+
+__device__ __forceinline__ int kwrap(int k, int n_key_pad) { return k >= n_key_pad ? k - n_key_pad : k; }
+
+// kstart: first key block of this workgroup's walk over the keys (a multiple of 32).  The row tiles of one scene start at
+// different blocks and wrap around: they all need the same K / V, so each one misses L2 only on the blocks it reaches first
+// and finds the others already fetched by its siblings (the softmax is order independent up to rounding).
+__device__ __forceinline__ void attention_prefetch_x(AttnPreX& a, const xhalf* __restrict__ Kh, const xhalf* __restrict__ Vh,
+                                                     const float* __restrict__ keybias, int n_key_pad, int kstart, int head, int lane) {
+    const int kq = lane >> 4;
+    const xhalf* kbase = Kh + head * (NPL * 1024) + lane * 8;
+    const xhalf* vbase = Vh + head * (NPL * 1024) + lane * 8;
+    const float* bbase = keybias + kq * 4;
+    TB_SCHED_FENCE();
+    k_load_x(a.k0f, kbase, bbase, kstart);
+    v_load_x(a.vc, vbase, kstart);
+    k_load_x(a.kn, kbase, bbase, n_key_pad > 32 ? kwrap(kstart + 32, n_key_pad) : kstart);
+    TB_SCHED_FENCE();
+}
+
+// One head over n_key_pad keys with online softmax; q = this wave's Q^T accumulators.  Returns o (normalised) and whether
+// the row had no valid key.  Same recurrences as attention_head (tb_device.hpp); the two matrix products are fp16-pair.
+__device__ __forceinline__ bool attention_head_x(const f32x4 (&q)[2], AttnPreX& pre, const xhalf* __restrict__ Kh,
+                                                 const xhalf* __restrict__ Vh, const float* __restrict__ keybias, int n_key_pad,
+                                                 int kstart, int head, int lane, int self_key, f32x4 (&o)[2], WUnitX& un,
+                                                 const WNextX& nx, long long* prof = nullptr) {
+    const int kq = lane >> 4;
+    const xhalf* kbase = Kh + head * (NPL * 1024) + lane * 8;
+    const xhalf* vbase = Vh + head * (NPL * 1024) + lane * 8;
+    const float* bbase = keybias + kq * 4;
+    xh8 qh, ql;
+    split8(q[0], q[1], qh, ql);
+    f32x4 oh[2] = {splat(0.f), splat(0.f)}, oc[2] = {splat(0.f), splat(0.f)};
+    KFragX kn = pre.kn;
+    VFragX vc = pre.vc;
+    float run_max = -INFINITY, run_sum = 0.f, new_max, alpha, sv[8];
+    {
+        f32x4 s[2], c[2];
+        attn_qk_x(pre.k0f, qh, ql, s, c);
+        attn_stats_x(s, c, pre.k0f.kb, kstart + kq * 4, self_key, run_max, sv, new_max, alpha);
+    }
+    // The next weight unit (the out-projection) is requested from inside the loop, two blocks before its end: loads
+    // return in issue order, so a 16 KB weight request in front of the K / V stream would stall every block behind it.
+    const int nblk = n_key_pad >> 5;
+    const int i_issue = nblk >= 2 ? nblk - 2 : 0;
+    int kc = kstart, k1 = kwrap(kstart + 32, n_key_pad), k2 = kwrap(k1 + 32, n_key_pad);
+    for (int i = 0; i < nblk; ++i) {
+        const int kn1 = (i + 1 < nblk) ? k1 : kc;  // clamped re-reads on the tail are harmless
+        const int kld = (i + 2 < nblk) ? k2 : kc;
+        TB_SCHED_FENCE();
+#ifdef TB_PROFILE
+        if (prof && threadIdx.x == 0 && i < 2) prof[25 + i * 2] = clock64();
+#endif
+        // QK of the next block (XDL) under the exponentials of this one
+        f32x4 ts[2], tc[2];
+        in_vgpr(oh[0]); in_vgpr(oh[1]); in_vgpr(oc[0]); in_vgpr(oc[1]);
+        attn_qk_x(kn, qh, ql, ts, tc);
+        in_vgpr(ts[0]); in_vgpr(ts[1]); in_vgpr(tc[0]); in_vgpr(tc[1]);
+        const f32x4 nb[2] = {kn.kb[0], kn.kb[1]};
+        KFragX k2f;
+        VFragX v1f;
+        k_load_x(k2f, kbase, bbase, kld);
+        v_load_x(v1f, vbase, kn1);
+        if (i == i_issue) wloadx(un, nx, lane);
+        float p[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) p[r] = exp_neg(sv[r] - new_max);
+        run_sum = run_sum * alpha + (((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7])));
+        run_max = new_max;
+        xh8 ph, pl;
+        split8(f32x4{p[0], p[1], p[2], p[3]}, f32x4{p[4], p[5], p[6], p[7]}, ph, pl);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+            oh[dt] *= splat(alpha);
+            oc[dt] *= splat(alpha);
+        }
+        TB_SCHED_FENCE();
+#ifdef TB_PROFILE
+        if (prof && threadIdx.x == 0 && i < 2) prof[26 + i * 2] = clock64();
+#endif
+        // PV of this block (XDL) under the scale / mask / running max of the next
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+            oc[dt] = mfma_h(vc.va[dt][0], pl, oc[dt]);
+            oh[dt] = mfma_h(vc.va[dt][0], ph, oh[dt]);
+            oc[dt] = mfma_h(vc.va[dt][1], ph, oc[dt]);
+        }
+        in_vgpr(oh[0]); in_vgpr(oh[1]); in_vgpr(oc[0]); in_vgpr(oc[1]);
+        attn_stats_x(ts, tc, nb, kn1 + kq * 4, self_key, run_max, sv, new_max, alpha);  // (unused after the last block)
+        TB_SCHED_FENCE();
+        kn = k2f;
+        vc = v1f;
+        kc = k1;
+        k1 = k2;
+        k2 = kwrap(k2 + 32, n_key_pad);
+#ifdef TB_PROFILE
+        if (prof && threadIdx.x == 0 && i == 1) prof[29] = clock64();
+#endif
+    }
+    run_sum = rows_sum(run_sum);
+    const bool novalid = !(run_sum > 0.f);
+    const float inv = novalid ? 0.f : 1.0f / run_sum;
+    o[0] = (oh[0] + oc[0] * splat(SPLIT_INV)) * splat(inv);
+    o[1] = (oh[1] + oc[1] * splat(SPLIT_INV)) * splat(inv);
+    return novalid;
+}
+
+// K / V accumulators of a 16-token tile -> global, fragment-major (see above).  ak / av : this wave's K / V tiles
+// (features (2 wave + t)*16 + 4 kq + r of token m); the wave is head `wave`.
+__device__ __forceinline__ void kv_store_x(xhalf* __restrict__ Kf, xhalf* __restrict__ Vf, int tok0, int wave, int lane,
+                                           const f32x4 (&ak)[2], const f32x4 (&av)[2], bool real) {
+    const int kq = lane >> 4, m = lane & 15;
+    const int tok = tok0 + m;
+    const int j = tok & 31;
+    xhalf* kblk = Kf + (size_t)(tok >> 5) * KV_BLOCK_HALFS + wave * (NPL * 1024);
+    xhalf* vblk = Vf + (size_t)(tok >> 5) * KV_BLOCK_HALFS + wave * (NPL * 1024);
+    const int kt = j >> 4, krow = j & 15;               // key tile / row of this token inside its block
+    const int vq = (j >> 2) & 3, ve = (j >> 4) * 4 + (j & 3);  // lane group / element that hold this key in the V fragments
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        xh4 h, l;
+        split2(real ? ak[t] : splat(0.f), h, l);
+        xhalf* pk = kblk + (kt * 64 + kq * 16 + krow) * 8 + t * 4;  // plane 0, tile kt
+        *reinterpret_cast<xh4*>(pk) = h;
+        *reinterpret_cast<xh4*>(pk + 1024) = l;
+        split2(real ? av[t] : splat(0.f), h, l);
+        xhalf* pv = vblk + (t * 64 + vq * 16 + kq * 4) * 8 + ve;    // plane 0, d tile t, rows 4 kq + r
+        pv[0] = h.x; pv[8] = h.y; pv[16] = h.z; pv[24] = h.w;
+        pv += 1024;
+        pv[0] = l.x; pv[8] = l.y; pv[16] = l.z; pv[24] = l.w;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// One pre-LN cross-attention layer, GEMMs and attention on XDL.
 //   X : [16][LDT] fp32 residual stream (LDS);  P1, P2 : plane buffers (LN output / attention output + FFN hidden)
 // ---------------------------------------------------------------------------------------------
 template <bool LNLDS = false>
 __device__ __forceinline__ void xattn_layer_x(const float* __restrict__ W, const XLayerW& L, const XLayerX& LX, float* X, xhalf* P1,
-                                              xhalf* P2, const float* __restrict__ Kmat, const float* __restrict__ VT,
-                                              const float* __restrict__ keybias, int n_key_pad, int self_key0, const uint8_t* rowvalid,
-                                              uint8_t* novalid_s, int tid, WUnitX& u, const WNextX& nxt, const float* lnblk = nullptr) {
+                                              xhalf* P2, const xhalf* __restrict__ Kmat, const xhalf* __restrict__ VT,
+                                              const float* __restrict__ keybias, int n_key_pad, int kstart, int self_key0,
+                                              const uint8_t* rowvalid, uint8_t* novalid_s, int tid, WUnitX& u, const WNextX& nxt,
+                                              const float* lnblk = nullptr, long long* prof = nullptr) {
     if (!LNLDS) lnblk = W + L.ln1_g;
     const int wave = wave_of(tid), lane = tid & 63;
     const int kq = lane >> 4, m = lane & 15;
+    TB_XSTAMP(16);
     const xhalf* b1 = P1 + m * LDP + kq * 8;
     const xhalf* b2 = P2 + m * LDP + kq * 8;
-    AttnPre apre;
-    attention_prefetch(apre, Kmat, VT, keybias, n_key_pad, wave, lane);
+    AttnPreX apre;
+    attention_prefetch_x(apre, Kmat, VT, keybias, n_key_pad, kstart, wave, lane);
     layernorm_planes<LNLDS>(X, LDT, P1, lnblk, lnblk + 128, tid);
     __syncthreads();
+    TB_XSTAMP(17);
     WUnitX u2;
     f32x4 q[2] = {u.b[0], u.b[1]};
-    wmmax_pf(q[0], q[1], u, b1, PLANE, u2, wstdx(W, LX.wo, W + L.bo, wave), lane);
+    wmmax(q[0], q[1], u, b1, PLANE);
+    TB_XSTAMP(18);
     f32x4 o[2];
-    const bool novalid = attention_head(q, apre, Kmat, VT, keybias, n_key_pad, wave, lane, self_key0 >= 0 ? self_key0 + m : -1, o);
+    const bool novalid = attention_head_x(q, apre, Kmat, VT, keybias, n_key_pad, kstart, wave, lane, self_key0 >= 0 ? self_key0 + m : -1, o, u2,
+                                          wstdx(W, LX.wo, W + L.bo, wave), prof);
+    TB_XSTAMP(19);
     planes_store_c(P2, 2 * wave, lane, o[0]);
     planes_store_c(P2, 2 * wave + 1, lane, o[1]);
     if (wave == 0 && kq == 0) novalid_s[m] = novalid ? 1 : 0;
     __syncthreads();
+    TB_XSTAMP(20);
     {
         f32x4 acc[2] = {u2.b[0], u2.b[1]};
         wmmax_pf(acc[0], acc[1], u2, b2, PLANE, u, wstdx(W, LX.w1, W + L.b1, wave), lane);
@@ -244,8 +489,10 @@ __device__ __forceinline__ void xattn_layer_x(const float* __restrict__ W, const
         }
     }
     __syncthreads();
+    TB_XSTAMP(21);
     layernorm_planes<LNLDS>(X, LDT, P1, lnblk + 512, lnblk + 640, tid);
     __syncthreads();
+    TB_XSTAMP(22);
     {
         f32x4 acc[2] = {u.b[0], u.b[1]};
         wmmax_pf(acc[0], acc[1], u, b1, PLANE, u2, wstdx(W, LX.w2, W + L.b2, wave), lane);
@@ -253,6 +500,7 @@ __device__ __forceinline__ void xattn_layer_x(const float* __restrict__ W, const
         planes_store_c(P2, 2 * wave + 1, lane, relu4(acc[1]));
     }
     __syncthreads();
+    TB_XSTAMP(23);
     {
         f32x4 acc[2] = {u2.b[0], u2.b[1]};
         wmmax_pf(acc[0], acc[1], u2, b2, PLANE, u, nxt, lane);
@@ -265,12 +513,13 @@ __device__ __forceinline__ void xattn_layer_x(const float* __restrict__ W, const
         }
     }
     __syncthreads();
+    TB_XSTAMP(24);
 }
 
-// K/V projection of the tile's tokens for one layer (LN_tgt -> in_proj rows 128:384), outputs fp32 as the fp32 path
+// K/V projection of the tile's tokens for one layer (LN_tgt -> in_proj rows 128:384), outputs in XDL operand order
 template <bool LNLDS = false>
 __device__ __forceinline__ void kv_project_tile_x(const float* __restrict__ W, const XLayerW& L, const XLayerX& LX, const float* T,
-                                                  xhalf* P1, float* __restrict__ Kmat, float* __restrict__ VT, int n_key_pad, int tok0,
+                                                  xhalf* P1, xhalf* __restrict__ Kmat, xhalf* __restrict__ VT, int n_key_pad, int tok0,
                                                   int n_real_rows, int tid, WUnitX& u, const WNextX& nxt, const float* lnblk = nullptr) {
     const int wave = wave_of(tid), lane = tid & 63;
     const int kq = lane >> 4, m = lane & 15;
@@ -283,17 +532,7 @@ __device__ __forceinline__ void kv_project_tile_x(const float* __restrict__ W, c
     wmmax_pf(ak[0], ak[1], u, b1, PLANE, u2, wnextx(W, LX.wkv, W + L.bkv, 8 + 2 * wave, 8 + 2 * wave + 1), lane);
     f32x4 av[2] = {u2.b[0], u2.b[1]};
     wmmax_pf(av[0], av[1], u2, b1, PLANE, u, nxt, lane);
-    const bool real = m < n_real_rows;
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        st4(Kmat + (size_t)(tok0 + m) * H + (2 * wave + t) * 16 + kq * 4, real ? ak[t] : splat(0.f));
-        const int f0 = (2 * wave + t) * 16 + kq * 4;
-        const f32x4 v = real ? av[t] : splat(0.f);
-        VT[(size_t)(f0 + 0) * n_key_pad + tok0 + m] = v.x;
-        VT[(size_t)(f0 + 1) * n_key_pad + tok0 + m] = v.y;
-        VT[(size_t)(f0 + 2) * n_key_pad + tok0 + m] = v.z;
-        VT[(size_t)(f0 + 3) * n_key_pad + tok0 + m] = v.w;
-    }
+    kv_store_x(Kmat, VT, tok0, wave, lane, ak, av, m < n_real_rows);
     __syncthreads();
 }
 

@@ -97,6 +97,9 @@ __global__ __launch_bounds__(NTHREADS) void k_step_x(RolloutP p, int t, int do_c
     const PolicyW& pw = p.pw;
     const PolicyWX& px = p.px;
     const size_t base_row = (size_t)n * p.a_pad + row0;
+    // staggered start of the key walks of the row tiles of one instance (attention_prefetch_x)
+    const int n_rt = gridDim.x;
+    const int ks_a = ((rt * (p.a_pad >> 5)) / n_rt) << 5, ks_p = ((rt * (p.p_pad >> 5)) / n_rt) << 5, ks_t = ((rt * (p.t_pad >> 5)) / n_rt) << 5;
 
     WUnitX u;
     TB_STAMP(0);
@@ -130,13 +133,13 @@ __global__ __launch_bounds__(NTHREADS) void k_step_x(RolloutP p, int t, int do_c
         if (!bypass) {
             const float* kvd = p.vbias + (size_t)n * p.a_pad;
             const size_t ls = (size_t)p.a_pad * H;
-            const float* K0 = p.kin + ((size_t)n * 3) * ls;
-            const float* V0 = p.vtin + ((size_t)n * 3) * ls;
-            xattn_layer_x<true>(W, pw.inter[0], px.inter[0], X, PA, PB, K0, V0, kvd, p.a_pad, row0, rowvalid, novalid_s, tid, u,
+            const xhalf* K0 = reinterpret_cast<const xhalf*>(p.kin + ((size_t)n * 3) * ls);
+            const xhalf* V0 = reinterpret_cast<const xhalf*>(p.vtin + ((size_t)n * 3) * ls);
+            xattn_layer_x<true>(W, pw.inter[0], px.inter[0], X, PA, PB, K0, V0, kvd, p.a_pad, ks_a, row0, rowvalid, novalid_s, tid, u,
                                 xlayer_first_x(W, pw.inter[1], px.inter[1], wave), LN + 0 * 768);
-            xattn_layer_x<true>(W, pw.inter[1], px.inter[1], X, PA, PB, K0 + ls, V0 + ls, kvd, p.a_pad, row0, rowvalid, novalid_s, tid,
+            xattn_layer_x<true>(W, pw.inter[1], px.inter[1], X, PA, PB, K0 + 2 * ls, V0 + 2 * ls, kvd, p.a_pad, ks_a, row0, rowvalid, novalid_s, tid,
                                 u, xlayer_first_x(W, pw.inter[2], px.inter[2], wave), LN + 1 * 768);
-            xattn_layer_x<true>(W, pw.inter[2], px.inter[2], X, PA, PB, K0 + 2 * ls, V0 + 2 * ls, kvd, p.a_pad, row0, rowvalid,
+            xattn_layer_x<true>(W, pw.inter[2], px.inter[2], X, PA, PB, K0 + 4 * ls, V0 + 4 * ls, kvd, p.a_pad, ks_a, row0, rowvalid,
                                 novalid_s, tid, u, gru_first_x(W, pw.gru[0], px.gru[0], wave), LN + 2 * 768);
         }
         TB_STAMP(2);
@@ -231,13 +234,14 @@ __global__ __launch_bounds__(NTHREADS) void k_step_x(RolloutP p, int t, int do_c
     {
         const float* kvd = p.kbias_pl + (size_t)b * p.p_pad;
         const size_t ls = (size_t)p.p_pad * H;
-        const float* K0 = p.kpl + ((size_t)b * 3) * ls;
-        const float* V0 = p.vtpl + ((size_t)b * 3) * ls;
-        xattn_layer_x<true>(W, pw.as2pl[0], px.as2pl[0], X, PA, PB, K0, V0, kvd, p.p_pad, -1, rowvalid, novalid_s, tid, u,
-                            xlayer_first_x(W, pw.as2pl[1], px.as2pl[1], wave), LN + 3 * 768);
-        xattn_layer_x<true>(W, pw.as2pl[1], px.as2pl[1], X, PA, PB, K0 + ls, V0 + ls, kvd, p.p_pad, -1, rowvalid, novalid_s, tid, u,
+        const xhalf* K0 = reinterpret_cast<const xhalf*>(p.kpl + ((size_t)b * 3) * ls);
+        const xhalf* V0 = reinterpret_cast<const xhalf*>(p.vtpl + ((size_t)b * 3) * ls);
+        xattn_layer_x<true>(W, pw.as2pl[0], px.as2pl[0], X, PA, PB, K0, V0, kvd, p.p_pad, ks_p, -1, rowvalid, novalid_s, tid, u,
+                            xlayer_first_x(W, pw.as2pl[1], px.as2pl[1], wave), LN + 3 * 768,
+                            p.prof + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 32);
+        xattn_layer_x<true>(W, pw.as2pl[1], px.as2pl[1], X, PA, PB, K0 + 2 * ls, V0 + 2 * ls, kvd, p.p_pad, ks_p, -1, rowvalid, novalid_s, tid, u,
                             xlayer_first_x(W, pw.as2pl[2], px.as2pl[2], wave), LN + 4 * 768);
-        xattn_layer_x<true>(W, pw.as2pl[2], px.as2pl[2], X, PA, PB, K0 + 2 * ls, V0 + 2 * ls, kvd, p.p_pad, -1, rowvalid, novalid_s, tid,
+        xattn_layer_x<true>(W, pw.as2pl[2], px.as2pl[2], X, PA, PB, K0 + 4 * ls, V0 + 4 * ls, kvd, p.p_pad, ks_p, -1, rowvalid, novalid_s, tid,
                             u, xlayer_first_x(W, pw.as2tl[0], px.as2tl[0], wave), LN + 5 * 768);
     }
     TB_STAMP(9);
@@ -245,29 +249,61 @@ __global__ __launch_bounds__(NTHREADS) void k_step_x(RolloutP p, int t, int do_c
         const int g_tl = b * p.n_hist + min(t1 - 1, p.n_hist - 1);
         const float* kvd = p.kbias_tl + (size_t)g_tl * p.t_pad;
         const size_t ls = (size_t)p.t_pad * H;
-        const float* K0 = p.ktl + ((size_t)g_tl * 3) * ls;
-        const float* V0 = p.vttl + ((size_t)g_tl * 3) * ls;
-        xattn_layer_x<true>(W, pw.as2tl[0], px.as2tl[0], X, PA, PB, K0, V0, kvd, p.t_pad, -1, rowvalid, novalid_s, tid, u,
+        const xhalf* K0 = reinterpret_cast<const xhalf*>(p.ktl + ((size_t)g_tl * 3) * ls);
+        const xhalf* V0 = reinterpret_cast<const xhalf*>(p.vttl + ((size_t)g_tl * 3) * ls);
+        xattn_layer_x<true>(W, pw.as2tl[0], px.as2tl[0], X, PA, PB, K0, V0, kvd, p.t_pad, ks_t, -1, rowvalid, novalid_s, tid, u,
                             xlayer_first_x(W, pw.as2tl[1], px.as2tl[1], wave), LN + 6 * 768);
-        xattn_layer_x<true>(W, pw.as2tl[1], px.as2tl[1], X, PA, PB, K0 + ls, V0 + ls, kvd, p.t_pad, -1, rowvalid, novalid_s, tid, u,
+        xattn_layer_x<true>(W, pw.as2tl[1], px.as2tl[1], X, PA, PB, K0 + 2 * ls, V0 + 2 * ls, kvd, p.t_pad, ks_t, -1, rowvalid, novalid_s, tid, u,
                             xlayer_first_x(W, pw.as2tl[2], px.as2tl[2], wave), LN + 7 * 768);
-        xattn_layer_x<true>(W, pw.as2tl[2], px.as2tl[2], X, PA, PB, K0 + 2 * ls, V0 + 2 * ls, kvd, p.t_pad, -1, rowvalid, novalid_s, tid,
+        xattn_layer_x<true>(W, pw.as2tl[2], px.as2tl[2], X, PA, PB, K0 + 4 * ls, V0 + 4 * ls, kvd, p.t_pad, ks_t, -1, rowvalid, novalid_s, tid,
                             u, kvproj_first_x(W, pw.inter[0], px.inter[0], wave), LN + 8 * 768);
     }
     TB_STAMP(10);
     store_tile(p.x_mid + base_row * H, X, LDT, TM, tid);
     {
         const size_t ls = (size_t)p.a_pad * H;
-        float* K0 = p.kin + ((size_t)n * 3) * ls;
-        float* V0 = p.vtin + ((size_t)n * 3) * ls;
+        xhalf* K0 = reinterpret_cast<xhalf*>(p.kin + ((size_t)n * 3) * ls);
+        xhalf* V0 = reinterpret_cast<xhalf*>(p.vtin + ((size_t)n * 3) * ls);
         kv_project_tile_x<true>(W, pw.inter[0], px.inter[0], X, PA, K0, V0, p.a_pad, row0, TM, tid, u,
                                 kvproj_first_x(W, pw.inter[1], px.inter[1], wave), LN + 0 * 768);
-        kv_project_tile_x<true>(W, pw.inter[1], px.inter[1], X, PA, K0 + ls, V0 + ls, p.a_pad, row0, TM, tid, u,
+        kv_project_tile_x<true>(W, pw.inter[1], px.inter[1], X, PA, K0 + 2 * ls, V0 + 2 * ls, p.a_pad, row0, TM, tid, u,
                                 kvproj_first_x(W, pw.inter[2], px.inter[2], wave), LN + 1 * 768);
-        kv_project_tile_x<true>(W, pw.inter[2], px.inter[2], X, PA, K0 + 2 * ls, V0 + 2 * ls, p.a_pad, row0, TM, tid, u,
+        kv_project_tile_x<true>(W, pw.inter[2], px.inter[2], X, PA, K0 + 4 * ls, V0 + 4 * ls, p.a_pad, row0, TM, tid, u,
                                 kvproj_first_x(W, pw.inter[2], px.inter[2], wave), LN + 2 * 768);
     }
     TB_STAMP(11);
+}
+
+// K/V of the three layers of a cross-attention block for fixed targets (map polylines, TL stop points), in the XDL operand
+// order (tb_device_xdl.hpp): the fp16-pair twin of k_kv_hoist.  grid = (n_pad/16, G)
+__global__ __launch_bounds__(NTHREADS) void k_kv_hoist_x(const float* __restrict__ W, XLayerW l0, XLayerW l1, XLayerW l2, XLayerX x0,
+                                                        XLayerX x1, XLayerX x2, const float* __restrict__ feat,
+                                                        const uint8_t* __restrict__ fvalid, int n_tok, int n_pad,
+                                                        float* __restrict__ Kout, float* __restrict__ VTout, float* __restrict__ kbias) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* T = smem;
+    xhalf* P1 = reinterpret_cast<xhalf*>(smem + TM * LDT);
+    const int tid = threadIdx.x, wave = wave_of(tid), lane = tid & 63, g = blockIdx.y, tok0 = blockIdx.x * TM;
+    const int n_real = max(0, min(TM, n_tok - tok0));
+    WUnitX u;
+    wloadx(u, kvproj_first_x(W, l0, x0, wave), lane);
+    load_tile(T, LDT, feat + ((size_t)g * n_tok + tok0) * H, n_real, tid);
+    if (tid < TM)
+        kbias[(size_t)g * n_pad + tok0 + tid] = (tid < n_real && fvalid[(size_t)g * n_tok + tok0 + tid]) ? 0.f : -INFINITY;
+    __syncthreads();
+    const size_t ls = (size_t)n_pad * H;  // floats per (group, layer) = fp16 per plane
+    xhalf* K0 = reinterpret_cast<xhalf*>(Kout + ((size_t)g * 3) * ls);
+    xhalf* V0 = reinterpret_cast<xhalf*>(VTout + ((size_t)g * 3) * ls);
+    kv_project_tile_x(W, l0, x0, T, P1, K0, V0, n_pad, tok0, n_real, tid, u, kvproj_first_x(W, l1, x1, wave));
+    kv_project_tile_x(W, l1, x1, T, P1, K0 + 2 * ls, V0 + 2 * ls, n_pad, tok0, n_real, tid, u, kvproj_first_x(W, l2, x2, wave));
+    kv_project_tile_x(W, l2, x2, T, P1, K0 + 4 * ls, V0 + 4 * ls, n_pad, tok0, n_real, tid, u, kvproj_first_x(W, l2, x2, wave));
+}
+
+void launch_kv_hoist_x(const float* W, const XLayerW* L3, const XLayerX* X3, const float* feat, const uint8_t* fvalid, int G, int n_tok,
+                       int n_pad, float* K, float* VT, float* kbias, hipStream_t s) {
+    dim3 grid(n_pad / TM, G);
+    hipLaunchKernelGGL(k_kv_hoist_x, grid, dim3(NTHREADS), TM * LDT * sizeof(float) + PLANES_BYTES, s, W, L3[0], L3[1], L3[2], X3[0],
+                       X3[1], X3[2], feat, fvalid, n_tok, n_pad, K, VT, kbias);
 }
 
 hipError_t configure_stepx_kernel() {
