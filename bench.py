@@ -26,10 +26,26 @@ from trafficbots_amd.config import load_model_config  # noqa: E402
 B_PER_GPU, N_AGENT, N_PL, N_TL, STEP_END = 32, 64, 256, 40, 90
 H = 128
 PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak
+# fabric-side bytes per fused launch from the PMC pass of this round (profiles/r01_rocprof_xdl.txt: FETCH_SIZE 41 061 KiB x 2, the
+# gfx950 correction of the guide, at the headline shape); collected with rocprofv3 --pmc in its own run, not at bench time
+TRAFFIC_BYTES_PER_LAUNCH_B32 = 2 * 41061 * 1024
 
 
 def flops_step_a(a, p, t):  # SURVEY 8(d) split: as2pl + as2tl + interaction K/V projections + agent encoder
     return 60 * a * H * H + 12 * a * H * (p + t) + 2 * a * (11 * 32 + 32 * 32)
+
+
+def load_path(k_us):
+    """Bytes every workgroup pulls through its CU's vector-memory path per fused launch (weights are streamed once per
+    16-agent tile, K/V once per head) against the ~64 B/clk/CU the L1 can fill (MI355X_MICROARCH.md: L2 34.5 TB/s / 256 CUs)."""
+    h = 128
+    w_bytes = 67 * h * h * 4          # 134 A H^2 flops per agent = 67 H^2 weights, 4 B each as an fp16 pair
+    pad = lambda n: (n + 31) // 32 * 32
+    kv_bytes = 3 * 2 * (pad(N_PL) + pad(N_TL) + pad(N_AGENT)) * h * 4
+    clk = 2.1e9                       # s_memtime ticks per second observed on this kernel
+    per_clk = (w_bytes + kv_bytes) / (k_us * 1e-6 * clk)
+    return {"bytes_per_workgroup_launch": w_bytes + kv_bytes, "weights": w_bytes, "kv": kv_bytes, "achieved_B_per_clk_per_CU": per_clk,
+            "peak_B_per_clk_per_CU": 64.0, "frac": per_clk / 64.0}
 
 
 def flops_step_c(a):  # interaction attention/FFN + GRU + add_goal + add_latent + one action-head branch
@@ -224,7 +240,7 @@ def main():
             "metric": "rollout scene-steps/sec (64 agents, 90 executed = 10 teacher-forced + 80 free steps)",
             "value": value, "unit": "scene-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f32 (fp16-pair operands on the XDL MFMA, fp32 accumulate; fp32 everywhere else)", "data": "synthetic",
             "config": {"workload": "BASELINE.json configs[1]: 32 synthetic WOMD-shaped scenes per GPU, 64 agents, 256 polylines, "
                                    "40 TL stop points, K=1, 90-step closed-loop rollout, fp32, random-init weights",
                        "scenes_per_gpu": B_PER_GPU, "n_agent": N_AGENT, "n_pl": N_PL, "n_tl": N_TL, "sim_steps": STEP_END,
@@ -232,11 +248,16 @@ def main():
             "agent_steps_per_s": value * N_AGENT,
             "encode_ms": encode_ms,
             "kernel_us": {"k_step_fused": k_us, "edge_launches_ms": tm["edge_ms"], "prologue_ms": tm["prologue_ms"]},
-            "roofline": {"bound": "mfma", "kernel": "tb::k_step (C(t)+A(t+1), one launch per simulation step)", "achieved": achieved,
-                         "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+            "roofline": {"bound": "mfma", "kernel": "tb::k_step_x (C(t)+A(t+1), one launch per simulation step)", "achieved": achieved,
+                         "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
+                         "traffic": TRAFFIC_BYTES_PER_LAUNCH_B32 if (N_AGENT, N_PL, N_TL, B_PER_GPU) == (64, 256, 40, 32) else None,
+                         "traffic_unit": "bytes per launch (rocprofv3 --pmc FETCH_SIZE, profiles/r01_rocprof_xdl.txt)",
                          "flops_per_launch": fl, "avg_launch_us": k_us,
-                         "note": "algorithmic flops = 176.1 MFLOP per scene-step (SURVEY 8(d)) x 32 scenes per launch; 128 workgroups "
-                                 "(one per 16 agents) occupy 128 of 256 CUs at this batch size"},
+                         "note": "algorithmic fp32 flops = 176.1 MFLOP per scene-step (SURVEY 8(d)) x 32 scenes per launch, priced against "
+                                 "the fp32-MFMA peak of the fp32 formulation; the kernel issues them as 3 fp16 MFMAs per product on the XDL "
+                                 "pipe (fp32-accurate, DESIGN.md 4) and is bound by the per-CU vector-load path, see load_path; 128 "
+                                 "workgroups (one per 16 agents) occupy 128 of 256 CUs at this batch size",
+                         "load_path": load_path(k_us)},
             "checks": dict(finite=finite, **red),
             "two_batches_in_flight": two_stream,
         }

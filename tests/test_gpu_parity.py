@@ -248,28 +248,30 @@ def test_stepwise_forward_equals_fused_rollout():
         wm.forward()  # past step_end
 
 
-def test_eight_wave_step_kernel_matches_default(monkeypatch):
-    """`TB_STEP_KERNEL=fp32w8` selects k_step8 (512-thread workgroups, tb_step8_kernels.hip): same arithmetic per agent,
-    different split over waves (two partial softmaxes merged, two accumulator chains per tile) -> equal flags,
-    trajectories within the closed-loop tolerance of the default kernel."""
+def test_fp32_mfma_step_kernels_match_default(monkeypatch):
+    """The default step kernel (k_step_x: fp16-pair operands on the XDL pipe, fp32 accumulate) against the two fp32-MFMA
+    kernels kept selectable with TB_STEP_KERNEL (k_step, and k_step8 on 512-thread workgroups): same arithmetic per
+    agent up to rounding order -> equal flags, trajectories within the closed-loop tolerance."""
     from trafficbots_amd import synth
 
     step_end, k = 50, 2
     sd = synth.make_state_dict(11)
     batch = synth.make_batch(9100, 3, n_agent=40, n_pl=96, n_tl=20, p_late_spawn=0.2, p_invalid_agent=0.2, pos_range=140.0)
     eps = torch.from_numpy(synth.make_latent_noise(11, 3 * k, 40)).cuda()
-    outs = []
-    for waves in ("fp32", "fp32w8"):
-        monkeypatch.setenv("TB_STEP_KERNEL", waves)
+    outs = {}
+    for kern in ("xdl", "fp32", "fp32w8"):
+        monkeypatch.setenv("TB_STEP_KERNEL", kern)
         wm = _engine({"time_step_end": step_end, "n_joint_future": k}, sd)
-        outs.append(wm.test_step(batch, latent_eps=eps, generator=torch.Generator(device="cuda").manual_seed(4))["rollout_buffer"])
-    a, b = outs
-    assert torch.equal(a.valid, b.valid)
-    assert torch.equal(a.violations["dest_reached"], b.violations["dest_reached"])
-    assert torch.equal(a.violations["outside_map"], b.violations["outside_map"])
-    err = (a.preds - b.preds).abs().max().item()
-    REPORT["k_step8_vs_k_step_max_abs"] = err
-    assert err <= 1e-4, err
+        outs[kern] = wm.test_step(batch, latent_eps=eps, generator=torch.Generator(device="cuda").manual_seed(4))["rollout_buffer"]
+    a = outs["xdl"]
+    for kern in ("fp32", "fp32w8"):
+        b = outs[kern]
+        assert torch.equal(a.valid, b.valid)
+        assert torch.equal(a.violations["dest_reached"], b.violations["dest_reached"])
+        assert torch.equal(a.violations["outside_map"], b.violations["outside_map"])
+        err = (a.preds - b.preds).abs().max().item()
+        REPORT[f"k_step_x_vs_{kern}_max_abs"] = err
+        assert err <= 1e-4, (kern, err)
 
 
 def test_empty_and_bad_inputs_fail_loudly():

@@ -224,7 +224,7 @@ tb::EncMlpW add_enc(Arena& a, Stage& s, const std::string& p, int attr_dim) {
 // ---------------------------------------------------------------------------------------------------
 extern "C" {
 
-const char* tb_version(void) { return "trafficbots_hip 0.1 (gfx950, fp32 MFMA 16x16x4)"; }
+const char* tb_version(void) { return "trafficbots_hip 0.2 (gfx950, fp16-pair XDL MFMA 16x16x32 with fp32 accumulate; fp32 MFMA 16x16x4 kernels selectable)"; }
 
 static void step_launch(const tb_ctx* ctx, const tb::RolloutP& p, int t, int do_c, int do_a, hipStream_t s) {
     if (ctx->step_kernel == 2)

@@ -24,7 +24,7 @@ struct tb_ctx {
     tb::PolicyWX px;
     tb::EncoderW ew;
     bool finalized = false;
-    int step_kernel = 0;  // 0: k_step (fp32 MFMA, 4 waves)  1: k_step8 (fp32 MFMA, 8 waves)  2: k_step_x (split-bf16 XDL GEMMs); TB_STEP_KERNEL overrides
+    int step_kernel = 2;  // 2: k_step_x (fp16-pair XDL MFMA, default)  0: k_step (fp32 MFMA)  1: k_step8 (fp32 MFMA, 8 waves); TB_STEP_KERNEL overrides
     // workspace
     char* d_ws = nullptr;
     size_t ws_bytes = 0;
