@@ -460,8 +460,10 @@ __device__ __forceinline__ void xattn_layer_x(const float* __restrict__ W, const
     const xhalf* b1 = P1 + m * LDP + kq * 8;
     const xhalf* b2 = P2 + m * LDP + kq * 8;
     AttnPreX apre;
-    attention_prefetch_x(apre, Kmat, VT, keybias, n_key_pad, kstart, wave, lane);
     layernorm_planes<LNLDS>(X, LDT, P1, lnblk, lnblk + 128, tid);
+    // (after the LayerNorm: the vector-memory queue is still draining this layer's Q weights, a load issued earlier would
+    // block the wave in front of the LayerNorm arithmetic instead of running beside it)
+    attention_prefetch_x(apre, Kmat, VT, keybias, n_key_pad, kstart, wave, lane);
     __syncthreads();
     TB_XSTAMP(17);
     WUnitX u2;

@@ -87,8 +87,14 @@ __device__ __forceinline__ void step_tile_map(int& n, int& rt) {
 // geometry + flags) as ONE burst: every global load is issued before the first LDS store, so the launch pays one cold
 // round trip here instead of one per tile (the compiler otherwise reuses one register quad and waits after each load).
 template <int NT>
-__device__ __forceinline__ void step_load_c_inputs(const RolloutP& p, int n, int row0, int tid, float* X, float* Hs, float* H1,
-                                                   float* H2, float* GP, float* LP, float* DG, int* dflag) {
+struct CInputs {
+    static constexpr int PER = (TM * 32) / NT;  // float4 per thread per tile: 2 (256 threads) or 1 (512)
+    f32x4 v[6][PER], g[2];
+    int df;
+};
+
+template <int NT>
+__device__ __forceinline__ void c_inputs_issue(const RolloutP& p, int n, int row0, int tid, CInputs<NT>& c) {
     const size_t base_row = (size_t)n * p.a_pad + row0;
     const float* src[6] = {p.x_mid + base_row * H,
                            p.hidden + (((size_t)0 * p.n_inst + n) * p.a_pad + row0) * H,
@@ -96,38 +102,48 @@ __device__ __forceinline__ void step_load_c_inputs(const RolloutP& p, int n, int
                            p.hidden + (((size_t)2 * p.n_inst + n) * p.a_pad + row0) * H,
                            p.goal_pre + base_row * H,
                            p.lat_pre + base_row * H};
+#pragma unroll
+    for (int s = 0; s < 6; ++s)
+#pragma unroll
+        for (int i = 0; i < CInputs<NT>::PER; ++i) {
+            const int idx = tid + i * NT;
+            c.v[s][i] = ldg4(src[s] + (size_t)(idx >> 5) * H + (idx & 31) * 4);
+        }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int idx = tid + i * NT;
+        c.g[i] = idx < TM * 20 ? ldg4(p.dest_geo + (base_row * 20 + idx) * 4) : splat(0.f);
+    }
+    c.df = tid < TM ? p.dest_flag[base_row + tid] : 0;
+}
+
+template <int NT>
+__device__ __forceinline__ void c_inputs_commit(int tid, const CInputs<NT>& c, float* X, float* Hs, float* H1, float* H2, float* GP,
+                                                float* LP, float* DG, int* dflag) {
     float* dst[6] = {X, Hs, H1, H2, GP, LP};
-    constexpr int PER = (TM * 32) / NT;  // float4 per thread per tile: 2 (256 threads) or 1 (512)
-    f32x4 v[6][PER], g[2];
-    int df = 0;
-    TB_SCHED_FENCE();
 #pragma unroll
     for (int s = 0; s < 6; ++s)
 #pragma unroll
-        for (int i = 0; i < PER; ++i) {
+        for (int i = 0; i < CInputs<NT>::PER; ++i) {
             const int idx = tid + i * NT;
-            v[s][i] = ldg4(src[s] + (size_t)(idx >> 5) * H + (idx & 31) * 4);
+            st4(dst[s] + (idx >> 5) * LDT + (idx & 31) * 4, c.v[s][i]);
         }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int idx = tid + i * NT;
-        g[i] = idx < TM * 20 ? ldg4(p.dest_geo + (base_row * 20 + idx) * 4) : splat(0.f);
+        if (idx < TM * 20) st4(DG + idx * 4, c.g[i]);
     }
-    if (tid < TM) df = p.dest_flag[base_row + tid];
+    if (tid < TM) dflag[tid] = c.df;
+}
+
+template <int NT>
+__device__ __forceinline__ void step_load_c_inputs(const RolloutP& p, int n, int row0, int tid, float* X, float* Hs, float* H1,
+                                                   float* H2, float* GP, float* LP, float* DG, int* dflag) {
+    CInputs<NT> c;
     TB_SCHED_FENCE();
-#pragma unroll
-    for (int s = 0; s < 6; ++s)
-#pragma unroll
-        for (int i = 0; i < PER; ++i) {
-            const int idx = tid + i * NT;
-            st4(dst[s] + (idx >> 5) * LDT + (idx & 31) * 4, v[s][i]);
-        }
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int idx = tid + i * NT;
-        if (idx < TM * 20) st4(DG + idx * 4, g[i]);
-    }
-    if (tid < TM) dflag[tid] = df;
+    c_inputs_issue<NT>(p, n, row0, tid, c);
+    TB_SCHED_FENCE();
+    c_inputs_commit<NT>(tid, c, X, Hs, H1, H2, GP, LP, DG, dflag);
 }
 
 // ---- per-agent simulator epilogue of C(t): dynamics, teacher forcing, rule checks, kill, navigator, buffer writes.
@@ -228,6 +244,129 @@ __device__ __forceinline__ void step_epilogue(const RolloutP& p, int t, int n, i
         p.outside[si] = outside;
         rst[tid].st[0] = cur.x; rst[tid].st[1] = cur.y; rst[tid].st[2] = cur.z; rst[tid].st[3] = cur.w;
         rowvalid[tid] = valid;
+        // RolloutBuffer.add (buffer.py:39-70)
+        const int s = t - p.step_start;
+        const size_t oi = ((size_t)n * p.n_agent + row) * p.n_step_out + s;
+        st4(p.preds + oi * 4, pred);
+        p.o_valid[oi] = valid_old;
+        p.o_override[oi] = ovr;
+        p.o_outside[oi] = outside;
+        p.o_outside_this[oi] = out_this;
+        p.o_dest_reached[oi] = dreached;
+        p.o_dest_reached_this[oi] = dr_this;
+        p.o_action_logp[oi] = alp;
+    }
+}
+
+// ---- the same epilogue spread over the whole 256-thread workgroup: 16 lanes per agent.  Every lane of a group evaluates the
+// agent's dynamics (uniform inside the group, free on a SIMD), the 20 destination nodes are split over the lanes and
+// OR-reduced with a ballot, lane 0 of the group writes.  All global loads are issued up front (clamped indices where the
+// reference reads nothing), so the stage pays one memory round trip instead of a chain of dependent ones.
+__device__ __forceinline__ void step_epilogue16(const RolloutP& p, int t, int n, int b, int row0, int n_real, int tid,
+                                                const StepSmall& sm, const float* DG) {
+    const PolicyW& pw = p.pw;
+    const float* W = p.W;
+    RowSt* rst = sm.rst; float* ubuf = sm.ubuf; uint8_t* rowvalid = sm.rowvalid; uint8_t* gvalid = sm.gvalid;
+    const int* rtype = sm.rtype; const int* dflag = sm.dflag;
+    const int a = tid >> 4, sub = tid & 15, lane = tid & 63;
+    const bool real = a < n_real;
+    const int row = row0 + a;
+    const int rowc = min(row, p.n_agent - 1);
+    const size_t si = (size_t)n * p.a_pad + row;
+    const bool in_hist = t < p.n_hist;
+    const size_t hi = ((size_t)b * p.n_hist + min(t, p.n_hist - 1)) * p.n_agent + rowc;
+    // ---- loads
+    const uint8_t killed0 = p.killed[si], outside0 = p.outside[si], dreached0 = p.dest_reached[si];
+    const uint8_t ovr0 = p.tf_mask[hi], gtv0 = p.hist_valid[hi];
+    const f32x4 hst = ldg4(p.hist_state + hi * 4);
+    const f32x4 hax = f32x4{p.hist_vel[hi * 2], p.hist_vel[hi * 2 + 1], p.hist_acc[hi], p.hist_yaw_rate[hi]};
+    const f32x4 bd = ldg4(p.map_boundary + (size_t)b * 4);
+    const int ty = rtype[a];
+    const bool valid_old = rowvalid[a] != 0;
+    const bool have = valid_old && ty >= 0;
+    const f32x4 st = f32x4{rst[a].st[0], rst[a].st[1], rst[a].st[2], rst[a].st[3]};
+    const float u0 = ubuf[a * 2 + 0], u1 = ubuf[a * 2 + 1];
+    const bool gv0 = gvalid[a] != 0;
+    const int dfl = dflag[a];
+    // ---- Dynamics.update + MultiPathPP (dynamics.py:74-119,194-228); tanh-bounded action, midpoint unicycle
+    float acc_ = 0.f, yr_ = 0.f;
+    if (have) {
+        acc_ = fmul_(tanhf(u0), pw.max_acc[ty]);
+        yr_ = fmul_(tanhf(u1), pw.max_yaw_rate[ty]);
+    }
+    const float half_dt = 0.5f * pw.dt;
+    const float v_t = fadd_(st.w, fmul_(half_dt, acc_));
+    const float th_t = fadd_(st.z, fmul_(half_dt, yr_));
+    float sn, cs;
+    sincosf(th_t, &sn, &cs);
+    f32x4 pred;
+    pred.x = fadd_(st.x, fmul_(pw.dt, fmul_(v_t, cs)));
+    pred.y = fadd_(st.y, fmul_(pw.dt, fmul_(v_t, sn)));
+    pred.z = fadd_(st.z, fmul_(pw.dt, yr_));
+    pred.w = fadd_(st.w, fmul_(pw.dt, acc_));
+    if (!have) pred = splat(0.f);
+    float alp = 0.f;
+    if (valid_old) {
+        for (int d = 0; d < 2; ++d) {
+            const float ls = (ty >= 0) ? W[pw.head_log_std[ty] + d] : 0.f;
+            alp += -logf(expf(ls)) - 0.9189385332046727f;
+        }
+    }
+    // ---- teacher forcing / spawn (dynamics.py:132-149)
+    f32x4 cur = pred;
+    bool valid = valid_old;
+    bool killed = killed0 != 0;
+    const uint8_t ovr = in_hist ? ovr0 : 0;
+    const bool gt_valid = in_hist && gtv0 != 0;
+    const bool forced = ovr && !killed;
+    if (forced) {
+        valid = true;
+        cur = hst;
+    }
+    // ---- rule checks on the post-override state (traffic_rule_checker.py:101-119,364-410)
+    const bool out_this = valid && ((cur.x > bd.y) || (cur.x < bd.x) || (cur.y > bd.w) || (cur.y < bd.z));
+    const bool outside = (outside0 != 0) || out_this;
+    bool dreached = dreached0 != 0;
+    bool dr_this;
+    {
+        const bool is_lane = (dfl & 1) != 0, is_edge = (dfl & 2) != 0;
+        const float thresh = is_edge ? fmul_(50.f, fadd_(1.f, -0.8f)) : 50.f;
+        float hs, hc;
+        sincosf(cur.z, &hs, &hc);
+        bool pos = false, rot = false;
+#pragma unroll
+        for (int k = sub; k < 20; k += 16) {
+            const f32x4 g = lds4(DG + (a * 20 + k) * 4);
+            const float dx = fadd_(cur.x, -g.x), dy = fadd_(cur.y, -g.y);
+            const float dist = sqrtf(fadd_(fmul_(dx, dx), fmul_(dy, dy)));
+            pos |= dist < thresh;
+            rot |= fadd_(fmul_(hc, g.z), fmul_(hs, g.w)) > 0.8660254037844387f;
+        }
+        const int sh = (lane >> 4) * 16;
+        const bool pos_r = ((__ballot(pos) >> sh) & 0xFFFFull) != 0;
+        const bool rot_r = ((__ballot(rot) >> sh) & 0xFFFFull) != 0;
+        dr_this = !dreached && valid && ((is_lane && pos_r && rot_r) || (is_edge && pos_r));
+        dreached |= dr_this;
+    }
+    // kill agents that left the map unless ground truth is still valid (dynamics.py:161-167); navigator (goal_manager.py:155-162)
+    const bool mk = out_this && !gt_valid;
+    killed |= mk;
+    valid = valid && !mk;
+    const bool gv = gv0 && valid && !dreached;
+    if (sub == 0 && real) {
+        if (forced) {
+            st4(p.aux + si * 4, hax);
+            rst[a].aux[0] = hax.x; rst[a].aux[1] = hax.y; rst[a].aux[2] = hax.z; rst[a].aux[3] = hax.w;
+        }
+        st4(p.state + si * 4, cur);
+        p.valid[si] = valid;
+        p.vbias[si] = valid ? 0.f : -INFINITY;
+        p.killed[si] = killed;
+        p.goal_valid[si] = gv;
+        p.dest_reached[si] = dreached;
+        p.outside[si] = outside;
+        rst[a].st[0] = cur.x; rst[a].st[1] = cur.y; rst[a].st[2] = cur.z; rst[a].st[3] = cur.w;
+        rowvalid[a] = valid;
         // RolloutBuffer.add (buffer.py:39-70)
         const int s = t - p.step_start;
         const size_t oi = ((size_t)n * p.n_agent + row) * p.n_step_out + s;
