@@ -100,6 +100,10 @@ typedef struct tb_rollout_io {
     int32_t tap_step;              /* absolute step whose policy feature to capture, or -1 */
     float* tap_policy_feature;     /* [N,A,128] */
     float* tap_agent_feature;      /* [N,A,128] */
+    /* optional (NULL to skip): the post-override simulator state of every step, i.e. what the reference passes to
+     * TrafficRuleChecker.check (waymo_motion.py:311) -- input of tb_rule_checks */
+    float* check_state;            /* [N,A,S,4] */
+    uint8_t* check_valid;          /* [N,A,S]   */
 } tb_rollout_io;
 
 /* Replaces: WaymoMotion.rollout (+ per-step WaymoMotion.forward, TrafficBots.forward, ActionHead,
@@ -162,6 +166,38 @@ int tb_encode_scene(tb_ctx* ctx, const tb_encode_io* io, tb_stream stream);
  * this query, which synchronises on the last event). */
 int tb_set_timing(tb_ctx* ctx, int enable);
 int tb_get_timing(tb_ctx* ctx, float* out4);
+
+/* Flag-gated traffic-rule checks over a recorded rollout.
+ * Replaces: TrafficRuleChecker._check_collided / _check_run_road_edge / _check_run_red_light / _check_passive and their
+ * accumulation in TrafficRuleChecker.check (src/utils/traffic_rule_checker.py:122-335, 412-516) for
+ * traffic_rule_checker.enable_check_* = True (configs/model/traffic_bots.yaml:240-244).  The checks are functions of the
+ * per-step state only and never feed back into the simulation, so they are evaluated once per rollout on
+ * tb_rollout_io.check_state / check_valid.  A disabled check returns zeros in both of its arrays, as the reference does.
+ * All outputs [N,A,S] uint8; scene tensors un-repeated ([B, ...], instance n -> scene n / K). */
+typedef struct tb_rule_io {
+    int32_t n_scene, k_futures, n_agent, n_pl, n_tl, n_step;
+    int32_t enable_check_collided, enable_check_run_road_edge, enable_check_run_red_light, enable_check_passive;
+    const float* check_state;      /* [N,A,S,4] */
+    const uint8_t* check_valid;    /* [N,A,S]   */
+    const int32_t* agent_type;     /* [B,A]  0 veh, 1 ped, 2 cyc */
+    const float* agent_size;       /* [B,A,3] */
+    const uint8_t* map_valid;      /* [B,P,20] */
+    const int32_t* map_type;       /* [B,P] */
+    const float* map_pos;          /* [B,P,20,2] */
+    const float* map_dir;          /* [B,P,20,2] */
+    const uint8_t* tl_valid;       /* [B,NH,T] */
+    const int32_t* tl_state;       /* [B,NH,T]  0 unknown, 1 stop, 2 caution, 3 go, 4 flashing */
+    const float* tl_pos;           /* [B,NH,T,2] */
+    uint8_t* collided;
+    uint8_t* collided_this_step;
+    uint8_t* run_road_edge;
+    uint8_t* run_road_edge_this_step;
+    uint8_t* run_red_light;
+    uint8_t* run_red_light_this_step;
+    uint8_t* passive;
+    uint8_t* passive_this_step;
+} tb_rule_io;
+int tb_rule_checks(tb_ctx* ctx, const tb_rule_io* io, tb_stream stream);
 
 #ifdef __cplusplus
 }

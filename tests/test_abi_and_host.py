@@ -70,9 +70,11 @@ def test_config_resolver_and_unsupported_branches():
         resolve_interpolations({"a": "${.b}", "b": "${.a}"})
     assert load_model_config()["model"]["tf_cfg"]["n_head"] == DEFAULT_MODEL_CONFIG["model"]["tf_cfg"]["n_head"]
     for key, val in (("model.goal_manager.goal_attr_mode", "goal_xy"), ("model.resample_latent", True),
-                     ("traffic_rule_checker.enable_check_collided", True), ("model.interaction_first", False)):
+                     ("model.interaction_first", False)):
         with pytest.raises(NotImplementedError):
             load_model_config(overrides={key: val})
+    # the flag-gated traffic-rule checks are built (tb_rule_checks): accepted
+    assert load_model_config(overrides={"traffic_rule_checker.enable_check_collided": True})["traffic_rule_checker"]["enable_check_collided"]
 
 
 def test_state_dict_spec_matches_reference_keys():

@@ -274,6 +274,49 @@ def test_fp32_mfma_step_kernels_match_default(monkeypatch):
         assert err <= 1e-4, (kern, err)
 
 
+@pytest.mark.parametrize("name", ["rules_k2", "rules_passive"])
+def test_rule_checks_kernel(name):
+    """SURVEY 8(f)-1, `tb_rule_checks`: (1) on the (valid, state) pairs the REFERENCE handed to TrafficRuleChecker.check the
+    HIP kernels must return the reference's flags exactly (compare work only, same operand order); (2) end to end -- flags
+    enabled in the config, checks evaluated on the HIP rollout's own states -- the flags may differ from the golden only where
+    a trajectory difference of ~1e-5 m moves a box across a threshold: at most 0.5 % of the agent-steps."""
+    from trafficbots_amd.runtime import RULE_KEYS, scene_from_batch
+
+    g, meta = load_golden(name)
+    cfg, sd, batch, eps = golden_inputs(meta)
+    k = meta["k"]
+    flags = {f"enable_check_{c}": True for c in ("collided", "run_road_edge", "run_red_light", "passive")}
+    wm = _engine({"time_step_end": meta["time_step_end"], "n_joint_future": k, "traffic_rule_checker": flags}, sd)
+    scene = scene_from_batch(batch, wm.device)
+    res = wm.engine.rule_checks(scene, torch.from_numpy(g["check_state"]).cuda(), torch.from_numpy(g["check_valid"]).cuda(), k, flags)
+    torch.cuda.synchronize()
+    n_true = 0
+    for key in RULE_KEYS:
+        ref = np.transpose(g[key], (0, 2, 1, 3)).reshape(res[key].shape)
+        got = res[key].cpu().numpy().astype(bool)
+        assert np.array_equal(got, ref), (key, int((got != ref).sum()), int(ref.sum()))
+        n_true += int(ref.sum())
+    assert n_true > 0
+    # disabled checks return zeros (traffic_rule_checker.py:430, 438, 456, 472)
+    off = wm.engine.rule_checks(scene, torch.from_numpy(g["check_state"]).cuda(), torch.from_numpy(g["check_valid"]).cuda(), k,
+                                {"enable_check_collided": True})
+    assert int(off["run_road_edge"].sum()) == 0 and int(off["passive"].sum()) == 0 and int(off["run_red_light_this_step"].sum()) == 0
+    assert np.array_equal(off["collided"].cpu().numpy(), res["collided"].cpu().numpy())
+    # end to end
+    gs = torch.from_numpy(np.transpose(g["goal_sample"], (0, 2, 1)).copy())
+    out = wm.test_step(batch, latent_eps=torch.from_numpy(eps).cuda(), goal_sample=gs)
+    buf = out["rollout_buffer"]
+    torch.cuda.synchronize()
+    assert torch.equal(buf.valid.cpu(), torch.from_numpy(g["valid"]))
+    rep = {}
+    for key in RULE_KEYS:
+        got = buf.violations[key].cpu().numpy()
+        diff = int((got != g[key]).sum())
+        rep[key] = {"true_ref": int(g[key].sum()), "mismatch": diff}
+        assert diff <= 0.005 * got.size, (key, diff)
+    REPORT[name] = rep
+
+
 def test_empty_and_bad_inputs_fail_loudly():
     from trafficbots_amd import synth
     from trafficbots_amd.waymo_motion import WaymoMotion

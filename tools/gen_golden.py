@@ -64,11 +64,32 @@ CASES = {
         base_seed=6000, n_scene=1, k=6, weight_seed=7, time_step_end=90,
         scene=dict(n_agent=64, n_pl=256, n_tl=40), tap_steps=[], fp64=False, store_feats=False,
     ),
+    # the four flag-gated traffic-rule checks on dense scenes (agents, polylines and stop points inside
+    # +-25 m so that collisions, road-edge crossings, red-light runs and passive agents actually occur); also stores the
+    # (valid, state) pairs the reference hands to TrafficRuleChecker.check
+    "rules_k2": dict(
+        base_seed=7000, n_scene=2, k=2, weight_seed=9, time_step_end=60,
+        scene=dict(n_agent=24, n_pl=40, n_tl=40, p_tl_valid=0.6, pos_range=25.0, p_invalid_agent=0.1, p_late_spawn=0.2),
+        tap_steps=[], fp64=False, store_feats=False, rule_flags=True,
+    ),
 }
+
+CASES["rules_passive"] = dict(
+    base_seed=7500, n_scene=2, k=1, weight_seed=9, time_step_end=70,
+    scene=dict(n_agent=12, n_pl=60, n_tl=40, p_tl_valid=0.3, pos_range=40.0, spd_max=1.0),
+    tap_steps=[], fp64=False, store_feats=False, rule_flags=True,
+)
+
+RULE_KEYS = ["collided", "collided_this_step", "run_road_edge", "run_road_edge_this_step", "run_red_light",
+             "run_red_light_this_step", "passive", "passive_this_step"]
 
 
 def run_reference(case: dict, dtype=torch.float32) -> dict:
-    cfg = load_model_config(overrides={"time_step_end": case["time_step_end"], "n_joint_future": case["k"]})
+    over = {"time_step_end": case["time_step_end"], "n_joint_future": case["k"]}
+    if case.get("rule_flags"):
+        over["traffic_rule_checker"] = {"enable_check_collided": True, "enable_check_run_road_edge": True,
+                                        "enable_check_run_red_light": True, "enable_check_passive": True}
+    cfg = load_model_config(overrides=over)
     sc = case["scene"]
     torch.set_default_dtype(torch.float32)
     model = ref_shim.build_reference(cfg, n_agent=sc["n_agent"], n_pl=sc["n_pl"], n_tl=sc.get("n_tl", 40))
@@ -131,11 +152,29 @@ def run_reference(case: dict, dtype=torch.float32) -> dict:
                     taps[f"tap{s}/state_in"] = model.dynamics.agent_state.clone()
 
             h = model.model.register_forward_hook(hook, with_kwargs=True)
+            check_in = {"valid": [], "state": []}
+            if case.get("rule_flags"):
+                from utils.traffic_rule_checker import TrafficRuleChecker
+
+                orig_check = TrafficRuleChecker.check
+
+                def spy_check(self, step, as_valid, as_state):
+                    check_in["valid"].append(as_valid.clone())
+                    check_in["state"].append(as_state.clone())
+                    return orig_check(self, step, as_valid, as_state)
+
+                TrafficRuleChecker.check = spy_check
             buf, goal_sample, goal_log_probs = model.joint_future_pred(
                 batch=batch, input_feature_dict=feats, latent=latent_prior, goal=goal_pred,
                 goal_valid=goal_valid, require_vis_dict=False,
             )
             h.remove()
+            if case.get("rule_flags"):
+                TrafficRuleChecker.check = orig_check
+                out["check_valid"] = torch.stack(check_in["valid"], 2)  # [N,A,S]
+                out["check_state"] = torch.stack(check_in["state"], 2)  # [N,A,S,4]
+                for k in RULE_KEYS:
+                    out[k] = buf.violations[k]
     finally:
         tdn._standard_normal = orig_std_normal
         torch.set_default_dtype(torch.float32)
@@ -190,7 +229,7 @@ def main() -> None:
             for k in feats:
                 save[k] = r32[k]
         for k, v in r32.items():
-            if k.startswith("tap"):
+            if k.startswith("tap") or k.startswith("check_") or k in RULE_KEYS:
                 save[k] = v
         if case["fp64"]:
             r64 = run_reference(case, torch.float64)

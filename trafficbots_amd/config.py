@@ -276,7 +276,4 @@ def check_supported(cfg: Dict[str, Any]) -> None:
     for k in ("veh", "cyc", "ped"):
         need(dy[k]["_target_"].endswith("MultiPathPP"), f"dynamics.{k}._target_ != MultiPathPP")
         need(not dy[k].get("disable_neg_spd", False), f"dynamics.{k}.disable_neg_spd")
-    trc = cfg["traffic_rule_checker"]
-    for k, v in trc.items():
-        if k.startswith("enable_check_"):
-            need(not v, f"traffic_rule_checker.{k}=True (SURVEY 8(f) 'next')")
+    # traffic_rule_checker.enable_check_*: all four flag-gated checks are built (tb_rule_checks)

@@ -28,6 +28,8 @@ hipError_t configure_stepx_kernel();
 void launch_kv_hoist_x(const float* W, const XLayerW* L3, const XLayerX* X3, const float* feat, const uint8_t* fvalid, int G, int n_tok,
                        int n_pad, float* K, float* VT, float* kbias, hipStream_t s);
 int run_encode(struct ::tb_ctx* ctx, const tb_encode_io* io, hipStream_t s);
+int run_rule_checks(const tb_rule_io* io, int n_hist, int step_start, uint8_t* raw_ws, hipStream_t s);
+hipError_t configure_rule_kernels();
 }  // namespace tb
 
 // ---------------------------------------------------------------------------------------------------
@@ -270,6 +272,7 @@ void tb_destroy(tb_ctx* ctx) {
     if (!ctx) return;
     if (ctx->d_arena) (void)hipFree(ctx->d_arena);
     if (ctx->d_ws) (void)hipFree(ctx->d_ws);
+    if (ctx->d_rule_ws) (void)hipFree(ctx->d_rule_ws);
     for (auto e : ctx->ev) (void)hipEventDestroy(e);
     delete ctx;
 }
@@ -289,6 +292,7 @@ int tb_finalize_weights(tb_ctx* ctx, tb_stream stream) {
     TB_HIP(ctx, tb::configure_rollout_kernels());
     TB_HIP(ctx, tb::configure_step8_kernel());
     TB_HIP(ctx, tb::configure_stepx_kernel());
+    TB_HIP(ctx, tb::configure_rule_kernels());
     Arena a;
     Stage s{ctx};
     tb::PolicyW& pw = ctx->pw;
@@ -548,6 +552,8 @@ static int rollout_setup(tb_ctx* ctx, const tb_rollout_io* io, tb::RolloutP& p) 
     p.o_dest_reached_this = io->dest_reached_this_step;
     p.o_action_logp = io->action_log_probs;
     p.o_latent_logp = io->latent_log_prob;
+    p.o_check_state = io->check_state;
+    p.o_check_valid = io->check_valid;
     p.tap_step = io->tap_step;
     p.tap_policy_feature = io->tap_policy_feature;
     p.tap_agent_feature = io->tap_agent_feature;
@@ -613,6 +619,35 @@ extern "C" int tb_rollout(tb_ctx* ctx, const tb_rollout_io* io, tb_stream stream
     // ---- final simulator state
     if (io->final_state || io->final_valid || io->final_hidden)
         tb::launch_rollout_final(p, io->final_state, io->final_valid, io->final_hidden, s);
+    TB_HIP(ctx, hipGetLastError());
+    return 0;
+}
+
+// ---- flag-gated traffic-rule checks over a recorded rollout (tb_rules_kernels.hip) ----------------------------------
+extern "C" int tb_rule_checks(tb_ctx* ctx, const tb_rule_io* io, tb_stream stream_) {
+    if (!ctx || !io) return 1;
+    TB_HIP(ctx, hipSetDevice(ctx->device));
+    if (io->n_scene <= 0 || io->k_futures <= 0 || io->n_agent <= 0 || io->n_pl <= 0 || io->n_tl <= 0 || io->n_step <= 0)
+        return tb_fail(ctx, "tb_rule_checks: empty dimension");
+    if (io->n_agent > 256) return tb_fail(ctx, "tb_rule_checks: n_agent %d > 256 not supported", io->n_agent);
+    const void* need[] = {io->check_state, io->check_valid, io->agent_type, io->agent_size, io->map_valid, io->map_type, io->map_pos,
+                          io->map_dir, io->tl_valid, io->tl_state, io->tl_pos, io->collided, io->collided_this_step,
+                          io->run_road_edge, io->run_road_edge_this_step, io->run_red_light, io->run_red_light_this_step,
+                          io->passive, io->passive_this_step};
+    for (const void* q : need)
+        if (!q) return tb_fail(ctx, "tb_rule_checks: a required buffer pointer is NULL");
+    const size_t raw_bytes = (size_t)4 * io->n_scene * io->k_futures * io->n_agent * io->n_step;
+    if (raw_bytes > ctx->rule_ws_bytes) {
+        if (ctx->d_rule_ws) {
+            TB_HIP(ctx, hipDeviceSynchronize());
+            TB_HIP(ctx, hipFree(ctx->d_rule_ws));
+            ctx->d_rule_ws = nullptr;
+            ctx->rule_ws_bytes = 0;
+        }
+        TB_HIP(ctx, hipMalloc((void**)&ctx->d_rule_ws, raw_bytes));
+        ctx->rule_ws_bytes = raw_bytes;
+    }
+    tb::run_rule_checks(io, ctx->cfg.time_step_current + 1, ctx->cfg.time_step_sim_start, ctx->d_rule_ws, (hipStream_t)stream_);
     TB_HIP(ctx, hipGetLastError());
     return 0;
 }

@@ -28,6 +28,8 @@ struct tb_ctx {
     // workspace
     char* d_ws = nullptr;
     size_t ws_bytes = 0;
+    uint8_t* d_rule_ws = nullptr;  // per-step flags of tb_rule_checks
+    size_t rule_ws_bytes = 0;
     long long* last_prof = nullptr;
     // stepwise rollout (tb_rollout_begin / _step / _state)
     tb::RolloutP step_p;

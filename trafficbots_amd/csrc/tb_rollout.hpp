@@ -98,6 +98,8 @@ struct RolloutP {
     uint8_t* o_dest_reached_this;
     float* o_action_logp;         // [N,A,S]
     float* o_latent_logp;         // [N,A]
+    float* o_check_state;         // [N,A,S,4] post-override state of every step (optional)
+    uint8_t* o_check_valid;       // [N,A,S]
     int tap_step;
     float* tap_policy_feature;    // [N,A,128]
     float* tap_agent_feature;     // [N,A,128]

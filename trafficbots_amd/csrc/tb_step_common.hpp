@@ -231,6 +231,11 @@ __device__ __forceinline__ void step_epilogue(const RolloutP& p, int t, int n, i
         // kill agents that left the map unless ground truth is still valid (dynamics.py:161-167)
         const bool mk = out_this && !gt_valid;
         killed |= mk;
+        if (p.o_check_state) {  // what TrafficRuleChecker.check sees (waymo_motion.py:311): post-override, pre-kill
+            const size_t ci = ((size_t)n * p.n_agent + row) * p.n_step_out + (t - p.step_start);
+            st4(p.o_check_state + ci * 4, cur);
+            p.o_check_valid[ci] = valid;
+        }
         valid = valid && !mk;
         // navigator (goal_manager.py:155-162)
         const bool gv = (gvalid[tid] != 0) && valid && !dreached;
@@ -351,9 +356,15 @@ __device__ __forceinline__ void step_epilogue16(const RolloutP& p, int t, int n,
     // kill agents that left the map unless ground truth is still valid (dynamics.py:161-167); navigator (goal_manager.py:155-162)
     const bool mk = out_this && !gt_valid;
     killed |= mk;
+    const bool valid_checked = valid;  // what TrafficRuleChecker.check sees (waymo_motion.py:311): post-override, pre-kill
     valid = valid && !mk;
     const bool gv = gv0 && valid && !dreached;
     if (sub == 0 && real) {
+        if (p.o_check_state) {
+            const size_t ci = ((size_t)n * p.n_agent + row) * p.n_step_out + (t - p.step_start);
+            st4(p.o_check_state + ci * 4, cur);
+            p.o_check_valid[ci] = valid_checked;
+        }
         if (forced) {
             st4(p.aux + si * 4, hax);
             rst[a].aux[0] = hax.x; rst[a].aux[1] = hax.y; rst[a].aux[2] = hax.z; rst[a].aux[3] = hax.w;

@@ -43,6 +43,21 @@ class TbRolloutIO(C.Structure):
         ("action_log_probs", c_f32p), ("latent_log_prob", c_f32p),
         ("final_state", c_f32p), ("final_valid", c_u8p), ("final_hidden", c_f32p),
         ("tap_step", C.c_int32), ("tap_policy_feature", c_f32p), ("tap_agent_feature", c_f32p),
+        ("check_state", c_f32p), ("check_valid", c_u8p),
+    ]
+
+
+class TbRuleIO(C.Structure):
+    _fields_ = [
+        ("n_scene", C.c_int32), ("k_futures", C.c_int32), ("n_agent", C.c_int32), ("n_pl", C.c_int32), ("n_tl", C.c_int32),
+        ("n_step", C.c_int32),
+        ("enable_check_collided", C.c_int32), ("enable_check_run_road_edge", C.c_int32),
+        ("enable_check_run_red_light", C.c_int32), ("enable_check_passive", C.c_int32),
+        ("check_state", c_f32p), ("check_valid", c_u8p), ("agent_type", c_i32p), ("agent_size", c_f32p),
+        ("map_valid", c_u8p), ("map_type", c_i32p), ("map_pos", c_f32p), ("map_dir", c_f32p),
+        ("tl_valid", c_u8p), ("tl_state", c_i32p), ("tl_pos", c_f32p),
+        ("collided", c_u8p), ("collided_this_step", c_u8p), ("run_road_edge", c_u8p), ("run_road_edge_this_step", c_u8p),
+        ("run_red_light", c_u8p), ("run_red_light_this_step", c_u8p), ("passive", c_u8p), ("passive_this_step", c_u8p),
     ]
 
 
@@ -61,6 +76,7 @@ class TbEncodeIO(C.Structure):
 EXPORTS = (
     "tb_create", "tb_destroy", "tb_last_error", "tb_version", "tb_load_weight", "tb_finalize_weights",
     "tb_rollout", "tb_rollout_begin", "tb_rollout_step", "tb_rollout_state", "tb_encode_scene", "tb_set_timing", "tb_get_timing",
+    "tb_rule_checks",
 )
 
 _lib: Optional[C.CDLL] = None
@@ -104,6 +120,8 @@ def load() -> C.CDLL:
     lib.tb_rollout_state.restype = C.c_int
     lib.tb_encode_scene.argtypes = [C.c_void_p, C.POINTER(TbEncodeIO), C.c_void_p]
     lib.tb_encode_scene.restype = C.c_int
+    lib.tb_rule_checks.argtypes = [C.c_void_p, C.POINTER(TbRuleIO), C.c_void_p]
+    lib.tb_rule_checks.restype = C.c_int
     lib.tb_set_timing.argtypes = [C.c_void_p, C.c_int]
     lib.tb_set_timing.restype = C.c_int
     lib.tb_get_timing.argtypes = [C.c_void_p, c_f32p]

@@ -39,6 +39,10 @@ def teacher_forcing_mask(valid: Tensor, step_spawn_agent: int = 10, step_warm_st
     return m
 
 
+RULE_KEYS = ("collided", "collided_this_step", "run_road_edge", "run_road_edge_this_step", "run_red_light",
+             "run_red_light_this_step", "passive", "passive_this_step")
+
+
 def scene_from_batch(batch: Dict[str, Tensor], device, n_hist: int = 11) -> Dict[str, Tensor]:
     """Reference test-split batch (`data_h5_womd.py:119-157`, bool tensors, history/ prefix) ->
     the C ABI's device layout (uint8 masks, int32 class indices, yaw/spd/acc as [B,NH,A])."""
@@ -169,6 +173,7 @@ class HipEngine:
         tap_step: int = -1,
         out: Optional[Dict[str, Tensor]] = None,
         stepwise: bool = False,
+        record_check_states: bool = False,
     ) -> Dict[str, Tensor]:
         """Closed-loop rollout of N = B*K instances (instance n uses scene n // K).  Returns the
         `RolloutBuffer` fields as [N, A, S, ...] tensors (`buffer.py:72-90`).  With `stepwise=True` only the
@@ -199,6 +204,9 @@ class HipEngine:
             if tap_step >= 0:
                 out["tap_policy_feature"] = torch.zeros(n, a, 128, device=dev, dtype=f32)
                 out["tap_agent_feature"] = torch.zeros(n, a, 128, device=dev, dtype=f32)
+            if record_check_states:  # what TrafficRuleChecker.check is handed every step (input of `rule_checks`)
+                out["check_state"] = torch.zeros(n, a, n_step, 4, device=dev, dtype=f32)
+                out["check_valid"] = torch.zeros(n, a, n_step, device=dev, dtype=u8)
         io = hip.TbRolloutIO()
         io.n_scene, io.k_futures, io.n_agent, io.n_pl, io.n_tl, io.n_hist, io.step_end = b, k_futures, a, p, t, nh, step_end
         io.map_feature = hip.ptr(feats["map_feature"], hip.c_f32p)
@@ -240,6 +248,8 @@ class HipEngine:
         io.tap_step = tap_step
         io.tap_policy_feature = hip.ptr(out.get("tap_policy_feature"), hip.c_f32p)
         io.tap_agent_feature = hip.ptr(out.get("tap_agent_feature"), hip.c_f32p)
+        io.check_state = hip.ptr(out.get("check_state"), hip.c_f32p)
+        io.check_valid = hip.ptr(out.get("check_valid"), hip.c_u8p)
         # keep the borrowed inputs alive until the stream work is done
         out["_keepalive"] = (latent_sample, latent_mean, dest, goal_valid, mask_teacher_forcing, s, feats)
         if stepwise:
@@ -247,6 +257,35 @@ class HipEngine:
             self._step_out = out
         else:
             self._check(self.lib.tb_rollout(self._ctx, C.byref(io), self._stream()), "tb_rollout")
+        return out
+
+    def rule_checks(self, s: Dict[str, Tensor], check_state: Tensor, check_valid: Tensor, k_futures: int,
+                    flags: Dict[str, bool]) -> Dict[str, Tensor]:
+        """The flag-gated checks of `TrafficRuleChecker.check` (`traffic_rule_checker.py:122-335, 412-516`) over a recorded
+        rollout (`tb_rule_checks`): `check_state` [N,A,S,4] / `check_valid` [N,A,S] as recorded by `rollout(...,
+        record_check_states=True)`, `s` the pre-processed scene, `flags` the `traffic_rule_checker` config group.
+        Returns the eight [N,A,S] uint8 arrays (zeros for a disabled check, like the reference)."""
+        n, a, n_step = check_valid.shape
+        b = s["agent_valid"].shape[0]
+        io = hip.TbRuleIO()
+        io.n_scene, io.k_futures, io.n_agent, io.n_pl, io.n_tl, io.n_step = b, k_futures, a, s["map_valid"].shape[1], s["tl_valid"].shape[2], n_step
+        io.enable_check_collided = int(bool(flags.get("enable_check_collided", False)))
+        io.enable_check_run_road_edge = int(bool(flags.get("enable_check_run_road_edge", False)))
+        io.enable_check_run_red_light = int(bool(flags.get("enable_check_run_red_light", False)))
+        io.enable_check_passive = int(bool(flags.get("enable_check_passive", False)))
+        cs, cv = check_state.to(torch.float32).contiguous(), check_valid.to(torch.uint8).contiguous()
+        assert cs.shape == (n, a, n_step, 4) and n == b * k_futures
+        io.check_state, io.check_valid = hip.ptr(cs, hip.c_f32p), hip.ptr(cv, hip.c_u8p)
+        io.agent_type, io.agent_size = hip.ptr(s["agent_type"], hip.c_i32p), hip.ptr(s["agent_size"], hip.c_f32p)
+        io.map_valid, io.map_type = hip.ptr(s["map_valid"], hip.c_u8p), hip.ptr(s["map_type"], hip.c_i32p)
+        io.map_pos, io.map_dir = hip.ptr(s["map_pos"], hip.c_f32p), hip.ptr(s["map_dir"], hip.c_f32p)
+        io.tl_valid, io.tl_state, io.tl_pos = hip.ptr(s["tl_valid"], hip.c_u8p), hip.ptr(s["tl_state"], hip.c_i32p), hip.ptr(s["tl_pos"], hip.c_f32p)
+        out = {}
+        for name in RULE_KEYS:
+            out[name] = torch.empty(n, a, n_step, device=self.device, dtype=torch.uint8)
+            setattr(io, name, hip.ptr(out[name], hip.c_u8p))
+        out["_keepalive"] = (cs, cv, s)
+        self._check(self.lib.tb_rule_checks(self._ctx, C.byref(io), self._stream()), "tb_rule_checks")
         return out
 
     def rollout_step(self) -> None:

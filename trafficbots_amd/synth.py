@@ -63,6 +63,7 @@ def make_scene(
     p_tl_valid: float = 0.3,
     pos_range: float = 100.0,
     boundary: float = 150.0,
+    spd_max: float = 15.0,
 ) -> Dict[str, np.ndarray]:
     """One scene (no batch dim) in the reference's test-split layout."""
     rs = RawStream(seed)
@@ -111,7 +112,7 @@ def make_scene(
     # ---- agents: smooth histories with constant acc / yaw-rate ----
     p0 = rs.uniform(-0.8 * pos_range, 0.8 * pos_range, (n_agent, 2))
     yaw0 = rs.uniform(-math.pi, math.pi, (n_agent,))
-    spd0 = rs.uniform(0.0, 15.0, (n_agent,))
+    spd0 = rs.uniform(0.0, spd_max, (n_agent,))
     acc0 = rs.uniform(-1.0, 1.0, (n_agent,))
     yr0 = rs.uniform(-0.2, 0.2, (n_agent,))
     a_type = rs.integers(3, (n_agent,))

@@ -151,12 +151,20 @@ class WaymoMotion:
         z = latent.sample(deterministic_latent, eps=latent_eps)
         b = features["agent_valid"].shape[0]
         mean_scene = latent.mean.reshape(b, k_futures, *latent.mean.shape[1:])[:, 0].contiguous()
+        # traffic_rule_checker.enable_check_* (traffic_bots.yaml:240-244): the flag-gated checks do not feed back into the
+        # simulation, they are evaluated on the recorded per-step states once the rollout is enqueued (tb_rule_checks)
+        flags = self.hparams.get("traffic_rule_checker", {})
+        want_checks = any(bool(v) for k, v in flags.items() if k.startswith("enable_check_"))
         out = self.engine.rollout(
             features, features, z, mean_scene, goal, goal_valid, k_futures, step_end,
             mask_teacher_forcing=mask_teacher_forcing.to(torch.uint8).contiguous(), tap_step=tap_step, stepwise=stepwise,
+            record_check_states=want_checks,
         )
         self._step_t = step_start
         self._rollout_meta = (step_start, step_end, z)
+        self._rule_ctx = (features, k_futures, flags) if want_checks else None
+        if want_checks and not stepwise:
+            out.update(self.engine.rule_checks(features, out["check_state"], out["check_valid"], k_futures, flags))
         return self._buffer_from(out)
 
     def _buffer_from(self, out: Dict[str, Tensor]) -> RolloutBuffer:
@@ -178,7 +186,11 @@ class WaymoMotion:
     def finish_rollout(self) -> RolloutBuffer:
         """`RolloutBuffer.finish()` for a stepwise rollout (`buffer.py:72-90`): the buffer over the steps taken so far
         (slots of steps not yet simulated are undefined)."""
-        return self._buffer_from(self.engine._step_out)
+        out = self.engine._step_out
+        if getattr(self, "_rule_ctx", None) is not None:
+            features, k_futures, flags = self._rule_ctx
+            out.update(self.engine.rule_checks(features, out["check_state"], out["check_valid"], k_futures, flags))
+        return self._buffer_from(out)
 
     def forward(self, *unused_feature_args, action_override=None, mask_action_override=None, state_override=None,
                 mask_state_override=None, deterministic_action: bool = True, require_train_dict: bool = True,
