@@ -199,6 +199,32 @@ typedef struct tb_rule_io {
 } tb_rule_io;
 int tb_rule_checks(tb_ctx* ctx, const tb_rule_io* io, tb_stream stream);
 
+/* Post-processing of the K joint futures into the k_pred scored modes of a Waymo motion submission.
+ * Replaces: WaymoPostProcessing.forward / traj_topk / mtr_nms / mpa_nms (src/data_modules/waymo_post_processing.py:33-192;
+ * config group waymo_post_processing, configs/model/traffic_bots.yaml:179-186).  traj_aggr (aggr_thresh != []) is not built:
+ * the reference raises TypeError there (:231).  n_pred <= 64, k_pred <= 16. */
+typedef struct tb_post_io {
+    int32_t n_scene, n_agent, n_pred, n_step, d_traj; /* d_traj in 2..4: x, y[, yaw[, speed]] */
+    int32_t k_pred;
+    float score_temperature;                          /* <= 0: off */
+    int32_t n_mpa;                                    /* 0: off, else 3 */
+    float mpa_nms_thresh[3];                          /* veh, ped, cyc [m] */
+    int32_t n_mtr;
+    float mtr_nms_thresh[3];
+    int32_t use_ade;
+    const uint8_t* valid;       /* [B,A] */
+    const float* scores;        /* [B,A,NP] un-normalised */
+    const float* trajs;         /* [B,A,NP,S,D] */
+    const int32_t* agent_type;  /* [B,A] */
+    float* waymo_trajs;         /* [B,S,A,K,2]   K = min(k_pred, n_pred) */
+    float* waymo_yaw_bbox;      /* [B,S,A,K,1] or NULL */
+    float* waymo_spd;           /* [B,S,A,K,1] or NULL */
+    float* waymo_scores;        /* [B,A,K] normalised */
+    uint8_t* waymo_valid;       /* [B,S,A] */
+    int32_t* mode_idx;          /* [B,A,K] selected input modes, or NULL */
+} tb_post_io;
+int tb_post_process(tb_ctx* ctx, const tb_post_io* io, tb_stream stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -317,6 +317,41 @@ def test_rule_checks_kernel(name):
     REPORT[name] = rep
 
 
+def test_post_processing_kernel():
+    """SURVEY 8(f)-2, `tb_post_process` against the goldens of the reference's WaymoPostProcessing: the same modes selected
+    (top-k / MTR NMS), scores within 1e-6 (MPA NMS, temperature softmax), trajectories exact copies, [B,S,A,K] layout."""
+    import json
+
+    from conftest import GOLDEN_DIR
+    from trafficbots_amd import synth
+    from trafficbots_amd.post_processing import WaymoPostProcessing
+    from trafficbots_amd.runtime import HipEngine
+    from trafficbots_amd.config import load_model_config
+
+    g = np.load(os.path.join(GOLDEN_DIR, "post_processing.npz"))
+    meta = json.loads(bytes(g["meta_json"]).decode())
+    eng = HipEngine(load_model_config())
+    for i, (name, c) in enumerate(meta["cases"].items()):
+        valid, scores, trajs, agent_type = synth.make_post_inputs(meta["seed0"] + i, meta["n_scene"], meta["n_agent"], c["n_pred"], meta["n_step"])
+        pp = WaymoPostProcessing(eng, c["k_pred"], c["score_temperature"], c["mpa"], c["mtr"], c["aggr"], c["n_iter_em"], c["use_ade"])
+        out = pp(torch.from_numpy(valid), torch.from_numpy(scores), torch.from_numpy(trajs), torch.from_numpy(agent_type))
+        torch.cuda.synchronize()
+        idx, sc = out["mode_idx"].cpu().numpy().astype(np.int64), out["waymo_scores"].cpu().numpy()
+        ref_idx, ref_s = g[f"{name}/mode_idx"].astype(np.int64), g[f"{name}/waymo_scores"]
+        o_ref, o_got = np.argsort(ref_idx, -1), np.argsort(idx, -1)
+        assert np.array_equal(np.take_along_axis(ref_idx, o_ref, -1), np.take_along_axis(idx, o_got, -1)), name
+        err = np.abs(np.take_along_axis(ref_s, o_ref, -1) - np.take_along_axis(sc, o_got, -1)).max()
+        REPORT[f"post_processing/{name}/score_max_abs"] = float(err)
+        assert err < 1e-6, (name, err)
+        assert np.array_equal(out["waymo_valid"].cpu().numpy(), g[f"{name}/waymo_valid"])
+        sel = np.moveaxis(np.take_along_axis(trajs, idx[..., None, None], 2), 3, 1)  # [B,S,A,K,4]
+        assert np.array_equal(out["waymo_trajs"].cpu().numpy(), sel[..., :2])
+        assert np.array_equal(out["waymo_yaw_bbox"].cpu().numpy(), sel[..., 2:3])
+        assert np.array_equal(out["waymo_spd"].cpu().numpy(), sel[..., 3:4])
+    with pytest.raises(NotImplementedError):
+        WaymoPostProcessing(eng, aggr_thresh=[2.0])
+
+
 def test_empty_and_bad_inputs_fail_loudly():
     from trafficbots_amd import synth
     from trafficbots_amd.waymo_motion import WaymoMotion

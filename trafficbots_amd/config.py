@@ -19,8 +19,7 @@ from typing import Any, Dict
 
 # Defaults for the keys of configs/model/traffic_bots.yaml that the path reads.
 # Training-only groups (optimizer, lr_scheduler, training_metrics,
-# differentiable_reward, sub_womd_*, waymo_post_processing) are accepted by the
-# loader but ignored.
+# differentiable_reward, sub_womd_*) are accepted by the loader but ignored.
 _MLP_CFG = {"use_layernorm": False, "activation": "relu", "dropout_p": 0.1}
 
 DEFAULT_MODEL_CONFIG: Dict[str, Any] = {
@@ -130,6 +129,10 @@ DEFAULT_MODEL_CONFIG: Dict[str, Any] = {
     },
     "teacher_forcing_joint_future_pred": {"step_spawn_agent": 10, "step_warm_start": 10},
     "teacher_forcing_reactive_replay": {"step_spawn_agent": 90, "step_warm_start": 10},
+    "waymo_post_processing": {  # traffic_bots.yaml:179-186
+        "k_pred": 6, "use_ade": True, "score_temperature": 1e2, "mpa_nms_thresh": [], "mtr_nms_thresh": [], "aggr_thresh": [],
+        "n_iter_em": 3,
+    },
     "traffic_rule_checker": {
         "enable_check_collided": False,
         "enable_check_run_road_edge": False,

@@ -30,6 +30,7 @@ void launch_kv_hoist_x(const float* W, const XLayerW* L3, const XLayerX* X3, con
 int run_encode(struct ::tb_ctx* ctx, const tb_encode_io* io, hipStream_t s);
 int run_rule_checks(const tb_rule_io* io, int n_hist, int step_start, uint8_t* raw_ws, hipStream_t s);
 hipError_t configure_rule_kernels();
+void launch_post_process(const tb_post_io& io, hipStream_t s);
 }  // namespace tb
 
 // ---------------------------------------------------------------------------------------------------
@@ -648,6 +649,24 @@ extern "C" int tb_rule_checks(tb_ctx* ctx, const tb_rule_io* io, tb_stream strea
         ctx->rule_ws_bytes = raw_bytes;
     }
     tb::run_rule_checks(io, ctx->cfg.time_step_current + 1, ctx->cfg.time_step_sim_start, ctx->d_rule_ws, (hipStream_t)stream_);
+    TB_HIP(ctx, hipGetLastError());
+    return 0;
+}
+
+// ---- WaymoPostProcessing (tb_post_kernels.hip) ---------------------------------------------------------------------
+extern "C" int tb_post_process(tb_ctx* ctx, const tb_post_io* io, tb_stream stream_) {
+    if (!ctx || !io) return 1;
+    TB_HIP(ctx, hipSetDevice(ctx->device));
+    if (io->n_scene <= 0 || io->n_agent <= 0 || io->n_pred <= 0 || io->n_step <= 0 || io->k_pred <= 0)
+        return tb_fail(ctx, "tb_post_process: empty dimension");
+    if (io->n_pred > 64 || io->k_pred > 16) return tb_fail(ctx, "tb_post_process: n_pred %d > 64 or k_pred %d > 16", io->n_pred, io->k_pred);
+    if (io->d_traj < 2 || io->d_traj > 4) return tb_fail(ctx, "tb_post_process: d_traj %d not in 2..4", io->d_traj);
+    if ((io->n_mpa != 0 && io->n_mpa != 3) || (io->n_mtr != 0 && io->n_mtr != 3))
+        return tb_fail(ctx, "tb_post_process: nms thresholds must be empty or [veh, ped, cyc]");
+    const void* need[] = {io->valid, io->scores, io->trajs, io->agent_type, io->waymo_trajs, io->waymo_scores, io->waymo_valid};
+    for (const void* q : need)
+        if (!q) return tb_fail(ctx, "tb_post_process: a required buffer pointer is NULL");
+    tb::launch_post_process(*io, (hipStream_t)stream_);
     TB_HIP(ctx, hipGetLastError());
     return 0;
 }

@@ -73,10 +73,21 @@ class TbEncodeIO(C.Structure):
     ]
 
 
+class TbPostIO(C.Structure):
+    _fields_ = [
+        ("n_scene", C.c_int32), ("n_agent", C.c_int32), ("n_pred", C.c_int32), ("n_step", C.c_int32), ("d_traj", C.c_int32),
+        ("k_pred", C.c_int32), ("score_temperature", C.c_float), ("n_mpa", C.c_int32), ("mpa_nms_thresh", C.c_float * 3),
+        ("n_mtr", C.c_int32), ("mtr_nms_thresh", C.c_float * 3), ("use_ade", C.c_int32),
+        ("valid", c_u8p), ("scores", c_f32p), ("trajs", c_f32p), ("agent_type", c_i32p),
+        ("waymo_trajs", c_f32p), ("waymo_yaw_bbox", c_f32p), ("waymo_spd", c_f32p), ("waymo_scores", c_f32p),
+        ("waymo_valid", c_u8p), ("mode_idx", c_i32p),
+    ]
+
+
 EXPORTS = (
     "tb_create", "tb_destroy", "tb_last_error", "tb_version", "tb_load_weight", "tb_finalize_weights",
     "tb_rollout", "tb_rollout_begin", "tb_rollout_step", "tb_rollout_state", "tb_encode_scene", "tb_set_timing", "tb_get_timing",
-    "tb_rule_checks",
+    "tb_rule_checks", "tb_post_process",
 )
 
 _lib: Optional[C.CDLL] = None
@@ -122,6 +133,8 @@ def load() -> C.CDLL:
     lib.tb_encode_scene.restype = C.c_int
     lib.tb_rule_checks.argtypes = [C.c_void_p, C.POINTER(TbRuleIO), C.c_void_p]
     lib.tb_rule_checks.restype = C.c_int
+    lib.tb_post_process.argtypes = [C.c_void_p, C.POINTER(TbPostIO), C.c_void_p]
+    lib.tb_post_process.restype = C.c_int
     lib.tb_set_timing.argtypes = [C.c_void_p, C.c_int]
     lib.tb_set_timing.restype = C.c_int
     lib.tb_get_timing.argtypes = [C.c_void_p, c_f32p]

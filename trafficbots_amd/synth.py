@@ -174,6 +174,25 @@ def make_batch(base_seed: int, n_scene: int, scene_offset: int = 0, **kw) -> Dic
     return {k: np.stack([s[k] for s in scenes], 0) for k in scenes[0].keys()}
 
 
+def make_post_inputs(seed: int, n_scene: int, n_agent: int, n_pred: int, n_step: int = 80):
+    """Seeded inputs of `WaymoPostProcessing.forward` (valid [B,A], scores [B,A,NP] un-normalised, trajs [B,A,NP,S,4],
+    agent_type [B,A,3]): clustered futures -- five base paths per agent plus small per-mode perturbations -- so that NMS has
+    something to merge."""
+    rs = RawStream(seed)
+    base = rs.uniform(-30, 30, (n_scene, n_agent, 5, 1, 2)) + np.cumsum(rs.uniform(-1.5, 1.5, (n_scene, n_agent, 5, n_step, 2)), 3)
+    pick = rs.integers(5, (n_scene, n_agent, n_pred))
+    xy = np.take_along_axis(base, pick[..., None, None], 2) + rs.uniform(-0.8, 0.8, (n_scene, n_agent, n_pred, n_step, 2))
+    yaw = rs.uniform(-3.14, 3.14, (n_scene, n_agent, n_pred, n_step, 1))
+    spd = rs.uniform(0, 15, (n_scene, n_agent, n_pred, n_step, 1))
+    trajs = np.concatenate([xy, yaw, spd], -1).astype(np.float32)
+    scores = np.exp(rs.uniform(-6, 0, (n_scene, n_agent, n_pred))).astype(np.float32)
+    valid = ~rs.bernoulli(0.2, (n_scene, n_agent))
+    ty = rs.integers(3, (n_scene, n_agent))
+    agent_type = np.zeros((n_scene, n_agent, 3), bool)
+    np.put_along_axis(agent_type, ty[..., None], True, -1)
+    return valid, scores, trajs, agent_type
+
+
 def make_latent_noise(seed: int, n_inst: int, n_agent: int, latent_dim: int = 16) -> np.ndarray:
     """Standard-normal draws eps[N, A, latent_dim] for the CVAE personality samples (the reference
     draws them from torch's CPU stream, `distributions.py:26-31`; goldens pass them explicitly)."""

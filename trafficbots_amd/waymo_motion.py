@@ -105,6 +105,9 @@ class WaymoMotion:
         self.engine = HipEngine(self.hparams, device)
         self.model = TrafficBots(self.engine)
         self.n_hist = self.hparams["time_step_current"] + 1
+        from .post_processing import WaymoPostProcessing
+
+        self.waymo_post_processing = WaymoPostProcessing(self.engine, **self.hparams.get("waymo_post_processing", {}))
 
     # ------------------------------------------------------------------ weights
     def load_state_dict(self, state_dict: Dict) -> None:
@@ -265,8 +268,8 @@ class WaymoMotion:
 
     def test_step(self, batch: Dict[str, Tensor], batch_idx: int = 0, latent_eps=None, goal_sample=None, generator=None,
                   tap_step: int = -1) -> Dict[str, Tensor]:
-        """Hot-path part of `WaymoMotion.test_step` (`waymo_motion.py:902-933`); post-processing and submission
-        (`:934-949`) are out of scope.  Returns the buffer plus the intermediate products."""
+        """`WaymoMotion.test_step` (`waymo_motion.py:902-940`) up to and including `waymo_post_processing`; the submission writer
+        (`:942-949`) is out of scope.  Returns the buffer, the intermediate products and the post-processed `pred_dict`."""
         scene = self.pre_processing(batch)
         input_feature_dict = self.model.encode_input_features(scene)
         goal_valid = scene["agent_valid"].bool().any(1)
@@ -277,8 +280,15 @@ class WaymoMotion:
             scene, input_feature_dict, latent_prior, goal_pred, goal_valid, latent_eps=latent_eps, goal_sample=goal_sample,
             generator=generator, tap_step=tap_step,
         )
+        scores = torch.exp(buf.latent_log_probs[..., 0] + glp)  # waymo_motion.py:936
+        pred_dict = None
+        if buf.preds.shape[3] > buf.step_future_start:  # (a rollout that stops at the current step has no future to post-process)
+            pred_dict = self.waymo_post_processing(
+                valid=buf.valid[:, :, 0].any(-1), scores=scores, trajs=buf.preds[:, :, :, buf.step_future_start:],
+                agent_type=scene["agent_type"],
+            )
         return {
             "rollout_buffer": buf, "goal_sample": gs, "goal_log_probs": glp, "input_feature_dict": input_feature_dict,
             "latent_mean": latent_mean, "latent_valid": latent_valid, "dest_logits": self.model._enc["dest_logits"],
-            "scores": torch.exp(buf.latent_log_probs[..., 0] + glp),  # waymo_motion.py:936
+            "scores": scores, "pred_dict": pred_dict,
         }
