@@ -79,7 +79,7 @@ def cpu_baseline_worker(budget_s: float = 15.0) -> None:
 
     n_threads = usable_cpus()
     torch.set_num_threads(n_threads)
-    cfg = load_model_config(overrides={"time_step_end": STEP_END, "n_joint_future": 1})
+    cfg = load_model_config(overrides={"time_step_end": STEP_END, "n_joint_future": 1, "operand_precision": args.operand_precision})
     sd = synth.make_state_dict(7)
     orc = Oracle(sd, cfg, torch.float32, hoist=False)
 
@@ -134,6 +134,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--operand-precision", choices=["fp32", "bf16"], default="fp32",
+                    help="bf16: BASELINE.json configs 4/5 operand precision (not the headline metric, which is fp32)")
     ap.add_argument("--cpu-baseline-worker", action="store_true")
     args = ap.parse_args()
     if args.cpu_baseline_worker:
@@ -156,7 +158,7 @@ def main():
 
     from trafficbots_amd.runtime import HipEngine, scene_from_batch
 
-    cfg = load_model_config(overrides={"time_step_end": STEP_END, "n_joint_future": 1})
+    cfg = load_model_config(overrides={"time_step_end": STEP_END, "n_joint_future": 1, "operand_precision": args.operand_precision})
     sd = synth.make_state_dict(7)
     eng = HipEngine(cfg, f"cuda:{local_rank}")
     eng.load_state_dict(sd)
@@ -240,7 +242,9 @@ def main():
             "metric": "rollout scene-steps/sec (64 agents, 90 executed = 10 teacher-forced + 80 free steps)",
             "value": value, "unit": "scene-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32 (fp16-pair operands on the XDL MFMA, fp32 accumulate; fp32 everywhere else)", "data": "synthetic",
+            "dtype": ("f32 (fp16-pair operands on the XDL MFMA, fp32 accumulate; fp32 everywhere else)" if args.operand_precision == "fp32"
+                      else "bf16 MFMA operands, fp32 accumulate and state (BASELINE configs 4/5 precision; NOT the headline fp32 metric)"),
+            "data": "synthetic",
             "config": {"workload": "BASELINE.json configs[1]: 32 synthetic WOMD-shaped scenes per GPU, 64 agents, 256 polylines, "
                                    "40 TL stop points, K=1, 90-step closed-loop rollout, fp32, random-init weights",
                        "scenes_per_gpu": B_PER_GPU, "n_agent": N_AGENT, "n_pl": N_PL, "n_tl": N_TL, "sim_steps": STEP_END,

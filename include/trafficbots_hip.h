@@ -36,6 +36,8 @@ typedef struct tb_config {
     float max_yaw_rate[3];
     float action_log_std;        /* -2 (traffic_bots.yaml:138) */
     float latent_log_std;        /* -1 (traffic_bots.yaml:76); overwritten by the loaded parameter */
+    int32_t operand_precision;   /* 0 (default): fp32-accurate (fp16-pair MFMA operands, fp32 accumulate);
+                                  * 1: bf16 MFMA operands, fp32 accumulate -- BASELINE.json configs 4/5, no fp32-parity claim */
 } tb_config;
 
 /* -- lifecycle ----------------------------------------------------------------------------------- */

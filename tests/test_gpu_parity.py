@@ -352,6 +352,39 @@ def test_post_processing_kernel():
         WaymoPostProcessing(eng, aggr_thresh=[2.0])
 
 
+def test_bf16_operand_mode():
+    """`operand_precision="bf16"` (tb_config.operand_precision = 1, BASELINE.json configs 4/5): the same kernels with one bf16
+    plane per MFMA operand and fp32 accumulation.  No fp32-parity claim: bf16 rounds every GEMM / attention operand to 8 bits, so
+    only short-horizon quantities are compared, with the tolerance bf16 allows -- the re-synced one-step policy feature within 5e-2
+    of the reference (values are O(1)), the first free-running step within 2 cm, everything finite, teacher-forced bookkeeping equal."""
+    g, meta = load_golden("small_k1")
+    cfg, sd, batch, eps = golden_inputs(meta)
+    from trafficbots_amd.waymo_motion import WaymoMotion
+
+    wm = WaymoMotion(time_step_end=meta["time_step_end"], n_joint_future=meta["k"], operand_precision="bf16")
+    wm.load_state_dict(sd)
+    gs = torch.from_numpy(np.transpose(g["goal_sample"], (0, 2, 1)).copy())
+    out = wm.test_step(batch, latent_eps=torch.from_numpy(eps).cuda(), goal_sample=gs, tap_step=1)
+    torch.cuda.synchronize()
+    buf = out["rollout_buffer"]
+    preds = buf.preds.cpu().numpy()
+    assert np.isfinite(preds).all()
+    s_free = meta_step = 11 - 1  # buffer slot of step 11, the first free-running step
+    assert np.array_equal(buf.valid.cpu().numpy()[..., : s_free + 1], g["valid"][..., : s_free + 1])
+    assert np.array_equal(buf.override_masks.cpu().numpy(), g["override_masks"])
+    v = g["valid"][..., s_free]
+    err_xy = np.abs(preds[..., s_free, :2] - g["preds"][..., s_free, :2])[v].max()
+    tap = buf.taps["tap_policy_feature"].cpu().numpy()
+    ref = g["tap1/policy_feature"]
+    err_f = np.abs(tap - ref).max()
+    REPORT["bf16_mode"] = {"policy_feature_step1_max_abs": float(err_f), "xy_first_free_step_max_abs": float(err_xy),
+                           "xy_final_step_max_abs": float(np.abs(preds[..., -1, :2] - g["preds"][..., -1, :2])[g["valid"][..., -1]].max())}
+    assert err_f <= 5e-2, err_f
+    assert err_xy <= 2e-2, err_xy
+    with pytest.raises(ValueError):
+        WaymoMotion(operand_precision="fp8")
+
+
 def test_empty_and_bad_inputs_fail_loudly():
     from trafficbots_amd import synth
     from trafficbots_amd.waymo_motion import WaymoMotion

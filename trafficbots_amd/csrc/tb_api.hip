@@ -23,10 +23,15 @@ void launch_rollout_final(const RolloutP& p, float* f_state, uint8_t* f_valid, f
 hipError_t configure_rollout_kernels();
 void launch_step8(const RolloutP& p, int t, int do_c, int do_a, hipStream_t s);
 hipError_t configure_step8_kernel();
-void launch_step_x(const RolloutP& p, int t, int do_c, int do_a, hipStream_t s);
-hipError_t configure_stepx_kernel();
-void launch_kv_hoist_x(const float* W, const XLayerW* L3, const XLayerX* X3, const float* feat, const uint8_t* fvalid, int G, int n_tok,
-                       int n_pad, float* K, float* VT, float* kbias, hipStream_t s);
+#define TB_DECLARE_XDL(NS)                                                                                                       \
+    namespace NS {                                                                                                                \
+    void launch_step_x(const RolloutP& p, int t, int do_c, int do_a, hipStream_t s);                                              \
+    hipError_t configure_stepx_kernel();                                                                                          \
+    void launch_kv_hoist_x(const float* W, const XLayerW* L3, const XLayerX* X3, const float* feat, const uint8_t* fvalid, int G, \
+                           int n_tok, int n_pad, float* K, float* VT, float* kbias, hipStream_t s);                               \
+    }
+TB_DECLARE_XDL(xh)  // fp16 pairs (tb_stepx_kernels.hip)
+TB_DECLARE_XDL(xb)  // bf16       (tb_stepx_bf16_kernels.hip)
 int run_encode(struct ::tb_ctx* ctx, const tb_encode_io* io, hipStream_t s);
 int run_rule_checks(const tb_rule_io* io, int n_hist, int step_start, uint8_t* raw_ws, hipStream_t s);
 hipError_t configure_rule_kernels();
@@ -154,11 +159,32 @@ uint32_t add_packed(Arena& a, Stage& s, const std::string& name, int n_out, int 
     return a.add(pack_mfma(v->data() + (size_t)row0 * k, n_out, k, kp));
 }
 
+// single-plane bf16 twin of pack_xdl (operand_precision = 1): [n_out/16][k/32][64 lanes][8 bf16]
+std::vector<float> pack_xdl_bf16(const float* w, int n_out, int k) {
+    const int n_tiles = n_out / 16, nch = k / 32;
+    std::vector<uint16_t> out((size_t)n_tiles * nch * 512);
+    for (int t = 0; t < n_tiles; ++t)
+        for (int c = 0; c < nch; ++c)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int e = 0; e < 8; ++e) {
+                    const float v = w[(size_t)(t * 16 + (lane & 15)) * k + c * 32 + (lane >> 4) * 8 + e];
+                    uint32_t u;
+                    memcpy(&u, &v, 4);
+                    u += 0x7fffu + ((u >> 16) & 1u);  // round to nearest even
+                    out[((size_t)(t * nch + c)) * 512 + (size_t)lane * 8 + e] = (uint16_t)(u >> 16);
+                }
+    std::vector<float> f(out.size() / 2);
+    memcpy(f.data(), out.data(), out.size() * 2);
+    return f;
+}
+
+static bool g_pack_bf16 = false;  // which packing add_xdl emits (set around the two passes of tb_finalize_weights)
+
 uint32_t add_xdl(Arena& a, Stage& s, const std::string& name, int n_out, int k, int row0 = 0, int rows_total = -1) {
     if (rows_total < 0) rows_total = n_out;
     auto v = s.get(name, (size_t)rows_total * k);
     if (!v) return 0;
-    return a.add(pack_xdl(v->data() + (size_t)row0 * k, n_out, k));
+    return a.add(g_pack_bf16 ? pack_xdl_bf16(v->data() + (size_t)row0 * k, n_out, k) : pack_xdl(v->data() + (size_t)row0 * k, n_out, k));
 }
 
 tb::XLayerX add_xlayer_x(Arena& a, Stage& s, const std::string& p) {
@@ -230,8 +256,10 @@ extern "C" {
 const char* tb_version(void) { return "trafficbots_hip 0.2 (gfx950, fp16-pair XDL MFMA 16x16x32 with fp32 accumulate; fp32 MFMA 16x16x4 kernels selectable)"; }
 
 static void step_launch(const tb_ctx* ctx, const tb::RolloutP& p, int t, int do_c, int do_a, hipStream_t s) {
-    if (ctx->step_kernel == 2)
-        tb::launch_step_x(p, t, do_c, do_a, s);
+    if (ctx->step_kernel == 3)
+        tb::xb::launch_step_x(p, t, do_c, do_a, s);
+    else if (ctx->step_kernel == 2)
+        tb::xh::launch_step_x(p, t, do_c, do_a, s);
     else if (ctx->step_kernel == 1)
         tb::launch_step8(p, t, do_c, do_a, s);
     else
@@ -247,7 +275,13 @@ int tb_create(const tb_config* cfg, tb_ctx** out) {
     }
     tb_ctx* c = new tb_ctx();
     c->cfg = *cfg;
-    if (const char* w = getenv("TB_STEP_KERNEL")) {  // development switch between the step-kernel implementations
+    if (cfg->operand_precision != 0 && cfg->operand_precision != 1) {
+        fprintf(stderr, "trafficbots_hip: tb_config.operand_precision must be 0 (fp32-accurate) or 1 (bf16 operands)\n");
+        delete c;
+        return 1;
+    }
+    if (cfg->operand_precision == 1) c->step_kernel = 3;
+    if (const char* w = cfg->operand_precision == 1 ? nullptr : getenv("TB_STEP_KERNEL")) {  // development switch between the fp32-accurate step kernels
         const std::string k = w;
         if (k == "fp32")
             c->step_kernel = 0;
@@ -292,7 +326,8 @@ int tb_finalize_weights(tb_ctx* ctx, tb_stream stream) {
     TB_HIP(ctx, hipSetDevice(ctx->device));
     TB_HIP(ctx, tb::configure_rollout_kernels());
     TB_HIP(ctx, tb::configure_step8_kernel());
-    TB_HIP(ctx, tb::configure_stepx_kernel());
+    TB_HIP(ctx, tb::xh::configure_stepx_kernel());
+    TB_HIP(ctx, tb::xb::configure_stepx_kernel());
     TB_HIP(ctx, tb::configure_rule_kernels());
     Arena a;
     Stage s{ctx};
@@ -344,9 +379,11 @@ int tb_finalize_weights(tb_ctx* ctx, tb_stream stream) {
         pw.max_yaw_rate[i] = ctx->cfg.max_yaw_rate[i];
     }
     pw.dt = ctx->cfg.dt;
-    // ---- the same policy Linears once more as fp16 pairs for k_step_x
+    // ---- the same policy Linears once more in the XDL packing of the configured operand precision (fp16 pairs / bf16)
     {
-        tb::PolicyWX& px = ctx->px;
+        const bool bf16 = ctx->cfg.operand_precision == 1;
+        g_pack_bf16 = bf16;
+        tb::PolicyWX& px = bf16 ? ctx->pxb : ctx->px;
         for (int i = 0; i < 3; ++i) {
             const std::string si = std::to_string(i);
             px.as2pl[i] = add_xlayer_x(a, s, "model.transformer_as2pl.layers." + si);
@@ -360,6 +397,7 @@ int tb_finalize_weights(tb_ctx* ctx, tb_stream stream) {
         px.goal_out_w2 = add_xdl(a, s, "model.add_goal.mlp_out.fc_layers.3.weight", 128, 128);
         px.lat_out_w1 = add_xdl(a, s, "model.add_latent.mlp_out.fc_layers.0.weight", 128, 256);
         px.lat_out_w2 = add_xdl(a, s, "model.add_latent.mlp_out.fc_layers.3.weight", 128, 128);
+        g_pack_bf16 = false;
     }
 
     // ---- scene-encoder weights
@@ -512,7 +550,7 @@ static int rollout_setup(tb_ctx* ctx, const tb_rollout_io* io, tb::RolloutP& p) 
     memset(&p, 0, sizeof(p));
     p.W = ctx->d_arena;
     p.pw = ctx->pw;
-    p.px = ctx->px;
+    p.px = ctx->step_kernel == 3 ? ctx->pxb : ctx->px;
     p.n_scene = io->n_scene;
     p.k_rep = io->k_futures;
     p.n_inst = io->n_scene * io->k_futures;
@@ -576,11 +614,11 @@ static int rollout_setup(tb_ctx* ctx, const tb_rollout_io* io, tb::RolloutP& p) 
 
 // prologue: hoisted K/V of the map and of every history step's traffic lights; simulator init
 static void rollout_prologue(const tb_ctx* ctx, const tb::RolloutP& p, const tb_rollout_io* io, hipStream_t s) {
-    if (ctx->step_kernel == 2) {  // k_step_x reads K / V as fp16 pairs in XDL operand order
-        tb::launch_kv_hoist_x(p.W, p.pw.as2pl, p.px.as2pl, p.map_feature, io->map_feature_valid, p.n_scene, p.n_pl, p.p_pad, p.kpl,
-                              p.vtpl, p.kbias_pl, s);
-        tb::launch_kv_hoist_x(p.W, p.pw.as2tl, p.px.as2tl, p.tl_feature, io->tl_feature_valid, p.n_scene * p.n_hist, p.n_tl, p.t_pad,
-                              p.ktl, p.vttl, p.kbias_tl, s);
+    if (ctx->step_kernel >= 2) {  // k_step_x reads K / V in XDL operand order (fp16 pairs or bf16)
+        auto hoist = ctx->step_kernel == 3 ? tb::xb::launch_kv_hoist_x : tb::xh::launch_kv_hoist_x;
+        hoist(p.W, p.pw.as2pl, p.px.as2pl, p.map_feature, io->map_feature_valid, p.n_scene, p.n_pl, p.p_pad, p.kpl, p.vtpl, p.kbias_pl, s);
+        hoist(p.W, p.pw.as2tl, p.px.as2tl, p.tl_feature, io->tl_feature_valid, p.n_scene * p.n_hist, p.n_tl, p.t_pad, p.ktl, p.vttl,
+              p.kbias_tl, s);
         tb::launch_rollout_init(p, s);
         return;
     }

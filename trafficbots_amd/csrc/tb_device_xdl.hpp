@@ -20,27 +20,51 @@
 #pragma once
 #include "tb_device.hpp"
 
-namespace tb {
+// Two builds of this header exist (one translation unit each): the default fp16-pair mode above (namespace tb::xh) and, with
+// -DTB_XDL_BF16 / tb_stepx_bf16_kernels.hip, a plain bf16 mode (namespace tb::xb): ONE bf16 plane per operand, fp32 accumulate --
+// the "bf16 MFMA inputs" configurations of BASELINE.json (configs 4/5); no fp32-parity claim there.
+#ifdef TB_XDL_BF16
+#define TB_XNS xb
+#else
+#define TB_XNS xh
+#endif
 
+namespace tb {
+namespace TB_XNS {
+
+#ifdef TB_XDL_BF16
+typedef __bf16 xhalf;
+constexpr int NPL = 1;              // planes per operand
+#else
 typedef _Float16 xhalf;
+constexpr int NPL = 2;              // planes per operand
+#endif
 typedef xhalf xh8 __attribute__((ext_vector_type(8)));
 typedef xhalf xh4 __attribute__((ext_vector_type(4)));
 
-constexpr int NPL = 2;              // planes per operand
 constexpr int LDP = 136;            // fp16 per plane row for 128-wide inputs (272 B: 16 rows x b128 reads hit 64 distinct banks)
 constexpr int PLANE = TM * LDP;     // fp16 per plane
 constexpr int PLANES_BYTES = NPL * PLANE * 2;  // 8704
 constexpr int LDPC = 264;           // row length of the 256-wide concat planes
 constexpr int PLANEC = TM * LDPC;
 
+#ifdef TB_XDL_BF16
+__device__ __forceinline__ f32x4 mfma_h(xh8 a, xh8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+#else
 __device__ __forceinline__ f32x4 mfma_h(xh8 a, xh8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+#endif
 constexpr float SPLIT_SCALE = 2048.0f, SPLIT_INV = 1.0f / 2048.0f;
+constexpr int P1 = NPL - 1;  // index of the low plane (aliases plane 0 in the single-plane build, where it is never used)
 
 // fp16 pair of four floats: v = h + 2^-11 l
 __device__ __forceinline__ void split2(f32x4 v, xh4& h, xh4& l) {
     h = xh4{(xhalf)v.x, (xhalf)v.y, (xhalf)v.z, (xhalf)v.w};
-    const f32x4 r = (v - f32x4{(float)h.x, (float)h.y, (float)h.z, (float)h.w}) * splat(SPLIT_SCALE);
-    l = xh4{(xhalf)r.x, (xhalf)r.y, (xhalf)r.z, (xhalf)r.w};
+    if (NPL == 2) {
+        const f32x4 r = (v - f32x4{(float)h.x, (float)h.y, (float)h.z, (float)h.w}) * splat(SPLIT_SCALE);
+        l = xh4{(xhalf)r.x, (xhalf)r.y, (xhalf)r.z, (xhalf)r.w};
+    } else {
+        l = h;  // (unused)
+    }
 }
 
 // store four consecutive features of one agent row into the two planes
@@ -49,7 +73,7 @@ __device__ __forceinline__ void planes_store4(xhalf* P, int plane_stride, int ld
     split2(v, h, l);
     xhalf* p = P + row * ld + col;
     *reinterpret_cast<xh4*>(p) = h;
-    *reinterpret_cast<xh4*>(p + plane_stride) = l;
+    if (NPL == 2) *reinterpret_cast<xh4*>(p + plane_stride) = l;
 }
 // C-layout helper: lane (kq, m) owns features tile*16 + kq*4 .. +3 of agent m
 __device__ __forceinline__ void planes_store_c(xhalf* P, int tile, int lane, f32x4 v) {
@@ -161,26 +185,32 @@ __device__ __forceinline__ void wmmax_pf(f32x4& acc_a, f32x4& acc_b, const WUnit
             un.w[0][c][p] = pa[(c * NPL + p) * 64];
             un.w[1][c][p] = pb[(c * NPL + p) * 64];
         }
-        mid_a = mfma_h(u.w[0][c][0], x[c][1], mid_a);
-        mid_b = mfma_h(u.w[1][c][0], x[c][1], mid_b);
-        mid_a = mfma_h(u.w[0][c][1], x[c][0], mid_a);
-        mid_b = mfma_h(u.w[1][c][1], x[c][0], mid_b);
+        if (NPL == 2) {
+            mid_a = mfma_h(u.w[0][c][0], x[c][P1], mid_a);
+            mid_b = mfma_h(u.w[1][c][0], x[c][P1], mid_b);
+            mid_a = mfma_h(u.w[0][c][P1], x[c][0], mid_a);
+            mid_b = mfma_h(u.w[1][c][P1], x[c][0], mid_b);
+        }
         acc_a = mfma_h(u.w[0][c][0], x[c][0], acc_a);
         acc_b = mfma_h(u.w[1][c][0], x[c][0], acc_b);
     }
-    // pin the order: 8 LDS reads + 2 bias loads, then 8 x (2 MFMA, 1 weight load, 1 MFMA, 1 weight load)
-    __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+    // pin the order: the LDS reads + 2 bias loads, then the weight loads spread under the MFMAs
+    __builtin_amdgcn_sched_group_barrier(0x100, 4 * NPL, 0);
     __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
 #pragma unroll
     for (int g = 0; g < 8; ++g) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        if (NPL == 2) {  // 8 x (2 MFMA, 1 load, 1 MFMA, 1 load)
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        }
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
         __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
     }
     TB_SCHED_FENCE();
-    acc_a += mid_a * splat(SPLIT_INV);
-    acc_b += mid_b * splat(SPLIT_INV);
+    if (NPL == 2) {
+        acc_a += mid_a * splat(SPLIT_INV);
+        acc_b += mid_b * splat(SPLIT_INV);
+    }
     if (!n.bias) {
         un.b[0] = splat(0.f);
         un.b[1] = splat(0.f);
@@ -197,24 +227,20 @@ __device__ __forceinline__ void wmmax(f32x4& acc_a, f32x4& acc_b, const WUnitX& 
     f32x4 mid_a = splat(0.f), mid_b = splat(0.f);
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-        mid_a = mfma_h(u.w[0][c][0], x[c][1], mid_a);
-        mid_b = mfma_h(u.w[1][c][0], x[c][1], mid_b);
-        mid_a = mfma_h(u.w[0][c][1], x[c][0], mid_a);
-        mid_b = mfma_h(u.w[1][c][1], x[c][0], mid_b);
+        if (NPL == 2) {
+            mid_a = mfma_h(u.w[0][c][0], x[c][P1], mid_a);
+            mid_b = mfma_h(u.w[1][c][0], x[c][P1], mid_b);
+            mid_a = mfma_h(u.w[0][c][P1], x[c][0], mid_a);
+            mid_b = mfma_h(u.w[1][c][P1], x[c][0], mid_b);
+        }
         acc_a = mfma_h(u.w[0][c][0], x[c][0], acc_a);
         acc_b = mfma_h(u.w[1][c][0], x[c][0], acc_b);
     }
-    acc_a += mid_a * splat(SPLIT_INV);
-    acc_b += mid_b * splat(SPLIT_INV);
+    if (NPL == 2) {
+        acc_a += mid_a * splat(SPLIT_INV);
+        acc_b += mid_b * splat(SPLIT_INV);
+    }
 }
-
-// offsets (in floats, into the same arena) of the fp16-pair packed Linears of one cross-attention layer / GRU layer
-struct XLayerX {
-    uint32_t wq, wkv, wo, w1, w2;
-};
-struct GruLayerX {
-    uint32_t wih, whh;
-};
 
 __device__ __forceinline__ WNextX xlayer_first_x(const float* W, const XLayerW& L, const XLayerX& LX, int wave) {
     return wstdx(W, LX.wq, W + L.bq, wave);
@@ -285,9 +311,10 @@ __device__ __forceinline__ void split8(const f32x4& a, const f32x4& b, xh8& h, x
 __device__ __forceinline__ void attn_qk_x(const KFragX& f, const xh8& qh, const xh8& ql, f32x4 (&s)[2], f32x4 (&c)[2]) {
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-        c[t] = mfma_h(f.ka[t][0], ql, splat(0.f));
+        c[t] = splat(0.f);
+        if (NPL == 2) c[t] = mfma_h(f.ka[t][0], ql, c[t]);
         s[t] = mfma_h(f.ka[t][0], qh, splat(0.f));
-        c[t] = mfma_h(f.ka[t][1], qh, c[t]);
+        if (NPL == 2) c[t] = mfma_h(f.ka[t][P1], qh, c[t]);
     }
 }
 
@@ -393,9 +420,9 @@ __device__ __forceinline__ bool attention_head_x(const f32x4 (&q)[2], AttnPreX& 
         // PV of this block (XDL) under the scale / mask / running max of the next
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt) {
-            oc[dt] = mfma_h(vc.va[dt][0], pl, oc[dt]);
+            if (NPL == 2) oc[dt] = mfma_h(vc.va[dt][0], pl, oc[dt]);
             oh[dt] = mfma_h(vc.va[dt][0], ph, oh[dt]);
-            oc[dt] = mfma_h(vc.va[dt][1], ph, oc[dt]);
+            if (NPL == 2) oc[dt] = mfma_h(vc.va[dt][P1], ph, oc[dt]);
         }
         in_vgpr(oh[0]); in_vgpr(oh[1]); in_vgpr(oc[0]); in_vgpr(oc[1]);
         attn_stats_x(ts, tc, nb, kn1 + kq * 4, self_key, run_max, sv, new_max, alpha);  // (unused after the last block)
@@ -434,12 +461,14 @@ __device__ __forceinline__ void kv_store_x(xhalf* __restrict__ Kf, xhalf* __rest
         split2(real ? ak[t] : splat(0.f), h, l);
         xhalf* pk = kblk + (kt * 64 + kq * 16 + krow) * 8 + t * 4;  // plane 0, tile kt
         *reinterpret_cast<xh4*>(pk) = h;
-        *reinterpret_cast<xh4*>(pk + 1024) = l;
+        if (NPL == 2) *reinterpret_cast<xh4*>(pk + 1024) = l;
         split2(real ? av[t] : splat(0.f), h, l);
         xhalf* pv = vblk + (t * 64 + vq * 16 + kq * 4) * 8 + ve;    // plane 0, d tile t, rows 4 kq + r
         pv[0] = h.x; pv[8] = h.y; pv[16] = h.z; pv[24] = h.w;
-        pv += 1024;
-        pv[0] = l.x; pv[8] = l.y; pv[16] = l.z; pv[24] = l.w;
+        if (NPL == 2) {
+            pv += 1024;
+            pv[0] = l.x; pv[8] = l.y; pv[16] = l.z; pv[24] = l.w;
+        }
     }
 }
 
@@ -585,4 +614,6 @@ __device__ __forceinline__ void gru_layer_x(const float* __restrict__ W, const G
     __syncthreads();
 }
 
+}  // namespace TB_XNS
+using namespace TB_XNS;
 }  // namespace tb

@@ -21,10 +21,11 @@ struct tb_ctx {
     float* d_arena = nullptr;
     size_t arena_floats = 0;
     tb::PolicyW pw;
-    tb::PolicyWX px;
+    tb::PolicyWX px;   // fp16-pair packings
+    tb::PolicyWX pxb;  // bf16 packings (operand_precision = 1)
     tb::EncoderW ew;
     bool finalized = false;
-    int step_kernel = 2;  // 2: k_step_x (fp16-pair XDL MFMA, default)  0: k_step (fp32 MFMA)  1: k_step8 (fp32 MFMA, 8 waves); TB_STEP_KERNEL overrides
+    int step_kernel = 2;  // 2: k_step_x (fp16-pair XDL MFMA, default)  3: k_step_x, bf16 operands (tb_config.operand_precision = 1)  0: k_step (fp32 MFMA)  1: k_step8 (fp32 MFMA, 8 waves); TB_STEP_KERNEL overrides
     // workspace
     char* d_ws = nullptr;
     size_t ws_bytes = 0;

@@ -1,7 +1,6 @@
 // Kernel-side parameter blocks of the rollout path (passed by value as kernel arguments).
 #pragma once
 #include "tb_device.hpp"
-#include "tb_device_xdl.hpp"
 
 namespace tb {
 
@@ -26,7 +25,14 @@ struct PolicyW {
     float dt;
 };
 
-// offsets of the split-bf16 (XDL) packings of the policy Linears (same arena; biases / LN parameters come from PolicyW)
+// offsets (in floats, into the same arena) of the XDL packings of the policy Linears: fp16 pairs or plain bf16
+// (tb_device_xdl.hpp); biases / LN parameters come from PolicyW
+struct XLayerX {
+    uint32_t wq, wkv, wo, w1, w2;
+};
+struct GruLayerX {
+    uint32_t wih, whh;
+};
 struct PolicyWX {
     XLayerX as2pl[3], as2tl[3], inter[3];
     GruLayerX gru[3];

@@ -3,9 +3,11 @@
 // online softmax), LayerNorm, GRU gate math, dynamics and rule checks are those of k_step; GEMM inputs live in LDS as
 // two fp16 planes instead of one fp32 tile.
 #include "tb_rollout.hpp"
+#include "tb_device_xdl.hpp"
 #include "tb_step_common.hpp"
 
 namespace tb {
+namespace TB_XNS {
 
 // LDS carve (floats): seven fp32 tiles, geometry, LN parameters, small state, four plane buffers
 constexpr int XO_X = 0;
@@ -341,4 +343,5 @@ void launch_step_x(const RolloutP& p, int t, int do_c, int do_a, hipStream_t s) 
     hipLaunchKernelGGL(k_step_x, grid, dim3(NTHREADS), STEPX_LDS_FLOATS * sizeof(float), s, p, t, do_c, do_a);
 }
 
+}  // namespace TB_XNS
 }  // namespace tb

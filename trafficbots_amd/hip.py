@@ -26,6 +26,7 @@ class TbConfig(C.Structure):
         ("max_yaw_rate", C.c_float * 3),
         ("action_log_std", C.c_float),
         ("latent_log_std", C.c_float),
+        ("operand_precision", C.c_int32),
     ]
 
 
@@ -162,4 +163,8 @@ def make_config(cfg: Dict) -> TbConfig:
         c.max_yaw_rate[i] = float(dyn[k]["max_yaw_rate"])
     c.action_log_std = float(cfg["action_head"]["log_std"])
     c.latent_log_std = float(cfg["model"]["latent_encoder"]["latent_prior"]["log_std"])
+    prec = str(cfg.get("operand_precision", "fp32"))  # not a key of the reference: "fp32" (default) or "bf16" (BASELINE configs 4/5)
+    if prec not in ("fp32", "bf16"):
+        raise ValueError(f"operand_precision must be 'fp32' or 'bf16', got {prec!r}")
+    c.operand_precision = 1 if prec == "bf16" else 0
     return c
