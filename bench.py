@@ -226,10 +226,21 @@ def main():
         del eng2
 
     # ---- metric partials + the one collective of the path (torchmetrics dist_reduce_fx="sum" states in the reference)
-    from trafficbots_amd.shard import all_reduce_partials, metric_partials
+    from trafficbots_amd.shard import PARTIAL_FIELDS, all_reduce_partials, metric_partials
 
     part = metric_partials(out["preds"], out["valid"], out["outside_map"], out["dest_reached"], B_PER_GPU, STEP_END)
-    red, elapsed = all_reduce_partials(part, elapsed)
+    # the reference's own metric states for this buffer (TrafficRuleMetrics sums; no ground-truth future in the test split, so the
+    # ErrorMetrics sums stay 0): tb_metric_partials, appended to the same all-reduced vector
+    from trafficbots_amd.runtime import METRIC_FIELDS
+
+    k1 = lambda x: x.reshape(B_PER_GPU, N_AGENT, 1, *x.shape[2:])  # noqa: E731  [N,A,S,..] -> [B,A,K=1,S,..]
+    ref_part = eng.metric_partials(
+        k1(out["valid"]), k1(out["preds"]), k1(out["override_masks"]),
+        {"outside_map": k1(out["outside_map"]), "dest_reached": k1(out["dest_reached"])},
+        scene["agent_type"], torch.from_numpy(batch["history/agent/role"]))
+    red_all, elapsed = all_reduce_partials(torch.cat([part, ref_part]), elapsed, fields=PARTIAL_FIELDS + METRIC_FIELDS)
+    red = {k: red_all[k] for k in PARTIAL_FIELDS}
+    ref_metrics = {k: red_all[k] for k in METRIC_FIELDS}
     finite = bool(torch.isfinite(out["preds"]).all())
 
     if rank == 0:
@@ -263,6 +274,9 @@ def main():
                                  "workgroups (one per 16 agents) occupy 128 of 256 CUs at this batch size",
                          "load_path": load_path(k_us)},
             "checks": dict(finite=finite, **red),
+            "reference_metric_states": dict(ref_metrics, note="sum-states of the reference's TrafficRuleMetrics / ErrorMetrics over all ranks "
+                                            "(tb_metric_partials + the all-reduce); e.g. dest_reached / counter_agent = "
+                                            f"{ref_metrics['dest_reached'] / max(1.0, ref_metrics['counter_agent']):.4f}"),
             "two_batches_in_flight": two_stream,
         }
         if world == 1 and not args.no_cpu_baseline:

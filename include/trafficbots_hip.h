@@ -227,6 +227,33 @@ typedef struct tb_post_io {
 } tb_post_io;
 int tb_post_process(tb_ctx* ctx, const tb_post_io* io, tb_stream stream);
 
+/* Metric partials of a rollout buffer: the thirteen "sum" states of the reference's torchmetrics classes, in this order:
+ *   ErrorMetrics (src/models/metrics/logging.py:9-54):        err_counter, err_pos_meter, err_rot_deg, err_spd_m_per_s
+ *   TrafficRuleMetrics (:68-129): counter_agent, counter_veh, outside_map, collided, run_road_edge, run_red_light, passive,
+ *                                 goal_reached, dest_reached
+ * These are what a multi-GPU run SUM-all-reduces (dist_reduce_fx="sum"); the ratios of `compute()` are formed afterwards.
+ * gt_valid / gt_states may be NULL (no ground truth: the four error sums are 0).  All masks uint8. */
+typedef struct tb_metric_io {
+    int32_t n_scene, n_agent, k_futures, n_step;
+    int32_t loss_for_teacher_forcing;
+    const uint8_t* pred_valid;      /* [B,A,K,S] */
+    const float* pred_states;       /* [B,A,K,S,4] */
+    const uint8_t* override_masks;  /* [B,A,K,S] */
+    const uint8_t* gt_valid;        /* [B,A,S] or NULL */
+    const float* gt_states;         /* [B,A,S,4] or NULL */
+    const uint8_t* agent_role;      /* [B,A,3] */
+    const int32_t* agent_type;      /* [B,A] */
+    const uint8_t* outside_map;     /* [B,A,K,S] each */
+    const uint8_t* collided;
+    const uint8_t* run_road_edge;
+    const uint8_t* run_red_light;
+    const uint8_t* passive;
+    const uint8_t* goal_reached;
+    const uint8_t* dest_reached;
+    double* out;                    /* [13] device buffer */
+} tb_metric_io;
+int tb_metric_partials(tb_ctx* ctx, const tb_metric_io* io, tb_stream stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -385,6 +385,35 @@ def test_bf16_operand_mode():
         WaymoMotion(operand_precision="fp8")
 
 
+def test_metric_partials_kernel():
+    """`tb_metric_partials` against the states the reference's ErrorMetrics / TrafficRuleMetrics accumulated (metrics.npz): the nine
+    counters exactly, the three error sums to 1e-5 relative (fp32 summation order)."""
+    import json
+
+    from conftest import GOLDEN_DIR
+    from trafficbots_amd import synth
+    from trafficbots_amd.config import load_model_config
+    from trafficbots_amd.runtime import METRIC_FIELDS, HipEngine
+
+    g = np.load(os.path.join(GOLDEN_DIR, "metrics.npz"))
+    meta = json.loads(bytes(g["meta_json"]).decode())
+    assert tuple(meta["fields"]) == METRIC_FIELDS
+    eng = HipEngine(load_model_config())
+    for name, c in meta["cases"].items():
+        d = {k: torch.from_numpy(v) for k, v in synth.make_metric_inputs(c["seed"], c["n_scene"], c["n_agent"], c["k"], c["n_step"]).items()}
+        vio = {k: d[k] for k in ("outside_map", "collided", "run_road_edge", "run_red_light", "passive", "goal_reached", "dest_reached")}
+        out = eng.metric_partials(d["pred_valid"], d["pred_states"], d["override_masks"], vio, d["agent_type"], d["agent_role"],
+                                  d["gt_valid"], d["gt_states"], c["tf"]).cpu().numpy()
+        ref = g[name]
+        counters = [0, 4, 5, 6, 7, 8, 9, 10, 11, 12]
+        assert np.array_equal(out[counters], ref[counters]), (name, out, ref)
+        assert np.allclose(out[1:4], ref[1:4], rtol=1e-5, atol=0), (name, out[1:4], ref[1:4])
+        # without ground truth the error sums stay zero and the rule sums do not change
+        out2 = eng.metric_partials(d["pred_valid"], d["pred_states"], d["override_masks"], vio, d["agent_type"], d["agent_role"],
+                                   None, None, c["tf"]).cpu().numpy()
+        assert np.array_equal(out2[:4], np.zeros(4)) and np.array_equal(out2[4:], out[4:])
+
+
 def test_empty_and_bad_inputs_fail_loudly():
     from trafficbots_amd import synth
     from trafficbots_amd.waymo_motion import WaymoMotion

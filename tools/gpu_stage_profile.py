@@ -17,7 +17,7 @@ from trafficbots_amd.runtime import HipEngine, scene_from_batch  # noqa: E402
 NAMES = ["C: tile/geometry loads", "C: interaction x3", "C: GRU x3", "C: add_goal", "C: add_latent", "C: action head",
          "C: epilogue", "A: attr+PE+encoder", "A: as2pl x3", "A: as2tl x3", "A: interaction K/V proj x3"]
 
-cfg = load_model_config()
+cfg = load_model_config(overrides={"operand_precision": os.environ.get("TB_PRECISION", "fp32")})
 sd = synth.make_state_dict(7)
 b, a, p, t = 32, 64, 256, 40
 batch = synth.make_batch(5000, b, n_agent=a, n_pl=p, n_tl=t)

@@ -36,6 +36,7 @@ int run_encode(struct ::tb_ctx* ctx, const tb_encode_io* io, hipStream_t s);
 int run_rule_checks(const tb_rule_io* io, int n_hist, int step_start, uint8_t* raw_ws, hipStream_t s);
 hipError_t configure_rule_kernels();
 void launch_post_process(const tb_post_io& io, hipStream_t s);
+void launch_metric_partials(const tb_metric_io& io, hipStream_t s);
 }  // namespace tb
 
 // ---------------------------------------------------------------------------------------------------
@@ -705,6 +706,21 @@ extern "C" int tb_post_process(tb_ctx* ctx, const tb_post_io* io, tb_stream stre
     for (const void* q : need)
         if (!q) return tb_fail(ctx, "tb_post_process: a required buffer pointer is NULL");
     tb::launch_post_process(*io, (hipStream_t)stream_);
+    TB_HIP(ctx, hipGetLastError());
+    return 0;
+}
+
+// ---- ErrorMetrics / TrafficRuleMetrics partial sums (tb_metrics_kernels.hip) -----------------------------------------
+extern "C" int tb_metric_partials(tb_ctx* ctx, const tb_metric_io* io, tb_stream stream_) {
+    if (!ctx || !io) return 1;
+    TB_HIP(ctx, hipSetDevice(ctx->device));
+    if (io->n_scene <= 0 || io->n_agent <= 0 || io->k_futures <= 0 || io->n_step <= 0) return tb_fail(ctx, "tb_metric_partials: empty dimension");
+    if ((io->gt_valid == nullptr) != (io->gt_states == nullptr)) return tb_fail(ctx, "tb_metric_partials: gt_valid and gt_states go together");
+    const void* need[] = {io->pred_valid, io->pred_states, io->override_masks, io->agent_role, io->agent_type, io->outside_map,
+                          io->collided, io->run_road_edge, io->run_red_light, io->passive, io->goal_reached, io->dest_reached, io->out};
+    for (const void* q : need)
+        if (!q) return tb_fail(ctx, "tb_metric_partials: a required buffer pointer is NULL");
+    tb::launch_metric_partials(*io, (hipStream_t)stream_);
     TB_HIP(ctx, hipGetLastError());
     return 0;
 }

@@ -85,10 +85,21 @@ class TbPostIO(C.Structure):
     ]
 
 
+class TbMetricIO(C.Structure):
+    _fields_ = [
+        ("n_scene", C.c_int32), ("n_agent", C.c_int32), ("k_futures", C.c_int32), ("n_step", C.c_int32),
+        ("loss_for_teacher_forcing", C.c_int32),
+        ("pred_valid", c_u8p), ("pred_states", c_f32p), ("override_masks", c_u8p), ("gt_valid", c_u8p), ("gt_states", c_f32p),
+        ("agent_role", c_u8p), ("agent_type", c_i32p),
+        ("outside_map", c_u8p), ("collided", c_u8p), ("run_road_edge", c_u8p), ("run_red_light", c_u8p), ("passive", c_u8p),
+        ("goal_reached", c_u8p), ("dest_reached", c_u8p), ("out", C.POINTER(C.c_double)),
+    ]
+
+
 EXPORTS = (
     "tb_create", "tb_destroy", "tb_last_error", "tb_version", "tb_load_weight", "tb_finalize_weights",
     "tb_rollout", "tb_rollout_begin", "tb_rollout_step", "tb_rollout_state", "tb_encode_scene", "tb_set_timing", "tb_get_timing",
-    "tb_rule_checks", "tb_post_process",
+    "tb_rule_checks", "tb_post_process", "tb_metric_partials",
 )
 
 _lib: Optional[C.CDLL] = None
@@ -136,6 +147,8 @@ def load() -> C.CDLL:
     lib.tb_rule_checks.restype = C.c_int
     lib.tb_post_process.argtypes = [C.c_void_p, C.POINTER(TbPostIO), C.c_void_p]
     lib.tb_post_process.restype = C.c_int
+    lib.tb_metric_partials.argtypes = [C.c_void_p, C.POINTER(TbMetricIO), C.c_void_p]
+    lib.tb_metric_partials.restype = C.c_int
     lib.tb_set_timing.argtypes = [C.c_void_p, C.c_int]
     lib.tb_set_timing.restype = C.c_int
     lib.tb_get_timing.argtypes = [C.c_void_p, c_f32p]

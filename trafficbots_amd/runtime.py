@@ -39,6 +39,8 @@ def teacher_forcing_mask(valid: Tensor, step_spawn_agent: int = 10, step_warm_st
     return m
 
 
+METRIC_FIELDS = ("err_counter", "err_pos_meter", "err_rot_deg", "err_spd_m_per_s", "counter_agent", "counter_veh", "outside_map",
+                 "collided", "run_road_edge", "run_red_light", "passive", "goal_reached", "dest_reached")
 RULE_KEYS = ("collided", "collided_this_step", "run_road_edge", "run_road_edge_this_step", "run_red_light",
              "run_red_light_this_step", "passive", "passive_this_step")
 
@@ -286,6 +288,47 @@ class HipEngine:
             setattr(io, name, hip.ptr(out[name], hip.c_u8p))
         out["_keepalive"] = (cs, cv, s)
         self._check(self.lib.tb_rule_checks(self._ctx, C.byref(io), self._stream()), "tb_rule_checks")
+        return out
+
+    def metric_partials(self, pred_valid: Tensor, pred_states: Tensor, override_masks: Tensor, violations: Dict[str, Tensor],
+                        agent_type: Tensor, agent_role: Tensor, gt_valid: Optional[Tensor] = None, gt_states: Optional[Tensor] = None,
+                        loss_for_teacher_forcing: bool = False) -> Tensor:
+        """The thirteen `dist_reduce_fx="sum"` states of the reference's `ErrorMetrics` / `TrafficRuleMetrics`
+        (`src/models/metrics/logging.py:9-129`) for one rollout buffer, as a float64 device vector in `METRIC_FIELDS` order
+        (`tb_metric_partials`) -- the packed partials the path's one collective sums over ranks.  Buffer tensors are
+        [B,A,K,S(,4)], agent_type [B,A] index, agent_role [B,A,3], ground truth [B,A,S(,4)] or None."""
+        dev, u8, f32 = self.device, torch.uint8, torch.float32
+        b, a, k, n_step = pred_valid.shape
+        io = hip.TbMetricIO()
+        io.n_scene, io.n_agent, io.k_futures, io.n_step, io.loss_for_teacher_forcing = b, a, k, n_step, int(loss_for_teacher_forcing)
+        keep = []
+
+        def c8(t):
+            t = t.to(dev).to(u8).contiguous()
+            keep.append(t)
+            return hip.ptr(t, hip.c_u8p)
+
+        def cf(t):
+            t = t.to(dev).to(f32).contiguous()
+            keep.append(t)
+            return hip.ptr(t, hip.c_f32p)
+
+        io.pred_valid, io.pred_states, io.override_masks = c8(pred_valid), cf(pred_states), c8(override_masks)
+        io.gt_valid = c8(gt_valid) if gt_valid is not None else hip.ptr(None, hip.c_u8p)
+        io.gt_states = cf(gt_states) if gt_states is not None else hip.ptr(None, hip.c_f32p)
+        io.agent_role = c8(agent_role)
+        ty = agent_type.to(dev)
+        ty = (ty.to(torch.int32).argmax(-1) if ty.dim() == 3 else ty).to(torch.int32).contiguous()
+        keep.append(ty)
+        io.agent_type = hip.ptr(ty, hip.c_i32p)
+        zeros = torch.zeros(b, a, k, n_step, device=dev, dtype=u8)
+        keep.append(zeros)
+        for name in ("outside_map", "collided", "run_road_edge", "run_red_light", "passive", "goal_reached", "dest_reached"):
+            setattr(io, name, c8(violations[name]) if name in violations else hip.ptr(zeros, hip.c_u8p))
+        out = torch.zeros(len(METRIC_FIELDS), device=dev, dtype=torch.float64)
+        io.out = C.cast(C.c_void_p(out.data_ptr()), C.POINTER(C.c_double))
+        self._check(self.lib.tb_metric_partials(self._ctx, C.byref(io), self._stream()), "tb_metric_partials")
+        self._metric_keepalive = keep
         return out
 
     def rollout_step(self) -> None:

@@ -36,12 +36,13 @@ def metric_partials(preds: Tensor, valid: Tensor, outside_map: Tensor, dest_reac
     ])
 
 
-def all_reduce_partials(partial: Tensor, elapsed_s: float) -> Tuple[Dict[str, float], float]:
-    """SUM the partials and MAX the elapsed time over the default process group (no-op when not initialised)."""
+def all_reduce_partials(partial: Tensor, elapsed_s: float, fields=PARTIAL_FIELDS) -> Tuple[Dict[str, float], float]:
+    """SUM the partials and MAX the elapsed time over the default process group (no-op when not initialised).  `fields` names the
+    entries of `partial` (default: PARTIAL_FIELDS; bench.py appends the reference's thirteen metric states, runtime.METRIC_FIELDS)."""
     import torch.distributed as dist
 
     t = torch.tensor([elapsed_s], device=partial.device, dtype=torch.float64)
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         dist.all_reduce(partial, op=dist.ReduceOp.SUM)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    return {k: float(partial[i]) for i, k in enumerate(PARTIAL_FIELDS)}, float(t.item())
+    return {k: float(partial[i]) for i, k in enumerate(fields)}, float(t.item())

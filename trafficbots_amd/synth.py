@@ -193,6 +193,31 @@ def make_post_inputs(seed: int, n_scene: int, n_agent: int, n_pred: int, n_step:
     return valid, scores, trajs, agent_type
 
 
+def make_metric_inputs(seed: int, n_scene: int, n_agent: int, k: int, n_step: int):
+    """Seeded inputs of `ErrorMetrics.update` / `TrafficRuleMetrics.update` (`src/models/metrics/logging.py`): a rollout buffer
+    ([B,A,K,S] masks and [B,A,K,S,4] states), ground truth ([B,A,S], [B,A,S,4]), agent type / role one-hots."""
+    rs = RawStream(seed)
+    shp = (n_scene, n_agent, k, n_step)
+    d = {
+        "pred_valid": ~rs.bernoulli(0.15, shp),
+        "override_masks": rs.bernoulli(0.1, shp),
+        "gt_valid": ~rs.bernoulli(0.2, (n_scene, n_agent, n_step)),
+    }
+    gt = np.concatenate([rs.uniform(-80, 80, (n_scene, n_agent, n_step, 2)), rs.uniform(-6.5, 6.5, (n_scene, n_agent, n_step, 1)),
+                         rs.uniform(0, 20, (n_scene, n_agent, n_step, 1))], -1)
+    noise = np.concatenate([rs.uniform(-3, 3, shp + (2,)), rs.uniform(-7, 7, shp + (1,)), rs.uniform(-2, 2, shp + (1,))], -1)
+    d["gt_states"] = gt.astype(np.float32)
+    d["pred_states"] = (gt[:, :, None] + noise).astype(np.float32)
+    for name, pr in (("outside_map", 0.01), ("collided", 0.03), ("run_road_edge", 0.02), ("run_red_light", 0.005), ("passive", 0.01),
+                     ("goal_reached", 0.02), ("dest_reached", 0.05)):
+        d[name] = rs.bernoulli(pr, shp)
+    ty = rs.integers(3, (n_scene, n_agent))
+    d["agent_type"] = np.zeros((n_scene, n_agent, 3), bool)
+    np.put_along_axis(d["agent_type"], ty[..., None], True, -1)
+    d["agent_role"] = rs.bernoulli(0.4, (n_scene, n_agent, 3))
+    return d
+
+
 def make_latent_noise(seed: int, n_inst: int, n_agent: int, latent_dim: int = 16) -> np.ndarray:
     """Standard-normal draws eps[N, A, latent_dim] for the CVAE personality samples (the reference
     draws them from torch's CPU stream, `distributions.py:26-31`; goldens pass them explicitly)."""
