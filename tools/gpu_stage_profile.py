@@ -54,8 +54,8 @@ for i in range(3):
     v = d_a[:, i]
     print(f"  {NAMES[8 + i]:32s} {np.median(v):9.0f}  [{v.min():8.0f} .. {v.max():8.0f}]")
     tot += np.median(v)
-v = st[:, 8] - st[:, 7]
-print(f"  {NAMES[7]:32s} {np.median(v):9.0f}  [{v.min():8.0f} .. {v.max():8.0f}]   (stamp 7 is from the last launch: only indicative)")
+v = st[:, 8] - st[:, 30]
+print(f"  {NAMES[7]:32s} {np.median(v):9.0f}  [{v.min():8.0f} .. {v.max():8.0f}]   (k_step_x only)")
 print(f"  sum of medians (without A front-end) {tot:9.0f}")
 seq = [0, 12, 13, 14, 15, 1]
 lab = ["LN params -> LDS (issue+store)", "row state loads (16 thr)", "valid ballots", "wload + 6 tile loads + geometry issue", "barrier (wait for all)"]

@@ -474,4 +474,168 @@ __device__ __forceinline__ void step_encode_inputs(const RolloutP& p, int t, int
     __syncthreads();
 }
 
+// ---- faster head of A(t+1) for k_step_x: the InputPeEncoder weights and the PE frequencies sit in LDS (transposed: lanes of
+// a row read consecutive outputs), and sin / cos are an fp64 Cody-Waite reduction + Taylor polynomial (|r| <= pi/4: truncation
+// < 1e-11, far below half an fp32 ulp) instead of the library's general-purpose double sincos.  The scalar-per-lane global
+// weight reads and the library call made this stage 28 k cycles per launch; same arithmetic for the MLP (fp32 fmaf chain in k
+// order) and correctly rounded PE values as before.
+constexpr int ENCW_W1T = 0;               // [11][32]
+constexpr int ENCW_B1 = ENCW_W1T + 352;   // [32]
+constexpr int ENCW_W2T = ENCW_B1 + 32;    // [32][32]
+constexpr int ENCW_B2 = ENCW_W2T + 1024;  // [32]
+constexpr int ENCW_FXY = ENCW_B2 + 32;    // [12]
+constexpr int ENCW_FYAW = ENCW_FXY + 12;  // [24]
+constexpr int ENCW_FLOATS = ENCW_FYAW + 24 + 4;
+
+struct EncWRegs {
+    f32x4 v[2];
+};
+
+// region table of the 369 float4 the encoder needs: (first float4 index, arena offset)
+__device__ __forceinline__ const float* encw_src(const PolicyW& pw, const float* W, int q, int& region, int& local) {
+    const int first[7] = {0, 88, 96, 352, 360, 363, 369};
+    const uint32_t off[6] = {pw.enc_w1, pw.enc_b1, pw.enc_w2, pw.enc_b2, pw.pe_fxy, pw.pe_fyaw};
+    region = 0;
+#pragma unroll
+    for (int r = 1; r < 6; ++r)
+        if (q >= first[r]) region = r;
+    local = q - first[region];
+    return W + off[region] + local * 4;
+}
+
+__device__ __forceinline__ void encw_issue(const PolicyW& pw, const float* W, int tid, EncWRegs& r) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int q = tid + i * 256;
+        int region, local;
+        const float* src = encw_src(pw, W, q < 369 ? q : 0, region, local);
+        r.v[i] = ldg4(src);
+    }
+}
+
+__device__ __forceinline__ void encw_commit(int tid, const EncWRegs& r, float* ENCW) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int q = tid + i * 256;
+        if (q >= 369) continue;
+        const int first[7] = {0, 88, 96, 352, 360, 363, 369};
+        int region = 0;
+#pragma unroll
+        for (int rr = 1; rr < 6; ++rr)
+            if (q >= first[rr]) region = rr;
+        const int local = q - first[region];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int idx = local * 4 + e;
+            const float val = r.v[i][e];
+            if (region == 0) ENCW[ENCW_W1T + (idx % 11) * 32 + idx / 11] = val;        // W1 [32][11] -> [11][32]
+            else if (region == 1) ENCW[ENCW_B1 + idx] = val;
+            else if (region == 2) ENCW[ENCW_W2T + (idx & 31) * 32 + (idx >> 5)] = val;  // W2 [32][32] -> transposed
+            else if (region == 3) ENCW[ENCW_B2 + idx] = val;
+            else if (region == 4) ENCW[ENCW_FXY + idx] = val;
+            else ENCW[ENCW_FYAW + idx] = val;
+        }
+    }
+}
+
+// sin and cos of an fp32 argument (|x| < ~1e5), evaluated in fp64 and rounded once
+__device__ __forceinline__ void sincos_pe(float xf, float& s_out, float& c_out) {
+    const double x = (double)xf;
+    const double n = rint(x * 0.63661977236758134308);  // 2/pi
+    double r = fma(-n, 1.57079632679489655800e+00, x);  // pi/2 in two pieces
+    r = fma(-n, 6.12323399573676603587e-17, r);
+    const double r2 = r * r;
+    double sp = fma(r2, -2.50521083854417187751e-08, 2.75573192239858906526e-06);  // 1/11!, 1/9!
+    sp = fma(r2, sp, -1.98412698412698412698e-04);
+    sp = fma(r2, sp, 8.33333333333333333333e-03);
+    sp = fma(r2, sp, -1.66666666666666666667e-01);
+    const double sv = fma(r * r2, sp, r);
+    double cp = fma(r2, 2.08767569878680989792e-09, -2.75573192239858906526e-07);  // 1/12!, 1/10!
+    cp = fma(r2, cp, 2.48015873015873015873e-05);
+    cp = fma(r2, cp, -1.38888888888888888889e-03);
+    cp = fma(r2, cp, 4.16666666666666666667e-02);
+    cp = fma(r2, cp, -0.5);
+    const double cv = fma(r2, cp, 1.0);
+    const int qd = (int)n & 3;
+    const double ss = (qd & 1) ? cv : sv, cc = (qd & 1) ? sv : cv;
+    s_out = (float)((qd & 2) ? -ss : ss);
+    c_out = (float)(((qd + 1) & 2) ? -cc : cc);
+}
+
+__device__ __forceinline__ void step_encode_inputs_lds(const RolloutP& p, int b, int row0, int n_real, int tid, const StepSmall& sm,
+                                                       const float* ENCW, float* X) {
+    float* attr = sm.attr; float* ench = sm.ench; const RowSt* rst = sm.rst; const uint8_t* rowvalid = sm.rowvalid;
+    const int* rtype = sm.rtype;
+    // ---- agent attributes (sc_input.py:142-165): vel2, spd, yaw_rate, acc, size3, type one-hot3
+    if (tid < TM) {
+        const int row = row0 + tid;
+        float* a = attr + tid * 16;
+        const int ty = rtype[tid];
+        f32x4 sz = splat(0.f);
+        if (tid < n_real) {
+            const float* s = p.agent_size + ((size_t)b * p.n_agent + row) * 3;
+            sz = f32x4{s[0], s[1], s[2], 0.f};
+        }
+        a[0] = rst[tid].aux[0]; a[1] = rst[tid].aux[1]; a[2] = rst[tid].st[3]; a[3] = rst[tid].aux[3]; a[4] = rst[tid].aux[2];
+        a[5] = sz.x; a[6] = sz.y; a[7] = sz.z;
+        a[8] = ty == 0 ? 1.f : 0.f; a[9] = ty == 1 ? 1.f : 0.f; a[10] = ty == 2 ? 1.f : 0.f;
+    }
+    __syncthreads();
+    const int row = tid >> 4, i = tid & 15, o0 = i * 2;
+    // ---- pose PE (pose_pe.py:57-62, pos_emb.py:24-25,54-55): 48 sincos per row, 3 per thread
+    {
+        const float px = rst[row].st[0], py = rst[row].st[1], pyaw = rst[row].st[2];
+        float* xr = X + row * LDT + 32;
+#pragma unroll
+        for (int uu = 0; uu < 3; ++uu) {
+            const int j = i * 3 + uu;
+            float arg;
+            int c_cos, c_sin;
+            if (j < 12) {
+                arg = px * ENCW[ENCW_FXY + j]; c_cos = j; c_sin = 12 + j;
+            } else if (j < 24) {
+                arg = py * ENCW[ENCW_FXY + j - 12]; c_cos = 24 + (j - 12); c_sin = 36 + (j - 12);
+            } else {
+                arg = pyaw * ENCW[ENCW_FYAW + j - 24]; c_cos = 48 + (j - 24); c_sin = 72 + (j - 24);
+            }
+            float sv, cv;
+            sincos_pe(arg, sv, cv);
+            xr[c_cos] = cv;
+            xr[c_sin] = sv;
+        }
+    }
+    // ---- InputPeEncoder MLP 11 -> 32 -> 32 (input_pe_encoder.py:52-54), 2 outputs per thread
+    {
+        float s0 = ENCW[ENCW_B1 + o0], s1 = ENCW[ENCW_B1 + o0 + 1];
+#pragma unroll
+        for (int k = 0; k < 11; ++k) {
+            const float a = attr[row * 16 + k];
+            s0 = fmaf(a, ENCW[ENCW_W1T + k * 32 + o0], s0);
+            s1 = fmaf(a, ENCW[ENCW_W1T + k * 32 + o0 + 1], s1);
+        }
+        ench[row * 32 + o0] = fmaxf(s0, 0.f);
+        ench[row * 32 + o0 + 1] = fmaxf(s1, 0.f);
+    }
+    __syncthreads();
+    {
+        float s0 = ENCW[ENCW_B2 + o0], s1 = ENCW[ENCW_B2 + o0 + 1];
+#pragma unroll
+        for (int k = 0; k < 32; ++k) {
+            const float h = ench[row * 32 + k];
+            s0 = fmaf(h, ENCW[ENCW_W2T + k * 32 + o0], s0);
+            s1 = fmaf(h, ENCW[ENCW_W2T + k * 32 + o0 + 1], s1);
+        }
+        const bool rv = rowvalid[row] != 0;  // zero invalid rows (input_pe_encoder.py:59)
+        X[row * LDT + o0] = rv ? s0 : 0.f;
+        X[row * LDT + o0 + 1] = rv ? s1 : 0.f;
+    }
+    __syncthreads();
+    // the PE part of invalid rows
+    for (int q = tid; q < TM * 24; q += 256) {
+        const int r = q / 24;
+        if (!rowvalid[r]) st4(X + r * LDT + 32 + (q - r * 24) * 4, splat(0.f));
+    }
+    __syncthreads();
+}
+
 }  // namespace tb

@@ -20,7 +20,8 @@ constexpr int XO_Y = XO_LP + TM * LDT;
 constexpr int XO_DG = XO_Y + TM * LDT;
 constexpr int XO_LN = XO_DG + TM * 80;
 constexpr int XO_SMALL = XO_LN + 9 * 768;
-constexpr int XO_PL = XO_SMALL + SMALL_FLOATS;  // 4 x [2][16][LDP] fp16
+constexpr int XO_ENCW = XO_SMALL + SMALL_FLOATS;  // InputPeEncoder weights + PE frequencies (transposed, step_encode_inputs_lds)
+constexpr int XO_PL = XO_ENCW + ENCW_FLOATS;    // 4 x [2][16][LDP] fp16
 constexpr int PLANES_FLOATS = PLANES_BYTES / 4;
 constexpr int STEPX_LDS_FLOATS = XO_PL + 4 * PLANES_FLOATS;
 static_assert(XO_PL % 4 == 0, "plane buffers must be 16-byte aligned");
@@ -77,6 +78,7 @@ __global__ __launch_bounds__(NTHREADS) void k_step_x(RolloutP p, int t, int do_c
     float* LP = smem + XO_LP;
     float* DG = smem + XO_DG;
     float* LN = smem + XO_LN;
+    float* ENCW = smem + XO_ENCW;
     xhalf* PA = reinterpret_cast<xhalf*>(smem + XO_PL);
     xhalf* PB = PA + NPL * PLANE;
     xhalf* PC = PB + NPL * PLANE;
@@ -114,6 +116,7 @@ __global__ __launch_bounds__(NTHREADS) void k_step_x(RolloutP p, int t, int do_c
     int rs_ty = -1;
     uint8_t rs_v = 0, rs_g = 0, vb[4] = {0, 0, 0, 0};
     CInputs<NTHREADS> cin;
+    EncWRegs encw;
     TB_SCHED_FENCE();
     wloadx(u, do_c ? xlayer_first_x(W, pw.inter[0], px.inter[0], wave) : xlayer_first_x(W, pw.as2pl[0], px.as2pl[0], wave), lane);
     if (tid < TM) {
@@ -133,7 +136,9 @@ __global__ __launch_bounds__(NTHREADS) void k_step_x(RolloutP p, int t, int do_c
 #pragma unroll
     for (int sl = 0; sl < 9; ++sl)
         if (tid < 192) lnv[sl] = ldg4(W + lnbase[sl] + tid * 4);
+    if (do_a) encw_issue(pw, W, tid, encw);
     TB_SCHED_FENCE();
+    if (do_a) encw_commit(tid, encw, ENCW);
     if (tid < TM) {
         rtype[tid] = rs_ty;
         rst[tid].st[0] = rs_st.x; rst[tid].st[1] = rs_st.y; rst[tid].st[2] = rs_st.z; rst[tid].st[3] = rs_st.w;
@@ -254,7 +259,8 @@ __global__ __launch_bounds__(NTHREADS) void k_step_x(RolloutP p, int t, int do_c
 
     // =================================== A(t+1) ===================================
     const int t1 = t + 1;
-    step_encode_inputs<NTHREADS>(p, t, n, b, row0, n_real, tid, sm, X);
+    TB_STAMP(30);
+    step_encode_inputs_lds(p, b, row0, n_real, tid, sm, ENCW, X);
     if (t1 == p.tap_step && p.tap_agent_feature)
         store_tile(p.tap_agent_feature + ((size_t)n * p.n_agent + row0) * H, X, LDT, n_real, tid);
     TB_STAMP(8);
