@@ -79,7 +79,7 @@ def cpu_baseline_worker(budget_s: float = 15.0) -> None:
 
     n_threads = usable_cpus()
     torch.set_num_threads(n_threads)
-    cfg = load_model_config(overrides={"time_step_end": STEP_END, "n_joint_future": 1, "operand_precision": args.operand_precision})
+    cfg = load_model_config(overrides={"time_step_end": STEP_END, "n_joint_future": 1})
     sd = synth.make_state_dict(7)
     orc = Oracle(sd, cfg, torch.float32, hoist=False)
 
@@ -102,12 +102,16 @@ def cpu_baseline_worker(budget_s: float = 15.0) -> None:
         b = B_PER_GPU if per_scene_step * STEP_END * B_PER_GPU <= 4 * budget_s else int(max(2, budget_s / (per_scene_step * STEP_END)))
         if b != 2:
             inp, f, mean, dest, gv = prep(b)
-        t0 = time.time()
-        orc.rollout(inp, f, mean, mean, dest, gv, 1, STEP_END)
-        dt_ = time.time() - t0
+        # repeat the rollout until ~budget_s of CPU work has been timed (at least once, at most 8 times)
+        reps, dt_ = 0, 0.0
+        while reps < 1 or (dt_ < budget_s and reps < 8):
+            t0 = time.time()
+            orc.rollout(inp, f, mean, mean, dest, gv, 1, STEP_END)
+            dt_ += time.time() - t0
+            reps += 1
     print(json.dumps({
-        "value": b * STEP_END / dt_, "unit": "scene-steps/s", "cores": int(n_threads), "kind": "port",
-        "sample": f"oracle rollout (the reference's op sequence, PyTorch-CPU fp32, {n_threads} threads) of {b} scenes x {N_AGENT} "
+        "value": reps * b * STEP_END / dt_, "unit": "scene-steps/s", "cores": int(n_threads), "kind": "port",
+        "sample": f"{reps} x oracle rollout (the reference's op sequence, PyTorch-CPU fp32, {n_threads} threads) of {b} scenes x {N_AGENT} "
                   f"agents x {N_PL} polylines x {STEP_END} steps in {dt_:.2f} s",
     }))
 

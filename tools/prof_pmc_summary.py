@@ -7,7 +7,7 @@ import statistics
 import sys
 
 root = sys.argv[1]
-kernel = sys.argv[2] if len(sys.argv) > 2 else "tb::k_step"
+kernel = sys.argv[2] if len(sys.argv) > 2 else "k_step"
 files = glob.glob(os.path.join(root, "**", "*.csv"), recursive=True)
 for f in sorted(files):
     if f.endswith("kernel_stats.csv"):
@@ -24,7 +24,7 @@ for f in sorted(files):
         rd = csv.DictReader(fh)
         for row in rd:
             name = row.get("Kernel_Name", "")
-            if not name.startswith(kernel):
+            if kernel not in name:
                 continue
             c, v = row.get("Counter_Name"), row.get("Counter_Value")
             if c is None or v is None:
