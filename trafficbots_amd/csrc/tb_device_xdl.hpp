@@ -390,16 +390,15 @@ __device__ __forceinline__ bool attention_head_x(const f32x4 (&q)[2], AttnPreX& 
 #ifdef TB_PROFILE
         if (prof && threadIdx.x == 0 && i < 2) prof[25 + i * 2] = clock64();
 #endif
-        // QK of the next block (XDL) under the exponentials of this one
+        // QK of the next block (XDL) under the exponentials of this one; its K fragments are consumed here, so the request for
+        // the block after it lands in the SAME registers (one K buffer, one V buffer: the loop stays inside the VGPR file)
         f32x4 ts[2], tc[2];
         in_vgpr(oh[0]); in_vgpr(oh[1]); in_vgpr(oc[0]); in_vgpr(oc[1]);
         attn_qk_x(kn, qh, ql, ts, tc);
         in_vgpr(ts[0]); in_vgpr(ts[1]); in_vgpr(tc[0]); in_vgpr(tc[1]);
         const f32x4 nb[2] = {kn.kb[0], kn.kb[1]};
-        KFragX k2f;
-        VFragX v1f;
-        k_load_x(k2f, kbase, bbase, kld);
-        v_load_x(v1f, vbase, kn1);
+        TB_SCHED_FENCE();
+        k_load_x(kn, kbase, bbase, kld);
         if (i == i_issue) wloadx(un, nx, lane);
         float p[8];
 #pragma unroll
@@ -417,18 +416,18 @@ __device__ __forceinline__ bool attention_head_x(const f32x4 (&q)[2], AttnPreX& 
 #ifdef TB_PROFILE
         if (prof && threadIdx.x == 0 && i < 2) prof[26 + i * 2] = clock64();
 #endif
-        // PV of this block (XDL) under the scale / mask / running max of the next
+        // PV of this block (XDL) under the scale / mask / running max of the next; then its V registers take the next block
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt) {
             if (NPL == 2) oc[dt] = mfma_h(vc.va[dt][0], pl, oc[dt]);
             oh[dt] = mfma_h(vc.va[dt][0], ph, oh[dt]);
             if (NPL == 2) oc[dt] = mfma_h(vc.va[dt][P1], ph, oc[dt]);
         }
+        TB_SCHED_FENCE();
+        v_load_x(vc, vbase, kn1);
         in_vgpr(oh[0]); in_vgpr(oh[1]); in_vgpr(oc[0]); in_vgpr(oc[1]);
         attn_stats_x(ts, tc, nb, kn1 + kq * 4, self_key, run_max, sv, new_max, alpha);  // (unused after the last block)
         TB_SCHED_FENCE();
-        kn = k2f;
-        vc = v1f;
         kc = k1;
         k1 = k2;
         k2 = kwrap(k2 + 32, n_key_pad);
