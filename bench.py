@@ -186,7 +186,6 @@ def main():
     gv = scene["agent_valid"].bool().any(1).to(torch.uint8)
 
     out = None
-    eng.set_timing(True)  # hipEventRecord markers around the per-step kernels (no host sync)
     for _ in range(args.warmup):
         out = eng.rollout(scene, feats, z, enc["latent_mean"], dest, gv, 1, STEP_END, out=out)
     torch.cuda.synchronize()
@@ -194,7 +193,9 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i in range(args.steps):
+        if i == args.steps - 1:
+            eng.set_timing(True)  # hipEventRecord markers around the per-step kernels of the LAST timed pass (no host sync)
         out = eng.rollout(scene, feats, z, enc["latent_mean"], dest, gv, 1, STEP_END, out=out)
     torch.cuda.synchronize()
     if world > 1:

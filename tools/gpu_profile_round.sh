@@ -3,6 +3,7 @@
 # one --kernel-trace --stats pass and three separate --pmc passes (never combined with other traces).  Output: gpurun_out/
 set -u
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
+rm -rf gpurun_out/prof
 mkdir -p gpurun_out/prof
 (timeout 900 python -m pytest tests -m gpu -x -q > gpurun_out/tests_gpu.log 2>&1; echo "rc=$?" >> gpurun_out/tests_gpu.log)
 tail -n 3 gpurun_out/tests_gpu.log
