@@ -254,6 +254,11 @@ typedef struct tb_metric_io {
 } tb_metric_io;
 int tb_metric_partials(tb_ctx* ctx, const tb_metric_io* io, tb_stream stream);
 
+/* sizeof() of the seven structs of this header as the library was compiled, in declaration order (tb_config, tb_rollout_io,
+ * tb_encode_io, tb_rule_io, tb_post_io, tb_metric_io) plus the pointer size -- lets a binding check its mirror of the layouts
+ * before the first call (no GPU needed). */
+void tb_struct_sizes(int32_t out[7]);
+
 #ifdef __cplusplus
 }
 #endif

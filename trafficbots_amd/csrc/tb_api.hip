@@ -254,6 +254,16 @@ tb::EncMlpW add_enc(Arena& a, Stage& s, const std::string& p, int attr_dim) {
 // ---------------------------------------------------------------------------------------------------
 extern "C" {
 
+void tb_struct_sizes(int32_t out[7]) {
+    out[0] = (int32_t)sizeof(tb_config);
+    out[1] = (int32_t)sizeof(tb_rollout_io);
+    out[2] = (int32_t)sizeof(tb_encode_io);
+    out[3] = (int32_t)sizeof(tb_rule_io);
+    out[4] = (int32_t)sizeof(tb_post_io);
+    out[5] = (int32_t)sizeof(tb_metric_io);
+    out[6] = (int32_t)sizeof(void*);
+}
+
 const char* tb_version(void) { return "trafficbots_hip 0.2 (gfx950, fp16-pair XDL MFMA 16x16x32 with fp32 accumulate; fp32 MFMA 16x16x4 kernels selectable)"; }
 
 static void step_launch(const tb_ctx* ctx, const tb::RolloutP& p, int t, int do_c, int do_a, hipStream_t s) {

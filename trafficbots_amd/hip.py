@@ -99,7 +99,7 @@ class TbMetricIO(C.Structure):
 EXPORTS = (
     "tb_create", "tb_destroy", "tb_last_error", "tb_version", "tb_load_weight", "tb_finalize_weights",
     "tb_rollout", "tb_rollout_begin", "tb_rollout_step", "tb_rollout_state", "tb_encode_scene", "tb_set_timing", "tb_get_timing",
-    "tb_rule_checks", "tb_post_process", "tb_metric_partials",
+    "tb_rule_checks", "tb_post_process", "tb_metric_partials", "tb_struct_sizes",
 )
 
 _lib: Optional[C.CDLL] = None
@@ -149,6 +149,13 @@ def load() -> C.CDLL:
     lib.tb_post_process.restype = C.c_int
     lib.tb_metric_partials.argtypes = [C.c_void_p, C.POINTER(TbMetricIO), C.c_void_p]
     lib.tb_metric_partials.restype = C.c_int
+    lib.tb_struct_sizes.argtypes = [C.POINTER(C.c_int32)]
+    lib.tb_struct_sizes.restype = None
+    sizes = (C.c_int32 * 7)()
+    lib.tb_struct_sizes(sizes)
+    mine = [C.sizeof(x) for x in (TbConfig, TbRolloutIO, TbEncodeIO, TbRuleIO, TbPostIO, TbMetricIO)] + [C.sizeof(C.c_void_p)]
+    if list(sizes) != mine:
+        raise RuntimeError(f"trafficbots_amd: ctypes struct layouts {mine} do not match the library's {list(sizes)} (stale build?)")
     lib.tb_set_timing.argtypes = [C.c_void_p, C.c_int]
     lib.tb_set_timing.restype = C.c_int
     lib.tb_get_timing.argtypes = [C.c_void_p, c_f32p]
