@@ -318,6 +318,9 @@ __device__ __forceinline__ void attn_qk_x(const KFragX& f, const xh8& qh, const 
     }
 }
 
+// 2^x for x <= 0; the clamp maps -inf (masked keys) and NaN (-inf - -inf: nothing valid yet) to an exact 0
+__device__ __forceinline__ float exp2_neg(float x) { return __builtin_amdgcn_exp2f(fmaxf(x, -160.f)); }
+
 __device__ __forceinline__ void attn_stats_x(const f32x4 (&s)[2], const f32x4 (&c)[2], const f32x4 (&kb)[2], int kb0, int self_key,
                                              float run_max, float (&sv)[8], float& new_max, float& alpha) {
     const float raw[8] = {s[0].x, s[0].y, s[0].z, s[0].w, s[1].x, s[1].y, s[1].z, s[1].w};
@@ -325,13 +328,17 @@ __device__ __forceinline__ void attn_stats_x(const f32x4 (&s)[2], const f32x4 (&
     const float bias[8] = {kb[0].x, kb[0].y, kb[0].z, kb[0].w, kb[1].x, kb[1].y, kb[1].z, kb[1].w};
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
-        const float v = fmaf(raw[r] + crs[r] * SPLIT_INV, ATTN_SCALE, bias[r]);
+        // logits in log2 units: exp(x - max) = 2^(x log2e - max log2e) is then ONE sub + v_exp_f32 per key instead of the
+        // seven instructions of the compensated exp_neg.  The exponent carries the rounding of the (logit x constant) product,
+        // ~2^-24 |x| <= 1e-6 relative in p -- the same order as the rounding of logit x scale in the reference's own softmax;
+        // closed-loop parity is unchanged within its noise (headline golden: 1.6e-4 vs fp32, 8.8e-5 vs fp64).
+        const float v = fmaf(raw[r] + crs[r] * SPLIT_INV, ATTN_SCALE * 1.44269504088896340736f, bias[r]);
         sv[r] = (kb0 + 16 * (r >> 2) + (r & 3) == self_key) ? -INFINITY : v;
     }
     float tmax = fmaxf(fmaxf(fmaxf(sv[0], sv[1]), fmaxf(sv[2], sv[3])), fmaxf(fmaxf(sv[4], sv[5]), fmaxf(sv[6], sv[7])));
     tmax = rows_max(tmax);
     new_max = fmaxf(run_max, tmax);
-    alpha = exp_neg(run_max - new_max);
+    alpha = exp2_neg(run_max - new_max);
 }
 
 struct AttnPreX {
@@ -402,7 +409,7 @@ __device__ __forceinline__ bool attention_head_x(const f32x4 (&q)[2], AttnPreX& 
         if (i == i_issue) wloadx(un, nx, lane);
         float p[8];
 #pragma unroll
-        for (int r = 0; r < 8; ++r) p[r] = exp_neg(sv[r] - new_max);
+        for (int r = 0; r < 8; ++r) p[r] = exp2_neg(sv[r] - new_max);
         run_sum = run_sum * alpha + (((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7])));
         run_max = new_max;
         xh8 ph, pl;
