@@ -321,6 +321,7 @@ __device__ __forceinline__ void attn_qk_x(const KFragX& f, const xh8& qh, const 
 // 2^x for x <= 0; the clamp maps -inf (masked keys) and NaN (-inf - -inf: nothing valid yet) to an exact 0
 __device__ __forceinline__ float exp2_neg(float x) { return __builtin_amdgcn_exp2f(fmaxf(x, -160.f)); }
 
+template <bool SELFMASK>
 __device__ __forceinline__ void attn_stats_x(const f32x4 (&s)[2], const f32x4 (&c)[2], const f32x4 (&kb)[2], int kb0, int self_key,
                                              float run_max, float (&sv)[8], float& new_max, float& alpha) {
     const float raw[8] = {s[0].x, s[0].y, s[0].z, s[0].w, s[1].x, s[1].y, s[1].z, s[1].w};
@@ -333,7 +334,7 @@ __device__ __forceinline__ void attn_stats_x(const f32x4 (&s)[2], const f32x4 (&
         // ~2^-24 |x| <= 1e-6 relative in p -- the same order as the rounding of logit x scale in the reference's own softmax;
         // closed-loop parity is unchanged within its noise (headline golden: 1.6e-4 vs fp32, 8.8e-5 vs fp64).
         const float v = fmaf(raw[r] + crs[r] * SPLIT_INV, ATTN_SCALE * 1.44269504088896340736f, bias[r]);
-        sv[r] = (kb0 + 16 * (r >> 2) + (r & 3) == self_key) ? -INFINITY : v;
+        sv[r] = (SELFMASK && kb0 + 16 * (r >> 2) + (r & 3) == self_key) ? -INFINITY : v;  // eye mask of MultiAgentTF only
     }
     float tmax = fmaxf(fmaxf(fmaxf(sv[0], sv[1]), fmaxf(sv[2], sv[3])), fmaxf(fmaxf(sv[4], sv[5]), fmaxf(sv[6], sv[7])));
     tmax = rows_max(tmax);
@@ -366,6 +367,7 @@ __device__ __forceinline__ void attention_prefetch_x(AttnPreX& a, const xhalf* _
 
 // One head over n_key_pad keys with online softmax; q = this wave's Q^T accumulators.  Returns o (normalised) and whether
 // the row had no valid key.  Same recurrences as attention_head (tb_device.hpp); the two matrix products are fp16-pair.
+template <bool SELFMASK>
 __device__ __forceinline__ bool attention_head_x(const f32x4 (&q)[2], AttnPreX& pre, const xhalf* __restrict__ Kh,
                                                  const xhalf* __restrict__ Vh, const float* __restrict__ keybias, int n_key_pad,
                                                  int kstart, int head, int lane, int self_key, f32x4 (&o)[2], WUnitX& un,
@@ -383,7 +385,7 @@ __device__ __forceinline__ bool attention_head_x(const f32x4 (&q)[2], AttnPreX& 
     {
         f32x4 s[2], c[2];
         attn_qk_x(pre.k0f, qh, ql, s, c);
-        attn_stats_x(s, c, pre.k0f.kb, kstart + kq * 4, self_key, run_max, sv, new_max, alpha);
+        attn_stats_x<SELFMASK>(s, c, pre.k0f.kb, kstart + kq * 4, self_key, run_max, sv, new_max, alpha);
     }
     // The next weight unit (the out-projection) is requested from inside the loop, two blocks before its end: loads
     // return in issue order, so a 16 KB weight request in front of the K / V stream would stall every block behind it.
@@ -433,7 +435,7 @@ __device__ __forceinline__ bool attention_head_x(const f32x4 (&q)[2], AttnPreX& 
         TB_SCHED_FENCE();
         v_load_x(vc, vbase, kn1);
         in_vgpr(oh[0]); in_vgpr(oh[1]); in_vgpr(oc[0]); in_vgpr(oc[1]);
-        attn_stats_x(ts, tc, nb, kn1 + kq * 4, self_key, run_max, sv, new_max, alpha);  // (unused after the last block)
+        attn_stats_x<SELFMASK>(ts, tc, nb, kn1 + kq * 4, self_key, run_max, sv, new_max, alpha);  // (unused after the last block)
         TB_SCHED_FENCE();
         kc = k1;
         k1 = k2;
@@ -482,7 +484,7 @@ __device__ __forceinline__ void kv_store_x(xhalf* __restrict__ Kf, xhalf* __rest
 // One pre-LN cross-attention layer, GEMMs and attention on XDL.
 //   X : [16][LDT] fp32 residual stream (LDS);  P1, P2 : plane buffers (LN output / attention output + FFN hidden)
 // ---------------------------------------------------------------------------------------------
-template <bool LNLDS = false>
+template <bool LNLDS = false, bool SELFMASK = false>
 __device__ __forceinline__ void xattn_layer_x(const float* __restrict__ W, const XLayerW& L, const XLayerX& LX, float* X, xhalf* P1,
                                               xhalf* P2, const xhalf* __restrict__ Kmat, const xhalf* __restrict__ VT,
                                               const float* __restrict__ keybias, int n_key_pad, int kstart, int self_key0,
@@ -506,7 +508,7 @@ __device__ __forceinline__ void xattn_layer_x(const float* __restrict__ W, const
     wmmax(q[0], q[1], u, b1, PLANE);
     TB_XSTAMP(18);
     f32x4 o[2];
-    const bool novalid = attention_head_x(q, apre, Kmat, VT, keybias, n_key_pad, kstart, wave, lane, self_key0 >= 0 ? self_key0 + m : -1, o, u2,
+    const bool novalid = attention_head_x<SELFMASK>(q, apre, Kmat, VT, keybias, n_key_pad, kstart, wave, lane, self_key0 >= 0 ? self_key0 + m : -1, o, u2,
                                           wstdx(W, LX.wo, W + L.bo, wave), prof);
     TB_XSTAMP(19);
     planes_store_c(P2, 2 * wave, lane, o[0]);

@@ -165,11 +165,11 @@ __global__ __launch_bounds__(NTHREADS) void k_step_x(RolloutP p, int t, int do_c
             const size_t ls = (size_t)p.a_pad * H;
             const xhalf* K0 = reinterpret_cast<const xhalf*>(p.kin + ((size_t)n * 3) * ls);
             const xhalf* V0 = reinterpret_cast<const xhalf*>(p.vtin + ((size_t)n * 3) * ls);
-            xattn_layer_x<true>(W, pw.inter[0], px.inter[0], X, PA, PB, K0, V0, kvd, p.a_pad, ks_a, row0, rowvalid, novalid_s, tid, u,
+            xattn_layer_x<true, true>(W, pw.inter[0], px.inter[0], X, PA, PB, K0, V0, kvd, p.a_pad, ks_a, row0, rowvalid, novalid_s, tid, u,
                                 xlayer_first_x(W, pw.inter[1], px.inter[1], wave), LN + 0 * 768);
-            xattn_layer_x<true>(W, pw.inter[1], px.inter[1], X, PA, PB, K0 + 2 * ls, V0 + 2 * ls, kvd, p.a_pad, ks_a, row0, rowvalid, novalid_s, tid,
+            xattn_layer_x<true, true>(W, pw.inter[1], px.inter[1], X, PA, PB, K0 + 2 * ls, V0 + 2 * ls, kvd, p.a_pad, ks_a, row0, rowvalid, novalid_s, tid,
                                 u, xlayer_first_x(W, pw.inter[2], px.inter[2], wave), LN + 1 * 768);
-            xattn_layer_x<true>(W, pw.inter[2], px.inter[2], X, PA, PB, K0 + 4 * ls, V0 + 4 * ls, kvd, p.a_pad, ks_a, row0, rowvalid,
+            xattn_layer_x<true, true>(W, pw.inter[2], px.inter[2], X, PA, PB, K0 + 4 * ls, V0 + 4 * ls, kvd, p.a_pad, ks_a, row0, rowvalid,
                                 novalid_s, tid, u, gru_first_x(W, pw.gru[0], px.gru[0], wave), LN + 2 * 768);
         }
         TB_STAMP(2);
