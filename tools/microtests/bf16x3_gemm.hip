@@ -29,6 +29,21 @@ __global__ void k_gemm(const float* __restrict__ W, const float* __restrict__ X,
                 const int k = kq * 32 + 4 * j + i;
                 acc = __builtin_amdgcn_mfma_f32_16x16x4f32(W[m * 128 + k], X[m * 128 + k], acc, 0, 0, 0);
             }
+    } else if (mode == 20) {
+        // fp16 pair WITHOUT the 2^11 scaling of the low part: x = g0 + g1, g1 = fp16(x - g0) (may be an fp16 denormal); all three
+        // products in ONE accumulator
+        for (int c = 0; c < 4; ++c) {
+            f16x8 a[2], b[2];
+            for (int e = 0; e < 8; ++e) {
+                const int k = c * 32 + kq * 8 + e;
+                const float w = W[m * 128 + k], x = X[m * 128 + k];
+                a[0][e] = (_Float16)w; a[1][e] = (_Float16)(w - (float)a[0][e]);
+                b[0][e] = (_Float16)x; b[1][e] = (_Float16)(x - (float)b[0][e]);
+            }
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[0], b[1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[1], b[0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[0], b[0], acc, 0, 0, 0);
+        }
     } else if (mode >= 12) {
         // fp16 pair: x = g0 + 2^-11 g1 (g1 = fp16((x - g0) * 2^11)); products g0g0 | (g0g1 + g1g0) * 2^-11 | g1g1 * 2^-22
         f32x4 mid = {0, 0, 0, 0}, lo = {0, 0, 0, 0};
@@ -133,9 +148,9 @@ int main() {
         printf("%-44s max|err| = %.3e   rms err / rms value = %.3e\n", nm, mx, sqrt(rms / scale));
     };
     report("host fp32 fmaf chain (k order)", f32seq.data());
-    const int modes[6] = {0, 3, 6, 9, 12, 13};
-    const char* nm[6] = {"fp32 MFMA 16x16x4 (k_step order)", "bf16 split, 3 products", "bf16 split, 6 products", "bf16 split, 9 products", "fp16 pair, 3 products", "fp16 pair, 4 products"};
-    for (int i = 0; i < 6; ++i) {
+    const int modes[7] = {0, 3, 6, 9, 12, 13, 20};
+    const char* nm[7] = {"fp32 MFMA 16x16x4 (k_step order)", "bf16 split, 3 products", "bf16 split, 6 products", "bf16 split, 9 products", "fp16 pair, 3 products", "fp16 pair, 4 products", "fp16 pair unscaled, 1 accumulator"};
+    for (int i = 0; i < 7; ++i) {
         hipLaunchKernelGGL(k_gemm, dim3(1), dim3(64), 0, 0, dW, dX, dY, modes[i]);
         std::vector<float> y(256);
         (void)hipMemcpy(y.data(), dY, 256 * 4, hipMemcpyDeviceToHost);
@@ -151,12 +166,32 @@ int main() {
                 ref[o * 16 + a] = s2;
             }
         (void)hipMemcpy(dW, W.data(), W.size() * 4, hipMemcpyHostToDevice);
-        for (int i : {0, 2, 4, 5}) {
+        for (int i : {0, 2, 4, 5, 6}) {
             hipLaunchKernelGGL(k_gemm, dim3(1), dim3(64), 0, 0, dW, dX, dY, modes[i]);
             std::vector<float> y(256);
             (void)hipMemcpy(y.data(), dY, 256 * 4, hipMemcpyDeviceToHost);
             char nm2[96];
             snprintf(nm2, sizeof nm2, "tiny w: %s", nm[i]);
+            report(nm2, y.data());
+        }
+    }
+    {
+        for (auto& w : W) w = u() * 0.088f;
+        for (auto& x : X) x = u() * u() * 0.05f;  // small, wide-dynamic-range inputs (softmax weights, small activations)
+        for (int o = 0; o < 16; ++o)
+            for (int a = 0; a < 16; ++a) {
+                double s2 = 0;
+                for (int k = 0; k < 128; ++k) s2 += (double)W[o * 128 + k] * (double)X[a * 128 + k];
+                ref[o * 16 + a] = s2;
+            }
+        (void)hipMemcpy(dW, W.data(), W.size() * 4, hipMemcpyHostToDevice);
+        (void)hipMemcpy(dX, X.data(), X.size() * 4, hipMemcpyHostToDevice);
+        for (int i : {0, 4, 6}) {
+            hipLaunchKernelGGL(k_gemm, dim3(1), dim3(64), 0, 0, dW, dX, dY, modes[i]);
+            std::vector<float> y(256);
+            (void)hipMemcpy(y.data(), dY, 256 * 4, hipMemcpyDeviceToHost);
+            char nm2[96];
+            snprintf(nm2, sizeof nm2, "small x: %s", nm[i]);
             report(nm2, y.data());
         }
     }
