@@ -532,9 +532,7 @@ __device__ __forceinline__ void xattn_layer(const float* __restrict__ W, const X
     const int kq = lane >> 4, m = lane & 15;
     TB_XSTAMP(16);
     AttnPre apre;
-#ifndef TB_LATE_KV_PREFETCH
     attention_prefetch(apre, Kmat, VT, keybias, n_key_pad, wave, lane);
-#endif
     // s = LN1(x)
     layernorm_tile<LNLDS>(X, LDT, S1, LDT, lnblk, lnblk + 128, tid);
     __syncthreads();
@@ -544,9 +542,6 @@ __device__ __forceinline__ void xattn_layer(const float* __restrict__ W, const X
     f32x4 q[2] = {u.b[0], u.b[1]};
     wmma_pf(q[0], q[1], u, S1 + m * LDT + kq * 32, u2, wstd(W + L.wo, W + L.bo, wave), lane);
     TB_XSTAMP(18);
-#ifdef TB_LATE_KV_PREFETCH
-    attention_prefetch(apre, Kmat, VT, keybias, n_key_pad, wave, lane);
-#endif
     f32x4 o[2];
     const bool novalid = attention_head(q, apre, Kmat, VT, keybias, n_key_pad, wave, lane,
                                         self_key0 >= 0 ? self_key0 + m : -1, o, prof);
