@@ -135,8 +135,8 @@ def cpu_baseline(timeout_s: float = 150.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--operand-precision", choices=["fp32", "bf16"], default="fp32",
                     help="bf16: BASELINE.json configs 4/5 operand precision (not the headline metric, which is fp32)")

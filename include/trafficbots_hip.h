@@ -62,9 +62,10 @@ typedef struct tb_rollout_io {
     /* encoded scene (outputs of encode_input_features, traffic_bots.py:109-151) */
     const float* map_feature;      /* [B,P,128] */
     const uint8_t* map_feature_valid; /* [B,P] */
-    const float* tl_feature;       /* [B,NH,T,128] */
-    const uint8_t* tl_feature_valid;  /* [B,NH,T] */
-    /* history used for init / teacher forcing (features{} of joint_future_pred, waymo_motion.py:533-546) */
+    const float* tl_feature;       /* [B,NT,T,128]  NT = n_tl_step ? n_tl_step : NH */
+    const uint8_t* tl_feature_valid;  /* [B,NT,T] */
+    /* history (test_step: NH = time_step_current+1) or full ground truth (validation: NH = 91) used for init / teacher
+     * forcing / the kill rule (features{} of joint_future_pred / reactive_replay, waymo_motion.py:533-546, 448-462) */
     const uint8_t* agent_valid;    /* [B,NH,A] */
     const float* agent_state;      /* [B,NH,A,4] x,y,yaw,spd */
     const float* agent_vel;        /* [B,NH,A,2] */
@@ -106,6 +107,13 @@ typedef struct tb_rollout_io {
      * TrafficRuleChecker.check (waymo_motion.py:311) -- input of tb_rule_checks */
     float* check_state;            /* [N,A,S,4] */
     uint8_t* check_valid;          /* [N,A,S]   */
+    /* number of steps held by tl_feature / tl_feature_valid when it differs from n_hist (0 = n_hist).  reactive_replay
+     * (waymo_motion.py:448-462) overrides from the 91-step ground truth (n_hist = 91) while the traffic-light features are
+     * those of the 11 history steps. */
+    int32_t n_tl_step;
+    /* nonzero: latent_sample / latent_mean come from the POSTERIOR (reactive_replay, waymo_motion.py:597-611), so
+     * latent_log_prob uses latent_post_dist.log_std instead of latent_prior_dist.log_std */
+    int32_t latent_posterior;
 } tb_rollout_io;
 
 /* Replaces: WaymoMotion.rollout (+ per-step WaymoMotion.forward, TrafficBots.forward, ActionHead,
@@ -160,6 +168,77 @@ typedef struct tb_encode_io {
  * (traffic_bots.py:109-151) + LatentEncoder.forward prior + GoalManager.pred_goal. */
 int tb_encode_scene(tb_ctx* ctx, const tb_encode_io* io, tb_stream stream);
 
+/* Posterior personality over a full ground-truth episode.
+ * Replaces: SceneCentricLatent.forward the latent_post inputs (sc_latent.py:150-163,196-217, eval mode) + the agent / traffic-light
+ * part of TrafficBots.encode_input_features + LatentEncoder.forward(posterior=True) (latent_encoder.py:98-136) as called by
+ * validation_step / training_step (waymo_motion.py:583,597 / 367,382).  map_feature is tb_encode_scene's output for the
+ * same scenes (the reference encodes the identical map inputs a second time). */
+typedef struct tb_posterior_io {
+    int32_t n_scene, n_agent, n_pl, n_tl, n_step;   /* n_step = ground-truth length (91), (n_step-1) % 5 == 0 */
+    const uint8_t* agent_valid;    /* [B,NS,A] */
+    const float* agent_pos;        /* [B,NS,A,2] */
+    const float* agent_yaw;        /* [B,NS,A] */
+    const float* agent_vel;        /* [B,NS,A,2] */
+    const float* agent_spd;        /* [B,NS,A] */
+    const float* agent_acc;        /* [B,NS,A] */
+    const float* agent_yaw_rate;   /* [B,NS,A] */
+    const int32_t* agent_type;     /* [B,A] */
+    const float* agent_size;       /* [B,A,3] */
+    const uint8_t* tl_valid;       /* [B,NS,T] */
+    const int32_t* tl_state;       /* [B,NS,T] */
+    const float* tl_pos;           /* [B,NS,T,2] */
+    const float* tl_dir;           /* [B,NS,T,2] */
+    const float* map_feature;      /* [B,P,128] */
+    const uint8_t* map_feature_valid; /* [B,P] */
+    float* latent_mean;            /* [B,A,16] posterior mean */
+    uint8_t* latent_valid;         /* [B,A] */
+} tb_posterior_io;
+int tb_encode_posterior(tb_ctx* ctx, const tb_posterior_io* io, tb_stream stream);
+
+/* Forward training losses of a replayed episode: the per-step differentiable reward and the six "sum" states of
+ * TrainingMetrics.
+ * Replaces: DifferentiableReward.get (src/utils/rewards.py:33-131; config group differentiable_reward,
+ * configs/model/traffic_bots.yaml:157-171) as called once per step by WaymoMotion.rollout (waymo_motion.py:320-330) -- it is
+ * a pure function of that step's prediction and ground truth, so it is evaluated over the recorded buffer -- AngularError
+ * (src/models/metrics/loss.py:9-32), BalancedKL forward value (:35-74) and TrainingMetrics.update
+ * (src/models/metrics/training.py:62-139; group training_metrics, traffic_bots.yaml:208-219).  K = 1 (reactive_replay).
+ * out[6], in this order: vae_kl_counter, vae_kl, diffbar_reward_counter, diffbar_reward, goal_loss, goal_counter -- the
+ * states a multi-GPU run SUM-all-reduces; TrainingMetrics.compute() forms the ratios.  Not built: w_relevant_agent > 0 and
+ * p_loss_for_irrelevant > 0.  Criteria: 0 SmoothL1Loss, 1 MSELoss, 2 L1Loss; angular_type: 0 null, 1 cast, 2 cosine, 3 vector. */
+typedef struct tb_train_io {
+    int32_t n_scene, n_agent, n_step, n_pl;
+    /* differentiable_reward */
+    float w_collision;
+    int32_t reduce_collision_with_max, use_il_loss;
+    int32_t crit_pos, crit_rot, angular_type, crit_spd;
+    float w_pos, w_rot, w_spd;
+    /* training_metrics */
+    int32_t use_vae_kl, use_diffbar_reward, use_goal;   /* w_* > 0 */
+    int32_t kl_for_unseen_agent, loss_for_teacher_forcing, step_training_start;
+    float kl_balance_scale, kl_free_nats;
+    /* rollout buffer (un-flattened, K = 1) */
+    const uint8_t* pred_valid;      /* [B,A,S] */
+    const float* pred_states;       /* [B,A,S,4] */
+    const uint8_t* override_masks;  /* [B,A,S] */
+    const uint8_t* gt_valid;        /* [B,A,S] or NULL (no ground truth for these steps: no imitation term) */
+    const float* gt_states;         /* [B,A,S,4] or NULL */
+    const float* agent_size;        /* [B,A,3] */
+    /* destination prediction (may be NULL when use_goal == 0) */
+    const float* dest_logits;       /* [B,A,P] masked, un-normalised (tb_encode_io.dest_logits) */
+    const uint8_t* goal_valid;      /* [B,A]  goal_pred.valid */
+    const int32_t* gt_dest;         /* [B,A] */
+    /* personalities (may be NULL when use_vae_kl == 0) */
+    const float* post_mean;         /* [B,A,16] */
+    const uint8_t* post_valid;      /* [B,A] */
+    const float* prior_mean;        /* [B,A,16] */
+    const uint8_t* prior_valid;     /* [B,A] */
+    /* outputs */
+    float* diffbar_rewards;         /* [B,A,S] */
+    uint8_t* diffbar_rewards_valid; /* [B,A,S] */
+    double* out;                    /* [6] device buffer */
+} tb_train_io;
+int tb_train_partials(tb_ctx* ctx, const tb_train_io* io, tb_stream stream);
+
 /* -- instrumentation ---------------------------------------------------------------------------------- */
 /* Per-launch durations (ms, HIP events recorded on `stream`) of the LAST tb_rollout when timing was enabled with
  * tb_set_timing(ctx, 1).  A rollout of S steps issues S+1 step launches: A(1) alone, S-1 fused launches
@@ -198,6 +277,15 @@ typedef struct tb_rule_io {
     uint8_t* run_red_light_this_step;
     uint8_t* passive;
     uint8_t* passive_this_step;
+    /* steps held by tl_valid / tl_state / tl_pos (0 = time_step_current + 1: the history, as joint_future_pred passes;
+     * reactive_replay passes the 91-step "tl_stop/..." arrays, waymo_motion.py:433-447) */
+    int32_t n_tl_step;
+    /* optional: ground-truth goal pose [B,A,4] (x,y,yaw,spd) and the goal-reached flags of
+     * TrafficRuleChecker._check_goal_reached (:337-361); the reference evaluates them whenever the batch carries
+     * "agent/goal" (validation / training).  NULL to skip. */
+    const float* agent_goal;
+    uint8_t* goal_reached;
+    uint8_t* goal_reached_this_step;
 } tb_rule_io;
 int tb_rule_checks(tb_ctx* ctx, const tb_rule_io* io, tb_stream stream);
 
@@ -254,10 +342,10 @@ typedef struct tb_metric_io {
 } tb_metric_io;
 int tb_metric_partials(tb_ctx* ctx, const tb_metric_io* io, tb_stream stream);
 
-/* sizeof() of the seven structs of this header as the library was compiled, in declaration order (tb_config, tb_rollout_io,
- * tb_encode_io, tb_rule_io, tb_post_io, tb_metric_io) plus the pointer size -- lets a binding check its mirror of the layouts
- * before the first call (no GPU needed). */
-void tb_struct_sizes(int32_t out[7]);
+/* sizeof() of the structs of this header as the library was compiled: out[0..5] = tb_config, tb_rollout_io, tb_encode_io,
+ * tb_rule_io, tb_post_io, tb_metric_io; out[6] = the pointer size; out[7..8] = tb_posterior_io, tb_train_io -- lets a binding
+ * check its mirror of the layouts before the first call (no GPU needed). */
+void tb_struct_sizes(int32_t out[9]);
 
 #ifdef __cplusplus
 }

@@ -212,6 +212,33 @@ class Oracle:
         out["tl_pe"] = self.pose_pe(g["history/tl_stop/pos"][:, :nh], torch.atan2(tl_dir[..., 1], tl_dir[..., 0]), "tl")
         return out
 
+    def preprocess_gt(self, batch: Dict[str, np.ndarray]) -> Dict[str, Tensor]:
+        """Validation-split extras: the `latent_post/*` inputs of `SceneCentricLatent.forward` (eval: no perturbation, no
+        dropout; `sc_latent.py:150-163,196-217`) and the `gt/*` tensors of `SceneCentricPreProcessing`
+        (`scene_centric.py:103-110`), all over the full ground-truth length."""
+        d = self.dtype
+        g = {k: _t(v, d) for k, v in batch.items() if k.startswith("agent/") or k.startswith("tl_stop/")}
+        if "agent/goal" in g:
+            out_goal = g["agent/goal"]
+        av = g["agent/valid"]
+        ns = av.shape[1]
+        out: Dict[str, Tensor] = {"agent_valid": av}
+        out["agent_attr"] = torch.cat(
+            [g["agent/vel"], g["agent/spd"], g["agent/yaw_rate"], g["agent/acc"],
+             g["agent/size"].unsqueeze(1).expand(-1, ns, -1, -1), g["agent/type"].unsqueeze(1).expand(-1, ns, -1, -1).to(d)], -1)
+        out["agent_pe"] = self.pose_pe(g["agent/pos"], g["agent/yaw_bbox"][..., 0], "agent")
+        out["tl_valid"] = g["tl_stop/valid"]
+        out["tl_attr"] = g["tl_stop/state"].to(d)
+        tl_dir = g["tl_stop/dir"]
+        out["tl_pe"] = self.pose_pe(g["tl_stop/pos"], torch.atan2(tl_dir[..., 1], tl_dir[..., 0]), "tl")
+        out["agent_state"] = torch.cat([g["agent/pos"], g["agent/yaw_bbox"], g["agent/spd"]], -1)
+        out["agent_vel"], out["agent_acc"], out["agent_yaw_rate"] = g["agent/vel"], g["agent/acc"], g["agent/yaw_rate"]
+        out["gt_dest"] = g["agent/dest"]
+        if "agent/goal" in g:
+            out["gt_goal"] = out_goal
+        out["agent_role"] = g["agent/role"]
+        return out
+
     def map_encoder(self, inp: Dict[str, Tensor]):
         """`MapEncoder.forward` (`map_encoder.py:72-114`), densetnt_vectornet + max pool."""
         mv = inp["map_valid"]
@@ -237,7 +264,20 @@ class Oracle:
         return f
 
     def latent_prior(self, f: Dict[str, Tensor]):
-        """`LatentEncoder.forward` prior branch (`latent_encoder.py:98-147`) + `DistEncoder` diag_gaus."""
+        return self.latent_encode(f, "prior")
+
+    def latent_post(self, f: Dict[str, Tensor], gt: Dict[str, Tensor]):
+        """Posterior over the full episode (`waymo_motion.py:583,597`): agent / traffic-light tokens of all ground-truth
+        steps, the map feature of the scene."""
+        fp = {"map_feature": f["map_feature"], "map_valid": f["map_valid"], "agent_valid": gt["agent_valid"],
+              "tl_valid": gt["tl_valid"],
+              "agent_feature": self.input_pe_encoder("model.agent_encoder", gt["agent_valid"], gt["agent_attr"], gt["agent_pe"]),
+              "tl_feature": self.input_pe_encoder("model.tl_encoder", gt["tl_valid"], gt["tl_attr"], gt["tl_pe"])}
+        return self.latent_encode(fp, "post")
+
+    def latent_encode(self, f: Dict[str, Tensor], which: str):
+        """`LatentEncoder.forward` (`latent_encoder.py:98-147`; prior and posterior branches differ only in the weights of
+        interaction / temporal / head) + `DistEncoder` diag_gaus."""
         r = self.cfg["model"]["latent_encoder"]["temporal_down_sample_rate"]
         av = f["agent_valid"][:, ::r]
         x = f["agent_feature"][:, ::r]
@@ -247,12 +287,12 @@ class Oracle:
         y = self.tf_block("model.transformer_as2pl", 3, x.flatten(1, 2), ~av.flatten(1, 2), f["map_feature"], ~f["map_valid"])
         y = y.view(b, s, a, H)
         y = self.tf_block("model.transformer_as2tl", 3, y.flatten(0, 1), ~av.flatten(0, 1), tf_.flatten(0, 1), ~tv.flatten(0, 1))
-        y = self.interaction("model.latent_encoder.agent_interaction_prior", y, av.flatten(0, 1)).view(b, s, a, H)
-        y = self.gru_scan("model.latent_encoder.agent_temporal_prior.rnn", y, av)
+        y = self.interaction(f"model.latent_encoder.agent_interaction_{which}", y, av.flatten(0, 1)).view(b, s, a, H)
+        y = self.gru_scan(f"model.latent_encoder.agent_temporal_{which}.rnn", y, av)
         agg = y.masked_fill(~av.unsqueeze(-1), -1e3).amax(1)
         valid = av.any(1)
         agg = agg.masked_fill(~valid.unsqueeze(-1), 0)
-        pre = "model.latent_encoder.latent_prior_dist"
+        pre = f"model.latent_encoder.latent_{which}_dist"
         mean = self._lin(torch.relu(self._lin(agg, pre + ".mlp_mean.fc_layers.0")), pre + ".mlp_mean.fc_layers.2")
         mean = mean.masked_fill(~valid.unsqueeze(-1), 0)
         return mean, self.w[pre + ".log_std"], valid
@@ -361,7 +401,8 @@ class Oracle:
         return mean
 
     def rollout(self, inp: Dict[str, Tensor], f: Dict[str, Tensor], z: Tensor, latent_mean: Tensor, dest: Tensor,
-                goal_valid: Tensor, k: int, step_end: int, tap_steps=()) -> Dict[str, Tensor]:
+                goal_valid: Tensor, k: int, step_end: int, tap_steps=(), gt: Optional[Dict[str, Tensor]] = None,
+                tf_cfg_name: str = "teacher_forcing_joint_future_pred", log_std_name: str = "prior") -> Dict[str, Tensor]:
         """`WaymoMotion.rollout` + `forward` + `Dynamics` + always-on `TrafficRuleChecker` + buffer
         (`waymo_motion.py:205-354,108-203`, `dynamics.py:50-167,187-228`,
         `traffic_rule_checker.py:77-98,101-119,364-410`), driven as `joint_future_pred` does
@@ -370,11 +411,12 @@ class Oracle:
         rep = lambda t: t.repeat_interleave(k, 0)  # noqa: E731
         map_f, map_inv = rep(f["map_feature"]), ~rep(f["map_valid"])
         tl_f, tl_v = rep(f["tl_feature"]), rep(f["tl_valid"])
-        hv = rep(inp["agent_valid"])
-        hs, hvel, hacc, hyr = rep(inp["agent_state"]), rep(inp["agent_vel"]), rep(inp["agent_acc"]), rep(inp["agent_yaw_rate"])
+        src = inp if gt is None else gt  # features["agent_valid"/...] of reactive_replay are the 91-step arrays (:457-461)
+        hv = rep(src["agent_valid"])
+        hs, hvel, hacc, hyr = rep(src["agent_state"]), rep(src["agent_vel"]), rep(src["agent_acc"]), rep(src["agent_yaw_rate"])
         a_type, a_size = rep(inp["agent_type"]), rep(inp["agent_size"])
         n, a = dest.shape
-        mask_tf = self.teacher_forcing_mask(hv, self.cfg["teacher_forcing_joint_future_pred"])
+        mask_tf = self.teacher_forcing_mask(hv, self.cfg[tf_cfg_name])
         n_gt = hv.shape[1]
         # rule-checker geometry gathered once (`traffic_rule_checker.py:85-98`)
         bidx = torch.arange(n).unsqueeze(1)
@@ -391,7 +433,7 @@ class Oracle:
         mask_lane = dest_type[:, :, :4].any(-1)
         mask_edge = dest_type[:, :, 4]
         # latent log-prob (`distributions.py:11-15`, Independent(Normal))
-        log_std = self.w["model.latent_encoder.latent_prior_dist.log_std"]
+        log_std = self.w[f"model.latent_encoder.latent_{log_std_name}_dist.log_std"]
         std = log_std.exp()
         lm = rep(latent_mean)
         latent_logp = (-((z - lm) ** 2) / (2 * std ** 2) - std.log() - math.log(math.sqrt(2 * math.pi))).sum(-1)
@@ -413,13 +455,16 @@ class Oracle:
         h = torch.zeros(3, n * a, H, dtype=d)
         outside = torch.zeros_like(valid)
         dest_reached = torch.zeros_like(valid)
+        goal_pose = rep(gt["gt_goal"]) if (gt is not None and "gt_goal" in gt) else None  # traffic_rule_checker.py:473-479
+        goal_reached = torch.zeros_like(valid)
         act_std_logp = 2 * (2.0 - math.log(math.sqrt(2 * math.pi)))  # Normal(mu, e^-2).log_prob(mu), 2 dims
         atype_idx = a_type.to(torch.int64).argmax(-1)
         max_acc = self.max_acc[atype_idx]
         max_yr = self.max_yr[atype_idx]
         has_type = a_type.any(-1)
         out = {k_: [] for k_ in ("preds", "valid", "override_masks", "outside_map", "outside_map_this_step",
-                                 "dest_reached", "dest_reached_this_step", "action_log_probs")}
+                                 "dest_reached", "dest_reached_this_step", "action_log_probs", "goal_reached",
+                                 "goal_reached_this_step", "check_state", "check_valid")}
         taps: Dict[str, Tensor] = {}
         for t in range(self.cfg["time_step_sim_start"], step_end + 1):
             m_ovr = mask_tf[:, t] if t < n_gt else torch.zeros_like(valid)
@@ -462,6 +507,7 @@ class Oracle:
                 acc = torch.where(m3, hacc[:, t], acc)
                 yr = torch.where(m3, hyr[:, t], yr)
             # rule check (`traffic_rule_checker.py:101-119,364-410`)
+            check_state, check_valid = state.clone(), valid.clone()  # what TrafficRuleChecker.check is handed (:311)
             xs, ys = state[:, :, 0], state[:, :, 1]
             out_this = ((xs > bound[:, [1]]) | (xs < bound[:, [0]]) | (ys > bound[:, [3]]) | (ys < bound[:, [2]])) & valid
             outside = outside | out_this
@@ -472,6 +518,12 @@ class Oracle:
             rot_reached = (rot > thresh_rot_cos).any(-1)
             dr_this = (~dest_reached) & valid & ((mask_lane & pos_reached & rot_reached) | (mask_edge & pos_reached))
             dest_reached = dest_reached | dr_this
+            gr_this = torch.zeros_like(valid)
+            if goal_pose is not None:  # _check_goal_reached (:337-361): 8 agent lengths, 15 degrees
+                pos_ok = torch.norm(state[..., :2] - goal_pose[..., :2], dim=-1) < a_size[:, :, 0] * 8
+                dyaw = (state[..., 2] - goal_pose[..., 2] + math.pi) % (2 * math.pi) - math.pi
+                gr_this = pos_ok & (dyaw.abs() < float(np.deg2rad(15))) & valid & (~goal_reached)
+            goal_reached = goal_reached | gr_this
             # kill (`dynamics.py:161-167`)
             mk = out_this & (~hv[:, t]) if t < n_gt else out_this
             killed = killed | mk
@@ -486,6 +538,10 @@ class Oracle:
             out["dest_reached"].append(dest_reached)
             out["dest_reached_this_step"].append(dr_this)
             out["action_log_probs"].append(alp)
+            out["goal_reached"].append(goal_reached)
+            out["check_state"].append(check_state)
+            out["check_valid"].append(check_valid)
+            out["goal_reached_this_step"].append(gr_this)
         res = {k_: torch.stack(v, 2) for k_, v in out.items()}
         s = res["valid"].shape[2]
         res["latent_log_probs"] = latent_logp.unsqueeze(-1).expand(-1, -1, s)
@@ -535,4 +591,26 @@ class Oracle:
         res["agent_feature_cur"], res["agent_feature_0"] = f["agent_feature"][:, -1], f["agent_feature"][:, 0]
         res["tl_feature_cur"] = f["tl_feature"][:, -1]
         res["_inp"], res["_feats"] = inp, f
+        return res
+
+    def reactive_replay(self, batch: Dict[str, np.ndarray], step_end: int) -> Dict[str, Tensor]:
+        """First half of `WaymoMotion.validation_step` (`waymo_motion.py:574-611`): posterior and prior personalities,
+        destination prediction, then the episode replayed with the posterior MEAN as personality, the ground-truth
+        destination as goal and `teacher_forcing_reactive_replay` (agents keep spawning from ground truth until step 90).
+        Outputs are the un-flattened RolloutBuffer fields [B,A,S,...] plus what `TrainingMetrics.update` consumes."""
+        inp = self.preprocess(batch)
+        f = self.encode_scene(inp)
+        gt = self.preprocess_gt(batch)
+        post_mean, post_log_std, post_valid = self.latent_post(f, gt)
+        prior_mean, prior_log_std, prior_valid = self.latent_prior(f)
+        logits = self.dest_logits(f, inp)
+        goal_valid = inp["agent_valid"].any(1)  # GoalManager.get_gt_goal, goal_manager.py:66-68
+        dest = gt["gt_dest"].to(torch.int64)
+        res = self.rollout(inp, f, post_mean.clone(), post_mean, dest, goal_valid, 1, step_end, gt=gt,
+                           tf_cfg_name="teacher_forcing_reactive_replay", log_std_name="post")
+        res.update(post_mean=post_mean, post_log_std=post_log_std, post_valid=post_valid, prior_mean=prior_mean,
+                   prior_log_std=prior_log_std, prior_valid=prior_valid, dest_logits_raw=logits, goal_valid=goal_valid,
+                   gt_dest=dest, gt_valid=gt["agent_valid"], gt_state=gt["agent_state"], agent_role=gt["agent_role"],
+                   agent_size=inp["agent_size"], agent_type=inp["agent_type"])
+        res["_inp"], res["_feats"], res["_gt"] = inp, f, gt
         return res

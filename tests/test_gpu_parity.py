@@ -414,6 +414,142 @@ def test_metric_partials_kernel():
         assert np.array_equal(out2[:4], np.zeros(4)) and np.array_equal(out2[4:], out[4:])
 
 
+TRAIN_FIELDS = ("vae_kl_counter", "vae_kl", "diffbar_reward_counter", "diffbar_reward", "goal_loss", "goal_counter")
+
+
+@pytest.mark.parametrize("name", ["val_small", "val_masks", "val_alt_losses"])
+def test_validation_step_against_reference_golden(name):
+    """SURVEY 8(f)-3 through the C ABI (tb_encode_posterior, tb_rollout driven by the 91-step ground truth, tb_train_partials,
+    tb_rule_checks' goal_reached, tb_metric_partials) against what the imported reference's validation_step produced."""
+    from trafficbots_amd import synth
+
+    g, meta = load_golden(name)
+    over = {"time_step_end": meta["time_step_end"], "n_joint_future": 2}
+    over.update(meta["overrides"])
+    wm = _engine(over, synth.make_state_dict(meta["weight_seed"]))
+    batch = synth.make_val_batch(meta["base_seed"], meta["n_scene"], **meta["scene"])
+    out = wm.validation_step(batch)
+    torch.cuda.synchronize()
+    rr = out["reactive_replay"]
+    buf = rr["rollout_buffer"]  # flattened [B,A,1,S,...]
+    rep = {}
+    rep["post_mean"] = float(np.abs(out["latent_post"].mean.cpu().numpy() - g["post_mean"]).max())
+    rep["prior_mean"] = float(np.abs(out["latent_prior_mean"].cpu().numpy() - g["prior_mean"]).max())
+    assert (out["latent_post"].valid.cpu().numpy() == g["post_valid"]).all()
+    assert (out["latent_prior_valid"].cpu().numpy() == g["prior_valid"]).all()
+    rep["latent_log_probs"] = float(np.abs(buf.latent_log_probs[:, :, 0].cpu().numpy() - g["latent_log_probs"]).max())
+    for k, v in rep.items():
+        assert v <= ONE_SHOT_TOL, f"{name}: {k} max-abs {v:.3e}"
+    # discrete outputs of the replay must be equal: spawns from ground truth up to step 90, kills, reached flags
+    assert (buf.valid[:, :, 0].cpu().numpy() == g["valid"]).all()
+    assert (buf.override_masks[:, :, 0].cpu().numpy() == g["override_masks"]).all()
+    for k in ("outside_map", "dest_reached", "goal_reached"):
+        assert (buf.violations[k][:, :, 0].cpu().numpy() == g[k]).all(), k
+    assert (buf.diffbar_rewards_valid[:, :, 0].cpu().numpy() == g["diffbar_rewards_valid"]).all()
+    preds = buf.preds[:, :, 0].cpu().numpy()
+    d = np.abs(preds - g["preds"]) * g["valid"][..., None]
+    per_step = d[..., :2].max(axis=(0, 1, 3))
+    rep["traj_xy_max"] = float(per_step.max())
+    if "preds_fp64" in g.files:
+        both = (g["valid"] & g["valid_fp64"])[..., None]
+        noise = np.maximum.accumulate((np.abs(g["preds"].astype(np.float64) - g["preds_fp64"]) * both)[..., :2].max(axis=(0, 1, 3)))
+        d64 = (np.abs(preds.astype(np.float64) - g["preds_fp64"]) * both)[..., :2].max(axis=(0, 1, 3))
+        rep["ref_fp32_vs_fp64_xy_max"], rep["traj_xy_vs_fp64_max"] = float(noise.max()), float(d64.max())
+        assert (d64 <= np.maximum(1e-4, 1.5 * noise)).all()
+        bound = np.maximum(1e-4, 2.5 * noise)
+    else:
+        bound = np.full_like(per_step, 2.5e-4)
+    assert (per_step <= bound).all(), f"{name}: replay xy error {per_step.max():.3e} exceeds envelope"
+    # rewards follow the trajectories: the criteria are 1-Lipschitz (SmoothL1 / L1) or quadratic (MSE) in errors of <= 2.5e-4
+    rw = buf.diffbar_rewards[:, :, 0].cpu().numpy()
+    rep["reward_max_abs"] = float(np.abs(rw - g["diffbar_rewards"]).max())
+    assert np.allclose(rw, g["diffbar_rewards"], rtol=5e-5, atol=5e-4)
+    ts = rr["train_states"].cpu().numpy()
+    for i in (0, 2, 5):
+        assert ts[i] == g["train_states"][i], TRAIN_FIELDS[i]
+    assert np.allclose(ts, g["train_states"], rtol=1e-4), (ts, g["train_states"])
+    comp = wm.train_metrics_reactive_replay.compute()
+    ref = json.loads(bytes(g["train_compute_json"]).decode())
+    assert set(comp) == set(ref) and all(abs(comp[k] - ref[k]) <= 1e-4 * max(1.0, abs(ref[k])) for k in ref), (comp, ref)
+    ms = rr["metric_states"].cpu().numpy()
+    want = np.concatenate([g["err_states"], g["rule_states"]])
+    assert (ms[[0, 4, 5, 6, 7, 8, 9, 10, 11, 12]] == want[[0, 4, 5, 6, 7, 8, 9, 10, 11, 12]]).all(), (ms, want)
+    assert np.allclose(ms, want, rtol=1e-4)
+    rep["loss"] = comp["reactive_replay/loss"]
+    # the loss kernels on the REFERENCE's buffer: their own arithmetic, no trajectory noise
+    gt = wm.pre_processing(batch)["gt"]
+    gv, gs = wm._gt_slices(gt, wm.hparams["time_step_sim_start"], meta["time_step_end"])
+    raw = {k: torch.from_numpy(g[k]).cuda() for k in ("valid", "preds", "override_masks")}
+    rw2, rv2, st2 = wm.engine.train_partials(
+        raw, gv, gs, gt["agent_size"], dest_logits=out["dest_logits"], goal_valid=wm.pre_processing(batch)["agent_valid"].bool().any(1),
+        gt_dest=gt["gt_dest"],
+        post={"latent_mean": torch.from_numpy(g["post_mean"]).cuda(), "latent_valid": torch.from_numpy(g["post_valid"]).cuda()},
+        prior={"latent_mean": torch.from_numpy(g["prior_mean"]).cuda(), "latent_valid": torch.from_numpy(g["prior_valid"]).cuda()})
+    torch.cuda.synchronize()
+    assert (rv2.bool().cpu().numpy() == g["diffbar_rewards_valid"]).all()
+    assert np.allclose(rw2.cpu().numpy(), g["diffbar_rewards"], rtol=3e-6, atol=3e-6)
+    assert np.allclose(st2.cpu().numpy(), g["train_states"], rtol=2e-5)
+    # second half of validation_step ran too (prior samples, predicted destinations, kill rule against the ground truth)
+    bj = out["joint_future_pred"]["rollout_buffer"]
+    assert bj.valid.shape[2] == 2 and out["joint_future_pred"]["pred_dict"]["waymo_trajs"].shape[3] == 2
+    REPORT[name] = rep
+
+
+def test_validation_step_against_oracle_fresh_seed():
+    """validation_step at a shape no golden covers (40 agents, 100 polylines, ragged), collision reward on, all four rule checks on
+    (so the replay's checker reads the 91-step traffic lights), against the CPU oracles."""
+    from oracle import training_oracle as TO
+    from oracle.rule_checks_oracle import rule_checks
+    from oracle.trafficbots_oracle import Oracle
+    from trafficbots_amd import synth
+    from trafficbots_amd.config import load_model_config
+
+    over = {"time_step_end": 90, "n_joint_future": 1, "differentiable_reward.w_collision": 0.3,
+            "traffic_rule_checker": {"enable_check_collided": True, "enable_check_run_road_edge": True,
+                                     "enable_check_run_red_light": True, "enable_check_passive": True}}
+    scene = dict(n_agent=40, n_pl=100, n_tl=40, p_invalid_agent=0.2, p_late_spawn=0.2, p_future_spawn=0.5, p_future_exit=0.3,
+                 pos_range=35.0, p_tl_valid=0.6)
+    sd = synth.make_state_dict(9700)
+    batch = synth.make_val_batch(9701, 2, **scene)
+    wm = _engine(over, sd)
+    out = wm.validation_step(batch)
+    torch.cuda.synchronize()
+    cfg = load_model_config(overrides=over)
+    r = Oracle(sd, cfg, dtype=torch.float32).reactive_replay(batch, 90)
+    buf = out["reactive_replay"]["rollout_buffer"]
+    assert np.abs(out["latent_post"].mean.cpu().numpy() - r["post_mean"].numpy()).max() <= ONE_SHOT_TOL
+    assert (out["latent_post"].valid.cpu().numpy() == r["post_valid"].numpy()).all()
+    for k in ("valid", "override_masks"):
+        assert (getattr(buf, k)[:, :, 0].cpu().numpy() == r[k].numpy()).all(), k
+    for k in ("outside_map", "dest_reached", "goal_reached"):
+        assert (buf.violations[k][:, :, 0].cpu().numpy() == r[k].numpy()).all(), k
+    v = r["valid"].numpy()[..., None]
+    dxy = (np.abs(buf.preds[:, :, 0].cpu().numpy() - r["preds"].numpy()) * v)[..., :2].max()
+    assert dxy <= 2.5e-4, dxy
+    gv = r["gt_valid"][:, 1:91].transpose(1, 2)
+    gs = r["gt_state"][:, 1:91].transpose(1, 2)
+    # losses: oracle arithmetic on the HIP buffer (isolates the loss kernels from trajectory noise)
+    pv, ps = buf.valid[:, :, 0].cpu(), buf.preds[:, :, 0].cpu()
+    rew, rv = TO.differentiable_reward(pv, ps, gv, gs, r["agent_size"], cfg["differentiable_reward"])
+    assert (buf.diffbar_rewards_valid[:, :, 0].cpu() == rv).all()
+    assert np.allclose(buf.diffbar_rewards[:, :, 0].cpu().numpy(), rew.numpy(), rtol=5e-6, atol=5e-6)
+    st = TO.training_metric_states(pv, rv, rew, buf.override_masks[:, :, 0].cpu(), r["agent_role"], out["dest_logits"].cpu(), r["goal_valid"],
+                                   r["gt_dest"], out["latent_post"].mean.cpu(), r["post_log_std"], out["latent_post"].valid.cpu(),
+                                   out["latent_prior_mean"].cpu(), r["prior_log_std"], out["latent_prior_valid"].cpu(),
+                                   cfg["training_metrics"])
+    ts = out["reactive_replay"]["train_states"].cpu().numpy()
+    assert np.allclose(ts, np.array([st[k] for k in TRAIN_FIELDS]), rtol=2e-5), (ts, st)
+    # flag-gated checks of the replay: oracle on the recorded per-step states with the GROUND-TRUTH traffic lights
+    inp = r["_inp"]
+    b64 = {k: torch.from_numpy(np.asarray(batch[k])) for k in ("tl_stop/valid", "tl_stop/pos", "tl_stop/state")}
+    ref = rule_checks(r["check_state"], r["check_valid"], 1, 1, inp["agent_type"], inp["agent_size"], inp["map_valid"], inp["map_type"],
+                      inp["map_pos"], inp["map_dir"], b64["tl_stop/valid"], b64["tl_stop/pos"], b64["tl_stop/state"])
+    for k, want in ref.items():
+        got = buf.violations[k][:, :, 0].cpu().numpy()
+        assert (got == want.numpy()).mean() >= 0.999, k  # (states differ by <= 2.5e-4 m: a threshold can flip on a rare tie)
+    assert ref["collided"].any() and ref["run_road_edge"].any()
+
+
 def test_empty_and_bad_inputs_fail_loudly():
     from trafficbots_amd import synth
     from trafficbots_amd.waymo_motion import WaymoMotion

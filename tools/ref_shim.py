@@ -165,7 +165,6 @@ def build_reference(cfg: dict, n_agent: int, n_pl: int, n_tl: int = 40) -> nn.Mo
     }
     c = to_attr(cfg)
     # groups the reference constructor wants but the hot path never reads
-    smooth = AttrDict(weight=1e-1, criterion="SmoothL1Loss")
     full = dict(
         time_step_current=c.time_step_current,
         time_step_gt=c.time_step_gt,
@@ -195,14 +194,7 @@ def build_reference(cfg: dict, n_agent: int, n_pl: int, n_tl: int = 40) -> nn.Mo
         p_training_rollout_prior=0.1,
         detach_state_policy=c.detach_state_policy,
         training_deterministic_action=True,
-        differentiable_reward=AttrDict(
-            w_collision=0,
-            reduce_collsion_with_max=True,
-            use_il_loss=True,
-            l_pos=smooth,
-            l_rot=AttrDict(weight=1e1, criterion="SmoothL1Loss", angular_type="cosine"),
-            l_spd=smooth,
-        ),
+        differentiable_reward=c.differentiable_reward,
         p_drop_hidden=-1.0,
         n_video_batch=0,
         n_joint_future=c.n_joint_future,
@@ -214,18 +206,7 @@ def build_reference(cfg: dict, n_agent: int, n_pl: int, n_tl: int = 40) -> nn.Mo
         teacher_forcing_training=AttrDict(step_spawn_agent=10, step_warm_start=10),
         teacher_forcing_reactive_replay=c.teacher_forcing_reactive_replay,
         teacher_forcing_joint_future_pred=c.teacher_forcing_joint_future_pred,
-        training_metrics=AttrDict(
-            w_vae_kl=1e-1,
-            kl_balance_scale=-1,
-            kl_free_nats=1e-2,
-            kl_for_unseen_agent=True,
-            w_diffbar_reward=1.0,
-            w_goal=1.0,
-            w_relevant_agent=0,
-            p_loss_for_irrelevant=-1.0,
-            loss_for_teacher_forcing=True,
-            step_training_start=10,
-        ),
+        training_metrics=c.training_metrics,
         traffic_rule_checker=c.traffic_rule_checker,
         optimizer=AttrDict(),
         lr_scheduler=None,

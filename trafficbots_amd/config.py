@@ -18,8 +18,8 @@ import re
 from typing import Any, Dict
 
 # Defaults for the keys of configs/model/traffic_bots.yaml that the path reads.
-# Training-only groups (optimizer, lr_scheduler, training_metrics,
-# differentiable_reward, sub_womd_*) are accepted by the loader but ignored.
+# Training-only groups (optimizer, lr_scheduler, sub_womd_*) are accepted by the loader but ignored;
+# training_metrics and differentiable_reward feed the forward losses of validation_step.
 _MLP_CFG = {"use_layernorm": False, "activation": "relu", "dropout_p": 0.1}
 
 DEFAULT_MODEL_CONFIG: Dict[str, Any] = {
@@ -133,6 +133,17 @@ DEFAULT_MODEL_CONFIG: Dict[str, Any] = {
         "k_pred": 6, "use_ade": True, "score_temperature": 1e2, "mpa_nms_thresh": [], "mtr_nms_thresh": [], "aggr_thresh": [],
         "n_iter_em": 3,
     },
+    "differentiable_reward": {  # traffic_bots.yaml:157-171
+        "w_collision": 0, "reduce_collsion_with_max": True, "use_il_loss": True,
+        "l_pos": {"weight": 1e-1, "criterion": "SmoothL1Loss"},
+        "l_rot": {"weight": 1e1, "criterion": "SmoothL1Loss", "angular_type": "cosine"},
+        "l_spd": {"weight": 1e-1, "criterion": "SmoothL1Loss"},
+    },
+    "training_metrics": {  # traffic_bots.yaml:208-219
+        "w_vae_kl": 1e-1, "kl_balance_scale": -1, "kl_free_nats": 1e-2, "kl_for_unseen_agent": True, "w_diffbar_reward": 1.0,
+        "w_goal": 1.0, "w_relevant_agent": 0, "p_loss_for_irrelevant": -1.0, "loss_for_teacher_forcing": True,
+        "step_training_start": 10,
+    },
     "traffic_rule_checker": {
         "enable_check_collided": False,
         "enable_check_run_road_edge": False,
@@ -215,6 +226,8 @@ def load_model_config(path: str | None = None, overrides: Dict[str, Any] | None 
         for p in parts[:-1]:
             node = node.setdefault(p, {})
         node[parts[-1]] = val
+    for group in ("differentiable_reward", "training_metrics"):
+        cfg.setdefault(group, copy.deepcopy(DEFAULT_MODEL_CONFIG[group]))
     check_supported(cfg)
     return cfg
 

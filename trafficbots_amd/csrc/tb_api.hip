@@ -34,6 +34,8 @@ TB_DECLARE_XDL(xh)  // fp16 pairs (tb_stepx_kernels.hip)
 TB_DECLARE_XDL(xb)  // bf16       (tb_stepx_bf16_kernels.hip)
 int run_encode(struct ::tb_ctx* ctx, const tb_encode_io* io, hipStream_t s);
 int run_rule_checks(const tb_rule_io* io, int n_hist, int step_start, uint8_t* raw_ws, hipStream_t s);
+int run_encode_posterior(struct ::tb_ctx* ctx, const tb_posterior_io* io, hipStream_t s);
+void launch_train_partials(const tb_train_io& io, const float* post_log_std, const float* prior_log_std, hipStream_t s);
 hipError_t configure_rule_kernels();
 void launch_post_process(const tb_post_io& io, hipStream_t s);
 void launch_metric_partials(const tb_metric_io& io, hipStream_t s);
@@ -254,7 +256,9 @@ tb::EncMlpW add_enc(Arena& a, Stage& s, const std::string& p, int attr_dim) {
 // ---------------------------------------------------------------------------------------------------
 extern "C" {
 
-void tb_struct_sizes(int32_t out[7]) {
+void tb_struct_sizes(int32_t out[9]) {
+    out[7] = (int32_t)sizeof(tb_posterior_io);
+    out[8] = (int32_t)sizeof(tb_train_io);
     out[0] = (int32_t)sizeof(tb_config);
     out[1] = (int32_t)sizeof(tb_rollout_io);
     out[2] = (int32_t)sizeof(tb_encode_io);
@@ -423,6 +427,8 @@ int tb_finalize_weights(tb_ctx* ctx, tb_stream stream) {
         ew.densetnt[i] = add_xlayer(a, s, "model.map_encoder.transformer_densetnt.layers." + si);
         ew.inter_prior[i] = add_xlayer(a, s, "model.latent_encoder.agent_interaction_prior.transformer.layers." + si);
         ew.gru_prior[i] = add_gru(a, s, "model.latent_encoder.agent_temporal_prior.rnn", i);
+        ew.inter_post[i] = add_xlayer(a, s, "model.latent_encoder.agent_interaction_post.transformer.layers." + si);
+        ew.gru_post[i] = add_gru(a, s, "model.latent_encoder.agent_temporal_post.rnn", i);
         ew.gru_dest[i] = add_gru(a, s, "model.goal_manager.goal_predictor.gru_as.rnn", i);
         ew.as2pl[i] = pw.as2pl[i];
         ew.as2tl[i] = pw.as2tl[i];
@@ -432,6 +438,11 @@ int tb_finalize_weights(tb_ctx* ctx, tb_stream stream) {
     ew.lat_b1 = add_plain(a, s, "model.latent_encoder.latent_prior_dist.mlp_mean.fc_layers.0.bias", 128);
     ew.lat_w2 = add_plain(a, s, "model.latent_encoder.latent_prior_dist.mlp_mean.fc_layers.2.weight", 16 * 128);
     ew.lat_b2 = add_plain(a, s, "model.latent_encoder.latent_prior_dist.mlp_mean.fc_layers.2.bias", 16);
+    ew.post_w1 = add_packed(a, s, "model.latent_encoder.latent_post_dist.mlp_mean.fc_layers.0.weight", 128, 128, 128);
+    ew.post_b1 = add_plain(a, s, "model.latent_encoder.latent_post_dist.mlp_mean.fc_layers.0.bias", 128);
+    ew.post_w2 = add_plain(a, s, "model.latent_encoder.latent_post_dist.mlp_mean.fc_layers.2.weight", 16 * 128);
+    ew.post_b2 = add_plain(a, s, "model.latent_encoder.latent_post_dist.mlp_mean.fc_layers.2.bias", 16);
+    ew.post_log_std = add_plain(a, s, "model.latent_encoder.latent_post_dist.log_std", 16);
     {
         // dest predictor first layer [128][256] split into the map half (cols 0:128) and the agent half (128:256)
         const std::string p = "model.goal_manager.goal_predictor.mlp.fc_layers.";
@@ -520,7 +531,7 @@ int tb_ensure_workspace(tb_ctx* ctx, size_t bytes) {
 }
 
 static void carve_rollout(tb::RolloutP& p, Carver& c) {
-    const size_t B = p.n_scene, N = p.n_inst, NH = p.n_hist;
+    const size_t B = p.n_scene, N = p.n_inst, NH = p.n_tl_hist;
     p.kpl = c.take<float>(B * 3 * p.p_pad * 128);
     p.vtpl = c.take<float>(B * 3 * 128 * p.p_pad);
     p.kbias_pl = c.take<float>(B * p.p_pad);
@@ -554,8 +565,7 @@ static int rollout_setup(tb_ctx* ctx, const tb_rollout_io* io, tb::RolloutP& p) 
         return tb_fail(ctx, "tb_rollout: empty dimension (B=%d K=%d A=%d P=%d T=%d)", io->n_scene, io->k_futures, io->n_agent,
                        io->n_pl, io->n_tl);
     if (io->n_agent > 256) return tb_fail(ctx, "tb_rollout: n_agent %d > 256 not supported", io->n_agent);
-    if (io->n_hist != ctx->cfg.time_step_current + 1)
-        return tb_fail(ctx, "tb_rollout: n_hist %d != time_step_current+1", io->n_hist);
+    if (io->n_hist < 1 || io->n_tl_step < 0) return tb_fail(ctx, "tb_rollout: n_hist %d / n_tl_step %d", io->n_hist, io->n_tl_step);
     const int step_start = ctx->cfg.time_step_sim_start;
     if (io->step_end < step_start) return tb_fail(ctx, "tb_rollout: step_end < time_step_sim_start");
     memset(&p, 0, sizeof(p));
@@ -572,6 +582,8 @@ static int rollout_setup(tb_ctx* ctx, const tb_rollout_io* io, tb::RolloutP& p) 
     p.n_tl = io->n_tl;
     p.t_pad = padk(io->n_tl);
     p.n_hist = io->n_hist;
+    p.n_tl_hist = io->n_tl_step > 0 ? io->n_tl_step : io->n_hist;
+    p.latent_log_std = io->latent_posterior ? ctx->ew.post_log_std : ctx->pw.latent_log_std;
     p.step_start = step_start;
     p.n_step_out = io->step_end - step_start + 1;
     p.map_feature = io->map_feature;
@@ -628,14 +640,14 @@ static void rollout_prologue(const tb_ctx* ctx, const tb::RolloutP& p, const tb_
     if (ctx->step_kernel >= 2) {  // k_step_x reads K / V in XDL operand order (fp16 pairs or bf16)
         auto hoist = ctx->step_kernel == 3 ? tb::xb::launch_kv_hoist_x : tb::xh::launch_kv_hoist_x;
         hoist(p.W, p.pw.as2pl, p.px.as2pl, p.map_feature, io->map_feature_valid, p.n_scene, p.n_pl, p.p_pad, p.kpl, p.vtpl, p.kbias_pl, s);
-        hoist(p.W, p.pw.as2tl, p.px.as2tl, p.tl_feature, io->tl_feature_valid, p.n_scene * p.n_hist, p.n_tl, p.t_pad, p.ktl, p.vttl,
+        hoist(p.W, p.pw.as2tl, p.px.as2tl, p.tl_feature, io->tl_feature_valid, p.n_scene * p.n_tl_hist, p.n_tl, p.t_pad, p.ktl, p.vttl,
               p.kbias_tl, s);
         tb::launch_rollout_init(p, s);
         return;
     }
     tb::launch_kv_hoist(p.W, p.pw.as2pl, p.map_feature, io->map_feature_valid, p.n_scene, p.n_pl, p.p_pad, p.kpl, p.vtpl,
                         p.kbias_pl, s);
-    tb::launch_kv_hoist(p.W, p.pw.as2tl, p.tl_feature, io->tl_feature_valid, p.n_scene * p.n_hist, p.n_tl, p.t_pad, p.ktl,
+    tb::launch_kv_hoist(p.W, p.pw.as2tl, p.tl_feature, io->tl_feature_valid, p.n_scene * p.n_tl_hist, p.n_tl, p.t_pad, p.ktl,
                         p.vttl, p.kbias_tl, s);
     tb::launch_rollout_init(p, s);
 }
@@ -697,7 +709,8 @@ extern "C" int tb_rule_checks(tb_ctx* ctx, const tb_rule_io* io, tb_stream strea
         TB_HIP(ctx, hipMalloc((void**)&ctx->d_rule_ws, raw_bytes));
         ctx->rule_ws_bytes = raw_bytes;
     }
-    tb::run_rule_checks(io, ctx->cfg.time_step_current + 1, ctx->cfg.time_step_sim_start, ctx->d_rule_ws, (hipStream_t)stream_);
+    const int n_tl_step = io->n_tl_step > 0 ? io->n_tl_step : ctx->cfg.time_step_current + 1;
+    tb::run_rule_checks(io, n_tl_step, ctx->cfg.time_step_sim_start, ctx->d_rule_ws, (hipStream_t)stream_);
     TB_HIP(ctx, hipGetLastError());
     return 0;
 }
@@ -774,6 +787,36 @@ extern "C" int tb_debug_read_prof(tb_ctx* ctx, long long* host_out, int n_blocks
     if (!ctx || !ctx->last_prof) return 1;
     TB_HIP(ctx, hipDeviceSynchronize());
     TB_HIP(ctx, hipMemcpy(host_out, ctx->last_prof, sizeof(long long) * 32 * n_blocks, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+extern "C" int tb_encode_posterior(tb_ctx* ctx, const tb_posterior_io* io, tb_stream stream) {
+    if (!ctx || !io) return 1;
+    if (!ctx->finalized) return tb_fail(ctx, "tb_encode_posterior: weights not finalized");
+    TB_HIP(ctx, hipSetDevice(ctx->device));
+    return tb::run_encode_posterior(ctx, io, (hipStream_t)stream);
+}
+
+extern "C" int tb_train_partials(tb_ctx* ctx, const tb_train_io* io, tb_stream stream_) {
+    if (!ctx || !io) return 1;
+    if (!ctx->finalized) return tb_fail(ctx, "tb_train_partials: weights not finalized");
+    TB_HIP(ctx, hipSetDevice(ctx->device));
+    if (io->n_scene <= 0 || io->n_agent <= 0 || io->n_step <= 0 || io->n_pl <= 0)
+        return tb_fail(ctx, "tb_train_partials: empty dimension");
+    if (io->crit_pos < 0 || io->crit_pos > 2 || io->crit_rot < 0 || io->crit_rot > 2 || io->crit_spd < 0 || io->crit_spd > 2 ||
+        io->angular_type < 0 || io->angular_type > 3)
+        return tb_fail(ctx, "tb_train_partials: unknown criterion / angular_type");
+    if ((io->gt_valid == nullptr) != (io->gt_states == nullptr)) return tb_fail(ctx, "tb_train_partials: gt_valid / gt_states must come together");
+    const void* req[] = {io->pred_valid, io->pred_states, io->override_masks, io->agent_size, io->diffbar_rewards,
+                         io->diffbar_rewards_valid, io->out};
+    for (const void* q : req)
+        if (!q) return tb_fail(ctx, "tb_train_partials: a required buffer pointer is NULL");
+    if (io->use_goal && (!io->dest_logits || !io->goal_valid || !io->gt_dest))
+        return tb_fail(ctx, "tb_train_partials: use_goal needs dest_logits, goal_valid and gt_dest");
+    if (io->use_vae_kl && (!io->post_mean || !io->post_valid || !io->prior_mean || !io->prior_valid))
+        return tb_fail(ctx, "tb_train_partials: use_vae_kl needs the posterior and prior personalities");
+    tb::launch_train_partials(*io, ctx->d_arena + ctx->ew.post_log_std, ctx->d_arena + ctx->pw.latent_log_std, (hipStream_t)stream_);
+    TB_HIP(ctx, hipGetLastError());
     return 0;
 }
 

@@ -468,6 +468,76 @@ static void launch_xblock(const XBlockP& p, int G, hipStream_t s) {
     hipLaunchKernelGGL(k_xattn_block, grid, dim3(NTHREADS), (3 * TM * LDT + 16) * sizeof(float), s, p);
 }
 
+// Scratch of one latent-encoder pass (LatentEncoder.forward, latent_encoder.py:98-147) over S3 down-sampled steps.
+struct LatentWs {
+    float *kpl, *vtpl, *kvpl, *x0, *x1, *x2, *x3, *tl3, *ktl, *vttl, *kvtl, *kin, *vtin, *kvin;
+    uint8_t *v0, *tlv3;
+};
+
+static void carve_latent(Carver& c, LatentWs& w, size_t B, size_t S3, size_t A, size_t T, size_t a_pad, size_t p_pad, size_t t_pad) {
+    w.kpl = c.take<float>(B * 3 * p_pad * 128);
+    w.vtpl = c.take<float>(B * 3 * 128 * p_pad);
+    w.kvpl = c.take<float>(B * p_pad);
+    w.x0 = c.take<float>(B * S3 * A * 128);
+    w.v0 = c.take<uint8_t>(B * S3 * A);
+    w.x1 = c.take<float>(B * S3 * A * 128);
+    w.x2 = c.take<float>(B * S3 * A * 128);
+    w.x3 = c.take<float>(B * S3 * A * 128);
+    w.tl3 = c.take<float>(B * S3 * T * 128);
+    w.tlv3 = c.take<uint8_t>(B * S3 * T);
+    w.ktl = c.take<float>(B * S3 * 3 * t_pad * 128);
+    w.vttl = c.take<float>(B * S3 * 3 * 128 * t_pad);
+    w.kvtl = c.take<float>(B * S3 * t_pad);
+    w.kin = c.take<float>(B * S3 * 3 * a_pad * 128);
+    w.vtin = c.take<float>(B * S3 * 3 * 128 * a_pad);
+    w.kvin = c.take<float>(B * S3 * a_pad);
+}
+
+// Prior (which = 0) or posterior (which = 1) personality over the steps {0, 5, 10, ...} of NS encoded steps: agent -> map,
+// agent -> traffic lights (shared as2pl / as2tl weights), interaction, GRU over time, max over valid steps, DistEncoder mean.
+static void launch_latent_branch(const float* W, const EncoderW& ew, int which, int B, int NS, int A, int P, int T,
+                                 const float* agent_feature, const uint8_t* agent_valid, const float* tl_feature,
+                                 const uint8_t* tl_valid, const float* map_feature, const uint8_t* map_fvalid, const LatentWs& w,
+                                 float* out_mean, uint8_t* out_valid, hipStream_t s) {
+    const int a_pad = padk(A), p_pad = padk(P), t_pad = padk(T);
+    const int S3 = (NS - 1) / 5 + 1;  // latent_encoder.py:98-103
+    const XLayerW* inter = which ? ew.inter_post : ew.inter_prior;
+    const GruLayerW* gru = which ? ew.gru_post : ew.gru_prior;
+    const int RC4 = A * 32;
+    size_t total = (size_t)B * S3 * RC4;
+    hipLaunchKernelGGL(k_gather_steps_f, dim3((total + 255) / 256), dim3(256), 0, s, agent_feature, w.x0, B, NS, S3, 5, RC4);
+    total = (size_t)B * S3 * A;
+    hipLaunchKernelGGL(k_gather_steps_u8, dim3((total + 255) / 256), dim3(256), 0, s, agent_valid, w.v0, B, NS, S3, 5, A);
+    total = (size_t)B * S3 * T * 32;
+    hipLaunchKernelGGL(k_gather_steps_f, dim3((total + 255) / 256), dim3(256), 0, s, tl_feature, w.tl3, B, NS, S3, 5, T * 32);
+    total = (size_t)B * S3 * T;
+    hipLaunchKernelGGL(k_gather_steps_u8, dim3((total + 255) / 256), dim3(256), 0, s, tl_valid, w.tlv3, B, NS, S3, 5, T);
+    // agent -> map over the S3*A tokens of each scene (shared as2pl weights)
+    launch_kv_hoist_n(W, ew.as2pl, 3, map_feature, map_fvalid, B, P, p_pad, w.kpl, w.vtpl, w.kvpl, s);
+    XBlockP x{};
+    x.W = W; x.n_layer = 3;
+    for (int l = 0; l < 3; ++l) x.L[l] = ew.as2pl[l];
+    x.src = w.x0; x.src_valid = w.v0; x.dst = w.x1; x.K = w.kpl; x.VT = w.vtpl; x.kbias = w.kvpl; x.n_rows = S3 * A; x.n_pad = p_pad; x.eye = 0;
+    launch_xblock(x, B, s);
+    // agent -> traffic lights, per step
+    launch_kv_hoist_n(W, ew.as2tl, 3, w.tl3, w.tlv3, B * S3, T, t_pad, w.ktl, w.vttl, w.kvtl, s);
+    for (int l = 0; l < 3; ++l) x.L[l] = ew.as2tl[l];
+    x.src = w.x1; x.dst = w.x2; x.K = w.ktl; x.VT = w.vttl; x.kbias = w.kvtl; x.n_rows = A; x.n_pad = t_pad;
+    launch_xblock(x, B * S3, s);
+    // interaction (own weights), tgt = block input
+    launch_kv_hoist_n(W, inter, 3, w.x2, w.v0, B * S3, A, a_pad, w.kin, w.vtin, w.kvin, s);
+    for (int l = 0; l < 3; ++l) x.L[l] = inter[l];
+    x.src = w.x2; x.dst = w.x3; x.K = w.kin; x.VT = w.vtin; x.kbias = w.kvin; x.n_rows = A; x.n_pad = a_pad; x.eye = 1;
+    launch_xblock(x, B * S3, s);
+    ScanP sp{};
+    sp.W = W;
+    for (int l = 0; l < 3; ++l) sp.gru[l] = gru[l];
+    sp.head_w1 = which ? ew.post_w1 : ew.lat_w1; sp.head_b1 = which ? ew.post_b1 : ew.lat_b1;
+    sp.head_w2 = which ? ew.post_w2 : ew.lat_w2; sp.head_b2 = which ? ew.post_b2 : ew.lat_b2;
+    sp.mode = 0; sp.B = B; sp.S = S3; sp.A = A; sp.x = w.x3; sp.valid = w.v0; sp.out_mean = out_mean; sp.out_valid = out_valid;
+    hipLaunchKernelGGL(k_gru_scan, dim3(a_pad / TM, B), dim3(NTHREADS), (8 * TM * LDT + 16) * sizeof(float), s, sp);
+}
+
 int run_encode(struct ::tb_ctx* ctx, const tb_encode_io* io, hipStream_t s) {
     const int B = io->n_scene, A = io->n_agent, P = io->n_pl, T = io->n_tl, NH = io->n_hist;
     if (B <= 0 || A <= 0 || P <= 0 || T <= 0) return tb_fail(ctx, "tb_encode_scene: empty dimension");
@@ -488,10 +558,10 @@ int run_encode(struct ::tb_ctx* ctx, const tb_encode_io* io, hipStream_t s) {
     // map-encoder chunking bounds the per-polyline K/V scratch (3 layers x 32 keys x 128 x 2 x 4 B = 96 KiB / polyline)
     const int scenes_per_chunk = std::max(1, std::min(B, (int)(((size_t)512 << 20) / ((size_t)P * 98304))));
 
-    auto carve = [&](Carver& c, float*& nodef, float*& nodeo, float*& kn, float*& vtn, float*& kvn, float*& plf, float*& kps,
-                     float*& vtps, float*& kvps, float*& kpl, float*& vtpl, float*& kvpl, float*& x0, uint8_t*& v0, float*& x1,
-                     float*& x2, float*& x3, float*& tl3, uint8_t*& tlv3, float*& ktl, float*& vttl, float*& kvtl, float*& kin,
-                     float*& vtin, float*& kvin, float*& tgt, uint8_t*& tgtv, float*& U, float*& V) {
+    float *nodef, *nodeo, *kn, *vtn, *kvn, *plf, *kps, *vtps, *kvps, *tgt, *U, *V;
+    uint8_t* tgtv;
+    LatentWs lws;
+    auto carve = [&](Carver& c) {
         nodef = c.take<float>((size_t)B * P * 20 * 128);
         nodeo = c.take<float>((size_t)scenes_per_chunk * P * 20 * 128);
         kn = c.take<float>((size_t)scenes_per_chunk * P * 3 * 32 * 128);
@@ -501,37 +571,17 @@ int run_encode(struct ::tb_ctx* ctx, const tb_encode_io* io, hipStream_t s) {
         kps = c.take<float>((size_t)B * p_pad * 128);
         vtps = c.take<float>((size_t)B * 128 * p_pad);
         kvps = c.take<float>((size_t)B * p_pad);
-        kpl = c.take<float>((size_t)B * 3 * p_pad * 128);
-        vtpl = c.take<float>((size_t)B * 3 * 128 * p_pad);
-        kvpl = c.take<float>((size_t)B * p_pad);
-        x0 = c.take<float>((size_t)B * S3 * A * 128);
-        v0 = c.take<uint8_t>((size_t)B * S3 * A);
-        x1 = c.take<float>((size_t)B * S3 * A * 128);
-        x2 = c.take<float>((size_t)B * S3 * A * 128);
-        x3 = c.take<float>((size_t)B * S3 * A * 128);
-        tl3 = c.take<float>((size_t)B * S3 * T * 128);
-        tlv3 = c.take<uint8_t>((size_t)B * S3 * T);
-        ktl = c.take<float>((size_t)B * S3 * 3 * t_pad * 128);
-        vttl = c.take<float>((size_t)B * S3 * 3 * 128 * t_pad);
-        kvtl = c.take<float>((size_t)B * S3 * t_pad);
-        kin = c.take<float>((size_t)B * S3 * 3 * a_pad * 128);
-        vtin = c.take<float>((size_t)B * S3 * 3 * 128 * a_pad);
-        kvin = c.take<float>((size_t)B * S3 * a_pad);
+        carve_latent(c, lws, B, S3, A, T, a_pad, p_pad, t_pad);
         tgt = c.take<float>((size_t)B * A * 128);
         tgtv = c.take<uint8_t>((size_t)B * A);
         U = c.take<float>((size_t)B * P * 128);
         V = c.take<float>((size_t)B * A * 128);
     };
-    float *nodef, *nodeo, *kn, *vtn, *plf, *kps, *vtps, *kpl, *vtpl, *x0, *x1, *x2, *x3, *tl3, *ktl, *vttl, *kin, *vtin, *tgt, *U, *V;
-    uint8_t *v0, *tlv3, *tgtv;
-    float *kvn, *kvps, *kvpl, *kvtl, *kvin;
     Carver sz{nullptr};
-    carve(sz, nodef, nodeo, kn, vtn, kvn, plf, kps, vtps, kvps, kpl, vtpl, kvpl, x0, v0, x1, x2, x3, tl3, tlv3, ktl, vttl, kvtl, kin,
-          vtin, kvin, tgt, tgtv, U, V);
+    carve(sz);
     if (tb_ensure_workspace(ctx, sz.off + 256)) return 1;
     Carver c{ctx->d_ws};
-    carve(c, nodef, nodeo, kn, vtn, kvn, plf, kps, vtps, kvps, kpl, vtpl, kvpl, x0, v0, x1, x2, x3, tl3, tlv3, ktl, vttl, kvtl, kin,
-          vtin, kvin, tgt, tgtv, U, V);
+    carve(c);
 
     // ---- input features (sc_input.py:100-140 + input_pe_encoder.py:52-59)
     {
@@ -578,40 +628,8 @@ int run_encode(struct ::tb_ctx* ctx, const tb_encode_io* io, hipStream_t s) {
         launch_xblock(x, B, s);
     }
     // ---- personality prior
-    {
-        const int RC4 = A * 32;
-        size_t total = (size_t)B * S3 * RC4;
-        hipLaunchKernelGGL(k_gather_steps_f, dim3((total + 255) / 256), dim3(256), 0, s, io->agent_feature, x0, B, NH, S3, 5, RC4);
-        total = (size_t)B * S3 * A;
-        hipLaunchKernelGGL(k_gather_steps_u8, dim3((total + 255) / 256), dim3(256), 0, s, io->agent_valid, v0, B, NH, S3, 5, A);
-        total = (size_t)B * S3 * T * 32;
-        hipLaunchKernelGGL(k_gather_steps_f, dim3((total + 255) / 256), dim3(256), 0, s, io->tl_feature, tl3, B, NH, S3, 5, T * 32);
-        total = (size_t)B * S3 * T;
-        hipLaunchKernelGGL(k_gather_steps_u8, dim3((total + 255) / 256), dim3(256), 0, s, io->tl_valid, tlv3, B, NH, S3, 5, T);
-        // agent -> map over the 3*A tokens of each scene (shared as2pl weights)
-        launch_kv_hoist_n(W, ew.as2pl, 3, io->map_feature, io->map_feature_valid, B, P, p_pad, kpl, vtpl, kvpl, s);
-        XBlockP x{};
-        x.W = W; x.n_layer = 3;
-        for (int l = 0; l < 3; ++l) x.L[l] = ew.as2pl[l];
-        x.src = x0; x.src_valid = v0; x.dst = x1; x.K = kpl; x.VT = vtpl; x.kbias = kvpl; x.n_rows = S3 * A; x.n_pad = p_pad; x.eye = 0;
-        launch_xblock(x, B, s);
-        // agent -> traffic lights, per step
-        launch_kv_hoist_n(W, ew.as2tl, 3, tl3, tlv3, B * S3, T, t_pad, ktl, vttl, kvtl, s);
-        for (int l = 0; l < 3; ++l) x.L[l] = ew.as2tl[l];
-        x.src = x1; x.dst = x2; x.K = ktl; x.VT = vttl; x.kbias = kvtl; x.n_rows = A; x.n_pad = t_pad;
-        launch_xblock(x, B * S3, s);
-        // interaction (own weights), tgt = block input
-        launch_kv_hoist_n(W, ew.inter_prior, 3, x2, v0, B * S3, A, a_pad, kin, vtin, kvin, s);
-        for (int l = 0; l < 3; ++l) x.L[l] = ew.inter_prior[l];
-        x.src = x2; x.dst = x3; x.K = kin; x.VT = vtin; x.kbias = kvin; x.n_rows = A; x.n_pad = a_pad; x.eye = 1;
-        launch_xblock(x, B * S3, s);
-        ScanP sp{};
-        sp.W = W;
-        for (int l = 0; l < 3; ++l) sp.gru[l] = ew.gru_prior[l];
-        sp.head_w1 = ew.lat_w1; sp.head_b1 = ew.lat_b1; sp.head_w2 = ew.lat_w2; sp.head_b2 = ew.lat_b2;
-        sp.mode = 0; sp.B = B; sp.S = S3; sp.A = A; sp.x = x3; sp.valid = v0; sp.out_mean = io->latent_mean; sp.out_valid = io->latent_valid;
-        hipLaunchKernelGGL(k_gru_scan, dim3(a_pad / TM, B), dim3(NTHREADS), (8 * TM * LDT + 16) * sizeof(float), s, sp);
-    }
+    launch_latent_branch(W, ew, 0, B, NH, A, P, T, io->agent_feature, io->agent_valid, io->tl_feature, io->tl_valid, io->map_feature,
+                         io->map_feature_valid, lws, io->latent_mean, io->latent_valid, s);
     // ---- destination predictor
     {
         ScanP sp{};
@@ -629,6 +647,55 @@ int run_encode(struct ::tb_ctx* ctx, const tb_encode_io* io, hipStream_t s) {
         d.agent_type = io->agent_type; d.dist_valid = tgtv; d.logits = io->dest_logits;
         hipLaunchKernelGGL(k_dest_pairs, dim3((P + TM - 1) / TM, A, B), dim3(NTHREADS), 0, s, d);
     }
+    TB_HIP(ctx, hipGetLastError());
+    return 0;
+}
+
+
+// Posterior personality of validation_step / training_step (waymo_motion.py:583,597; latent_encoder.py:119-136): the agent and
+// traffic-light tokens of ALL ground-truth steps are encoded (sc_latent.py:150-163,196-217), then the latent branch runs with
+// the posterior interaction / GRU / head weights over every 5th step.  The map feature is the one tb_encode_scene produced
+// (the reference re-encodes the identical map inputs).
+int run_encode_posterior(struct ::tb_ctx* ctx, const tb_posterior_io* io, hipStream_t s) {
+    const int B = io->n_scene, A = io->n_agent, P = io->n_pl, T = io->n_tl, NS = io->n_step;
+    if (B <= 0 || A <= 0 || P <= 0 || T <= 0) return tb_fail(ctx, "tb_encode_posterior: empty dimension");
+    if (A > 256) return tb_fail(ctx, "tb_encode_posterior: n_agent %d > 256 not supported", A);
+    if (NS < 1 || (NS - 1) % 5 != 0) return tb_fail(ctx, "tb_encode_posterior: (n_step - 1) %% 5 != 0 (n_step %d)", NS);
+    const void* req[] = {io->agent_valid, io->agent_pos, io->agent_yaw, io->agent_vel, io->agent_spd, io->agent_acc,
+                         io->agent_yaw_rate, io->agent_type, io->agent_size, io->tl_valid, io->tl_state, io->tl_pos, io->tl_dir,
+                         io->map_feature, io->map_feature_valid, io->latent_mean, io->latent_valid};
+    for (const void* q : req)
+        if (!q) return tb_fail(ctx, "tb_encode_posterior: a required buffer pointer is NULL");
+    const float* W = ctx->d_arena;
+    const EncoderW& ew = ctx->ew;
+    const int a_pad = padk(A), p_pad = padk(P), t_pad = padk(T);
+    const int S3 = (NS - 1) / 5 + 1;
+    float *af, *tf;
+    LatentWs lws;
+    auto carve = [&](Carver& c) {
+        af = c.take<float>((size_t)B * NS * A * 128);
+        tf = c.take<float>((size_t)B * NS * T * 128);
+        carve_latent(c, lws, B, S3, A, T, a_pad, p_pad, t_pad);
+    };
+    Carver sz{nullptr};
+    carve(sz);
+    if (tb_ensure_workspace(ctx, sz.off + 256)) return 1;
+    Carver c{ctx->d_ws};
+    carve(c);
+    TokP t{};
+    t.W = W; t.pe_fxy = ew.pe_fxy; t.pe_fyaw = ew.pe_fyaw;
+    t.kind = 0; t.mlp = ew.agent_enc; t.n_tok = B * NS * A; t.per_scene = NS * A; t.inner = A;
+    t.valid = io->agent_valid; t.pos = io->agent_pos; t.yaw = io->agent_yaw; t.vel = io->agent_vel; t.spd = io->agent_spd;
+    t.acc = io->agent_acc; t.yaw_rate = io->agent_yaw_rate; t.cls = io->agent_type; t.size = io->agent_size;
+    t.out = af;
+    hipLaunchKernelGGL(k_encode_tokens, dim3((t.n_tok + TM - 1) / TM), dim3(NTHREADS), 0, s, t);
+    TokP l{};
+    l.W = W; l.pe_fxy = ew.pe_fxy; l.pe_fyaw = ew.pe_fyaw;
+    l.kind = 1; l.mlp = ew.tl_enc; l.n_tok = B * NS * T; l.per_scene = NS * T; l.inner = T;
+    l.valid = io->tl_valid; l.pos = io->tl_pos; l.dir = io->tl_dir; l.cls = io->tl_state; l.out = tf;
+    hipLaunchKernelGGL(k_encode_tokens, dim3((l.n_tok + TM - 1) / TM), dim3(NTHREADS), 0, s, l);
+    launch_latent_branch(W, ew, 1, B, NS, A, P, T, af, io->agent_valid, tf, io->tl_valid, io->map_feature, io->map_feature_valid, lws,
+                         io->latent_mean, io->latent_valid, s);
     TB_HIP(ctx, hipGetLastError());
     return 0;
 }

@@ -45,7 +45,8 @@ struct RolloutP {
     PolicyW pw;
     PolicyWX px;
     // sizes
-    int n_scene, k_rep, n_inst, n_agent, a_pad, n_pl, p_pad, n_tl, t_pad, n_hist, step_start, n_step_out;
+    int n_scene, k_rep, n_inst, n_agent, a_pad, n_pl, p_pad, n_tl, t_pad, n_hist, n_tl_hist, step_start, n_step_out;
+    uint32_t latent_log_std;  // offset of the log_std (prior or posterior) that latent_log_prob uses
     // encoded scene
     const float* map_feature;     // [B,P,128]
     const float* tl_feature;      // [B,NH,T,128]

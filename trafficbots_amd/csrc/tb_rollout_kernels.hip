@@ -108,7 +108,7 @@ __global__ __launch_bounds__(NTHREADS) void k_rollout_init(RolloutP p) {
         const int row = row0 + tid;
         float lp = 0.f;
         for (int d = 0; d < 16; ++d) {
-            const float stdv = expf(W[pw.latent_log_std + d]);
+            const float stdv = expf(W[p.latent_log_std + d]);
             const float diff = Z[tid * 20 + d] - p.latent_mean[((size_t)b * p.n_agent + row) * 16 + d];
             lp += -(diff * diff) / (2.f * (stdv * stdv)) - logf(stdv) - 0.9189385332046727f;
         }
@@ -429,7 +429,7 @@ __global__ __launch_bounds__(NTHREADS) void k_step(RolloutP p, int t, int do_c, 
     TB_STAMP(9);
     // ---- agent -> traffic lights of step min(t1-1, n_hist-1) (waymo_motion.py:287, traffic_bots.py:213-219)
     {
-        const int g_tl = b * p.n_hist + min(t1 - 1, p.n_hist - 1);
+        const int g_tl = b * p.n_tl_hist + min(t1 - 1, p.n_tl_hist - 1);
         const float* kvd = p.kbias_tl + (size_t)g_tl * p.t_pad;
         const size_t ls = (size_t)p.t_pad * H;
         const float* K0 = p.ktl + ((size_t)g_tl * 3) * ls;

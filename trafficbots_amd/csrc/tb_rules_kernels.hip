@@ -216,12 +216,35 @@ __global__ __launch_bounds__(RT) void k_rule_step(RuleP p) {
 // sticky flags and the passive counter (:331-334, :424-465): thread per (instance, agent)
 __global__ void k_rule_scan(const uint8_t* __restrict__ raw, int n_rows, int n_step, uint8_t* collided, uint8_t* collided_this,
                             uint8_t* road_edge, uint8_t* road_edge_this, uint8_t* red_light, uint8_t* red_light_this,
-                            uint8_t* passive, uint8_t* passive_this) {
+                            uint8_t* passive, uint8_t* passive_this, const float* __restrict__ state,
+                            const uint8_t* __restrict__ valid, const float* __restrict__ goal, const float* __restrict__ agent_size,
+                            int n_agent, int k_rep, uint8_t* goal_reached, uint8_t* goal_reached_this) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_rows) return;
     const size_t plane = (size_t)n_rows * n_step, base = (size_t)r * n_step;
     bool c = false, e = false, l = false, pz = false;
     float counter = 0.f;
+    if (goal && goal_reached) {  // _check_goal_reached (:337-361): within 8 agent lengths and 15 degrees of the goal pose, once
+        const int n = r / n_agent, a = r % n_agent;
+        const size_t ba = (size_t)(n / k_rep) * n_agent + a;
+        const float gx = goal[ba * 4], gy = goal[ba * 4 + 1], gyaw = goal[ba * 4 + 2];
+        const float thr_pos = mul_(agent_size[ba * 3], 8.f);
+        const float thr_rot = 0.2617993877991494f;  // np.deg2rad(15)
+        const float PI_F = 3.14159265358979323846f, TWO_PI_F = 6.28318530717958647692f;
+        bool g = false;
+        for (int s = 0; s < n_step; ++s) {
+            const float* st = state + (base + s) * 4;
+            const float dx = sub_(st[0], gx), dy = sub_(st[1], gy);
+            const bool pos_ok = sqrtf(add_(mul_(dx, dx), mul_(dy, dy))) < thr_pos;
+            float rr = fmodf(add_(sub_(st[2], gyaw), PI_F), TWO_PI_F);  // cast_rad, python remainder
+            if (rr != 0.f && rr < 0.f) rr = add_(rr, TWO_PI_F);
+            const bool rot_ok = fabsf(sub_(rr, PI_F)) < thr_rot;
+            const bool gt_ = pos_ok && rot_ok && valid[base + s] && !g;
+            g |= gt_;
+            if (goal_reached_this) goal_reached_this[base + s] = gt_;
+            goal_reached[base + s] = g;
+        }
+    }
     for (int s = 0; s < n_step; ++s) {
         const bool ct = raw[base + s], et = raw[plane + base + s], lt = raw[2 * plane + base + s], pr = raw[3 * plane + base + s];
         counter = (counter + (pr ? 1.f : 0.f)) * (pr ? 1.f : 0.f);
@@ -249,7 +272,8 @@ int run_rule_checks(const tb_rule_io* io, int n_hist, int step_start, uint8_t* r
     const int n_rows = n_inst * io->n_agent;
     hipLaunchKernelGGL(k_rule_scan, dim3((n_rows + 255) / 256), dim3(256), 0, s, raw_ws, n_rows, io->n_step, io->collided,
                        io->collided_this_step, io->run_road_edge, io->run_road_edge_this_step, io->run_red_light,
-                       io->run_red_light_this_step, io->passive, io->passive_this_step);
+                       io->run_red_light_this_step, io->passive, io->passive_this_step, io->check_state, io->check_valid,
+                       io->agent_goal, io->agent_size, io->n_agent, io->k_futures, io->goal_reached, io->goal_reached_this_step);
     return 0;
 }
 

@@ -208,7 +208,7 @@ __global__ __launch_bounds__(NTHREADS8) void k_step8(RolloutP p, int t, int do_c
     TB_STAMP(9);
     // ---- agent -> traffic lights of step min(t1-1, n_hist-1) (waymo_motion.py:287, traffic_bots.py:213-219)
     {
-        const int g_tl = b * p.n_hist + min(t1 - 1, p.n_hist - 1);
+        const int g_tl = b * p.n_tl_hist + min(t1 - 1, p.n_tl_hist - 1);
         const float* kvd = p.kbias_tl + (size_t)g_tl * p.t_pad;
         const size_t ls = (size_t)p.t_pad * H;
         const float* K0 = p.ktl + ((size_t)g_tl * 3) * ls;

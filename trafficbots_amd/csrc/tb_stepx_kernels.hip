@@ -279,7 +279,7 @@ __global__ __launch_bounds__(NTHREADS) void k_step_x(RolloutP p, int t, int do_c
     }
     TB_STAMP(9);
     {
-        const int g_tl = b * p.n_hist + min(t1 - 1, p.n_hist - 1);
+        const int g_tl = b * p.n_tl_hist + min(t1 - 1, p.n_tl_hist - 1);
         const float* kvd = p.kbias_tl + (size_t)g_tl * p.t_pad;
         const size_t ls = (size_t)p.t_pad * H;
         const xhalf* K0 = reinterpret_cast<const xhalf*>(p.ktl + ((size_t)g_tl * 3) * ls);

@@ -45,6 +45,7 @@ class TbRolloutIO(C.Structure):
         ("final_state", c_f32p), ("final_valid", c_u8p), ("final_hidden", c_f32p),
         ("tap_step", C.c_int32), ("tap_policy_feature", c_f32p), ("tap_agent_feature", c_f32p),
         ("check_state", c_f32p), ("check_valid", c_u8p),
+        ("n_tl_step", C.c_int32), ("latent_posterior", C.c_int32),
     ]
 
 
@@ -59,6 +60,7 @@ class TbRuleIO(C.Structure):
         ("tl_valid", c_u8p), ("tl_state", c_i32p), ("tl_pos", c_f32p),
         ("collided", c_u8p), ("collided_this_step", c_u8p), ("run_road_edge", c_u8p), ("run_road_edge_this_step", c_u8p),
         ("run_red_light", c_u8p), ("run_red_light_this_step", c_u8p), ("passive", c_u8p), ("passive_this_step", c_u8p),
+        ("n_tl_step", C.c_int32), ("agent_goal", c_f32p), ("goal_reached", c_u8p), ("goal_reached_this_step", c_u8p),
     ]
 
 
@@ -96,10 +98,36 @@ class TbMetricIO(C.Structure):
     ]
 
 
+class TbPosteriorIO(C.Structure):
+    _fields_ = [
+        ("n_scene", C.c_int32), ("n_agent", C.c_int32), ("n_pl", C.c_int32), ("n_tl", C.c_int32), ("n_step", C.c_int32),
+        ("agent_valid", c_u8p), ("agent_pos", c_f32p), ("agent_yaw", c_f32p), ("agent_vel", c_f32p), ("agent_spd", c_f32p),
+        ("agent_acc", c_f32p), ("agent_yaw_rate", c_f32p), ("agent_type", c_i32p), ("agent_size", c_f32p),
+        ("tl_valid", c_u8p), ("tl_state", c_i32p), ("tl_pos", c_f32p), ("tl_dir", c_f32p),
+        ("map_feature", c_f32p), ("map_feature_valid", c_u8p), ("latent_mean", c_f32p), ("latent_valid", c_u8p),
+    ]
+
+
+class TbTrainIO(C.Structure):
+    _fields_ = [
+        ("n_scene", C.c_int32), ("n_agent", C.c_int32), ("n_step", C.c_int32), ("n_pl", C.c_int32),
+        ("w_collision", C.c_float), ("reduce_collision_with_max", C.c_int32), ("use_il_loss", C.c_int32),
+        ("crit_pos", C.c_int32), ("crit_rot", C.c_int32), ("angular_type", C.c_int32), ("crit_spd", C.c_int32),
+        ("w_pos", C.c_float), ("w_rot", C.c_float), ("w_spd", C.c_float),
+        ("use_vae_kl", C.c_int32), ("use_diffbar_reward", C.c_int32), ("use_goal", C.c_int32),
+        ("kl_for_unseen_agent", C.c_int32), ("loss_for_teacher_forcing", C.c_int32), ("step_training_start", C.c_int32),
+        ("kl_balance_scale", C.c_float), ("kl_free_nats", C.c_float),
+        ("pred_valid", c_u8p), ("pred_states", c_f32p), ("override_masks", c_u8p), ("gt_valid", c_u8p), ("gt_states", c_f32p),
+        ("agent_size", c_f32p), ("dest_logits", c_f32p), ("goal_valid", c_u8p), ("gt_dest", c_i32p),
+        ("post_mean", c_f32p), ("post_valid", c_u8p), ("prior_mean", c_f32p), ("prior_valid", c_u8p),
+        ("diffbar_rewards", c_f32p), ("diffbar_rewards_valid", c_u8p), ("out", C.POINTER(C.c_double)),
+    ]
+
+
 EXPORTS = (
     "tb_create", "tb_destroy", "tb_last_error", "tb_version", "tb_load_weight", "tb_finalize_weights",
     "tb_rollout", "tb_rollout_begin", "tb_rollout_step", "tb_rollout_state", "tb_encode_scene", "tb_set_timing", "tb_get_timing",
-    "tb_rule_checks", "tb_post_process", "tb_metric_partials", "tb_struct_sizes",
+    "tb_rule_checks", "tb_post_process", "tb_metric_partials", "tb_struct_sizes", "tb_encode_posterior", "tb_train_partials",
 )
 
 _lib: Optional[C.CDLL] = None
@@ -149,11 +177,16 @@ def load() -> C.CDLL:
     lib.tb_post_process.restype = C.c_int
     lib.tb_metric_partials.argtypes = [C.c_void_p, C.POINTER(TbMetricIO), C.c_void_p]
     lib.tb_metric_partials.restype = C.c_int
+    lib.tb_encode_posterior.argtypes = [C.c_void_p, C.POINTER(TbPosteriorIO), C.c_void_p]
+    lib.tb_encode_posterior.restype = C.c_int
+    lib.tb_train_partials.argtypes = [C.c_void_p, C.POINTER(TbTrainIO), C.c_void_p]
+    lib.tb_train_partials.restype = C.c_int
     lib.tb_struct_sizes.argtypes = [C.POINTER(C.c_int32)]
     lib.tb_struct_sizes.restype = None
-    sizes = (C.c_int32 * 7)()
+    sizes = (C.c_int32 * 9)()
     lib.tb_struct_sizes(sizes)
     mine = [C.sizeof(x) for x in (TbConfig, TbRolloutIO, TbEncodeIO, TbRuleIO, TbPostIO, TbMetricIO)] + [C.sizeof(C.c_void_p)]
+    mine += [C.sizeof(TbPosteriorIO), C.sizeof(TbTrainIO)]
     if list(sizes) != mine:
         raise RuntimeError(f"trafficbots_amd: ctypes struct layouts {mine} do not match the library's {list(sizes)} (stale build?)")
     lib.tb_set_timing.argtypes = [C.c_void_p, C.c_int]

@@ -83,6 +83,47 @@ def scene_from_batch(batch: Dict[str, Tensor], device, n_hist: int = 11) -> Dict
     return s
 
 
+TRAIN_FIELDS = ("vae_kl_counter", "vae_kl", "diffbar_reward_counter", "diffbar_reward", "goal_loss", "goal_counter")
+_CRITERIA = {"SmoothL1Loss": 0, "MSELoss": 1, "L1Loss": 2}
+_ANGULAR = {None: 0, "cast": 1, "cosine": 2, "vector": 3}
+
+
+def gt_from_batch(batch: Dict[str, Tensor], device) -> Dict[str, Tensor]:
+    """Ground-truth part of a validation / training batch (`data_h5_womd.py:85-118`: "agent/*", "tl_stop/*" over all 91
+    steps) -> the C ABI's device layout: what `SceneCentricPreProcessing` exposes as "gt/*" (`scene_centric.py:103-110`),
+    `SceneCentricLatent` as "latent_post/*" (`sc_latent.py:150-163,196-217`) and `reactive_replay` as `features`
+    (`waymo_motion.py:448-462`)."""
+
+    def g(k):
+        v = batch[k]
+        if isinstance(v, np.ndarray):
+            v = torch.from_numpy(v)
+        return v.to(device)
+
+    f32, u8 = torch.float32, torch.uint8
+    s: Dict[str, Tensor] = {}
+    s["agent_valid"] = g("agent/valid").to(u8).contiguous()
+    pos, yaw, spd = g("agent/pos").to(f32), g("agent/yaw_bbox").to(f32), g("agent/spd").to(f32)
+    s["agent_pos"] = pos.contiguous()
+    s["agent_yaw"] = yaw[..., 0].contiguous()
+    s["agent_spd"] = spd[..., 0].contiguous()
+    s["agent_state"] = torch.cat([pos, yaw, spd], -1).contiguous()
+    s["agent_vel"] = g("agent/vel").to(f32).contiguous()
+    s["agent_acc"] = g("agent/acc")[..., 0].to(f32).contiguous()
+    s["agent_yaw_rate"] = g("agent/yaw_rate")[..., 0].to(f32).contiguous()
+    s["agent_type"] = _onehot_to_index(g("agent/type"))
+    s["agent_size"] = g("agent/size").to(f32).contiguous()
+    s["agent_role"] = g("agent/role").to(u8).contiguous()
+    s["tl_valid"] = g("tl_stop/valid").to(u8).contiguous()
+    s["tl_state"] = _onehot_to_index(g("tl_stop/state"))
+    s["tl_pos"] = g("tl_stop/pos").to(f32).contiguous()
+    s["tl_dir"] = g("tl_stop/dir").to(f32).contiguous()
+    s["gt_dest"] = g("agent/dest").to(torch.int32).contiguous()
+    if "agent/goal" in batch:
+        s["gt_goal"] = g("agent/goal").to(f32).contiguous()
+    return s
+
+
 class HipEngine:
     """One `tb_ctx` on one device."""
 
@@ -160,6 +201,93 @@ class HipEngine:
         self._check(self.lib.tb_encode_scene(self._ctx, C.byref(io), self._stream()), "tb_encode_scene")
         return out
 
+    def encode_posterior(self, gt: Dict[str, Tensor], feats: Dict[str, Tensor]) -> Dict[str, Tensor]:
+        """Posterior personality over the full ground-truth episode (`tb_encode_posterior`; `LatentEncoder.forward(posterior=
+        True)`, `latent_encoder.py:98-136`, on the "latent_post/*" inputs): `gt` from :func:`gt_from_batch`, `feats` the output
+        of :meth:`encode_scene` for the same scenes (its map feature is reused).  Returns latent_mean [B,A,16], latent_valid."""
+        b, ns, a = gt["agent_valid"].shape
+        p = feats["map_feature"].shape[1]
+        t = gt["tl_valid"].shape[2]
+        out = {"latent_mean": torch.empty(b, a, 16, device=self.device, dtype=torch.float32),
+               "latent_valid": torch.empty(b, a, device=self.device, dtype=torch.uint8)}
+        io = hip.TbPosteriorIO()
+        io.n_scene, io.n_agent, io.n_pl, io.n_tl, io.n_step = b, a, p, t, ns
+        for name in ("agent_valid", "tl_valid"):
+            setattr(io, name, hip.ptr(gt[name], hip.c_u8p))
+        for name in ("agent_pos", "agent_yaw", "agent_vel", "agent_spd", "agent_acc", "agent_yaw_rate", "agent_size", "tl_pos", "tl_dir"):
+            setattr(io, name, hip.ptr(gt[name], hip.c_f32p))
+        for name in ("agent_type", "tl_state"):
+            setattr(io, name, hip.ptr(gt[name], hip.c_i32p))
+        io.map_feature = hip.ptr(feats["map_feature"], hip.c_f32p)
+        io.map_feature_valid = hip.ptr(feats["map_feature_valid"], hip.c_u8p)
+        io.latent_mean = hip.ptr(out["latent_mean"], hip.c_f32p)
+        io.latent_valid = hip.ptr(out["latent_valid"], hip.c_u8p)
+        out["_keepalive"] = (gt, feats)
+        self._check(self.lib.tb_encode_posterior(self._ctx, C.byref(io), self._stream()), "tb_encode_posterior")
+        return out
+
+    def train_partials(self, buf: Dict[str, Tensor], gt_valid: Optional[Tensor], gt_states: Optional[Tensor], agent_size: Tensor,
+                       dest_logits: Optional[Tensor] = None, goal_valid: Optional[Tensor] = None, gt_dest: Optional[Tensor] = None,
+                       post: Optional[Dict[str, Tensor]] = None, prior: Optional[Dict[str, Tensor]] = None):
+        """Forward training losses of a replayed episode (`tb_train_partials`): the per-step `DifferentiableReward`
+        (`rewards.py:33-131`, config group `differentiable_reward`) over the buffer `buf` (preds [B,A,S,4], valid,
+        override_masks [B,A,S]; K = 1) against ground truth [B,A,S(,4)], and the six `TrainingMetrics` "sum" states
+        (`training.py:62-139`, group `training_metrics`) as a float64 device vector in `TRAIN_FIELDS` order.
+        Without destination logits / personalities only the rewards (and the two reward states) are produced.
+        Returns (diffbar_rewards [B,A,S], diffbar_rewards_valid [B,A,S] uint8, states [6])."""
+        rw, tm = self.cfg["differentiable_reward"], self.cfg["training_metrics"]
+        if tm["w_relevant_agent"] > 0 or tm["p_loss_for_irrelevant"] > 0:
+            raise NotImplementedError("training_metrics.w_relevant_agent / p_loss_for_irrelevant > 0 are not built")
+        dev, u8, f32 = self.device, torch.uint8, torch.float32
+        b, a, n_step = buf["valid"].shape
+        io = hip.TbTrainIO()
+        io.n_scene, io.n_agent, io.n_step, io.n_pl = b, a, n_step, (dest_logits.shape[-1] if dest_logits is not None else 1)
+        io.w_collision = float(rw["w_collision"])
+        io.reduce_collision_with_max = int(bool(rw["reduce_collsion_with_max"]))
+        io.use_il_loss = int(bool(rw["use_il_loss"]))
+        io.crit_pos, io.crit_rot, io.crit_spd = (_CRITERIA[rw[k]["criterion"]] for k in ("l_pos", "l_rot", "l_spd"))
+        io.angular_type = _ANGULAR[rw["l_rot"].get("angular_type")]
+        io.w_pos, io.w_rot, io.w_spd = (float(rw[k]["weight"]) for k in ("l_pos", "l_rot", "l_spd"))
+        io.use_vae_kl = int(tm["w_vae_kl"] > 0 and post is not None and prior is not None)
+        io.use_diffbar_reward = int(tm["w_diffbar_reward"] > 0)
+        io.use_goal = int(tm["w_goal"] > 0 and dest_logits is not None)
+        io.kl_for_unseen_agent = int(bool(tm["kl_for_unseen_agent"]))
+        io.loss_for_teacher_forcing = int(bool(tm["loss_for_teacher_forcing"]))
+        io.step_training_start = int(tm["step_training_start"])
+        io.kl_balance_scale, io.kl_free_nats = float(tm["kl_balance_scale"]), float(tm["kl_free_nats"])
+        keep = []
+
+        def c8(t):
+            t = t.to(dev).to(u8).contiguous()
+            keep.append(t)
+            return hip.ptr(t, hip.c_u8p)
+
+        def cf(t):
+            t = t.to(dev).to(f32).contiguous()
+            keep.append(t)
+            return hip.ptr(t, hip.c_f32p)
+
+        io.pred_valid, io.pred_states, io.override_masks = c8(buf["valid"]), cf(buf["preds"]), c8(buf["override_masks"])
+        io.gt_valid = c8(gt_valid) if gt_valid is not None else hip.ptr(None, hip.c_u8p)
+        io.gt_states = cf(gt_states) if gt_states is not None else hip.ptr(None, hip.c_f32p)
+        io.agent_size = cf(agent_size)
+        if io.use_goal:
+            io.dest_logits, io.goal_valid = cf(dest_logits), c8(goal_valid)
+            gd = gt_dest.to(dev).to(torch.int32).contiguous()
+            keep.append(gd)
+            io.gt_dest = hip.ptr(gd, hip.c_i32p)
+        if io.use_vae_kl:
+            io.post_mean, io.post_valid = cf(post["latent_mean"]), c8(post["latent_valid"])
+            io.prior_mean, io.prior_valid = cf(prior["latent_mean"]), c8(prior["latent_valid"])
+        rewards = torch.empty(b, a, n_step, device=dev, dtype=f32)
+        rvalid = torch.empty(b, a, n_step, device=dev, dtype=u8)
+        states = torch.zeros(len(TRAIN_FIELDS), device=dev, dtype=torch.float64)
+        io.diffbar_rewards, io.diffbar_rewards_valid = hip.ptr(rewards, hip.c_f32p), hip.ptr(rvalid, hip.c_u8p)
+        io.out = C.cast(C.c_void_p(states.data_ptr()), C.POINTER(C.c_double))
+        self._check(self.lib.tb_train_partials(self._ctx, C.byref(io), self._stream()), "tb_train_partials")
+        self._train_keepalive = keep
+        return rewards, rvalid, states
+
     # -------------------------------------------------------------------------------- rollout
     def rollout(
         self,
@@ -176,11 +304,18 @@ class HipEngine:
         out: Optional[Dict[str, Tensor]] = None,
         stepwise: bool = False,
         record_check_states: bool = False,
+        gt: Optional[Dict[str, Tensor]] = None,
+        latent_posterior: bool = False,
     ) -> Dict[str, Tensor]:
         """Closed-loop rollout of N = B*K instances (instance n uses scene n // K).  Returns the
         `RolloutBuffer` fields as [N, A, S, ...] tensors (`buffer.py:72-90`).  With `stepwise=True` only the
-        prologue runs (`tb_rollout_begin`); advance with :meth:`rollout_step`, inspect with :meth:`rollout_state`."""
-        b, nh, a = s["agent_valid"].shape
+        prologue runs (`tb_rollout_begin`); advance with :meth:`rollout_step`, inspect with :meth:`rollout_state`.
+        `gt` (:func:`gt_from_batch`) makes the full ground truth the source of initial state / overrides / the kill rule, as
+        `reactive_replay` and the validation-time `joint_future_pred` do (`waymo_motion.py:457-461,538-545`); the traffic
+        lights stay those of the history.  `latent_posterior` selects the posterior log_std for `latent_log_prob`."""
+        n_tl_step = s["tl_valid"].shape[1]
+        ag = s if gt is None else gt
+        b, nh, a = ag["agent_valid"].shape
         p = s["map_valid"].shape[1]
         t = s["tl_valid"].shape[2]
         n = b * k_futures
@@ -189,8 +324,9 @@ class HipEngine:
         if mask_teacher_forcing is None:
             tf = self.cfg["teacher_forcing_joint_future_pred"]
             mask_teacher_forcing = teacher_forcing_mask(
-                s["agent_valid"].bool(), tf.get("step_spawn_agent", 10), tf.get("step_warm_start", 10)
+                ag["agent_valid"].bool(), tf.get("step_spawn_agent", 10), tf.get("step_warm_start", 10)
             ).to(u8).contiguous()
+        assert mask_teacher_forcing.shape == (b, nh, a)
         if out is None:
             out = {
                 "preds": torch.empty(n, a, n_step, 4, device=dev, dtype=f32),
@@ -215,11 +351,12 @@ class HipEngine:
         io.map_feature_valid = hip.ptr(feats["map_feature_valid"], hip.c_u8p)
         io.tl_feature = hip.ptr(feats["tl_feature"], hip.c_f32p)
         io.tl_feature_valid = hip.ptr(s["tl_valid"], hip.c_u8p)
-        io.agent_valid = hip.ptr(s["agent_valid"], hip.c_u8p)
-        io.agent_state = hip.ptr(s["agent_state"], hip.c_f32p)
-        io.agent_vel = hip.ptr(s["agent_vel"], hip.c_f32p)
-        io.agent_acc = hip.ptr(s["agent_acc"], hip.c_f32p)
-        io.agent_yaw_rate = hip.ptr(s["agent_yaw_rate"], hip.c_f32p)
+        io.n_tl_step, io.latent_posterior = n_tl_step, int(latent_posterior)
+        io.agent_valid = hip.ptr(ag["agent_valid"], hip.c_u8p)
+        io.agent_state = hip.ptr(ag["agent_state"], hip.c_f32p)
+        io.agent_vel = hip.ptr(ag["agent_vel"], hip.c_f32p)
+        io.agent_acc = hip.ptr(ag["agent_acc"], hip.c_f32p)
+        io.agent_yaw_rate = hip.ptr(ag["agent_yaw_rate"], hip.c_f32p)
         io.mask_teacher_forcing = hip.ptr(mask_teacher_forcing, hip.c_u8p)
         io.agent_type = hip.ptr(s["agent_type"], hip.c_i32p)
         io.agent_size = hip.ptr(s["agent_size"], hip.c_f32p)
@@ -253,7 +390,7 @@ class HipEngine:
         io.check_state = hip.ptr(out.get("check_state"), hip.c_f32p)
         io.check_valid = hip.ptr(out.get("check_valid"), hip.c_u8p)
         # keep the borrowed inputs alive until the stream work is done
-        out["_keepalive"] = (latent_sample, latent_mean, dest, goal_valid, mask_teacher_forcing, s, feats)
+        out["_keepalive"] = (latent_sample, latent_mean, dest, goal_valid, mask_teacher_forcing, s, feats, gt)
         if stepwise:
             self._check(self.lib.tb_rollout_begin(self._ctx, C.byref(io), self._stream()), "tb_rollout_begin")
             self._step_out = out
@@ -262,11 +399,14 @@ class HipEngine:
         return out
 
     def rule_checks(self, s: Dict[str, Tensor], check_state: Tensor, check_valid: Tensor, k_futures: int,
-                    flags: Dict[str, bool]) -> Dict[str, Tensor]:
+                    flags: Dict[str, bool], tl: Optional[Dict[str, Tensor]] = None, agent_goal: Optional[Tensor] = None
+                    ) -> Dict[str, Tensor]:
         """The flag-gated checks of `TrafficRuleChecker.check` (`traffic_rule_checker.py:122-335, 412-516`) over a recorded
         rollout (`tb_rule_checks`): `check_state` [N,A,S,4] / `check_valid` [N,A,S] as recorded by `rollout(...,
         record_check_states=True)`, `s` the pre-processed scene, `flags` the `traffic_rule_checker` config group.
-        Returns the eight [N,A,S] uint8 arrays (zeros for a disabled check, like the reference)."""
+        Returns the eight [N,A,S] uint8 arrays (zeros for a disabled check, like the reference).  `tl` (tl_valid / tl_state /
+        tl_pos over any number of steps) replaces the history traffic lights (reactive_replay hands the checker the 91-step
+        ground truth); `agent_goal` [B,A,4] adds goal_reached / goal_reached_this_step (`_check_goal_reached`, :337-361)."""
         n, a, n_step = check_valid.shape
         b = s["agent_valid"].shape[0]
         io = hip.TbRuleIO()
@@ -281,12 +421,23 @@ class HipEngine:
         io.agent_type, io.agent_size = hip.ptr(s["agent_type"], hip.c_i32p), hip.ptr(s["agent_size"], hip.c_f32p)
         io.map_valid, io.map_type = hip.ptr(s["map_valid"], hip.c_u8p), hip.ptr(s["map_type"], hip.c_i32p)
         io.map_pos, io.map_dir = hip.ptr(s["map_pos"], hip.c_f32p), hip.ptr(s["map_dir"], hip.c_f32p)
-        io.tl_valid, io.tl_state, io.tl_pos = hip.ptr(s["tl_valid"], hip.c_u8p), hip.ptr(s["tl_state"], hip.c_i32p), hip.ptr(s["tl_pos"], hip.c_f32p)
+        tls = s if tl is None else tl
+        assert tls["tl_valid"].shape[2] == s["tl_valid"].shape[2]
+        io.tl_valid, io.tl_state, io.tl_pos = hip.ptr(tls["tl_valid"], hip.c_u8p), hip.ptr(tls["tl_state"], hip.c_i32p), hip.ptr(tls["tl_pos"], hip.c_f32p)
+        io.n_tl_step = tls["tl_valid"].shape[1]
         out = {}
         for name in RULE_KEYS:
             out[name] = torch.empty(n, a, n_step, device=self.device, dtype=torch.uint8)
             setattr(io, name, hip.ptr(out[name], hip.c_u8p))
-        out["_keepalive"] = (cs, cv, s)
+        goal = None
+        if agent_goal is not None:
+            goal = agent_goal.to(self.device).to(torch.float32).contiguous()
+            assert goal.shape == (b, a, 4)
+            io.agent_goal = hip.ptr(goal, hip.c_f32p)
+            for name in ("goal_reached", "goal_reached_this_step"):
+                out[name] = torch.empty(n, a, n_step, device=self.device, dtype=torch.uint8)
+                setattr(io, name, hip.ptr(out[name], hip.c_u8p))
+        out["_keepalive"] = (cs, cv, s, tls, goal)
         self._check(self.lib.tb_rule_checks(self._ctx, C.byref(io), self._stream()), "tb_rule_checks")
         return out
 

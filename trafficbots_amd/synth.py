@@ -174,6 +174,93 @@ def make_batch(base_seed: int, n_scene: int, scene_offset: int = 0, **kw) -> Dic
     return {k: np.stack([s[k] for s in scenes], 0) for k in scenes[0].keys()}
 
 
+N_STEP_GT = 91
+
+
+def make_val_scene(seed: int, p_future_spawn: float = 0.15, p_future_exit: float = 0.25, wiggle: float = 0.3,
+                   **kw) -> Dict[str, np.ndarray]:
+    """One scene in the reference's validation-split layout (`src/data_modules/data_h5_womd.py:85-118`): the test-split keys
+    of :func:`make_scene` (unchanged, same seed) plus the 91-step ground truth -- `agent/*`, `tl_stop/*`, `agent/goal`,
+    `agent/dest`, `agent/cmd` -- whose first 11 steps ARE the history.  The future continues each history with a slowly
+    varying acceleration / yaw rate (so a policy rollout and the ground truth differ by a non-trivial amount), agents leave
+    (`p_future_exit`) or first appear (`p_future_spawn`, exercising step_spawn_agent=90 of teacher_forcing_reactive_replay)
+    after the history."""
+    out = make_scene(seed, **kw)
+    rs = RawStream(seed + 0x5EED0000)
+    f32 = np.float32
+    n_agent = out["history/agent/valid"].shape[1]
+    n_tl = out["history/tl_stop/valid"].shape[1]
+    n_pl = out["map/valid"].shape[0]
+    nf = N_STEP_GT - N_STEP_HIST
+    h = {k: out[f"history/agent/{k}"].astype(np.float64) for k in ("pos", "vel", "spd", "acc", "yaw_bbox", "yaw_rate")}
+    # future controls: history value + a smooth random drift
+    acc_f = h["acc"][-1, :, 0][None] + np.cumsum(rs.uniform(-wiggle, wiggle, (nf, n_agent)), 0) * 0.2
+    yr_f = h["yaw_rate"][-1, :, 0][None] + np.cumsum(rs.uniform(-wiggle, wiggle, (nf, n_agent)), 0) * 0.05
+    spd, yaw, pos = [h["spd"][-1, :, 0]], [h["yaw_bbox"][-1, :, 0]], [h["pos"][-1]]
+    vel = []
+    for i in range(nf):
+        v_mid = spd[-1] + 0.5 * DT * acc_f[i]
+        th_mid = yaw[-1] + 0.5 * DT * yr_f[i]
+        pos.append(pos[-1] + DT * np.stack([v_mid * np.cos(th_mid), v_mid * np.sin(th_mid)], -1))
+        spd.append(spd[-1] + DT * acc_f[i])
+        yaw.append(yaw[-1] + DT * yr_f[i])
+        vel.append(np.stack([spd[-1] * np.cos(yaw[-1]), spd[-1] * np.sin(yaw[-1])], -1))
+    fut = {
+        "pos": np.stack(pos[1:], 0), "vel": np.stack(vel, 0), "spd": np.stack(spd[1:], 0)[..., None],
+        "acc": acc_f[..., None], "yaw_bbox": np.stack(yaw[1:], 0)[..., None], "yaw_rate": yr_f[..., None],
+    }
+    for k, v in fut.items():
+        out[f"agent/{k}"] = np.concatenate([out[f"history/agent/{k}"], v.astype(f32)], 0)
+    out["agent/z"] = np.zeros((N_STEP_GT, n_agent, 1), dtype=f32)
+    hv = out["history/agent/valid"]
+    steps = np.arange(N_STEP_HIST, N_STEP_GT)[:, None]
+    exits = rs.bernoulli(p_future_exit, (n_agent,))
+    t_exit = rs.integers(nf, (n_agent,)) + N_STEP_HIST
+    spawns = rs.bernoulli(p_future_spawn, (n_agent,)) & ~hv.any(0)
+    t_spawn = rs.integers(nf - 1, (n_agent,)) + N_STEP_HIST
+    fv = np.broadcast_to(hv[-1][None], (nf, n_agent)).copy()
+    fv &= ~(exits[None] & (steps >= t_exit[None]))
+    fv |= spawns[None] & (steps >= t_spawn[None])
+    fv[:, 0] = True
+    out["agent/valid"] = np.concatenate([hv, fv], 0)
+    for k in ("type", "role", "size", "object_id"):
+        out[f"agent/{k}"] = out[f"history/agent/{k}"]
+    # ground-truth destination (index of a polyline) and goal (last valid state)
+    # (a feasible one for the agent's type, as in the dataset: the destination predictor masks the others to -inf,
+    # goal_manager.py:294-307, and their negative log-likelihood would be infinite)
+    pl_idx = out["map/type"].argmax(-1)
+    pl_ok = out["map/valid"].any(-1) & (pl_idx < 5)
+    a_idx = out["history/agent/type"].argmax(-1)
+    banned = np.stack([pl_idx == 3, pl_idx < 4, pl_idx < 3], 0)[a_idx]  # [A,P] veh / ped / cyc
+    feas = pl_ok[None] & ~banned
+    feas[~feas.any(-1)] = True
+    pick = (rs.u01((n_agent,)) * feas.sum(-1)).astype(np.int64)
+    out["agent/dest"] = np.argmax(np.cumsum(feas, -1) > pick[:, None], -1).astype(np.int64)
+    st = np.concatenate([out["agent/pos"], out["agent/yaw_bbox"], out["agent/spd"]], -1)  # [91,A,4]
+    last = N_STEP_GT - 1 - np.argmax(out["agent/valid"][::-1], 0)
+    out["agent/goal"] = st[last, np.arange(n_agent)].astype(f32)
+    out["agent/cmd"] = np.zeros((n_agent, 8), dtype=bool)
+    out["agent/cmd"][np.arange(n_agent), rs.integers(8, (n_agent,))] = True
+    # traffic lights: history, then fresh flicker / states over the same stop points
+    tv0 = out["history/tl_stop/valid"][0]
+    flick = rs.bernoulli(0.05, (nf, n_tl))
+    tvf = tv0[None] ^ (flick & tv0[None])
+    idx = rs.integers(N_TL_STATE, (nf, n_tl))
+    tsf = np.zeros((nf, n_tl, N_TL_STATE), dtype=bool)
+    tsf[np.arange(nf)[:, None], np.arange(n_tl)[None, :], idx] = True
+    out["tl_stop/valid"] = np.concatenate([out["history/tl_stop/valid"], tvf], 0)
+    out["tl_stop/state"] = np.concatenate([out["history/tl_stop/state"], tsf], 0)
+    for k in ("pos", "dir"):
+        out[f"tl_stop/{k}"] = np.broadcast_to(out[f"history/tl_stop/{k}"][:1], (N_STEP_GT, n_tl, 2)).copy()
+    return out
+
+
+def make_val_batch(base_seed: int, n_scene: int, scene_offset: int = 0, **kw) -> Dict[str, np.ndarray]:
+    """Batch-stacked :func:`make_val_scene` (same seeding rule as :func:`make_batch`)."""
+    scenes = [make_val_scene(base_seed + scene_offset + i, **kw) for i in range(n_scene)]
+    return {k: np.stack([s[k] for s in scenes], 0) for k in scenes[0].keys()}
+
+
 def make_post_inputs(seed: int, n_scene: int, n_agent: int, n_pred: int, n_step: int = 80):
     """Seeded inputs of `WaymoPostProcessing.forward` (valid [B,A], scores [B,A,NP] un-normalised, trajs [B,A,NP,S,4],
     agent_type [B,A,3]): clustered futures -- five base paths per agent plus small per-mode perturbations -- so that NMS has

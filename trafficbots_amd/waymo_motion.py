@@ -3,7 +3,8 @@
 Same method names, argument meaning and outputs as `pl_modules.waymo_motion.WaymoMotion`
 (`src/pl_modules/waymo_motion.py`) and `models.traffic_bots.TrafficBots`
 (`src/models/traffic_bots.py`) for: `pre_processing`, `encode_input_features`,
-`goal_manager.pred_goal`, `latent_encoder`, `rollout`, `joint_future_pred`, `test_step`.
+`goal_manager.pred_goal` / `get_gt_goal`, `latent_encoder` (prior and posterior), `rollout`, `reactive_replay`,
+`joint_future_pred`, `test_step`, `validation_step` (forward losses and metric states; no backward).
 Everything numerical is executed by `libtrafficbots_hip.so` through :class:`HipEngine`; this file
 is argument plumbing.  Lightning/Hydra are not required (and not rebuilt): the class is a plain
 object that can be wrapped by a LightningModule in the reference harness.
@@ -17,7 +18,8 @@ from torch import Tensor
 
 from .config import load_model_config
 from .distributions import DestCategorical, DiagGaussian
-from .runtime import HipEngine, scene_from_batch, teacher_forcing_mask
+from .metrics import ErrorMetrics, TrafficRuleMetrics, TrainingMetrics
+from .runtime import HipEngine, gt_from_batch, scene_from_batch, teacher_forcing_mask
 
 _VIOLATION_KEYS = (
     "outside_map", "outside_map_this_step", "collided", "collided_this_step", "run_road_edge",
@@ -39,7 +41,7 @@ class RolloutBuffer:
         self.violations: Dict[str, Tensor] = {}
         self.latent_log_probs: Tensor = None
         self.action_log_probs: Tensor = None
-        self.diffbar_rewards = []  # training-only in the reference; not produced (OUT OF SCOPE)
+        self.diffbar_rewards = []  # [N, A, S] once a rollout ran against ground truth (K = 1), else empty
         self.diffbar_rewards_valid = []
         self.vis_dicts: Dict[str, Tensor] = {}
 
@@ -56,6 +58,8 @@ class RolloutBuffer:
         self.violations = {k: fr(v) for k, v in self.violations.items()}
         self.latent_log_probs = fr(self.latent_log_probs)
         self.action_log_probs = fr(self.action_log_probs)
+        if torch.is_tensor(self.diffbar_rewards):
+            self.diffbar_rewards, self.diffbar_rewards_valid = fr(self.diffbar_rewards), fr(self.diffbar_rewards_valid)
 
 
 class _GoalManager:
@@ -69,7 +73,11 @@ class _GoalManager:
     def pred_goal(self, **kwargs) -> DestCategorical:
         """`GoalManager.pred_goal` -> `DestPredictor.forward` (`goal_manager.py:78-82,202-333`).  The logits
         were produced together with the features by `encode_input_features`."""
-        return DestCategorical(logits=self._o._enc["dest_logits"], valid=self._o._enc["latent_valid"].bool())
+        return DestCategorical(logits=self._o._enc["dest_logits"], valid=self._o._scene["agent_valid"].bool().any(1))
+
+    def get_gt_goal(self, agent_valid: Tensor, gt_goal: Optional[Tensor], gt_dest: Tensor) -> Tuple[Tensor, Tensor]:
+        """`GoalManager.get_gt_goal`, goal_attr_mode "dest" (`goal_manager.py:50-75`)."""
+        return gt_dest, agent_valid.bool().any(1)
 
 
 class TrafficBots:
@@ -79,13 +87,16 @@ class TrafficBots:
         self.engine = engine
         self.goal_manager = _GoalManager(self)
         self._enc: Dict[str, Tensor] = {}
+        self._scene: Dict[str, Tensor] = {}
         self._log_std: Optional[Tensor] = None
+        self._log_std_post: Optional[Tensor] = None
 
     def encode_input_features(self, scene: Dict[str, Tensor]) -> Dict[str, Tensor]:
         """`TrafficBots.encode_input_features` (`traffic_bots.py:109-151`) on a pre-processed scene
         (:meth:`WaymoMotion.pre_processing`).  One HIP call also yields the prior mean and the destination
         logits, which `latent_encoder` / `goal_manager.pred_goal` then hand out."""
         self._enc = self.engine.encode_scene(scene)
+        self._scene = scene
         e = self._enc
         return {
             "agent_feature": e["agent_feature"], "agent_feature_valid": scene["agent_valid"].bool(),
@@ -93,8 +104,15 @@ class TrafficBots:
             "tl_feature": e["tl_feature"], "tl_feature_valid": scene["tl_valid"].bool(),
         }
 
-    def latent_encoder(self, **kwargs) -> DiagGaussian:
-        """`LatentEncoder.forward`, prior branch (`latent_encoder.py:70-147`)."""
+    def latent_encoder(self, posterior: bool = False, gt: Optional[Dict[str, Tensor]] = None, **kwargs) -> DiagGaussian:
+        """`LatentEncoder.forward` (`latent_encoder.py:70-147`).  The prior was produced by `encode_input_features`; the
+        posterior (`posterior=True`) runs `tb_encode_posterior` on the full ground truth `gt` (the "gt" entry of the
+        pre-processed validation scene) and the map feature of the last `encode_input_features`."""
+        if posterior:
+            if gt is None:
+                raise ValueError("latent_encoder(posterior=True) needs the ground truth (pre_processing(batch)['gt'])")
+            post = self.engine.encode_posterior(gt, self._enc)
+            return DiagGaussian(post["latent_mean"], self._log_std_post, valid=post["latent_valid"].bool())
         return DiagGaussian(self._enc["latent_mean"], self._log_std, valid=self._enc["latent_valid"].bool())
 
 
@@ -108,18 +126,32 @@ class WaymoMotion:
         from .post_processing import WaymoPostProcessing
 
         self.waymo_post_processing = WaymoPostProcessing(self.engine, **self.hparams.get("waymo_post_processing", {}))
+        # metric holders of validation_step (waymo_motion.py:86-105); the states are produced on the GPU
+        tm = self.hparams["training_metrics"]
+        self.train_metrics_reactive_replay = TrainingMetrics("reactive_replay", **tm)
+        self.err_metrics_reactive_replay = ErrorMetrics("reactive_replay")
+        self.rule_metrics_reactive_replay = TrafficRuleMetrics("reactive_replay")
+        self.err_metrics_joint_future_pred = ErrorMetrics("joint_future_pred")
+        self.rule_metrics_joint_future_pred = TrafficRuleMetrics("joint_future_pred")
 
     # ------------------------------------------------------------------ weights
     def load_state_dict(self, state_dict: Dict) -> None:
         self.engine.load_state_dict(state_dict)
         ls = state_dict["model.latent_encoder.latent_prior_dist.log_std"]
         self.model._log_std = torch.as_tensor(ls, dtype=torch.float32).to(self.device)
+        lp = state_dict["model.latent_encoder.latent_post_dist.log_std"]
+        self.model._log_std_post = torch.as_tensor(lp, dtype=torch.float32).to(self.device)
 
     # ------------------------------------------------------------------ pre-processing
     def pre_processing(self, batch: Dict[str, Tensor]) -> Dict[str, Tensor]:
         """Eval-mode `SceneCentricPreProcessing` + the layout half of `SceneCentricInput`
-        (`scene_centric.py:103-133`, `sc_input.py:100-140`); attr/PE/MLP run inside `tb_encode_scene`."""
-        return scene_from_batch(batch, self.device, self.n_hist)
+        (`scene_centric.py:103-133`, `sc_input.py:100-140`); attr/PE/MLP run inside `tb_encode_scene`.  A validation /
+        training batch (one that carries "agent/valid") also yields the full ground truth as the nested dict `scene["gt"]`
+        (`scene_centric.py:103-110`, `sc_latent.py:150-163,196-217`)."""
+        scene = scene_from_batch(batch, self.device, self.n_hist)
+        if "agent/valid" in batch:
+            scene["gt"] = gt_from_batch(batch, self.device)
+        return scene
 
     # ------------------------------------------------------------------ rollout
     def rollout(
@@ -140,8 +172,13 @@ class WaymoMotion:
         latent_eps: Optional[Tensor] = None,
         tap_step: int = -1,
         stepwise: bool = False,
+        gt: Optional[Dict[str, Tensor]] = None,
+        latent_posterior: bool = False,
+        rule_checker_tl: Optional[Dict[str, Tensor]] = None,
     ) -> RolloutBuffer:
-        """`WaymoMotion.rollout` (`waymo_motion.py:205-354`).  `stepwise=True` only initialises the simulator
+        """`WaymoMotion.rollout` (`waymo_motion.py:205-354`).  `gt` (the scene's "gt" dict) replaces the history as
+        `features["agent_valid" / "agent_state" / ...]`, the way validation and training call it (`:457-461`); with it and
+        K = 1 the per-step `DifferentiableReward` is attached to the buffer (`:320-330`).  `stepwise=True` only initialises the simulator
         (`model.init`, `dynamics.init`, goal features: `waymo_motion.py:246-266`); drive it with :meth:`forward`.  `features` is the pre-processed scene merged
         with the encoder outputs (un-repeated: K futures share scene tensors, instance n uses scene n // K);
         `latent` / `goal` / `goal_valid` are per instance [N, ...] as in the reference."""
@@ -157,17 +194,24 @@ class WaymoMotion:
         # traffic_rule_checker.enable_check_* (traffic_bots.yaml:240-244): the flag-gated checks do not feed back into the
         # simulation, they are evaluated on the recorded per-step states once the rollout is enqueued (tb_rule_checks)
         flags = self.hparams.get("traffic_rule_checker", {})
-        want_checks = any(bool(v) for k, v in flags.items() if k.startswith("enable_check_"))
+        # (and goal_reached whenever the batch carries a ground-truth goal, traffic_rule_checker.py:473-479)
+        agent_goal = gt.get("gt_goal") if gt is not None else None
+        want_checks = any(bool(v) for k, v in flags.items() if k.startswith("enable_check_")) or agent_goal is not None
         out = self.engine.rollout(
             features, features, z, mean_scene, goal, goal_valid, k_futures, step_end,
             mask_teacher_forcing=mask_teacher_forcing.to(torch.uint8).contiguous(), tap_step=tap_step, stepwise=stepwise,
-            record_check_states=want_checks,
+            record_check_states=want_checks, gt=gt, latent_posterior=latent_posterior,
         )
+        if (gt is not None and k_futures == 1 and not stepwise and self.hparams["training_metrics"]["w_diffbar_reward"] > 0
+                and gt["agent_valid"].shape[1] > step_end):
+            gv, gs = self._gt_slices(gt, step_start, step_end)
+            out["diffbar_rewards"], out["diffbar_rewards_valid"], _ = self.engine.train_partials(out, gv, gs, features["agent_size"])
         self._step_t = step_start
         self._rollout_meta = (step_start, step_end, z)
-        self._rule_ctx = (features, k_futures, flags) if want_checks else None
+        self._rule_ctx = (features, k_futures, flags, rule_checker_tl, agent_goal) if want_checks else None
         if want_checks and not stepwise:
-            out.update(self.engine.rule_checks(features, out["check_state"], out["check_valid"], k_futures, flags))
+            out.update(self.engine.rule_checks(features, out["check_state"], out["check_valid"], k_futures, flags,
+                                               tl=rule_checker_tl, agent_goal=agent_goal))
         return self._buffer_from(out)
 
     def _buffer_from(self, out: Dict[str, Tensor]) -> RolloutBuffer:
@@ -184,15 +228,42 @@ class WaymoMotion:
         buf.final = {k: out[k] for k in ("final_state", "final_valid", "final_hidden")}
         buf.taps = {k: out[k] for k in ("tap_policy_feature", "tap_agent_feature") if k in out}
         buf.latent_sample = z
+        if "diffbar_rewards" in out:
+            buf.diffbar_rewards, buf.diffbar_rewards_valid = out["diffbar_rewards"], out["diffbar_rewards_valid"].bool()
         return buf
+
+    @staticmethod
+    def _gt_slices(gt: Dict[str, Tensor], step_start: int, step_end: int) -> Tuple[Tensor, Tensor]:
+        """batch["gt/valid"][:, s0:].transpose(1, 2), batch["gt/state"][:, s0:].transpose(1, 2) (`waymo_motion.py:616-617`)."""
+        gv = gt["agent_valid"][:, step_start: step_end + 1].transpose(1, 2).contiguous()
+        gs = gt["agent_state"][:, step_start: step_end + 1].transpose(1, 2).contiguous()
+        return gv, gs
+
+    def reactive_replay(self, batch: Dict[str, Tensor], input_feature_dict: Dict[str, Tensor], mask_teacher_forcing: Tensor,
+                        latent: DiagGaussian, goal: Tensor, goal_valid: Tensor, deterministic_latent: bool = True,
+                        deterministic_action: bool = True, require_vis_dict: bool = False) -> RolloutBuffer:
+        """`WaymoMotion.reactive_replay` (`waymo_motion.py:420-476`): the episode replayed from its ground truth (`batch` is the
+        pre-processed validation scene, `batch["gt"]` its ground truth) with the given personality and goal; K = 1.  The
+        personality is taken as a POSTERIOR for `latent_log_prob` (that is what validation / training pass, `:382-387,605`)."""
+        features = {k: v for k, v in batch.items() if k != "gt"}
+        features["map_feature"] = input_feature_dict["map_feature"]
+        features["map_feature_valid"] = input_feature_dict["map_feature_valid"].to(torch.uint8).contiguous()
+        features["tl_feature"] = input_feature_dict["tl_feature"]
+        return self.rollout(
+            features, latent=latent, goal=goal, goal_valid=goal_valid, mask_teacher_forcing=mask_teacher_forcing,
+            deterministic_latent=deterministic_latent, deterministic_action=deterministic_action,
+            step_start=self.hparams["time_step_sim_start"], step_end=self.hparams["time_step_end"], k_futures=1,
+            gt=batch["gt"], latent_posterior=True, require_vis_dict=require_vis_dict, rule_checker_tl=batch["gt"],
+        )
 
     def finish_rollout(self) -> RolloutBuffer:
         """`RolloutBuffer.finish()` for a stepwise rollout (`buffer.py:72-90`): the buffer over the steps taken so far
         (slots of steps not yet simulated are undefined)."""
         out = self.engine._step_out
         if getattr(self, "_rule_ctx", None) is not None:
-            features, k_futures, flags = self._rule_ctx
-            out.update(self.engine.rule_checks(features, out["check_state"], out["check_valid"], k_futures, flags))
+            features, k_futures, flags, tl, agent_goal = self._rule_ctx
+            out.update(self.engine.rule_checks(features, out["check_state"], out["check_valid"], k_futures, flags, tl=tl,
+                                               agent_goal=agent_goal))
         return self._buffer_from(out)
 
     def forward(self, *unused_feature_args, action_override=None, mask_action_override=None, state_override=None,
@@ -249,17 +320,21 @@ class WaymoMotion:
             goal_sample = goal_sample.to(self.device).reshape(b * k, a)
         goal_log_probs = goal.log_prob(goal_sample)
         goal_valid = goal_valid.repeat_interleave(k, 0)
-        features = dict(batch)
+        features = {k_: v for k_, v in batch.items() if k_ != "gt"}
         features["map_feature"] = input_feature_dict["map_feature"]
         features["map_feature_valid"] = input_feature_dict["map_feature_valid"].to(torch.uint8).contiguous()
         features["tl_feature"] = input_feature_dict["tl_feature"]
         tf = self.hparams["teacher_forcing_joint_future_pred"]
-        mask_tf = teacher_forcing_mask(batch["agent_valid"].bool(), tf.get("step_spawn_agent", 10), tf.get("step_warm_start", 10))
+        # validation: features["agent_valid"] etc. are the 91-step ground truth (waymo_motion.py:538-545 with batch["agent/*"]
+        # left untouched), which only matters for the kill rule; test_step overwrites them with the history (:925-926)
+        gt = batch.get("gt")
+        src_valid = (gt if gt is not None else batch)["agent_valid"].bool()
+        mask_tf = teacher_forcing_mask(src_valid, tf.get("step_spawn_agent", 10), tf.get("step_warm_start", 10))
         buf = self.rollout(
             features, latent=latent, goal=goal_sample, goal_valid=goal_valid, mask_teacher_forcing=mask_tf,
             deterministic_latent=deterministic, deterministic_action=True,
             step_start=self.hparams["time_step_sim_start"], step_end=self.hparams["time_step_end"],
-            k_futures=k, latent_eps=latent_eps, tap_step=tap_step,
+            k_futures=k, latent_eps=latent_eps, tap_step=tap_step, gt=gt,
         )
         buf.flatten_repeat(k)
         goal_log_probs = goal_log_probs.view(b, k, a).transpose(1, 2)
@@ -271,6 +346,7 @@ class WaymoMotion:
         """`WaymoMotion.test_step` (`waymo_motion.py:902-940`) up to and including `waymo_post_processing`; the submission writer
         (`:942-949`) is out of scope.  Returns the buffer, the intermediate products and the post-processed `pred_dict`."""
         scene = self.pre_processing(batch)
+        scene.pop("gt", None)  # batch["agent/*"] = batch["history/agent/*"] (waymo_motion.py:925-926)
         input_feature_dict = self.model.encode_input_features(scene)
         goal_valid = scene["agent_valid"].bool().any(1)
         goal_pred = self.model.goal_manager.pred_goal()
@@ -291,4 +367,72 @@ class WaymoMotion:
             "rollout_buffer": buf, "goal_sample": gs, "goal_log_probs": glp, "input_feature_dict": input_feature_dict,
             "latent_mean": latent_mean, "latent_valid": latent_valid, "dest_logits": self.model._enc["dest_logits"],
             "scores": scores, "pred_dict": pred_dict,
+        }
+
+    def validation_step(self, batch: Dict[str, Tensor], batch_idx: int = 0, latent_eps=None, goal_sample=None, generator=None
+                        ) -> Dict[str, object]:
+        """`WaymoMotion.validation_step` (`waymo_motion.py:574-735`) without the WOMD-metric ops, submission writers and videos:
+        posterior / prior personalities and the destination prediction, `reactive_replay` (posterior mean, ground-truth
+        destination, teacher_forcing_reactive_replay) with its error / traffic-rule / training metric states and post-processed
+        prediction, then `joint_future_pred` (prior samples, predicted destinations) with its error / traffic-rule states.
+        The metric holders accumulate over calls; `validation_epoch_end`-style reporting = `.sync()` + `.compute()` on them."""
+        scene = self.pre_processing(batch)
+        if "gt" not in scene:
+            raise ValueError("validation_step needs a validation batch (agent/*, tl_stop/* ground truth)")
+        gt = scene["gt"]
+        hp = self.hparams
+        s0, s1 = hp["time_step_sim_start"], hp["time_step_end"]
+        if gt["agent_valid"].shape[1] <= s1:
+            raise ValueError("ground truth shorter than time_step_end")
+        input_feature_dict = self.model.encode_input_features(scene)
+        goal_gt, goal_valid = self.model.goal_manager.get_gt_goal(scene["agent_valid"], gt.get("gt_goal"), gt["gt_dest"])
+        goal_pred = self.model.goal_manager.pred_goal()
+        latent_post = self.model.latent_encoder(posterior=True, gt=gt)
+        latent_prior = self.model.latent_encoder()
+        prior_mean, prior_valid = latent_prior.mean, latent_prior.valid
+        # ---- reactive replay
+        tf = hp["teacher_forcing_reactive_replay"]
+        mask_tf = teacher_forcing_mask(gt["agent_valid"].bool(), tf.get("step_spawn_agent", 10), tf.get("step_warm_start", 10))
+        buf = self.reactive_replay(scene, input_feature_dict, mask_tf, latent_post, goal_gt, goal_valid,
+                                   deterministic_latent=True, deterministic_action=True)
+        gv, gs = self._gt_slices(gt, s0, s1)
+        raw = {"valid": buf.valid, "preds": buf.preds, "override_masks": buf.override_masks}
+        _, _, train_states = self.engine.train_partials(
+            raw, gv, gs, scene["agent_size"], dest_logits=self.model._enc["dest_logits"], goal_valid=goal_pred.valid, gt_dest=goal_gt,
+            post={"latent_mean": latent_post.mean, "latent_valid": latent_post.valid},
+            prior={"latent_mean": prior_mean, "latent_valid": prior_valid})
+        buf.flatten_repeat(1)
+        states = self.engine.metric_partials(buf.valid, buf.preds, buf.override_masks, buf.violations, scene["agent_type"],
+                                             gt["agent_role"], gt_valid=gv, gt_states=gs, loss_for_teacher_forcing=False)
+        self.err_metrics_reactive_replay.update(states[:4])
+        self.rule_metrics_reactive_replay.update(states[4:])
+        self.train_metrics_reactive_replay.update(train_states)
+        # TrainingMetrics.update masks the first step_training_start steps of the buffer's `valid` IN PLACE when it takes no
+        # copy first (training.py:87-93: p_loss_for_irrelevant <= 0 and loss_for_teacher_forcing), so the reference's
+        # post-processing below sees that mask; mirrored for the same agents-with-a-prediction set
+        tm = hp["training_metrics"]
+        post_valid = buf.valid
+        if tm["p_loss_for_irrelevant"] <= 0 and tm["loss_for_teacher_forcing"] and tm["step_training_start"] > 0:
+            post_valid = buf.valid.clone()
+            post_valid[..., : tm["step_training_start"]] = False
+        pred_dict_rr = self.waymo_post_processing(
+            valid=post_valid[:, :, 0].any(-1), scores=torch.ones_like(buf.preds[:, :, :, 0, 0]),
+            trajs=buf.preds[:, :, :, buf.step_future_start:], agent_type=scene["agent_type"])
+        # ---- joint future prediction
+        buf_j, gsamp, glp = self.joint_future_pred(scene, input_feature_dict, latent_prior, goal_pred, goal_valid,
+                                                   latent_eps=latent_eps, goal_sample=goal_sample, generator=generator)
+        states_j = self.engine.metric_partials(buf_j.valid, buf_j.preds, buf_j.override_masks, buf_j.violations, scene["agent_type"],
+                                               gt["agent_role"], gt_valid=gv, gt_states=gs, loss_for_teacher_forcing=False)
+        self.err_metrics_joint_future_pred.update(states_j[:4])
+        self.rule_metrics_joint_future_pred.update(states_j[4:])
+        scores = torch.exp(buf_j.latent_log_probs[..., 0] + glp)
+        pred_dict_j = self.waymo_post_processing(
+            valid=buf_j.valid[:, :, 0].any(-1), scores=scores, trajs=buf_j.preds[:, :, :, buf_j.step_future_start:],
+            agent_type=scene["agent_type"])
+        return {
+            "reactive_replay": {"rollout_buffer": buf, "train_states": train_states, "metric_states": states, "pred_dict": pred_dict_rr},
+            "joint_future_pred": {"rollout_buffer": buf_j, "goal_sample": gsamp, "goal_log_probs": glp, "metric_states": states_j,
+                                  "scores": scores, "pred_dict": pred_dict_j},
+            "latent_post": latent_post, "latent_prior_mean": prior_mean, "latent_prior_valid": prior_valid,
+            "dest_logits": self.model._enc["dest_logits"], "input_feature_dict": input_feature_dict,
         }
