@@ -185,6 +185,12 @@ def main():
     dest = enc["dest_logits"].argmax(-1).to(torch.int32)
     gv = scene["agent_valid"].bool().any(1).to(torch.uint8)
 
+    # a generation-2 collection of the interpreter (tens of ms with the weight / scene dicts alive) in the launching thread
+    # starves the stream right after a synchronize, when nothing is queued ahead: collect now, keep the collector off while timing
+    import gc
+
+    gc.collect()
+    gc.disable()
     out = None
     for _ in range(args.warmup):
         out = eng.rollout(scene, feats, z, enc["latent_mean"], dest, gv, 1, STEP_END, out=out)
@@ -192,16 +198,24 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    pass_ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]  # one marker per pass, same stream
     t0 = time.perf_counter()
+    pass_ev[0].record()
     for i in range(args.steps):
         if i == args.steps - 1:
             eng.set_timing(True)  # hipEventRecord markers around the per-step kernels of the LAST timed pass (no host sync)
         out = eng.rollout(scene, feats, z, enc["latent_mean"], dest, gv, 1, STEP_END, out=out)
+        pass_ev[i + 1].record()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    gc.enable()
+    pass_ms = [pass_ev[i].elapsed_time(pass_ev[i + 1]) for i in range(args.steps)]
+    if os.environ.get("TB_BENCH_VERBOSE"):
+        print("pass_ms:", " ".join(f"{x:.2f}" for x in pass_ms), file=sys.stderr)
+    pass_ms = sorted(pass_ms)
     tm = eng.get_timing()  # HIP-event durations of the LAST pass of the timed region
     k_us = tm["fused_ms"] / max(1, tm["n_fused"]) * 1e3  # average duration of one fused k_step launch (C(t)+A(t+1))
 
@@ -270,6 +284,7 @@ def main():
                        "parallelism": f"scene-parallel x{world}"},
             "agent_steps_per_s": value * N_AGENT,
             "encode_ms": encode_ms,
+            "pass_ms": {"min": pass_ms[0], "median": pass_ms[len(pass_ms) // 2], "max": pass_ms[-1]},
             "kernel_us": {"k_step_fused": k_us, "edge_launches_ms": tm["edge_ms"], "prologue_ms": tm["prologue_ms"]},
             "roofline": {"bound": "mfma", "kernel": "tb::k_step_x (C(t)+A(t+1), one launch per simulation step)", "achieved": achieved,
                          "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
