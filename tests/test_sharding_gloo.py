@@ -75,3 +75,73 @@ def test_two_rank_gloo_matches_single_process():
     for i, k in enumerate(PARTIAL_FIELDS):
         assert abs(red[k] - float(whole[i])) <= 1e-6 * max(1.0, abs(float(whole[i]))), k
     assert t == 2.0  # MAX over ranks of the elapsed time
+
+
+def _val_states_for(lo, hi):
+    """TrainingMetrics sum-states of scenes [lo, hi) of a seeded validation batch (oracles standing in for the GPU engine)."""
+    import sys
+
+    sys.path.insert(0, ROOT)
+    from oracle import training_oracle as TO
+    from oracle.trafficbots_oracle import Oracle
+    from trafficbots_amd import synth
+    from trafficbots_amd.config import load_model_config
+    from trafficbots_amd.runtime import TRAIN_FIELDS
+
+    step_end = 20
+    cfg = load_model_config(overrides={"time_step_end": step_end, "n_joint_future": 1})
+    sd = synth.make_state_dict(4)
+    batch = synth.make_val_batch(900, hi - lo, scene_offset=lo, n_agent=6, n_pl=12, n_tl=4, p_future_exit=0.3)
+    with torch.no_grad():
+        r = Oracle(sd, cfg, torch.float32).reactive_replay(batch, step_end)
+    gv = r["gt_valid"][:, 1: step_end + 1].transpose(1, 2)
+    gs = r["gt_state"][:, 1: step_end + 1].transpose(1, 2)
+    rew, rv = TO.differentiable_reward(r["valid"], r["preds"], gv, gs, r["agent_size"], cfg["differentiable_reward"])
+    st = TO.training_metric_states(r["valid"], rv, rew, r["override_masks"], r["agent_role"], r["dest_logits_raw"], r["goal_valid"],
+                                   r["gt_dest"], r["post_mean"], r["post_log_std"], r["post_valid"], r["prior_mean"],
+                                   r["prior_log_std"], r["prior_valid"], cfg["training_metrics"])
+    return torch.tensor([st[k] for k in TRAIN_FIELDS], dtype=torch.float64), cfg
+
+
+def _val_worker(rank, world, port, n_global, q):
+    import torch.distributed as dist
+
+    torch.set_num_threads(1)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from trafficbots_amd.metrics import TrainingMetrics
+    from trafficbots_amd.shard import shard_range
+
+    lo, hi = shard_range(n_global, rank, world)
+    st, cfg = _val_states_for(lo, hi)
+    m = TrainingMetrics("reactive_replay", **cfg["training_metrics"])
+    m.update(st)
+    m.sync()  # the validation path's collective: one SUM all-reduce of the packed states
+    if rank == 0:
+        q.put(m.compute())
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_validation_losses_match_single_process():
+    from trafficbots_amd.metrics import TrainingMetrics
+
+    n_global, world = 3, 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_val_worker, args=(r, world, port, n_global, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    st, cfg = _val_states_for(0, n_global)
+    m = TrainingMetrics("reactive_replay", **cfg["training_metrics"])
+    m.update(st)
+    want = m.compute()
+    assert set(got) == set(want) == {"reactive_replay/loss", "reactive_replay/vae_kl", "reactive_replay/diffbar_reward",
+                                     "reactive_replay/goal_loss"}
+    for k in want:
+        assert abs(got[k] - want[k]) <= 1e-5 * max(1.0, abs(want[k])), k
