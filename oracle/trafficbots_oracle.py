@@ -552,7 +552,7 @@ class Oracle:
 
     # ------------------------------------------------------------------ end to end
     def joint_future_pred(self, batch: Dict[str, np.ndarray], k: int, eps: Optional[np.ndarray], step_end: int,
-                          dest_override: Optional[np.ndarray] = None, tap_steps=()) -> Dict[str, Tensor]:
+                          dest_override: Optional[np.ndarray] = None, tap_steps=(), use_gt: bool = False) -> Dict[str, Tensor]:
         """Prologue of `WaymoMotion.test_step` + `joint_future_pred` (`waymo_motion.py:902-933,478-572`).
         `eps` [N,A,16] are the standard-normal draws of the latent sample; `dest_override` [N,A]
         replaces the destination sample (instances k>0 are multinomial draws in the reference)."""
@@ -576,10 +576,13 @@ class Oracle:
             dest = _t(dest_override, self.dtype).to(torch.int64).reshape(n, a)
         goal_logp = logp_table.gather(-1, dest.unsqueeze(-1)).squeeze(-1)
         goal_valid = inp["agent_valid"].any(1).repeat_interleave(k, 0)
-        res = self.rollout(inp, f, z, mean, dest, goal_valid, k, step_end, tap_steps)
+        # validation_step leaves batch["agent/*"] = the 91-step ground truth in place (waymo_motion.py:538-545), which the kill
+        # rule and goal_reached then see; test_step overwrites it with the history (:925-926)
+        gt = self.preprocess_gt(batch) if use_gt else None
+        res = self.rollout(inp, f, z, mean, dest, goal_valid, k, step_end, tap_steps, gt=gt)
         # RolloutBuffer.flatten_repeat (`buffer.py:92-123`): [N,A,S,..] -> [B,A,K,S,..]
         for key in ("preds", "valid", "override_masks", "outside_map", "outside_map_this_step", "dest_reached",
-                    "dest_reached_this_step", "action_log_probs", "latent_log_probs"):
+                    "dest_reached_this_step", "action_log_probs", "latent_log_probs", "goal_reached", "goal_reached_this_step"):
             v = res[key]
             res[key] = v.reshape(b, k, *v.shape[1:]).transpose(1, 2)
         res["goal_sample"] = dest.view(b, k, a).transpose(1, 2)

@@ -548,6 +548,16 @@ def test_validation_step_against_oracle_fresh_seed():
         got = buf.violations[k][:, :, 0].cpu().numpy()
         assert (got == want.numpy()).mean() >= 0.999, k  # (states differ by <= 2.5e-4 m: a threshold can flip on a rare tie)
     assert ref["collided"].any() and ref["run_road_edge"].any()
+    # second half of validation_step: joint_future_pred against the ground truth (kill rule, goal_reached), K = 1 deterministic
+    bj = out["joint_future_pred"]["rollout_buffer"]
+    dest = out["joint_future_pred"]["goal_sample"].transpose(1, 2).reshape(2, -1).cpu().numpy()
+    rj = Oracle(sd, cfg, dtype=torch.float32).joint_future_pred(batch, 1, None, 90, dest_override=dest, use_gt=True)
+    for k in ("valid", "override_masks"):
+        assert (getattr(bj, k).cpu().numpy() == rj[k].numpy()).all(), k
+    for k in ("outside_map", "dest_reached", "goal_reached"):
+        assert (bj.violations[k].cpu().numpy() == rj[k].numpy()).all(), k
+    dj = (np.abs(bj.preds.cpu().numpy() - rj["preds"].numpy()) * rj["valid"].numpy()[..., None])[..., :2].max()
+    assert dj <= 2.5e-4, dj
 
 
 def test_empty_and_bad_inputs_fail_loudly():
