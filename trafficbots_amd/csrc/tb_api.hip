@@ -296,6 +296,18 @@ int tb_create(const tb_config* cfg, tb_ctx** out) {
         return 1;
     }
     if (cfg->operand_precision == 1) c->step_kernel = 3;
+    if (const char* w = getenv("TB_ENCODE_KERNEL")) {  // development switch between the scene-encoder attention kernels
+        const std::string k = w;
+        if (k == "fp32")
+            c->encode_kernel = 0;
+        else if (k == "xdl")
+            c->encode_kernel = 1;
+        else {
+            fprintf(stderr, "trafficbots_hip: TB_ENCODE_KERNEL must be fp32 or xdl\n");
+            delete c;
+            return 1;
+        }
+    }
     if (const char* w = cfg->operand_precision == 1 ? nullptr : getenv("TB_STEP_KERNEL")) {  // development switch between the fp32-accurate step kernels
         const std::string k = w;
         if (k == "fp32")
@@ -434,6 +446,16 @@ int tb_finalize_weights(tb_ctx* ctx, tb_stream stream) {
         ew.as2tl[i] = pw.as2tl[i];
     }
     ew.map_self = add_xlayer(a, s, "model.map_encoder.transformer_self_attn.layers.0");
+    g_pack_bf16 = false;  // the encoders keep fp32-accurate fp16 pairs in either operand_precision
+    for (int i = 0; i < 3; ++i) {
+        const std::string si = std::to_string(i);
+        ew.densetnt_x[i] = add_xlayer_x(a, s, "model.map_encoder.transformer_densetnt.layers." + si);
+        ew.as2pl_x[i] = add_xlayer_x(a, s, "model.transformer_as2pl.layers." + si);
+        ew.as2tl_x[i] = add_xlayer_x(a, s, "model.transformer_as2tl.layers." + si);
+        ew.inter_prior_x[i] = add_xlayer_x(a, s, "model.latent_encoder.agent_interaction_prior.transformer.layers." + si);
+        ew.inter_post_x[i] = add_xlayer_x(a, s, "model.latent_encoder.agent_interaction_post.transformer.layers." + si);
+    }
+    ew.map_self_x = add_xlayer_x(a, s, "model.map_encoder.transformer_self_attn.layers.0");
     ew.lat_w1 = add_packed(a, s, "model.latent_encoder.latent_prior_dist.mlp_mean.fc_layers.0.weight", 128, 128, 128);
     ew.lat_b1 = add_plain(a, s, "model.latent_encoder.latent_prior_dist.mlp_mean.fc_layers.0.bias", 128);
     ew.lat_w2 = add_plain(a, s, "model.latent_encoder.latent_prior_dist.mlp_mean.fc_layers.2.weight", 16 * 128);

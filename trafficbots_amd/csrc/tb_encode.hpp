@@ -2,6 +2,7 @@
 // CVAE personality prior, destination predictor).
 #pragma once
 #include "tb_device.hpp"
+#include "tb_rollout.hpp"
 
 namespace tb {
 
@@ -17,8 +18,32 @@ struct EncoderW {
     uint32_t lat_w1, lat_b1, lat_w2, lat_b2;      // latent_prior_dist.mlp_mean
     uint32_t post_w1, post_b1, post_w2, post_b2;  // latent_post_dist.mlp_mean
     uint32_t post_log_std;                        // latent_post_dist.log_std [16]
+    // fp16-pair (XDL) packing of the attention blocks, for the encoders' default kernels (tb_encodex_kernels.hip)
+    XLayerX densetnt_x[3], map_self_x, as2pl_x[3], as2tl_x[3], inter_prior_x[3], inter_post_x[3];
     uint32_t dest_w0_map, dest_w0_agent, dest_b0, dest_ln0_g, dest_ln0_b;
     uint32_t dest_w1, dest_b1, dest_ln1_g, dest_ln1_b, dest_w2, dest_b2;
 };
+
+// one cross-attention block over 16-row tiles, XDL kernels (K / VT in fragment-major fp16 pairs, same byte size as fp32)
+struct XBlockPX {
+    const float* W;
+    XLayerW L[3];
+    XLayerX LX[3];
+    int n_layer;
+    const float* src;          // [G][n_rows][128]
+    const uint8_t* src_valid;  // [G][n_rows]
+    float* dst;                // [G][n_rows][128]
+    const float* K;            // [G][n_layer] fragment-major K planes
+    const float* VT;           // [G][n_layer] fragment-major V planes
+    const float* kbias;        // [G][n_pad] additive key mask
+    int n_rows, n_pad;
+    int eye;                   // MultiAgentTF: self key masked; groups with exactly one valid row pass through
+};
+
+namespace xh {
+void launch_kv_hoist_nx(const float* W, const XLayerW* L, const XLayerX* X, int n_layer, const float* feat, const uint8_t* fvalid, int G,
+                        int n_tok, int n_pad, float* K, float* VT, float* kbias, hipStream_t s);
+void launch_xblock_x(const XBlockPX& p, int G, hipStream_t s);
+}  // namespace xh
 
 }  // namespace tb

@@ -468,6 +468,27 @@ static void launch_xblock(const XBlockP& p, int G, hipStream_t s) {
     hipLaunchKernelGGL(k_xattn_block, grid, dim3(NTHREADS), (3 * TM * LDT + 16) * sizeof(float), s, p);
 }
 
+// One attention block (K/V hoist of the targets + the source tiles through the layers) with either kernel family.
+static void run_block(bool xdl, const float* W, const XLayerW* L, const XLayerX* LX, int n_layer, const float* tgt, const uint8_t* tgt_valid,
+                      int G, int n_tgt, int n_pad, float* K, float* VT, float* kbias, const float* src, const uint8_t* src_valid, float* dst,
+                      int n_rows, int eye, hipStream_t s) {
+    if (xdl) {
+        xh::launch_kv_hoist_nx(W, L, LX, n_layer, tgt, tgt_valid, G, n_tgt, n_pad, K, VT, kbias, s);
+        XBlockPX x{};
+        x.W = W; x.n_layer = n_layer;
+        for (int l = 0; l < n_layer; ++l) { x.L[l] = L[l]; x.LX[l] = LX[l]; }
+        x.src = src; x.src_valid = src_valid; x.dst = dst; x.K = K; x.VT = VT; x.kbias = kbias; x.n_rows = n_rows; x.n_pad = n_pad; x.eye = eye;
+        xh::launch_xblock_x(x, G, s);
+        return;
+    }
+    launch_kv_hoist_n(W, L, n_layer, tgt, tgt_valid, G, n_tgt, n_pad, K, VT, kbias, s);
+    XBlockP x{};
+    x.W = W; x.n_layer = n_layer;
+    for (int l = 0; l < n_layer; ++l) x.L[l] = L[l];
+    x.src = src; x.src_valid = src_valid; x.dst = dst; x.K = K; x.VT = VT; x.kbias = kbias; x.n_rows = n_rows; x.n_pad = n_pad; x.eye = eye;
+    launch_xblock(x, G, s);
+}
+
 // Scratch of one latent-encoder pass (LatentEncoder.forward, latent_encoder.py:98-147) over S3 down-sampled steps.
 struct LatentWs {
     float *kpl, *vtpl, *kvpl, *x0, *x1, *x2, *x3, *tl3, *ktl, *vttl, *kvtl, *kin, *vtin, *kvin;
@@ -495,7 +516,7 @@ static void carve_latent(Carver& c, LatentWs& w, size_t B, size_t S3, size_t A, 
 
 // Prior (which = 0) or posterior (which = 1) personality over the steps {0, 5, 10, ...} of NS encoded steps: agent -> map,
 // agent -> traffic lights (shared as2pl / as2tl weights), interaction, GRU over time, max over valid steps, DistEncoder mean.
-static void launch_latent_branch(const float* W, const EncoderW& ew, int which, int B, int NS, int A, int P, int T,
+static void launch_latent_branch(bool xdl, const float* W, const EncoderW& ew, int which, int B, int NS, int A, int P, int T,
                                  const float* agent_feature, const uint8_t* agent_valid, const float* tl_feature,
                                  const uint8_t* tl_valid, const float* map_feature, const uint8_t* map_fvalid, const LatentWs& w,
                                  float* out_mean, uint8_t* out_valid, hipStream_t s) {
@@ -513,22 +534,12 @@ static void launch_latent_branch(const float* W, const EncoderW& ew, int which, 
     total = (size_t)B * S3 * T;
     hipLaunchKernelGGL(k_gather_steps_u8, dim3((total + 255) / 256), dim3(256), 0, s, tl_valid, w.tlv3, B, NS, S3, 5, T);
     // agent -> map over the S3*A tokens of each scene (shared as2pl weights)
-    launch_kv_hoist_n(W, ew.as2pl, 3, map_feature, map_fvalid, B, P, p_pad, w.kpl, w.vtpl, w.kvpl, s);
-    XBlockP x{};
-    x.W = W; x.n_layer = 3;
-    for (int l = 0; l < 3; ++l) x.L[l] = ew.as2pl[l];
-    x.src = w.x0; x.src_valid = w.v0; x.dst = w.x1; x.K = w.kpl; x.VT = w.vtpl; x.kbias = w.kvpl; x.n_rows = S3 * A; x.n_pad = p_pad; x.eye = 0;
-    launch_xblock(x, B, s);
+    run_block(xdl, W, ew.as2pl, ew.as2pl_x, 3, map_feature, map_fvalid, B, P, p_pad, w.kpl, w.vtpl, w.kvpl, w.x0, w.v0, w.x1, S3 * A, 0, s);
     // agent -> traffic lights, per step
-    launch_kv_hoist_n(W, ew.as2tl, 3, w.tl3, w.tlv3, B * S3, T, t_pad, w.ktl, w.vttl, w.kvtl, s);
-    for (int l = 0; l < 3; ++l) x.L[l] = ew.as2tl[l];
-    x.src = w.x1; x.dst = w.x2; x.K = w.ktl; x.VT = w.vttl; x.kbias = w.kvtl; x.n_rows = A; x.n_pad = t_pad;
-    launch_xblock(x, B * S3, s);
+    run_block(xdl, W, ew.as2tl, ew.as2tl_x, 3, w.tl3, w.tlv3, B * S3, T, t_pad, w.ktl, w.vttl, w.kvtl, w.x1, w.v0, w.x2, A, 0, s);
     // interaction (own weights), tgt = block input
-    launch_kv_hoist_n(W, inter, 3, w.x2, w.v0, B * S3, A, a_pad, w.kin, w.vtin, w.kvin, s);
-    for (int l = 0; l < 3; ++l) x.L[l] = inter[l];
-    x.src = w.x2; x.dst = w.x3; x.K = w.kin; x.VT = w.vtin; x.kbias = w.kvin; x.n_rows = A; x.n_pad = a_pad; x.eye = 1;
-    launch_xblock(x, B * S3, s);
+    run_block(xdl, W, inter, which ? ew.inter_post_x : ew.inter_prior_x, 3, w.x2, w.v0, B * S3, A, a_pad, w.kin, w.vtin, w.kvin, w.x2, w.v0,
+              w.x3, A, 1, s);
     ScanP sp{};
     sp.W = W;
     for (int l = 0; l < 3; ++l) sp.gru[l] = gru[l];
@@ -609,26 +620,17 @@ int run_encode(struct ::tb_ctx* ctx, const tb_encode_io* io, hipStream_t s) {
         const int G = nb * P;
         const float* src = nodef + (size_t)b0 * P * 20 * 128;
         const uint8_t* sv = io->map_valid + (size_t)b0 * P * 20;
-        launch_kv_hoist_n(W, ew.densetnt, 3, src, sv, G, 20, 32, kn, vtn, kvn, s);
-        XBlockP x{};
-        x.W = W; x.n_layer = 3;
-        for (int l = 0; l < 3; ++l) x.L[l] = ew.densetnt[l];
-        x.src = src; x.src_valid = sv; x.dst = nodeo; x.K = kn; x.VT = vtn; x.kbias = kvn; x.n_rows = 20; x.n_pad = 32; x.eye = 0;
-        launch_xblock(x, G, s);
+        run_block(ctx->encode_kernel == 1, W, ew.densetnt, ew.densetnt_x, 3, src, sv, G, 20, 32, kn, vtn, kvn, src, sv, nodeo, 20, 0, s);
         const int nthr = G * 32;
         hipLaunchKernelGGL(k_pool_nodes, dim3((nthr + 255) / 256), dim3(256), 0, s, nodeo, sv, G, plf + (size_t)b0 * P * 128,
                            io->map_feature_valid + (size_t)b0 * P);
     }
     {
-        launch_kv_hoist_n(W, &ew.map_self, 1, plf, io->map_feature_valid, B, P, p_pad, kps, vtps, kvps, s);
-        XBlockP x{};
-        x.W = W; x.n_layer = 1; x.L[0] = ew.map_self;
-        x.src = plf; x.src_valid = io->map_feature_valid; x.dst = io->map_feature; x.K = kps; x.VT = vtps; x.kbias = kvps;
-        x.n_rows = P; x.n_pad = p_pad; x.eye = 0;
-        launch_xblock(x, B, s);
+        run_block(ctx->encode_kernel == 1, W, &ew.map_self, &ew.map_self_x, 1, plf, io->map_feature_valid, B, P, p_pad, kps, vtps, kvps, plf,
+                  io->map_feature_valid, io->map_feature, P, 0, s);
     }
     // ---- personality prior
-    launch_latent_branch(W, ew, 0, B, NH, A, P, T, io->agent_feature, io->agent_valid, io->tl_feature, io->tl_valid, io->map_feature,
+    launch_latent_branch(ctx->encode_kernel == 1, W, ew, 0, B, NH, A, P, T, io->agent_feature, io->agent_valid, io->tl_feature, io->tl_valid, io->map_feature,
                          io->map_feature_valid, lws, io->latent_mean, io->latent_valid, s);
     // ---- destination predictor
     {
@@ -694,7 +696,7 @@ int run_encode_posterior(struct ::tb_ctx* ctx, const tb_posterior_io* io, hipStr
     l.kind = 1; l.mlp = ew.tl_enc; l.n_tok = B * NS * T; l.per_scene = NS * T; l.inner = T;
     l.valid = io->tl_valid; l.pos = io->tl_pos; l.dir = io->tl_dir; l.cls = io->tl_state; l.out = tf;
     hipLaunchKernelGGL(k_encode_tokens, dim3((l.n_tok + TM - 1) / TM), dim3(NTHREADS), 0, s, l);
-    launch_latent_branch(W, ew, 1, B, NS, A, P, T, af, io->agent_valid, tf, io->tl_valid, io->map_feature, io->map_feature_valid, lws,
+    launch_latent_branch(ctx->encode_kernel == 1, W, ew, 1, B, NS, A, P, T, af, io->agent_valid, tf, io->tl_valid, io->map_feature, io->map_feature_valid, lws,
                          io->latent_mean, io->latent_valid, s);
     TB_HIP(ctx, hipGetLastError());
     return 0;

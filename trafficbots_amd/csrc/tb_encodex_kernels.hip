@@ -1,0 +1,91 @@
+// Scene-encoder attention blocks on the XDL pipe: the fp16-pair twins of k_xattn_block / k_kv_hoist_n (tb_encode_kernels.hip),
+// built from the device code of the step kernel (tb_device_xdl.hpp: fp32-accurate GEMMs as three fp16 MFMAs per product, K / V
+// in fragment-major fp16 pairs, log2-domain softmax).  Used by the map encoder (densetnt per polyline, polyline self-attention)
+// and by the personality prior / posterior (agent -> map, agent -> traffic lights, interaction).
+//   k_kv_hoist_nx    grid (n_pad/16, G): LN_tgt + K/V projection of a 16-token tile for 1..3 layers
+//   k_xattn_block_x  grid (ceil(n_rows/16), G): a 16-row tile of the source through the 1..3 layers of one block
+#include <hip/hip_runtime.h>
+
+#include "tb_rollout.hpp"
+#include "tb_device_xdl.hpp"
+#include "tb_encode.hpp"
+
+namespace tb {
+namespace TB_XNS {
+
+__global__ __launch_bounds__(NTHREADS) void k_kv_hoist_nx(const float* __restrict__ W, XLayerW l0, XLayerW l1, XLayerW l2, XLayerX x0,
+                                                         XLayerX x1, XLayerX x2, int n_layer, const float* __restrict__ feat,
+                                                         const uint8_t* __restrict__ fvalid, int n_tok, int n_pad,
+                                                         float* __restrict__ Kout, float* __restrict__ VTout, float* __restrict__ kbias) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* T = smem;
+    xhalf* P1 = reinterpret_cast<xhalf*>(smem + TM * LDT);
+    const int tid = threadIdx.x, wave = wave_of(tid), lane = tid & 63, g = blockIdx.y, tok0 = blockIdx.x * TM;
+    const int n_real = max(0, min(TM, n_tok - tok0));
+    WUnitX u;
+    wloadx(u, kvproj_first_x(W, l0, x0, wave), lane);
+    load_tile(T, LDT, feat + ((size_t)g * n_tok + tok0) * H, n_real, tid);
+    if (tid < TM)
+        kbias[(size_t)g * n_pad + tok0 + tid] = (tid < n_real && fvalid[(size_t)g * n_tok + tok0 + tid]) ? 0.f : -INFINITY;
+    __syncthreads();
+    const size_t ls = (size_t)n_pad * H;  // floats per (group, layer) = fp16 per plane
+    xhalf* K0 = reinterpret_cast<xhalf*>(Kout + ((size_t)g * n_layer) * ls);
+    xhalf* V0 = reinterpret_cast<xhalf*>(VTout + ((size_t)g * n_layer) * ls);
+    kv_project_tile_x(W, l0, x0, T, P1, K0, V0, n_pad, tok0, n_real, tid, u, kvproj_first_x(W, l1, x1, wave));
+    if (n_layer > 1) kv_project_tile_x(W, l1, x1, T, P1, K0 + 2 * ls, V0 + 2 * ls, n_pad, tok0, n_real, tid, u, kvproj_first_x(W, l2, x2, wave));
+    if (n_layer > 2) kv_project_tile_x(W, l2, x2, T, P1, K0 + 4 * ls, V0 + 4 * ls, n_pad, tok0, n_real, tid, u, kvproj_first_x(W, l2, x2, wave));
+}
+
+void launch_kv_hoist_nx(const float* W, const XLayerW* L, const XLayerX* X, int n_layer, const float* feat, const uint8_t* fvalid, int G,
+                        int n_tok, int n_pad, float* K, float* VT, float* kbias, hipStream_t s) {
+    dim3 grid(n_pad / TM, G);
+    const int i1 = n_layer > 1 ? 1 : 0, i2 = n_layer > 2 ? 2 : 0;
+    hipLaunchKernelGGL(k_kv_hoist_nx, grid, dim3(NTHREADS), TM * LDT * sizeof(float) + PLANES_BYTES, s, W, L[0], L[i1], L[i2], X[0], X[i1],
+                       X[i2], n_layer, feat, fvalid, n_tok, n_pad, K, VT, kbias);
+}
+
+template <bool EYE>
+__global__ __launch_bounds__(NTHREADS) void k_xattn_block_x(XBlockPX p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* X = smem;
+    xhalf* PA = reinterpret_cast<xhalf*>(X + TM * LDT);
+    xhalf* PB = PA + NPL * PLANE;
+    uint8_t* rowvalid = reinterpret_cast<uint8_t*>(PB + NPL * PLANE);
+    uint8_t* novalid_s = rowvalid + 16;
+    const int tid = threadIdx.x, wave = wave_of(tid), lane = tid & 63, g = blockIdx.y, row0 = blockIdx.x * TM;
+    const int n_real = min(TM, p.n_rows - row0);
+    WUnitX u;
+    wloadx(u, xlayer_first_x(p.W, p.L[0], p.LX[0], wave), lane);
+    load_tile(X, LDT, p.src + ((size_t)g * p.n_rows + row0) * H, n_real, tid);
+    if (tid < TM) rowvalid[tid] = tid < n_real ? p.src_valid[(size_t)g * p.n_rows + row0 + tid] : 0;
+    bool bypass = false;
+    if (EYE) {  // MultiAgentTF: a scene with exactly one valid agent passes through (agent_interaction.py)
+        const int cnt = __syncthreads_count(tid < p.n_rows && p.src_valid[(size_t)g * p.n_rows + tid]);
+        bypass = cnt == 1;
+    } else {
+        __syncthreads();
+    }
+    if (!bypass) {
+        const size_t ls = (size_t)p.n_pad * H;
+        const xhalf* K0 = reinterpret_cast<const xhalf*>(p.K + ((size_t)g * p.n_layer) * ls);
+        const xhalf* V0 = reinterpret_cast<const xhalf*>(p.VT + ((size_t)g * p.n_layer) * ls);
+        const float* kb = p.kbias + (size_t)g * p.n_pad;
+#pragma unroll 1
+        for (int l = 0; l < p.n_layer; ++l) {
+            const int ln = l + 1 < p.n_layer ? l + 1 : l;
+            xattn_layer_x<false, EYE>(p.W, p.L[l], p.LX[l], X, PA, PB, K0 + 2 * l * ls, V0 + 2 * l * ls, kb, p.n_pad, 0, EYE ? row0 : -1,
+                                      rowvalid, novalid_s, tid, u, xlayer_first_x(p.W, p.L[ln], p.LX[ln], wave));
+        }
+    }
+    store_tile(p.dst + ((size_t)g * p.n_rows + row0) * H, X, LDT, n_real, tid);
+}
+
+void launch_xblock_x(const XBlockPX& p, int G, hipStream_t s) {
+    dim3 grid((p.n_rows + TM - 1) / TM, G);
+    const size_t lds = TM * LDT * sizeof(float) + 2 * PLANES_BYTES + 32;
+    if (p.eye) hipLaunchKernelGGL(k_xattn_block_x<true>, grid, dim3(NTHREADS), lds, s, p);
+    else hipLaunchKernelGGL(k_xattn_block_x<false>, grid, dim3(NTHREADS), lds, s, p);
+}
+
+}  // namespace TB_XNS
+}  // namespace tb
