@@ -152,13 +152,21 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    # TB_BENCH_BACKEND=gloo is a dry-run hook: several ranks sharing the visible GPU(s) exercise the N > 1 control flow (shards,
+    # barriers, max-over-ranks time, the all-reduce through host memory) where RCCL would refuse two ranks on one device
+    backend = os.environ.get("TB_BENCH_BACKEND", "nccl")
+    if backend == "gloo":
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if backend == "gloo":
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=dev)
 
     from trafficbots_amd.runtime import HipEngine, scene_from_batch
 

@@ -43,6 +43,13 @@ def all_reduce_partials(partial: Tensor, elapsed_s: float, fields=PARTIAL_FIELDS
 
     t = torch.tensor([elapsed_s], device=partial.device, dtype=torch.float64)
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        dist.all_reduce(partial, op=dist.ReduceOp.SUM)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        if dist.get_backend() == "gloo" and partial.is_cuda:  # dry runs of the N > 1 flow without RCCL: reduce through host memory
+            hp, ht = partial.cpu(), t.cpu()
+            dist.all_reduce(hp, op=dist.ReduceOp.SUM)
+            dist.all_reduce(ht, op=dist.ReduceOp.MAX)
+            partial.copy_(hp)
+            t.copy_(ht)
+        else:
+            dist.all_reduce(partial, op=dist.ReduceOp.SUM)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return {k: float(partial[i]) for i, k in enumerate(fields)}, float(t.item())
