@@ -303,7 +303,11 @@ def main():
                                  "the fp32-MFMA peak of the fp32 formulation; the kernel issues them as 3 fp16 MFMAs per product on the XDL "
                                  "pipe (fp32-accurate, DESIGN.md 4) and is bound by the per-CU vector-load path, see load_path; 128 "
                                  "workgroups (one per 16 agents) occupy 128 of 256 CUs at this batch size",
-                         "load_path": load_path(k_us)},
+                         "load_path": load_path(k_us),
+                         "hbm": {"achieved": TRAFFIC_BYTES_PER_LAUNCH_B32 / (k_us * 1e-6) / 1e9, "peak": 8000.0, "unit": "GB/s",
+                                 "frac": TRAFFIC_BYTES_PER_LAUNCH_B32 / (k_us * 1e-6) / 1e9 / 8000.0,
+                                 "note": "measured FETCH bytes per launch / launch time: the launch is not HBM-bound"}
+                         if (N_AGENT, N_PL, N_TL, B_PER_GPU) == (64, 256, 40, 32) else None},
             "checks": dict(finite=finite, **red),
             "reference_metric_states": dict(ref_metrics, note="sum-states of the reference's TrafficRuleMetrics / ErrorMetrics over all ranks "
                                             "(tb_metric_partials + the all-reduce); e.g. dest_reached / counter_agent = "
