@@ -596,7 +596,8 @@ class Oracle:
         res["_inp"], res["_feats"] = inp, f
         return res
 
-    def reactive_replay(self, batch: Dict[str, np.ndarray], step_end: int) -> Dict[str, Tensor]:
+    def reactive_replay(self, batch: Dict[str, np.ndarray], step_end: int, tf_cfg_name: str = "teacher_forcing_reactive_replay",
+                        eps: Optional[np.ndarray] = None, rollout_prior: bool = False) -> Dict[str, Tensor]:
         """First half of `WaymoMotion.validation_step` (`waymo_motion.py:574-611`): posterior and prior personalities,
         destination prediction, then the episode replayed with the posterior MEAN as personality, the ground-truth
         destination as goal and `teacher_forcing_reactive_replay` (agents keep spawning from ground truth until step 90).
@@ -609,8 +610,10 @@ class Oracle:
         logits = self.dest_logits(f, inp)
         goal_valid = inp["agent_valid"].any(1)  # GoalManager.get_gt_goal, goal_manager.py:66-68
         dest = gt["gt_dest"].to(torch.int64)
-        res = self.rollout(inp, f, post_mean.clone(), post_mean, dest, goal_valid, 1, step_end, gt=gt,
-                           tf_cfg_name="teacher_forcing_reactive_replay", log_std_name="post")
+        # training_step (`waymo_motion.py:384-400`): a SAMPLE (mean + std * eps) of the posterior, or of the prior
+        mean, log_std, which = (prior_mean, prior_log_std, "prior") if rollout_prior else (post_mean, post_log_std, "post")
+        z = mean.clone() if eps is None else mean + _t(eps, self.dtype) * log_std.exp()
+        res = self.rollout(inp, f, z, mean, dest, goal_valid, 1, step_end, gt=gt, tf_cfg_name=tf_cfg_name, log_std_name=which)
         res.update(post_mean=post_mean, post_log_std=post_log_std, post_valid=post_valid, prior_mean=prior_mean,
                    prior_log_std=prior_log_std, prior_valid=prior_valid, dest_logits_raw=logits, goal_valid=goal_valid,
                    gt_dest=dest, gt_valid=gt["agent_valid"], gt_state=gt["agent_state"], agent_role=gt["agent_role"],

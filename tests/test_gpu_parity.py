@@ -560,6 +560,46 @@ def test_validation_step_against_oracle_fresh_seed():
     assert dj <= 2.5e-4, dj
 
 
+@pytest.mark.parametrize("rollout_prior", [False, True])
+def test_training_step_forward_against_oracle(rollout_prior):
+    """Forward value of training_step (teacher_forcing_training, a SAMPLE of the posterior / prior personality, ground-truth
+    destination, TrainingMetrics.compute) against the oracles."""
+    from oracle import training_oracle as TO
+    from oracle.trafficbots_oracle import Oracle
+    from trafficbots_amd import synth
+    from trafficbots_amd.config import load_model_config
+
+    over = {"time_step_end": 60, "differentiable_reward.w_collision": 0.2}
+    scene = dict(n_agent=20, n_pl=48, n_tl=12, p_invalid_agent=0.2, p_late_spawn=0.3, p_future_spawn=0.5, p_future_exit=0.3, pos_range=60.0)
+    sd = synth.make_state_dict(9800)
+    batch = synth.make_val_batch(9801, 3, **scene)
+    eps = synth.make_latent_noise(9802, 3, 20)
+    wm = _engine(over, sd)
+    out = wm.training_step(batch, latent_eps=torch.from_numpy(eps).cuda(), rollout_prior=rollout_prior)
+    torch.cuda.synchronize()
+    cfg = load_model_config(overrides=over)
+    r = Oracle(sd, cfg, dtype=torch.float32).reactive_replay(batch, 60, tf_cfg_name="teacher_forcing_training", eps=eps,
+                                                              rollout_prior=rollout_prior)
+    buf = out["rollout_buffer"]
+    assert (buf.valid.cpu() == r["valid"]).all() and (buf.override_masks.cpu() == r["override_masks"]).all()
+    assert r["override_masks"][:, :, 10:].sum() == 0  # teacher_forcing_training: nothing is forced after the warm start
+    assert np.abs(buf.latent_sample.cpu().numpy() - (r["prior_mean"] if rollout_prior else r["post_mean"]).numpy()
+                  - eps * float(np.exp(-1.0))).max() <= 1e-6
+    dxy = ((buf.preds.cpu() - r["preds"]).abs() * r["valid"].unsqueeze(-1))[..., :2].max()
+    assert dxy <= 2.5e-4, dxy
+    gv, gs = r["gt_valid"][:, 1:61].transpose(1, 2), r["gt_state"][:, 1:61].transpose(1, 2)
+    rew, rv = TO.differentiable_reward(buf.valid.cpu(), buf.preds.cpu(), gv, gs, r["agent_size"], cfg["differentiable_reward"])
+    st = TO.training_metric_states(buf.valid.cpu(), rv, rew, buf.override_masks.cpu(), r["agent_role"], r["dest_logits_raw"], r["goal_valid"],
+                                   r["gt_dest"], r["post_mean"], r["post_log_std"], r["post_valid"], r["prior_mean"], r["prior_log_std"],
+                                   r["prior_valid"], cfg["training_metrics"])
+    want = TO.training_metric_compute(st, cfg["training_metrics"], "training")
+    got = out["metrics_dict"]
+    assert set(got) == set(want)
+    for k in want:
+        assert abs(got[k] - want[k]) <= 2e-5 * max(1.0, abs(want[k])), (k, got[k], want[k])
+    assert out["loss"] == got["training/loss"]
+
+
 def test_empty_and_bad_inputs_fail_loudly():
     from trafficbots_amd import synth
     from trafficbots_amd.waymo_motion import WaymoMotion

@@ -127,6 +127,12 @@ DEFAULT_MODEL_CONFIG: Dict[str, Any] = {
         "cyc": {"_target_": "utils.dynamics.MultiPathPP", "max_acc": 6, "max_yaw_rate": 3, "disable_neg_spd": False},
         "ped": {"_target_": "utils.dynamics.MultiPathPP", "max_acc": 7, "max_yaw_rate": 7},
     },
+    "teacher_forcing_training": {  # traffic_bots.yaml:127-133
+        "step_spawn_agent": 10, "step_warm_start": 10, "step_horizon": 0, "step_horizon_decrease_per_epoch": 0,
+        "prob_forcing_agent": 0, "prob_forcing_agent_decrease_per_epoch": 0,
+    },
+    "p_training_rollout_prior": 0.1,  # traffic_bots.yaml
+    "training_deterministic_action": True,
     "teacher_forcing_joint_future_pred": {"step_spawn_agent": 10, "step_warm_start": 10},
     "teacher_forcing_reactive_replay": {"step_spawn_agent": 90, "step_warm_start": 10},
     "waymo_post_processing": {  # traffic_bots.yaml:179-186
@@ -226,7 +232,8 @@ def load_model_config(path: str | None = None, overrides: Dict[str, Any] | None 
         for p in parts[:-1]:
             node = node.setdefault(p, {})
         node[parts[-1]] = val
-    for group in ("differentiable_reward", "training_metrics"):
+    for group in ("differentiable_reward", "training_metrics", "teacher_forcing_training", "p_training_rollout_prior",
+                  "training_deterministic_action"):
         cfg.setdefault(group, copy.deepcopy(DEFAULT_MODEL_CONFIG[group]))
     check_supported(cfg)
     return cfg

@@ -241,10 +241,12 @@ class WaymoMotion:
 
     def reactive_replay(self, batch: Dict[str, Tensor], input_feature_dict: Dict[str, Tensor], mask_teacher_forcing: Tensor,
                         latent: DiagGaussian, goal: Tensor, goal_valid: Tensor, deterministic_latent: bool = True,
-                        deterministic_action: bool = True, require_vis_dict: bool = False) -> RolloutBuffer:
+                        deterministic_action: bool = True, require_vis_dict: bool = False, latent_eps: Optional[Tensor] = None,
+                        latent_is_posterior: bool = True) -> RolloutBuffer:
         """`WaymoMotion.reactive_replay` (`waymo_motion.py:420-476`): the episode replayed from its ground truth (`batch` is the
         pre-processed validation scene, `batch["gt"]` its ground truth) with the given personality and goal; K = 1.  The
-        personality is taken as a POSTERIOR for `latent_log_prob` (that is what validation / training pass, `:382-387,605`)."""
+        personality is taken as a POSTERIOR for `latent_log_prob` (that is what validation / training pass, `:382-387,605`).
+        `deterministic_latent=False` draws the personality as mean + std * `latent_eps` (training_step's rsample, `:397`)."""
         features = {k: v for k, v in batch.items() if k != "gt"}
         features["map_feature"] = input_feature_dict["map_feature"]
         features["map_feature_valid"] = input_feature_dict["map_feature_valid"].to(torch.uint8).contiguous()
@@ -253,7 +255,8 @@ class WaymoMotion:
             features, latent=latent, goal=goal, goal_valid=goal_valid, mask_teacher_forcing=mask_teacher_forcing,
             deterministic_latent=deterministic_latent, deterministic_action=deterministic_action,
             step_start=self.hparams["time_step_sim_start"], step_end=self.hparams["time_step_end"], k_futures=1,
-            gt=batch["gt"], latent_posterior=True, require_vis_dict=require_vis_dict, rule_checker_tl=batch["gt"],
+            gt=batch["gt"], latent_posterior=latent_is_posterior, require_vis_dict=require_vis_dict, rule_checker_tl=batch["gt"],
+            latent_eps=latent_eps,
         )
 
     def finish_rollout(self) -> RolloutBuffer:
@@ -368,6 +371,48 @@ class WaymoMotion:
             "latent_mean": latent_mean, "latent_valid": latent_valid, "dest_logits": self.model._enc["dest_logits"],
             "scores": scores, "pred_dict": pred_dict,
         }
+
+    def training_step(self, batch: Dict[str, Tensor], batch_idx: int = 0, latent_eps: Optional[Tensor] = None,
+                      rollout_prior: bool = False, current_epoch: int = 0) -> Dict[str, object]:
+        """Forward value of `WaymoMotion.training_step` (`waymo_motion.py:356-418`): the episode replayed under
+        `teacher_forcing_training` with a SAMPLE of the posterior personality (or of the prior when `rollout_prior`, which the
+        reference decides with `torch.rand(1) < p_training_rollout_prior`) and the ground-truth destination, then
+        `TrainingMetrics` -> {"training/loss", "training/vae_kl", "training/diffbar_reward", "training/goal_loss"}.
+        Random draws are explicit (`latent_eps` [B,A,16] standard normal; None = the mean), the network runs without dropout
+        (the reference's eval-mode arithmetic), and there is no backward pass: this is the loss a validation of the training
+        objective reports, not an optimisation step."""
+        hp = self.hparams
+        if not hp.get("training_deterministic_action", True):
+            raise NotImplementedError("stochastic actions (training_deterministic_action=False) are outside the built path")
+        tf = hp["teacher_forcing_training"]
+        if tf.get("step_horizon", 0) - tf.get("step_horizon_decrease_per_epoch", 0) * current_epoch > 0 or \
+                tf.get("prob_forcing_agent", 0) - tf.get("prob_forcing_agent_decrease_per_epoch", 0) * current_epoch > 0:
+            raise NotImplementedError("teacher_forcing_training schedules (step_horizon / prob_forcing_agent) are not built")
+        scene = self.pre_processing(batch)
+        if "gt" not in scene:
+            raise ValueError("training_step needs a training / validation batch (agent/*, tl_stop/* ground truth)")
+        gt = scene["gt"]
+        input_feature_dict = self.model.encode_input_features(scene)
+        goal_gt, goal_valid = self.model.goal_manager.get_gt_goal(scene["agent_valid"], gt.get("gt_goal"), gt["gt_dest"])
+        goal_pred = self.model.goal_manager.pred_goal()
+        latent_post = self.model.latent_encoder(posterior=True, gt=gt)
+        latent_prior = self.model.latent_encoder()
+        latent = latent_prior if rollout_prior else latent_post
+        mask_tf = teacher_forcing_mask(gt["agent_valid"].bool(), tf.get("step_spawn_agent", 10), tf.get("step_warm_start", 10))
+        buf = self.reactive_replay(scene, input_feature_dict, mask_tf, latent, goal_gt, goal_valid,
+                                   deterministic_latent=latent_eps is None, deterministic_action=True, latent_eps=latent_eps,
+                                   latent_is_posterior=not rollout_prior)
+        gv, gs = self._gt_slices(gt, hp["time_step_sim_start"], hp["time_step_end"])
+        raw = {"valid": buf.valid, "preds": buf.preds, "override_masks": buf.override_masks}
+        _, _, states = self.engine.train_partials(
+            raw, gv, gs, scene["agent_size"], dest_logits=self.model._enc["dest_logits"], goal_valid=goal_pred.valid, gt_dest=goal_gt,
+            post={"latent_mean": latent_post.mean, "latent_valid": latent_post.valid},
+            prior={"latent_mean": latent_prior.mean, "latent_valid": latent_prior.valid})
+        m = TrainingMetrics("training", **hp["training_metrics"])
+        m.update(states)
+        out = m.compute()  # (the reference logs and resets per step, :415-417)
+        return {"loss": out["training/loss"], "metrics_dict": out, "train_states": states, "rollout_buffer": buf,
+                "latent_post": latent_post, "latent_prior": latent_prior}
 
     def validation_step(self, batch: Dict[str, Tensor], batch_idx: int = 0, latent_eps=None, goal_sample=None, generator=None
                         ) -> Dict[str, object]:
