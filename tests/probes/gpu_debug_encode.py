@@ -1,7 +1,7 @@
 """Development probe: encoder outputs of tb_encode_scene vs the oracle."""
 import os, sys
 import numpy as np, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from oracle.trafficbots_oracle import Oracle
 from trafficbots_amd import synth

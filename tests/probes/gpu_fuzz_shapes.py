@@ -7,7 +7,7 @@ import sys
 import numpy as np
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from oracle.trafficbots_oracle import Oracle  # noqa: E402
 from trafficbots_amd import synth  # noqa: E402
