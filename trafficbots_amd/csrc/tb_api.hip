@@ -27,6 +27,7 @@ hipError_t configure_step8_kernel();
     namespace NS {                                                                                                                \
     void launch_step_x(const RolloutP& p, int t, int do_c, int do_a, hipStream_t s);                                              \
     hipError_t configure_stepx_kernel();                                                                                          \
+    void launch_fuse_hoist_x(const RolloutP& p, hipStream_t s);                                                                   \
     void launch_kv_hoist_x(const float* W, const XLayerW* L3, const XLayerX* X3, const float* feat, const uint8_t* fvalid, int G, \
                            int n_tok, int n_pad, float* K, float* VT, float* kbias, hipStream_t s);                               \
     }
@@ -665,6 +666,9 @@ static void rollout_prologue(const tb_ctx* ctx, const tb::RolloutP& p, const tb_
         hoist(p.W, p.pw.as2tl, p.px.as2tl, p.tl_feature, io->tl_feature_valid, p.n_scene * p.n_tl_hist, p.n_tl, p.t_pad, p.ktl, p.vttl,
               p.kbias_tl, s);
         tb::launch_rollout_init(p, s);
+        // the constant half of add_goal / add_latent's first fusion Linear (reads what k_rollout_init just wrote)
+        if (ctx->step_kernel == 3) tb::xb::launch_fuse_hoist_x(p, s);
+        else tb::xh::launch_fuse_hoist_x(p, s);
         return;
     }
     tb::launch_kv_hoist(p.W, p.pw.as2pl, p.map_feature, io->map_feature_valid, p.n_scene, p.n_pl, p.p_pad, p.kpl, p.vtpl,

@@ -28,44 +28,84 @@ static_assert(XO_PL % 4 == 0, "plane buffers must be 16-byte aligned");
 static_assert(NPL * PLANEC * 2 <= 2 * PLANES_BYTES, "concat planes must fit two plane buffers");
 static_assert(STEPX_LDS_FLOATS * 4 <= 160 * 1024, "LDS budget");
 
-// add_goal / add_latent fusion MLP (add_latent_goal.py:57-77): h = relu(W2 relu(W1 [x ; relu(mask(pre))] + b1) + b2) ...
-//   CP : concat planes [3][16][LDPC];  P2 : plane buffer for the hidden;  uw : in = first K half of W1 (carries b1)
-__device__ __forceinline__ void fuse_latent_goal_x(const float* __restrict__ W, uint32_t w1x, uint32_t w2x, uint32_t b2, float* X,
-                                                   xhalf* CP, xhalf* P2, const float* PRE, const uint8_t* zvalid,
-                                                   const uint8_t* rowvalid, int tid, WUnitX& uw, const WNextX& nxt) {
+// add_goal / add_latent fusion MLP (add_latent_goal.py:57-77): h = relu(W2 relu(W1 [x ; u] + b1) + b2), u = relu(mask(pre)).
+// u does not change during a rollout (only its mask does), so its half of the first Linear is hoisted: k_fuse_hoist_x leaves
+// PRE = W1[:, 128:256] u in the rollout workspace and the step multiplies only the x half (one weight unit instead of two).
+//   CP : planes of x ([16][LDPC] rows);  P2 : plane buffer for the hidden;  uw : in = the x half of W1 (carries b1)
+__device__ __forceinline__ void fuse_latent_goal_x(const float* __restrict__ W, uint32_t w2x, uint32_t b2, float* X, xhalf* CP, xhalf* P2,
+                                                   const float* PRE, const uint8_t* zvalid, const uint8_t* rowvalid, int tid, WUnitX& uw,
+                                                   const WNextX& nxt) {
     const int wave = wave_of(tid), lane = tid & 63, kq = lane >> 4, m = lane & 15;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int idx = tid + i * NTHREADS;
         const int r = idx >> 5, c4 = (idx & 31) * 4;
         planes_store4(CP, PLANEC, LDPC, r, c4, lds4(X + r * LDT + c4));
-        planes_store4(CP, PLANEC, LDPC, r, 128 + c4, zvalid[r] ? relu4(lds4(PRE + r * LDT + c4)) : splat(0.f));
     }
     __syncthreads();
     WUnitX u2;
+    const bool zv = zvalid[m] != 0;
     {
         const int ta = 2 * wave, tb_ = 2 * wave + 1;
         f32x4 acc[2] = {uw.b[0], uw.b[1]};
-        const xhalf* xr = CP + m * LDPC + kq * 8;
-        wmmax_pf(acc[0], acc[1], uw, xr, PLANEC, u2, wnextx(W, w1x, nullptr, ta, tb_, 8, 4), lane);
-        wmmax_pf(acc[0], acc[1], u2, xr + 128, PLANEC, uw, wstdx(W, w2x, W + b2, wave), lane);
+        wmmax_pf(acc[0], acc[1], uw, CP + m * LDPC + kq * 8, PLANEC, u2, wstdx(W, w2x, W + b2, wave), lane);
+        if (zv) {
+            acc[0] += lds4(cptr(const_cast<float*>(PRE), LDT, ta, lane));
+            acc[1] += lds4(cptr(const_cast<float*>(PRE), LDT, tb_, lane));
+        }
         planes_store_c(P2, ta, lane, relu4(acc[0]));
         planes_store_c(P2, tb_, lane, relu4(acc[1]));
     }
     __syncthreads();
     {
-        f32x4 acc[2] = {uw.b[0], uw.b[1]};
-        wmmax_pf(acc[0], acc[1], uw, P2 + m * LDP + kq * 8, PLANE, u2, nxt, lane);
-        const bool zv = zvalid[m] != 0, rv = rowvalid[m] != 0;
+        f32x4 acc[2] = {u2.b[0], u2.b[1]};
+        wmmax_pf(acc[0], acc[1], u2, P2 + m * LDP + kq * 8, PLANE, uw, nxt, lane);
+        const bool rv = rowvalid[m] != 0;
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             float* px = cptr(X, LDT, 2 * wave + t, lane);
             const f32x4 h = zv ? relu4(acc[t]) : splat(0.f);
             st4(px, rv ? h + lds4(px) : splat(0.f));
         }
-        uw = u2;
     }
     __syncthreads();
+}
+
+// Rollout prologue: goal_pre / lat_pre (pre-activations of add_goal / add_latent's mlp_in, k_rollout_init) -> the hoisted half of
+// the fusion MLPs' first Linear, in place: PRE <- W1[:, 128:256] relu(PRE)  (no bias: b1 rides with the x half).  grid (a_pad/16, N)
+__global__ __launch_bounds__(NTHREADS) void k_fuse_hoist_x(RolloutP p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* T = smem;
+    xhalf* P1 = reinterpret_cast<xhalf*>(smem + TM * LDT);
+    const int tid = threadIdx.x, wave = wave_of(tid), lane = tid & 63, kq = lane >> 4, m = lane & 15;
+    const size_t base_row = (size_t)blockIdx.y * p.a_pad + blockIdx.x * TM;
+    const int ta = 2 * wave, tb_ = 2 * wave + 1;
+    WUnitX u, u2;
+    wloadx(u, wnextx(p.W, p.px.goal_out_w1, nullptr, ta, tb_, 8, 4), lane);
+    wloadx(u2, wnextx(p.W, p.px.lat_out_w1, nullptr, ta, tb_, 8, 4), lane);
+#pragma unroll 1
+    for (int which = 0; which < 2; ++which) {
+        float* pre = (which ? p.lat_pre : p.goal_pre) + base_row * H;
+        load_tile(T, LDT, pre, TM, tid);
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int idx = tid + i * NTHREADS;
+            const int r = idx >> 5, c4 = (idx & 31) * 4;
+            planes_store4(P1, PLANE, LDP, r, c4, relu4(lds4(T + r * LDT + c4)));
+        }
+        __syncthreads();
+        f32x4 acc[2] = {splat(0.f), splat(0.f)};
+        wmmax(acc[0], acc[1], which ? u2 : u, P1 + m * LDP + kq * 8, PLANE);
+        st4(pre + (size_t)m * H + ta * 16 + kq * 4, acc[0]);
+        st4(pre + (size_t)m * H + tb_ * 16 + kq * 4, acc[1]);
+        __syncthreads();
+    }
+}
+
+void launch_fuse_hoist_x(const RolloutP& p, hipStream_t s) {
+    dim3 grid(p.a_pad / TM, p.n_inst);
+    hipLaunchKernelGGL(k_fuse_hoist_x, grid, dim3(NTHREADS), TM * LDT * sizeof(float) + PLANES_BYTES, s, p);
 }
 
 __global__ __launch_bounds__(NTHREADS) void k_step_x(RolloutP p, int t, int do_c, int do_a) {
@@ -190,7 +230,7 @@ __global__ __launch_bounds__(NTHREADS) void k_step_x(RolloutP p, int t, int do_c
         }
         TB_STAMP(3);
         // ---- add_goal, add_latent (traffic_bots.py:240-241); concat planes = PC..PD, hidden = PB
-        fuse_latent_goal_x(W, px.goal_out_w1, px.goal_out_w2, pw.goal_out_b2, X, PC, PB, GP, gvalid, rowvalid, tid, u,
+        fuse_latent_goal_x(W, px.goal_out_w2, pw.goal_out_b2, X, PC, PB, GP, gvalid, rowvalid, tid, u,
                            wnextx(W, px.lat_out_w1, W + pw.lat_out_b1, 2 * wave, 2 * wave + 1, 8, 0));
         const int my_ty = (lane < TM && rowvalid[lane]) ? rtype[lane] : -1;
         const bool has0 = __ballot(my_ty == 0) != 0, has1 = __ballot(my_ty == 1) != 0, has2 = __ballot(my_ty == 2) != 0;
@@ -199,7 +239,7 @@ __global__ __launch_bounds__(NTHREADS) void k_step_x(RolloutP p, int t, int do_c
         const WNextX h1 = has1 ? wstdx(W, px.head_w1[1], W + pw.head_b1[1], wave) : h2;
         const WNextX h0 = has0 ? wstdx(W, px.head_w1[0], W + pw.head_b1[0], wave) : h1;
         TB_STAMP(4);
-        fuse_latent_goal_x(W, px.lat_out_w1, px.lat_out_w2, pw.lat_out_b2, X, PC, PB, LP, rowvalid, rowvalid, tid, u, h0);
+        fuse_latent_goal_x(W, px.lat_out_w2, pw.lat_out_b2, X, PC, PB, LP, rowvalid, rowvalid, tid, u, h0);
         TB_STAMP(5);
         if (t == p.tap_step && p.tap_policy_feature)
             store_tile(p.tap_policy_feature + ((size_t)n * p.n_agent + row0) * H, X, LDT, n_real, tid);
