@@ -28,7 +28,7 @@ H = 128
 PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak
 # fabric-side bytes per fused launch from the PMC pass of this round (profiles/r01_rocprof_xdl.txt: FETCH_SIZE 41 061 KiB x 2, the
 # gfx950 correction of the guide, at the headline shape); collected with rocprofv3 --pmc in its own run, not at bench time
-TRAFFIC_BYTES_PER_LAUNCH_B32 = 2 * 40923 * 1024
+TRAFFIC_BYTES_PER_LAUNCH_B32 = 2 * 40412 * 1024
 
 
 def flops_step_a(a, p, t):  # SURVEY 8(d) split: as2pl + as2tl + interaction K/V projections + agent encoder
@@ -39,7 +39,8 @@ def load_path(k_us):
     """Bytes every workgroup pulls through its CU's vector-memory path per fused launch (weights are streamed once per
     16-agent tile, K/V once per head) against the ~64 B/clk/CU the L1 can fill (MI355X_MICROARCH.md: L2 34.5 TB/s / 256 CUs)."""
     h = 128
-    w_bytes = 67 * h * h * 4          # 134 A H^2 flops per agent = 67 H^2 weights, 4 B each as an fp16 pair
+    w_bytes = 65 * h * h * 4          # 67 H^2 weights of the path, 4 B each as an fp16 pair, minus the two constant half-Linears of
+                                      # add_goal / add_latent that the rollout prologue hoists (k_fuse_hoist_x)
     pad = lambda n: (n + 31) // 32 * 32
     kv_bytes = 3 * 2 * (pad(N_PL) + pad(N_TL) + pad(N_AGENT)) * h * 4
     clk = 2.1e9                       # s_memtime ticks per second observed on this kernel
