@@ -417,6 +417,27 @@ int tb_finalize_weights(tb_ctx* ctx, tb_stream stream) {
             px.as2pl[i] = add_xlayer_x(a, s, "model.transformer_as2pl.layers." + si);
             px.as2tl[i] = add_xlayer_x(a, s, "model.transformer_as2tl.layers." + si);
             px.inter[i] = add_xlayer_x(a, s, "model.agent_interaction.transformer.layers." + si);
+            {
+                const std::string lp = "model.agent_interaction.transformer.layers." + si;
+                auto w = s.get(lp + ".attn.in_proj_weight", 384 * 128);
+                auto b = s.get(lp + ".attn.in_proj_bias", 384);
+                auto g = s.get(lp + ".norm_tgt.weight", 128);
+                auto be = s.get(lp + ".norm_tgt.bias", 128);
+                if (w && b && g && be) {
+                    std::vector<float> wf(256 * 128), bf(256);
+                    for (int r = 0; r < 256; ++r) {
+                        double acc = (*b)[128 + r];
+                        for (int c = 0; c < 128; ++c) {
+                            const float wv = (*w)[(size_t)(128 + r) * 128 + c];
+                            wf[(size_t)r * 128 + c] = wv * (*g)[c];
+                            acc += (double)wv * (double)(*be)[c];
+                        }
+                        bf[r] = (float)acc;
+                    }
+                    px.inter_kvf[i] = a.add(bf16 ? pack_xdl_bf16(wf.data(), 256, 128) : pack_xdl(wf.data(), 256, 128));
+                    px.inter_bkvf[i] = a.add(bf);
+                }
+            }
             px.gru[i].wih = add_xdl(a, s, "model.agent_temporal.rnn.weight_ih_l" + si, 384, 128);
             px.gru[i].whh = add_xdl(a, s, "model.agent_temporal.rnn.weight_hh_l" + si, 384, 128);
             px.head_w1[i] = add_xdl(a, s, "action_head.mlp_mean." + si + ".fc_layers.0.weight", 128, 128);

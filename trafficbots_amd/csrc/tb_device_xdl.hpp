@@ -575,6 +575,42 @@ __device__ __forceinline__ void kv_project_tile_x(const float* __restrict__ W, c
     __syncthreads();
 }
 
+// (x - mean) rstd of a [16][128] fp32 LDS tile as planes: the LayerNorm without its affine (folded into the consumer's weights)
+__device__ __forceinline__ void normalize_planes(const float* src, int lds_, xhalf* P, int tid) {
+    const int row = tid >> 4, c0 = (tid & 15) * 8;
+    const f32x4 a = lds4(src + row * lds_ + c0), c = lds4(src + row * lds_ + c0 + 4);
+    const float s = row16_sum((a.x + a.y) + (a.z + a.w) + (c.x + c.y) + (c.z + c.w));
+    const float mean = s * (1.0f / 128.0f);
+    const f32x4 da = a - splat(mean), dc = c - splat(mean);
+    const float v = row16_sum((da.x * da.x + da.y * da.y) + (da.z * da.z + da.w * da.w) + (dc.x * dc.x + dc.y * dc.y) +
+                              (dc.z * dc.z + dc.w * dc.w));
+    const float rstd = 1.0f / sqrtf(v * (1.0f / 128.0f) + LN_EPS);
+    planes_store4(P, PLANE, LDP, row, c0, da * splat(rstd));
+    planes_store4(P, PLANE, LDP, row, c0 + 4, dc * splat(rstd));
+}
+
+// K/V of the tile for the three interaction layers from ONE normalisation (norm_tgt folded into kvf / bkvf, PolicyWX).
+// u holds the K unit of layer 0 on entry and `nxt` on exit; Kmat / VT point at layer 0, layer l at + 2 l ls (fp16).
+__device__ __forceinline__ void kv_project_shared_x(const float* __restrict__ W, const uint32_t (&kvf)[3], const uint32_t (&bkvf)[3],
+                                                    const float* T, xhalf* P1, xhalf* __restrict__ Kmat, xhalf* __restrict__ VT, size_t ls,
+                                                    int tok0, int n_real_rows, int tid, WUnitX& u, const WNextX& nxt) {
+    const int wave = wave_of(tid), lane = tid & 63;
+    const int kq = lane >> 4, m = lane & 15;
+    normalize_planes(T, LDT, P1, tid);
+    __syncthreads();
+    const xhalf* b1 = P1 + m * LDP + kq * 8;
+    WUnitX u2;
+#pragma unroll
+    for (int l = 0; l < 3; ++l) {
+        f32x4 ak[2] = {u.b[0], u.b[1]};
+        wmmax_pf(ak[0], ak[1], u, b1, PLANE, u2, wnextx(W, kvf[l], W + bkvf[l], 8 + 2 * wave, 8 + 2 * wave + 1), lane);
+        f32x4 av[2] = {u2.b[0], u2.b[1]};
+        wmmax_pf(av[0], av[1], u2, b1, PLANE, u, l < 2 ? wstdx(W, kvf[l + 1], W + bkvf[l + 1], wave) : nxt, lane);
+        kv_store_x(Kmat + 2 * l * ls, VT + 2 * l * ls, tok0, wave, lane, ak, av, m < n_real_rows);
+    }
+    __syncthreads();
+}
+
 // One GRU layer step: inputs as planes (XinP, HsP) + the fp32 previous hidden (Hs) for the convex update.
 //   OutP : planes for the next layer's input, or nullptr;  Out : fp32 LDS tile, or nullptr
 __device__ __forceinline__ void gru_layer_x(const float* __restrict__ W, const GruLayerW& G, const GruLayerX& GX, const xhalf* XinP,

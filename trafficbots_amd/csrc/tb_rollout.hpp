@@ -35,6 +35,9 @@ struct GruLayerX {
 };
 struct PolicyWX {
     XLayerX as2pl[3], as2tl[3], inter[3];
+    // interaction K/V projection with norm_tgt folded in: W' = W_kv diag(gamma_tgt), b' = b_kv + W_kv beta_tgt (the three layers
+    // project the SAME tile, so its normalisation (x - mean) rstd is computed once per step instead of once per layer)
+    uint32_t inter_kvf[3], inter_bkvf[3];
     GruLayerX gru[3];
     uint32_t goal_out_w1, goal_out_w2, lat_out_w1, lat_out_w2;
     uint32_t head_w1[3];

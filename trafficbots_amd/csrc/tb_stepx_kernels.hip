@@ -329,7 +329,7 @@ __global__ __launch_bounds__(NTHREADS) void k_step_x(RolloutP p, int t, int do_c
         xattn_layer_x<true>(W, pw.as2tl[1], px.as2tl[1], X, PA, PB, K0 + 2 * ls, V0 + 2 * ls, kvd, p.t_pad, ks_t, -1, rowvalid, novalid_s, tid, u,
                             xlayer_first_x(W, pw.as2tl[2], px.as2tl[2], wave), LN + 7 * 768);
         xattn_layer_x<true>(W, pw.as2tl[2], px.as2tl[2], X, PA, PB, K0 + 4 * ls, V0 + 4 * ls, kvd, p.t_pad, ks_t, -1, rowvalid, novalid_s, tid,
-                            u, kvproj_first_x(W, pw.inter[0], px.inter[0], wave), LN + 8 * 768);
+                            u, wstdx(W, px.inter_kvf[0], W + px.inter_bkvf[0], wave), LN + 8 * 768);
     }
     TB_STAMP(10);
     store_tile(p.x_mid + base_row * H, X, LDT, TM, tid);
@@ -337,12 +337,8 @@ __global__ __launch_bounds__(NTHREADS) void k_step_x(RolloutP p, int t, int do_c
         const size_t ls = (size_t)p.a_pad * H;
         xhalf* K0 = reinterpret_cast<xhalf*>(p.kin + ((size_t)n * 3) * ls);
         xhalf* V0 = reinterpret_cast<xhalf*>(p.vtin + ((size_t)n * 3) * ls);
-        kv_project_tile_x<true>(W, pw.inter[0], px.inter[0], X, PA, K0, V0, p.a_pad, row0, TM, tid, u,
-                                kvproj_first_x(W, pw.inter[1], px.inter[1], wave), LN + 0 * 768);
-        kv_project_tile_x<true>(W, pw.inter[1], px.inter[1], X, PA, K0 + 2 * ls, V0 + 2 * ls, p.a_pad, row0, TM, tid, u,
-                                kvproj_first_x(W, pw.inter[2], px.inter[2], wave), LN + 1 * 768);
-        kv_project_tile_x<true>(W, pw.inter[2], px.inter[2], X, PA, K0 + 4 * ls, V0 + 4 * ls, p.a_pad, row0, TM, tid, u,
-                                kvproj_first_x(W, pw.inter[2], px.inter[2], wave), LN + 2 * 768);
+        // (the last unit request points at a valid unit that nobody consumes: the launch ends here)
+        kv_project_shared_x(W, px.inter_kvf, px.inter_bkvf, X, PA, K0, V0, ls, row0, TM, tid, u, wstdx(W, px.inter_kvf[0], W + px.inter_bkvf[0], wave));
     }
     TB_STAMP(11);
 }
