@@ -357,6 +357,7 @@ int tb_finalize_weights(tb_ctx* ctx, tb_stream stream) {
     TB_HIP(ctx, tb::xh::configure_stepx_kernel());
     TB_HIP(ctx, tb::xb::configure_stepx_kernel());
     TB_HIP(ctx, tb::configure_rule_kernels());
+    TB_HIP(ctx, tb::xh::configure_encodex_kernels());
     Arena a;
     Stage s{ctx};
     tb::PolicyW& pw = ctx->pw;
@@ -478,6 +479,16 @@ int tb_finalize_weights(tb_ctx* ctx, tb_stream stream) {
         ew.inter_post_x[i] = add_xlayer_x(a, s, "model.latent_encoder.agent_interaction_post.transformer.layers." + si);
     }
     ew.map_self_x = add_xlayer_x(a, s, "model.map_encoder.transformer_self_attn.layers.0");
+    for (int i = 0; i < 3; ++i) {
+        const std::string si = std::to_string(i);
+        const char* names[3] = {"model.latent_encoder.agent_temporal_prior.rnn", "model.goal_manager.goal_predictor.gru_as.rnn",
+                                "model.latent_encoder.agent_temporal_post.rnn"};
+        tb::GruLayerX* dst[3] = {ew.gru_prior_x, ew.gru_dest_x, ew.gru_post_x};
+        for (int k = 0; k < 3; ++k) {
+            dst[k][i].wih = add_xdl(a, s, std::string(names[k]) + ".weight_ih_l" + si, 384, 128);
+            dst[k][i].whh = add_xdl(a, s, std::string(names[k]) + ".weight_hh_l" + si, 384, 128);
+        }
+    }
     ew.lat_w1 = add_packed(a, s, "model.latent_encoder.latent_prior_dist.mlp_mean.fc_layers.0.weight", 128, 128, 128);
     ew.lat_b1 = add_plain(a, s, "model.latent_encoder.latent_prior_dist.mlp_mean.fc_layers.0.bias", 128);
     ew.lat_w2 = add_plain(a, s, "model.latent_encoder.latent_prior_dist.mlp_mean.fc_layers.2.weight", 16 * 128);

@@ -20,6 +20,7 @@ struct EncoderW {
     uint32_t post_log_std;                        // latent_post_dist.log_std [16]
     // fp16-pair (XDL) packing of the attention blocks, for the encoders' default kernels (tb_encodex_kernels.hip)
     XLayerX densetnt_x[3], map_self_x, as2pl_x[3], as2tl_x[3], inter_prior_x[3], inter_post_x[3];
+    GruLayerX gru_prior_x[3], gru_dest_x[3], gru_post_x[3];
     uint32_t dest_w0_map, dest_w0_agent, dest_b0, dest_ln0_g, dest_ln0_b;
     uint32_t dest_w1, dest_b1, dest_ln1_g, dest_ln1_b, dest_w2, dest_b2;
 };
@@ -40,7 +41,24 @@ struct XBlockPX {
     int eye;                   // MultiAgentTF: self key masked; groups with exactly one valid row pass through
 };
 
+// GRU over time for a 16-agent tile (k_gru_scan / k_gru_scan_x): mode 0 = latent encoder (max over valid steps + DistEncoder mean),
+// mode 1 = destination predictor (last valid output + input residual)
+struct ScanP {
+    const float* W;
+    GruLayerW gru[3];
+    GruLayerX grux[3];     // XDL kernel only
+    uint32_t head_w1, head_b1, head_w2, head_b2;  // mode 0
+    int mode, B, S, A;
+    const float* x;        // [B][S][A][128]
+    const uint8_t* valid;  // [B][S][A]
+    float* out_feat;       // mode 1: [B][A][128]
+    float* out_mean;       // mode 0: [B][A][16]
+    uint8_t* out_valid;    // [B][A]
+};
+
 namespace xh {
+void launch_gru_scan_x(const ScanP& p, int a_pad, hipStream_t s);
+hipError_t configure_encodex_kernels();
 void launch_kv_hoist_nx(const float* W, const XLayerW* L, const XLayerX* X, int n_layer, const float* feat, const uint8_t* fvalid, int G,
                         int n_tok, int n_pad, float* K, float* VT, float* kbias, hipStream_t s);
 void launch_xblock_x(const XBlockPX& p, int G, hipStream_t s);

@@ -260,18 +260,6 @@ __global__ void k_gather_steps_u8(const uint8_t* __restrict__ src, uint8_t* __re
 //   mode 0: masked max over time (fill -1e3), then latent mean head  (agent_temporal.py:28-29, latent_encoder.py:194-198)
 //   mode 1: + residual, last valid step                              (goal_manager.py:295-300, agent_temporal.py:30-33)
 // ------------------------------------------------------------------------------------------------
-struct ScanP {
-    const float* W;
-    GruLayerW gru[3];
-    uint32_t head_w1, head_b1, head_w2, head_b2;  // mode 0
-    int mode, B, S, A;
-    const float* x;        // [B][S][A][128]
-    const uint8_t* valid;  // [B][S][A]
-    float* out_feat;       // mode 1: [B][A][128]
-    float* out_mean;       // mode 0: [B][A][16]
-    uint8_t* out_valid;    // [B][A]
-};
-
 __global__ __launch_bounds__(NTHREADS) void k_gru_scan(ScanP p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* X = smem;                 // step input
@@ -546,7 +534,9 @@ static void launch_latent_branch(bool xdl, const float* W, const EncoderW& ew, i
     sp.head_w1 = which ? ew.post_w1 : ew.lat_w1; sp.head_b1 = which ? ew.post_b1 : ew.lat_b1;
     sp.head_w2 = which ? ew.post_w2 : ew.lat_w2; sp.head_b2 = which ? ew.post_b2 : ew.lat_b2;
     sp.mode = 0; sp.B = B; sp.S = S3; sp.A = A; sp.x = w.x3; sp.valid = w.v0; sp.out_mean = out_mean; sp.out_valid = out_valid;
-    hipLaunchKernelGGL(k_gru_scan, dim3(a_pad / TM, B), dim3(NTHREADS), (8 * TM * LDT + 16) * sizeof(float), s, sp);
+    for (int l = 0; l < 3; ++l) sp.grux[l] = (which ? ew.gru_post_x : ew.gru_prior_x)[l];
+    if (xdl) xh::launch_gru_scan_x(sp, a_pad, s);
+    else hipLaunchKernelGGL(k_gru_scan, dim3(a_pad / TM, B), dim3(NTHREADS), (8 * TM * LDT + 16) * sizeof(float), s, sp);
 }
 
 int run_encode(struct ::tb_ctx* ctx, const tb_encode_io* io, hipStream_t s) {
@@ -638,7 +628,9 @@ int run_encode(struct ::tb_ctx* ctx, const tb_encode_io* io, hipStream_t s) {
         sp.W = W;
         for (int l = 0; l < 3; ++l) sp.gru[l] = ew.gru_dest[l];
         sp.mode = 1; sp.B = B; sp.S = NH; sp.A = A; sp.x = io->agent_feature; sp.valid = io->agent_valid; sp.out_feat = tgt; sp.out_valid = tgtv;
-        hipLaunchKernelGGL(k_gru_scan, dim3(a_pad / TM, B), dim3(NTHREADS), (8 * TM * LDT + 16) * sizeof(float), s, sp);
+        for (int l = 0; l < 3; ++l) sp.grux[l] = ew.gru_dest_x[l];
+        if (ctx->encode_kernel == 1) xh::launch_gru_scan_x(sp, a_pad, s);
+        else hipLaunchKernelGGL(k_gru_scan, dim3(a_pad / TM, B), dim3(NTHREADS), (8 * TM * LDT + 16) * sizeof(float), s, sp);
         hipLaunchKernelGGL(k_linear_rows, dim3((B * P + TM - 1) / TM), dim3(NTHREADS), 0, s, W, ew.dest_w0_map, ew.dest_b0, 1,
                            io->map_feature, B * P, U);
         hipLaunchKernelGGL(k_linear_rows, dim3((B * A + TM - 1) / TM), dim3(NTHREADS), 0, s, W, ew.dest_w0_agent, 0u, 0, tgt, B * A, V);

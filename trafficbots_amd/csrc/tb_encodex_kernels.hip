@@ -87,5 +87,97 @@ void launch_xblock_x(const XBlockPX& p, int G, hipStream_t s) {
     else hipLaunchKernelGGL(k_xattn_block_x<false>, grid, dim3(NTHREADS), lds, s, p);
 }
 
+// GRU over the S steps of a 16-agent tile on the XDL pipe (the twin of k_gru_scan): the three hidden states live in LDS as fp32
+// tiles (convex update) and are re-split into fp16 pairs every step; plane rotation as in k_step_x's GRU block.  grid (a_pad/16, B)
+constexpr int SCANX_LDS_BYTES = 6 * TM * LDT * 4 + 4 * PLANES_BYTES + 64;
+
+__global__ __launch_bounds__(NTHREADS) void k_gru_scan_x(ScanP p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* X = smem;                 // step input
+    float* HS = X + TM * LDT;        // 3 hidden tiles [3][16][LDT]
+    float* AGG = HS + 3 * TM * LDT;  // aggregate
+    float* Y0 = AGG + TM * LDT;      // head scratch
+    xhalf* PA = reinterpret_cast<xhalf*>(Y0 + TM * LDT);
+    xhalf* PB = PA + NPL * PLANE;
+    xhalf* PC = PB + NPL * PLANE;
+    xhalf* PD = PC + NPL * PLANE;
+    uint8_t* rowvalid = reinterpret_cast<uint8_t*>(PD + NPL * PLANE);
+    uint8_t* anyvalid = rowvalid + 16;
+    const int tid = threadIdx.x, wave = wave_of(tid), lane = tid & 63, kq = lane >> 4, m = lane & 15;
+    const int b = blockIdx.y, row0 = blockIdx.x * TM;
+    const int n_real = min(TM, p.A - row0);
+    float* H0 = HS, *H1 = HS + TM * LDT, *H2 = HS + 2 * TM * LDT;
+    WUnitX u;
+    wloadx(u, gru_first_x(p.W, p.gru[0], p.grux[0], wave), lane);
+    for (int i = tid; i < 3 * TM * LDT; i += NTHREADS) HS[i] = 0.f;
+    for (int i = tid; i < TM * LDT; i += NTHREADS) AGG[i] = p.mode == 0 ? -INFINITY : 0.f;
+    if (tid < TM) anyvalid[tid] = 0;
+    __syncthreads();
+#pragma unroll 1
+    for (int s = 0; s < p.S; ++s) {
+        load_tile(X, LDT, p.x + (((size_t)b * p.S + s) * p.A + row0) * H, n_real, tid);
+        if (tid < TM) {
+            const uint8_t v = tid < n_real ? p.valid[((size_t)b * p.S + s) * p.A + row0 + tid] : 0;
+            rowvalid[tid] = v;
+            if (v) anyvalid[tid] = 1;
+        }
+        __syncthreads();
+        tile_to_planes(X, LDT, PA, tid);
+        tile_to_planes(H0, LDT, PB, tid);
+        tile_to_planes(H1, LDT, PD, tid);
+        __syncthreads();
+        // (the new hidden of a layer overwrites its fp32 tile in place: every lane reads and writes only its own four elements)
+        gru_layer_x(p.W, p.gru[0], p.grux[0], PA, PB, H0, PC, H0, rowvalid, nullptr, 0, tid, u, gru_first_x(p.W, p.gru[1], p.grux[1], wave));
+        tile_to_planes(H2, LDT, PB, tid);  // h0's planes are free after the barrier that closed layer 0
+        gru_layer_x(p.W, p.gru[1], p.grux[1], PC, PD, H1, PA, H1, rowvalid, nullptr, 0, tid, u, gru_first_x(p.W, p.gru[2], p.grux[2], wave));
+        gru_layer_x(p.W, p.gru[2], p.grux[2], PA, PB, H2, nullptr, H2, rowvalid, nullptr, 0, tid, u, gru_first_x(p.W, p.gru[0], p.grux[0], wave));
+        // aggregate (outputs of invalid rows are already zero; hidden reset to zero likewise)
+        for (int i = tid; i < TM * 32; i += NTHREADS) {
+            const int r = i >> 5, c4 = (i & 31) * 4;
+            if (p.mode == 0) {  // x.masked_fill(~valid, -1e3).amax(1)
+                const f32x4 o = rowvalid[r] ? lds4(H2 + r * LDT + c4) : splat(-1e3f);
+                const f32x4 a = lds4(AGG + r * LDT + c4);
+                st4(AGG + r * LDT + c4, f32x4{fmaxf(a.x, o.x), fmaxf(a.y, o.y), fmaxf(a.z, o.z), fmaxf(a.w, o.w)});
+            } else if (rowvalid[r]) {
+                st4(AGG + r * LDT + c4, lds4(H2 + r * LDT + c4) + lds4(X + r * LDT + c4));
+            }
+        }
+        __syncthreads();
+    }
+    for (int i = tid; i < TM * 32; i += NTHREADS) {  // rows that were never valid -> 0
+        const int r = i >> 5, c4 = (i & 31) * 4;
+        if (!anyvalid[r]) st4(AGG + r * LDT + c4, splat(0.f));
+    }
+    __syncthreads();
+    if (tid < n_real) p.out_valid[(size_t)b * p.A + row0 + tid] = anyvalid[tid];
+    if (p.mode == 1) {
+        store_tile(p.out_feat + ((size_t)b * p.A + row0) * H, AGG, LDT, n_real, tid);
+        return;
+    }
+    // latent mean = W2 relu(W1 agg + b1) + b2, masked (latent_encoder.py:168-178): once per tile, the fp32-MFMA Linear
+    {
+        f32x4 acc[2];
+        linear128<128>(acc, p.W + p.head_w1, p.W + p.head_b1, AGG + m * LDT + kq * 32, wave, lane);
+        st4(cptr(Y0, LDT, 2 * wave, lane), relu4(acc[0]));
+        st4(cptr(Y0, LDT, 2 * wave + 1, lane), relu4(acc[1]));
+    }
+    __syncthreads();
+    {
+        const int r = tid >> 4, o = tid & 15;
+        float sacc = p.W[p.head_b2 + o];
+        const float* w2 = p.W + p.head_w2 + o * H;
+        for (int k = 0; k < H; ++k) sacc = fmaf(Y0[r * LDT + k], w2[k], sacc);
+        if (r < n_real) p.out_mean[((size_t)b * p.A + row0 + r) * 16 + o] = anyvalid[r] ? sacc : 0.f;
+    }
+}
+
+void launch_gru_scan_x(const ScanP& p, int a_pad, hipStream_t s) {
+    hipLaunchKernelGGL(k_gru_scan_x, dim3(a_pad / TM, p.B), dim3(NTHREADS), SCANX_LDS_BYTES, s, p);
+}
+
+hipError_t configure_encodex_kernels() {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(k_gru_scan_x), hipFuncAttributeMaxDynamicSharedMemorySize, SCANX_LDS_BYTES);
+}
+
 }  // namespace TB_XNS
 }  // namespace tb
