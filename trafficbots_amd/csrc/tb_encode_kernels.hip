@@ -36,99 +36,120 @@ struct TokP {
     float* out;           // [n_tok][128]
 };
 
+// One workgroup encodes TOK_GROUPS consecutive groups of 16 tokens with the MLP weights (transposed) and the PE frequencies staged
+// in LDS once: the scalar weight loads of a 16-token workgroup were an L1-latency chain of ~130 dependent loads.
+constexpr int TOK_GROUPS = 16;
+
 __global__ __launch_bounds__(NTHREADS) void k_encode_tokens(TokP p) {
     __shared__ __attribute__((aligned(16))) float attr[TM][32];
     __shared__ __attribute__((aligned(16))) float hid[TM][32];
     __shared__ __attribute__((aligned(16))) float outt[TM][LDT];
+    __shared__ float w1t[31 * 32], w2t[32 * 32], b1s[32], b2s[32], fxy[12], fyaw[24];
     __shared__ float pose[TM][4];
     __shared__ uint8_t rv[TM];
     const int tid = threadIdx.x;
-    const int tok0 = blockIdx.x * TM;
     const int attr_dim = p.kind == 0 ? 11 : (p.kind == 1 ? 5 : 31);
-    if (tid < TM) {
-        const int tk = tok0 + tid;
-        float* a = attr[tid];
-        for (int k = 0; k < 32; ++k) a[k] = 0.f;
-        float x = 0.f, y = 0.f, yw = 0.f;
-        uint8_t v = 0;
-        if (tk < p.n_tok) {
-            v = p.valid[tk];
-            x = p.pos[(size_t)tk * 2];
-            y = p.pos[(size_t)tk * 2 + 1];
-            const int b = tk / p.per_scene, r = tk % p.inner;
-            if (p.kind == 0) {
-                yw = p.yaw[tk];
-                const int A = p.inner;
-                a[0] = p.vel[(size_t)tk * 2]; a[1] = p.vel[(size_t)tk * 2 + 1]; a[2] = p.spd[tk];
-                a[3] = p.yaw_rate[tk]; a[4] = p.acc[tk];
-                const float* sz = p.size + ((size_t)b * A + r) * 3;
-                a[5] = sz[0]; a[6] = sz[1]; a[7] = sz[2];
-                const int ty = p.cls[(size_t)b * A + r];
-                if (ty >= 0 && ty < 3) a[8 + ty] = 1.f;
-            } else {
-                yw = (float)atan2((double)p.dir[(size_t)tk * 2 + 1], (double)p.dir[(size_t)tk * 2]);  // pose_pe.py:61
-                if (p.kind == 1) {
-                    const int st = p.cls[tk];
-                    if (st >= 0 && st < 5) a[st] = 1.f;
+    for (int i = tid; i < attr_dim * 32; i += NTHREADS) w1t[i] = p.W[p.mlp.w1 + (i & 31) * attr_dim + (i >> 5)];
+    for (int i = tid; i < 32 * 32; i += NTHREADS) w2t[i] = p.W[p.mlp.w2 + (i & 31) * 32 + (i >> 5)];
+    if (tid < 32) {
+        b1s[tid] = p.W[p.mlp.b1 + tid];
+        b2s[tid] = p.W[p.mlp.b2 + tid];
+    }
+    if (tid < 12) fxy[tid] = p.W[p.pe_fxy + tid];
+    if (tid >= 32 && tid < 56) fyaw[tid - 32] = p.W[p.pe_fyaw + tid - 32];
+    __syncthreads();
+#pragma unroll 1
+    for (int g = 0; g < TOK_GROUPS; ++g) {
+        const int tok0 = (blockIdx.x * TOK_GROUPS + g) * TM;
+        if (tok0 >= p.n_tok) break;
+        if (tid < TM) {
+            const int tk = tok0 + tid;
+            float* a = attr[tid];
+            for (int k = 0; k < 32; ++k) a[k] = 0.f;
+            float x = 0.f, y = 0.f, yw = 0.f;
+            uint8_t v = 0;
+            if (tk < p.n_tok) {
+                v = p.valid[tk];
+                x = p.pos[(size_t)tk * 2];
+                y = p.pos[(size_t)tk * 2 + 1];
+                const int b = tk / p.per_scene, r = tk % p.inner;
+                if (p.kind == 0) {
+                    yw = p.yaw[tk];
+                    const int A = p.inner;
+                    a[0] = p.vel[(size_t)tk * 2]; a[1] = p.vel[(size_t)tk * 2 + 1]; a[2] = p.spd[tk];
+                    a[3] = p.yaw_rate[tk]; a[4] = p.acc[tk];
+                    const float* sz = p.size + ((size_t)b * A + r) * 3;
+                    a[5] = sz[0]; a[6] = sz[1]; a[7] = sz[2];
+                    const int ty = p.cls[(size_t)b * A + r];
+                    if (ty >= 0 && ty < 3) a[8 + ty] = 1.f;
                 } else {
-                    const int pl = tk / 20;  // global polyline index
-                    const int ty = p.cls[pl];
-                    if (ty >= 0 && ty < 11) a[ty] = 1.f;
-                    a[11 + r] = 1.f;  // node one-hot (sc_input.py:127-133)
+                    yw = (float)atan2((double)p.dir[(size_t)tk * 2 + 1], (double)p.dir[(size_t)tk * 2]);  // pose_pe.py:61
+                    if (p.kind == 1) {
+                        const int st = p.cls[tk];
+                        if (st >= 0 && st < 5) a[st] = 1.f;
+                    } else {
+                        const int pl = tk / 20;  // global polyline index
+                        const int ty = p.cls[pl];
+                        if (ty >= 0 && ty < 11) a[ty] = 1.f;
+                        a[11 + r] = 1.f;  // node one-hot (sc_input.py:127-133)
+                    }
                 }
             }
+            pose[tid][0] = x; pose[tid][1] = y; pose[tid][2] = yw;
+            rv[tid] = v;
         }
-        pose[tid][0] = x; pose[tid][1] = y; pose[tid][2] = yw;
-        rv[tid] = v;
-    }
-    __syncthreads();
-    {
-        const int row = tid >> 4, i = tid & 15;
-        const float px = pose[row][0], py = pose[row][1], pyaw = pose[row][2];
-        float* xr = outt[row] + 32;
+        __syncthreads();
+        {
+            const int row = tid >> 4, i = tid & 15;
+            const float px = pose[row][0], py = pose[row][1], pyaw = pose[row][2];
+            float* xr = outt[row] + 32;
 #pragma unroll
-        for (int u = 0; u < 3; ++u) {
-            const int j = i * 3 + u;
-            float arg;
-            int c_cos, c_sin;
-            if (j < 12) {
-                arg = px * p.W[p.pe_fxy + j]; c_cos = j; c_sin = 12 + j;
-            } else if (j < 24) {
-                arg = py * p.W[p.pe_fxy + j - 12]; c_cos = 24 + (j - 12); c_sin = 36 + (j - 12);
-            } else {
-                arg = pyaw * p.W[p.pe_fyaw + j - 24]; c_cos = 48 + (j - 24); c_sin = 72 + (j - 24);
+            for (int u = 0; u < 3; ++u) {
+                const int j = i * 3 + u;
+                float arg;
+                int c_cos, c_sin;
+                if (j < 12) {
+                    arg = px * fxy[j]; c_cos = j; c_sin = 12 + j;
+                } else if (j < 24) {
+                    arg = py * fxy[j - 12]; c_cos = 24 + (j - 12); c_sin = 36 + (j - 12);
+                } else {
+                    arg = pyaw * fyaw[j - 24]; c_cos = 48 + (j - 24); c_sin = 72 + (j - 24);
+                }
+                // fp64 sin/cos of the fp32 argument, rounded once (sincos_pe: Cody-Waite reduction + Taylor, the step kernel's routine)
+                float sv, cv;
+                sincos_pe(arg, sv, cv);
+                xr[c_cos] = cv;
+                xr[c_sin] = sv;
             }
-            // fp64 sin/cos of the fp32 argument, rounded once: within 0.5 ulp of exact, i.e. as close as
-            // possible to whatever libm the reference's host uses (48 per agent, negligible)
-            double sv, cv;
-            sincos((double)arg, &sv, &cv);
-            xr[c_cos] = (float)cv;
-            xr[c_sin] = (float)sv;
+            const int o0 = i * 2;
+            float s0 = b1s[o0], s1 = b1s[o0 + 1];
+            for (int k = 0; k < attr_dim; ++k) {
+                const float av = attr[row][k];
+                s0 = fmaf(av, w1t[k * 32 + o0], s0);
+                s1 = fmaf(av, w1t[k * 32 + o0 + 1], s1);
+            }
+            hid[row][o0] = fmaxf(s0, 0.f);
+            hid[row][o0 + 1] = fmaxf(s1, 0.f);
         }
-        const int o0 = i * 2;
+        __syncthreads();
+        {
+            const int row = tid >> 4, o0 = (tid & 15) * 2;
+            float s0 = b2s[o0], s1 = b2s[o0 + 1];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int o = o0 + u;
-            float s = p.W[p.mlp.b1 + o];
-            for (int k = 0; k < attr_dim; ++k) s = fmaf(attr[row][k], p.W[p.mlp.w1 + o * attr_dim + k], s);
-            hid[row][o] = fmaxf(s, 0.f);
+            for (int k = 0; k < 32; ++k) {
+                const float hv = hid[row][k];
+                s0 = fmaf(hv, w2t[k * 32 + o0], s0);
+                s1 = fmaf(hv, w2t[k * 32 + o0 + 1], s1);
+            }
+            outt[row][o0] = s0;
+            outt[row][o0 + 1] = s1;
         }
-    }
-    __syncthreads();
-    {
-        const int row = tid >> 4, o0 = (tid & 15) * 2;
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int o = o0 + u;
-            float s = p.W[p.mlp.b2 + o];
-            for (int k = 0; k < 32; ++k) s = fmaf(hid[row][k], p.W[p.mlp.w2 + o * 32 + k], s);
-            outt[row][o] = s;
+        __syncthreads();
+        for (int i = tid; i < TM * 32; i += NTHREADS) {
+            const int r = i >> 5, c4 = (i & 31) * 4;
+            if (tok0 + r < p.n_tok) st4(p.out + (size_t)(tok0 + r) * H + c4, rv[r] ? lds4(&outt[r][c4]) : splat(0.f));
         }
-    }
-    __syncthreads();
-    for (int i = tid; i < TM * 32; i += NTHREADS) {
-        const int r = i >> 5, c4 = (i & 31) * 4;
-        if (tok0 + r < p.n_tok) st4(p.out + (size_t)(tok0 + r) * H + c4, rv[r] ? lds4(&outt[r][c4]) : splat(0.f));
+        __syncthreads();
     }
 }
 
@@ -592,17 +613,17 @@ int run_encode(struct ::tb_ctx* ctx, const tb_encode_io* io, hipStream_t s) {
         t.valid = io->agent_valid; t.pos = io->agent_pos; t.yaw = io->agent_yaw; t.vel = io->agent_vel; t.spd = io->agent_spd;
         t.acc = io->agent_acc; t.yaw_rate = io->agent_yaw_rate; t.cls = io->agent_type; t.size = io->agent_size;
         t.out = io->agent_feature;
-        hipLaunchKernelGGL(k_encode_tokens, dim3((t.n_tok + TM - 1) / TM), dim3(NTHREADS), 0, s, t);
+        hipLaunchKernelGGL(k_encode_tokens, dim3((t.n_tok + TM * TOK_GROUPS - 1) / (TM * TOK_GROUPS)), dim3(NTHREADS), 0, s, t);
         TokP l{};
         l.W = W; l.pe_fxy = ew.pe_fxy; l.pe_fyaw = ew.pe_fyaw;
         l.kind = 1; l.mlp = ew.tl_enc; l.n_tok = B * NH * T; l.per_scene = NH * T; l.inner = T;
         l.valid = io->tl_valid; l.pos = io->tl_pos; l.dir = io->tl_dir; l.cls = io->tl_state; l.out = io->tl_feature;
-        hipLaunchKernelGGL(k_encode_tokens, dim3((l.n_tok + TM - 1) / TM), dim3(NTHREADS), 0, s, l);
+        hipLaunchKernelGGL(k_encode_tokens, dim3((l.n_tok + TM * TOK_GROUPS - 1) / (TM * TOK_GROUPS)), dim3(NTHREADS), 0, s, l);
         TokP m{};
         m.W = W; m.pe_fxy = ew.pe_fxy; m.pe_fyaw = ew.pe_fyaw;
         m.kind = 2; m.mlp = ew.map_enc; m.n_tok = B * P * 20; m.per_scene = P * 20; m.inner = 20;
         m.valid = io->map_valid; m.pos = io->map_pos; m.dir = io->map_dir; m.cls = io->map_type; m.out = nodef;
-        hipLaunchKernelGGL(k_encode_tokens, dim3((m.n_tok + TM - 1) / TM), dim3(NTHREADS), 0, s, m);
+        hipLaunchKernelGGL(k_encode_tokens, dim3((m.n_tok + TM * TOK_GROUPS - 1) / (TM * TOK_GROUPS)), dim3(NTHREADS), 0, s, m);
     }
     // ---- map encoder
     for (int b0 = 0; b0 < B; b0 += scenes_per_chunk) {
@@ -682,12 +703,12 @@ int run_encode_posterior(struct ::tb_ctx* ctx, const tb_posterior_io* io, hipStr
     t.valid = io->agent_valid; t.pos = io->agent_pos; t.yaw = io->agent_yaw; t.vel = io->agent_vel; t.spd = io->agent_spd;
     t.acc = io->agent_acc; t.yaw_rate = io->agent_yaw_rate; t.cls = io->agent_type; t.size = io->agent_size;
     t.out = af;
-    hipLaunchKernelGGL(k_encode_tokens, dim3((t.n_tok + TM - 1) / TM), dim3(NTHREADS), 0, s, t);
+    hipLaunchKernelGGL(k_encode_tokens, dim3((t.n_tok + TM * TOK_GROUPS - 1) / (TM * TOK_GROUPS)), dim3(NTHREADS), 0, s, t);
     TokP l{};
     l.W = W; l.pe_fxy = ew.pe_fxy; l.pe_fyaw = ew.pe_fyaw;
     l.kind = 1; l.mlp = ew.tl_enc; l.n_tok = B * NS * T; l.per_scene = NS * T; l.inner = T;
     l.valid = io->tl_valid; l.pos = io->tl_pos; l.dir = io->tl_dir; l.cls = io->tl_state; l.out = tf;
-    hipLaunchKernelGGL(k_encode_tokens, dim3((l.n_tok + TM - 1) / TM), dim3(NTHREADS), 0, s, l);
+    hipLaunchKernelGGL(k_encode_tokens, dim3((l.n_tok + TM * TOK_GROUPS - 1) / (TM * TOK_GROUPS)), dim3(NTHREADS), 0, s, l);
     launch_latent_branch(ctx->encode_kernel == 1, W, ew, 1, B, NS, A, P, T, af, io->agent_valid, tf, io->tl_valid, io->map_feature, io->map_feature_valid, lws,
                          io->latent_mean, io->latent_valid, s);
     TB_HIP(ctx, hipGetLastError());

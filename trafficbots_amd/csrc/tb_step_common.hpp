@@ -538,30 +538,6 @@ __device__ __forceinline__ void encw_commit(int tid, const EncWRegs& r, float* E
     }
 }
 
-// sin and cos of an fp32 argument (|x| < ~1e5), evaluated in fp64 and rounded once
-__device__ __forceinline__ void sincos_pe(float xf, float& s_out, float& c_out) {
-    const double x = (double)xf;
-    const double n = rint(x * 0.63661977236758134308);  // 2/pi
-    double r = fma(-n, 1.57079632679489655800e+00, x);  // pi/2 in two pieces
-    r = fma(-n, 6.12323399573676603587e-17, r);
-    const double r2 = r * r;
-    double sp = fma(r2, -2.50521083854417187751e-08, 2.75573192239858906526e-06);  // 1/11!, 1/9!
-    sp = fma(r2, sp, -1.98412698412698412698e-04);
-    sp = fma(r2, sp, 8.33333333333333333333e-03);
-    sp = fma(r2, sp, -1.66666666666666666667e-01);
-    const double sv = fma(r * r2, sp, r);
-    double cp = fma(r2, 2.08767569878680989792e-09, -2.75573192239858906526e-07);  // 1/12!, 1/10!
-    cp = fma(r2, cp, 2.48015873015873015873e-05);
-    cp = fma(r2, cp, -1.38888888888888888889e-03);
-    cp = fma(r2, cp, 4.16666666666666666667e-02);
-    cp = fma(r2, cp, -0.5);
-    const double cv = fma(r2, cp, 1.0);
-    const int qd = (int)n & 3;
-    const double ss = (qd & 1) ? cv : sv, cc = (qd & 1) ? sv : cv;
-    s_out = (float)((qd & 2) ? -ss : ss);
-    c_out = (float)(((qd + 1) & 2) ? -cc : cc);
-}
-
 __device__ __forceinline__ void step_encode_inputs_lds(const RolloutP& p, int b, int row0, int n_real, int tid, const StepSmall& sm,
                                                        const float* ENCW, float* X) {
     float* attr = sm.attr; float* ench = sm.ench; const RowSt* rst = sm.rst; const uint8_t* rowvalid = sm.rowvalid;
