@@ -516,6 +516,7 @@ int tb_finalize_weights(tb_ctx* ctx, tb_stream stream) {
         ew.dest_ln0_g = add_plain(a, s, p + "1.weight", 128);
         ew.dest_ln0_b = add_plain(a, s, p + "1.bias", 128);
         ew.dest_w1 = add_packed(a, s, p + "3.weight", 128, 128, 128);
+        ew.dest_w1_x = add_xdl(a, s, p + "3.weight", 128, 128);
         ew.dest_b1 = add_plain(a, s, p + "3.bias", 128);
         ew.dest_ln1_g = add_plain(a, s, p + "4.weight", 128);
         ew.dest_ln1_b = add_plain(a, s, p + "4.bias", 128);

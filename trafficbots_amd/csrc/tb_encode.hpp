@@ -21,6 +21,7 @@ struct EncoderW {
     // fp16-pair (XDL) packing of the attention blocks, for the encoders' default kernels (tb_encodex_kernels.hip)
     XLayerX densetnt_x[3], map_self_x, as2pl_x[3], as2tl_x[3], inter_prior_x[3], inter_post_x[3];
     GruLayerX gru_prior_x[3], gru_dest_x[3], gru_post_x[3];
+    uint32_t dest_w1_x;
     uint32_t dest_w0_map, dest_w0_agent, dest_b0, dest_ln0_g, dest_ln0_b;
     uint32_t dest_w1, dest_b1, dest_ln1_g, dest_ln1_b, dest_w2, dest_b2;
 };
@@ -56,7 +57,23 @@ struct ScanP {
     uint8_t* out_valid;    // [B][A]
 };
 
+// destination predictor over (agent, polyline) pairs (DestPredictor.forward mode mlp, goal_manager.py:294-333)
+struct DestP {
+    const float* W;
+    uint32_t ln0_g, ln0_b, w1, b1, ln1_g, ln1_b, w2, b2;
+    uint32_t w1x;              // XDL packing of w1 (k_dest_pairs_x)
+    int B, A, P;
+    const float* U;            // [B][P][128]  = W0[:, :128] map_feature + b0
+    const float* V;            // [B][A][128]  = W0[:, 128:] agent
+    const uint8_t* map_fvalid; // [B][P]
+    const int32_t* map_type;   // [B][P]
+    const int32_t* agent_type; // [B][A]
+    const uint8_t* dist_valid; // [B][A]
+    float* logits;             // [B][A][P]
+};
+
 namespace xh {
+void launch_dest_pairs_x(const DestP& p, hipStream_t s);
 void launch_gru_scan_x(const ScanP& p, int a_pad, hipStream_t s);
 hipError_t configure_encodex_kernels();
 void launch_kv_hoist_nx(const float* W, const XLayerW* L, const XLayerX* X, int n_layer, const float* feat, const uint8_t* fvalid, int G,

@@ -392,19 +392,6 @@ __global__ __launch_bounds__(NTHREADS) void k_linear_rows(const float* __restric
 //   y = relu(LN(U[p] + V[a])) ; y = relu(LN(W1 y + b1)) ; logit = w2.y + b2 ; masks
 // grid = (p_tiles, A, B)
 // ------------------------------------------------------------------------------------------------
-struct DestP {
-    const float* W;
-    uint32_t ln0_g, ln0_b, w1, b1, ln1_g, ln1_b, w2, b2;
-    int B, A, P;
-    const float* U;            // [B][P][128]  = W0[:, :128] map_feature + b0
-    const float* V;            // [B][A][128]  = W0[:, 128:] agent
-    const uint8_t* map_fvalid; // [B][P]
-    const int32_t* map_type;   // [B][P]
-    const int32_t* agent_type; // [B][A]
-    const uint8_t* dist_valid; // [B][A]
-    float* logits;             // [B][A][P]
-};
-
 __device__ __forceinline__ bool dest_candidate(int mtype, bool mvalid, int atype) {
     // map_type_mask (goal_manager.py:235) and the per-class exclusions (:237-244)
     if (!(mvalid && mtype >= 0 && mtype < 5)) return false;
@@ -660,7 +647,9 @@ int run_encode(struct ::tb_ctx* ctx, const tb_encode_io* io, hipStream_t s) {
         d.ln1_b = ew.dest_ln1_b; d.w2 = ew.dest_w2; d.b2 = ew.dest_b2;
         d.B = B; d.A = A; d.P = P; d.U = U; d.V = V; d.map_fvalid = io->map_feature_valid; d.map_type = io->map_type;
         d.agent_type = io->agent_type; d.dist_valid = tgtv; d.logits = io->dest_logits;
-        hipLaunchKernelGGL(k_dest_pairs, dim3((P + TM - 1) / TM, A, B), dim3(NTHREADS), 0, s, d);
+        d.w1x = ew.dest_w1_x;
+        if (ctx->encode_kernel == 1) xh::launch_dest_pairs_x(d, s);
+        else hipLaunchKernelGGL(k_dest_pairs, dim3((P + TM - 1) / TM, A, B), dim3(NTHREADS), 0, s, d);
     }
     TB_HIP(ctx, hipGetLastError());
     return 0;

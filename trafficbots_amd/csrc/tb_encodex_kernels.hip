@@ -171,6 +171,108 @@ __global__ __launch_bounds__(NTHREADS) void k_gru_scan_x(ScanP p) {
     }
 }
 
+// Destination logits of (agent, polyline) pairs, XDL: one workgroup owns a 16-polyline tile of a scene and walks DEST_AGENTS
+// agents with the 128x128 Linear resident in registers (the fp32 kernel re-reads that 64 KB unit for every (agent, tile)).
+//   logit = w2 . relu(LN1(W1 relu(LN0(U[p] + V[a])) + b1)) + b2, masked by candidate type.      grid (P/16, ceil(A/DEST_AGENTS), B)
+constexpr int DEST_AGENTS = 16;
+
+__device__ __forceinline__ bool dest_candidate_x(int mtype, bool mvalid, int atype) {  // goal_manager.py:235-244
+    if (!(mvalid && mtype >= 0 && mtype < 5)) return false;
+    if (atype == 0 && mtype == 3) return false;
+    if (atype == 1 && mtype < 4) return false;
+    if (atype == 2 && mtype < 3) return false;
+    return true;
+}
+
+__global__ __launch_bounds__(NTHREADS) void k_dest_pairs_x(DestP p) {
+    __shared__ __attribute__((aligned(16))) float Ut[TM * LDT];
+    __shared__ __attribute__((aligned(16))) float X[TM * LDT];
+    __shared__ __attribute__((aligned(16))) xhalf P1[NPL * PLANE];
+    __shared__ int mtype_s[TM];
+    __shared__ uint8_t mvalid_s[TM];
+    const int tid = threadIdx.x, wave = wave_of(tid), lane = tid & 63, kq = lane >> 4, m = lane & 15;
+    const int p0 = blockIdx.x * TM, b = blockIdx.z, a0 = blockIdx.y * DEST_AGENTS;
+    const int n_real = min(TM, p.P - p0);
+    WUnitX u;
+    wloadx(u, wstdx(p.W, p.w1x, p.W + p.b1, wave), lane);
+    // which agent classes have any candidate polyline in this scene (rows that are all -inf become 0, :331-332)
+    bool mine[3] = {false, false, false};
+    for (int q = tid; q < p.P; q += NTHREADS) {
+        const int mt = p.map_type[(size_t)b * p.P + q];
+        const bool mv = p.map_fvalid[(size_t)b * p.P + q] != 0;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) mine[c] |= dest_candidate_x(mt, mv, c);
+    }
+    const bool any0 = __syncthreads_or(mine[0]), any1 = __syncthreads_or(mine[1]), any2 = __syncthreads_or(mine[2]);
+    for (int i = tid; i < TM * 32; i += NTHREADS) {
+        const int r = i >> 5, c4 = (i & 31) * 4;
+        st4(Ut + r * LDT + c4, r < n_real ? ldg4(p.U + ((size_t)b * p.P + p0 + r) * H + c4) : splat(0.f));
+    }
+    if (tid < TM) {
+        mtype_s[tid] = tid < n_real ? p.map_type[(size_t)b * p.P + p0 + tid] : -1;
+        mvalid_s[tid] = tid < n_real ? p.map_fvalid[(size_t)b * p.P + p0 + tid] : 0;
+    }
+    const int row = tid >> 4, c0 = (tid & 15) * 8;
+    const f32x4 g0a = ldg4(p.W + p.ln0_g + c0), g0b = ldg4(p.W + p.ln0_g + c0 + 4), b0a = ldg4(p.W + p.ln0_b + c0), b0b = ldg4(p.W + p.ln0_b + c0 + 4);
+    const f32x4 g1a = ldg4(p.W + p.ln1_g + c0), g1b = ldg4(p.W + p.ln1_g + c0 + 4), b1a = ldg4(p.W + p.ln1_b + c0), b1b = ldg4(p.W + p.ln1_b + c0 + 4);
+    const f32x4 w2a = ldg4(p.W + p.w2 + c0), w2b = ldg4(p.W + p.w2 + c0 + 4);
+    const float bias2 = p.W[p.b2];
+    __syncthreads();
+#pragma unroll 1
+    for (int a = a0; a < min(a0 + DEST_AGENTS, p.A); ++a) {
+        const int atype = p.agent_type[(size_t)b * p.A + a];
+        const bool dvalid = p.dist_valid[(size_t)b * p.A + a] != 0;
+        const bool any_cand = atype == 0 ? any0 : (atype == 1 ? any1 : (atype == 2 ? any2 : false));
+        {   // relu(LN0(U + V[a])) -> planes
+            const float* v = p.V + ((size_t)b * p.A + a) * H + c0;
+            const f32x4 xa = lds4(Ut + row * LDT + c0) + ldg4(v), xc = lds4(Ut + row * LDT + c0 + 4) + ldg4(v + 4);
+            const float sm = row16_sum((xa.x + xa.y) + (xa.z + xa.w) + (xc.x + xc.y) + (xc.z + xc.w));
+            const float mean = sm * (1.0f / 128.0f);
+            const f32x4 da = xa - splat(mean), dc = xc - splat(mean);
+            const float var = row16_sum((da.x * da.x + da.y * da.y) + (da.z * da.z + da.w * da.w) + (dc.x * dc.x + dc.y * dc.y) +
+                                        (dc.z * dc.z + dc.w * dc.w));
+            const float rstd = 1.0f / sqrtf(var * (1.0f / 128.0f) + LN_EPS);
+            planes_store4(P1, PLANE, LDP, row, c0, relu4(da * splat(rstd) * g0a + b0a));
+            planes_store4(P1, PLANE, LDP, row, c0 + 4, relu4(dc * splat(rstd) * g0b + b0b));
+        }
+        __syncthreads();
+        {
+            f32x4 acc[2] = {u.b[0], u.b[1]};
+            wmmax(acc[0], acc[1], u, P1 + m * LDP + kq * 8, PLANE);
+            st4(cptr(X, LDT, 2 * wave, lane), acc[0]);
+            st4(cptr(X, LDT, 2 * wave + 1, lane), acc[1]);
+        }
+        __syncthreads();
+        {   // w2 . relu(LN1(x)) + b2
+            const f32x4 xa = lds4(X + row * LDT + c0), xc = lds4(X + row * LDT + c0 + 4);
+            const float sm = row16_sum((xa.x + xa.y) + (xa.z + xa.w) + (xc.x + xc.y) + (xc.z + xc.w));
+            const float mean = sm * (1.0f / 128.0f);
+            const f32x4 da = xa - splat(mean), dc = xc - splat(mean);
+            const float var = row16_sum((da.x * da.x + da.y * da.y) + (da.z * da.z + da.w * da.w) + (dc.x * dc.x + dc.y * dc.y) +
+                                        (dc.z * dc.z + dc.w * dc.w));
+            const float rstd = 1.0f / sqrtf(var * (1.0f / 128.0f) + LN_EPS);
+            const f32x4 ya = relu4(da * splat(rstd) * g1a + b1a), yc = relu4(dc * splat(rstd) * g1b + b1b);
+            float s = 0.f;
+            s = fmaf(ya.x, w2a.x, s); s = fmaf(ya.y, w2a.y, s); s = fmaf(ya.z, w2a.z, s); s = fmaf(ya.w, w2a.w, s);
+            s = fmaf(yc.x, w2b.x, s); s = fmaf(yc.y, w2b.y, s); s = fmaf(yc.z, w2b.z, s); s = fmaf(yc.w, w2b.w, s);
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) s += __shfl_xor(s, o);
+            if ((tid & 15) == 0 && row < n_real) {
+                float lg = s + bias2;
+                if (!dest_candidate_x(mtype_s[row], mvalid_s[row] != 0, atype)) lg = -INFINITY;
+                if (!dvalid || !any_cand) lg = 0.f;
+                p.logits[((size_t)b * p.A + a) * p.P + p0 + row] = lg;
+            }
+        }
+        // (the next agent's planes are written before anyone reads X again; P1 was last read before the barrier above)
+    }
+}
+
+void launch_dest_pairs_x(const DestP& p, hipStream_t s) {
+    dim3 grid((p.P + TM - 1) / TM, (p.A + DEST_AGENTS - 1) / DEST_AGENTS, p.B);
+    hipLaunchKernelGGL(k_dest_pairs_x, grid, dim3(NTHREADS), 0, s, p);
+}
+
 void launch_gru_scan_x(const ScanP& p, int a_pad, hipStream_t s) {
     hipLaunchKernelGGL(k_gru_scan_x, dim3(a_pad / TM, p.B), dim3(NTHREADS), SCANX_LDS_BYTES, s, p);
 }
