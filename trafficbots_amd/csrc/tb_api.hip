@@ -29,7 +29,7 @@ hipError_t configure_step8_kernel();
     hipError_t configure_stepx_kernel();                                                                                          \
     void launch_fuse_hoist_x(const RolloutP& p, hipStream_t s);                                                                   \
     void launch_kv_hoist_x(const float* W, const XLayerW* L3, const XLayerX* X3, const float* feat, const uint8_t* fvalid, int G, \
-                           int n_tok, int n_pad, float* K, float* VT, float* kbias, hipStream_t s);                               \
+                           int n_tok, int n_pad, float* K, float* VT, float* kbias, int* nkey, hipStream_t s);                    \
     }
 TB_DECLARE_XDL(xh)  // fp16 pairs (tb_stepx_kernels.hip)
 TB_DECLARE_XDL(xb)  // bf16       (tb_stepx_bf16_kernels.hip)
@@ -594,6 +594,8 @@ static void carve_rollout(tb::RolloutP& p, Carver& c) {
     p.ktl = c.take<float>(B * NH * 3 * p.t_pad * 128);
     p.vttl = c.take<float>(B * NH * 3 * 128 * p.t_pad);
     p.kbias_tl = c.take<float>(B * NH * p.t_pad);
+    p.nkey_pl = c.take<int>(B);
+    p.nkey_tl = c.take<int>(B * NH);
     p.state = c.take<float>(N * p.a_pad * 4);
     p.aux = c.take<float>(N * p.a_pad * 4);
     p.valid = c.take<uint8_t>(N * p.a_pad);
@@ -695,9 +697,10 @@ static int rollout_setup(tb_ctx* ctx, const tb_rollout_io* io, tb::RolloutP& p) 
 static void rollout_prologue(const tb_ctx* ctx, const tb::RolloutP& p, const tb_rollout_io* io, hipStream_t s) {
     if (ctx->step_kernel >= 2) {  // k_step_x reads K / V in XDL operand order (fp16 pairs or bf16)
         auto hoist = ctx->step_kernel == 3 ? tb::xb::launch_kv_hoist_x : tb::xh::launch_kv_hoist_x;
-        hoist(p.W, p.pw.as2pl, p.px.as2pl, p.map_feature, io->map_feature_valid, p.n_scene, p.n_pl, p.p_pad, p.kpl, p.vtpl, p.kbias_pl, s);
+        hoist(p.W, p.pw.as2pl, p.px.as2pl, p.map_feature, io->map_feature_valid, p.n_scene, p.n_pl, p.p_pad, p.kpl, p.vtpl, p.kbias_pl,
+              p.nkey_pl, s);
         hoist(p.W, p.pw.as2tl, p.px.as2tl, p.tl_feature, io->tl_feature_valid, p.n_scene * p.n_tl_hist, p.n_tl, p.t_pad, p.ktl, p.vttl,
-              p.kbias_tl, s);
+              p.kbias_tl, p.nkey_tl, s);
         tb::launch_rollout_init(p, s);
         // the constant half of add_goal / add_latent's first fusion Linear (reads what k_rollout_init just wrote)
         if (ctx->step_kernel == 3) tb::xb::launch_fuse_hoist_x(p, s);

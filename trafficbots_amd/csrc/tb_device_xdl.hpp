@@ -454,10 +454,10 @@ __device__ __forceinline__ bool attention_head_x(const f32x4 (&q)[2], AttnPreX& 
 
 // K / V accumulators of a 16-token tile -> global, fragment-major (see above).  ak / av : this wave's K / V tiles
 // (features (2 wave + t)*16 + 4 kq + r of token m); the wave is head `wave`.
-__device__ __forceinline__ void kv_store_x(xhalf* __restrict__ Kf, xhalf* __restrict__ Vf, int tok0, int wave, int lane,
-                                           const f32x4 (&ak)[2], const f32x4 (&av)[2], bool real) {
-    const int kq = lane >> 4, m = lane & 15;
-    const int tok = tok0 + m;
+// `tok` = the key slot this lane's token goes to (its index, or its rank among the valid tokens when the hoist compacts)
+__device__ __forceinline__ void kv_store_key_x(xhalf* __restrict__ Kf, xhalf* __restrict__ Vf, int tok, int wave, int lane,
+                                               const f32x4 (&ak)[2], const f32x4 (&av)[2], bool real) {
+    const int kq = lane >> 4;
     const int j = tok & 31;
     xhalf* kblk = Kf + (size_t)(tok >> 5) * KV_BLOCK_HALFS + wave * (NPL * 1024);
     xhalf* vblk = Vf + (size_t)(tok >> 5) * KV_BLOCK_HALFS + wave * (NPL * 1024);
@@ -555,11 +555,19 @@ __device__ __forceinline__ void xattn_layer_x(const float* __restrict__ W, const
     TB_XSTAMP(24);
 }
 
-// K/V projection of the tile's tokens for one layer (LN_tgt -> in_proj rows 128:384), outputs in XDL operand order
+__device__ __forceinline__ void kv_store_x(xhalf* __restrict__ Kf, xhalf* __restrict__ Vf, int tok0, int wave, int lane,
+                                           const f32x4 (&ak)[2], const f32x4 (&av)[2], bool real) {
+    kv_store_key_x(Kf, Vf, tok0 + (lane & 15), wave, lane, ak, av, real);
+}
+
+// K/V projection of the tile's tokens for one layer (LN_tgt -> in_proj rows 128:384), outputs in XDL operand order.
+// slot != nullptr (compacting hoist): token m goes to key slot slot[m] (< 0: not stored) and the slots tok0 + m >= n_valid_keys
+// of this tile's own range are zero-filled (masked keys must still hold finite data: 0 x NaN would poison P V).
 template <bool LNLDS = false>
 __device__ __forceinline__ void kv_project_tile_x(const float* __restrict__ W, const XLayerW& L, const XLayerX& LX, const float* T,
                                                   xhalf* P1, xhalf* __restrict__ Kmat, xhalf* __restrict__ VT, int n_key_pad, int tok0,
-                                                  int n_real_rows, int tid, WUnitX& u, const WNextX& nxt, const float* lnblk = nullptr) {
+                                                  int n_real_rows, int tid, WUnitX& u, const WNextX& nxt, const float* lnblk = nullptr,
+                                                  const int* slot = nullptr, int n_valid_keys = 0) {
     const int wave = wave_of(tid), lane = tid & 63;
     const int kq = lane >> 4, m = lane & 15;
     if (!LNLDS) lnblk = W + L.ln1_g;
@@ -571,7 +579,13 @@ __device__ __forceinline__ void kv_project_tile_x(const float* __restrict__ W, c
     wmmax_pf(ak[0], ak[1], u, b1, PLANE, u2, wnextx(W, LX.wkv, W + L.bkv, 8 + 2 * wave, 8 + 2 * wave + 1), lane);
     f32x4 av[2] = {u2.b[0], u2.b[1]};
     wmmax_pf(av[0], av[1], u2, b1, PLANE, u, nxt, lane);
-    kv_store_x(Kmat, VT, tok0, wave, lane, ak, av, m < n_real_rows);
+    if (slot) {
+        const int sl = slot[m];
+        if (sl >= 0) kv_store_key_x(Kmat, VT, sl, wave, lane, ak, av, true);
+        if (tok0 + m >= n_valid_keys) kv_store_key_x(Kmat, VT, tok0 + m, wave, lane, ak, av, false);
+    } else {
+        kv_store_x(Kmat, VT, tok0, wave, lane, ak, av, m < n_real_rows);
+    }
     __syncthreads();
 }
 

@@ -56,6 +56,8 @@ struct RolloutP {
     // hoisted keys/values
     float* kpl;                   // [B,3,p_pad,128]
     float* vtpl;                  // [B,3,128,p_pad]
+    int* nkey_pl;                 // [B]      keys the XDL step kernel walks per scene (valid polylines compacted, whole blocks)
+    int* nkey_tl;                 // [B*NH]   likewise per (scene, traffic-light step)
     float* kbias_pl;              // [B,p_pad]   additive key mask: 0 valid, -inf invalid / padding
     float* ktl;                   // [B*NH,3,t_pad,128]
     float* vttl;                  // [B*NH,3,128,t_pad]

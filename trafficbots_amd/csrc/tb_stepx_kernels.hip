@@ -143,7 +143,7 @@ __global__ __launch_bounds__(NTHREADS) void k_step_x(RolloutP p, int t, int do_c
     const size_t base_row = (size_t)n * p.a_pad + row0;
     // staggered start of the key walks of the row tiles of one instance (attention_prefetch_x)
     const int n_rt = gridDim.x;
-    const int ks_a = ((rt * (p.a_pad >> 5)) / n_rt) << 5, ks_p = ((rt * (p.p_pad >> 5)) / n_rt) << 5, ks_t = ((rt * (p.t_pad >> 5)) / n_rt) << 5;
+    const int ks_a = ((rt * (p.a_pad >> 5)) / n_rt) << 5;
 
     WUnitX u;
     TB_STAMP(0);
@@ -306,29 +306,33 @@ __global__ __launch_bounds__(NTHREADS) void k_step_x(RolloutP p, int t, int do_c
     TB_STAMP(8);
     {
         const float* kvd = p.kbias_pl + (size_t)b * p.p_pad;
+        const int nk_p = p.nkey_pl[b];  // valid polylines, compacted to the front by the hoist, rounded up to whole key blocks
+        const int ks_p = ((rt * (nk_p >> 5)) / n_rt) << 5;
         const size_t ls = (size_t)p.p_pad * H;
         const xhalf* K0 = reinterpret_cast<const xhalf*>(p.kpl + ((size_t)b * 3) * ls);
         const xhalf* V0 = reinterpret_cast<const xhalf*>(p.vtpl + ((size_t)b * 3) * ls);
-        xattn_layer_x<true>(W, pw.as2pl[0], px.as2pl[0], X, PA, PB, K0, V0, kvd, p.p_pad, ks_p, -1, rowvalid, novalid_s, tid, u,
+        xattn_layer_x<true>(W, pw.as2pl[0], px.as2pl[0], X, PA, PB, K0, V0, kvd, nk_p, ks_p, -1, rowvalid, novalid_s, tid, u,
                             xlayer_first_x(W, pw.as2pl[1], px.as2pl[1], wave), LN + 3 * 768,
                             p.prof + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 32);
-        xattn_layer_x<true>(W, pw.as2pl[1], px.as2pl[1], X, PA, PB, K0 + 2 * ls, V0 + 2 * ls, kvd, p.p_pad, ks_p, -1, rowvalid, novalid_s, tid, u,
+        xattn_layer_x<true>(W, pw.as2pl[1], px.as2pl[1], X, PA, PB, K0 + 2 * ls, V0 + 2 * ls, kvd, nk_p, ks_p, -1, rowvalid, novalid_s, tid, u,
                             xlayer_first_x(W, pw.as2pl[2], px.as2pl[2], wave), LN + 4 * 768);
-        xattn_layer_x<true>(W, pw.as2pl[2], px.as2pl[2], X, PA, PB, K0 + 4 * ls, V0 + 4 * ls, kvd, p.p_pad, ks_p, -1, rowvalid, novalid_s, tid,
+        xattn_layer_x<true>(W, pw.as2pl[2], px.as2pl[2], X, PA, PB, K0 + 4 * ls, V0 + 4 * ls, kvd, nk_p, ks_p, -1, rowvalid, novalid_s, tid,
                             u, xlayer_first_x(W, pw.as2tl[0], px.as2tl[0], wave), LN + 5 * 768);
     }
     TB_STAMP(9);
     {
         const int g_tl = b * p.n_tl_hist + min(t1 - 1, p.n_tl_hist - 1);
         const float* kvd = p.kbias_tl + (size_t)g_tl * p.t_pad;
+        const int nk_t = p.nkey_tl[g_tl];
+        const int ks_t = ((rt * (nk_t >> 5)) / n_rt) << 5;
         const size_t ls = (size_t)p.t_pad * H;
         const xhalf* K0 = reinterpret_cast<const xhalf*>(p.ktl + ((size_t)g_tl * 3) * ls);
         const xhalf* V0 = reinterpret_cast<const xhalf*>(p.vttl + ((size_t)g_tl * 3) * ls);
-        xattn_layer_x<true>(W, pw.as2tl[0], px.as2tl[0], X, PA, PB, K0, V0, kvd, p.t_pad, ks_t, -1, rowvalid, novalid_s, tid, u,
+        xattn_layer_x<true>(W, pw.as2tl[0], px.as2tl[0], X, PA, PB, K0, V0, kvd, nk_t, ks_t, -1, rowvalid, novalid_s, tid, u,
                             xlayer_first_x(W, pw.as2tl[1], px.as2tl[1], wave), LN + 6 * 768);
-        xattn_layer_x<true>(W, pw.as2tl[1], px.as2tl[1], X, PA, PB, K0 + 2 * ls, V0 + 2 * ls, kvd, p.t_pad, ks_t, -1, rowvalid, novalid_s, tid, u,
+        xattn_layer_x<true>(W, pw.as2tl[1], px.as2tl[1], X, PA, PB, K0 + 2 * ls, V0 + 2 * ls, kvd, nk_t, ks_t, -1, rowvalid, novalid_s, tid, u,
                             xlayer_first_x(W, pw.as2tl[2], px.as2tl[2], wave), LN + 7 * 768);
-        xattn_layer_x<true>(W, pw.as2tl[2], px.as2tl[2], X, PA, PB, K0 + 4 * ls, V0 + 4 * ls, kvd, p.t_pad, ks_t, -1, rowvalid, novalid_s, tid,
+        xattn_layer_x<true>(W, pw.as2tl[2], px.as2tl[2], X, PA, PB, K0 + 4 * ls, V0 + 4 * ls, kvd, nk_t, ks_t, -1, rowvalid, novalid_s, tid,
                             u, wstdx(W, px.inter_kvf[0], W + px.inter_bkvf[0], wave), LN + 8 * 768);
     }
     TB_STAMP(10);
@@ -345,34 +349,70 @@ __global__ __launch_bounds__(NTHREADS) void k_step_x(RolloutP p, int t, int do_c
 
 // K/V of the three layers of a cross-attention block for fixed targets (map polylines, TL stop points), in the XDL operand
 // order (tb_device_xdl.hpp): the fp16-pair twin of k_kv_hoist.  grid = (n_pad/16, G)
+// The VALID targets of a group are compacted to the front (softmax is order independent): nkey[g] = their count rounded up to a
+// whole 32-key block (at least one), and the step kernel walks only that many keys -- 40 traffic-light slots of which a dozen are
+// lit cost one block instead of two, a 1024-slot map with 300 valid polylines ten blocks instead of 32.
 __global__ __launch_bounds__(NTHREADS) void k_kv_hoist_x(const float* __restrict__ W, XLayerW l0, XLayerW l1, XLayerW l2, XLayerX x0,
                                                         XLayerX x1, XLayerX x2, const float* __restrict__ feat,
                                                         const uint8_t* __restrict__ fvalid, int n_tok, int n_pad,
-                                                        float* __restrict__ Kout, float* __restrict__ VTout, float* __restrict__ kbias) {
+                                                        float* __restrict__ Kout, float* __restrict__ VTout, float* __restrict__ kbias,
+                                                        int* __restrict__ nkey) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* T = smem;
     xhalf* P1 = reinterpret_cast<xhalf*>(smem + TM * LDT);
+    __shared__ int slot[TM];
+    __shared__ int cnt_s[2];
     const int tid = threadIdx.x, wave = wave_of(tid), lane = tid & 63, g = blockIdx.y, tok0 = blockIdx.x * TM;
     const int n_real = max(0, min(TM, n_tok - tok0));
     WUnitX u;
     wloadx(u, kvproj_first_x(W, l0, x0, wave), lane);
     load_tile(T, LDT, feat + ((size_t)g * n_tok + tok0) * H, n_real, tid);
-    if (tid < TM)
-        kbias[(size_t)g * n_pad + tok0 + tid] = (tid < n_real && fvalid[(size_t)g * n_tok + tok0 + tid]) ? 0.f : -INFINITY;
+    // rank of this tile's tokens among the valid tokens of the group, and the group's valid count (wave 0, 64 tokens per pass)
+    if (wave == 0) {
+        int before = 0, total = 0;  // valid tokens in front of this tile / in the group
+        for (int base = 0; base < n_tok; base += 64) {
+            const int i = base + lane;
+            const bool v = i < n_tok && fvalid[(size_t)g * n_tok + i] != 0;
+            const unsigned long long mask = __ballot(v);
+            total += __popcll(mask);
+            if (base + 64 <= tok0) before += __popcll(mask);
+            else if (base < tok0) before += __popcll(mask & ((1ull << (tok0 - base)) - 1ull));
+            if (i >= tok0 && i < tok0 + TM) {
+                // valid tokens of this 64-chunk in front of token i, minus those that are in front of the tile (counted in `before` later)
+                const unsigned long long lower = mask & ((1ull << lane) - 1ull);
+                const int in_tile_before = __popcll(lower) - ((base < tok0) ? __popcll(mask & ((1ull << (tok0 - base)) - 1ull)) : 0);
+                slot[i - tok0] = v ? in_tile_before : -1;  // completed below with `before`
+            }
+        }
+        if (lane == 0) {
+            cnt_s[0] = before;
+            cnt_s[1] = total;
+        }
+    }
+    __syncthreads();
+    const int n_valid = cnt_s[1];
+    if (tid < TM) {
+        const int sl = slot[tid];
+        slot[tid] = (sl >= 0 && tid < n_real) ? sl + cnt_s[0] : -1;
+        kbias[(size_t)g * n_pad + tok0 + tid] = (tok0 + tid < n_valid) ? 0.f : -INFINITY;
+    }
+    if (tid == 0 && blockIdx.x == 0) nkey[g] = max(32, (n_valid + 31) & ~31);
     __syncthreads();
     const size_t ls = (size_t)n_pad * H;  // floats per (group, layer) = fp16 per plane
     xhalf* K0 = reinterpret_cast<xhalf*>(Kout + ((size_t)g * 3) * ls);
     xhalf* V0 = reinterpret_cast<xhalf*>(VTout + ((size_t)g * 3) * ls);
-    kv_project_tile_x(W, l0, x0, T, P1, K0, V0, n_pad, tok0, n_real, tid, u, kvproj_first_x(W, l1, x1, wave));
-    kv_project_tile_x(W, l1, x1, T, P1, K0 + 2 * ls, V0 + 2 * ls, n_pad, tok0, n_real, tid, u, kvproj_first_x(W, l2, x2, wave));
-    kv_project_tile_x(W, l2, x2, T, P1, K0 + 4 * ls, V0 + 4 * ls, n_pad, tok0, n_real, tid, u, kvproj_first_x(W, l2, x2, wave));
+    kv_project_tile_x(W, l0, x0, T, P1, K0, V0, n_pad, tok0, n_real, tid, u, kvproj_first_x(W, l1, x1, wave), nullptr, slot, n_valid);
+    kv_project_tile_x(W, l1, x1, T, P1, K0 + 2 * ls, V0 + 2 * ls, n_pad, tok0, n_real, tid, u, kvproj_first_x(W, l2, x2, wave), nullptr, slot,
+                      n_valid);
+    kv_project_tile_x(W, l2, x2, T, P1, K0 + 4 * ls, V0 + 4 * ls, n_pad, tok0, n_real, tid, u, kvproj_first_x(W, l2, x2, wave), nullptr, slot,
+                      n_valid);
 }
 
 void launch_kv_hoist_x(const float* W, const XLayerW* L3, const XLayerX* X3, const float* feat, const uint8_t* fvalid, int G, int n_tok,
-                       int n_pad, float* K, float* VT, float* kbias, hipStream_t s) {
+                       int n_pad, float* K, float* VT, float* kbias, int* nkey, hipStream_t s) {
     dim3 grid(n_pad / TM, G);
     hipLaunchKernelGGL(k_kv_hoist_x, grid, dim3(NTHREADS), TM * LDT * sizeof(float) + PLANES_BYTES, s, W, L3[0], L3[1], L3[2], X3[0],
-                       X3[1], X3[2], feat, fvalid, n_tok, n_pad, K, VT, kbias);
+                       X3[1], X3[2], feat, fvalid, n_tok, n_pad, K, VT, kbias, nkey);
 }
 
 hipError_t configure_stepx_kernel() {
