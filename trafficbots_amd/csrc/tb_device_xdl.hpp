@@ -560,6 +560,41 @@ __device__ __forceinline__ void kv_store_x(xhalf* __restrict__ Kf, xhalf* __rest
     kv_store_key_x(Kf, Vf, tok0 + (lane & 15), wave, lane, ak, av, real);
 }
 
+// The same layer when its target set has no valid key at all (a scene without a lit traffic light): every row is "all keys
+// invalid", the reference zeroes such a row's attention output after the out-projection, so x passes the attention
+// half unchanged and only x += FFN(LN2(x)) remains.  u = the FFN1 unit on entry.
+template <bool LNLDS = false>
+__device__ __forceinline__ void ffn_layer_x(const float* __restrict__ W, const XLayerW& L, const XLayerX& LX, float* X, xhalf* P1, xhalf* P2,
+                                            const uint8_t* rowvalid, int tid, WUnitX& u, const WNextX& nxt, const float* lnblk = nullptr) {
+    if (!LNLDS) lnblk = W + L.ln1_g;
+    const int wave = wave_of(tid), lane = tid & 63;
+    const int kq = lane >> 4, m = lane & 15;
+    const xhalf* b1 = P1 + m * LDP + kq * 8;
+    const xhalf* b2 = P2 + m * LDP + kq * 8;
+    WUnitX u2;
+    layernorm_planes<LNLDS>(X, LDT, P1, lnblk + 512, lnblk + 640, tid);
+    __syncthreads();
+    {
+        f32x4 acc[2] = {u.b[0], u.b[1]};
+        wmmax_pf(acc[0], acc[1], u, b1, PLANE, u2, wstdx(W, LX.w2, W + L.b2, wave), lane);
+        planes_store_c(P2, 2 * wave, lane, relu4(acc[0]));
+        planes_store_c(P2, 2 * wave + 1, lane, relu4(acc[1]));
+    }
+    __syncthreads();
+    {
+        f32x4 acc[2] = {u2.b[0], u2.b[1]};
+        wmmax_pf(acc[0], acc[1], u2, b2, PLANE, u, nxt, lane);
+        const bool rv = rowvalid[m] != 0;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            float* px = cptr(X, LDT, 2 * wave + t, lane);
+            const f32x4 xo = lds4(px);
+            st4(px, rv ? xo + acc[t] : splat(0.f));
+        }
+    }
+    __syncthreads();
+}
+
 // K/V projection of the tile's tokens for one layer (LN_tgt -> in_proj rows 128:384), outputs in XDL operand order.
 // slot != nullptr (compacting hoist): token m goes to key slot slot[m] (< 0: not stored) and the slots tok0 + m >= n_valid_keys
 // of this tile's own range are zero-filled (masked keys must still hold finite data: 0 x NaN would poison P V).

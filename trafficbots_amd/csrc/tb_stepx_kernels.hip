@@ -304,6 +304,9 @@ __global__ __launch_bounds__(NTHREADS) void k_step_x(RolloutP p, int t, int do_c
     if (t1 == p.tap_step && p.tap_agent_feature)
         store_tile(p.tap_agent_feature + ((size_t)n * p.n_agent + row0) * H, X, LDT, n_real, tid);
     TB_STAMP(8);
+    const int g_tl = b * p.n_tl_hist + min(t1 - 1, p.n_tl_hist - 1);
+    // no lit traffic light at this step (valid keys are compacted to the front, so slot 0 tells): as2tl keeps only its FFN halves
+    const bool tl_empty = p.kbias_tl[(size_t)g_tl * p.t_pad] == -INFINITY;
     {
         const float* kvd = p.kbias_pl + (size_t)b * p.p_pad;
         const int nk_p = p.nkey_pl[b];  // valid polylines, compacted to the front by the hoist, rounded up to whole key blocks
@@ -320,8 +323,14 @@ __global__ __launch_bounds__(NTHREADS) void k_step_x(RolloutP p, int t, int do_c
                             u, xlayer_first_x(W, pw.as2tl[0], px.as2tl[0], wave), LN + 5 * 768);
     }
     TB_STAMP(9);
-    {
-        const int g_tl = b * p.n_tl_hist + min(t1 - 1, p.n_tl_hist - 1);
+    if (tl_empty) {
+        // (the Q unit requested above is dropped; one exposed unit load here keeps the common path free of any select)
+        wloadx(u, wstdx(W, px.as2tl[0].w1, W + pw.as2tl[0].b1, wave), lane);
+        ffn_layer_x<true>(W, pw.as2tl[0], px.as2tl[0], X, PA, PB, rowvalid, tid, u, wstdx(W, px.as2tl[1].w1, W + pw.as2tl[1].b1, wave), LN + 6 * 768);
+        ffn_layer_x<true>(W, pw.as2tl[1], px.as2tl[1], X, PA, PB, rowvalid, tid, u, wstdx(W, px.as2tl[2].w1, W + pw.as2tl[2].b1, wave), LN + 7 * 768);
+        ffn_layer_x<true>(W, pw.as2tl[2], px.as2tl[2], X, PA, PB, rowvalid, tid, u, wstdx(W, px.inter_kvf[0], W + px.inter_bkvf[0], wave),
+                          LN + 8 * 768);
+    } else {
         const float* kvd = p.kbias_tl + (size_t)g_tl * p.t_pad;
         const int nk_t = p.nkey_tl[g_tl];
         const int ks_t = ((rt * (nk_t >> 5)) / n_rt) << 5;
