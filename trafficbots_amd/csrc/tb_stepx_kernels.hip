@@ -143,7 +143,6 @@ __global__ __launch_bounds__(NTHREADS) void k_step_x(RolloutP p, int t, int do_c
     const size_t base_row = (size_t)n * p.a_pad + row0;
     // staggered start of the key walks of the row tiles of one instance (attention_prefetch_x)
     const int n_rt = gridDim.x;
-    const int ks_a = ((rt * (p.a_pad >> 5)) / n_rt) << 5;
 
     WUnitX u;
     TB_STAMP(0);
@@ -189,10 +188,18 @@ __global__ __launch_bounds__(NTHREADS) void k_step_x(RolloutP p, int t, int do_c
 
     if (do_c) {
         // =================================== C(t) ===================================
-        int n_valid = 0;
+        int n_valid = 0, hi_valid = 0;  // number of valid agents of the instance / one past the last valid one
 #pragma unroll
-        for (int i = 0; i < 4; ++i) n_valid += __popcll(__ballot(vb[i] != 0));
+        for (int i = 0; i < 4; ++i) {
+            const unsigned long long vm = __ballot(vb[i] != 0);
+            n_valid += __popcll(vm);
+            if (vm) hi_valid = i * 64 + 64 - __clzll(vm);
+        }
         const bool bypass = n_valid == 1;  // agent_interaction.py:61
+        // keys past the last valid agent are all masked: the interaction walks only the key blocks in front of it (exact; real
+        // scenes keep their valid agents in the leading slots)
+        const int nk_a = min(p.a_pad, max(32, (hi_valid + 31) & ~31));
+        const int ks_a = ((rt * (nk_a >> 5)) / n_rt) << 5;
         c_inputs_commit<NTHREADS>(tid, cin, X, Hs, H1, H2, GP, LP, DG, dflag);
 #pragma unroll
         for (int sl = 0; sl < 9; ++sl)
@@ -205,11 +212,11 @@ __global__ __launch_bounds__(NTHREADS) void k_step_x(RolloutP p, int t, int do_c
             const size_t ls = (size_t)p.a_pad * H;
             const xhalf* K0 = reinterpret_cast<const xhalf*>(p.kin + ((size_t)n * 3) * ls);
             const xhalf* V0 = reinterpret_cast<const xhalf*>(p.vtin + ((size_t)n * 3) * ls);
-            xattn_layer_x<true, true>(W, pw.inter[0], px.inter[0], X, PA, PB, K0, V0, kvd, p.a_pad, ks_a, row0, rowvalid, novalid_s, tid, u,
+            xattn_layer_x<true, true>(W, pw.inter[0], px.inter[0], X, PA, PB, K0, V0, kvd, nk_a, ks_a, row0, rowvalid, novalid_s, tid, u,
                                 xlayer_first_x(W, pw.inter[1], px.inter[1], wave), LN + 0 * 768);
-            xattn_layer_x<true, true>(W, pw.inter[1], px.inter[1], X, PA, PB, K0 + 2 * ls, V0 + 2 * ls, kvd, p.a_pad, ks_a, row0, rowvalid, novalid_s, tid,
+            xattn_layer_x<true, true>(W, pw.inter[1], px.inter[1], X, PA, PB, K0 + 2 * ls, V0 + 2 * ls, kvd, nk_a, ks_a, row0, rowvalid, novalid_s, tid,
                                 u, xlayer_first_x(W, pw.inter[2], px.inter[2], wave), LN + 1 * 768);
-            xattn_layer_x<true, true>(W, pw.inter[2], px.inter[2], X, PA, PB, K0 + 4 * ls, V0 + 4 * ls, kvd, p.a_pad, ks_a, row0, rowvalid,
+            xattn_layer_x<true, true>(W, pw.inter[2], px.inter[2], X, PA, PB, K0 + 4 * ls, V0 + 4 * ls, kvd, nk_a, ks_a, row0, rowvalid,
                                 novalid_s, tid, u, gru_first_x(W, pw.gru[0], px.gru[0], wave), LN + 2 * 768);
         }
         TB_STAMP(2);
