@@ -28,21 +28,22 @@ H = 128
 PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak
 # fabric-side bytes per fused launch from the PMC pass of this round (profiles/r01_rocprof_xdl.txt: FETCH_SIZE 41 061 KiB x 2, the
 # gfx950 correction of the guide, at the headline shape); collected with rocprofv3 --pmc in its own run, not at bench time
-TRAFFIC_BYTES_PER_LAUNCH_B32 = 2 * 40412 * 1024
+TRAFFIC_BYTES_PER_LAUNCH_B32 = 2 * 38862 * 1024
 
 
 def flops_step_a(a, p, t):  # SURVEY 8(d) split: as2pl + as2tl + interaction K/V projections + agent encoder
     return 60 * a * H * H + 12 * a * H * (p + t) + 2 * a * (11 * 32 + 32 * 32)
 
 
-def load_path(k_us):
+def load_path(k_us, n_tl_keys=None):
     """Bytes every workgroup pulls through its CU's vector-memory path per fused launch (weights are streamed once per
     16-agent tile, K/V once per head) against the ~64 B/clk/CU the L1 can fill (MI355X_MICROARCH.md: L2 34.5 TB/s / 256 CUs)."""
     h = 128
     w_bytes = 65 * h * h * 4          # 67 H^2 weights of the path, 4 B each as an fp16 pair, minus the two constant half-Linears of
                                       # add_goal / add_latent that the rollout prologue hoists (k_fuse_hoist_x)
     pad = lambda n: (n + 31) // 32 * 32
-    kv_bytes = 3 * 2 * (pad(N_PL) + pad(N_TL) + pad(N_AGENT)) * h * 4
+    # (the hoist compacts the valid targets: the step walks pad32(valid) keys; all polylines / agents of the synthetic scenes are valid)
+    kv_bytes = 3 * 2 * (pad(N_PL) + (pad(N_TL) if n_tl_keys is None else n_tl_keys) + pad(N_AGENT)) * h * 4
     clk = 2.1e9                       # s_memtime ticks per second observed on this kernel
     per_clk = (w_bytes + kv_bytes) / (k_us * 1e-6 * clk)
     return {"bytes_per_workgroup_launch": w_bytes + kv_bytes, "weights": w_bytes, "kv": kv_bytes, "achieved_B_per_clk_per_CU": per_clk,
@@ -200,6 +201,9 @@ def main():
 
     gc.collect()
     gc.disable()
+    # keys of the traffic-light attention the step kernel actually walks: valid stop points per (scene, history step), whole blocks
+    tl_cnt = scene["tl_valid"].sum(-1).float()
+    tl_keys_eff = float(torch.clamp(torch.ceil(tl_cnt / 32) * 32, min=32).mean())
     out = None
     for _ in range(args.warmup):
         out = eng.rollout(scene, feats, z, enc["latent_mean"], dest, gv, 1, STEP_END, out=out)
@@ -304,7 +308,7 @@ def main():
                                  "the fp32-MFMA peak of the fp32 formulation; the kernel issues them as 3 fp16 MFMAs per product on the XDL "
                                  "pipe (fp32-accurate, DESIGN.md 4) and is bound by the per-CU vector-load path, see load_path; 128 "
                                  "workgroups (one per 16 agents) occupy 128 of 256 CUs at this batch size",
-                         "load_path": load_path(k_us),
+                         "load_path": load_path(k_us, tl_keys_eff),
                          "hbm": {"achieved": TRAFFIC_BYTES_PER_LAUNCH_B32 / (k_us * 1e-6) / 1e9, "peak": 8000.0, "unit": "GB/s",
                                  "frac": TRAFFIC_BYTES_PER_LAUNCH_B32 / (k_us * 1e-6) / 1e9 / 8000.0,
                                  "note": "measured FETCH bytes per launch / launch time: the launch is not HBM-bound"}
