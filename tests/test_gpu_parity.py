@@ -614,6 +614,29 @@ def test_training_step_forward_against_oracle(rollout_prior):
     assert out["loss"] == got["training/loss"]
 
 
+def test_row_tiles_of_an_instance_may_run_apart():
+    """720 workgroups of 6 row tiles per instance (80 agents -> a_pad 96) do not fit the chip at once and 6 does not divide the 32 CUs of
+    an XCD, so some instances have their tiles in different dispatch waves: a tile then runs its C(t) long after a sibling finished
+    A(t+1).  The interaction K / V and the validity bytes the tiles exchange are double-buffered by step parity for exactly this case
+    (tb_rollout.hpp); with one buffer this test differs by centimetres.  Results must equal those of the same scenes run 4 at a time."""
+    from trafficbots_amd import synth
+
+    a, p_, b, k, s_end = 80, 64, 40, 3, 20
+    wm = _engine({"time_step_end": s_end, "n_joint_future": k}, synth.make_state_dict(11))
+    batch = synth.make_batch(4200, b, n_agent=a, n_pl=p_, n_tl=8, p_late_spawn=0.2, p_invalid_agent=0.1)
+    eps = synth.make_latent_noise(4201, b * k, a)
+    big = wm.test_step(batch, latent_eps=torch.from_numpy(eps).cuda(), generator=torch.Generator(device="cuda").manual_seed(5))
+    torch.cuda.synchronize()
+    gs = big["goal_sample"]
+    for b0 in (0, 12, 24, 28):  # (with this shape the straddling instances are 40..47 and 80..87: scenes 13..15 and 26..29)
+        sub = {key: v[b0:b0 + 4] for key, v in batch.items()}
+        e = eps.reshape(b, k, a, -1)[b0:b0 + 4].reshape(4 * k, a, -1)
+        small = wm.test_step(sub, latent_eps=torch.from_numpy(e).cuda(), goal_sample=gs[b0:b0 + 4].transpose(1, 2).contiguous())
+        torch.cuda.synchronize()
+        assert torch.equal(small["rollout_buffer"].valid, big["rollout_buffer"].valid[b0:b0 + 4])
+        assert torch.equal(small["rollout_buffer"].preds, big["rollout_buffer"].preds[b0:b0 + 4]), b0
+
+
 def test_empty_and_bad_inputs_fail_loudly():
     from trafficbots_amd import synth
     from trafficbots_amd.waymo_motion import WaymoMotion

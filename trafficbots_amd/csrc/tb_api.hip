@@ -271,7 +271,9 @@ void tb_struct_sizes(int32_t out[9]) {
 
 const char* tb_version(void) { return "trafficbots_hip 0.2 (gfx950, fp16-pair XDL MFMA 16x16x32 with fp32 accumulate; fp32 MFMA 16x16x4 kernels selectable)"; }
 
-static void step_launch(const tb_ctx* ctx, const tb::RolloutP& p, int t, int do_c, int do_a, hipStream_t s) {
+static void step_launch(const tb_ctx* ctx, const tb::RolloutP& p0, int t, int do_c, int do_a, hipStream_t s) {
+    tb::RolloutP p = p0;
+    tb::set_parity(p, t);  // launch t reads the cross-tile buffers of parity t & 1 and writes the other pair (tb_rollout.hpp)
     if (ctx->step_kernel == 3)
         tb::xb::launch_step_x(p, t, do_c, do_a, s);
     else if (ctx->step_kernel == 2)
@@ -598,16 +600,21 @@ static void carve_rollout(tb::RolloutP& p, Carver& c) {
     p.nkey_tl = c.take<int>(B * NH);
     p.state = c.take<float>(N * p.a_pad * 4);
     p.aux = c.take<float>(N * p.a_pad * 4);
-    p.valid = c.take<uint8_t>(N * p.a_pad);
-    p.vbias = c.take<float>(N * p.a_pad);
+    for (int k = 0; k < 2; ++k) {
+        p.valid_b[k] = c.take<uint8_t>(N * p.a_pad);
+        p.vbias_b[k] = c.take<float>(N * p.a_pad);
+    }
     p.killed = c.take<uint8_t>(N * p.a_pad);
     p.goal_valid = c.take<uint8_t>(N * p.a_pad);
     p.dest_reached = c.take<uint8_t>(N * p.a_pad);
     p.outside = c.take<uint8_t>(N * p.a_pad);
     p.hidden = c.take<float>(3 * N * p.a_pad * 128);
     p.x_mid = c.take<float>(N * p.a_pad * 128);
-    p.kin = c.take<float>(N * 3 * p.a_pad * 128);
-    p.vtin = c.take<float>(N * 3 * 128 * p.a_pad);
+    for (int k = 0; k < 2; ++k) {
+        p.kin_b[k] = c.take<float>(N * 3 * p.a_pad * 128);
+        p.vtin_b[k] = c.take<float>(N * 3 * 128 * p.a_pad);
+    }
+    tb::set_parity(p, 0);
     p.goal_pre = c.take<float>(N * p.a_pad * 128);
     p.lat_pre = c.take<float>(N * p.a_pad * 128);
     p.dest_geo = c.take<float>(N * p.a_pad * 80);
@@ -742,7 +749,11 @@ extern "C" int tb_rollout(tb_ctx* ctx, const tb_rollout_io* io, tb_stream stream
     ctx->n_timed_steps = ctx->timing ? n_launch : 0;
     // ---- final simulator state
     if (io->final_state || io->final_valid || io->final_hidden)
-        tb::launch_rollout_final(p, io->final_state, io->final_valid, io->final_hidden, s);
+    {
+        tb::RolloutP pf = p;
+        tb::set_parity(pf, step_start + n_steps);  // validity after the last step = what launch t = step_end wrote
+        tb::launch_rollout_final(pf, io->final_state, io->final_valid, io->final_hidden, s);
+    }
     TB_HIP(ctx, hipGetLastError());
     return 0;
 }
@@ -839,7 +850,9 @@ extern "C" int tb_rollout_step(tb_ctx* ctx, tb_stream stream_) {
 extern "C" int tb_rollout_state(tb_ctx* ctx, float* state, uint8_t* valid, float* hidden, tb_stream stream_) {
     if (!ctx) return 1;
     if (!ctx->step_active) return tb_fail(ctx, "tb_rollout_state: no rollout in progress");
-    tb::launch_rollout_final(ctx->step_p, state, valid, hidden, (hipStream_t)stream_);
+    tb::RolloutP pf = ctx->step_p;
+    tb::set_parity(pf, ctx->step_next);  // the last launch ran t = step_next - 1 and wrote parity (t + 1) & 1
+    tb::launch_rollout_final(pf, state, valid, hidden, (hipStream_t)stream_);
     TB_HIP(ctx, hipGetLastError());
     return 0;
 }

@@ -85,8 +85,20 @@ struct RolloutP {
     // simulator state (workspace)
     float* state;                 // [N,a_pad,4]
     float* aux;                   // [N,a_pad,4]  vel_x, vel_y, acc, yaw_rate as last teacher-forced
+    // The four arrays through which the row tiles of an instance see EACH OTHER (validity of all agents, interaction K / V) are
+    // double-buffered by step parity: launch t reads what launch t-1 wrote (valid / vbias / kin / vtin = buffer t & 1) and writes
+    // buffer (t + 1) & 1 (*_w), so a tile that runs late inside a launch -- second dispatch wave, another stream's kernel on the
+    // chip -- never reads a sibling's step-t+1 data in its step-t interaction.  Everything else is read and written by its own tile only.
     uint8_t* valid;               // [N,a_pad]
     float* vbias;                 // [N,a_pad]  same as `valid` as additive key mask for the interaction
+    uint8_t* valid_w;
+    float* vbias_w;
+    float* kin_w;                 // [N,3,a_pad,128]
+    float* vtin_w;                // [N,3,128,a_pad]
+    uint8_t* valid_b[2];          // the two buffers of each (host side: step_launch picks by parity)
+    float* vbias_b[2];
+    float* kin_b[2];
+    float* vtin_b[2];
     uint8_t* killed;
     uint8_t* goal_valid;
     uint8_t* dest_reached;
@@ -116,5 +128,12 @@ struct RolloutP {
     float* tap_policy_feature;    // [N,A,128]
     float* tap_agent_feature;     // [N,A,128]
 };
+
+// reads from the buffers of parity t & 1, writes to the others
+inline void set_parity(RolloutP& p, int t) {
+    const int r = t & 1, w = r ^ 1;
+    p.valid = p.valid_b[r]; p.vbias = p.vbias_b[r]; p.kin = p.kin_b[r]; p.vtin = p.vtin_b[r];
+    p.valid_w = p.valid_b[w]; p.vbias_w = p.vbias_b[w]; p.kin_w = p.kin_b[w]; p.vtin_w = p.vtin_b[w];
+}
 
 }  // namespace tb

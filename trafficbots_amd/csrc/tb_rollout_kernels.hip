@@ -75,8 +75,10 @@ __global__ __launch_bounds__(NTHREADS) void k_rollout_init(RolloutP p) {
         }
         st4(p.state + si * 4, st);
         st4(p.aux + si * 4, ax);
-        p.valid[si] = v;
+        p.valid[si] = v;  // both parities: the first launch (A half only) reads one and leaves the other to C(step_start)
         p.vbias[si] = v ? 0.f : -INFINITY;
+        p.valid_w[si] = v;
+        p.vbias_w[si] = v ? 0.f : -INFINITY;
         p.killed[si] = 0;
         p.goal_valid[si] = gv;
         p.dest_reached[si] = 0;
@@ -447,8 +449,8 @@ __global__ __launch_bounds__(NTHREADS) void k_step(RolloutP p, int t, int do_c, 
     store_tile(p.x_mid + base_row * H, X, LDT, TM, tid);
     {
         const size_t ls = (size_t)p.a_pad * H;
-        float* K0 = p.kin + ((size_t)n * 3) * ls;
-        float* V0 = p.vtin + ((size_t)n * 3) * ls;
+        float* K0 = p.kin_w + ((size_t)n * 3) * ls;
+        float* V0 = p.vtin_w + ((size_t)n * 3) * ls;
         kv_project_tile<true>(W, pw.inter[0], X, S1, K0, V0, p.a_pad, row0, TM, tid, u, kvproj_first(W, pw.inter[1], wave), LN + 0 * 768);
         kv_project_tile<true>(W, pw.inter[1], X, S1, K0 + ls, V0 + ls, p.a_pad, row0, TM, tid, u, kvproj_first(W, pw.inter[2], wave), LN + 1 * 768);
         kv_project_tile<true>(W, pw.inter[2], X, S1, K0 + 2 * ls, V0 + 2 * ls, p.a_pad, row0, TM, tid, u, kvproj_first(W, pw.inter[2], wave),

@@ -225,8 +225,8 @@ __global__ __launch_bounds__(NTHREADS8) void k_step8(RolloutP p, int t, int do_c
     store_tile8(p.x_mid + base_row * H, X, LDT, TM, tid);
     {
         const size_t ls = (size_t)p.a_pad * H;
-        float* K0 = p.kin + ((size_t)n * 3) * ls;
-        float* V0 = p.vtin + ((size_t)n * 3) * ls;
+        float* K0 = p.kin_w + ((size_t)n * 3) * ls;
+        float* V0 = p.vtin_w + ((size_t)n * 3) * ls;
         kv_project_tile8<true>(W, pw.inter[0], X, S1, K0, V0, p.a_pad, row0, TM, tid, u, kvproj_first8(W, pw.inter[1], wave), LN + 0 * 768);
         kv_project_tile8<true>(W, pw.inter[1], X, S1, K0 + ls, V0 + ls, p.a_pad, row0, TM, tid, u, kvproj_first8(W, pw.inter[2], wave),
                                LN + 1 * 768);

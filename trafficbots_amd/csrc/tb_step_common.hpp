@@ -241,8 +241,8 @@ __device__ __forceinline__ void step_epilogue(const RolloutP& p, int t, int n, i
         const bool gv = (gvalid[tid] != 0) && valid && !dreached;
         // simulator state: global (the next launch's interaction reads `valid` of every agent) + LDS (A half below)
         st4(p.state + si * 4, cur);
-        p.valid[si] = valid;
-        p.vbias[si] = valid ? 0.f : -INFINITY;
+        p.valid_w[si] = valid;
+        p.vbias_w[si] = valid ? 0.f : -INFINITY;
         p.killed[si] = killed;
         p.goal_valid[si] = gv;
         p.dest_reached[si] = dreached;
@@ -370,8 +370,8 @@ __device__ __forceinline__ void step_epilogue16(const RolloutP& p, int t, int n,
             rst[a].aux[0] = hax.x; rst[a].aux[1] = hax.y; rst[a].aux[2] = hax.z; rst[a].aux[3] = hax.w;
         }
         st4(p.state + si * 4, cur);
-        p.valid[si] = valid;
-        p.vbias[si] = valid ? 0.f : -INFINITY;
+        p.valid_w[si] = valid;
+        p.vbias_w[si] = valid ? 0.f : -INFINITY;
         p.killed[si] = killed;
         p.goal_valid[si] = gv;
         p.dest_reached[si] = dreached;

@@ -145,6 +145,12 @@ __global__ __launch_bounds__(NTHREADS) void k_step_x(RolloutP p, int t, int do_c
     const int n_rt = gridDim.x;
 
     WUnitX u;
+#ifdef TB_DEBUG_LATE_TILE  // experiment: row tile 1 of every instance starts ~200 us after its siblings
+    if (rt == 1) {
+        const long long t0 = clock64();
+        while (clock64() - t0 < 450000) __builtin_amdgcn_s_sleep(64);
+    }
+#endif
     TB_STAMP(0);
     // ---- launch start: EVERY load of the prologue is issued before the first result is consumed (one cold round trip
     // instead of four): first weight unit, LayerNorm parameter blocks, row state, validity bytes, the C-half tile inputs.
@@ -355,8 +361,8 @@ __global__ __launch_bounds__(NTHREADS) void k_step_x(RolloutP p, int t, int do_c
     store_tile(p.x_mid + base_row * H, X, LDT, TM, tid);
     {
         const size_t ls = (size_t)p.a_pad * H;
-        xhalf* K0 = reinterpret_cast<xhalf*>(p.kin + ((size_t)n * 3) * ls);
-        xhalf* V0 = reinterpret_cast<xhalf*>(p.vtin + ((size_t)n * 3) * ls);
+        xhalf* K0 = reinterpret_cast<xhalf*>(p.kin_w + ((size_t)n * 3) * ls);
+        xhalf* V0 = reinterpret_cast<xhalf*>(p.vtin_w + ((size_t)n * 3) * ls);
         // (the last unit request points at a valid unit that nobody consumes: the launch ends here)
         kv_project_shared_x(W, px.inter_kvf, px.inter_bkvf, X, PA, K0, V0, ls, row0, TM, tid, u, wstdx(W, px.inter_kvf[0], W + px.inter_bkvf[0], wave));
     }
