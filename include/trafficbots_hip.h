@@ -114,6 +114,13 @@ typedef struct tb_rollout_io {
     /* nonzero: latent_sample / latent_mean come from the POSTERIOR (reactive_replay, waymo_motion.py:597-611), so
      * latent_log_prob uses latent_post_dist.log_std instead of latent_prior_dist.log_std */
     int32_t latent_posterior;
+    /* W > 0: the caller guarantees that for every step t <= W (t < n_hist) each agent that is valid in agent_valid[:, t] is
+     * teacher-forced (mask_teacher_forcing[:, t] set) and that no agent turns from valid to invalid within steps 0..W (the
+     * default warm start, TeacherForcing.step_warm_start = time_step_current, on histories without early exits).  Then the
+     * simulator state after each of those steps IS the ground truth of that step and the map / traffic-light attention half of
+     * the steps up to W + 1 does not depend on the rollout: it is run as one batched launch that fills the chip.  Results are
+     * bit-identical to W = 0, which is always allowed. */
+    int32_t warm_start_steps;
 } tb_rollout_io;
 
 /* Replaces: WaymoMotion.rollout (+ per-step WaymoMotion.forward, TrafficBots.forward, ActionHead,

@@ -614,6 +614,40 @@ def test_training_step_forward_against_oracle(rollout_prior):
     assert out["loss"] == got["training/loss"]
 
 
+@pytest.mark.parametrize("shape", [dict(n_agent=64, n_pl=256, n_tl=40), dict(n_agent=20, n_pl=33, n_tl=5, p_late_spawn=0.4, p_invalid_agent=0.2)])
+def test_batched_warm_start_is_bit_identical(shape):
+    """tb_rollout_io.warm_start_steps: the map / traffic-light attention halves of the teacher-forced steps run as one batched launch
+    from the ground truth; every output must equal the step-by-step rollout bit for bit (late spawns included; histories with
+    early exits are not eligible and never get the flag from the host mirror)."""
+    from trafficbots_amd import synth
+    from trafficbots_amd.config import load_model_config
+    from trafficbots_amd.runtime import HipEngine, scene_from_batch
+
+    cfg = load_model_config(overrides={"time_step_end": 30, "n_joint_future": 2})
+    eng = HipEngine(cfg, "cuda:0")
+    eng.load_state_dict(synth.make_state_dict(21))
+    batch = synth.make_batch(4400, 6, **shape)
+    s = scene_from_batch(batch, torch.device("cuda:0"))
+    assert s["warm_ok"]
+    enc = eng.encode_scene(s)
+    feats = {"map_feature": enc["map_feature"], "map_feature_valid": enc["map_feature_valid"], "tl_feature": enc["tl_feature"]}
+    a = shape["n_agent"]
+    z = enc["latent_mean"].repeat_interleave(2, 0) + 0.3 * torch.from_numpy(synth.make_latent_noise(4401, 12, a)).cuda()
+    dest = enc["dest_logits"].argmax(-1).to(torch.int32).repeat_interleave(2, 0)
+    gv = s["agent_valid"].bool().any(1).to(torch.uint8).repeat_interleave(2, 0)
+    outs = []
+    for w in (-1, 10, 4):  # -1: explicitly off (0 would let the engine derive it from the scene)
+        s2 = dict(s, warm_ok=False) if w < 0 else s
+        o = eng.rollout(s2, feats, z, enc["latent_mean"], dest, gv, 2, 30, warm_start_steps=max(w, 0), tap_step=3)
+        torch.cuda.synchronize()
+        outs.append({k: v.clone() for k, v in o.items() if torch.is_tensor(v)})
+    for other in outs[1:]:
+        for k, v in outs[0].items():
+            assert torch.equal(v, other[k]), k
+    # a history with an early exit is flagged not eligible by the host
+    assert not scene_from_batch(synth.make_batch(4402, 4, n_agent=16, n_pl=20, p_early_exit=0.9), torch.device("cuda:0"))["warm_ok"]
+
+
 def test_row_tiles_of_an_instance_may_run_apart():
     """720 workgroups of 6 row tiles per instance (80 agents -> a_pad 96) do not fit the chip at once and 6 does not divide the 32 CUs of
     an XCD, so some instances have their tiles in different dispatch waves: a tile then runs its C(t) long after a sibling finished

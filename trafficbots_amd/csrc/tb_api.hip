@@ -28,6 +28,7 @@ hipError_t configure_step8_kernel();
     void launch_step_x(const RolloutP& p, int t, int do_c, int do_a, hipStream_t s);                                              \
     hipError_t configure_stepx_kernel();                                                                                          \
     void launch_fuse_hoist_x(const RolloutP& p, hipStream_t s);                                                                   \
+    void launch_step_pre_x(const RolloutP& p, int t0, int n, hipStream_t s);                                                      \
     void launch_kv_hoist_x(const float* W, const XLayerW* L3, const XLayerX* X3, const float* feat, const uint8_t* fvalid, int G, \
                            int n_tok, int n_pad, float* K, float* VT, float* kbias, int* nkey, hipStream_t s);                    \
     }
@@ -271,9 +272,16 @@ void tb_struct_sizes(int32_t out[9]) {
 
 const char* tb_version(void) { return "trafficbots_hip 0.2 (gfx950, fp16-pair XDL MFMA 16x16x32 with fp32 accumulate; fp32 MFMA 16x16x4 kernels selectable)"; }
 
-static void step_launch(const tb_ctx* ctx, const tb::RolloutP& p0, int t, int do_c, int do_a, hipStream_t s) {
-    tb::RolloutP p = p0;
+// `rd` supplies what C(t) reads (normally the same struct as `wr`; the batched warm start substitutes its slices), `wr` what
+// the launch writes
+static void step_launch(const tb_ctx* ctx, const tb::RolloutP& rd, const tb::RolloutP& wr, int t, int do_c, int do_a, hipStream_t s) {
+    tb::RolloutP p = rd;
     tb::set_parity(p, t);  // launch t reads the cross-tile buffers of parity t & 1 and writes the other pair (tb_rollout.hpp)
+    {
+        tb::RolloutP w = wr;
+        tb::set_parity(w, t);
+        p.valid_w = w.valid_w; p.vbias_w = w.vbias_w; p.kin_w = w.kin_w; p.vtin_w = w.vtin_w; p.x_mid_w = w.x_mid_w;
+    }
     if (ctx->step_kernel == 3)
         tb::xb::launch_step_x(p, t, do_c, do_a, s);
     else if (ctx->step_kernel == 2)
@@ -556,16 +564,19 @@ int tb_get_timing(tb_ctx* ctx, float* out4) {
     float ms = 0.f;
     TB_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));
     out4[2] = ms;
-    // launch 0 = A(1) alone, launches 1..n-2 = fused C(t)+A(t+1), launch n-1 = C(S) alone
-    TB_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev[1], ctx->ev[2]));
-    out4[1] += ms;
-    TB_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev[n], ctx->ev[n + 1]));
-    out4[1] += ms;
-    for (int i = 1; i + 1 < n; ++i) {
+    // per launch: 2 = fused C(t)+A(t+1), 1 = one half only (A(1) alone, C(S) alone, the C-only steps of a batched warm start --
+    // whose batched A launch is charged to the first of them), 0 = nothing launched
+    int n_fused = 0;
+    for (int i = 0; i < n; ++i) {
         TB_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev[1 + i], ctx->ev[2 + i]));
-        out4[0] += ms;
+        if (ctx->launch_kind[i] == 2) {
+            out4[0] += ms;
+            ++n_fused;
+        } else {
+            out4[1] += ms;
+        }
     }
-    out4[3] = (float)(n - 2);
+    out4[3] = (float)n_fused;
     return 0;
 }
 
@@ -610,6 +621,13 @@ static void carve_rollout(tb::RolloutP& p, Carver& c) {
     p.outside = c.take<uint8_t>(N * p.a_pad);
     p.hidden = c.take<float>(3 * N * p.a_pad * 128);
     p.x_mid = c.take<float>(N * p.a_pad * 128);
+    p.x_mid_w = p.x_mid;
+    if (p.pre_t0 > 0) {  // (pre_t0 doubles as the number of batched warm-start slices while the workspace is carved)
+        const size_t n_pre = (size_t)p.pre_t0;
+        p.x_mid_pre = c.take<float>(n_pre * N * p.a_pad * 128);
+        p.kin_pre = c.take<float>(n_pre * N * 3 * p.a_pad * 128);
+        p.vtin_pre = c.take<float>(n_pre * N * 3 * 128 * p.a_pad);
+    }
     for (int k = 0; k < 2; ++k) {
         p.kin_b[k] = c.take<float>(N * 3 * p.a_pad * 128);
         p.vtin_b[k] = c.take<float>(N * 3 * 128 * p.a_pad);
@@ -691,11 +709,20 @@ static int rollout_setup(tb_ctx* ctx, const tb_rollout_io* io, tb::RolloutP& p) 
                               p.o_dest_reached_this, p.o_action_logp, p.o_latent_logp};
     for (const void* q : required)
         if (!q) return tb_fail(ctx, "tb_rollout: a required buffer pointer is NULL");
+    // batched warm start (XDL kernels only): A halves of steps step_start .. Wp + 1, Wp = min(W, n_hist - 1, step_end - 1)
+    int n_pre = 0;
+    if (ctx->step_kernel >= 2 && io->warm_start_steps > 0) {
+        const int wp = std::min(std::min(io->warm_start_steps, io->n_hist - 1), io->step_end - 1);
+        n_pre = std::max(0, wp - (step_start - 1) + 1);
+    }
+    p.pre_t0 = n_pre;  // (carve_rollout reads the slice count here)
     Carver sizing{nullptr};
     carve_rollout(p, sizing);
     if (tb_ensure_workspace(ctx, sizing.off + 256)) return 1;
     Carver c{ctx->d_ws};
     carve_rollout(p, c);
+    p.pre_t0 = 0;
+    ctx->n_pre = n_pre;
     ctx->last_prof = p.prof;
     return 0;
 }
@@ -740,10 +767,28 @@ extern "C" int tb_rollout(tb_ctx* ctx, const tb_rollout_io* io, tb_stream stream
     }
     rollout_prologue(ctx, p, io, s);
     if (ctx->timing) TB_HIP(ctx, hipEventRecord(ctx->ev[1], s));
+    // ---- batched warm start: the A halves of steps t = step_start-1 .. step_start-1+n_pre-1 in one launch (tb_rollout_io.warm_start_steps)
+    const int n_pre = ctx->n_pre;
+    const int t_pre0 = step_start - 1;
+    if (n_pre > 0) {
+        if (ctx->step_kernel == 3) tb::xb::launch_step_pre_x(p, t_pre0, n_pre, s);
+        else tb::xh::launch_step_pre_x(p, t_pre0, n_pre, s);
+    }
     // ---- the sequential loop (waymo_motion.py:269): launch i runs C(start+i-1) then A(start+i); no host sync
+    ctx->launch_kind.assign(n_launch, 0);
     for (int i = 0; i < n_launch; ++i) {
         const int t = step_start + i - 1;
-        step_launch(ctx, p, t, /*do_c=*/i > 0, /*do_a=*/i < n_steps, s);
+        int do_c = i > 0, do_a = i < n_steps;
+        tb::RolloutP q = p;
+        if (t - t_pre0 < n_pre) do_a = 0;                  // A(t+1) came out of the batched launch
+        if (do_c && t - 1 - t_pre0 < n_pre && t - 1 >= t_pre0) {  // C(t) consumes slice t-1-t_pre0 of the batched results
+            const size_t z = (size_t)(t - 1 - t_pre0) * p.n_inst * p.a_pad * 128;
+            q.x_mid = p.x_mid_pre + z;
+            q.kin_b[0] = q.kin_b[1] = p.kin_pre + 3 * z;     // (read side only: step_launch picks by parity, the write side is restored below)
+            q.vtin_b[0] = q.vtin_b[1] = p.vtin_pre + 3 * z;
+        }
+        if (do_c || do_a) step_launch(ctx, q, p, t, do_c, do_a, s);
+        ctx->launch_kind[i] = (do_c && do_a) ? 2 : ((do_c || do_a) ? 1 : 0);
         if (ctx->timing) TB_HIP(ctx, hipEventRecord(ctx->ev[2 + i], s));
     }
     ctx->n_timed_steps = ctx->timing ? n_launch : 0;
@@ -827,7 +872,7 @@ extern "C" int tb_rollout_begin(tb_ctx* ctx, const tb_rollout_io* io, tb_stream 
     if (rollout_setup(ctx, io, p)) return 1;
     hipStream_t s = (hipStream_t)stream_;
     rollout_prologue(ctx, p, io, s);
-    step_launch(ctx, p, p.step_start - 1, /*do_c=*/0, /*do_a=*/1, s);  // A(sim_start)
+    step_launch(ctx, p, p, p.step_start - 1, /*do_c=*/0, /*do_a=*/1, s);  // A(sim_start)
     ctx->step_p = p;
     ctx->step_next = p.step_start;
     ctx->step_end = io->step_end;
@@ -841,7 +886,7 @@ extern "C" int tb_rollout_step(tb_ctx* ctx, tb_stream stream_) {
     if (!ctx->step_active) return tb_fail(ctx, "tb_rollout_step: no rollout in progress (call tb_rollout_begin)");
     if (ctx->step_next > ctx->step_end) return tb_fail(ctx, "tb_rollout_step: step %d is past step_end %d", ctx->step_next, ctx->step_end);
     const int t = ctx->step_next;
-    step_launch(ctx, ctx->step_p, t, /*do_c=*/1, /*do_a=*/t < ctx->step_end, (hipStream_t)stream_);
+    step_launch(ctx, ctx->step_p, ctx->step_p, t, /*do_c=*/1, /*do_a=*/t < ctx->step_end, (hipStream_t)stream_);
     ctx->step_next = t + 1;
     TB_HIP(ctx, hipGetLastError());
     return 0;

@@ -41,6 +41,8 @@ struct tb_ctx {
     bool timing = false;
     std::vector<hipEvent_t> ev;
     int n_timed_steps = 0;
+    std::vector<uint8_t> launch_kind;  // per step launch of the last tb_rollout: 2 fused, 1 one half, 0 skipped (tb_get_timing)
+    int n_pre = 0;                     // batched warm-start slices of the rollout being set up
 };
 
 

@@ -104,7 +104,15 @@ struct RolloutP {
     uint8_t* dest_reached;
     uint8_t* outside;
     float* hidden;                // [3,N,a_pad,128]
-    float* x_mid;                 // [N,a_pad,128]
+    float* x_mid;                 // [N,a_pad,128]  read by C(t)
+    float* x_mid_w;               // written by A(t+1): the same buffer, except on the step that leaves the batched warm start
+    // Batched warm start (k_step_x, A half only, grid.z = n steps): while every valid agent is teacher-forced and nobody leaves, the
+    // state the A half of step t+1 starts from IS the ground truth of step t, so those A halves do not depend on the rollout and run
+    // as ONE launch of n x tiles workgroups (the chip is half empty at 32 scenes); slice z of the *_pre buffers takes A(pre_t0 + z + 1)
+    int pre_mode, pre_t0;
+    float* x_mid_pre;             // [n_pre][N,a_pad,128]
+    float* kin_pre;               // [n_pre][N,3,a_pad,128]
+    float* vtin_pre;              // [n_pre][N,3,128,a_pad]
     float* kin;                   // [N,3,a_pad,128]
     float* vtin;                  // [N,3,128,a_pad]
     float* goal_pre;              // [N,a_pad,128]

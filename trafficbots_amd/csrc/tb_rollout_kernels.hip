@@ -446,7 +446,7 @@ __global__ __launch_bounds__(NTHREADS) void k_step(RolloutP p, int t, int do_c, 
     TB_STAMP(10);
     // ---- hand-off to the next launch: x_mid and the interaction K/V of this tile's agents (tgt = block input for
     // all three layers, agent_interaction.py:51-52 + transformer.py:82-92)
-    store_tile(p.x_mid + base_row * H, X, LDT, TM, tid);
+    store_tile(p.x_mid_w + base_row * H, X, LDT, TM, tid);
     {
         const size_t ls = (size_t)p.a_pad * H;
         float* K0 = p.kin_w + ((size_t)n * 3) * ls;

@@ -222,7 +222,7 @@ __global__ __launch_bounds__(NTHREADS8) void k_step8(RolloutP p, int t, int do_c
     }
     TB_STAMP(10);
     // ---- hand-off to the next launch: x_mid and the interaction K/V of this tile's agents
-    store_tile8(p.x_mid + base_row * H, X, LDT, TM, tid);
+    store_tile8(p.x_mid_w + base_row * H, X, LDT, TM, tid);
     {
         const size_t ls = (size_t)p.a_pad * H;
         float* K0 = p.kin_w + ((size_t)n * 3) * ls;

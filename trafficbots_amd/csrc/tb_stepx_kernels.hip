@@ -108,7 +108,13 @@ void launch_fuse_hoist_x(const RolloutP& p, hipStream_t s) {
     hipLaunchKernelGGL(k_fuse_hoist_x, grid, dim3(NTHREADS), TM * LDT * sizeof(float) + PLANES_BYTES, s, p);
 }
 
+// PRE = the batched warm start (RolloutP::pre_mode): A half only, inputs from the ground truth, grid.z = steps
+template <bool PRE>
 __global__ __launch_bounds__(NTHREADS) void k_step_x(RolloutP p, int t, int do_c, int do_a) {
+    if (PRE) {
+        do_c = 0;
+        do_a = 1;
+    }
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* X = smem + XO_X;
     float* Hs = smem + XO_H;
@@ -135,6 +141,7 @@ __global__ __launch_bounds__(NTHREADS) void k_step_x(RolloutP p, int t, int do_c
     const int tid = threadIdx.x, wave = wave_of(tid), lane = tid & 63, kq = lane >> 4, m = lane & 15;
     int n, rt;
     step_tile_map(n, rt);
+    if (PRE) t = p.pre_t0 + (int)blockIdx.z;  // batched warm start: A(t + 1) of step t from the ground truth of step t
     const int b = n / p.k_rep, row0 = rt * TM;
     const int n_real = max(0, min(TM, p.n_agent - row0));
     const float* W = p.W;
@@ -167,10 +174,19 @@ __global__ __launch_bounds__(NTHREADS) void k_step_x(RolloutP p, int t, int do_c
     if (tid < TM) {
         const size_t si = base_row + tid;
         rs_ty = (tid < n_real) ? p.agent_type[(size_t)b * p.n_agent + row0 + tid] : -1;
-        rs_st = ldg4(p.state + si * 4);
-        rs_ax = ldg4(p.aux + si * 4);
-        rs_v = p.valid[si];
-        rs_g = p.goal_valid[si];
+        if (PRE) {  // the post-override simulator state of step t is the ground truth of step t (RolloutP::pre_mode)
+            if (tid < n_real) {
+                const size_t hi = ((size_t)b * p.n_hist + t) * p.n_agent + row0 + tid;
+                rs_st = ldg4(p.hist_state + hi * 4);
+                rs_ax = f32x4{p.hist_vel[hi * 2], p.hist_vel[hi * 2 + 1], p.hist_acc[hi], p.hist_yaw_rate[hi]};
+                rs_v = p.hist_valid[hi];
+            }
+        } else {
+            rs_st = ldg4(p.state + si * 4);
+            rs_ax = ldg4(p.aux + si * 4);
+            rs_v = p.valid[si];
+            rs_g = p.goal_valid[si];
+        }
     }
     if (do_c) {
 #pragma unroll
@@ -358,16 +374,20 @@ __global__ __launch_bounds__(NTHREADS) void k_step_x(RolloutP p, int t, int do_c
                             u, wstdx(W, px.inter_kvf[0], W + px.inter_bkvf[0], wave), LN + 8 * 768);
     }
     TB_STAMP(10);
-    store_tile(p.x_mid + base_row * H, X, LDT, TM, tid);
+    const size_t zslice = PRE ? (size_t)blockIdx.z * p.n_inst * p.a_pad * H : 0;  // floats per x_mid slice; K / V slices are 3x
+    store_tile((PRE ? p.x_mid_pre + zslice : p.x_mid_w) + base_row * H, X, LDT, TM, tid);
     {
         const size_t ls = (size_t)p.a_pad * H;
-        xhalf* K0 = reinterpret_cast<xhalf*>(p.kin_w + ((size_t)n * 3) * ls);
-        xhalf* V0 = reinterpret_cast<xhalf*>(p.vtin_w + ((size_t)n * 3) * ls);
+        xhalf* K0 = reinterpret_cast<xhalf*>((PRE ? p.kin_pre + 3 * zslice : p.kin_w) + ((size_t)n * 3) * ls);
+        xhalf* V0 = reinterpret_cast<xhalf*>((PRE ? p.vtin_pre + 3 * zslice : p.vtin_w) + ((size_t)n * 3) * ls);
         // (the last unit request points at a valid unit that nobody consumes: the launch ends here)
         kv_project_shared_x(W, px.inter_kvf, px.inter_bkvf, X, PA, K0, V0, ls, row0, TM, tid, u, wstdx(W, px.inter_kvf[0], W + px.inter_bkvf[0], wave));
     }
     TB_STAMP(11);
 }
+
+template __global__ void k_step_x<false>(RolloutP, int, int, int);  // (emitted first: the launch of every simulation step)
+template __global__ void k_step_x<true>(RolloutP, int, int, int);
 
 // K/V of the three layers of a cross-attention block for fixed targets (map polylines, TL stop points), in the XDL operand
 // order (tb_device_xdl.hpp): the fp16-pair twin of k_kv_hoist.  grid = (n_pad/16, G)
@@ -438,13 +458,25 @@ void launch_kv_hoist_x(const float* W, const XLayerW* L3, const XLayerX* X3, con
 }
 
 hipError_t configure_stepx_kernel() {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(k_step_x), hipFuncAttributeMaxDynamicSharedMemorySize,
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_step_x<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)(STEPX_LDS_FLOATS * sizeof(float)));
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(k_step_x<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                (int)(STEPX_LDS_FLOATS * sizeof(float)));
 }
 
 void launch_step_x(const RolloutP& p, int t, int do_c, int do_a, hipStream_t s) {
     dim3 grid(p.a_pad / TM, p.n_inst);
-    hipLaunchKernelGGL(k_step_x, grid, dim3(NTHREADS), STEPX_LDS_FLOATS * sizeof(float), s, p, t, do_c, do_a);
+    hipLaunchKernelGGL(k_step_x<false>, grid, dim3(NTHREADS), STEPX_LDS_FLOATS * sizeof(float), s, p, t, do_c, do_a);
+}
+
+// A halves of steps t0 + 1 .. t0 + n from the ground truth of steps t0 .. t0 + n - 1, one launch (RolloutP::pre_mode)
+void launch_step_pre_x(const RolloutP& p0, int t0, int n, hipStream_t s) {
+    RolloutP p = p0;
+    p.pre_mode = 1;
+    p.pre_t0 = t0;
+    dim3 grid(p.a_pad / TM, p.n_inst, n);
+    hipLaunchKernelGGL(k_step_x<true>, grid, dim3(NTHREADS), STEPX_LDS_FLOATS * sizeof(float), s, p, t0, 0, 1);
 }
 
 }  // namespace TB_XNS

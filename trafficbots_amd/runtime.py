@@ -45,9 +45,18 @@ RULE_KEYS = ("collided", "collided_this_step", "run_road_edge", "run_road_edge_t
              "run_red_light_this_step", "passive", "passive_this_step")
 
 
+def no_early_exit(valid, n_steps: int) -> bool:
+    """True when no agent turns from valid to invalid within the first `n_steps` steps of `valid` [B,S,A] (evaluated where the
+    batch still lives, normally on the host before the upload): the condition under which the warm start can be batched
+    (`tb_rollout_io.warm_start_steps`)."""
+    v = torch.as_tensor(valid)[:, :n_steps].bool()
+    return not bool((v[:, :-1] & ~v[:, 1:]).any())
+
+
 def scene_from_batch(batch: Dict[str, Tensor], device, n_hist: int = 11) -> Dict[str, Tensor]:
     """Reference test-split batch (`data_h5_womd.py:119-157`, bool tensors, history/ prefix) ->
-    the C ABI's device layout (uint8 masks, int32 class indices, yaw/spd/acc as [B,NH,A])."""
+    the C ABI's device layout (uint8 masks, int32 class indices, yaw/spd/acc as [B,NH,A]).  `warm_ok` (a Python bool, not a
+    tensor) records that no agent leaves within the history, see :func:`no_early_exit`."""
 
     def g(k):
         v = batch[k]
@@ -57,6 +66,7 @@ def scene_from_batch(batch: Dict[str, Tensor], device, n_hist: int = 11) -> Dict
 
     f32, u8 = torch.float32, torch.uint8
     s: Dict[str, Tensor] = {}
+    s["warm_ok"] = no_early_exit(batch["history/agent/valid"], n_hist)
     av = g("history/agent/valid")[:, :n_hist]
     s["agent_valid"] = av.to(u8).contiguous()
     pos = g("history/agent/pos")[:, :n_hist].to(f32)
@@ -102,6 +112,7 @@ def gt_from_batch(batch: Dict[str, Tensor], device) -> Dict[str, Tensor]:
 
     f32, u8 = torch.float32, torch.uint8
     s: Dict[str, Tensor] = {}
+    s["warm_ok"] = no_early_exit(batch["agent/valid"], 11)  # (time_step_current + 1 steps: the warm start of every TeacherForcing config)
     s["agent_valid"] = g("agent/valid").to(u8).contiguous()
     pos, yaw, spd = g("agent/pos").to(f32), g("agent/yaw_bbox").to(f32), g("agent/spd").to(f32)
     s["agent_pos"] = pos.contiguous()
@@ -306,13 +317,17 @@ class HipEngine:
         record_check_states: bool = False,
         gt: Optional[Dict[str, Tensor]] = None,
         latent_posterior: bool = False,
+        warm_start_steps: int = 0,
     ) -> Dict[str, Tensor]:
         """Closed-loop rollout of N = B*K instances (instance n uses scene n // K).  Returns the
         `RolloutBuffer` fields as [N, A, S, ...] tensors (`buffer.py:72-90`).  With `stepwise=True` only the
         prologue runs (`tb_rollout_begin`); advance with :meth:`rollout_step`, inspect with :meth:`rollout_state`.
         `gt` (:func:`gt_from_batch`) makes the full ground truth the source of initial state / overrides / the kill rule, as
         `reactive_replay` and the validation-time `joint_future_pred` do (`waymo_motion.py:457-461,538-545`); the traffic
-        lights stay those of the history.  `latent_posterior` selects the posterior log_std for `latent_log_prob`."""
+        lights stay those of the history.  `latent_posterior` selects the posterior log_std for `latent_log_prob`.
+        `warm_start_steps` = W > 0 promises that all valid agents are teacher-forced up to step W and none leaves before it
+        (`tb_rollout_io.warm_start_steps`): same results, the first W+1 map / traffic-light attention halves run as one launch.
+        With the default mask (mask_teacher_forcing=None) it is derived from the config and the scene's `warm_ok`."""
         n_tl_step = s["tl_valid"].shape[1]
         ag = s if gt is None else gt
         b, nh, a = ag["agent_valid"].shape
@@ -323,6 +338,8 @@ class HipEngine:
         dev, f32, u8 = self.device, torch.float32, torch.uint8
         if mask_teacher_forcing is None:
             tf = self.cfg["teacher_forcing_joint_future_pred"]
+            if warm_start_steps == 0 and ag.get("warm_ok", False) and tf.get("step_warm_start", 10) >= 0:
+                warm_start_steps = min(int(tf.get("step_warm_start", 10)), self.n_hist - 1)
             mask_teacher_forcing = teacher_forcing_mask(
                 ag["agent_valid"].bool(), tf.get("step_spawn_agent", 10), tf.get("step_warm_start", 10)
             ).to(u8).contiguous()
@@ -352,6 +369,7 @@ class HipEngine:
         io.tl_feature = hip.ptr(feats["tl_feature"], hip.c_f32p)
         io.tl_feature_valid = hip.ptr(s["tl_valid"], hip.c_u8p)
         io.n_tl_step, io.latent_posterior = n_tl_step, int(latent_posterior)
+        io.warm_start_steps = 0 if stepwise else int(warm_start_steps)
         io.agent_valid = hip.ptr(ag["agent_valid"], hip.c_u8p)
         io.agent_state = hip.ptr(ag["agent_state"], hip.c_f32p)
         io.agent_vel = hip.ptr(ag["agent_vel"], hip.c_f32p)

@@ -175,6 +175,7 @@ class WaymoMotion:
         gt: Optional[Dict[str, Tensor]] = None,
         latent_posterior: bool = False,
         rule_checker_tl: Optional[Dict[str, Tensor]] = None,
+        warm_start_steps: int = 0,
     ) -> RolloutBuffer:
         """`WaymoMotion.rollout` (`waymo_motion.py:205-354`).  `gt` (the scene's "gt" dict) replaces the history as
         `features["agent_valid" / "agent_state" / ...]`, the way validation and training call it (`:457-461`); with it and
@@ -200,7 +201,7 @@ class WaymoMotion:
         out = self.engine.rollout(
             features, features, z, mean_scene, goal, goal_valid, k_futures, step_end,
             mask_teacher_forcing=mask_teacher_forcing.to(torch.uint8).contiguous(), tap_step=tap_step, stepwise=stepwise,
-            record_check_states=want_checks, gt=gt, latent_posterior=latent_posterior,
+            record_check_states=want_checks, gt=gt, latent_posterior=latent_posterior, warm_start_steps=warm_start_steps,
         )
         if (gt is not None and k_futures == 1 and not stepwise and self.hparams["training_metrics"]["w_diffbar_reward"] > 0
                 and gt["agent_valid"].shape[1] > step_end):
@@ -232,6 +233,13 @@ class WaymoMotion:
             buf.diffbar_rewards, buf.diffbar_rewards_valid = out["diffbar_rewards"], out["diffbar_rewards_valid"].bool()
         return buf
 
+    def _warm_start_steps(self, tf: Dict, src: Dict[str, Tensor]) -> int:
+        """W for `tb_rollout_io.warm_start_steps`: the TeacherForcing warm start (all valid agents forced up to step_warm_start,
+        `teacher_forcing.py:56-58`) when no agent leaves within it (`warm_ok`, computed on the host batch), else 0."""
+        if not src.get("warm_ok", False) or tf.get("step_warm_start", 10) < 0:
+            return 0
+        return min(int(tf.get("step_warm_start", 10)), self.n_hist - 1)
+
     @staticmethod
     def _gt_slices(gt: Dict[str, Tensor], step_start: int, step_end: int) -> Tuple[Tensor, Tensor]:
         """batch["gt/valid"][:, s0:].transpose(1, 2), batch["gt/state"][:, s0:].transpose(1, 2) (`waymo_motion.py:616-617`)."""
@@ -242,7 +250,7 @@ class WaymoMotion:
     def reactive_replay(self, batch: Dict[str, Tensor], input_feature_dict: Dict[str, Tensor], mask_teacher_forcing: Tensor,
                         latent: DiagGaussian, goal: Tensor, goal_valid: Tensor, deterministic_latent: bool = True,
                         deterministic_action: bool = True, require_vis_dict: bool = False, latent_eps: Optional[Tensor] = None,
-                        latent_is_posterior: bool = True) -> RolloutBuffer:
+                        latent_is_posterior: bool = True, teacher_forcing_cfg: Optional[Dict] = None) -> RolloutBuffer:
         """`WaymoMotion.reactive_replay` (`waymo_motion.py:420-476`): the episode replayed from its ground truth (`batch` is the
         pre-processed validation scene, `batch["gt"]` its ground truth) with the given personality and goal; K = 1.  The
         personality is taken as a POSTERIOR for `latent_log_prob` (that is what validation / training pass, `:382-387,605`).
@@ -251,12 +259,14 @@ class WaymoMotion:
         features["map_feature"] = input_feature_dict["map_feature"]
         features["map_feature_valid"] = input_feature_dict["map_feature_valid"].to(torch.uint8).contiguous()
         features["tl_feature"] = input_feature_dict["tl_feature"]
+        # (the masks of validation / training force every valid agent up to step_warm_start = time_step_current)
         return self.rollout(
             features, latent=latent, goal=goal, goal_valid=goal_valid, mask_teacher_forcing=mask_teacher_forcing,
             deterministic_latent=deterministic_latent, deterministic_action=deterministic_action,
             step_start=self.hparams["time_step_sim_start"], step_end=self.hparams["time_step_end"], k_futures=1,
             gt=batch["gt"], latent_posterior=latent_is_posterior, require_vis_dict=require_vis_dict, rule_checker_tl=batch["gt"],
             latent_eps=latent_eps,
+            warm_start_steps=self._warm_start_steps(teacher_forcing_cfg or self.hparams["teacher_forcing_reactive_replay"], batch["gt"]),
         )
 
     def finish_rollout(self) -> RolloutBuffer:
@@ -338,6 +348,7 @@ class WaymoMotion:
             deterministic_latent=deterministic, deterministic_action=True,
             step_start=self.hparams["time_step_sim_start"], step_end=self.hparams["time_step_end"],
             k_futures=k, latent_eps=latent_eps, tap_step=tap_step, gt=gt,
+            warm_start_steps=self._warm_start_steps(tf, gt if gt is not None else batch),
         )
         buf.flatten_repeat(k)
         goal_log_probs = goal_log_probs.view(b, k, a).transpose(1, 2)
@@ -401,7 +412,7 @@ class WaymoMotion:
         mask_tf = teacher_forcing_mask(gt["agent_valid"].bool(), tf.get("step_spawn_agent", 10), tf.get("step_warm_start", 10))
         buf = self.reactive_replay(scene, input_feature_dict, mask_tf, latent, goal_gt, goal_valid,
                                    deterministic_latent=latent_eps is None, deterministic_action=True, latent_eps=latent_eps,
-                                   latent_is_posterior=not rollout_prior)
+                                   latent_is_posterior=not rollout_prior, teacher_forcing_cfg=tf)
         gv, gs = self._gt_slices(gt, hp["time_step_sim_start"], hp["time_step_end"])
         raw = {"valid": buf.valid, "preds": buf.preds, "override_masks": buf.override_masks}
         _, _, states = self.engine.train_partials(
