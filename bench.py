@@ -28,7 +28,7 @@ H = 128
 PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak
 # fabric-side bytes per fused launch from the PMC pass of this round (profiles/r01_rocprof_xdl.txt: FETCH_SIZE 41 061 KiB x 2, the
 # gfx950 correction of the guide, at the headline shape); collected with rocprofv3 --pmc in its own run, not at bench time
-TRAFFIC_BYTES_PER_LAUNCH_B32 = 2 * 38862 * 1024
+TRAFFIC_BYTES_PER_LAUNCH_B32 = 2 * 38870 * 1024
 
 
 def flops_step_a(a, p, t):  # SURVEY 8(d) split: as2pl + as2tl + interaction K/V projections + agent encoder
