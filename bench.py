@@ -298,8 +298,10 @@ def main():
             "agent_steps_per_s": value * N_AGENT,
             "encode_ms": encode_ms,
             "pass_ms": {"min": pass_ms[0], "median": pass_ms[len(pass_ms) // 2], "max": pass_ms[-1]},
-            "kernel_us": {"k_step_fused": k_us, "edge_launches_ms": tm["edge_ms"], "prologue_ms": tm["prologue_ms"]},
-            "roofline": {"bound": "mfma", "kernel": "tb::k_step_x (C(t)+A(t+1), one launch per simulation step)", "achieved": achieved,
+            "kernel_us": {"k_step_fused": k_us, "n_fused": tm["n_fused"], "edge_launches_ms": tm["edge_ms"], "prologue_ms": tm["prologue_ms"],
+                          "note": "per rollout: n_fused fused launches; edge_launches_ms = the batched warm-start launch (A halves of the "
+                                  "teacher-forced steps, k_step_x<true>), their C-only launches and the last step's"},
+            "roofline": {"bound": "mfma", "kernel": "tb::xh::k_step_x<false> (the fused C(t)+A(t+1) launch of a simulation step)", "achieved": achieved,
                          "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
                          "traffic": TRAFFIC_BYTES_PER_LAUNCH_B32 if (N_AGENT, N_PL, N_TL, B_PER_GPU) == (64, 256, 40, 32) else None,
                          "traffic_unit": "bytes per launch (rocprofv3 --pmc FETCH_SIZE, profiles/r01_rocprof_xdl.txt)",
