@@ -142,7 +142,11 @@ __global__ __launch_bounds__(NTHREADS) void k_step_x(RolloutP p, int t, int do_c
     int n, rt;
     step_tile_map(n, rt);
     if (PRE) t = p.pre_t0 + (int)blockIdx.z;  // batched warm start: A(t + 1) of step t from the ground truth of step t
-    const int b = n / p.k_rep, row0 = rt * TM;
+    // (the K futures of a scene share the ground truth: the batched launch runs once per SCENE, in the slot of future 0, and
+    // k_pre_replicate copies the slices to the other futures)
+    const int b = PRE ? n : n / p.k_rep;
+    if (PRE) n = b * p.k_rep;
+    const int row0 = rt * TM;
     const int n_real = max(0, min(TM, p.n_agent - row0));
     const float* W = p.W;
     const PolicyW& pw = p.pw;
@@ -331,7 +335,8 @@ __global__ __launch_bounds__(NTHREADS) void k_step_x(RolloutP p, int t, int do_c
     TB_STAMP(30);
     step_encode_inputs_lds(p, b, row0, n_real, tid, sm, ENCW, X);
     if (t1 == p.tap_step && p.tap_agent_feature)
-        store_tile(p.tap_agent_feature + ((size_t)n * p.n_agent + row0) * H, X, LDT, n_real, tid);
+        for (int k = 0; k < (PRE ? p.k_rep : 1); ++k)  // (the batched launch runs once per scene: same feature for its K futures)
+            store_tile(p.tap_agent_feature + ((size_t)(n + k) * p.n_agent + row0) * H, X, LDT, n_real, tid);
     TB_STAMP(8);
     const int g_tl = b * p.n_tl_hist + min(t1 - 1, p.n_tl_hist - 1);
     // no lit traffic light at this step (valid keys are compacted to the front, so slot 0 tells): as2tl keeps only its FFN halves
@@ -470,13 +475,36 @@ void launch_step_x(const RolloutP& p, int t, int do_c, int do_a, hipStream_t s) 
     hipLaunchKernelGGL(k_step_x<false>, grid, dim3(NTHREADS), STEPX_LDS_FLOATS * sizeof(float), s, p, t, do_c, do_a);
 }
 
+// slices of future 0 of every scene -> futures 1 .. K-1 (x_mid rows, K and V of the three layers).  grid (n_pre * n_scene * (K - 1))
+__global__ __launch_bounds__(256) void k_pre_replicate(RolloutP p, int n_pre) {
+    const int km1 = p.k_rep - 1;
+    const int k = 1 + (int)(blockIdx.x % km1), b = (int)((blockIdx.x / km1) % p.n_scene), z = (int)(blockIdx.x / (km1 * p.n_scene));
+    if (z >= n_pre) return;
+    const size_t rowf = (size_t)p.a_pad * H;                         // floats of one instance's x_mid
+    const size_t zx = (size_t)z * p.n_inst * rowf;
+    const size_t src = (size_t)b * p.k_rep, dst = src + k;
+    const f32x4* s0 = reinterpret_cast<const f32x4*>(p.x_mid_pre + zx + src * rowf);
+    f32x4* d0 = reinterpret_cast<f32x4*>(p.x_mid_pre + zx + dst * rowf);
+    const f32x4* s1 = reinterpret_cast<const f32x4*>(p.kin_pre + 3 * zx + src * 3 * rowf);
+    f32x4* d1 = reinterpret_cast<f32x4*>(p.kin_pre + 3 * zx + dst * 3 * rowf);
+    const f32x4* s2 = reinterpret_cast<const f32x4*>(p.vtin_pre + 3 * zx + src * 3 * rowf);
+    f32x4* d2 = reinterpret_cast<f32x4*>(p.vtin_pre + 3 * zx + dst * 3 * rowf);
+    const size_t n4 = rowf / 4;
+    for (size_t i = threadIdx.x; i < n4; i += 256) d0[i] = s0[i];
+    for (size_t i = threadIdx.x; i < 3 * n4; i += 256) {
+        d1[i] = s1[i];
+        d2[i] = s2[i];
+    }
+}
+
 // A halves of steps t0 + 1 .. t0 + n from the ground truth of steps t0 .. t0 + n - 1, one launch (RolloutP::pre_mode)
 void launch_step_pre_x(const RolloutP& p0, int t0, int n, hipStream_t s) {
     RolloutP p = p0;
     p.pre_mode = 1;
     p.pre_t0 = t0;
-    dim3 grid(p.a_pad / TM, p.n_inst, n);
+    dim3 grid(p.a_pad / TM, p.n_scene, n);
     hipLaunchKernelGGL(k_step_x<true>, grid, dim3(NTHREADS), STEPX_LDS_FLOATS * sizeof(float), s, p, t0, 0, 1);
+    if (p.k_rep > 1) hipLaunchKernelGGL(k_pre_replicate, dim3((unsigned)(n * p.n_scene * (p.k_rep - 1))), dim3(256), 0, s, p, n);
 }
 
 }  // namespace TB_XNS
