@@ -367,7 +367,7 @@ __device__ __forceinline__ void attention_prefetch_x(AttnPreX& a, const xhalf* _
 
 // One head over n_key_pad keys with online softmax; q = this wave's Q^T accumulators.  Returns o (normalised) and whether
 // the row had no valid key.  Same recurrences as attention_head (tb_device.hpp); the two matrix products are fp16-pair.
-template <bool SELFMASK>
+template <bool SELFMASK, bool ISSUE = true>
 __device__ __forceinline__ bool attention_head_x(const f32x4 (&q)[2], AttnPreX& pre, const xhalf* __restrict__ Kh,
                                                  const xhalf* __restrict__ Vh, const float* __restrict__ keybias, int n_key_pad,
                                                  int kstart, int head, int lane, int self_key, f32x4 (&o)[2], WUnitX& un,
@@ -408,7 +408,7 @@ __device__ __forceinline__ bool attention_head_x(const f32x4 (&q)[2], AttnPreX& 
         const f32x4 nb[2] = {kn.kb[0], kn.kb[1]};
         TB_SCHED_FENCE();
         k_load_x(kn, kbase, bbase, kld);
-        if (i == i_issue) wloadx(un, nx, lane);
+        if (ISSUE && i == i_issue) wloadx(un, nx, lane);
         float p[8];
 #pragma unroll
         for (int r = 0; r < 8; ++r) p[r] = exp2_neg(sv[r] - new_max);
@@ -657,6 +657,111 @@ __device__ __forceinline__ void kv_project_shared_x(const float* __restrict__ W,
         wmmax_pf(av[0], av[1], u2, b1, PLANE, u, l < 2 ? wstdx(W, kvf[l + 1], W + bkvf[l + 1], wave) : nxt, lane);
         kv_store_x(Kmat + 2 * l * ls, VT + 2 * l * ls, tok0, wave, lane, ak, av, m < n_real_rows);
     }
+    __syncthreads();
+}
+
+// The same layer for TWO 16-row tiles of one group (X0 / X1, their plane buffers P1a / P1b and P2a / P2b): every weight unit is
+// loaded once and multiplied against both tiles, which halves the weight stream per row -- the encoders' blocks are bound by it.
+// The two tiles walk the same keys; their attentions run one after the other (the out-projection unit is requested by the first).
+template <bool SELFMASK = false>
+__device__ __forceinline__ void xattn_layer_x2(const float* __restrict__ W, const XLayerW& L, const XLayerX& LX, float* X0, float* X1,
+                                               xhalf* P1a, xhalf* P1b, xhalf* P2a, xhalf* P2b, const xhalf* __restrict__ Kmat,
+                                               const xhalf* __restrict__ VT, const float* __restrict__ keybias, int n_key_pad,
+                                               int self_key0a, int self_key0b, const uint8_t* rowvalid0, const uint8_t* rowvalid1,
+                                               uint8_t* novalid_s0, uint8_t* novalid_s1, int tid, WUnitX& u, const WNextX& nxt) {
+    const float* lnblk = W + L.ln1_g;
+    const int wave = wave_of(tid), lane = tid & 63;
+    const int kq = lane >> 4, m = lane & 15;
+    const int po = m * LDP + kq * 8;
+    AttnPreX apre;
+    layernorm_planes<false>(X0, LDT, P1a, lnblk, lnblk + 128, tid);
+    layernorm_planes<false>(X1, LDT, P1b, lnblk, lnblk + 128, tid);
+    attention_prefetch_x(apre, Kmat, VT, keybias, n_key_pad, 0, wave, lane);
+    __syncthreads();
+    WUnitX u2;
+    f32x4 q0[2] = {u.b[0], u.b[1]}, q1[2] = {u.b[0], u.b[1]};
+    wmmax(q0[0], q0[1], u, P1a + po, PLANE);
+    wmmax(q1[0], q1[1], u, P1b + po, PLANE);
+    f32x4 o0[2], o1[2];
+    const bool nov0 = attention_head_x<SELFMASK, true>(q0, apre, Kmat, VT, keybias, n_key_pad, 0, wave, lane, self_key0a >= 0 ? self_key0a + m : -1,
+                                                       o0, u2, wstdx(W, LX.wo, W + L.bo, wave));
+    attention_prefetch_x(apre, Kmat, VT, keybias, n_key_pad, 0, wave, lane);
+    const bool nov1 = attention_head_x<SELFMASK, false>(q1, apre, Kmat, VT, keybias, n_key_pad, 0, wave, lane, self_key0b >= 0 ? self_key0b + m : -1,
+                                                        o1, u2, wstdx(W, LX.wo, W + L.bo, wave));
+    planes_store_c(P2a, 2 * wave, lane, o0[0]);
+    planes_store_c(P2a, 2 * wave + 1, lane, o0[1]);
+    planes_store_c(P2b, 2 * wave, lane, o1[0]);
+    planes_store_c(P2b, 2 * wave + 1, lane, o1[1]);
+    if (wave == 0 && kq == 0) {
+        novalid_s0[m] = nov0 ? 1 : 0;
+        novalid_s1[m] = nov1 ? 1 : 0;
+    }
+    __syncthreads();
+    {
+        f32x4 a0[2] = {u2.b[0], u2.b[1]}, a1[2] = {u2.b[0], u2.b[1]};
+        wmmax_pf(a0[0], a0[1], u2, P2a + po, PLANE, u, wstdx(W, LX.w1, W + L.b1, wave), lane);
+        wmmax(a1[0], a1[1], u2, P2b + po, PLANE);
+        const bool nv0 = novalid_s0[m] != 0, nv1 = novalid_s1[m] != 0;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            float* px = cptr(X0, LDT, 2 * wave + t, lane);
+            const f32x4 x0 = lds4(px);
+            st4(px, nv0 ? x0 : x0 + a0[t]);
+            float* py = cptr(X1, LDT, 2 * wave + t, lane);
+            const f32x4 x1 = lds4(py);
+            st4(py, nv1 ? x1 : x1 + a1[t]);
+        }
+    }
+    __syncthreads();
+    layernorm_planes<false>(X0, LDT, P1a, lnblk + 512, lnblk + 640, tid);
+    layernorm_planes<false>(X1, LDT, P1b, lnblk + 512, lnblk + 640, tid);
+    __syncthreads();
+    {
+        f32x4 a0[2] = {u.b[0], u.b[1]}, a1[2] = {u.b[0], u.b[1]};
+        wmmax_pf(a0[0], a0[1], u, P1a + po, PLANE, u2, wstdx(W, LX.w2, W + L.b2, wave), lane);
+        wmmax(a1[0], a1[1], u, P1b + po, PLANE);
+        planes_store_c(P2a, 2 * wave, lane, relu4(a0[0]));
+        planes_store_c(P2a, 2 * wave + 1, lane, relu4(a0[1]));
+        planes_store_c(P2b, 2 * wave, lane, relu4(a1[0]));
+        planes_store_c(P2b, 2 * wave + 1, lane, relu4(a1[1]));
+    }
+    __syncthreads();
+    {
+        f32x4 a0[2] = {u2.b[0], u2.b[1]}, a1[2] = {u2.b[0], u2.b[1]};
+        wmmax_pf(a0[0], a0[1], u2, P2a + po, PLANE, u, nxt, lane);
+        wmmax(a1[0], a1[1], u2, P2b + po, PLANE);
+        const bool rv0 = rowvalid0[m] != 0, rv1 = rowvalid1[m] != 0;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            float* px = cptr(X0, LDT, 2 * wave + t, lane);
+            st4(px, rv0 ? lds4(px) + a0[t] : splat(0.f));
+            float* py = cptr(X1, LDT, 2 * wave + t, lane);
+            st4(py, rv1 ? lds4(py) + a1[t] : splat(0.f));
+        }
+    }
+    __syncthreads();
+}
+
+// K/V projection of TWO 16-token tiles of a group for one layer with each unit loaded once
+__device__ __forceinline__ void kv_project_tile_x2(const float* __restrict__ W, const XLayerW& L, const XLayerX& LX, const float* T0,
+                                                   const float* T1, xhalf* P1a, xhalf* P1b, xhalf* __restrict__ Kmat, xhalf* __restrict__ VT,
+                                                   int tok0, int n_real0, int n_real1, int tid, WUnitX& u, const WNextX& nxt) {
+    const int wave = wave_of(tid), lane = tid & 63;
+    const int kq = lane >> 4, m = lane & 15;
+    const float* lnblk = W + L.ln1_g;
+    layernorm_planes<false>(T0, LDT, P1a, lnblk + 256, lnblk + 384, tid);
+    layernorm_planes<false>(T1, LDT, P1b, lnblk + 256, lnblk + 384, tid);
+    __syncthreads();
+    const int po = m * LDP + kq * 8;
+    WUnitX u2;
+    f32x4 k0[2] = {u.b[0], u.b[1]}, k1[2] = {u.b[0], u.b[1]};
+    wmmax_pf(k0[0], k0[1], u, P1a + po, PLANE, u2, wnextx(W, LX.wkv, W + L.bkv, 8 + 2 * wave, 8 + 2 * wave + 1), lane);
+    wmmax(k1[0], k1[1], u, P1b + po, PLANE);
+    f32x4 v0[2] = {u2.b[0], u2.b[1]}, v1[2] = {u2.b[0], u2.b[1]};
+    wmmax_pf(v0[0], v0[1], u2, P1a + po, PLANE, u, nxt, lane);
+    wmmax(v1[0], v1[1], u2, P1b + po, PLANE);
+    kv_store_x(Kmat, VT, tok0, wave, lane, k0, v0, m < n_real0);
+    kv_store_x(Kmat, VT, tok0 + TM, wave, lane, k1, v1, m < n_real1);
     __syncthreads();
 }
 

@@ -36,10 +36,20 @@ __global__ __launch_bounds__(NTHREADS) void k_kv_hoist_nx(const float* __restric
     if (n_layer > 2) kv_project_tile_x(W, l2, x2, T, P1, K0 + 4 * ls, V0 + 4 * ls, n_pad, tok0, n_real, tid, u, kvproj_first_x(W, l2, x2, wave));
 }
 
+__global__ void k_kv_hoist_nx2(const float* __restrict__ W, XLayerW l0, XLayerW l1, XLayerW l2, XLayerX x0, XLayerX x1, XLayerX x2, int n_layer,
+                               const float* __restrict__ feat, const uint8_t* __restrict__ fvalid, int n_tok, int n_pad,
+                               float* __restrict__ Kout, float* __restrict__ VTout, float* __restrict__ kbias);
+
 void launch_kv_hoist_nx(const float* W, const XLayerW* L, const XLayerX* X, int n_layer, const float* feat, const uint8_t* fvalid, int G,
                         int n_tok, int n_pad, float* K, float* VT, float* kbias, hipStream_t s) {
     dim3 grid(n_pad / TM, G);
     const int i1 = n_layer > 1 ? 1 : 0, i2 = n_layer > 2 ? 2 : 0;
+    dim3 grid2(n_pad / (2 * TM), G);
+    if (n_tok > TM && (int)grid2.x * G >= 256) {  // (n_pad is a multiple of 32: token tiles pair up)
+        hipLaunchKernelGGL(k_kv_hoist_nx2, grid2, dim3(NTHREADS), 2 * TM * LDT * sizeof(float) + 2 * PLANES_BYTES, s, W, L[0], L[i1], L[i2],
+                           X[0], X[i1], X[i2], n_layer, feat, fvalid, n_tok, n_pad, K, VT, kbias);
+        return;
+    }
     hipLaunchKernelGGL(k_kv_hoist_nx, grid, dim3(NTHREADS), TM * LDT * sizeof(float) + PLANES_BYTES, s, W, L[0], L[i1], L[i2], X[0], X[i1],
                        X[i2], n_layer, feat, fvalid, n_tok, n_pad, K, VT, kbias);
 }
@@ -80,7 +90,86 @@ __global__ __launch_bounds__(NTHREADS) void k_xattn_block_x(XBlockPX p) {
     store_tile(p.dst + ((size_t)g * p.n_rows + row0) * H, X, LDT, n_real, tid);
 }
 
+// Two row tiles per workgroup (xattn_layer_x2): grid (ceil(n_rows/32), G)
+template <bool EYE>
+__global__ __launch_bounds__(NTHREADS) void k_xattn_block_x2(XBlockPX p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* X0 = smem;
+    float* X1 = X0 + TM * LDT;
+    xhalf* PA0 = reinterpret_cast<xhalf*>(X1 + TM * LDT);
+    xhalf* PA1 = PA0 + NPL * PLANE;
+    xhalf* PB0 = PA1 + NPL * PLANE;
+    xhalf* PB1 = PB0 + NPL * PLANE;
+    uint8_t* rowvalid = reinterpret_cast<uint8_t*>(PB1 + NPL * PLANE);  // [32]
+    uint8_t* novalid_s = rowvalid + 32;                                 // [32]
+    const int tid = threadIdx.x, wave = wave_of(tid), lane = tid & 63, g = blockIdx.y, row0 = blockIdx.x * 2 * TM;
+    const int n_real0 = max(0, min(TM, p.n_rows - row0)), n_real1 = max(0, min(TM, p.n_rows - row0 - TM));
+    WUnitX u;
+    wloadx(u, xlayer_first_x(p.W, p.L[0], p.LX[0], wave), lane);
+    load_tile(X0, LDT, p.src + ((size_t)g * p.n_rows + row0) * H, n_real0, tid);
+    load_tile(X1, LDT, p.src + ((size_t)g * p.n_rows + row0 + TM) * H, n_real1, tid);
+    if (tid < 2 * TM) rowvalid[tid] = row0 + tid < p.n_rows ? p.src_valid[(size_t)g * p.n_rows + row0 + tid] : 0;
+    bool bypass = false;
+    if (EYE) {
+        const int cnt = __syncthreads_count(tid < p.n_rows && p.src_valid[(size_t)g * p.n_rows + tid]);
+        bypass = cnt == 1;
+    } else {
+        __syncthreads();
+    }
+    if (!bypass) {
+        const size_t ls = (size_t)p.n_pad * H;
+        const xhalf* K0 = reinterpret_cast<const xhalf*>(p.K + ((size_t)g * p.n_layer) * ls);
+        const xhalf* V0 = reinterpret_cast<const xhalf*>(p.VT + ((size_t)g * p.n_layer) * ls);
+        const float* kb = p.kbias + (size_t)g * p.n_pad;
+#pragma unroll 1
+        for (int l = 0; l < p.n_layer; ++l) {
+            const int ln = l + 1 < p.n_layer ? l + 1 : l;
+            xattn_layer_x2<EYE>(p.W, p.L[l], p.LX[l], X0, X1, PA0, PA1, PB0, PB1, K0 + 2 * l * ls, V0 + 2 * l * ls, kb, p.n_pad,
+                                EYE ? row0 : -1, EYE ? row0 + TM : -1, rowvalid, rowvalid + TM, novalid_s, novalid_s + TM, tid, u,
+                                xlayer_first_x(p.W, p.L[ln], p.LX[ln], wave));
+        }
+    }
+    store_tile(p.dst + ((size_t)g * p.n_rows + row0) * H, X0, LDT, n_real0, tid);
+    store_tile(p.dst + ((size_t)g * p.n_rows + row0 + TM) * H, X1, LDT, n_real1, tid);
+}
+
+// K/V hoist, two token tiles per workgroup: grid (n_pad/32, G)
+__global__ __launch_bounds__(NTHREADS) void k_kv_hoist_nx2(const float* __restrict__ W, XLayerW l0, XLayerW l1, XLayerW l2, XLayerX x0,
+                                                          XLayerX x1, XLayerX x2, int n_layer, const float* __restrict__ feat,
+                                                          const uint8_t* __restrict__ fvalid, int n_tok, int n_pad,
+                                                          float* __restrict__ Kout, float* __restrict__ VTout, float* __restrict__ kbias) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* T0 = smem;
+    float* T1 = T0 + TM * LDT;
+    xhalf* P1a = reinterpret_cast<xhalf*>(T1 + TM * LDT);
+    xhalf* P1b = P1a + NPL * PLANE;
+    const int tid = threadIdx.x, wave = wave_of(tid), lane = tid & 63, g = blockIdx.y, tok0 = blockIdx.x * 2 * TM;
+    const int n_real0 = max(0, min(TM, n_tok - tok0)), n_real1 = max(0, min(TM, n_tok - tok0 - TM));
+    WUnitX u;
+    wloadx(u, kvproj_first_x(W, l0, x0, wave), lane);
+    load_tile(T0, LDT, feat + ((size_t)g * n_tok + tok0) * H, n_real0, tid);
+    load_tile(T1, LDT, feat + ((size_t)g * n_tok + tok0 + TM) * H, n_real1, tid);
+    if (tid < 2 * TM)
+        kbias[(size_t)g * n_pad + tok0 + tid] = (tok0 + tid < n_tok && fvalid[(size_t)g * n_tok + tok0 + tid]) ? 0.f : -INFINITY;
+    __syncthreads();
+    const size_t ls = (size_t)n_pad * H;
+    xhalf* K0 = reinterpret_cast<xhalf*>(Kout + ((size_t)g * n_layer) * ls);
+    xhalf* V0 = reinterpret_cast<xhalf*>(VTout + ((size_t)g * n_layer) * ls);
+    kv_project_tile_x2(W, l0, x0, T0, T1, P1a, P1b, K0, V0, tok0, n_real0, n_real1, tid, u, kvproj_first_x(W, l1, x1, wave));
+    if (n_layer > 1)
+        kv_project_tile_x2(W, l1, x1, T0, T1, P1a, P1b, K0 + 2 * ls, V0 + 2 * ls, tok0, n_real0, n_real1, tid, u, kvproj_first_x(W, l2, x2, wave));
+    if (n_layer > 2)
+        kv_project_tile_x2(W, l2, x2, T0, T1, P1a, P1b, K0 + 4 * ls, V0 + 4 * ls, tok0, n_real0, n_real1, tid, u, kvproj_first_x(W, l2, x2, wave));
+}
+
 void launch_xblock_x(const XBlockPX& p, int G, hipStream_t s) {
+    dim3 grid2((p.n_rows + 2 * TM - 1) / (2 * TM), G);
+    if (p.n_rows > TM && (int)grid2.x * G >= 256) {  // two row tiles per workgroup share every weight unit -- when that still fills the chip
+        const size_t lds2 = 2 * TM * LDT * sizeof(float) + 4 * PLANES_BYTES + 64;
+        if (p.eye) hipLaunchKernelGGL(k_xattn_block_x2<true>, grid2, dim3(NTHREADS), lds2, s, p);
+        else hipLaunchKernelGGL(k_xattn_block_x2<false>, grid2, dim3(NTHREADS), lds2, s, p);
+        return;
+    }
     dim3 grid((p.n_rows + TM - 1) / TM, G);
     const size_t lds = TM * LDT * sizeof(float) + 2 * PLANES_BYTES + 32;
     if (p.eye) hipLaunchKernelGGL(k_xattn_block_x<true>, grid, dim3(NTHREADS), lds, s, p);
