@@ -339,11 +339,12 @@ __global__ __launch_bounds__(NTHREADS) void k_step_x(RolloutP p, int t, int do_c
             store_tile(p.tap_agent_feature + ((size_t)(n + k) * p.n_agent + row0) * H, X, LDT, n_real, tid);
     TB_STAMP(8);
     const int g_tl = b * p.n_tl_hist + min(t1 - 1, p.n_tl_hist - 1);
-    // no lit traffic light at this step (valid keys are compacted to the front, so slot 0 tells): as2tl keeps only its FFN halves
-    const bool tl_empty = p.kbias_tl[(size_t)g_tl * p.t_pad] == -INFINITY;
+    // no lit traffic light at this step (the hoist counted the valid keys): as2tl keeps only its FFN halves
+    const int nk_t_raw = p.nkey_tl[g_tl];
+    const bool tl_empty = nk_t_raw == 0;
     {
         const float* kvd = p.kbias_pl + (size_t)b * p.p_pad;
-        const int nk_p = p.nkey_pl[b];  // valid polylines, compacted to the front by the hoist, rounded up to whole key blocks
+        const int nk_p = max(32, p.nkey_pl[b]);  // valid polylines, compacted to the front by the hoist, rounded up to whole key blocks
         const int ks_p = ((rt * (nk_p >> 5)) / n_rt) << 5;
         const size_t ls = (size_t)p.p_pad * H;
         const xhalf* K0 = reinterpret_cast<const xhalf*>(p.kpl + ((size_t)b * 3) * ls);
@@ -366,7 +367,7 @@ __global__ __launch_bounds__(NTHREADS) void k_step_x(RolloutP p, int t, int do_c
                           LN + 8 * 768);
     } else {
         const float* kvd = p.kbias_tl + (size_t)g_tl * p.t_pad;
-        const int nk_t = p.nkey_tl[g_tl];
+        const int nk_t = nk_t_raw;
         const int ks_t = ((rt * (nk_t >> 5)) / n_rt) << 5;
         const size_t ls = (size_t)p.t_pad * H;
         const xhalf* K0 = reinterpret_cast<const xhalf*>(p.ktl + ((size_t)g_tl * 3) * ls);
@@ -443,7 +444,7 @@ __global__ __launch_bounds__(NTHREADS) void k_kv_hoist_x(const float* __restrict
         slot[tid] = (sl >= 0 && tid < n_real) ? sl + cnt_s[0] : -1;
         kbias[(size_t)g * n_pad + tok0 + tid] = (tok0 + tid < n_valid) ? 0.f : -INFINITY;
     }
-    if (tid == 0 && blockIdx.x == 0) nkey[g] = max(32, (n_valid + 31) & ~31);
+    if (tid == 0 && blockIdx.x == 0) nkey[g] = (n_valid + 31) & ~31;  // 0: the group has no valid target at all
     __syncthreads();
     const size_t ls = (size_t)n_pad * H;  // floats per (group, layer) = fp16 per plane
     xhalf* K0 = reinterpret_cast<xhalf*>(Kout + ((size_t)g * 3) * ls);
