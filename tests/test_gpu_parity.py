@@ -671,6 +671,47 @@ def test_row_tiles_of_an_instance_may_run_apart():
         assert torch.equal(small["rollout_buffer"].preds, big["rollout_buffer"].preds[b0:b0 + 4]), b0
 
 
+def test_packed_h5_loader_drives_validation_and_test_steps(tmp_path):
+    """SURVEY 8(f)-4 end to end: episodes written in the reference's packed-h5 format and read back by the native loader (decoded on
+    the host into the C-ABI layout, uploaded from pinned buffers) give bit-identical validation_step / test_step results to the same
+    episodes handed over as an in-memory batch of the reference's layout."""
+    from trafficbots_amd import data_h5, synth
+
+    scene = dict(n_agent=20, n_pl=48, n_tl=12, p_invalid_agent=0.2, p_late_spawn=0.3, p_future_spawn=0.4, p_future_exit=0.3, pos_range=60.0)
+    episodes, attrs = synth.make_h5_episodes(9900, 5, **scene)
+    data_h5.write_packed_h5(str(tmp_path / "validation.h5"), episodes, attrs)
+    data_h5.write_packed_h5(str(tmp_path / "testing.h5"), [{k: v for k, v in e.items() if k.startswith(("history/", "map/"))} for e in episodes], attrs)
+    dm = data_h5.DataH5womd(str(tmp_path), batch_size=2, n_agent=20, n_pl=48, n_tl_stop=12)
+    for table in (dm.tensor_size_val, dm.tensor_size_test):
+        for k in list(table):
+            table[k] = episodes[0][k].shape  # (the synthetic agent_no_sim / tl_lane tensors are smaller than Waymo's)
+    sd = synth.make_state_dict(9901)
+    wm = _engine({"time_step_end": 90, "n_joint_future": 1}, sd)
+    dm.setup("validate")
+    n = 0
+    for batch in dm.val_dataloader():
+        idx = batch["episode_idx"].tolist()
+        assert batch["packed/agent_pos"].is_pinned()
+        mem = {k: np.stack([episodes[i][k] for i in idx]) for k in episodes[0]}
+        a, b = wm.validation_step(batch), wm.validation_step(mem)
+        for part in ("reactive_replay", "joint_future_pred"):
+            assert torch.equal(a[part]["rollout_buffer"].preds, b[part]["rollout_buffer"].preds), part
+            assert torch.equal(a[part]["rollout_buffer"].valid, b[part]["rollout_buffer"].valid), part
+        assert torch.equal(a["reactive_replay"]["train_states"], b["reactive_replay"]["train_states"])
+        assert torch.equal(a["latent_post"].mean, b["latent_post"].mean)
+        n += len(idx)
+    assert n == 5
+    wm3 = _engine({"time_step_end": 40, "n_joint_future": 3}, sd)
+    dm.setup("test")
+    for batch in dm.test_dataloader():
+        idx = batch["episode_idx"].tolist()
+        mem = {k: np.stack([episodes[i][k] for i in idx]) for k in episodes[0] if k.startswith(("history/", "map/"))}
+        eps = torch.from_numpy(synth.make_latent_noise(9902, len(idx) * 3, 20)).cuda()
+        a, b = wm3.test_step(batch, latent_eps=eps), wm3.test_step(mem, latent_eps=eps)
+        assert torch.equal(a["rollout_buffer"].preds, b["rollout_buffer"].preds)
+        assert torch.equal(a["goal_sample"], b["goal_sample"])
+
+
 def test_empty_and_bad_inputs_fail_loudly():
     from trafficbots_amd import synth
     from trafficbots_amd.waymo_motion import WaymoMotion

@@ -1,0 +1,192 @@
+"""SURVEY 8(f)-4, host side: the packed-h5 reader against the numpy restatement of the reference's datasets
+(`oracle/h5_oracle.py`, parity unpinned -- see its header) and against the content the files were written from."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import h5_oracle
+from trafficbots_amd import data_h5, synth
+from trafficbots_amd.runtime import gt_from_batch, scene_from_batch
+
+SCENE = dict(n_agent=7, n_pl=12, n_tl=5, p_invalid_agent=0.3, p_late_spawn=0.3, p_early_exit=0.2, p_invalid_pl=0.2)
+N_NO_SIM = 4
+
+
+@pytest.fixture(scope="module")
+def packed(tmp_path_factory):
+    d = tmp_path_factory.mktemp("h5")
+    episodes, attrs = synth.make_h5_episodes(4100, 5, **SCENE)
+    data_h5.write_packed_h5(str(d / "validation.h5"), episodes, attrs)
+    test_keys = [k for k in episodes[0] if k.startswith("history/") or k.startswith("map/")]
+    data_h5.write_packed_h5(str(d / "testing.h5"), [{k: e[k] for k in test_keys} for e in episodes], attrs)
+    train_keys = None
+    dm = data_module(str(d))
+    train_keys = list(dm.tensor_size_train)
+    data_h5.write_packed_h5(str(d / "training.h5"), [{k: e[k] for k in train_keys} for e in episodes])
+    return str(d), episodes, attrs
+
+
+def data_module(data_dir, **kw):
+    dm = data_h5.DataH5womd(data_dir, batch_size=2, n_agent=kw.pop("n_agent", SCENE["n_agent"]), n_pl=SCENE["n_pl"], n_tl_stop=SCENE["n_tl"], **kw)
+    # the synthetic files are smaller than Waymo's in the two sizes the reference hard-codes
+    for table in (dm.tensor_size_train, dm.tensor_size_test, dm.tensor_size_val):
+        for k, size in list(table.items()):
+            if "agent_no_sim" in k:
+                table[k] = tuple(N_NO_SIM if s == 256 else s for s in size)
+            if "tl_lane" in k:
+                table[k] = tuple(6 if s == 100 else s for s in size)
+    return dm
+
+
+def test_library_exports_every_declared_symbol():
+    lib = data_h5.load()
+    header = open(os.path.join(os.path.dirname(__file__), "..", "include", "trafficbots_h5.h")).read()
+    for name in data_h5.EXPORTS:
+        assert name + "(" in header
+        getattr(lib, name)
+    import re
+    declared = set(re.findall(r"\b(tb_h5_\w+)\(", header))
+    assert declared == set(data_h5.EXPORTS)
+
+
+def test_file_round_trip_is_exact(packed):
+    d, episodes, attrs = packed
+    assert h5_oracle.dataset_len(d + "/validation.h5") == 5
+    f = data_h5.PackedH5File(d + "/validation.h5")
+    assert len(f) == 5
+    for i in (0, 4):
+        a = f.episode_attrs(i)
+        assert a["scenario_id"] == attrs[i]["scenario_id"] and a["with_map"] == attrs[i]["with_map"]
+        assert np.array_equal(a["scenario_center"], attrs[i]["scenario_center"]) and a["scenario_yaw"] == attrs[i]["scenario_yaw"]
+        sample = h5_oracle.getitem_val(d + "/validation.h5", {k: v.shape for k, v in episodes[i].items()}, i)
+        for k, v in episodes[i].items():
+            assert sample[k].dtype == v.dtype and np.array_equal(sample[k], v), k
+            assert f.dataset_shape(i, k) == v.shape
+
+
+@pytest.mark.parametrize("split", ["val", "test", "train"])
+def test_reference_batch_matches_dataset_restatement(packed, split):
+    d, _, _ = packed
+    dm = data_module(d)
+    path, table = {"val": (dm.path_val_h5, dm.tensor_size_val), "test": (dm.path_test_h5, dm.tensor_size_test),
+                   "train": (dm.path_train_h5, dm.tensor_size_train)}[split]
+    idx = [3, 0, 4]
+    get = h5_oracle.getitem_train if split == "train" else h5_oracle.getitem_val
+    want = h5_oracle.collate([get(path, table, i) for i in idx])
+    got = data_h5.PackedH5File(path).read_reference_batch(idx, table, with_attrs=split != "train")
+    assert set(got) == set(want)
+    for k, w in want.items():
+        if isinstance(w, list):
+            assert got[k] == w
+            continue
+        g = got[k].numpy()
+        assert g.dtype == w.dtype and g.shape == w.shape and np.array_equal(g, w), k
+
+
+@pytest.mark.parametrize("split", ["val", "test", "train"])
+def test_packed_batch_equals_preprocessing_of_the_reference_batch(packed, split):
+    """decode-in-the-reader == `scene_from_batch` / `gt_from_batch` applied to what the reference's DataLoader would yield"""
+    d, _, _ = packed
+    dm = data_module(d)
+    dm.setup({"val": "validate", "test": "test", "train": "fit"}[split])
+    loader = {"val": dm.val_dataloader, "test": dm.test_dataloader, "train": dm.train_dataloader}[split]()
+    assert len(loader) == 3
+    path, table = (loader.filepath, loader.tensor_size)
+    get = h5_oracle.getitem_train if split == "train" else h5_oracle.getitem_val
+    n_seen = 0
+    for batch in loader:
+        idx = batch["episode_idx"].tolist()
+        n_seen += len(idx)
+        ref = h5_oracle.collate([get(path, table, i) for i in idx])
+        if split == "train":  # scene_centric.py:103-133: the history is the first 11 steps of the episode
+            for k in list(ref):
+                if k.startswith("agent/") or k.startswith("tl_stop/"):
+                    ref["history/" + k] = ref[k][:, :11] if k.rsplit("/", 1)[-1] in data_h5._STEP_KEYS else ref[k]
+        else:
+            assert batch["scenario_id"] == ref["scenario_id"]
+            assert np.array_equal(batch["scenario_center"].numpy(), ref["scenario_center"])
+            assert np.array_equal(batch["with_map"].numpy(), ref["with_map"])
+        want = scene_from_batch(ref, "cpu")
+        if split != "test":
+            want["gt"] = gt_from_batch(ref, "cpu")
+        got = data_h5.scene_from_packed(batch, "cpu")
+
+        def same(a, b, where):
+            assert set(a) == set(b), (where, set(a) ^ set(b))
+            for k in a:
+                if isinstance(a[k], dict):
+                    same(a[k], b[k], where + k + "/")
+                elif isinstance(a[k], bool):
+                    assert a[k] == b[k], where + k
+                else:
+                    assert a[k].dtype == b[k].dtype and a[k].shape == b[k].shape and torch.equal(a[k], b[k]), where + k
+
+        same(want, got, "")
+    assert n_seen == 5
+    if split != "train":
+        assert sorted(sum((b["episode_idx"].tolist() for b in loader), [])) == list(range(5))  # re-iterable
+
+
+@pytest.mark.parametrize("storage", [dict(chunk_div=2), dict(chunk_div=3, shuffle=False), dict(chunk_div=2, deflate=0), dict(chunk_div=0, deflate=0),
+                                     dict(chunk_div=1, deflate=9)])
+def test_storage_forms_and_reader_paths_agree(packed, tmp_path, storage):
+    """multi-chunk tensors with partial edge chunks (what h5py's automatic chunking produces), unshuffled / uncompressed / contiguous
+    storage: the threaded chunk decoder, the single-threaded one and the H5Dread path (n_threads = 0) give the stored content"""
+    _, episodes, attrs = packed
+    path = str(tmp_path / "v.h5")
+    data_h5.write_packed_h5(path, episodes, attrs, **storage)
+    dm = data_module(str(tmp_path))
+    f = data_h5.PackedH5File(path)
+    idx = [4, 1, 2]
+    specs = [(k, size, data_h5.reference_kind(k), 0, False) for k, size in dm.tensor_size_val.items()]
+    specs += [("agent/pos", dm.tensor_size_val["agent/pos"], data_h5.F32, 11, False), ("tl_stop/state", dm.tensor_size_val["tl_stop/state"], data_h5.ONEHOT_I32, 47, False),
+              ("agent/valid", dm.tensor_size_val["agent/valid"], data_h5.MASK_U8, 46, False), ("map/type", dm.tensor_size_val["map/type"], data_h5.ONEHOT_I32, 0, False)]
+    a, b, c = (f.read_keys(idx, specs, n_threads=n) for n in (8, 1, 0))
+    for (key, size, kind, lead, _), ta, tb, tc in zip(specs, a, b, c):
+        assert torch.equal(ta, tb) and torch.equal(ta, tc), key
+        want = np.stack([episodes[i][key] for i in idx])
+        if lead:
+            want = want[:, :lead]
+        if kind == data_h5.ONEHOT_I32:
+            want = np.where(want.any(-1), want.argmax(-1), -1).astype(np.int32)
+        assert np.array_equal(ta.numpy(), want.astype(ta.numpy().dtype)), key
+
+
+def test_agent_count_override_yields_dummy_agents(packed):
+    """`data_h5_womd.py:50-52`: an agent tensor whose stored shape differs from the configured one is replaced by ones"""
+    d, _, _ = packed
+    dm = data_module(d, n_agent=9)
+    ref = h5_oracle.collate([h5_oracle.getitem_val(dm.path_test_h5, dm.tensor_size_test, i) for i in (1, 2)])
+    got = data_h5.PackedH5File(dm.path_test_h5).read_reference_batch([1, 2], dm.tensor_size_test, with_attrs=True)
+    for k, w in ref.items():
+        if not isinstance(w, list):
+            assert np.array_equal(got[k].numpy(), w), k
+    assert got["history/agent/pos"].shape == (2, 11, 9, 2) and bool((got["history/agent/pos"] == 1).all())
+    packed_batch = data_h5.PackedH5File(dm.path_test_h5).read_packed_batch([1, 2], dm.tensor_size_test, "test")
+    assert bool((packed_batch["packed/agent_type"] == 0).all()) and bool((packed_batch["packed/agent_valid"] == 1).all())
+    assert packed_batch["packed/map_pos"].shape == (2, 12, 20, 2)
+
+
+def test_sharded_loaders_partition_the_file(packed):
+    d, _, _ = packed
+    seen = []
+    for r in range(2):
+        dm = data_module(d, rank=r, world_size=2)
+        dm.setup("validate")
+        seen.append(sum((b["episode_idx"].tolist() for b in dm.val_dataloader()), []))
+    assert seen == [[0, 2, 4], [1, 3]]
+
+
+def test_errors_are_loud(packed, tmp_path):
+    d, _, _ = packed
+    with pytest.raises(RuntimeError, match="cannot open"):
+        data_h5.PackedH5File(str(tmp_path / "missing.h5"))
+    f = data_h5.PackedH5File(d + "/testing.h5")
+    with pytest.raises(RuntimeError, match="no dataset"):
+        f.read_key([0], "agent/goal", (7, 4), data_h5.F32)  # a testing file holds no ground truth
+    with pytest.raises(RuntimeError, match="differs"):
+        f.read_key([0], "map/pos", (13, 20, 2), data_h5.F32)  # only agent tensors may be replaced by dummies
+    with pytest.raises(RuntimeError, match="no dataset"):
+        f.read_key([7], "map/pos", (12, 20, 2), data_h5.F32)

@@ -261,6 +261,34 @@ def make_val_batch(base_seed: int, n_scene: int, scene_offset: int = 0, **kw) ->
     return {k: np.stack([s[k] for s in scenes], 0) for k in scenes[0].keys()}
 
 
+def make_h5_episodes(base_seed: int, n_episode: int, n_tl_lane: int = 6, **kw):
+    """Per-episode tensor dicts holding every key of `DataH5womd.tensor_size_val` (`data_h5_womd.py:85-173`), ready for
+    `data_h5.write_packed_h5`: :func:`make_val_scene` plus seeded filler for the tensors the hot path never reads (tl_lane/*, the
+    91-step agent_no_sim/*), and the episode attributes of `pack_h5_womd.py:379-382`."""
+    episodes, attrs = [], []
+    for i in range(n_episode):
+        ep = dict(make_val_scene(base_seed + i, **kw))
+        rs = RawStream(base_seed + i + 7919)
+        n_ns = ep["history/agent_no_sim/valid"].shape[1]
+        for pre, s in (("", N_STEP_GT), ("history/", N_STEP_HIST)):
+            ep[f"{pre}tl_lane/valid"] = rs.bernoulli(0.5, (s, n_tl_lane))
+            st = np.zeros((s, n_tl_lane, N_TL_STATE), bool)
+            np.put_along_axis(st, rs.integers(N_TL_STATE, (s, n_tl_lane))[..., None], True, -1)
+            ep[f"{pre}tl_lane/state"] = st
+            ep[f"{pre}tl_lane/idx"] = rs.integers(40, (s, n_tl_lane)).astype(np.int64) - 1
+        ep["agent_no_sim/valid"] = rs.bernoulli(0.6, (N_STEP_GT, n_ns))
+        for k, c in (("pos", 2), ("z", 1), ("vel", 2), ("spd", 1), ("yaw_bbox", 1)):
+            ep[f"agent_no_sim/{k}"] = rs.uniform(-20, 20, (N_STEP_GT, n_ns, c)).astype(np.float32)
+        ep["agent_no_sim/type"] = ep["history/agent_no_sim/type"]
+        ep["agent_no_sim/size"] = ep["history/agent_no_sim/size"]
+        ep["agent_no_sim/object_id"] = np.arange(1000, 1000 + n_ns, dtype=np.int64)
+        ep["history/agent_no_sim/object_id"] = ep["agent_no_sim/object_id"]
+        episodes.append(ep)
+        attrs.append({"scenario_id": f"synth{base_seed + i:08x}", "scenario_center": rs.uniform(-500, 500, (2,)),
+                      "scenario_yaw": float(rs.uniform(-3.1, 3.1, (1,))[0]), "with_map": bool(i % 3 != 2)})
+    return episodes, attrs
+
+
 def make_post_inputs(seed: int, n_scene: int, n_agent: int, n_pred: int, n_step: int = 80):
     """Seeded inputs of `WaymoPostProcessing.forward` (valid [B,A], scores [B,A,NP] un-normalised, trajs [B,A,NP,S,4],
     agent_type [B,A,3]): clustered futures -- five base paths per agent plus small per-mode perturbations -- so that NMS has

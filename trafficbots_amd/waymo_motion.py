@@ -148,6 +148,10 @@ class WaymoMotion:
         (`scene_centric.py:103-133`, `sc_input.py:100-140`); attr/PE/MLP run inside `tb_encode_scene`.  A validation /
         training batch (one that carries "agent/valid") also yields the full ground truth as the nested dict `scene["gt"]`
         (`scene_centric.py:103-110`, `sc_latent.py:150-163,196-217`)."""
+        if "packed/agent_valid" in batch:  # a `data_h5.PackedSceneLoader` batch: decoded by the reader, upload only
+            from .data_h5 import scene_from_packed
+
+            return scene_from_packed(batch, self.device, self.n_hist)
         scene = scene_from_batch(batch, self.device, self.n_hist)
         if "agent/valid" in batch:
             scene["gt"] = gt_from_batch(batch, self.device)
