@@ -53,6 +53,10 @@ int64_t tb_h5_len(const tb_h5_file* f);
 int32_t tb_h5_episode_attrs(tb_h5_file* f, int64_t episode, char* scenario_id, int32_t id_cap, double center[3], int32_t* n_center,
                             double* yaw, int32_t* with_map);
 
+/* the same for a batch in one call: scenario_ids [n_episode, id_cap] bytes, centers [n_episode, 3], the rest [n_episode] */
+int32_t tb_h5_batch_attrs(tb_h5_file* f, const int64_t* episodes, int32_t n_episode, char* scenario_ids, int32_t id_cap, double* centers,
+                          int32_t* n_center, double* yaws, int32_t* with_maps);
+
 /* Stored shape of "<episode>/<key>": rank (<= 8) and dims; elem_size in bytes. */
 int32_t tb_h5_dataset_shape(tb_h5_file* f, int64_t episode, const char* key, int32_t* rank, int64_t dims[8], int32_t* elem_size);
 
@@ -83,6 +87,11 @@ typedef struct tb_h5_key_spec {
  * everything through H5Dread. */
 int32_t tb_h5_read_batch(tb_h5_file* f, const int64_t* episodes, int32_t n_episode, const tb_h5_key_spec* specs, int32_t n_spec,
                          int32_t n_threads);
+
+/* tb_h5_read_batch remembers, per handle, the stored form and chunk extents of every (episode, key) it has visited, so that the next
+ * visit of that episode (the next validation epoch, training's random re-draws) makes no HDF5 call at all.  max_entries bounds that
+ * index (default 2^20 tensors, about 150 bytes each); 0 disables and clears it.  The file must not change while it is open. */
+int32_t tb_h5_set_index_cache(tb_h5_file* f, int64_t max_entries);
 
 /* ---- writer (pack_h5_womd.py:235,378-392) ---- */
 int32_t tb_h5_writer_open(const char* path, tb_h5_writer** out);

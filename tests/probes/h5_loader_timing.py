@@ -56,6 +56,28 @@ with tempfile.TemporaryDirectory() as d:
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
             print(f"loader -> validation_step pass {rep}: {dt / n_ep * 1e3:.2f} ms / episode at batch {bs}")
+        pre = list(loader)
+        for rep in range(2):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for batch in pre:
+                out = wm.validation_step(batch)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            print(f"already-read packed batches -> validation_step pass {rep}: {dt / n_ep * 1e3:.2f} ms / episode")
+        it, waited = iter(loader), 0.0
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        while True:
+            w0 = time.perf_counter()
+            batch = next(it, None)
+            waited += time.perf_counter() - w0
+            if batch is None:
+                break
+            out = wm.validation_step(batch)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        print(f"loader -> validation_step: {dt / n_ep * 1e3:.2f} ms / episode, of which {waited / n_ep * 1e3:.2f} ms waiting for the reader")
         mem = [{k: np.stack([episodes[i][k] for i in range(j, j + bs)]) for k in episodes[0]} for j in range(0, n_ep, bs)]
         torch.cuda.synchronize()
         t0 = time.perf_counter()

@@ -707,9 +707,10 @@ def test_packed_h5_loader_drives_validation_and_test_steps(tmp_path):
         idx = batch["episode_idx"].tolist()
         mem = {k: np.stack([episodes[i][k] for i in idx]) for k in episodes[0] if k.startswith(("history/", "map/"))}
         eps = torch.from_numpy(synth.make_latent_noise(9902, len(idx) * 3, 20)).cuda()
-        a, b = wm3.test_step(batch, latent_eps=eps), wm3.test_step(mem, latent_eps=eps)
-        assert torch.equal(a["rollout_buffer"].preds, b["rollout_buffer"].preds)
+        gen = lambda: torch.Generator(device="cuda").manual_seed(9903)  # the K destination draws
+        a, b = wm3.test_step(batch, latent_eps=eps, generator=gen()), wm3.test_step(mem, latent_eps=eps, generator=gen())
         assert torch.equal(a["goal_sample"], b["goal_sample"])
+        assert torch.equal(a["rollout_buffer"].preds, b["rollout_buffer"].preds)
 
 
 def test_empty_and_bad_inputs_fail_loudly():

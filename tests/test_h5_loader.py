@@ -154,6 +154,26 @@ def test_storage_forms_and_reader_paths_agree(packed, tmp_path, storage):
         assert np.array_equal(ta.numpy(), want.astype(ta.numpy().dtype)), key
 
 
+def test_chunk_index_makes_second_visit_metadata_free(packed, capfd):
+    d, episodes, _ = packed
+    dm = data_module(d)
+    f = data_h5.PackedH5File(dm.path_val_h5)
+    specs = [(k, size, data_h5.reference_kind(k), 0, False) for k, size in dm.tensor_size_val.items()]
+    os.environ["TB_H5_DEBUG"] = "1"
+    try:
+        first = f.read_keys([0, 3], specs)
+        second = f.read_keys([3, 0], specs)
+        f.set_index_cache(0)
+        third = f.read_keys([0, 3], specs)
+    finally:
+        del os.environ["TB_H5_DEBUG"]
+    log = [l for l in capfd.readouterr().err.splitlines() if "tb_h5_read_batch" in l]
+    n = 2 * len(specs)
+    assert f"({n} probed" in log[0] and "(0 probed" in log[1] and f"({n} probed" in log[2], log
+    for a, b, c in zip(first, second, third):
+        assert torch.equal(a, b.flip(0)) and torch.equal(a, c)
+
+
 def test_agent_count_override_yields_dummy_agents(packed):
     """`data_h5_womd.py:50-52`: an agent tensor whose stored shape differs from the configured one is replaced by ones"""
     d, _, _ = packed

@@ -19,6 +19,7 @@
 #include <mutex>
 #include <string>
 #include <thread>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/trafficbots_h5.h"
@@ -79,7 +80,11 @@ struct tb_h5_file {
     int64_t len = 0;
     int fd = -1;       // second, plain descriptor of the same file: chunk bytes are pread() outside the HDF5 library
     haddr_t base = 0;  // user block size: chunk addresses are relative to it
+    struct tb_h5_index* index = nullptr;  // stored forms + chunk extents of the tensors visited so far
 };
+
+struct tb_h5_index* tb_h5_new_index();
+void tb_h5_free_index(struct tb_h5_index*);
 
 struct tb_h5_writer {
     hid_t file = -1;
@@ -113,6 +118,7 @@ int32_t tb_h5_open(const char* path, tb_h5_file** out) {
     f->file = file;
     f->len = len;
     f->fd = open(path, O_RDONLY);
+    f->index = tb_h5_new_index();
     {
         Hid fcpl(H5Fget_create_plist(file), H5Pclose);
         hsize_t ub = 0;
@@ -126,6 +132,7 @@ void tb_h5_close(tb_h5_file* f) {
     if (!f) return;
     if (f->file >= 0) H5Fclose(f->file);
     if (f->fd >= 0) close(f->fd);
+    tb_h5_free_index(f->index);
     delete f;
 }
 
@@ -186,6 +193,18 @@ int32_t tb_h5_episode_attrs(tb_h5_file* f, int64_t episode, char* scenario_id, i
         int any = 0;
         for (size_t i = 0; i < H5Tget_size(nt); ++i) any |= raw[i];
         *with_map = any != 0;
+    }
+    return 0;
+}
+
+int32_t tb_h5_batch_attrs(tb_h5_file* f, const int64_t* episodes, int32_t n_episode, char* scenario_ids, int32_t id_cap, double* centers,
+                          int32_t* n_center, double* yaws, int32_t* with_maps) {
+    if (!f || !episodes || !scenario_ids || id_cap < 1 || !centers || !n_center || !yaws || !with_maps)
+        return fail(TB_H5_ERR_ARG, "tb_h5_batch_attrs: null argument");
+    for (int32_t e = 0; e < n_episode; ++e) {
+        const int32_t rc = tb_h5_episode_attrs(f, episodes[e], scenario_ids + (size_t)e * (size_t)id_cap, id_cap, centers + 3 * e, n_center + e,
+                                               yaws + e, with_maps + e);
+        if (rc) return rc;
     }
     return 0;
 }
@@ -357,6 +376,93 @@ int32_t read_generic(tb_h5_file* f, hid_t d, hid_t sp, DsTask& t) {
 
 }  // namespace
 
+namespace {
+
+// what phase 1 learns about one stored tensor; kept per (episode, key) in the handle's index so that a later visit of the same
+// episode (next epoch, training's random re-draws) costs no HDF5 call at all
+struct ChunkRec {
+    haddr_t addr;
+    hsize_t nbytes;
+    unsigned filter_mask;
+    hsize_t coord[8];
+};
+struct StoredForm {
+    int rank = -1;
+    hsize_t dd[8] = {0}, cd[8] = {0};
+    size_t esz = 0;
+    H5T_class_t cls = H5T_NO_CLASS;
+    bool little = false, direct = false;  // direct: chunk extents known, storage in one of the expected forms
+    bool shuffle = false, deflate = false;
+    int shuffle_bit = -1, deflate_bit = -1;
+    hsize_t n_expected = 0;
+    std::vector<ChunkRec> chunks;
+};
+
+bool probe(hid_t d, hid_t sp, StoredForm& sf) {
+    sf.rank = H5Sget_simple_extent_ndims(sp);
+    if (sf.rank < 0 || sf.rank > 8) return false;
+    H5Sget_simple_extent_dims(sp, sf.dd, nullptr);
+    Hid ty(H5Dget_type(d), H5Tclose);
+    sf.cls = H5Tget_class(ty);
+    sf.esz = H5Tget_size(ty);
+    sf.little = sf.esz == 1 || H5Tget_order(ty) == H5T_ORDER_LE;
+    Hid dcpl(H5Dget_create_plist(d), H5Pclose);
+    const H5D_layout_t layout = H5Pget_layout(dcpl);
+    const int nf = H5Pget_nfilters(dcpl);
+    bool ok = sf.rank >= 1;
+    for (int i = 0; ok && i < nf; ++i) {
+        unsigned flags = 0, cfg = 0;
+        size_t nel = 0;
+        const H5Z_filter_t id = H5Pget_filter2(dcpl, (unsigned)i, &flags, &nel, nullptr, 0, nullptr, &cfg);
+        if (id == H5Z_FILTER_SHUFFLE && !sf.shuffle && !sf.deflate) sf.shuffle = true, sf.shuffle_bit = i;
+        else if (id == H5Z_FILTER_DEFLATE && !sf.deflate) sf.deflate = true, sf.deflate_bit = i;
+        else ok = false;
+    }
+    if (ok && layout == H5D_CHUNKED) {
+        H5Pget_chunk(dcpl, sf.rank, sf.cd);
+        hsize_t n_chunk = 0;
+        sf.n_expected = 1;
+        for (int i = 0; i < sf.rank; ++i) sf.n_expected *= sf.cd[i] ? (sf.dd[i] + sf.cd[i] - 1) / sf.cd[i] : 0;
+        ok = H5Dget_num_chunks(d, sp, &n_chunk) >= 0;
+        for (hsize_t c = 0; ok && c < n_chunk; ++c) {
+            ChunkRec r;
+            ok = H5Dget_chunk_info(d, sp, c, r.coord, &r.filter_mask, &r.addr, &r.nbytes) >= 0 && r.addr != HADDR_UNDEF;
+            if (ok) sf.chunks.push_back(r);
+        }
+    } else if (ok && layout == H5D_CONTIGUOUS && nf == 0) {
+        ChunkRec r;
+        r.addr = H5Dget_offset(d);
+        r.filter_mask = 0;
+        r.nbytes = sf.esz;
+        for (int i = 0; i < sf.rank; ++i) sf.cd[i] = sf.dd[i], r.coord[i] = 0, r.nbytes *= sf.dd[i];
+        sf.n_expected = 1;
+        ok = r.addr != HADDR_UNDEF && r.nbytes > 0;
+        if (ok) sf.chunks.push_back(r);
+    } else {
+        ok = false;
+    }
+    sf.direct = ok;
+    if (!ok) sf.chunks.clear();
+    return true;
+}
+
+}  // namespace
+
+struct tb_h5_index {
+    std::unordered_map<std::string, StoredForm> map;
+    size_t max_entries = (size_t)1 << 20;
+};
+
+tb_h5_index* tb_h5_new_index() { return new tb_h5_index(); }
+void tb_h5_free_index(tb_h5_index* p) { delete p; }
+
+extern "C" int32_t tb_h5_set_index_cache(tb_h5_file* f, int64_t max_entries) {
+    if (!f || max_entries < 0) return fail(TB_H5_ERR_ARG, "tb_h5_set_index_cache: bad argument");
+    f->index->max_entries = (size_t)max_entries;
+    if (f->index->map.size() > (size_t)max_entries) f->index->map.clear();
+    return 0;
+}
+
 extern "C" int32_t tb_h5_read_batch(tb_h5_file* f, const int64_t* episodes, int32_t n_episode, const tb_h5_key_spec* specs, int32_t n_spec,
                                     int32_t n_threads) {
     if (!f || !episodes || !specs || n_episode < 0 || n_spec < 0) return fail(TB_H5_ERR_ARG, "tb_h5_read_batch: bad argument");
@@ -365,17 +471,15 @@ extern "C" int32_t tb_h5_read_batch(tb_h5_file* f, const int64_t* episodes, int3
     std::deque<DsTask> tasks;  // stable addresses
     std::vector<ChunkTask> chunks;
     std::vector<std::vector<uint8_t>> stages;
-    struct Groups {  // the episode groups, opened once per batch
+    struct Groups {  // the episode groups, opened on first need, once per batch
         std::vector<hid_t> ids;
         ~Groups() {
             for (hid_t g : ids)
                 if (g >= 0) H5Gclose(g);
         }
     } groups;
-    for (int32_t e = 0; e < n_episode; ++e) {
-        groups.ids.push_back(H5Gopen2(f->file, std::to_string(episodes[e]).c_str(), H5P_DEFAULT));
-        if (groups.ids.back() < 0) return fail(TB_H5_ERR_IO, "tb_h5_read: no dataset " + std::to_string(episodes[e]) + "/ (episode group missing)");
-    }
+    groups.ids.assign((size_t)n_episode, -1);
+    size_t n_probed = 0;
     for (int32_t k = 0; k < n_spec; ++k) {
         const tb_h5_key_spec& sp_ = specs[k];
         const int rank = sp_.rank;
@@ -394,14 +498,32 @@ extern "C" int32_t tb_h5_read_batch(tb_h5_file* f, const int64_t* episodes, int3
             t.dst = (uint8_t*)sp_.out + (size_t)e * (size_t)n_out * osz;
             t.path = std::to_string(episodes[e]) + "/" + sp_.key;
             for (int i = 0; i < rank; ++i) t.lim[i] = (hsize_t)(i == 0 && sp_.n_lead > 0 ? sp_.n_lead : sp_.dims[i]);
-            Hid d(H5Dopen2(groups.ids[e], sp_.key, H5P_DEFAULT), H5Dclose);
-            if (!d.ok()) return fail(TB_H5_ERR_IO, "tb_h5_read: no dataset " + t.path);
-            Hid sp(H5Dget_space(d), H5Sclose);
-            bool same = H5Sget_simple_extent_ndims(sp) == rank;
-            if (same) {
-                H5Sget_simple_extent_dims(sp, t.dd, nullptr);
-                for (int i = 0; i < rank; ++i) same = same && (int64_t)t.dd[i] == sp_.dims[i];
+            // stored form: from the index, or from the file
+            StoredForm local;
+            const StoredForm* sf = nullptr;
+            auto hit = f->index->map.find(t.path);
+            if (hit != f->index->map.end()) sf = &hit->second;
+            hid_t d_id = -1, sp_id = -1;
+            auto open_ds = [&]() -> bool {
+                if (groups.ids[e] < 0) groups.ids[e] = H5Gopen2(f->file, std::to_string(episodes[e]).c_str(), H5P_DEFAULT);
+                if (groups.ids[e] < 0) return false;
+                d_id = H5Dopen2(groups.ids[e], sp_.key, H5P_DEFAULT);
+                if (d_id < 0) return false;
+                sp_id = H5Dget_space(d_id);
+                return sp_id >= 0;
+            };
+            Hid d_guard(-1, H5Dclose), sp_guard(-1, H5Sclose);
+            if (!sf) {
+                const bool opened = open_ds();
+                d_guard.id = d_id, sp_guard.id = sp_id;
+                if (!opened) return fail(TB_H5_ERR_IO, "tb_h5_read: no dataset " + t.path);
+                if (!probe(d_id, sp_id, local)) return fail(TB_H5_ERR_IO, "tb_h5_read: rank of " + t.path + " is not in 0..8");
+                ++n_probed;
+                if (f->index->map.size() < f->index->max_entries) sf = &(f->index->map[t.path] = std::move(local));
+                else sf = &local;
             }
+            bool same = sf->rank == rank;
+            for (int i = 0; same && i < rank; ++i) same = (int64_t)sf->dd[i] == sp_.dims[i];
             if (!same) {
                 if (!sp_.dummy_on_mismatch)
                     return fail(TB_H5_ERR_SHAPE, "tb_h5_read: stored shape of " + t.path + " differs from the configured one");
@@ -419,65 +541,38 @@ extern "C" int32_t tb_h5_read_batch(tb_h5_file* f, const int64_t* episodes, int3
             } else {
                 t.stage = t.dst;
             }
-            // storage form
-            Hid ty(H5Dget_type(d), H5Tclose);
-            const H5T_class_t cls = H5Tget_class(ty);
-            const size_t tsz = H5Tget_size(ty);
-            bool fast = f->fd >= 0 && n_threads > 0;
-            if (t.kind == TB_H5_F32) fast = fast && cls == H5T_FLOAT && tsz == 4 && H5Tget_order(ty) == H5T_ORDER_LE;
-            else if (t.kind == TB_H5_I64) fast = fast && cls == H5T_INTEGER && tsz == 8 && H5Tget_order(ty) == H5T_ORDER_LE;
-            else fast = fast && (cls == H5T_ENUM || cls == H5T_INTEGER) && tsz == 1;
-            t.esz = tsz;
-            Hid dcpl(H5Dget_create_plist(d), H5Pclose);
-            const H5D_layout_t layout = H5Pget_layout(dcpl);
-            const int nf = H5Pget_nfilters(dcpl);
-            for (int i = 0; fast && i < nf; ++i) {
-                unsigned flags = 0, cfg = 0;
-                size_t nel = 0;
-                const H5Z_filter_t id = H5Pget_filter2(dcpl, (unsigned)i, &flags, &nel, nullptr, 0, nullptr, &cfg);
-                if (id == H5Z_FILTER_SHUFFLE && !t.shuffle && !t.deflate) t.shuffle = true, t.shuffle_bit = i;
-                else if (id == H5Z_FILTER_DEFLATE && !t.deflate) t.deflate = true, t.deflate_bit = i;
-                else fast = false;
-            }
-            const size_t first = chunks.size();
-            if (fast && layout == H5D_CHUNKED) {
-                H5Pget_chunk(dcpl, rank, t.cd);
-                hsize_t n_chunk = 0, expect = 1;
-                if (H5Dget_num_chunks(d, sp, &n_chunk) < 0) fast = false;
-                for (int i = 0; i < rank; ++i) expect *= (t.dd[i] + t.cd[i] - 1) / t.cd[i];
-                if (fast && n_chunk != expect) memset(t.stage, 0, (size_t)n_read * t.esz);  // unwritten chunks read as the fill value
-                for (hsize_t c = 0; fast && c < n_chunk; ++c) {
-                    ChunkTask ct;
-                    ct.ds = &t;
-                    if (H5Dget_chunk_info(d, sp, c, ct.coord, &ct.filter_mask, &ct.addr, &ct.nbytes) < 0 || ct.addr == HADDR_UNDEF) {
-                        fast = false;
-                        break;
-                    }
-                    if (ct.coord[0] < t.lim[0]) chunks.push_back(ct);  // chunks wholly past the wanted leading rows are never touched
+            for (int i = 0; i < rank; ++i) t.dd[i] = sf->dd[i], t.cd[i] = sf->cd[i];
+            t.esz = sf->esz;
+            bool fast = sf->direct && f->fd >= 0 && n_threads > 0 && sf->little;
+            if (t.kind == TB_H5_F32) fast = fast && sf->cls == H5T_FLOAT && sf->esz == 4;
+            else if (t.kind == TB_H5_I64) fast = fast && sf->cls == H5T_INTEGER && sf->esz == 8;
+            else fast = fast && (sf->cls == H5T_ENUM || sf->cls == H5T_INTEGER) && sf->esz == 1;
+            if (!fast) {  // the library's own read + conversion
+                if (d_id < 0) {
+                    const bool opened = open_ds();
+                    d_guard.id = d_id, sp_guard.id = sp_id;
+                    if (!opened) return fail(TB_H5_ERR_IO, "tb_h5_read: no dataset " + t.path);
                 }
-            } else if (fast && layout == H5D_CONTIGUOUS && nf == 0) {
-                ChunkTask ct;
-                ct.ds = &t;
-                ct.addr = H5Dget_offset(d);
-                ct.filter_mask = 0;
-                ct.nbytes = t.esz;
-                for (int i = 0; i < rank; ++i) t.cd[i] = t.dd[i], ct.coord[i] = 0, ct.nbytes *= t.dd[i];
-                if (ct.addr == HADDR_UNDEF) fast = false;
-                else chunks.push_back(ct);
-            } else {
-                fast = false;
-            }
-            if (!fast) {
-                chunks.resize(first);
-                t.shuffle = t.deflate = false;
-                const int32_t rc = read_generic(f, d, sp, t);
+                const int32_t rc = read_generic(f, d_id, sp_id, t);
                 if (rc) return rc;
                 continue;
             }
-            t.remaining.store((int)(chunks.size() - first));
-            if (chunks.size() == first) decode_in_place(t);
+            t.shuffle = sf->shuffle, t.deflate = sf->deflate, t.shuffle_bit = sf->shuffle_bit, t.deflate_bit = sf->deflate_bit;
+            if (sf->chunks.size() != sf->n_expected) memset(t.stage, 0, (size_t)n_read * t.esz);  // unwritten chunks read as the fill value
+            int n_mine = 0;
+            for (const ChunkRec& r : sf->chunks) {
+                if (r.coord[0] >= t.lim[0]) continue;  // chunks wholly past the wanted leading rows are never touched
+                ChunkTask ct;
+                ct.ds = &t, ct.addr = r.addr, ct.nbytes = r.nbytes, ct.filter_mask = r.filter_mask;
+                memcpy(ct.coord, r.coord, sizeof(ct.coord));
+                chunks.push_back(ct);
+                ++n_mine;
+            }
+            t.remaining.store(n_mine);
+            if (n_mine == 0) decode_in_place(t);
         }
     }
+    const size_t n_probed_total = n_probed;
     if (chunks.empty()) return 0;
     const auto t_meta = std::chrono::steady_clock::now();
     // phase 2
@@ -505,7 +600,8 @@ extern "C" int32_t tb_h5_read_batch(tb_h5_file* f, const int64_t* episodes, int3
     for (auto& th : pool) th.join();
     if (getenv("TB_H5_DEBUG")) {
         const auto t_end = std::chrono::steady_clock::now();
-        fprintf(stderr, "tb_h5_read_batch: %zu tensors, %zu chunks, metadata %.2f ms, decode %.2f ms on %d threads\n", tasks.size(), chunks.size(),
+        fprintf(stderr, "tb_h5_read_batch: %zu tensors (%zu probed in the file), %zu chunks, metadata %.2f ms, decode %.2f ms on %d threads\n", tasks.size(),
+                n_probed_total, chunks.size(),
                 std::chrono::duration<double, std::milli>(t_meta - t_begin).count(), std::chrono::duration<double, std::milli>(t_end - t_meta).count(), nt);
     }
     if (bad.load()) return fail(TB_H5_ERR_IO, "tb_h5_read: " + err);

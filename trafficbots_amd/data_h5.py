@@ -26,8 +26,8 @@ import torch
 F32, MASK_U8, ONEHOT_I32, I64 = 0, 1, 2, 3
 _LIB_PATH = os.environ.get("TB_H5_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libtrafficbots_h5.so")
 _HDF5_CANDIDATES = ("/opt/conda/lib/libhdf5.so.103", "libhdf5.so.103", "libhdf5_serial.so.103")
-EXPORTS = ("tb_h5_last_error", "tb_h5_open", "tb_h5_close", "tb_h5_len", "tb_h5_episode_attrs", "tb_h5_dataset_shape", "tb_h5_read_key",
-           "tb_h5_read_batch",
+EXPORTS = ("tb_h5_last_error", "tb_h5_open", "tb_h5_close", "tb_h5_len", "tb_h5_episode_attrs", "tb_h5_batch_attrs", "tb_h5_dataset_shape", "tb_h5_read_key",
+           "tb_h5_read_batch", "tb_h5_set_index_cache",
            "tb_h5_writer_open", "tb_h5_writer_options", "tb_h5_writer_episode", "tb_h5_writer_dataset", "tb_h5_writer_close")
 _lib = None
 N_THREADS = int(os.environ.get("TB_H5_THREADS", min(16, os.cpu_count() or 1)))  # decode workers of one batch read
@@ -65,9 +65,12 @@ def load() -> C.CDLL:
     lib.tb_h5_len.restype = C.c_int64
     lib.tb_h5_episode_attrs.argtypes = [C.c_void_p, C.c_int64, C.c_char_p, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_int32),
                                         C.POINTER(C.c_double), C.POINTER(C.c_int32)]
+    lib.tb_h5_batch_attrs.argtypes = [C.c_void_p, i64p, C.c_int32, C.c_char_p, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_int32),
+                                      C.POINTER(C.c_double), C.POINTER(C.c_int32)]
     lib.tb_h5_dataset_shape.argtypes = [C.c_void_p, C.c_int64, C.c_char_p, C.POINTER(C.c_int32), i64p, C.POINTER(C.c_int32)]
     lib.tb_h5_read_key.argtypes = [C.c_void_p, i64p, C.c_int32, C.c_char_p, i64p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
     lib.tb_h5_read_batch.argtypes = [C.c_void_p, i64p, C.c_int32, C.POINTER(TbH5KeySpec), C.c_int32, C.c_int32]
+    lib.tb_h5_set_index_cache.argtypes = [C.c_void_p, C.c_int64]
     lib.tb_h5_writer_open.argtypes = [C.c_char_p, C.POINTER(C.c_void_p)]
     lib.tb_h5_writer_options.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]
     lib.tb_h5_writer_episode.argtypes = [C.c_void_p, C.c_int64, C.c_char_p, C.POINTER(C.c_double), C.c_int32, C.c_double, C.c_int32]
@@ -132,6 +135,9 @@ class PackedH5File:
         except Exception:
             pass
 
+    def set_index_cache(self, max_entries: int) -> None:
+        _check(self.lib.tb_h5_set_index_cache(self._h, max_entries), "tb_h5_set_index_cache")
+
     def episode_attrs(self, episode: int) -> Dict:
         sid = C.create_string_buffer(256)
         center = (C.c_double * 3)()
@@ -187,11 +193,19 @@ class PackedH5File:
         return out
 
     def _collate_attrs(self, episodes: Sequence[int]) -> Dict:
-        attrs = [self.episode_attrs(int(e)) for e in episodes]
-        return {"scenario_id": [a["scenario_id"] for a in attrs],
-                "scenario_center": torch.from_numpy(np.stack([a["scenario_center"] for a in attrs])),
-                "scenario_yaw": torch.tensor([a["scenario_yaw"] for a in attrs], dtype=torch.float64),
-                "with_map": torch.tensor([a["with_map"] for a in attrs])}
+        """The four episode attributes of a batch in one C call (a reader thread re-acquires the GIL once, not once per episode)."""
+        n, cap = len(episodes), 256
+        ep = (C.c_int64 * max(n, 1))(*[int(e) for e in episodes])
+        ids = C.create_string_buffer(max(n, 1) * cap)
+        centers, yaws = np.zeros((n, 3), np.float64), np.zeros((n,), np.float64)
+        n_center, with_map = np.zeros((n,), np.int32), np.zeros((n,), np.int32)
+        dp, ip = C.POINTER(C.c_double), C.POINTER(C.c_int32)
+        _check(self.lib.tb_h5_batch_attrs(self._h, ep, n, ids, cap, centers.ctypes.data_as(dp), n_center.ctypes.data_as(ip),
+                                          yaws.ctypes.data_as(dp), with_map.ctypes.data_as(ip)), "tb_h5_batch_attrs")
+        nc = int(n_center.max()) if n else 2
+        return {"scenario_id": [ids.raw[i * cap:(i + 1) * cap].split(b"\0", 1)[0].decode() for i in range(n)],
+                "scenario_center": torch.from_numpy(centers[:, :nc].copy()), "scenario_yaw": torch.from_numpy(yaws),
+                "with_map": torch.from_numpy(with_map.astype(np.bool_))}
 
     def read_packed_batch(self, episodes: Sequence[int], tensor_size: Dict[str, Tuple[int, ...]], split: str, n_hist: int = 11,
                           pin: bool = False) -> Dict:
@@ -254,9 +268,9 @@ class PackedSceneLoader:
         self.filepath, self.tensor_size, self.split, self.batch_size, self.n_hist = filepath, tensor_size, split, batch_size, n_hist
         self.prefetch, self.pin = prefetch, torch.cuda.is_available() if pin is None else pin
         self.rank, self.world_size, self.seed, self.limit_batches = rank, world_size, seed, limit_batches
-        f = PackedH5File(filepath)
-        self.dataset_len = len(f)
-        f.close()
+        self._file = PackedH5File(filepath)  # kept across epochs: its chunk index makes every later visit of an episode metadata-free
+        self._busy = threading.Lock()        # one iteration at a time uses it; a concurrent second one opens its own
+        self.dataset_len = len(self._file)
         self._epoch = 0
 
     def _indices(self) -> List[int]:
@@ -278,16 +292,21 @@ class PackedSceneLoader:
         stop = threading.Event()
 
         def work() -> None:
+            mine = self._busy.acquire(blocking=False)
             try:
-                f = PackedH5File(self.filepath)
+                f = self._file if mine else PackedH5File(self.filepath)
                 for c in chunks:
                     if stop.is_set():
                         break
                     q.put(f.read_packed_batch(c, self.tensor_size, self.split, self.n_hist, self.pin))
-                f.close()
                 q.put(None)
             except BaseException as e:  # surfaced in the consumer
                 q.put(e)
+            finally:
+                if mine:
+                    self._busy.release()
+                else:
+                    f.close()
 
         t = threading.Thread(target=work, daemon=True)
         t.start()
