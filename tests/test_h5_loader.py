@@ -174,6 +174,40 @@ def test_chunk_index_makes_second_visit_metadata_free(packed, capfd):
         assert torch.equal(a, b.flip(0)) and torch.equal(a, c)
 
 
+def test_random_shapes_chunkings_and_slices(tmp_path):
+    """seeded sweep: ranks 1-4, dims 1-9 (class dims 1-6), every kind, chunk splits 1-4 per dim, leading-row slices"""
+    rng = np.random.default_rng(77)
+    for trial in range(12):
+        episodes, specs, want = [dict() for _ in range(3)], [], []
+        for j in range(10):
+            rank = int(rng.integers(1, 5))
+            dims = tuple(int(x) for x in rng.integers(1, 10, rank))
+            kind = int(rng.integers(0, 4))
+            key = f"g{j % 3}/agent_t{j}"
+            for ep in episodes:
+                if kind == data_h5.F32:
+                    ep[key] = rng.normal(size=dims).astype(np.float32)
+                elif kind == data_h5.I64:
+                    ep[key] = rng.integers(-2**40, 2**40, dims).astype(np.int64)
+                else:
+                    ep[key] = rng.random(dims) < (0.15 if kind == data_h5.ONEHOT_I32 else 0.5)
+            lead = int(rng.integers(0, dims[0] + 1)) if (rank > 1 or kind != data_h5.ONEHOT_I32) and rng.random() < 0.5 else 0
+            specs.append((key, dims, kind, lead, False))
+        path = str(tmp_path / f"r{trial}.h5")
+        data_h5.write_packed_h5(path, episodes, chunk_div=int(rng.integers(0, 5)), deflate=int(rng.choice([0, 1, 4])), shuffle=bool(rng.integers(0, 2)))
+        f = data_h5.PackedH5File(path)
+        idx = [2, 0, 1, 2]
+        for n_threads in (4, 0):
+            got = f.read_keys(idx, specs, n_threads=n_threads)
+            for (key, dims, kind, lead, _), t in zip(specs, got):
+                w = np.stack([episodes[i][key] for i in idx])
+                if lead:
+                    w = w[:, :lead]
+                if kind == data_h5.ONEHOT_I32:
+                    w = np.where(w.any(-1), w.argmax(-1), -1).astype(np.int32)
+                assert t.shape == w.shape and np.array_equal(t.numpy(), w.astype(t.numpy().dtype)), (trial, key, dims, kind, lead, n_threads)
+
+
 def test_agent_count_override_yields_dummy_agents(packed):
     """`data_h5_womd.py:50-52`: an agent tensor whose stored shape differs from the configured one is replaced by ones"""
     d, _, _ = packed
