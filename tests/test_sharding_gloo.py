@@ -77,8 +77,8 @@ def test_two_rank_gloo_matches_single_process():
     assert t == 2.0  # MAX over ranks of the elapsed time
 
 
-def _val_states_for(lo, hi):
-    """TrainingMetrics sum-states of scenes [lo, hi) of a seeded validation batch (oracles standing in for the GPU engine)."""
+def _val_states_for(lo, hi, batch=None):
+    """TrainingMetrics sum-states of scenes [lo, hi) of a seeded validation batch, or of `batch` (oracles standing in for the GPU engine)."""
     import sys
 
     sys.path.insert(0, ROOT)
@@ -91,7 +91,8 @@ def _val_states_for(lo, hi):
     step_end = 20
     cfg = load_model_config(overrides={"time_step_end": step_end, "n_joint_future": 1})
     sd = synth.make_state_dict(4)
-    batch = synth.make_val_batch(900, hi - lo, scene_offset=lo, n_agent=6, n_pl=12, n_tl=4, p_future_exit=0.3)
+    if batch is None:
+        batch = synth.make_val_batch(900, hi - lo, scene_offset=lo, n_agent=6, n_pl=12, n_tl=4, p_future_exit=0.3)
     with torch.no_grad():
         r = Oracle(sd, cfg, torch.float32).reactive_replay(batch, step_end)
     gv = r["gt_valid"][:, 1: step_end + 1].transpose(1, 2)
@@ -143,5 +144,82 @@ def test_two_rank_gloo_validation_losses_match_single_process():
     want = m.compute()
     assert set(got) == set(want) == {"reactive_replay/loss", "reactive_replay/vae_kl", "reactive_replay/diffbar_reward",
                                      "reactive_replay/goal_loss"}
+    for k in want:
+        assert abs(got[k] - want[k]) <= 1e-5 * max(1.0, abs(want[k])), k
+
+
+H5_SCENE = dict(n_agent=6, n_pl=12, n_tl=4, p_future_exit=0.3)
+
+
+def _h5_module(data_dir, rank, world):
+    from trafficbots_amd import data_h5, synth
+
+    dm = data_h5.DataH5womd(data_dir, batch_size=2, n_agent=6, n_pl=12, n_tl_stop=4, rank=rank, world_size=world)
+    ep = synth.make_h5_episodes(900, 1, **H5_SCENE)[0][0]
+    for k in list(dm.tensor_size_val):
+        dm.tensor_size_val[k] = ep[k].shape
+    dm.setup("validate")
+    return dm
+
+
+def _h5_states(dm):
+    """sum-states over the batches of this rank's loader (the oracle wants the reference's layout: re-read each batch that way)"""
+    from trafficbots_amd import data_h5
+
+    f = data_h5.PackedH5File(dm.path_val_h5)
+    total, cfg = None, None
+    for packed in dm.val_dataloader():
+        ref = {k: (v.numpy() if torch.is_tensor(v) else v)
+               for k, v in f.read_reference_batch(packed["episode_idx"].tolist(), dm.tensor_size_val, False).items()}
+        st, cfg = _val_states_for(0, 0, batch=ref)
+        total = st if total is None else total + st
+    return total, cfg
+
+
+def _h5_worker(rank, world, port, data_dir, q):
+    import sys
+
+    import torch.distributed as dist
+
+    sys.path.insert(0, ROOT)
+    torch.set_num_threads(1)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from trafficbots_amd.metrics import TrainingMetrics
+
+    st, cfg = _h5_states(_h5_module(data_dir, rank, world))
+    m = TrainingMetrics("reactive_replay", **cfg["training_metrics"])
+    m.update(st)
+    m.sync()
+    if rank == 0:
+        q.put(m.compute())
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_validation_from_a_packed_h5_file(tmp_path):
+    """both ranks read their round-robin share of one packed file concurrently; the synced losses equal one process over the whole file"""
+    from trafficbots_amd import data_h5, synth
+    from trafficbots_amd.metrics import TrainingMetrics
+
+    episodes, attrs = synth.make_h5_episodes(900, 5, **H5_SCENE)
+    data_h5.write_packed_h5(str(tmp_path / "validation.h5"), episodes, attrs)
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_h5_worker, args=(r, world, port, str(tmp_path), q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    st, cfg = _h5_states(_h5_module(str(tmp_path), 0, 1))
+    m = TrainingMetrics("reactive_replay", **cfg["training_metrics"])
+    m.update(st)
+    want = m.compute()
+    st_mem, _ = _val_states_for(0, 5)  # and the file holds what synth.make_val_batch(900, 5) holds
+    assert torch.allclose(st, st_mem, rtol=1e-6)
     for k in want:
         assert abs(got[k] - want[k]) <= 1e-5 * max(1.0, abs(want[k])), k
