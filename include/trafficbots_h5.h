@@ -92,6 +92,12 @@ int32_t tb_h5_read_batch(tb_h5_file* f, const int64_t* episodes, int32_t n_episo
  * visit of that episode (the next validation epoch, training's random re-draws) makes no HDF5 call at all.  max_entries bounds that
  * index (default 2^20 tensors, about 150 bytes each); 0 disables and clears it.  The file must not change while it is open. */
 int32_t tb_h5_set_index_cache(tb_h5_file* f, int64_t max_entries);
+/* The same index on disk, so that the FIRST pass of a later run is metadata-free too.  save: writes the handle's index (merge_existing
+ * != 0: after adding the entries an index file at `path` already holds, e.g. those of another reader's handle) atomically (temp file +
+ * rename); load: adds the file's entries to the handle's index -- TB_H5_ERR_SHAPE and nothing loaded when the index was made for a data
+ * file of another size or modification time. */
+int32_t tb_h5_save_index(tb_h5_file* f, const char* path, int32_t merge_existing);
+int32_t tb_h5_load_index(tb_h5_file* f, const char* path);
 
 /* ---- writer (pack_h5_womd.py:235,378-392) ---- */
 int32_t tb_h5_writer_open(const char* path, tb_h5_writer** out);

@@ -78,6 +78,32 @@ with tempfile.TemporaryDirectory() as d:
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         print(f"loader -> validation_step: {dt / n_ep * 1e3:.2f} ms / episode, of which {waited / n_ep * 1e3:.2f} ms waiting for the reader")
+        dm.setup("validate")  # a fresh loader: cold chunk index, warm GPU
+        it, waited = iter(dm.val_dataloader()), 0.0
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        while True:
+            w0 = time.perf_counter()
+            batch = next(it, None)
+            waited += time.perf_counter() - w0
+            if batch is None:
+                break
+            out = wm.validation_step(batch)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        print(f"cold-index loader -> validation_step: {dt / n_ep * 1e3:.2f} ms / episode, of which {waited / n_ep * 1e3:.2f} ms waiting for the reader")
+        for label in ("writes", "starts from"):  # a fresh data module per pass, as a new run would have
+            dmi = data_h5.DataH5womd(d, batch_size=bs, index_dir=d)
+            dmi.tensor_size_val.update(dm.tensor_size_val)
+            dmi.setup("validate")
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for batch in dmi.val_dataloader():
+                out = wm.validation_step(batch)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            print(f"fresh loader that {label} the on-disk chunk index -> validation_step: {dt / n_ep * 1e3:.2f} ms / episode")
+        print(f"index file: {os.path.getsize(d + '/validation.h5.r0of1.tbidx') / n_ep:.0f} B / episode")
         mem = [{k: np.stack([episodes[i][k] for i in range(j, j + bs)]) for k in episodes[0]} for j in range(0, n_ep, bs)]
         torch.cuda.synchronize()
         t0 = time.perf_counter()

@@ -208,6 +208,34 @@ def test_random_shapes_chunkings_and_slices(tmp_path):
                 assert t.shape == w.shape and np.array_equal(t.numpy(), w.astype(t.numpy().dtype)), (trial, key, dims, kind, lead, n_threads)
 
 
+def test_chunk_index_on_disk(packed, tmp_path, capfd):
+    d, _, _ = packed
+    idx_dir = str(tmp_path)
+
+    def run():
+        dm = data_module(d, index_dir=idx_dir)
+        dm.setup("validate")
+        os.environ["TB_H5_DEBUG"] = "1"
+        try:
+            out = list(dm.val_dataloader())
+        finally:
+            del os.environ["TB_H5_DEBUG"]
+        return out, [l for l in capfd.readouterr().err.splitlines() if "tb_h5_read_batch" in l]
+
+    first, log1 = run()
+    assert os.path.exists(idx_dir + "/validation.h5.r0of1.tbidx") and all("(0 probed" not in l for l in log1)
+    second, log2 = run()  # a new process would do the same: every handle starts from the file's index
+    assert len(log2) == 3 and all("(0 probed" in l for l in log2), log2
+    for a, b in zip(first, second):
+        assert all(torch.equal(a[k], b[k]) for k in a if torch.is_tensor(a[k]))
+    # an index made for another version of the data file is refused, loudly at the C level and quietly by the loader
+    f = data_h5.PackedH5File(d + "/testing.h5")
+    assert not f.load_index(idx_dir + "/validation.h5.r0of1.tbidx") and "another version" in data_h5.load().tb_h5_last_error().decode()
+    with open(idx_dir + "/bad.tbidx", "wb") as fh:
+        fh.write(b"nonsense")
+    assert not f.load_index(idx_dir + "/bad.tbidx") and "not an index file" in data_h5.load().tb_h5_last_error().decode()
+
+
 def test_agent_count_override_yields_dummy_agents(packed):
     """`data_h5_womd.py:50-52`: an agent tensor whose stored shape differs from the configured one is replaced by ones"""
     d, _, _ = packed

@@ -27,7 +27,7 @@ F32, MASK_U8, ONEHOT_I32, I64 = 0, 1, 2, 3
 _LIB_PATH = os.environ.get("TB_H5_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libtrafficbots_h5.so")
 _HDF5_CANDIDATES = ("/opt/conda/lib/libhdf5.so.103", "libhdf5.so.103", "libhdf5_serial.so.103")
 EXPORTS = ("tb_h5_last_error", "tb_h5_open", "tb_h5_close", "tb_h5_len", "tb_h5_episode_attrs", "tb_h5_batch_attrs", "tb_h5_dataset_shape", "tb_h5_read_key",
-           "tb_h5_read_batch", "tb_h5_set_index_cache",
+           "tb_h5_read_batch", "tb_h5_set_index_cache", "tb_h5_save_index", "tb_h5_load_index",
            "tb_h5_writer_open", "tb_h5_writer_options", "tb_h5_writer_episode", "tb_h5_writer_dataset", "tb_h5_writer_close")
 _lib = None
 N_THREADS = int(os.environ.get("TB_H5_THREADS", min(16, os.cpu_count() or 1)))  # decode workers of one batch read
@@ -71,6 +71,8 @@ def load() -> C.CDLL:
     lib.tb_h5_read_key.argtypes = [C.c_void_p, i64p, C.c_int32, C.c_char_p, i64p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
     lib.tb_h5_read_batch.argtypes = [C.c_void_p, i64p, C.c_int32, C.POINTER(TbH5KeySpec), C.c_int32, C.c_int32]
     lib.tb_h5_set_index_cache.argtypes = [C.c_void_p, C.c_int64]
+    lib.tb_h5_save_index.argtypes = [C.c_void_p, C.c_char_p, C.c_int32]
+    lib.tb_h5_load_index.argtypes = [C.c_void_p, C.c_char_p]
     lib.tb_h5_writer_open.argtypes = [C.c_char_p, C.POINTER(C.c_void_p)]
     lib.tb_h5_writer_options.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]
     lib.tb_h5_writer_episode.argtypes = [C.c_void_p, C.c_int64, C.c_char_p, C.POINTER(C.c_double), C.c_int32, C.c_double, C.c_int32]
@@ -137,6 +139,13 @@ class PackedH5File:
 
     def set_index_cache(self, max_entries: int) -> None:
         _check(self.lib.tb_h5_set_index_cache(self._h, max_entries), "tb_h5_set_index_cache")
+
+    def save_index(self, path: str, merge_existing: bool = True) -> None:
+        _check(self.lib.tb_h5_save_index(self._h, path.encode(), int(merge_existing)), f"tb_h5_save_index({path})")
+
+    def load_index(self, path: str) -> bool:
+        """True when the index file existed, matched this data file and was loaded."""
+        return self.lib.tb_h5_load_index(self._h, path.encode()) == 0
 
     def episode_attrs(self, episode: int) -> Dict:
         sid = C.create_string_buffer(256)
@@ -257,21 +266,30 @@ def scene_from_packed(batch: Dict, device, n_hist: int = 11) -> Dict:
 
 
 class PackedSceneLoader:
-    """Iterable over packed batches of one file; a reader thread keeps `prefetch` decoded batches ahead of the consumer (the C calls
-    release the GIL).  `rank` / `world_size` deal episodes round-robin like the DistributedSampler of the reference's DDP run
-    (`run.py:51-53`), without its padding: the last batches of a rank may simply be absent."""
+    """Iterable over packed batches of one file.  `readers` reader threads (each with its own file handle, batch i goes to reader
+    i % readers in every epoch, so a handle's chunk index sees the same episodes again) keep `prefetch` decoded batches each ahead of
+    the consumer, which takes them in order; the C calls release the GIL, and while one reader walks HDF5 metadata (the library
+    serialises that) the other decodes, allocates and enqueues.  `rank` / `world_size` deal episodes round-robin like the
+    DistributedSampler of the reference's DDP run (`run.py:51-53`), without its padding: the last batches of a rank may simply be
+    absent."""
 
     def __init__(self, filepath: str, tensor_size: Dict[str, Tuple[int, ...]], split: str, batch_size: int, n_hist: int = 11,
                  prefetch: int = 2, pin: Optional[bool] = None, rank: int = 0, world_size: int = 1, seed: int = 0,
-                 limit_batches: Optional[int] = None) -> None:
-        assert split in ("train", "val", "test")
+                 limit_batches: Optional[int] = None, readers: int = 2, index_path: Optional[str] = None) -> None:
+        assert split in ("train", "val", "test") and readers >= 1
         self.filepath, self.tensor_size, self.split, self.batch_size, self.n_hist = filepath, tensor_size, split, batch_size, n_hist
         self.prefetch, self.pin = prefetch, torch.cuda.is_available() if pin is None else pin
         self.rank, self.world_size, self.seed, self.limit_batches = rank, world_size, seed, limit_batches
-        self._file = PackedH5File(filepath)  # kept across epochs: its chunk index makes every later visit of an episode metadata-free
-        self._busy = threading.Lock()        # one iteration at a time uses it; a concurrent second one opens its own
-        self.dataset_len = len(self._file)
+        # kept across epochs: a handle's chunk index makes every later visit of an episode metadata-free
+        self._files = [PackedH5File(filepath) for _ in range(readers)]
+        self._busy = threading.Lock()  # one iteration at a time uses them; a concurrent second one opens its own
+        self.dataset_len = len(self._files[0])
         self._epoch = 0
+        # chunk index on disk: loaded now when it matches the data file, (re)written after the first complete epoch
+        self.index_path = index_path
+        self._index_saved = False
+        if index_path and os.path.exists(index_path):
+            self._index_saved = all([f.load_index(index_path) for f in self._files]) and split != "train"
 
     def _indices(self) -> List[int]:
         if self.split == "train":  # DatasetTrain.__getitem__ draws a random episode per item (:31)
@@ -288,57 +306,65 @@ class PackedSceneLoader:
         idx = self._indices()
         self._epoch += 1
         chunks = [idx[i:i + self.batch_size] for i in range(0, len(idx), self.batch_size)][: len(self)]
-        q: "queue.Queue" = queue.Queue(maxsize=max(self.prefetch, 1))
+        mine = self._busy.acquire(blocking=False)
+        files = self._files if mine else [PackedH5File(self.filepath) for _ in self._files]
+        n = len(files)
+        queues = [queue.Queue(maxsize=max(self.prefetch, 1)) for _ in range(n)]
         stop = threading.Event()
 
-        def work() -> None:
-            mine = self._busy.acquire(blocking=False)
+        def work(r: int) -> None:
             try:
-                f = self._file if mine else PackedH5File(self.filepath)
-                for c in chunks:
+                for c in chunks[r::n]:
                     if stop.is_set():
                         break
-                    q.put(f.read_packed_batch(c, self.tensor_size, self.split, self.n_hist, self.pin))
-                q.put(None)
-            except BaseException as e:  # surfaced in the consumer
-                q.put(e)
-            finally:
-                if mine:
-                    self._busy.release()
-                else:
-                    f.close()
+                    queues[r].put(files[r].read_packed_batch(c, self.tensor_size, self.split, self.n_hist, self.pin))
+            except BaseException as e:  # surfaced in the consumer, in order
+                queues[r].put(e)
 
-        t = threading.Thread(target=work, daemon=True)
-        t.start()
+        threads = [threading.Thread(target=work, args=(r,), daemon=True) for r in range(n)]
+        for t in threads:
+            t.start()
         try:
-            while True:
-                item = q.get()
-                if item is None:
-                    break
+            for i in range(len(chunks)):
+                item = queues[i % n].get()
                 if isinstance(item, BaseException):
                     raise item
                 yield item
+            if mine and self.index_path and not self._index_saved:
+                for t in threads:
+                    t.join()
+                for f in files:
+                    f.save_index(self.index_path, merge_existing=True)
+                self._index_saved = True
         finally:
             stop.set()
-            while t.is_alive():
-                try:
-                    q.get_nowait()
-                except queue.Empty:
-                    t.join(0.01)
+            while any(t.is_alive() for t in threads):
+                for q in queues:
+                    try:
+                        q.get_nowait()
+                    except queue.Empty:
+                        pass
+                threads[0].join(0.005)
+            if mine:
+                self._busy.release()
+            else:
+                for f in files:
+                    f.close()
 
 
 class DataH5womd:
     """`data_h5_womd.py:58-241` without Lightning: same arguments, tensor tables and loader names.  `num_workers` is accepted and
-    unused (one native reader thread per loader replaces the worker processes)."""
+    unused (two native reader threads per loader, each fanning its decode out to `TB_H5_THREADS` workers, replace the worker processes)."""
 
     def __init__(self, data_dir: str, filename_train: str = "training", filename_val: str = "validation", filename_test: str = "testing",
                  batch_size: int = 3, num_workers: int = 4, n_agent: int = 64, n_pl: int = 1024, n_tl_stop: int = 40,
-                 rank: int = 0, world_size: int = 1) -> None:
+                 rank: int = 0, world_size: int = 1, index_dir: Optional[str] = None) -> None:
         self.interactive_challenge = "interactive" in filename_val or "interactive" in filename_test
         self.path_train_h5 = f"{data_dir}/{filename_train}.h5"
         self.path_val_h5 = f"{data_dir}/{filename_val}.h5"
         self.path_test_h5 = f"{data_dir}/{filename_test}.h5"
         self.batch_size, self.num_workers, self.rank, self.world_size = batch_size, num_workers, rank, world_size
+        self.index_dir = index_dir  # where the loaders keep "<file>.r<rank>of<world>.tbidx" chunk indices (None: in memory only)
         n_step, n_hist, n_no_sim, n_tl, n_node = 91, 11, 256, 100, 20
 
         def agent_tables(pre: str, s: int, who: str, n: int, full: bool) -> Dict[str, Tuple[int, ...]]:
@@ -365,7 +391,10 @@ class DataH5womd:
         self.train_dataset = self.val_dataset = self.test_dataset = None
 
     def setup(self, stage: Optional[str] = None) -> None:
-        mk = lambda path, size, split: PackedSceneLoader(path, size, split, self.batch_size, rank=self.rank, world_size=self.world_size)
+        def mk(path: str, size: Dict, split: str) -> PackedSceneLoader:
+            idx = f"{self.index_dir}/{os.path.basename(path)}.r{self.rank}of{self.world_size}.tbidx" if self.index_dir else None
+            return PackedSceneLoader(path, size, split, self.batch_size, rank=self.rank, world_size=self.world_size, index_path=idx)
+
         if stage == "fit" or stage is None:
             self.train_dataset = mk(self.path_train_h5, self.tensor_size_train, "train")
             self.val_dataset = mk(self.path_val_h5, self.tensor_size_val, "val")
