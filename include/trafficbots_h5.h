@@ -90,7 +90,7 @@ int32_t tb_h5_read_batch(tb_h5_file* f, const int64_t* episodes, int32_t n_episo
 
 /* tb_h5_read_batch remembers, per handle, the stored form and chunk extents of every (episode, key) it has visited, so that the next
  * visit of that episode (the next validation epoch, training's random re-draws) makes no HDF5 call at all.  max_entries bounds that
- * index (default 2^20 tensors, about 150 bytes each); 0 disables and clears it.  The file must not change while it is open. */
+ * index (default 2^20 tensors, about 280 bytes each); 0 disables and clears it.  The file must not change while it is open. */
 int32_t tb_h5_set_index_cache(tb_h5_file* f, int64_t max_entries);
 /* The same index on disk, so that the FIRST pass of a later run is metadata-free too.  save: writes the handle's index (merge_existing
  * != 0: after adding the entries an index file at `path` already holds, e.g. those of another reader's handle) atomically (temp file +
