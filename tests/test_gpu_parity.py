@@ -701,6 +701,18 @@ def test_packed_h5_loader_drives_validation_and_test_steps(tmp_path):
         assert torch.equal(a["latent_post"].mean, b["latent_post"].mean)
         n += len(idx)
     assert n == 5
+    # a training file holds no "history/*" tensors: the scene part is the first 11 steps of the ground truth (n_lead in the reader)
+    data_h5.write_packed_h5(str(tmp_path / "training.h5"), [{k: e[k] for k in dm.tensor_size_train} for e in episodes])
+    for k in list(dm.tensor_size_train):
+        dm.tensor_size_train[k] = episodes[0][k].shape
+    dm.setup("fit")
+    for batch in dm.train_dataloader():
+        idx = batch["episode_idx"].tolist()  # random draws (DatasetTrain)
+        mem = {k: np.stack([episodes[i][k] for i in idx]) for k in episodes[0]}
+        eps = torch.from_numpy(synth.make_latent_noise(9904, len(idx), 20)).cuda()
+        a, b = wm.training_step(batch, latent_eps=eps), wm.training_step(mem, latent_eps=eps)
+        assert torch.equal(a["train_states"], b["train_states"]) and a["loss"] == b["loss"]
+        assert torch.equal(a["rollout_buffer"].preds, b["rollout_buffer"].preds)
     wm3 = _engine({"time_step_end": 40, "n_joint_future": 3}, sd)
     dm.setup("test")
     for batch in dm.test_dataloader():
