@@ -16,6 +16,15 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def require_h5():
+    """Build the packed-h5 reader if this checkout has not yet (g++, seconds); skip the calling test on a host without HDF5."""
+    import __graft_entry__ as ge
+
+    ge.build_h5()
+    if not os.path.exists(ge.H5_LIB):
+        pytest.skip("no HDF5 headers / runtime on this host: packed-h5 reader not built")
+
+
 def load_golden(name):
     g = np.load(os.path.join(GOLDEN_DIR, f"{name}.npz"))
     meta = json.loads(bytes(g["meta_json"]).decode())

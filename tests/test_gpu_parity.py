@@ -675,6 +675,9 @@ def test_packed_h5_loader_drives_validation_and_test_steps(tmp_path):
     """SURVEY 8(f)-4 end to end: episodes written in the reference's packed-h5 format and read back by the native loader (decoded on
     the host into the C-ABI layout, uploaded from pinned buffers) give bit-identical validation_step / test_step results to the same
     episodes handed over as an in-memory batch of the reference's layout."""
+    from conftest import require_h5
+
+    require_h5()
     from trafficbots_amd import data_h5, synth
 
     scene = dict(n_agent=20, n_pl=48, n_tl=12, p_invalid_agent=0.2, p_late_spawn=0.3, p_future_spawn=0.4, p_future_exit=0.3, pos_range=60.0)

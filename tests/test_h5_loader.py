@@ -10,6 +10,13 @@ from oracle import h5_oracle
 from trafficbots_amd import data_h5, synth
 from trafficbots_amd.runtime import gt_from_batch, scene_from_batch
 
+@pytest.fixture(scope="module", autouse=True)
+def _reader_built():
+    from conftest import require_h5
+
+    require_h5()
+
+
 SCENE = dict(n_agent=7, n_pl=12, n_tl=5, p_invalid_agent=0.3, p_late_spawn=0.3, p_early_exit=0.2, p_invalid_pl=0.2)
 N_NO_SIM = 4
 

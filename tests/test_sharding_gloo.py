@@ -199,6 +199,9 @@ def _h5_worker(rank, world, port, data_dir, q):
 
 def test_two_rank_gloo_validation_from_a_packed_h5_file(tmp_path):
     """both ranks read their round-robin share of one packed file concurrently; the synced losses equal one process over the whole file"""
+    from conftest import require_h5
+
+    require_h5()
     from trafficbots_amd import data_h5, synth
     from trafficbots_amd.metrics import TrainingMetrics
 
