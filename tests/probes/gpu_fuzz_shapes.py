@@ -15,7 +15,7 @@ from trafficbots_amd.config import load_model_config  # noqa: E402
 from trafficbots_amd.waymo_motion import WaymoMotion  # noqa: E402
 
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 24
-rng = np.random.default_rng(12345)
+rng = np.random.default_rng(int(os.environ.get("FUZZ_SEED", "12345")))
 EDGE_A = [1, 2, 15, 16, 17, 31, 32, 33, 48, 64, 65]
 EDGE_P = [1, 2, 16, 31, 32, 33, 63, 64, 65, 96, 130]
 EDGE_T = [1, 2, 15, 31, 32, 33, 40]
