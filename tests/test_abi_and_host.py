@@ -166,3 +166,29 @@ def test_rollout_buffer_flatten_repeat():
     b.flatten_repeat(k)
     assert b.preds.shape == (2, a, k, s, 4)
     assert torch.equal(b.preds[1, 2, 1], p0[1 * k + 1, 2])
+
+
+def test_training_split_batch_has_no_history_keys():
+    """A reference TRAINING batch (`tensor_size_train`, `data_h5_womd.py:85-117`) carries no "history/*" keys: the scene is the
+    first n_hist steps of "agent/*" / "tl_stop/*" (`scene_centric.py:92-121`, prefix "" in training).  Same device-layout scene
+    as from a validation batch whose history equals those steps; `warm_ok` follows n_hist."""
+    from trafficbots_amd import synth
+    from trafficbots_amd.runtime import gt_from_batch, scene_from_batch
+
+    val = synth.make_val_batch(31, 2, n_agent=9, n_pl=20, n_tl=6)
+    train = {k: v for k, v in val.items() if not k.startswith("history/")}
+    a = scene_from_batch(val, "cpu", 11)
+    b = scene_from_batch(train, "cpu", 11)
+    assert set(a) == set(b)
+    for k in a:
+        if k == "warm_ok":
+            assert a[k] == b[k]
+        else:
+            assert torch.equal(a[k], b[k]), k
+    with pytest.raises(KeyError):
+        scene_from_batch({k: v for k, v in train.items() if not k.startswith("agent/")}, "cpu", 11)
+    # an exit at step 12 is inside a 14-step history but not inside the default 11
+    v = np.ones_like(np.asarray(train["agent/valid"]))
+    v[:, 12:, 0] = False
+    t3 = dict(train, **{"agent/valid": v})
+    assert gt_from_batch(t3, "cpu", 11)["warm_ok"] is True and gt_from_batch(t3, "cpu", 14)["warm_ok"] is False

@@ -226,3 +226,48 @@ def test_two_rank_gloo_validation_from_a_packed_h5_file(tmp_path):
     assert torch.allclose(st, st_mem, rtol=1e-6)
     for k in want:
         assert abs(got[k] - want[k]) <= 1e-5 * max(1.0, abs(want[k])), k
+
+
+def _sync_worker(rank, world, port, q):
+    import sys
+    import torch.distributed as dist
+
+    sys.path.insert(0, ROOT)
+    torch.set_num_threads(1)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from trafficbots_amd.metrics import ErrorMetrics
+
+    m = ErrorMetrics("x")
+    if rank == 0:  # rank 1 received no batch (PackedSceneLoader does not pad ranks): it must still take part in the collective
+        m.update(torch.tensor([2.0, 4.0, 6.0, 8.0], dtype=torch.float64))
+    m.sync()
+    first = m.compute()
+    m.sync()  # a second sync must not multiply anything by the world size
+    second = m.compute()
+    own = None if m.states is None else m.states.clone()
+    if rank == 0:
+        m.update(torch.tensor([2.0, 0.0, 0.0, 0.0], dtype=torch.float64))  # update after sync: the accumulator was never all-reduced in place
+    m.sync()
+    third = m.compute()
+    q.put((rank, first, second, third, None if own is None else own.tolist()))
+    dist.destroy_process_group()
+
+
+def test_metric_sync_is_idempotent_and_tolerates_an_idle_rank():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sync_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict((r[0], r[1:]) for r in (q.get(timeout=120), q.get(timeout=120)))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank in (0, 1):
+        first, second, third, own = got[rank]
+        assert first == second == {"x/err/pos_meter": 2.0, "x/err/rot_deg": 3.0, "x/err/spd_m_per_s": 4.0}
+        assert third == {"x/err/pos_meter": 1.0, "x/err/rot_deg": 1.5, "x/err/spd_m_per_s": 2.0}
+    assert got[0][3] == [2.0, 4.0, 6.0, 8.0] and got[1][3] is None

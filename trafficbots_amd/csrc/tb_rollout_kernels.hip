@@ -94,8 +94,10 @@ __global__ __launch_bounds__(NTHREADS) void k_rollout_init(RolloutP p) {
         const int r = i >> 5, c4 = (i & 31) * 4;
         f32x4 v = splat(0.f);
         if (r < n_real) {
+            // (an out-of-range destination index -- a caller-supplied goal_sample, file contents -- reads nothing: zero goal feature,
+            // far geometry and no destination flag below; the host mirror rejects such indices before the launch)
             const int d = p.dest[(size_t)n * p.n_agent + row0 + r];
-            v = ldg4(p.map_feature + ((size_t)b * p.n_pl + d) * H + c4);
+            if (d >= 0 && d < p.n_pl) v = ldg4(p.map_feature + ((size_t)b * p.n_pl + d) * H + c4);
         }
         st4(X + r * LDT + c4, v);
     }
@@ -123,8 +125,9 @@ __global__ __launch_bounds__(NTHREADS) void k_rollout_init(RolloutP p) {
         f32x4 g = f32x4{1e30f, 1e30f, 0.f, 0.f};
         if (r < n_real) {
             const int d = p.dest[(size_t)n * p.n_agent + row0 + r];
-            const size_t nb = ((size_t)b * p.n_pl + d) * 20 + k;
-            if (p.map_valid[nb]) {
+            const bool dok = d >= 0 && d < p.n_pl;
+            const size_t nb = ((size_t)b * p.n_pl + (dok ? d : 0)) * 20 + k;
+            if (dok && p.map_valid[nb]) {
                 const float ddx = p.map_dir[nb * 2], ddy = p.map_dir[nb * 2 + 1];
                 const float nrm = sqrtf(fadd_(fmul_(ddx, ddx), fmul_(ddy, ddy)));
                 g = f32x4{p.map_pos[nb * 2], p.map_pos[nb * 2 + 1], ddx / nrm, ddy / nrm};
@@ -136,7 +139,7 @@ __global__ __launch_bounds__(NTHREADS) void k_rollout_init(RolloutP p) {
         int fl = 0;
         if (tid < n_real) {
             const int d = p.dest[(size_t)n * p.n_agent + row0 + tid];
-            const int dty = p.map_type[(size_t)b * p.n_pl + d];
+            const int dty = (d >= 0 && d < p.n_pl) ? p.map_type[(size_t)b * p.n_pl + d] : -1;
             fl = (dty >= 0 && dty < 4 ? 1 : 0) | (dty == 4 ? 2 : 0);
         }
         p.dest_flag[(size_t)n * p.a_pad + row0 + tid] = fl;

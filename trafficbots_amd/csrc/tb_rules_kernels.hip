@@ -122,7 +122,7 @@ __global__ __launch_bounds__(RT) void k_rule_step(RuleP p) {
                 const int mt = p.map_type[(size_t)b * p.n_pl + e / 20];
                 const bool mv = p.map_valid[ei] != 0;
                 edge_ok = p.en_road_edge && mv && (mt == 4 || mt == 5 || mt == 7);  // :571
-                lane_ok = p.en_passive && mv && mt < 3;                            // :587
+                lane_ok = p.en_passive && mv && mt >= 0 && mt < 3;                 // :587 (class -1 = all-zero one-hot: no type)
                 cx = p.map_pos[ei * 2];
                 cy = p.map_pos[ei * 2 + 1];
                 dx = add_(cx, p.map_dir[ei * 2]);  // segment end = pos + dir (:575)
@@ -187,7 +187,7 @@ __global__ __launch_bounds__(RT) void k_rule_step(RuleP p) {
                     const bool in1 = fabsf(add_(mul_(d1x, c), mul_(d1y, sn))) < rl && fabsf(add_(mul_(d1x, sn), mul_(d1y, -c))) < rw;
                     red |= in0 && !in1;
                 }
-                if (p.en_passive && ts != 3) {  // anything but GO (:311)
+                if (p.en_passive && (ts == 0 || ts == 1 || ts == 2 || ts == 4)) {  // tl_state[[0,1,2,4]].any (:308); -1 = no state set
                     const float vx = sub_(tx, x), vy = sub_(ty_, y);
                     const float nr = sqrtf(add_(mul_(vx, vx), mul_(vy, vy)));
                     red_ahead |= (nr < 10.f) && (add_(mul_(c, vx), mul_(sn, vy)) / nr > 0.95f);

@@ -167,7 +167,9 @@ __global__ __launch_bounds__(256) void k_train_partials(tb_train_io io, const fl
                 for (int j = 0; j < P; ++j) m = fmaxf(m, lg[j]);
                 float se = 0.f;
                 for (int j = 0; j < P; ++j) se += expf(__fadd_rn(lg[j], -m));
-                const float logp = __fadd_rn(__fadd_rn(lg[io.gt_dest[row]], -m), -logf(se));
+                const int gd = io.gt_dest[row];  // (out of range: -inf logit = an impossible destination, never an out-of-bounds read)
+                const float lgd = (gd >= 0 && gd < P) ? lg[gd] : -INFINITY;
+                const float logp = __fadd_rn(__fadd_rn(lgd, -m), -logf(se));
                 acc[4] = -logp;
                 acc[5] = 1.f;
             }

@@ -20,25 +20,42 @@ class _PackedSumMetric:
 
     def __init__(self, prefix: str) -> None:
         self.prefix = prefix
-        self.states: Tensor = None
+        self.states: Tensor = None   # this rank's accumulator
+        self._synced: Tensor = None  # the all-reduced copy `compute()` reads after `sync()`; dropped by update() / reset()
 
     def update(self, packed: Tensor) -> None:
         """Add one batch's packed states (float64 vector in `fields` order)."""
         assert packed.shape == (len(self.fields),)
         self.states = packed.clone() if self.states is None else self.states + packed
+        self._synced = None
 
     def reset(self) -> None:
         self.states = None
+        self._synced = None
 
-    def sync(self) -> None:
-        """SUM over the default process group (no-op for a single process)."""
+    def sync(self, device=None) -> None:
+        """SUM over the default process group (no-op for a single process).  Like torchmetrics, the reduction works on a COPY:
+        calling it twice, or `update()` after it, does not multiply the accumulator by the world size.  Every rank takes part in
+        the collective, also one that received no batch (`PackedSceneLoader` does not pad ranks): it contributes zeros."""
         import torch.distributed as dist
 
-        if self.states is not None and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            dist.all_reduce(self.states, op=dist.ReduceOp.SUM)
+        if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+            self._synced = None
+            return
+        if self.states is None:
+            if device is None:
+                device = "cpu" if dist.get_backend() == "gloo" or not torch.cuda.is_available() else torch.device("cuda", torch.cuda.current_device())
+            red = torch.zeros(len(self.fields), dtype=torch.float64, device=device)
+        else:
+            red = self.states.clone()
+        dist.all_reduce(red, op=dist.ReduceOp.SUM)
+        self._synced = red
 
     def state_dict(self) -> Dict[str, float]:
-        return {k: float(self.states[i]) for i, k in enumerate(self.fields)}
+        s = self._synced if self._synced is not None else self.states
+        if s is None:
+            s = torch.zeros(len(self.fields), dtype=torch.float64)
+        return {k: float(s[i]) for i, k in enumerate(self.fields)}
 
 
 class ErrorMetrics(_PackedSumMetric):

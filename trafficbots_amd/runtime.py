@@ -36,7 +36,20 @@ def teacher_forcing_mask(valid: Tensor, step_spawn_agent: int = 10, step_warm_st
         m[:, 1:] |= sp
     if step_warm_start >= 0:
         m[:, : step_warm_start + 1] |= valid[:, : step_warm_start + 1]
+    m._tb_warm_start = int(step_warm_start)  # provenance for `warm_start_promise_holds` (a plain attribute on the tensor object)
     return m
+
+
+def warm_start_promise_holds(mask_teacher_forcing: Tensor, valid: Tensor, w: int) -> bool:
+    """`tb_rollout_io.warm_start_steps` = w promises that every valid agent is teacher-forced at steps 0..w.  True without a look at
+    the data when the mask came out of :func:`teacher_forcing_mask` with step_warm_start >= w; a caller-made mask is checked
+    (one device -> host read)."""
+    if w <= 0:
+        return True
+    if getattr(mask_teacher_forcing, "_tb_warm_start", -1) >= w:
+        return True
+    m, v = mask_teacher_forcing[:, : w + 1].bool(), valid[:, : w + 1].bool().to(mask_teacher_forcing.device)
+    return bool((m | ~v).all())
 
 
 METRIC_FIELDS = ("err_counter", "err_pos_meter", "err_rot_deg", "err_spd_m_per_s", "counter_agent", "counter_veh", "outside_map",
@@ -54,9 +67,14 @@ def no_early_exit(valid, n_steps: int) -> bool:
 
 
 def scene_from_batch(batch: Dict[str, Tensor], device, n_hist: int = 11) -> Dict[str, Tensor]:
-    """Reference test-split batch (`data_h5_womd.py:119-157`, bool tensors, history/ prefix) ->
-    the C ABI's device layout (uint8 masks, int32 class indices, yaw/spd/acc as [B,NH,A]).  `warm_ok` (a Python bool, not a
-    tensor) records that no agent leaves within the history, see :func:`no_early_exit`."""
+    """Reference batch (`data_h5_womd.py:85-157`, bool tensors) -> the C ABI's device layout (uint8 masks, int32 class
+    indices, yaw/spd/acc as [B,NH,A]).  Test / validation batches carry the history under "history/*"; a TRAINING-split batch
+    has only "agent/*" / "tl_stop/*" over 91 steps, of which `SceneCentricPreProcessing` (prefix "" in training,
+    `scene_centric.py:92-121`) takes the first `n_hist` steps -- same here.  `warm_ok` (a Python bool, not a tensor) records
+    that no agent leaves within the history, see :func:`no_early_exit`."""
+    pre = "history/" if "history/agent/valid" in batch else ""
+    if not pre and "agent/valid" not in batch:
+        raise KeyError("batch carries neither 'history/agent/*' nor 'agent/*'")
 
     def g(k):
         v = batch[k]
@@ -64,32 +82,34 @@ def scene_from_batch(batch: Dict[str, Tensor], device, n_hist: int = 11) -> Dict
             v = torch.from_numpy(v)
         return v.to(device)
 
+    def h(k):  # history part of a per-step tensor
+        return g(pre + k)[:, :n_hist]
+
     f32, u8 = torch.float32, torch.uint8
     s: Dict[str, Tensor] = {}
-    s["warm_ok"] = no_early_exit(batch["history/agent/valid"], n_hist)
-    av = g("history/agent/valid")[:, :n_hist]
-    s["agent_valid"] = av.to(u8).contiguous()
-    pos = g("history/agent/pos")[:, :n_hist].to(f32)
-    yaw = g("history/agent/yaw_bbox")[:, :n_hist].to(f32)
-    spd = g("history/agent/spd")[:, :n_hist].to(f32)
+    s["warm_ok"] = no_early_exit(batch[pre + "agent/valid"], n_hist)
+    s["agent_valid"] = h("agent/valid").to(u8).contiguous()
+    pos = h("agent/pos").to(f32)
+    yaw = h("agent/yaw_bbox").to(f32)
+    spd = h("agent/spd").to(f32)
     s["agent_pos"] = pos.contiguous()
     s["agent_yaw"] = yaw[..., 0].contiguous()
     s["agent_spd"] = spd[..., 0].contiguous()
     s["agent_state"] = torch.cat([pos, yaw, spd], -1).contiguous()
-    s["agent_vel"] = g("history/agent/vel")[:, :n_hist].to(f32).contiguous()
-    s["agent_acc"] = g("history/agent/acc")[:, :n_hist, :, 0].to(f32).contiguous()
-    s["agent_yaw_rate"] = g("history/agent/yaw_rate")[:, :n_hist, :, 0].to(f32).contiguous()
-    s["agent_type"] = _onehot_to_index(g("history/agent/type"))
-    s["agent_size"] = g("history/agent/size").to(f32).contiguous()
+    s["agent_vel"] = h("agent/vel").to(f32).contiguous()
+    s["agent_acc"] = h("agent/acc")[..., 0].to(f32).contiguous()
+    s["agent_yaw_rate"] = h("agent/yaw_rate")[..., 0].to(f32).contiguous()
+    s["agent_type"] = _onehot_to_index(g(pre + "agent/type"))
+    s["agent_size"] = g(pre + "agent/size").to(f32).contiguous()
     s["map_valid"] = g("map/valid").to(u8).contiguous()
     s["map_type"] = _onehot_to_index(g("map/type"))
     s["map_pos"] = g("map/pos").to(f32).contiguous()
     s["map_dir"] = g("map/dir").to(f32).contiguous()
     s["map_boundary"] = g("map/boundary").to(f32).contiguous()
-    s["tl_valid"] = g("history/tl_stop/valid")[:, :n_hist].to(u8).contiguous()
-    s["tl_state"] = _onehot_to_index(g("history/tl_stop/state")[:, :n_hist])
-    s["tl_pos"] = g("history/tl_stop/pos")[:, :n_hist].to(f32).contiguous()
-    s["tl_dir"] = g("history/tl_stop/dir")[:, :n_hist].to(f32).contiguous()
+    s["tl_valid"] = h("tl_stop/valid").to(u8).contiguous()
+    s["tl_state"] = _onehot_to_index(h("tl_stop/state"))
+    s["tl_pos"] = h("tl_stop/pos").to(f32).contiguous()
+    s["tl_dir"] = h("tl_stop/dir").to(f32).contiguous()
     return s
 
 
@@ -98,7 +118,7 @@ _CRITERIA = {"SmoothL1Loss": 0, "MSELoss": 1, "L1Loss": 2}
 _ANGULAR = {None: 0, "cast": 1, "cosine": 2, "vector": 3}
 
 
-def gt_from_batch(batch: Dict[str, Tensor], device) -> Dict[str, Tensor]:
+def gt_from_batch(batch: Dict[str, Tensor], device, n_hist: int = 11) -> Dict[str, Tensor]:
     """Ground-truth part of a validation / training batch (`data_h5_womd.py:85-118`: "agent/*", "tl_stop/*" over all 91
     steps) -> the C ABI's device layout: what `SceneCentricPreProcessing` exposes as "gt/*" (`scene_centric.py:103-110`),
     `SceneCentricLatent` as "latent_post/*" (`sc_latent.py:150-163,196-217`) and `reactive_replay` as `features`
@@ -112,7 +132,7 @@ def gt_from_batch(batch: Dict[str, Tensor], device) -> Dict[str, Tensor]:
 
     f32, u8 = torch.float32, torch.uint8
     s: Dict[str, Tensor] = {}
-    s["warm_ok"] = no_early_exit(batch["agent/valid"], 11)  # (time_step_current + 1 steps: the warm start of every TeacherForcing config)
+    s["warm_ok"] = no_early_exit(batch["agent/valid"], n_hist)  # (time_step_current + 1 steps: the warm start of every TeacherForcing config)
     s["agent_valid"] = g("agent/valid").to(u8).contiguous()
     pos, yaw, spd = g("agent/pos").to(f32), g("agent/yaw_bbox").to(f32), g("agent/spd").to(f32)
     s["agent_pos"] = pos.contiguous()

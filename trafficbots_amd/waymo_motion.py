@@ -19,7 +19,7 @@ from torch import Tensor
 from .config import load_model_config
 from .distributions import DestCategorical, DiagGaussian
 from .metrics import ErrorMetrics, TrafficRuleMetrics, TrainingMetrics
-from .runtime import HipEngine, gt_from_batch, scene_from_batch, teacher_forcing_mask
+from .runtime import HipEngine, gt_from_batch, scene_from_batch, teacher_forcing_mask, warm_start_promise_holds
 
 _VIOLATION_KEYS = (
     "outside_map", "outside_map_this_step", "collided", "collided_this_step", "run_road_edge",
@@ -154,7 +154,7 @@ class WaymoMotion:
             return scene_from_packed(batch, self.device, self.n_hist)
         scene = scene_from_batch(batch, self.device, self.n_hist)
         if "agent/valid" in batch:
-            scene["gt"] = gt_from_batch(batch, self.device)
+            scene["gt"] = gt_from_batch(batch, self.device, self.n_hist)
         return scene
 
     # ------------------------------------------------------------------ rollout
@@ -195,6 +195,9 @@ class WaymoMotion:
             raise NotImplementedError("step_start must equal time_step_sim_start")
         z = latent.sample(deterministic_latent, eps=latent_eps)
         b = features["agent_valid"].shape[0]
+        if warm_start_steps > 0 and not warm_start_promise_holds(
+                mask_teacher_forcing, (gt if gt is not None else features)["agent_valid"], warm_start_steps):
+            warm_start_steps = 0  # a caller-made mask that does not force every valid agent: step by step
         mean_scene = latent.mean.reshape(b, k_futures, *latent.mean.shape[1:])[:, 0].contiguous()
         # traffic_rule_checker.enable_check_* (traffic_bots.yaml:240-244): the flag-gated checks do not feed back into the
         # simulation, they are evaluated on the recorded per-step states once the rollout is enqueued (tb_rule_checks)
@@ -263,14 +266,15 @@ class WaymoMotion:
         features["map_feature"] = input_feature_dict["map_feature"]
         features["map_feature_valid"] = input_feature_dict["map_feature_valid"].to(torch.uint8).contiguous()
         features["tl_feature"] = input_feature_dict["tl_feature"]
-        # (the masks of validation / training force every valid agent up to step_warm_start = time_step_current)
+        # (the masks of validation / training force every valid agent up to step_warm_start = time_step_current; a mask the
+        # caller made itself is checked against that promise, and the warm start is not batched when it does not hold)
+        w = self._warm_start_steps(teacher_forcing_cfg or self.hparams["teacher_forcing_reactive_replay"], batch["gt"])
         return self.rollout(
             features, latent=latent, goal=goal, goal_valid=goal_valid, mask_teacher_forcing=mask_teacher_forcing,
             deterministic_latent=deterministic_latent, deterministic_action=deterministic_action,
             step_start=self.hparams["time_step_sim_start"], step_end=self.hparams["time_step_end"], k_futures=1,
             gt=batch["gt"], latent_posterior=latent_is_posterior, require_vis_dict=require_vis_dict, rule_checker_tl=batch["gt"],
-            latent_eps=latent_eps,
-            warm_start_steps=self._warm_start_steps(teacher_forcing_cfg or self.hparams["teacher_forcing_reactive_replay"], batch["gt"]),
+            latent_eps=latent_eps, warm_start_steps=w,
         )
 
     def finish_rollout(self) -> RolloutBuffer:
@@ -334,6 +338,10 @@ class WaymoMotion:
         if goal_sample is None:
             goal_sample = goal.sample(deterministic, generator=generator)
         else:
+            if not goal_sample.is_cuda:  # a caller-supplied destination (host tensor: checked for free; the device clamps anyway)
+                n_pl = input_feature_dict["map_feature"].shape[1]
+                if int(goal_sample.min()) < 0 or int(goal_sample.max()) >= n_pl:
+                    raise IndexError(f"goal_sample holds a polyline index outside [0, {n_pl})")
             goal_sample = goal_sample.to(self.device).reshape(b * k, a)
         goal_log_probs = goal.log_prob(goal_sample)
         goal_valid = goal_valid.repeat_interleave(k, 0)
