@@ -9,13 +9,17 @@ Tolerances (fp32, stated per north_star):
   * closed-loop xy over the 8 s horizon: north_star's target is <= 1e-4 m.  The rollout is chaotic: the
     REFERENCE's own fp32 run differs from its fp64 run by up to 1.3e-4 m at step 90 on the headline shape
     (fixtures `preds_fp64`), so two correct fp32 implementations cannot agree better than that noise.
-    Asserted, per step t, with noise(t) = running max of |reference fp32 - reference fp64|:
+    Asserted, per step t, with noise(t) = running max of |reference fp32 - reference fp64| (every closed-loop golden stores its
+    fp64 twin, generated with the fp32 run's sampled destinations):
         (a) |hip - reference fp64|(t) <= max(1e-4, 1.5 * noise(t))   -- no farther from the exact answer
                                                                          than the reference's fp32 path is;
         (b) |hip - reference fp32|(t) <= max(1e-4, 2.5 * noise(t))   -- both noises add;
-    where no fp64 twin is stored: flat 2.5e-4.  Measured values are written to gpurun_out/parity_report.json
-    (typical: 5e-5 .. 2.5e-4 at step 90).  Discrete outputs (valid / override / kill / destination-reached
-    flags) must be EQUAL.
+        (c) north_star's flat bound where it is attainable: |hip - reference fp32|(t) <= 1e-4 over the WHOLE horizon on the
+            small shapes (<= 16 agents without dense interaction: c1_plumbing, small_k1, degenerate, val_small, val_alt_losses)
+            and for every step t <= 60 on the headline shape and the mask-heavy cases (FLAT_1E4_UNTIL below).
+    Measured values are written to gpurun_out/parity_report.json (typical: 5e-5 .. 2.5e-4 at step 90; the reference's own
+    fp32-vs-fp64 distance is 1.3e-4 / 1.9e-4 / 2.6e-4 on headline_2 / headline_k6 / val_masks).  Discrete outputs
+    (valid / override / kill / destination-reached flags) must be EQUAL.
 """
 import json
 import os
@@ -30,6 +34,35 @@ pytestmark = pytest.mark.gpu
 
 ONE_SHOT_TOL = 2e-5
 REPORT = {}
+
+
+# simulation step up to which |hip - reference fp32| <= 1e-4 m is asserted flat (None = the whole horizon)
+FLAT_1E4_UNTIL = {"c1_plumbing": None, "small_k1": None, "degenerate": None, "val_small": None, "val_alt_losses": None,
+                  "masks_k3": 60, "headline_2": 60, "headline_k6": 60, "val_masks": 60}
+
+
+def _closed_loop_check(name, preds, g, step_axis, rep, step_start=1):
+    """Assertions (a), (b), (c) of the module docstring for one golden.  `preds` / g["preds"] have the simulation steps on
+    `step_axis` and xy/yaw/spd last; returns nothing, fills `rep`."""
+    assert "preds_fp64" in g.files, f"{name}: golden without fp64 twin"
+    ax = tuple(i for i in range(preds.ndim) if i != step_axis)
+    v32 = g["valid"][..., None]
+    both = (g["valid"] & g["valid_fp64"])[..., None]
+    d32 = (np.abs(preds - g["preds"]) * v32)[..., :2].max(axis=ax)
+    noise = np.maximum.accumulate((np.abs(g["preds"].astype(np.float64) - g["preds_fp64"]) * both)[..., :2].max(axis=ax))
+    d64 = (np.abs(preds.astype(np.float64) - g["preds_fp64"]) * both)[..., :2].max(axis=ax)
+    rep["traj_xy_max"] = float(d32.max())
+    rep["ref_fp32_vs_fp64_xy_max"] = float(noise.max())
+    rep["traj_xy_vs_fp64_max"] = float(d64.max())
+    above = np.nonzero(d32 > 1e-4)[0]
+    rep["first_step_above_1e-4_vs_fp32"] = int(above[0]) + step_start if above.size else None
+    until = FLAT_1E4_UNTIL[name]
+    n_flat = d32.shape[0] if until is None else min(d32.shape[0], until - step_start + 1)
+    rep["traj_xy_max_flat_window"] = float(d32[:n_flat].max())
+    REPORT[name] = rep
+    assert (d64 <= np.maximum(1e-4, 1.5 * noise)).all(), f"{name}: {d64.max():.3e} from fp64, farther than the reference fp32 path ({noise.max():.3e})"
+    assert (d32 <= np.maximum(1e-4, 2.5 * noise)).all(), f"{name}: closed-loop xy error {d32.max():.3e} exceeds envelope"
+    assert d32[:n_flat].max() <= 1e-4, f"{name}: {d32[:n_flat].max():.3e} > 1e-4 within the first {n_flat} steps"
 
 
 def _assert_closed_loop(preds, r32, r64, what):
@@ -109,27 +142,12 @@ def test_against_reference_golden(name):
     preds = buf.preds.cpu().numpy()
     d = np.abs(preds - g["preds"]) * g["valid"][..., None]  # [B,A,K,S,4]
     per_step = d[..., :2].max(axis=(0, 1, 2, 4))
-    rep["traj_xy_max"] = float(per_step.max())
     rep["traj_yaw_max"] = float(d[..., 2].max())
     rep["traj_spd_max"] = float(d[..., 3].max())
     n_open = min(10, per_step.shape[0])
     rep["traj_xy_open_loop_max"] = float(per_step[:n_open].max())
     assert rep["traj_xy_open_loop_max"] <= 1e-5
-    if "preds_fp64" in g.files:
-        ref_noise = (np.abs(g["preds"].astype(np.float64) - g["preds_fp64"]) * (g["valid"] & g["valid_fp64"])[..., None])
-        noise_step = ref_noise[..., :2].max(axis=(0, 1, 2, 4))
-        rep["ref_fp32_vs_fp64_xy_max"] = float(noise_step.max())
-        d64 = np.abs(preds.astype(np.float64) - g["preds_fp64"]) * (g["valid"] & g["valid_fp64"])[..., None]
-        rep["traj_xy_vs_fp64_max"] = float(d64[..., :2].max())
-        noise = np.maximum.accumulate(noise_step)
-        d64_step = d64[..., :2].max(axis=(0, 1, 2, 4))
-        REPORT[name] = rep
-        assert (d64_step <= np.maximum(1e-4, 1.5 * noise)).all(), f"{name}: farther from fp64 than the reference fp32 path"
-        bound = np.maximum(1e-4, 2.5 * noise)
-    else:
-        bound = np.full_like(per_step, 2.5e-4)
-    REPORT[name] = rep
-    assert (per_step <= bound).all(), f"{name}: closed-loop xy error {per_step.max():.3e} exceeds envelope"
+    _closed_loop_check(name, preds, g, 3, rep)
 
 
 @pytest.mark.parametrize("seed,scene", [
@@ -462,18 +480,7 @@ def test_validation_step_against_reference_golden(name):
     assert (buf.diffbar_rewards_valid[:, :, 0].cpu().numpy() == g["diffbar_rewards_valid"]).all()
     preds = buf.preds[:, :, 0].cpu().numpy()
     d = np.abs(preds - g["preds"]) * g["valid"][..., None]
-    per_step = d[..., :2].max(axis=(0, 1, 3))
-    rep["traj_xy_max"] = float(per_step.max())
-    if "preds_fp64" in g.files:
-        both = (g["valid"] & g["valid_fp64"])[..., None]
-        noise = np.maximum.accumulate((np.abs(g["preds"].astype(np.float64) - g["preds_fp64"]) * both)[..., :2].max(axis=(0, 1, 3)))
-        d64 = (np.abs(preds.astype(np.float64) - g["preds_fp64"]) * both)[..., :2].max(axis=(0, 1, 3))
-        rep["ref_fp32_vs_fp64_xy_max"], rep["traj_xy_vs_fp64_max"] = float(noise.max()), float(d64.max())
-        assert (d64 <= np.maximum(1e-4, 1.5 * noise)).all()
-        bound = np.maximum(1e-4, 2.5 * noise)
-    else:
-        bound = np.full_like(per_step, 2.5e-4)
-    assert (per_step <= bound).all(), f"{name}: replay xy error {per_step.max():.3e} exceeds envelope"
+    _closed_loop_check(name, preds, g, 2, rep)
     # rewards follow the trajectories: the criteria are 1-Lipschitz (SmoothL1 / L1) or quadratic (MSE) in errors of <= 2.5e-4
     rw = buf.diffbar_rewards[:, :, 0].cpu().numpy()
     rep["reward_max_abs"] = float(np.abs(rw - g["diffbar_rewards"]).max())

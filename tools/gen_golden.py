@@ -46,13 +46,13 @@ CASES = {
         base_seed=3000, n_scene=3, k=3, weight_seed=8, time_step_end=90,
         scene=dict(n_agent=16, n_pl=48, n_tl=40, p_invalid_agent=0.3, p_late_spawn=0.3, p_early_exit=0.2,
                    p_invalid_pl=0.2, p_invalid_node=0.5, pos_range=140.0),
-        tap_steps=[1, 11, 30], fp64=False, store_feats=True,
+        tap_steps=[1, 11, 30], fp64=True, store_feats=True,
     ),
     # degenerate scenes: a single valid agent (interaction bypass), no valid TL, few polylines
     "degenerate": dict(
         base_seed=4000, n_scene=2, k=2, weight_seed=8, time_step_end=40,
         scene=dict(n_agent=16, n_pl=16, n_tl=40, p_invalid_agent=0.97, p_tl_valid=0.0, p_invalid_pl=0.5),
-        tap_steps=[1, 11], fp64=False, store_feats=True,
+        tap_steps=[1, 11], fp64=True, store_feats=True,
     ),
     # BASELINE.json configs[1] shape (headline), 2 scenes of it
     "headline_2": dict(
@@ -62,7 +62,7 @@ CASES = {
     # configs[3] shape: K=6 multi-modal, one scene
     "headline_k6": dict(
         base_seed=6000, n_scene=1, k=6, weight_seed=7, time_step_end=90,
-        scene=dict(n_agent=64, n_pl=256, n_tl=40), tap_steps=[], fp64=False, store_feats=False,
+        scene=dict(n_agent=64, n_pl=256, n_tl=40), tap_steps=[], fp64=True, store_feats=False,
     ),
     # the four flag-gated traffic-rule checks on dense scenes (agents, polylines and stop points inside
     # +-25 m so that collisions, road-edge crossings, red-light runs and passive agents actually occur); also stores the
@@ -84,7 +84,10 @@ RULE_KEYS = ["collided", "collided_this_step", "run_road_edge", "run_road_edge_t
              "run_red_light_this_step", "passive", "passive_this_step"]
 
 
-def run_reference(case: dict, dtype=torch.float32) -> dict:
+def run_reference(case: dict, dtype=torch.float32, force_goal_sample=None) -> dict:
+    """`force_goal_sample` [B,A,K] (the fp32 run's destinations): the fp64 twin must follow the SAME sampled destinations -- the
+    multinomial draw of `DestCategorical.sample` depends on the dtype of the probabilities -- so the sampler is replaced by the stored
+    indices for that run (argmax destinations of instance 0 are checked to agree anyway)."""
     over = {"time_step_end": case["time_step_end"], "n_joint_future": case["k"]}
     if case.get("rule_flags"):
         over["traffic_rule_checker"] = {"enable_check_collided": True, "enable_check_run_road_edge": True,
@@ -164,6 +167,13 @@ def run_reference(case: dict, dtype=torch.float32) -> dict:
                     return orig_check(self, step, as_valid, as_state)
 
                 TrafficRuleChecker.check = spy_check
+            if force_goal_sample is not None:
+                forced = torch.from_numpy(np.ascontiguousarray(np.transpose(force_goal_sample, (0, 2, 1)))).reshape(n_inst, -1)
+
+                def forced_sample(deterministic, _f=forced):
+                    return _f.clone()
+
+                goal_pred.sample = forced_sample  # (instance attribute: joint_future_pred calls goal.sample(deterministic), :500)
             buf, goal_sample, goal_log_probs = model.joint_future_pred(
                 batch=batch, input_feature_dict=feats, latent=latent_prior, goal=goal_pred,
                 goal_valid=goal_valid, require_vis_dict=False,
@@ -232,7 +242,7 @@ def main() -> None:
             if k.startswith("tap") or k.startswith("check_") or k in RULE_KEYS:
                 save[k] = v
         if case["fp64"]:
-            r64 = run_reference(case, torch.float64)
+            r64 = run_reference(case, torch.float64, force_goal_sample=r32["goal_sample"])
             save["preds_fp64"] = r64["preds"]
             save["valid_fp64"] = r64["valid"]
             save["goal_sample_fp64"] = r64["goal_sample"]

@@ -41,7 +41,7 @@ CASES = {
                    "training_metrics.kl_for_unseen_agent": False},
         scene=dict(n_agent=16, n_pl=48, n_tl=40, p_invalid_agent=0.3, p_late_spawn=0.3, p_early_exit=0.2, p_invalid_pl=0.2,
                    p_invalid_node=0.5, pos_range=40.0, p_future_spawn=0.6, p_future_exit=0.4),
-        fp64=False,
+        fp64=True,
     ),
     # collision penalty averaged over agents, MSE / cast-angle criteria, KL balancing, no free nats
     "val_alt_losses": dict(
@@ -50,7 +50,7 @@ CASES = {
                    "differentiable_reward.l_pos.criterion": "MSELoss", "differentiable_reward.l_rot.angular_type": "cast",
                    "differentiable_reward.l_spd.criterion": "L1Loss", "training_metrics.kl_balance_scale": 0.8,
                    "training_metrics.kl_free_nats": -1, "training_metrics.step_training_start": 0},
-        scene=dict(n_agent=12, n_pl=40, n_tl=40, pos_range=25.0, p_invalid_agent=0.1, p_future_exit=0.2), fp64=False,
+        scene=dict(n_agent=12, n_pl=40, n_tl=40, pos_range=25.0, p_invalid_agent=0.1, p_future_exit=0.2), fp64=True,
     ),
 }
 
