@@ -1,0 +1,200 @@
+"""GPU tests of the BASELINE.json configurations beyond the headline (configs[3]: K = 6 futures with bf16 operands at B = 32;
+configs[4]: the A = 128 / P = 1024 / 170-step stress shape, bf16 and fp32-accurate) and of the bench command's N > 1 path."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, golden_inputs, load_golden
+
+pytestmark = pytest.mark.gpu
+
+REPORT = {}
+
+
+def _wm(**over):
+    from trafficbots_amd.waymo_motion import WaymoMotion
+
+    return WaymoMotion(**over)
+
+
+def _per_step_max(a, b, valid):
+    """max-abs xy difference per simulation step of two [B,A,K,S,4] buffers over `valid` [B,A,K,S]"""
+    d = (a[..., :2] - b[..., :2]).abs() * valid.unsqueeze(-1)
+    return d.amax(dim=(0, 1, 2, 4))
+
+
+def test_config3_k6_bf16_at_batch_32():
+    """BASELINE configs[3] exactly: B = 32 scenes, K = 6 futures, A = 64, P = 256, 90 steps, operand_precision = "bf16", against
+    the fp32-accurate run of the same inputs: teacher-forced bookkeeping equal (valid / override masks of the warm-up steps, the
+    teacher-forced predictions within bf16's one-step error), everything finite, bitwise deterministic; the bf16 error is REPORTED
+    per step (gpurun_out/configs_report.json), against the fp32-accurate HIP run and against the reference golden `headline_k6`
+    (scene 0 of that golden's seed stream)."""
+    from trafficbots_amd import synth
+
+    sd = synth.make_state_dict(7)
+    batch = synth.make_batch(6000, 32, n_agent=64, n_pl=256, n_tl=40)  # scene 0 = the `headline_k6` golden's scene
+    g, meta = load_golden("headline_k6")
+    eps = synth.make_latent_noise(meta["base_seed"] + 99 + 1000, 32 * 6, 64)
+    eps[:6] = synth.make_latent_noise(meta["base_seed"] + 99, 6, 64)  # the golden's draws for scene 0
+    eps_t = torch.from_numpy(eps).cuda()
+    outs = {}
+    wm = _wm(time_step_end=90, n_joint_future=6)
+    wm.load_state_dict(sd)
+    o = wm.test_step(batch, latent_eps=eps_t, generator=torch.Generator(device="cuda").manual_seed(5))
+    goal = o["goal_sample"]                       # [B,A,K]; both precisions follow the same sampled destinations
+    gs = goal.transpose(1, 2).contiguous().cpu()  # [B,K,A]
+    outs["fp32"] = o["rollout_buffer"]
+    wm = _wm(time_step_end=90, n_joint_future=6, operand_precision="bf16")
+    wm.load_state_dict(sd)
+    o = wm.test_step(batch, latent_eps=eps_t, goal_sample=gs)
+    o2 = wm.test_step(batch, latent_eps=eps_t, goal_sample=gs)
+    assert torch.equal(o["rollout_buffer"].preds, o2["rollout_buffer"].preds), "bf16 run is not bitwise deterministic"
+    outs["bf16"] = o["rollout_buffer"]
+    torch.cuda.synchronize()
+    a, b = outs["fp32"], outs["bf16"]
+    assert torch.isfinite(b.preds).all() and torch.isfinite(a.preds).all()
+    assert a.preds.shape == (32, 64, 6, 90, 4)
+    # teacher-forced steps 1..10: identical bookkeeping, predictions one bf16 policy step away from the fp32 ones
+    assert torch.equal(a.override_masks, b.override_masks)
+    assert torch.equal(a.valid[..., :11], b.valid[..., :11])
+    per_step = _per_step_max(a.preds, b.preds, a.valid & b.valid)
+    assert per_step[:10].max() <= 5e-2, per_step[:10]
+    # flags: the discrete outputs may only differ where a trajectory moved (reported), never at the forced steps
+    for key in ("outside_map", "dest_reached"):
+        assert torch.equal(a.violations[key][..., :10], b.violations[key][..., :10]), key
+    rep = {"bf16_vs_fp32_xy_per_step": [float(x) for x in per_step.cpu()],
+           "valid_mismatch_frac": float((a.valid != b.valid).float().mean()),
+           "dest_reached_mismatch_frac": float((a.violations["dest_reached"] != b.violations["dest_reached"]).float().mean())}
+    # scene 0 against the reference golden (fp32 HIP run: the closed-loop envelope; bf16: reported)
+    gp, gv = torch.from_numpy(g["preds"]).cuda(), torch.from_numpy(g["valid"]).cuda()
+    # (the destinations of scene 0 are the HIP sampler's draws, not the golden's: compare the futures where they agree --
+    # future 0, the argmax, always does unless two logits nearly tie)
+    same = torch.from_numpy(g["goal_sample"]).cuda() == goal[:1]            # [1,A,K]
+    m = (gv & same.unsqueeze(-1))
+    rep["scene0_dest_agree_frac"] = float(same.float().mean())
+    for t in (11, 30, 60, 90):
+        mt = m[..., t - 1, None]
+        rep[f"scene0_fp32_vs_reference_xy_step{t}"] = float(((a.preds[:1] - gp)[..., t - 1, :2].abs() * mt).max())
+        rep[f"scene0_bf16_vs_reference_xy_step{t}"] = float(((b.preds[:1] - gp)[..., t - 1, :2].abs() * mt).max())
+    REPORT["config3_k6_bf16"] = rep
+    assert rep["scene0_fp32_vs_reference_xy_step11"] <= 1e-4
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_config4_stress_shape_170_steps(prec):
+    """BASELINE configs[4] shape at its full horizon: A = 128, P = 1024, time_step_end = 170 (160 future steps), 4 scenes, both
+    operand precisions.  Size-independent properties (no oracle finishes this in seconds): finite, bitwise deterministic, sub-batch
+    independence (scenes 1..2 alone = the same rows), the teacher-forced steps reproduce the history, yaw is never wrapped, agents
+    that leave the map are killed; plus a short-horizon check against the CPU oracle (fp32 only: 1 scene, 14 steps)."""
+    from trafficbots_amd import synth
+
+    sd = synth.make_state_dict(7)
+    scene = dict(n_agent=128, n_pl=1024, n_tl=40)
+    batch = synth.make_batch(9400, 4, **scene)
+    eps = torch.from_numpy(synth.make_latent_noise(9401, 4, 128)).cuda()
+    wm = _wm(time_step_end=170, n_joint_future=1, operand_precision=prec)
+    wm.load_state_dict(sd)
+    a = wm.test_step(batch, latent_eps=eps)["rollout_buffer"]
+    b = wm.test_step(batch, latent_eps=eps)["rollout_buffer"]
+    torch.cuda.synchronize()
+    assert a.preds.shape == (4, 128, 1, 170, 4)
+    assert torch.isfinite(a.preds).all()
+    assert torch.equal(a.preds, b.preds) and torch.equal(a.valid, b.valid), "not bitwise deterministic"
+    sub = {k_: v[1:3] for k_, v in batch.items()}
+    c = wm.test_step(sub, latent_eps=eps[1:3])["rollout_buffer"]
+    assert torch.equal(c.preds, a.preds[1:3]), "a scene's result depends on its neighbours in the batch"
+    hist = torch.from_numpy(batch["history/agent/pos"]).cuda()  # [B,11,A,2]
+    gap = (a.preds[:, :, 0, :10, :2] - hist[:, 1:11].transpose(1, 2)).norm(dim=-1)
+    assert gap.max() < 3.0
+    # an agent flagged outside the map without ground truth behind it is invalid from the next step on (dynamics.py:161-167)
+    out_this = a.violations["outside_map_this_step"][:, :, 0, 10:-1]
+    nxt_valid = a.valid[:, :, 0, 11:]
+    assert not (out_this & nxt_valid).any()
+    REPORT[f"config4_stress_{prec}"] = {"valid_frac_final": float(a.valid[..., -1].float().mean()),
+                                        "dest_reached_final": float(a.violations["dest_reached"][..., -1].float().mean()),
+                                        "max_abs_xy": float(a.preds[..., :2].abs().max())}
+    if prec == "bf16":
+        wm32 = _wm(time_step_end=170, n_joint_future=1)
+        wm32.load_state_dict(sd)
+        r = wm32.test_step(batch, latent_eps=eps)["rollout_buffer"]
+        per_step = _per_step_max(r.preds, a.preds, r.valid & a.valid)
+        REPORT["config4_stress_bf16"]["bf16_vs_fp32_xy_per_step"] = [float(x) for x in per_step.cpu()]
+        assert torch.equal(r.override_masks, a.override_masks)
+        assert per_step[:10].max() <= 5e-2
+        return
+    from oracle.trafficbots_oracle import Oracle
+    from trafficbots_amd.config import load_model_config
+
+    cfg = load_model_config(overrides={"time_step_end": 14, "n_joint_future": 1})
+    one = {k_: v[:1] for k_, v in batch.items()}
+    wm14 = _wm(time_step_end=14, n_joint_future=1)
+    wm14.load_state_dict(sd)
+    o = wm14.test_step(one, latent_eps=eps[:1])
+    dest = o["goal_sample"].transpose(1, 2).reshape(1, -1).cpu().numpy()
+    with torch.no_grad():
+        ref = Oracle(sd, cfg, torch.float32, hoist=True).joint_future_pred(one, 1, eps[:1].cpu().numpy(), 14, dest_override=dest)
+    buf = o["rollout_buffer"]
+    assert (buf.valid.cpu() == ref["valid"]).all()
+    err = ((buf.preds.cpu() - ref["preds"]).abs() * ref["valid"].unsqueeze(-1))[..., :2].max().item()
+    REPORT["config4_stress_fp32"]["xy_vs_oracle_14_steps"] = err
+    assert err <= 1e-4
+    # the 170-step run and the 14-step run agree bitwise on their common steps (nothing depends on the horizon)
+    assert torch.equal(buf.preds[0, :, 0], a.preds[0, :, 0, :14])
+
+
+def _run_bench(extra, env_extra=None):
+    env = dict(os.environ)
+    env.update(env_extra or {})
+    env.pop("RANK", None)
+    env.pop("WORLD_SIZE", None)
+    env.pop("LOCAL_RANK", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu-baseline"] + extra,
+                       capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_plain_command_spawns_its_ranks():
+    """`python bench.py --gpus 2` as a PLAIN command (no torchrun, no WORLD_SIZE) spawns its own two ranks and prints one line;
+    with TB_BENCH_BACKEND=gloo the ranks share the visible GPU(s), which exercises shards, barriers, the max-over-ranks time and the
+    single packed all-reduce on a 1-GPU box.  The N = 2 line covers twice the scenes of the N = 1 line of the same command."""
+    one = _run_bench(["--gpus", "1", "--lean"])
+    two = _run_bench(["--gpus", "2", "--lean"], {"TB_BENCH_BACKEND": "gloo"})
+    assert one["n_gpus"] == 1 and two["n_gpus"] == 2
+    assert two["checks"]["scene_steps"] == 2 * one["checks"]["scene_steps"] == 2 * 32 * 90
+    assert two["checks"]["finite"] and one["checks"]["finite"]
+    # rank 1 rolled out scenes 32..63 of the seeded stream: different scenes, same count of agent slots
+    assert two["reference_metric_states"]["counter_agent"] == 2 * one["reference_metric_states"]["counter_agent"]
+    assert two["checks"]["valid_agent_steps"] != 2 * one["checks"]["valid_agent_steps"]
+    for ln in (one, two):
+        for key in ("metric", "value", "unit", "ms_per_step", "scaling", "roofline", "config"):
+            assert key in ln
+        assert ln["roofline"]["frac"] > 0 and ln["value"] > 0
+    REPORT["bench_gloo_dry_run"] = {"n1_value": one["value"], "n2_value_two_ranks_one_gpu": two["value"]}
+
+
+def test_bench_sub_records_and_traj_err():
+    """the default single-GPU command carries the configs[3] / configs[4] sub-records and the golden trajectory error"""
+    ln = _run_bench(["--gpus", "1", "--config-steps", "2", "--configs", "k6_bf16", "stress_bf16"])
+    assert set(ln["configs"]) == {"k6_bf16", "stress_bf16"}
+    for name, rec in ln["configs"].items():
+        assert "error" not in rec, rec
+        assert rec["finite"] and rec["value"] > 0 and rec["k_step_fused_us"] > 0
+    assert ln["configs"]["k6_bf16"]["instances_per_gpu"] == 192 and ln["configs"]["stress_bf16"]["sim_steps"] == 170
+    e = ln["max_abs_traj_err"]
+    assert e["flags_equal"] and e["xy_vs_reference_fp32_steps_1_to_60"] <= 1e-4
+    assert e["xy_vs_reference_fp64"] <= max(1e-4, 1.5 * e["reference_fp32_vs_its_fp64"])
+    assert ln["roofline"]["mfma_busy"]["estimated"] > 0 and ln["encode_roofline"]["frac"] > 0
+
+
+def teardown_module(module):
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "configs_report.json"), "w") as f:
+        json.dump(REPORT, f, indent=1)

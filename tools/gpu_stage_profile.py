@@ -59,17 +59,10 @@ print(f"  {NAMES[7]:32s} {np.median(v):9.0f}  [{v.min():8.0f} .. {v.max():8.0f}]
 print(f"  sum of medians (without A front-end) {tot:9.0f}")
 seq = [0, 12, 13, 14, 15, 1]
 lab = ["LN params -> LDS (issue+store)", "row state loads (16 thr)", "valid ballots", "wload + 6 tile loads + geometry issue", "barrier (wait for all)"]
-if os.environ.get("TB_STEP_KERNEL") in ("fp32", "fp32w8"):  # (k_step_x keeps no stamps inside its one-round-trip prologue)
+if os.environ.get("TB_STEP_KERNEL") == "fp32":  # (k_step_x keeps no stamps inside its one-round-trip prologue)
     for i in range(5):
         v = st[:, seq[i + 1]] - st[:, seq[i]]
         print(f"    C-start/{lab[i]:40s} {np.median(v):8.0f}  [{v.min():7.0f} .. {v.max():7.0f}]")
-if os.environ.get("TB_STEP_KERNEL") == "fp32w8":
-    lab = ["LN1 + barrier", "Q proj (32 MFMA) + LDS exchange + barrier", "attention half: 128 keys (4 x 32 MFMA)", "partial store + barrier",
-           "softmax merge + barrier", "out proj + residual + barrier", "LN2 + barrier", "FFN1 + relu + barrier", "FFN2 + residual + barrier"]
-    for i in range(9):
-        v = st[:, 17 + i] - st[:, 16 + i]
-        print(f"    as2pl[0]/{lab[i]:44s} {np.median(v):8.0f}  [{v.min():7.0f} .. {v.max():7.0f}]")
-    sys.exit(0)
 lab = ["LN1 + barrier", "wload + Q proj (64 MFMA)", "attention 256 keys (8 x 32 MFMA)", "store + barrier", "wload + out proj + residual + barrier",
        "LN2 + barrier", "wload + FFN1 + relu + barrier", "wload + FFN2 + residual + barrier"]
 for i in range(8):

@@ -21,8 +21,6 @@ void launch_rollout_init(const RolloutP& p, hipStream_t s);
 void launch_step(const RolloutP& p, int t, int do_c, int do_a, hipStream_t s);
 void launch_rollout_final(const RolloutP& p, float* f_state, uint8_t* f_valid, float* f_hidden, hipStream_t s);
 hipError_t configure_rollout_kernels();
-void launch_step8(const RolloutP& p, int t, int do_c, int do_a, hipStream_t s);
-hipError_t configure_step8_kernel();
 #define TB_DECLARE_XDL(NS)                                                                                                       \
     namespace NS {                                                                                                                \
     void launch_step_x(const RolloutP& p, int t, int do_c, int do_a, hipStream_t s);                                              \
@@ -286,8 +284,6 @@ static void step_launch(const tb_ctx* ctx, const tb::RolloutP& rd, const tb::Rol
         tb::xb::launch_step_x(p, t, do_c, do_a, s);
     else if (ctx->step_kernel == 2)
         tb::xh::launch_step_x(p, t, do_c, do_a, s);
-    else if (ctx->step_kernel == 1)
-        tb::launch_step8(p, t, do_c, do_a, s);
     else
         tb::launch_step(p, t, do_c, do_a, s);
 }
@@ -323,12 +319,10 @@ int tb_create(const tb_config* cfg, tb_ctx** out) {
         const std::string k = w;
         if (k == "fp32")
             c->step_kernel = 0;
-        else if (k == "fp32w8")
-            c->step_kernel = 1;
         else if (k == "xdl")
             c->step_kernel = 2;
         else {
-            fprintf(stderr, "trafficbots_hip: TB_STEP_KERNEL must be fp32, fp32w8 or xdl\n");
+            fprintf(stderr, "trafficbots_hip: TB_STEP_KERNEL must be fp32 or xdl\n");
             delete c;
             return 1;
         }
@@ -363,7 +357,6 @@ int tb_finalize_weights(tb_ctx* ctx, tb_stream stream) {
     if (!ctx) return 1;
     TB_HIP(ctx, hipSetDevice(ctx->device));
     TB_HIP(ctx, tb::configure_rollout_kernels());
-    TB_HIP(ctx, tb::configure_step8_kernel());
     TB_HIP(ctx, tb::xh::configure_stepx_kernel());
     TB_HIP(ctx, tb::xb::configure_stepx_kernel());
     TB_HIP(ctx, tb::configure_rule_kernels());

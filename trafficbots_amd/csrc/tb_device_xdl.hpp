@@ -56,8 +56,24 @@ __device__ __forceinline__ f32x4 mfma_h(xh8 a, xh8 b, f32x4 c) { return __builti
 constexpr float SPLIT_SCALE = 2048.0f, SPLIT_INV = 1.0f / 2048.0f;
 constexpr int P1 = NPL - 1;  // index of the low plane (aliases plane 0 in the single-plane build, where it is never used)
 
+// Range guard of the fp16-pair mode: an operand with |x| >= 65504 becomes inf in its high plane and NaN in its low one, and a
+// NaN does not always survive to the outputs (ReLU and the softmax clamp squash it), so the overflow is FLAGGED where it
+// happens: one sticky word per translation unit, fetched and cleared by tb_check_status (two v_max3 + one compare per four values
+// on the GEMM-input stores; the softmax probabilities, in [0, 1], are split unchecked).  The bf16 build has fp32's range.
+#ifndef TB_XDL_BF16
+static __device__ unsigned int g_range_flag;
+#endif
+constexpr float XH_MAX = 65504.0f;
+
 // fp16 pair of four floats: v = h + 2^-11 l
+template <bool CHECK = true>
 __device__ __forceinline__ void split2(f32x4 v, xh4& h, xh4& l) {
+#ifndef TB_XDL_BF16
+    if (CHECK) {
+        const float m = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
+        if (m >= XH_MAX) g_range_flag = 1u;
+    }
+#endif
     h = xh4{(xhalf)v.x, (xhalf)v.y, (xhalf)v.z, (xhalf)v.w};
     if (NPL == 2) {
         const f32x4 r = (v - f32x4{(float)h.x, (float)h.y, (float)h.z, (float)h.w}) * splat(SPLIT_SCALE);
@@ -299,10 +315,11 @@ __device__ __forceinline__ void v_load_x(VFragX& f, const xhalf* __restrict__ vf
 }
 
 // eight floats of a lane -> fp16 pair (B operand)
+template <bool CHECK = true>
 __device__ __forceinline__ void split8(const f32x4& a, const f32x4& b, xh8& h, xh8& l) {
     xh4 h0, l0, h1, l1;
-    split2(a, h0, l0);
-    split2(b, h1, l1);
+    split2<CHECK>(a, h0, l0);
+    split2<CHECK>(b, h1, l1);
     h = xh8{h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
     l = xh8{l0.x, l0.y, l0.z, l0.w, l1.x, l1.y, l1.z, l1.w};
 }
@@ -415,7 +432,7 @@ __device__ __forceinline__ bool attention_head_x(const f32x4 (&q)[2], AttnPreX& 
         run_sum = run_sum * alpha + (((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7])));
         run_max = new_max;
         xh8 ph, pl;
-        split8(f32x4{p[0], p[1], p[2], p[3]}, f32x4{p[4], p[5], p[6], p[7]}, ph, pl);
+        split8<false>(f32x4{p[0], p[1], p[2], p[3]}, f32x4{p[4], p[5], p[6], p[7]}, ph, pl);  // (probabilities: in [0, 1])
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt) {
             oh[dt] *= splat(alpha);

@@ -69,6 +69,15 @@ struct RolloutP {
     const float* hist_acc;        // [B,NH,A]
     const float* hist_yaw_rate;   // [B,NH,A]
     const uint8_t* tf_mask;       // [B,NH,A]
+    // Per-call overrides of the stepwise API (tb_rollout_step_ex, the reference's forward(state_override=, mask_state_override=)
+    // followed by Dynamics.kill(gt_valid)): when ovr_mask != nullptr the teacher-forcing inputs of THIS launch's C half come
+    // from these per-INSTANCE arrays instead of step t of the per-scene history arrays above.
+    const uint8_t* ovr_mask;      // [N,A]
+    const float* ovr_state;       // [N,A,4]
+    const float* ovr_vel;         // [N,A,2]
+    const float* ovr_acc;         // [N,A]
+    const float* ovr_yaw_rate;    // [N,A]
+    const uint8_t* ovr_gt_valid;  // [N,A], or nullptr = no ground truth: every agent that leaves the map is killed
     const int32_t* agent_type;    // [B,A]
     const float* agent_size;      // [B,A,3]
     // rule checker geometry

@@ -1,4 +1,4 @@
-// Pieces shared by the 4-wave (k_step) and the 8-wave (k_step8) step kernels: LDS carve, per-row state,
+// Pieces shared by the step kernels (k_step_x and its fp32-MFMA twin k_step): LDS carve, per-row state,
 // the per-agent simulator epilogue and the agent input encoding at the head of the A half.
 #pragma once
 #include "tb_rollout.hpp"
@@ -278,13 +278,22 @@ __device__ __forceinline__ void step_epilogue16(const RolloutP& p, int t, int n,
     const int row = row0 + a;
     const int rowc = min(row, p.n_agent - 1);
     const size_t si = (size_t)n * p.a_pad + row;
-    const bool in_hist = t < p.n_hist;
-    const size_t hi = ((size_t)b * p.n_hist + min(t, p.n_hist - 1)) * p.n_agent + rowc;
+    // teacher-forcing source of this step: step t of the per-scene history arrays, or the caller's per-instance arrays of a
+    // tb_rollout_step_ex call (wave-uniform select of base pointers and index)
+    const bool per_call = p.ovr_mask != nullptr;
+    const bool in_hist = per_call || t < p.n_hist;
+    const size_t hi = per_call ? (size_t)n * p.n_agent + rowc : ((size_t)b * p.n_hist + min(t, p.n_hist - 1)) * p.n_agent + rowc;
+    const uint8_t* src_mask = per_call ? p.ovr_mask : p.tf_mask;
+    const uint8_t* src_gtv = per_call ? (p.ovr_gt_valid ? p.ovr_gt_valid : nullptr) : p.hist_valid;
+    const float* src_state = per_call ? p.ovr_state : p.hist_state;
+    const float* src_vel = per_call ? p.ovr_vel : p.hist_vel;
+    const float* src_acc = per_call ? p.ovr_acc : p.hist_acc;
+    const float* src_yr = per_call ? p.ovr_yaw_rate : p.hist_yaw_rate;
     // ---- loads
     const uint8_t killed0 = p.killed[si], outside0 = p.outside[si], dreached0 = p.dest_reached[si];
-    const uint8_t ovr0 = p.tf_mask[hi], gtv0 = p.hist_valid[hi];
-    const f32x4 hst = ldg4(p.hist_state + hi * 4);
-    const f32x4 hax = f32x4{p.hist_vel[hi * 2], p.hist_vel[hi * 2 + 1], p.hist_acc[hi], p.hist_yaw_rate[hi]};
+    const uint8_t ovr0 = src_mask[hi], gtv0 = src_gtv ? src_gtv[hi] : (uint8_t)0;
+    const f32x4 hst = ldg4(src_state + hi * 4);
+    const f32x4 hax = f32x4{src_vel[hi * 2], src_vel[hi * 2 + 1], src_acc[hi], src_yr[hi]};
     const f32x4 bd = ldg4(p.map_boundary + (size_t)b * 4);
     const int ty = rtype[a];
     const bool valid_old = rowvalid[a] != 0;
