@@ -45,6 +45,13 @@ typedef struct tb_config {
 int tb_create(const tb_config* cfg, tb_ctx** out);
 void tb_destroy(tb_ctx* ctx);
 const char* tb_last_error(tb_ctx* ctx);
+/* Range check of the fp32-accurate mode (the one call of this header that SYNCHRONISES `stream`).  The XDL kernels carry an fp32
+ * value as an fp16 pair, valid for |x| < 65504; a GEMM / attention operand beyond that raises a sticky device flag where it is
+ * produced (the overflow would otherwise turn into inf / NaN that ReLU and the softmax clamp can squash silently).  Returns 0 when
+ * no kernel queued on this device since the previous check raised it, non-zero otherwise (tb_last_error names the stage); the
+ * flag is cleared either way.  The reference has no counterpart (its fp32 ops overflow at 3.4e38); operand_precision = 1 (bf16)
+ * has fp32's range and never raises it. */
+int tb_check_status(tb_ctx* ctx, tb_stream stream);
 /* Version / build info string (static storage). */
 const char* tb_version(void);
 
@@ -138,6 +145,23 @@ int tb_rollout(tb_ctx* ctx, const tb_rollout_io* io, tb_stream stream);
  * tb_rollout(io) == tb_rollout_begin(io) + (step_end - sim_start + 1) x tb_rollout_step, fused into fewer launches. */
 int tb_rollout_begin(tb_ctx* ctx, const tb_rollout_io* io, tb_stream stream);
 int tb_rollout_step(tb_ctx* ctx, tb_stream stream);
+
+/* Per-call teacher forcing of ONE step, the reference's `forward(..., state_override=, mask_state_override=)` followed by
+ * `Dynamics.kill(violations, gt_valid)` (waymo_motion.py:112-119,177,269-314; dynamics.py:132-167): where mask[n,a] is set (and the
+ * agent was not killed before) the agent becomes valid and takes agent_state / vel / acc / yaw_rate -- this is also how agents are
+ * spawned -- and an agent that leaves the map is killed unless gt_valid[n,a] is set (gt_valid NULL: killed always).  All arrays are
+ * per INSTANCE (N = n_scene * k_futures), device pointers borrowed until the stream work completes.  The history arrays and the
+ * teacher-forcing mask given to tb_rollout_begin are NOT consulted for this step. */
+typedef struct tb_step_override {
+    const uint8_t* mask;         /* [N,A]   mask_state_override */
+    const float* agent_state;    /* [N,A,4] state_override["agent_state"]: x, y, yaw, spd */
+    const float* vel;            /* [N,A,2] state_override["vel"] */
+    const float* acc;            /* [N,A]   state_override["acc"] */
+    const float* yaw_rate;       /* [N,A]   state_override["yaw_rate"] */
+    const uint8_t* gt_valid;     /* [N,A] or NULL */
+} tb_step_override;
+/* tb_rollout_step_ex(ctx, NULL, s) == tb_rollout_step(ctx, s) */
+int tb_rollout_step_ex(tb_ctx* ctx, const tb_step_override* ov, tb_stream stream);
 int tb_rollout_state(tb_ctx* ctx, float* state /*[N,A,4]*/, uint8_t* valid /*[N,A]*/, float* hidden /*[3,N,A,128]*/, tb_stream stream);
 
 /* -- hot path: scene encoders ------------------------------------------------------------------------ */
@@ -169,6 +193,18 @@ typedef struct tb_encode_io {
     float* latent_mean;            /* [B,A,16]  prior mean (LatentEncoder.forward, latent_encoder.py:70-147) */
     uint8_t* latent_valid;         /* [B,A] */
     float* dest_logits;            /* [B,A,P] masked, un-normalised (DestPredictor.forward, goal_manager.py:202-333) */
+    /* Optional: the reference's OWN encoder inputs -- `TrafficBots.encode_input_features(agent_attr, agent_pe, map_attr, map_pe,
+     * tl_attr, tl_pe, ...)` as `SceneCentricInput` produced them (traffic_bots.py:109-151, sc_input.py:107-140): attribute vectors
+     * (agent 11 = vel2 spd yaw_rate acc size3 type3; map 31 = type11 node-one-hot20; tl 5 = state one-hot) and the 96-wide pose PE,
+     * fp32, taken AS GIVEN instead of being assembled / evaluated from the raw fields above.  Per token kind both or neither; when a
+     * pair is given, that kind's raw position / yaw / velocity ... fields above may be NULL (the class indices agent_type / map_type
+     * and all *_valid stay required: the destination predictor and the masks read them). */
+    const float* ext_agent_attr;   /* [B,NH,A,11] or NULL */
+    const float* ext_agent_pe;     /* [B,NH,A,96] */
+    const float* ext_map_attr;     /* [B,P,20,31] or NULL */
+    const float* ext_map_pe;       /* [B,P,20,96] */
+    const float* ext_tl_attr;      /* [B,NH,T,5] or NULL */
+    const float* ext_tl_pe;        /* [B,NH,T,96] */
 } tb_encode_io;
 
 /* Replaces: SceneCentricInput.forward (sc_input.py:50-140) + TrafficBots.encode_input_features

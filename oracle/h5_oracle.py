@@ -5,10 +5,13 @@ index passed in instead of drawn), `DatasetVal.__getitem__` (:38-55) and the def
 reference reads through h5py, which this image does not have; the restatement reads the same HDF5 objects through the HDF5 C
 library directly from Python (ctypes), one call chain per dataset, independent of `trafficbots_amd/csrc/tb_h5_loader.cpp`.
 
-PARITY UNPINNED for this row: without h5py the reference's dataset classes cannot be imported here, so no golden vector generated by
-the reference itself backs this file.  It is pinned only by construction (numpy semantics of `np.ascontiguousarray(hf[idx][k])`:
-h5py maps the 8-bit FALSE/TRUE enum to numpy bool, IEEE floats and integers to the same numpy dtype) and by round trips of files
-whose content is known.
+PINNED by the reference itself: tests/golden/gen_h5_reference.py imports the reference's `data_modules.data_h5_womd` in the build
+container with an h5py stand-in (`tools/ref_shim.install_h5py`: h5py's File / group / dataset / attrs object model over the `H5Reader`
+below, i.e. over the HDF5 C library) and runs ITS `DatasetVal` / `DatasetTrain.__getitem__` + torch's default collate on packed files
+written from seeds; dtype / shape / sha256 of every key of those batches are committed as tests/golden/h5_reference.json, and
+tests/test_h5_loader.py checks `getitem_*` + `collate` below (and the product reader) against them bit for bit.  What the stand-in
+cannot pin is h5py's own dtype mapping (8-bit FALSE/TRUE enum <-> numpy bool, variable-length UTF-8 string attribute <-> str), which
+`_numpy_dtype` / `attr` restate from h5py's documented behaviour; the on-disk conventions were checked with `h5dump`.
 
 Only tests/ may import this module.
 """

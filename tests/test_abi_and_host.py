@@ -192,3 +192,89 @@ def test_training_split_batch_has_no_history_keys():
     v[:, 12:, 0] = False
     t3 = dict(train, **{"agent/valid": v})
     assert gt_from_batch(t3, "cpu", 11)["warm_ok"] is True and gt_from_batch(t3, "cpu", 14)["warm_ok"] is False
+
+
+def _yaml_shaped_config():
+    """A dict with the keys and nesting of `configs/model/traffic_bots.yaml` as Hydra would hand it to `instantiate` (with the
+    relative interpolations still in place), built from this package's default tree -- the reference's file itself does not travel."""
+    import copy
+
+    from trafficbots_amd.config import DEFAULT_MODEL_CONFIG
+
+    cfg = copy.deepcopy(DEFAULT_MODEL_CONFIG)
+    cfg["_target_"] = "pl_modules.waymo_motion.WaymoMotion"
+    cfg["model"]["_target_"] = "models.traffic_bots.TrafficBots"
+    cfg["model"]["hidden_dim"] = "${..hidden_dim}"
+    cfg["model"]["tf_cfg"]["d_model"] = "${...hidden_dim}"
+    cfg["pre_processing"] = {
+        "scene_centric": {"_target_": "data_modules.scene_centric.SceneCentricPreProcessing"},
+        "input": dict(cfg["pre_processing"]["input"], _target_="data_modules.sc_input.SceneCentricInput",
+                      pose_pe={"map": "pe_xy_yaw", "tl": "${.map}", "agent": "${.map}"}),
+        "latent": {"_target_": "data_modules.sc_latent.SceneCentricLatent", "pe_dim": "${..input.pe_dim}", "pose_pe": "${..input.pose_pe}",
+                   "perturb_input_to_latent": False, "dropout_p_history": -1, "max_meter": 50.0, "max_rad": 3.14},
+    }
+    cfg.update(n_video_batch=3, interactive_challenge=False, step_detach_hidden=-1, p_drop_hidden=-1.0, lr_goal=1e-3,
+               optimizer={"_target_": "torch.optim.AdamW", "lr": 3e-4}, lr_scheduler=None,
+               sub_womd_reactive_replay={"activate": False}, sub_womd_joint_future_pred={"activate": False},
+               data_size={"agent/valid": [91, 64], "map/valid": [1024, 20]}, wb_artifact=None)
+    return cfg
+
+
+def test_hydra_style_instantiation_of_the_mirror():
+    """`trafficbots_amd.instantiate(cfg)` = `hydra.utils.instantiate(cfg.model)` of `src/run.py:34-36`: the `_target_` of the
+    reference's task module resolves to the mirror and the constructor takes the reference's keyword arguments
+    (`waymo_motion.py:28-62`).  Without a GPU the call must get as far as creating the engine (configuration accepted) and fail
+    THERE, loudly; unsupported ablation branches and foreign targets are rejected before that."""
+    import copy
+
+    import trafficbots_amd
+    from trafficbots_amd.config import config_from_hydra_kwargs
+
+    cfg = _yaml_shaped_config()
+    resolved = config_from_hydra_kwargs({k: v for k, v in copy.deepcopy(cfg).items() if k != "_target_"})
+    assert resolved["model"]["tf_cfg"]["d_model"] == 128 and resolved["pre_processing"]["input"]["pose_pe"]["agent"] == "pe_xy_yaw"
+    assert resolved["optimizer"]["lr"] == 3e-4 and resolved["data_size"]["agent/valid"] == [91, 64]  # carried along, unused
+    if not torch.cuda.is_available():
+        with pytest.raises(RuntimeError, match="no HIP device"):
+            trafficbots_amd.instantiate(copy.deepcopy(cfg))
+    bad = copy.deepcopy(cfg)
+    bad["model"]["interaction_first"] = False
+    with pytest.raises(NotImplementedError, match="interaction_first"):
+        trafficbots_amd.instantiate(bad)
+    with pytest.raises(NotImplementedError, match="_target_"):
+        trafficbots_amd.instantiate(dict(copy.deepcopy(cfg), _target_="pl_modules.something_else.Model"))
+    missing = copy.deepcopy(cfg)
+    del missing["dynamics"]
+    with pytest.raises(KeyError):
+        trafficbots_amd.instantiate(missing)
+    ref_yaml = "/root/reference/configs/model/traffic_bots.yaml"
+    if os.path.exists(ref_yaml):  # build container only: the reference's own file passes as it is
+        import yaml
+
+        y = yaml.safe_load(open(ref_yaml))
+        got = config_from_hydra_kwargs(dict(y, data_size={}))
+        assert got["teacher_forcing_reactive_replay"]["step_spawn_agent"] == 90 and got["n_joint_future"] == 6
+
+
+def test_pre_processed_scene_carries_the_reference_keys():
+    """the twelve "input/*" arguments of `encode_input_features` (+ the aliased "latent_prior/*", + "ref/*") are on the
+    pre-processed scene; attr / pe are zero-storage stand-ins that point back at the scene"""
+    from trafficbots_amd import synth
+    from trafficbots_amd.runtime import scene_from_batch
+    from trafficbots_amd.waymo_motion import _with_reference_keys
+
+    scene = _with_reference_keys(scene_from_batch(synth.make_batch(5, 2, n_agent=7, n_pl=9, n_tl=3), "cpu", 11))
+    names = ("agent_valid", "agent_attr", "agent_pe", "agent_pos", "map_valid", "map_attr", "map_pe", "map_pos", "tl_valid", "tl_attr",
+             "tl_pe", "tl_pos")
+    input_dict = {k.split("input/")[-1]: v for k, v in scene.items() if "input/" in k}  # the reference harness' idiom (:907)
+    assert set(input_dict) == set(names)
+    shapes = {"agent_attr": (2, 11, 7, 11), "agent_pe": (2, 11, 7, 96), "map_attr": (2, 9, 20, 31), "map_pe": (2, 9, 20, 96),
+              "tl_attr": (2, 11, 3, 5), "tl_pe": (2, 11, 3, 96), "map_pos": (2, 9, 2), "agent_valid": (2, 11, 7)}
+    for k, shp in shapes.items():
+        assert tuple(input_dict[k].shape) == shp, k
+    assert input_dict["agent_valid"].dtype == torch.bool and input_dict["agent_valid"].any(1).shape == (2, 7)
+    for k in ("agent_attr", "agent_pe", "map_attr", "map_pe", "tl_attr", "tl_pe"):
+        assert input_dict[k]._tb_scene is scene and input_dict[k].untyped_storage().nbytes() == 4
+        assert scene["latent_prior/" + k] is input_dict[k]
+    assert scene["ref/agent_type"].shape == (2, 7, 3) and scene["ref/agent_type"].sum(-1).max() == 1
+    assert scene["ref/map_type"].shape == (2, 9, 11) and scene["ref/agent_state"].shape == (2, 11, 7, 4)

@@ -1,5 +1,6 @@
 """SURVEY 8(f)-4, host side: the packed-h5 reader against the numpy restatement of the reference's datasets
-(`oracle/h5_oracle.py`, parity unpinned -- see its header) and against the content the files were written from."""
+(`oracle/h5_oracle.py`), against the content the files were written from, and -- the pin -- both of them against what the REFERENCE's
+own dataset classes returned for the same files (tests/golden/h5_reference.json, made by tests/golden/gen_h5_reference.py)."""
 import os
 
 import numpy as np
@@ -279,3 +280,53 @@ def test_errors_are_loud(packed, tmp_path):
         f.read_key([0], "map/pos", (13, 20, 2), data_h5.F32)  # only agent tensors may be replaced by dummies
     with pytest.raises(RuntimeError, match="no dataset"):
         f.read_key([7], "map/pos", (12, 20, 2), data_h5.F32)
+
+
+def _digest(v):
+    import hashlib
+
+    if isinstance(v, (list, tuple)) and v and isinstance(v[0], str):
+        return {"kind": "str", "values": list(v)}
+    a = np.ascontiguousarray(v.numpy() if torch.is_tensor(v) else np.asarray(v))
+    return {"kind": "array", "dtype": str(a.dtype), "shape": list(a.shape), "sha256": hashlib.sha256(a.tobytes()).hexdigest()}
+
+
+def test_reader_and_restatement_match_the_references_own_datasets(tmp_path):
+    """The pin of this row.  tests/golden/h5_reference.json holds, per split and key, dtype / shape / sha256 of the batches the
+    REFERENCE's `DatasetVal` / `DatasetTrain.__getitem__` + default collate produced (`data_h5_womd.py:9-55`, run in the build
+    container over an h5py stand-in on the HDF5 C library) for files written from seeds.  The same files are rebuilt here; the numpy
+    restatement (`oracle/h5_oracle.py`) and the product reader (`tb_h5_read_batch` via `read_reference_batch`) must reproduce every
+    entry bit for bit -- including the all-ones dummy tensors when n_agent differs from the file's (:50-53), the episode attributes
+    and their dtypes (variable-length string, float64 centre / yaw, bool with_map)."""
+    import importlib.util
+    import json
+
+    from conftest import GOLDEN_DIR
+
+    spec = importlib.util.spec_from_file_location("gen_h5_reference", os.path.join(GOLDEN_DIR, "gen_h5_reference.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    golden = json.load(open(os.path.join(GOLDEN_DIR, "h5_reference.json")))
+    assert golden["case"] == json.loads(json.dumps(gen.CASE)), "the generator's case changed: regenerate the golden"
+    case = golden["case"]
+    d = str(tmp_path)
+    gen.write_files(d, case)
+    idx = case["batch"]
+    n_checked = 0
+    for n_agent, tag in ((case["scene"]["n_agent"], "file_agents"), (case["n_agent_dummy"], "dummy_agents")):
+        dm = data_h5.DataH5womd(d, n_agent=n_agent, n_pl=case["scene"]["n_pl"], n_tl_stop=case["scene"]["n_tl"])
+        gen.patch_sizes(dm, case)
+        for split, path, table in (("val", dm.path_val_h5, dm.tensor_size_val), ("test", dm.path_test_h5, dm.tensor_size_test),
+                                   ("train", dm.path_train_h5, dm.tensor_size_train)):
+            want = golden["splits"].get(f"{split}/{tag}")
+            if want is None:
+                continue
+            get = h5_oracle.getitem_train if split == "train" else h5_oracle.getitem_val
+            restated = h5_oracle.collate([get(path, table, i) for i in idx])
+            product = data_h5.PackedH5File(path).read_reference_batch(idx, table, with_attrs=split != "train")
+            assert set(restated) == set(want) == set(product), (split, tag, set(want) ^ set(product))
+            for k, w in want.items():
+                assert _digest(restated[k]) == w, ("restatement", split, tag, k)
+                assert _digest(product[k]) == w, ("product reader", split, tag, k)
+                n_checked += 1
+    assert n_checked == 69 + 38 + 27 + 69 + 38

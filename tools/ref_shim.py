@@ -217,3 +217,71 @@ def build_reference(cfg: dict, n_agent: int, n_pl: int, n_tl: int = 40) -> nn.Mo
     model = WaymoMotion(**full)
     model.eval()
     return model
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# h5py stand-in (the image has the HDF5 C library but no h5py): just enough of h5py's object model for the reference's
+# dataset classes (`src/data_modules/data_h5_womd.py:9-55`) -- File as a context manager, `hf.attrs[...]`, `hf[key]` groups,
+# `group.attrs[...]`, `group[key]` datasets that `np.ascontiguousarray` can take.  Values come from a reader object handed in
+# by the caller (`reader_cls(filepath)` with `.dataset(path) -> ndarray`, `.attr(obj, name)`, `.close()`): tests/golden/
+# gen_h5_reference.py passes the ctypes -> libhdf5 reader, so that the reference's OWN `__getitem__` logic runs on real files.
+def install_h5py(reader_cls) -> None:
+    import numpy as np
+
+    class _Attrs:
+        def __init__(self, reader, obj):
+            self._r, self._obj = reader, obj
+
+        def __getitem__(self, name):
+            return self._r.attr(self._obj, name)
+
+    class _Dataset:
+        def __init__(self, reader, path):
+            self._r, self._path = reader, path
+
+        def __array__(self, dtype=None, copy=None):
+            a = self._r.dataset(self._path)
+            return a if dtype is None else a.astype(dtype)
+
+        @property
+        def shape(self):
+            return np.asarray(self).shape
+
+    class _Group:
+        def __init__(self, reader, path):
+            self._r, self._path = reader, path
+            self.attrs = _Attrs(reader, path or "/")
+
+        def __getitem__(self, key):
+            path = f"{self._path}/{key}" if self._path else str(key)
+            try:
+                self._r.dataset(path)  # a dataset if it can be opened as one, a group otherwise
+            except (KeyError, OSError, TypeError):
+                return _Group(self._r, path)
+            return _Dataset(self._r, path)
+
+    class File(_Group):
+        def __init__(self, filepath, mode="r", libver=None, swmr=False):
+            assert mode == "r"
+            super().__init__(reader_cls(filepath), "")
+
+        def __enter__(self):
+            return self
+
+        def __exit__(self, *exc):
+            self._r.close()
+            return False
+
+    m = types.ModuleType("h5py")
+    m.File = File
+    sys.modules["h5py"] = m
+
+
+def import_reference_datasets(reader_cls):
+    """`data_modules.data_h5_womd` of the reference with the h5py stand-in in place (build container only)."""
+    install()
+    install_h5py(reader_cls)
+    pl = sys.modules["pytorch_lightning"]
+    if not hasattr(pl, "LightningDataModule"):
+        pl.LightningDataModule = type("LightningDataModule", (), {"__init__": lambda self, *a, **k: None})
+    return importlib.import_module("data_modules.data_h5_womd")

@@ -239,6 +239,55 @@ def load_model_config(path: str | None = None, overrides: Dict[str, Any] | None 
     return cfg
 
 
+def _plain(node: Any) -> Any:
+    """dict-likes (OmegaConf DictConfig, attribute dicts) and list-likes -> plain dict / list, recursively"""
+    if hasattr(node, "items"):
+        return {str(k): _plain(v) for k, v in node.items()}
+    if isinstance(node, (list, tuple)) or (hasattr(node, "__iter__") and not isinstance(node, (str, bytes)) and hasattr(node, "__len__")
+                                              and not hasattr(node, "shape")):
+        return [_plain(v) for v in node]
+    return node
+
+
+def config_from_hydra_kwargs(kwargs: Dict[str, Any]) -> Dict[str, Any]:
+    """The keyword arguments `hydra.utils.instantiate` hands `WaymoMotion.__init__` for `configs/model/traffic_bots.yaml`
+    (`src/pl_modules/waymo_motion.py:28-62`, `src/run.py:34-36`) -> this package's config dict: same keys, `_target_` entries
+    kept where the supported-branch check reads them, interpolations resolved if the caller did not, groups the hot path does not
+    read (data_size, optimizer, lr_scheduler, sub_womd_*, n_video_batch, wb_artifact, step_detach_hidden, p_drop_hidden, lr_goal,
+    interactive_challenge) accepted and carried along untouched.  Missing OPTIONAL groups get this package's defaults; the
+    operand_precision extension key is honoured."""
+    cfg = _plain(kwargs)
+    cfg.pop("_target_", None)
+    cfg = resolve_interpolations(cfg)
+    for key, val in DEFAULT_MODEL_CONFIG.items():
+        if key not in cfg:
+            if key in ("model", "dynamics", "action_head", "pre_processing"):
+                raise KeyError(f"WaymoMotion(**kwargs): the reference's constructor argument '{key}' is missing")
+            cfg[key] = copy.deepcopy(val)
+    # (the reference's pre_processing group also lists scene_centric / latent stages, `traffic_bots.yaml:13-32`; only `input` is read)
+    cfg["pre_processing"].setdefault("input", copy.deepcopy(DEFAULT_MODEL_CONFIG["pre_processing"]["input"]))
+    check_supported(cfg)
+    return cfg
+
+
+REFERENCE_TARGETS = ("pl_modules.waymo_motion.WaymoMotion", "trafficbots_amd.waymo_motion.WaymoMotion", "trafficbots_amd.WaymoMotion")
+
+
+def instantiate(cfg: Dict[str, Any], **kwargs):
+    """`hydra.utils.instantiate(cfg.model, ...)` for this package (`src/run.py:34-36`): `cfg` is a dict shaped like
+    `configs/model/traffic_bots.yaml` -- `_target_: pl_modules.waymo_motion.WaymoMotion` (or this package's class path) plus the
+    constructor arguments; `kwargs` are added on top (e.g. data_size=..., device="cuda:1").  Nested `_target_`s (the model, the
+    pre-processing stages, the dynamics) are not instantiated one by one: `WaymoMotion` takes the groups as configuration."""
+    from .waymo_motion import WaymoMotion
+
+    cfg = _plain(cfg)
+    target = cfg.pop("_target_", REFERENCE_TARGETS[0])
+    if target not in REFERENCE_TARGETS:
+        raise NotImplementedError(f"trafficbots_amd.instantiate: _target_ '{target}' is not the hot path's task module")
+    cfg.update(kwargs)
+    return WaymoMotion(**cfg)
+
+
 def check_supported(cfg: Dict[str, Any]) -> None:
     """Raise NotImplementedError for config branches outside the built path."""
     m = cfg["model"]

@@ -31,6 +31,9 @@ hipError_t configure_rollout_kernels();
                            int n_tok, int n_pad, float* K, float* VT, float* kbias, int* nkey, hipStream_t s);                    \
     }
 TB_DECLARE_XDL(xh)  // fp16 pairs (tb_stepx_kernels.hip)
+namespace xh {
+void launch_range_flag_take_step(unsigned int* out, hipStream_t s);
+}
 TB_DECLARE_XDL(xb)  // bf16       (tb_stepx_bf16_kernels.hip)
 int run_encode(struct ::tb_ctx* ctx, const tb_encode_io* io, hipStream_t s);
 int run_rule_checks(const tb_rule_io* io, int n_hist, int step_start, uint8_t* raw_ws, hipStream_t s);
@@ -340,6 +343,7 @@ void tb_destroy(tb_ctx* ctx) {
     if (ctx->d_arena) (void)hipFree(ctx->d_arena);
     if (ctx->d_ws) (void)hipFree(ctx->d_ws);
     if (ctx->d_rule_ws) (void)hipFree(ctx->d_rule_ws);
+    if (ctx->d_status) (void)hipFree(ctx->d_status);
     for (auto e : ctx->ev) (void)hipEventDestroy(e);
     delete ctx;
 }
@@ -874,14 +878,48 @@ extern "C" int tb_rollout_begin(tb_ctx* ctx, const tb_rollout_io* io, tb_stream 
     return 0;
 }
 
-extern "C" int tb_rollout_step(tb_ctx* ctx, tb_stream stream_) {
+extern "C" int tb_rollout_step_ex(tb_ctx* ctx, const tb_step_override* ov, tb_stream stream_) {
     if (!ctx) return 1;
     if (!ctx->step_active) return tb_fail(ctx, "tb_rollout_step: no rollout in progress (call tb_rollout_begin)");
     if (ctx->step_next > ctx->step_end) return tb_fail(ctx, "tb_rollout_step: step %d is past step_end %d", ctx->step_next, ctx->step_end);
     const int t = ctx->step_next;
-    step_launch(ctx, ctx->step_p, ctx->step_p, t, /*do_c=*/1, /*do_a=*/t < ctx->step_end, (hipStream_t)stream_);
+    tb::RolloutP p = ctx->step_p;
+    if (ov) {
+        if (ctx->step_kernel < 2) return tb_fail(ctx, "tb_rollout_step_ex: per-call overrides need the XDL step kernel (TB_STEP_KERNEL=fp32 is the A/B twin only)");
+        if (!ov->mask) return tb_fail(ctx, "tb_rollout_step_ex: tb_step_override.mask is NULL");
+        if (!ov->agent_state || !ov->vel || !ov->acc || !ov->yaw_rate)
+            return tb_fail(ctx, "tb_rollout_step_ex: agent_state / vel / acc / yaw_rate must all be given (they are read only where mask is set)");
+        p.ovr_mask = ov->mask;
+        p.ovr_state = ov->agent_state;
+        p.ovr_vel = ov->vel;
+        p.ovr_acc = ov->acc;
+        p.ovr_yaw_rate = ov->yaw_rate;
+        p.ovr_gt_valid = ov->gt_valid;
+    }
+    step_launch(ctx, p, p, t, /*do_c=*/1, /*do_a=*/t < ctx->step_end, (hipStream_t)stream_);
     ctx->step_next = t + 1;
     TB_HIP(ctx, hipGetLastError());
+    return 0;
+}
+
+extern "C" int tb_rollout_step(tb_ctx* ctx, tb_stream stream_) { return tb_rollout_step_ex(ctx, nullptr, stream_); }
+
+// ---- sticky range flag of the fp16-pair kernels (tb_device_xdl.hpp) -----------------------------------------------
+extern "C" int tb_check_status(tb_ctx* ctx, tb_stream stream_) {
+    if (!ctx) return 1;
+    TB_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = (hipStream_t)stream_;
+    if (!ctx->d_status) TB_HIP(ctx, hipMalloc((void**)&ctx->d_status, sizeof(unsigned int)));
+    TB_HIP(ctx, hipMemsetAsync(ctx->d_status, 0, sizeof(unsigned int), s));
+    tb::xh::launch_range_flag_take_step(ctx->d_status, s);
+    tb::xh::launch_range_flag_take_encode(ctx->d_status, s);
+    unsigned int h = 0;
+    TB_HIP(ctx, hipMemcpyAsync(&h, ctx->d_status, sizeof(unsigned int), hipMemcpyDeviceToHost, s));
+    TB_HIP(ctx, hipStreamSynchronize(s));
+    if (h)
+        return tb_fail(ctx, "fp16-pair operand range exceeded: a GEMM / attention input of the %s%s%s reached |x| >= 65504 since the last "
+                            "check (results of those calls are invalid; activations of this magnitude need operand_precision = bf16 or rescaled weights)",
+                       (h & 1u) ? "step kernels" : "", (h == 3u) ? " and the " : "", (h & 2u) ? "scene encoders" : "");
     return 0;
 }
 

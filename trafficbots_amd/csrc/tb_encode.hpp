@@ -76,6 +76,7 @@ namespace xh {
 void launch_dest_pairs_x(const DestP& p, hipStream_t s);
 void launch_gru_scan_x(const ScanP& p, int a_pad, hipStream_t s);
 hipError_t configure_encodex_kernels();
+void launch_range_flag_take_encode(unsigned int* out, hipStream_t s);
 void launch_kv_hoist_nx(const float* W, const XLayerW* L, const XLayerX* X, int n_layer, const float* feat, const uint8_t* fvalid, int G,
                         int n_tok, int n_pad, float* K, float* VT, float* kbias, hipStream_t s);
 void launch_xblock_x(const XBlockPX& p, int G, hipStream_t s);

@@ -34,6 +34,10 @@ struct TokP {
     const int32_t* cls;   // agent: type [B][A]; tl: state [n_tok]; map: type [B][P]
     const float* size;    // [B][A][3]
     float* out;           // [n_tok][128]
+    // the reference's own inputs (tb_encode_io.ext_*): attributes [n_tok][attr_dim] and pose PE [n_tok][96] taken as given instead of
+    // being assembled / evaluated here (both or neither)
+    const float* ext_attr;
+    const float* ext_pe;
 };
 
 // One workgroup encodes TOK_GROUPS consecutive groups of 16 tokens with the MLP weights (transposed) and the PE frequencies staged
@@ -68,7 +72,10 @@ __global__ __launch_bounds__(NTHREADS) void k_encode_tokens(TokP p) {
             for (int k = 0; k < 32; ++k) a[k] = 0.f;
             float x = 0.f, y = 0.f, yw = 0.f;
             uint8_t v = 0;
-            if (tk < p.n_tok) {
+            if (tk < p.n_tok && p.ext_attr) {
+                v = p.valid[tk];
+                for (int k = 0; k < attr_dim; ++k) a[k] = p.ext_attr[(size_t)tk * attr_dim + k];
+            } else if (tk < p.n_tok) {
                 v = p.valid[tk];
                 x = p.pos[(size_t)tk * 2];
                 y = p.pos[(size_t)tk * 2 + 1];
@@ -103,6 +110,11 @@ __global__ __launch_bounds__(NTHREADS) void k_encode_tokens(TokP p) {
             const int row = tid >> 4, i = tid & 15;
             const float px = pose[row][0], py = pose[row][1], pyaw = pose[row][2];
             float* xr = outt[row] + 32;
+            if (p.ext_pe) {  // (wave-uniform) the caller's PE: 96 floats per token, 6 per thread
+                const int tk = tok0 + row;
+#pragma unroll
+                for (int u = 0; u < 6; ++u) xr[i * 6 + u] = tk < p.n_tok ? p.ext_pe[(size_t)tk * 96 + i * 6 + u] : 0.f;
+            } else
 #pragma unroll
             for (int u = 0; u < 3; ++u) {
                 const int j = i * 3 + u;
@@ -553,13 +565,22 @@ int run_encode(struct ::tb_ctx* ctx, const tb_encode_io* io, hipStream_t s) {
     if (A > 256) return tb_fail(ctx, "tb_encode_scene: n_agent %d > 256 not supported", A);
     if (NH != ctx->cfg.time_step_current + 1 || (NH - 1) % 5 != 0)
         return tb_fail(ctx, "tb_encode_scene: n_hist %d does not match the config", NH);
-    const void* req[] = {io->agent_valid, io->agent_pos, io->agent_yaw, io->agent_vel, io->agent_spd, io->agent_acc,
-                         io->agent_yaw_rate, io->agent_type, io->agent_size, io->map_valid, io->map_type, io->map_pos,
-                         io->map_dir, io->tl_valid, io->tl_state, io->tl_pos, io->tl_dir, io->map_feature,
+    const void* req[] = {io->agent_valid, io->agent_type, io->map_valid, io->map_type, io->tl_valid, io->map_feature,
                          io->map_feature_valid, io->agent_feature, io->tl_feature, io->latent_mean, io->latent_valid,
                          io->dest_logits};
     for (const void* q : req)
         if (!q) return tb_fail(ctx, "tb_encode_scene: a required buffer pointer is NULL");
+    // raw scene fields of a token kind are needed unless the caller hands over its attributes and pose PE (ext_*)
+    if ((io->ext_agent_attr == nullptr) != (io->ext_agent_pe == nullptr) || (io->ext_map_attr == nullptr) != (io->ext_map_pe == nullptr) ||
+        (io->ext_tl_attr == nullptr) != (io->ext_tl_pe == nullptr))
+        return tb_fail(ctx, "tb_encode_scene: ext_*_attr and ext_*_pe come in pairs");
+    if (!io->ext_agent_attr) {
+        const void* raw[] = {io->agent_pos, io->agent_yaw, io->agent_vel, io->agent_spd, io->agent_acc, io->agent_yaw_rate, io->agent_size};
+        for (const void* q : raw)
+            if (!q) return tb_fail(ctx, "tb_encode_scene: a raw agent field is NULL (and no ext_agent_attr / ext_agent_pe given)");
+    }
+    if (!io->ext_map_attr && (!io->map_pos || !io->map_dir)) return tb_fail(ctx, "tb_encode_scene: map_pos / map_dir NULL (and no ext_map_*)");
+    if (!io->ext_tl_attr && (!io->tl_state || !io->tl_pos || !io->tl_dir)) return tb_fail(ctx, "tb_encode_scene: tl_state / tl_pos / tl_dir NULL (and no ext_tl_*)");
     const float* W = ctx->d_arena;
     const EncoderW& ew = ctx->ew;
     const int a_pad = padk(A), p_pad = padk(P), t_pad = padk(T);
@@ -600,16 +621,19 @@ int run_encode(struct ::tb_ctx* ctx, const tb_encode_io* io, hipStream_t s) {
         t.valid = io->agent_valid; t.pos = io->agent_pos; t.yaw = io->agent_yaw; t.vel = io->agent_vel; t.spd = io->agent_spd;
         t.acc = io->agent_acc; t.yaw_rate = io->agent_yaw_rate; t.cls = io->agent_type; t.size = io->agent_size;
         t.out = io->agent_feature;
+        t.ext_attr = io->ext_agent_attr; t.ext_pe = io->ext_agent_pe;
         hipLaunchKernelGGL(k_encode_tokens, dim3((t.n_tok + TM * TOK_GROUPS - 1) / (TM * TOK_GROUPS)), dim3(NTHREADS), 0, s, t);
         TokP l{};
         l.W = W; l.pe_fxy = ew.pe_fxy; l.pe_fyaw = ew.pe_fyaw;
         l.kind = 1; l.mlp = ew.tl_enc; l.n_tok = B * NH * T; l.per_scene = NH * T; l.inner = T;
         l.valid = io->tl_valid; l.pos = io->tl_pos; l.dir = io->tl_dir; l.cls = io->tl_state; l.out = io->tl_feature;
+        l.ext_attr = io->ext_tl_attr; l.ext_pe = io->ext_tl_pe;
         hipLaunchKernelGGL(k_encode_tokens, dim3((l.n_tok + TM * TOK_GROUPS - 1) / (TM * TOK_GROUPS)), dim3(NTHREADS), 0, s, l);
         TokP m{};
         m.W = W; m.pe_fxy = ew.pe_fxy; m.pe_fyaw = ew.pe_fyaw;
         m.kind = 2; m.mlp = ew.map_enc; m.n_tok = B * P * 20; m.per_scene = P * 20; m.inner = 20;
         m.valid = io->map_valid; m.pos = io->map_pos; m.dir = io->map_dir; m.cls = io->map_type; m.out = nodef;
+        m.ext_attr = io->ext_map_attr; m.ext_pe = io->ext_map_pe;
         hipLaunchKernelGGL(k_encode_tokens, dim3((m.n_tok + TM * TOK_GROUPS - 1) / (TM * TOK_GROUPS)), dim3(NTHREADS), 0, s, m);
     }
     // ---- map encoder

@@ -366,6 +366,14 @@ void launch_gru_scan_x(const ScanP& p, int a_pad, hipStream_t s) {
     hipLaunchKernelGGL(k_gru_scan_x, dim3(a_pad / TM, p.B), dim3(NTHREADS), SCANX_LDS_BYTES, s, p);
 }
 
+
+// fp16-pair range flag of THIS translation unit (the scene encoders): OR it into *out (bit 1) and clear it (tb_check_status)
+__global__ void k_range_flag_take_encode(unsigned int* out) {
+    const unsigned int f = atomicExch(&g_range_flag, 0u);
+    if (f) atomicOr(out, 2u);
+}
+void launch_range_flag_take_encode(unsigned int* out, hipStream_t s) { hipLaunchKernelGGL(k_range_flag_take_encode, dim3(1), dim3(1), 0, s, out); }
+
 hipError_t configure_encodex_kernels() {
     return hipFuncSetAttribute(reinterpret_cast<const void*>(k_gru_scan_x), hipFuncAttributeMaxDynamicSharedMemorySize, SCANX_LDS_BYTES);
 }

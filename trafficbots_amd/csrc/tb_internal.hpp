@@ -33,6 +33,7 @@ struct tb_ctx {
     uint8_t* d_rule_ws = nullptr;  // per-step flags of tb_rule_checks
     size_t rule_ws_bytes = 0;
     long long* last_prof = nullptr;
+    unsigned int* d_status = nullptr;  // device word of tb_check_status
     // stepwise rollout (tb_rollout_begin / _step / _state)
     tb::RolloutP step_p;
     int step_next = 0, step_end = -1;

@@ -463,6 +463,16 @@ void launch_kv_hoist_x(const float* W, const XLayerW* L3, const XLayerX* X3, con
                        X3[1], X3[2], feat, fvalid, n_tok, n_pad, K, VT, kbias, nkey);
 }
 
+
+// fp16-pair range flag of THIS translation unit (tb_device_xdl.hpp): OR it into *out and clear it (tb_check_status)
+#ifndef TB_XDL_BF16
+__global__ void k_range_flag_take_step(unsigned int* out) {
+    const unsigned int f = atomicExch(&g_range_flag, 0u);
+    if (f) atomicOr(out, 1u);
+}
+void launch_range_flag_take_step(unsigned int* out, hipStream_t s) { hipLaunchKernelGGL(k_range_flag_take_step, dim3(1), dim3(1), 0, s, out); }
+#endif
+
 hipError_t configure_stepx_kernel() {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_step_x<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)(STEPX_LDS_FLOATS * sizeof(float)));

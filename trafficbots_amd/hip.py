@@ -49,6 +49,10 @@ class TbRolloutIO(C.Structure):
     ]
 
 
+class TbStepOverride(C.Structure):
+    _fields_ = [("mask", c_u8p), ("agent_state", c_f32p), ("vel", c_f32p), ("acc", c_f32p), ("yaw_rate", c_f32p), ("gt_valid", c_u8p)]
+
+
 class TbRuleIO(C.Structure):
     _fields_ = [
         ("n_scene", C.c_int32), ("k_futures", C.c_int32), ("n_agent", C.c_int32), ("n_pl", C.c_int32), ("n_tl", C.c_int32),
@@ -73,6 +77,8 @@ class TbEncodeIO(C.Structure):
         ("tl_valid", c_u8p), ("tl_state", c_i32p), ("tl_pos", c_f32p), ("tl_dir", c_f32p),
         ("map_feature", c_f32p), ("map_feature_valid", c_u8p), ("agent_feature", c_f32p), ("tl_feature", c_f32p),
         ("latent_mean", c_f32p), ("latent_valid", c_u8p), ("dest_logits", c_f32p),
+        ("ext_agent_attr", c_f32p), ("ext_agent_pe", c_f32p), ("ext_map_attr", c_f32p), ("ext_map_pe", c_f32p),
+        ("ext_tl_attr", c_f32p), ("ext_tl_pe", c_f32p),
     ]
 
 
@@ -126,7 +132,7 @@ class TbTrainIO(C.Structure):
 
 EXPORTS = (
     "tb_create", "tb_destroy", "tb_last_error", "tb_version", "tb_load_weight", "tb_finalize_weights",
-    "tb_rollout", "tb_rollout_begin", "tb_rollout_step", "tb_rollout_state", "tb_encode_scene", "tb_set_timing", "tb_get_timing",
+    "tb_rollout", "tb_rollout_begin", "tb_rollout_step", "tb_rollout_step_ex", "tb_check_status", "tb_rollout_state", "tb_encode_scene", "tb_set_timing", "tb_get_timing",
     "tb_rule_checks", "tb_post_process", "tb_metric_partials", "tb_struct_sizes", "tb_encode_posterior", "tb_train_partials",
 )
 
@@ -167,6 +173,10 @@ def load() -> C.CDLL:
     lib.tb_rollout_begin.restype = C.c_int
     lib.tb_rollout_step.argtypes = [C.c_void_p, C.c_void_p]
     lib.tb_rollout_step.restype = C.c_int
+    lib.tb_rollout_step_ex.argtypes = [C.c_void_p, C.POINTER(TbStepOverride), C.c_void_p]
+    lib.tb_rollout_step_ex.restype = C.c_int
+    lib.tb_check_status.argtypes = [C.c_void_p, C.c_void_p]
+    lib.tb_check_status.restype = C.c_int
     lib.tb_rollout_state.argtypes = [C.c_void_p, c_f32p, c_u8p, c_f32p, C.c_void_p]
     lib.tb_rollout_state.restype = C.c_int
     lib.tb_encode_scene.argtypes = [C.c_void_p, C.POINTER(TbEncodeIO), C.c_void_p]

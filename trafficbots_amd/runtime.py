@@ -220,11 +220,15 @@ class HipEngine:
         io.n_scene, io.n_agent, io.n_pl, io.n_tl, io.n_hist = b, a, p, t, nh
         for name in ("agent_valid", "map_valid", "tl_valid"):
             setattr(io, name, hip.ptr(s[name], hip.c_u8p))
+        # (a scene made from the reference's own attr / pe tensors carries "ext_*" entries and no raw fields for that token kind)
         for name in ("agent_pos", "agent_yaw", "agent_vel", "agent_spd", "agent_acc", "agent_yaw_rate", "agent_size",
                      "map_pos", "map_dir", "tl_pos", "tl_dir"):
-            setattr(io, name, hip.ptr(s[name], hip.c_f32p))
+            setattr(io, name, hip.ptr(s.get(name), hip.c_f32p))
         for name in ("agent_type", "map_type", "tl_state"):
-            setattr(io, name, hip.ptr(s[name], hip.c_i32p))
+            setattr(io, name, hip.ptr(s.get(name), hip.c_i32p))
+        for name in ("ext_agent_attr", "ext_agent_pe", "ext_map_attr", "ext_map_pe", "ext_tl_attr", "ext_tl_pe"):
+            setattr(io, name, hip.ptr(s.get(name), hip.c_f32p))
+        out["_keepalive"] = s
         for name in ("map_feature", "agent_feature", "tl_feature", "latent_mean", "dest_logits"):
             setattr(io, name, hip.ptr(out[name], hip.c_f32p))
         io.map_feature_valid = hip.ptr(out["map_feature_valid"], hip.c_u8p)
@@ -520,9 +524,37 @@ class HipEngine:
         self._metric_keepalive = keep
         return out
 
-    def rollout_step(self) -> None:
-        """One simulation step of the rollout opened with `rollout(..., stepwise=True)` (`tb_rollout_step`)."""
-        self._check(self.lib.tb_rollout_step(self._ctx, self._stream()), "tb_rollout_step")
+    def rollout_step(self, override: Optional[Dict[str, Tensor]] = None) -> None:
+        """One simulation step of the rollout opened with `rollout(..., stepwise=True)` (`tb_rollout_step`).  `override`
+        (`tb_rollout_step_ex`, per instance: "mask" [N,A], "agent_state" [N,A,4], "vel" [N,A,2], "acc" / "yaw_rate" [N,A(,1)],
+        optional "gt_valid" [N,A]) replaces the history arrays as the teacher-forcing source of THIS step, the way the
+        reference's `forward(state_override=, mask_state_override=)` + `Dynamics.kill(gt_valid)` do."""
+        if override is None:
+            self._check(self.lib.tb_rollout_step(self._ctx, self._stream()), "tb_rollout_step")
+            return
+        n, a = self._step_out["preds"].shape[:2]
+        dev, f32, u8 = self.device, torch.float32, torch.uint8
+        keep = {}
+
+        def prep(key, dtype, shape):
+            t = override[key].to(dev).to(dtype).reshape(shape).contiguous()
+            keep[key] = t
+            return t
+
+        ov = hip.TbStepOverride()
+        ov.mask = hip.ptr(prep("mask", u8, (n, a)), hip.c_u8p)
+        ov.agent_state = hip.ptr(prep("agent_state", f32, (n, a, 4)), hip.c_f32p)
+        ov.vel = hip.ptr(prep("vel", f32, (n, a, 2)), hip.c_f32p)
+        ov.acc = hip.ptr(prep("acc", f32, (n, a)), hip.c_f32p)
+        ov.yaw_rate = hip.ptr(prep("yaw_rate", f32, (n, a)), hip.c_f32p)
+        ov.gt_valid = hip.ptr(prep("gt_valid", u8, (n, a)) if override.get("gt_valid") is not None else None, hip.c_u8p)
+        self._step_keepalive = keep  # borrowed until the stream work is done (replaced by the next step's)
+        self._check(self.lib.tb_rollout_step_ex(self._ctx, C.byref(ov), self._stream()), "tb_rollout_step_ex")
+
+    def check_status(self) -> None:
+        """`tb_check_status`: synchronises the current stream and raises if an fp16-pair operand left the fp16 range since the
+        last check (fp32-accurate mode only; see include/trafficbots_hip.h)."""
+        self._check(self.lib.tb_check_status(self._ctx, self._stream()), "tb_check_status")
 
     def rollout_state(self) -> Dict[str, Tensor]:
         """Current simulator state of the stepwise rollout: `Dynamics.agent_state / agent_valid`, `TrafficBots.hidden`."""

@@ -16,7 +16,7 @@ from typing import Dict, Optional, Tuple, Union
 import torch
 from torch import Tensor
 
-from .config import load_model_config
+from .config import config_from_hydra_kwargs, load_model_config
 from .distributions import DestCategorical, DiagGaussian
 from .metrics import ErrorMetrics, TrafficRuleMetrics, TrainingMetrics
 from .runtime import HipEngine, gt_from_batch, scene_from_batch, teacher_forcing_mask, warm_start_promise_holds
@@ -26,6 +26,71 @@ _VIOLATION_KEYS = (
     "run_road_edge_this_step", "run_red_light", "run_red_light_this_step", "passive", "passive_this_step",
     "goal_reached", "goal_reached_this_step", "dest_reached", "dest_reached_this_step",
 )
+
+
+def _with_reference_keys(scene: Dict[str, Tensor]) -> Dict[str, Tensor]:
+    """Adds the entries the reference's harness reads off the pre-processed batch (`waymo_motion.py:902-921`): "input/*" and
+    "latent_prior/*" (the twelve arguments of `encode_input_features`; in eval mode the second set aliases the first,
+    `sc_latent.py:142-144,165-167,210-212`) and "ref/*" (`scene_centric.py:127-133`).  valid / pos entries are real tensors; the
+    attr / pe entries are shape-only stand-ins (a one-element tensor expanded with stride 0: no memory, no arithmetic) that carry
+    a reference to the scene, because the HIP encoders assemble the attributes and evaluate the pose PE from the raw scene inside
+    `tb_encode_scene` (`sc_input.py:107-140`) -- `TrafficBots.encode_input_features` recognises them."""
+    b, nh, a = scene["agent_valid"].shape
+    p, t = scene["map_valid"].shape[1], scene["tl_valid"].shape[2]
+    dev = scene["agent_valid"].device
+    z = torch.zeros(1, device=dev, dtype=torch.float32)
+
+    def stand_in(*shape):
+        x = z.expand(*shape)
+        x._tb_scene = scene
+        return x
+
+    ref = {
+        "agent_valid": scene["agent_valid"].bool(), "agent_attr": stand_in(b, nh, a, 11), "agent_pe": stand_in(b, nh, a, 96),
+        "agent_pos": scene["agent_pos"],
+        "map_valid": scene["map_valid"].bool(), "map_attr": stand_in(b, p, 20, 31), "map_pe": stand_in(b, p, 20, 96),
+        "map_pos": scene["map_pos"][:, :, 0],
+        "tl_valid": scene["tl_valid"].bool(), "tl_attr": stand_in(b, nh, t, 5), "tl_pe": stand_in(b, nh, t, 96), "tl_pos": scene["tl_pos"],
+    }
+    for k, v in ref.items():
+        scene["input/" + k] = v
+        scene["latent_prior/" + k] = v
+    idx = torch.arange(11, device=dev)
+    scene["ref/agent_type"] = scene["agent_type"].unsqueeze(-1) == idx[:3]
+    scene["ref/map_type"] = scene["map_type"].unsqueeze(-1) == idx
+    scene["ref/agent_state"] = scene["agent_state"]
+    return scene
+
+
+def _scene_from_reference_inputs(agent_valid, agent_attr, agent_pe, agent_pos, map_valid, map_attr, map_pe, map_pos, tl_valid, tl_attr,
+                                 tl_pe, tl_pos, device) -> Dict[str, Tensor]:
+    """Scene for `tb_encode_scene` from tensors the CALLER produced with the reference's layout (`traffic_bots.py:125-137`,
+    `sc_input.py:107-140`): attributes and pose PE go to the encoders as given (`tb_encode_io.ext_*`); the class indices the
+    destination predictor masks with are the one-hot parts of the attributes (agent type: attr[..., 8:11] of history step 0, the
+    attribute is the same at every step; polyline type: attr[..., :11] of node 0)."""
+    f32, u8 = torch.float32, torch.uint8
+
+    def f(x):
+        return x.to(device).to(f32).contiguous()
+
+    def onehot_idx(x):
+        x = x.to(device)
+        idx = x.argmax(-1).to(torch.int32)
+        return torch.where(x.sum(-1) > 0.5, idx, torch.full_like(idx, -1)).contiguous()
+
+    if agent_attr.shape[-1] != 11 or map_attr.shape[-1] != 31 or tl_attr.shape[-1] != 5:
+        raise ValueError("attribute widths must be agent 11 / map 31 / tl 5 (sc_input.py:110-138)")
+    if agent_pe.shape[-1] != 96 or map_pe.shape[-1] != 96 or tl_pe.shape[-1] != 96:
+        raise ValueError("pose PE must be 96 wide (pe_xy_yaw with pe_dim 96)")
+    s: Dict[str, Tensor] = {
+        "agent_valid": agent_valid.to(device).to(u8).contiguous(), "map_valid": map_valid.to(device).to(u8).contiguous(),
+        "tl_valid": tl_valid.to(device).to(u8).contiguous(),
+        "agent_type": onehot_idx(agent_attr[:, 0, :, 8:11]), "map_type": onehot_idx(map_attr[:, :, 0, :11]),
+        "ext_agent_attr": f(agent_attr), "ext_agent_pe": f(agent_pe), "ext_map_attr": f(map_attr), "ext_map_pe": f(map_pe),
+        "ext_tl_attr": f(tl_attr), "ext_tl_pe": f(tl_pe),
+        "agent_pos": f(agent_pos), "tl_pos": f(tl_pos), "warm_ok": False,
+    }
+    return s
 
 
 class RolloutBuffer:
@@ -91,18 +156,60 @@ class TrafficBots:
         self._log_std: Optional[Tensor] = None
         self._log_std_post: Optional[Tensor] = None
 
-    def encode_input_features(self, scene: Dict[str, Tensor]) -> Dict[str, Tensor]:
-        """`TrafficBots.encode_input_features` (`traffic_bots.py:109-151`) on a pre-processed scene
-        (:meth:`WaymoMotion.pre_processing`).  One HIP call also yields the prior mean and the destination
-        logits, which `latent_encoder` / `goal_manager.pred_goal` then hand out."""
-        self._enc = self.engine.encode_scene(scene)
-        self._scene = scene
+    def encode_input_features(self, agent_valid=None, agent_attr: Optional[Tensor] = None, agent_pe: Optional[Tensor] = None,
+                              agent_pos: Optional[Tensor] = None, map_valid: Optional[Tensor] = None, map_attr: Optional[Tensor] = None,
+                              map_pe: Optional[Tensor] = None, map_pos: Optional[Tensor] = None, tl_valid: Optional[Tensor] = None,
+                              tl_attr: Optional[Tensor] = None, tl_pe: Optional[Tensor] = None, tl_pos: Optional[Tensor] = None
+                              ) -> Dict[str, Tensor]:
+        """`TrafficBots.encode_input_features` with the reference's argument list (`traffic_bots.py:109-151`):
+        `model.encode_input_features(**input_dict)`, `input_dict` = the "input/*" (or "latent_prior/*") entries of the
+        pre-processed batch.  One HIP call also yields the prior mean and the destination logits, which `latent_encoder` /
+        `goal_manager.pred_goal` then hand out.  Three ways in:
+
+        * the pre-processed scene of :meth:`WaymoMotion.pre_processing` as the only argument (the mirror's own short form);
+        * the "input/*" entries of that scene: its attr / pe entries are shape-only stand-ins that point back at the scene (the
+          kernels assemble the attributes and evaluate the pose PE themselves, `sc_input.py:107-140`), so this is the same call;
+        * tensors the CALLER made (e.g. the reference's own `SceneCentricInput` outputs): attributes and PE are taken as given
+          (`tb_encode_io.ext_*`), class indices for the destination predictor are read off the one-hot parts of the attributes.
+        A second call on the same scene (the reference encodes "latent_prior/*" too, which aliases "input/*" in eval mode,
+        `sc_latent.py:142-144`) returns the first call's result."""
+        if isinstance(agent_valid, dict):
+            scene = agent_valid
+        else:
+            given = (agent_valid, agent_attr, agent_pe, agent_pos, map_valid, map_attr, map_pe, map_pos, tl_valid, tl_attr, tl_pe, tl_pos)
+            if any(t is None for t in given):
+                raise TypeError("encode_input_features needs the pre-processed scene or all twelve tensors of the reference's signature")
+            scene = next((getattr(t, "_tb_scene", None) for t in (agent_attr, agent_pe, map_attr, map_pe, tl_attr, tl_pe)
+                          if getattr(t, "_tb_scene", None) is not None), None)
+            if scene is None:
+                scene = _scene_from_reference_inputs(agent_valid, agent_attr, agent_pe, agent_pos, map_valid, map_attr, map_pe, map_pos,
+                                                     tl_valid, tl_attr, tl_pe, tl_pos, self.engine.device)
+        if scene is not self._scene or not self._enc:
+            self._enc = self.engine.encode_scene(scene)
+            self._scene = scene
         e = self._enc
         return {
             "agent_feature": e["agent_feature"], "agent_feature_valid": scene["agent_valid"].bool(),
             "map_feature": e["map_feature"], "map_feature_valid": e["map_feature_valid"].bool(),
             "tl_feature": e["tl_feature"], "tl_feature_valid": scene["tl_valid"].bool(),
         }
+
+    def init(self, latent: DiagGaussian, deterministic: Union[bool, Tensor], eps: Optional[Tensor] = None) -> None:
+        """`TrafficBots.init` (`traffic_bots.py:153-161`): binds the personality distribution for the next rollout and clears the
+        recurrent state.  The sample itself is drawn when the simulator is opened (`WaymoMotion.rollout(..., latent=None)` picks it
+        up); `eps` are the explicit standard-normal draws (the reference takes them from torch's global RNG)."""
+        self.latent, self.deterministic, self._latent_eps = latent, deterministic, eps
+        self.hidden = None
+        self.latent_sample = None
+        self.latent_logp = None
+
+    def forward(self, *args, **kwargs):
+        """`TrafficBots.forward` (`traffic_bots.py:163-247`) is not a separate entry point here: the policy trunk is fused with the
+        action head, the dynamics and the rule checks inside the step kernel and runs through `WaymoMotion.forward` / `rollout`."""
+        raise NotImplementedError("TrafficBots.forward is fused into the step kernel: drive WaymoMotion.forward / rollout "
+                                  "(tap_step exposes the policy feature of one step; attention weights are not produced)")
+
+    __call__ = forward
 
     def latent_encoder(self, posterior: bool = False, gt: Optional[Dict[str, Tensor]] = None, **kwargs) -> DiagGaussian:
         """`LatentEncoder.forward` (`latent_encoder.py:70-147`).  The prior was produced by `encode_input_features`; the
@@ -118,7 +225,16 @@ class TrafficBots:
 
 class WaymoMotion:
     def __init__(self, config_path: Optional[str] = None, device: str = "cuda:0", **overrides) -> None:
-        self.hparams = load_model_config(config_path, overrides or None)
+        """Two call forms.  The mirror's own: `WaymoMotion(config_path=None, device=..., **dotted_overrides)`.  The reference's:
+        `WaymoMotion(time_step_current=..., time_step_gt=..., ..., model={...}, dynamics={...}, ...)` -- the keyword arguments
+        `hydra.utils.instantiate` passes for `configs/model/traffic_bots.yaml` (`waymo_motion.py:28-62`); nested groups as plain
+        dicts (or anything dict-like), `_target_` keys and the training-only groups (optimizer, lr_scheduler, sub_womd_*, data_size,
+        wb_artifact ...) accepted and not used.  See also :func:`trafficbots_amd.instantiate`."""
+        if isinstance(overrides.get("model"), dict) or hasattr(overrides.get("model"), "items"):
+            self.hparams = config_from_hydra_kwargs(overrides)
+        else:
+            self.hparams = load_model_config(config_path, overrides or None)
+        self.check_range = True  # tb_check_status at the end of test_step / validation_step / training_step (one stream sync each)
         self.device = torch.device(device)
         self.engine = HipEngine(self.hparams, device)
         self.model = TrafficBots(self.engine)
@@ -151,17 +267,17 @@ class WaymoMotion:
         if "packed/agent_valid" in batch:  # a `data_h5.PackedSceneLoader` batch: decoded by the reader, upload only
             from .data_h5 import scene_from_packed
 
-            return scene_from_packed(batch, self.device, self.n_hist)
+            return _with_reference_keys(scene_from_packed(batch, self.device, self.n_hist))
         scene = scene_from_batch(batch, self.device, self.n_hist)
         if "agent/valid" in batch:
             scene["gt"] = gt_from_batch(batch, self.device, self.n_hist)
-        return scene
+        return _with_reference_keys(scene)
 
     # ------------------------------------------------------------------ rollout
     def rollout(
         self,
         features: Dict[str, Tensor],
-        latent: DiagGaussian,
+        latent: Optional[DiagGaussian],
         goal: Tensor,
         goal_valid: Tensor,
         mask_teacher_forcing: Tensor,
@@ -189,8 +305,12 @@ class WaymoMotion:
         `latent` / `goal` / `goal_valid` are per instance [N, ...] as in the reference."""
         if not deterministic_action:
             raise NotImplementedError("stochastic actions (training rollouts) are outside the built path")
-        if gt_sdc is not None or require_vis_dict:
-            raise NotImplementedError("what-if (gt_sdc) / visualisation dicts are outside the built path")
+        if require_vis_dict:
+            raise NotImplementedError("visualisation dicts (attention weights) are outside the built path")
+        if latent is None:  # the reference's `self.model.init(latent, deterministic)` + rollout without re-passing them
+            latent, deterministic_latent = self.model.latent, self.model.deterministic
+            latent_eps = latent_eps if latent_eps is not None else getattr(self.model, "_latent_eps", None)
+        per_step = gt_sdc is not None  # what-if: the SDC's trajectory is forced at every step -> the loop is driven per step
         if step_start != self.hparams["time_step_sim_start"]:
             raise NotImplementedError("step_start must equal time_step_sim_start")
         z = latent.sample(deterministic_latent, eps=latent_eps)
@@ -207,9 +327,14 @@ class WaymoMotion:
         want_checks = any(bool(v) for k, v in flags.items() if k.startswith("enable_check_")) or agent_goal is not None
         out = self.engine.rollout(
             features, features, z, mean_scene, goal, goal_valid, k_futures, step_end,
-            mask_teacher_forcing=mask_teacher_forcing.to(torch.uint8).contiguous(), tap_step=tap_step, stepwise=stepwise,
+            mask_teacher_forcing=mask_teacher_forcing.to(torch.uint8).contiguous(), tap_step=tap_step, stepwise=stepwise or per_step,
             record_check_states=want_checks, gt=gt, latent_posterior=latent_posterior, warm_start_steps=warm_start_steps,
         )
+        if per_step:
+            self._step_t = step_start
+            self._rollout_with_per_step_overrides(features, mask_teacher_forcing, k_futures, step_start, step_end, gt, gt_sdc)
+            st = self.engine.rollout_state()
+            out["final_state"], out["final_valid"], out["final_hidden"] = st["agent_state"], st["agent_valid"], st["hidden"]
         if (gt is not None and k_futures == 1 and not stepwise and self.hparams["training_metrics"]["w_diffbar_reward"] > 0
                 and gt["agent_valid"].shape[1] > step_end):
             gv, gs = self._gt_slices(gt, step_start, step_end)
@@ -217,6 +342,7 @@ class WaymoMotion:
         self._step_t = step_start
         self._rollout_meta = (step_start, step_end, z)
         self._rule_ctx = (features, k_futures, flags, rule_checker_tl, agent_goal) if want_checks else None
+        self.model.latent_sample = z
         if want_checks and not stepwise:
             out.update(self.engine.rule_checks(features, out["check_state"], out["check_valid"], k_futures, flags,
                                                tl=rule_checker_tl, agent_goal=agent_goal))
@@ -287,23 +413,60 @@ class WaymoMotion:
                                                agent_goal=agent_goal))
         return self._buffer_from(out)
 
-    def forward(self, *unused_feature_args, action_override=None, mask_action_override=None, state_override=None,
-                mask_state_override=None, deterministic_action: bool = True, require_train_dict: bool = True,
-                require_vis_dict: bool = False):
-        """One simulation step, the reference's stateful `WaymoMotion.forward` (`waymo_motion.py:108-203`): advances the
-        simulator opened by `rollout(..., stepwise=True)` and returns `(agent_state, agent_valid, train_dict, vis_dict)`.
-        The scene / goal features and the teacher-forcing overrides were bound when the rollout was opened (the reference's
-        `rollout()` passes exactly those per step, `waymo_motion.py:271-306`); custom per-call overrides are not built."""
-        if action_override is not None or state_override is not None or mask_state_override is not None or require_vis_dict:
-            raise NotImplementedError("per-call action/state overrides and vis dicts are outside the built path")
+    def forward(self, map_feature: Optional[Tensor] = None, map_valid: Optional[Tensor] = None, tl_feature: Optional[Tensor] = None,
+                tl_valid: Optional[Tensor] = None, goal_feature: Optional[Tensor] = None, goal_valid: Optional[Tensor] = None,
+                action_override: Optional[Tensor] = None, mask_action_override: Optional[Tensor] = None,
+                state_override: Optional[Dict[str, Tensor]] = None, mask_state_override: Optional[Tensor] = None,
+                deterministic_action: bool = True, require_train_dict: bool = True, require_vis_dict: bool = False,
+                gt_valid: Optional[Tensor] = None):
+        """One simulation step with the reference's signature, the stateful `WaymoMotion.forward` (`waymo_motion.py:108-203`):
+        advances the simulator opened by `rollout(..., stepwise=True)` and returns `(agent_state, agent_valid, train_dict, vis_dict)`.
+
+        * `state_override` ({"agent_state" [N,A,4], "vel" [N,A,2], "acc" [N,A,1], "yaw_rate" [N,A,1]}, `Dynamics.state_keys`) and
+          `mask_state_override` [N,A] are APPLIED to this step (`Dynamics.override_states`, `dynamics.py:132-149`; also how agents
+          are spawned) -- this is how the reference's `rollout()` teacher-forces, `waymo_motion.py:269-306`.  A mask without a
+          state dict must be all False (the reference passes `state_override=None` then).
+        * With BOTH left at None the step takes the overrides bound when the rollout was opened (step t of the history arrays and of
+          `mask_teacher_forcing`): the short form `forward()` of this mirror.  "No override at this step" is a zero mask.
+        * The kill rule (`Dynamics.kill(violations, gt_valid)`, which the reference's loop calls right after `forward`, `:311-312`),
+          the rule checks, the navigator and the buffer write are part of the same kernel launch, so `gt_valid` [N,A] (the ground
+          truth's validity at this step, None = kill every agent that leaves the map) is an argument HERE, and the returned
+          `agent_valid` is the validity after the kill.
+        * The feature arguments are those bound at `rollout(stepwise=True)`: map / goal features are loop invariants whose K/V
+          and fusion halves were hoisted there, the traffic-light step follows the step counter (`step_tl = min(step - 1, n - 1)`,
+          `:291`), `goal_valid` is maintained by the navigator inside the kernel.  They are accepted for signature parity and
+          checked for shape only.
+        * `action_override`, stochastic actions and `require_vis_dict` (attention weights) are outside the built path."""
+        if action_override is not None or mask_action_override is not None or require_vis_dict:
+            raise NotImplementedError("action overrides and vis dicts (attention weights) are outside the built path")
         if not deterministic_action:
             raise NotImplementedError("stochastic actions are outside the built path")
         eng = self.engine
-        eng.rollout_step()
+        o = eng._step_out
+        n, a = o["preds"].shape[:2]
+        for name, ten, shape in (("map_feature", map_feature, (None, None, 128)), ("tl_feature", tl_feature, (None, None, 128)),
+                                 ("goal_feature", goal_feature, (n, a, 128)), ("goal_valid", goal_valid, (n, a))):
+            if ten is not None and (ten.dim() != len(shape) or any(e is not None and e != g for e, g in zip(shape, ten.shape))):
+                raise ValueError(f"forward: {name} has shape {tuple(ten.shape)}, expected {shape}")
+        override = None
+        if state_override is not None or mask_state_override is not None:
+            if mask_state_override is None:
+                raise ValueError("forward: state_override needs mask_state_override")
+            mask = mask_state_override
+            if state_override is None:
+                z = torch.zeros(n, a, 4, device=self.device)
+                state_override = {"agent_state": z, "vel": z[..., :2], "acc": z[..., :1], "yaw_rate": z[..., :1]}
+                # (checked lazily by the kernel's semantics: with no state dict nothing may be forced)
+                if not isinstance(mask, Tensor) or (mask.device.type == "cpu" and bool(mask.any())):
+                    raise ValueError("forward: mask_state_override is set somewhere but state_override is None")
+            override = {"mask": mask, "agent_state": state_override["agent_state"], "vel": state_override["vel"],
+                        "acc": state_override["acc"], "yaw_rate": state_override["yaw_rate"], "gt_valid": gt_valid}
+        elif gt_valid is not None:
+            raise ValueError("forward: gt_valid goes with state_override / mask_state_override (the bound history supplies its own)")
+        eng.rollout_step(override)
         st = eng.rollout_state()
         s_idx = self._step_t - self.hparams["time_step_sim_start"]
         self._step_t += 1
-        o = eng._step_out
         train_dict = {}
         if require_train_dict:
             train_dict = {
@@ -312,6 +475,30 @@ class WaymoMotion:
             }
         self.model.hidden = st["hidden"].flatten(1, 2)
         return st["agent_state"], st["agent_valid"].bool(), train_dict, {}
+
+    def _rollout_with_per_step_overrides(self, features: Dict[str, Tensor], mask_teacher_forcing: Tensor, k_futures: int,
+                                         step_start: int, step_end: int, gt: Optional[Dict[str, Tensor]],
+                                         gt_sdc: Optional[Dict[str, Tensor]]) -> None:
+        """The reference's loop (`waymo_motion.py:269-306`) over `forward(state_override=..., mask_state_override=...)` for a
+        simulator already opened with `stepwise=True`: per step the override of step t of the teacher-forcing source, plus -- the
+        what-if motion prediction of `gt_sdc` ({"agent_state" [N,S,4], "vel" [N,S,2], "acc" / "yaw_rate" [N,S,1]}) -- agent 0 forced
+        to the given trajectory at EVERY step (`:279-284`)."""
+        src = gt if gt is not None else features
+        n_src = src["agent_valid"].shape[1]
+        rep = (lambda x: x.repeat_interleave(k_futures, 0)) if k_futures > 1 else (lambda x: x)
+        mask_tf = mask_teacher_forcing.to(self.device).bool()
+        for t in range(step_start, step_end + 1):
+            in_src = t < n_src
+            m = rep(mask_tf[:, t]).clone() if in_src else torch.zeros_like(rep(mask_tf[:, 0]))
+            tt = t if in_src else 0
+            so = {"agent_state": rep(src["agent_state"][:, tt]).clone(), "vel": rep(src["agent_vel"][:, tt]).clone(),
+                  "acc": rep(src["agent_acc"][:, tt]).unsqueeze(-1).clone(), "yaw_rate": rep(src["agent_yaw_rate"][:, tt]).unsqueeze(-1).clone()}
+            if gt_sdc is not None:
+                m[:, 0] = True
+                for k in so:
+                    so[k][:, 0] = gt_sdc[k][:, t].to(self.device).to(so[k].dtype).reshape(so[k][:, 0].shape)
+            gtv = rep(src["agent_valid"][:, t]) if in_src else None
+            self.forward(state_override=so, mask_state_override=m, gt_valid=gtv, require_train_dict=False)
 
     def joint_future_pred(
         self,
@@ -389,11 +576,19 @@ class WaymoMotion:
                 valid=buf.valid[:, :, 0].any(-1), scores=scores, trajs=buf.preds[:, :, :, buf.step_future_start:],
                 agent_type=scene["agent_type"],
             )
+        self._check_range()
         return {
             "rollout_buffer": buf, "goal_sample": gs, "goal_log_probs": glp, "input_feature_dict": input_feature_dict,
             "latent_mean": latent_mean, "latent_valid": latent_valid, "dest_logits": self.model._enc["dest_logits"],
             "scores": scores, "pred_dict": pred_dict,
         }
+
+    def _check_range(self) -> None:
+        """`tb_check_status` after a step of the harness (one stream synchronisation; `self.check_range = False` skips it): raises if an
+        fp16-pair operand of the fp32-accurate kernels left the fp16 range -- trained-checkpoint activations far beyond the O(1..100)
+        this model produces would otherwise turn into silently squashed inf / NaN."""
+        if self.check_range:
+            self.engine.check_status()
 
     def training_step(self, batch: Dict[str, Tensor], batch_idx: int = 0, latent_eps: Optional[Tensor] = None,
                       rollout_prior: bool = False, current_epoch: int = 0) -> Dict[str, object]:
@@ -431,6 +626,7 @@ class WaymoMotion:
             raw, gv, gs, scene["agent_size"], dest_logits=self.model._enc["dest_logits"], goal_valid=goal_pred.valid, gt_dest=goal_gt,
             post={"latent_mean": latent_post.mean, "latent_valid": latent_post.valid},
             prior={"latent_mean": latent_prior.mean, "latent_valid": latent_prior.valid})
+        self._check_range()
         m = TrainingMetrics("training", **hp["training_metrics"])
         m.update(states)
         out = m.compute()  # (the reference logs and resets per step, :415-417)
@@ -497,6 +693,7 @@ class WaymoMotion:
         pred_dict_j = self.waymo_post_processing(
             valid=buf_j.valid[:, :, 0].any(-1), scores=scores, trajs=buf_j.preds[:, :, :, buf_j.step_future_start:],
             agent_type=scene["agent_type"])
+        self._check_range()
         return {
             "reactive_replay": {"rollout_buffer": buf, "train_states": train_states, "metric_states": states, "pred_dict": pred_dict_rr},
             "joint_future_pred": {"rollout_buffer": buf_j, "goal_sample": gsamp, "goal_log_probs": glp, "metric_states": states_j,
