@@ -186,10 +186,25 @@ std::vector<float> pack_xdl_bf16(const float* w, int n_out, int k) {
 
 static bool g_pack_bf16 = false;  // which packing add_xdl emits (set around the two passes of tb_finalize_weights)
 
+// fp16-pair weights share the operand range of tb_device_xdl.hpp: |w| < 65504 (the high plane would be inf).  Checked where the
+// planes are made, so that a checkpoint outside the range fails at tb_finalize_weights with the tensor's name instead of producing
+// inf / NaN products; the bf16 packing has fp32's range.
+bool xdl_range_ok(Stage& s, const std::string& name, const float* w, size_t n) {
+    if (g_pack_bf16) return true;
+    float m = 0.f;
+    for (size_t i = 0; i < n; ++i) m = std::fmax(m, std::fabs(w[i]));
+    if (m < 65504.0f) return true;
+    if (s.ok) tb_fail(s.ctx, "weight '%s': max |w| = %g is outside the fp16-pair range of the fp32-accurate kernels (|w| < 65504); "
+                             "rescale the layer or use operand_precision = bf16", name.c_str(), (double)m);
+    s.ok = false;
+    return false;
+}
+
 uint32_t add_xdl(Arena& a, Stage& s, const std::string& name, int n_out, int k, int row0 = 0, int rows_total = -1) {
     if (rows_total < 0) rows_total = n_out;
     auto v = s.get(name, (size_t)rows_total * k);
     if (!v) return 0;
+    if (!xdl_range_ok(s, name, v->data() + (size_t)row0 * k, (size_t)n_out * k)) return 0;
     return a.add(g_pack_bf16 ? pack_xdl_bf16(v->data() + (size_t)row0 * k, n_out, k) : pack_xdl(v->data() + (size_t)row0 * k, n_out, k));
 }
 
@@ -442,6 +457,7 @@ int tb_finalize_weights(tb_ctx* ctx, tb_stream stream) {
                         }
                         bf[r] = (float)acc;
                     }
+                    xdl_range_ok(s, lp + ".attn.in_proj_weight (K/V rows x norm_tgt.weight)", wf.data(), wf.size());
                     px.inter_kvf[i] = a.add(bf16 ? pack_xdl_bf16(wf.data(), 256, 128) : pack_xdl(wf.data(), 256, 128));
                     px.inter_bkvf[i] = a.add(bf);
                 }
