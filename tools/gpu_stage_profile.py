@@ -19,7 +19,7 @@ NAMES = ["C: tile/geometry loads", "C: interaction x3", "C: GRU x3", "C: add_goa
 
 cfg = load_model_config(overrides={"operand_precision": os.environ.get("TB_PRECISION", "fp32")})
 sd = synth.make_state_dict(7)
-b, a, p, t = 32, 64, 256, 40
+b, a, p, t = 32, int(os.environ.get("AB_A", 64)), int(os.environ.get("AB_P", 256)), 40
 batch = synth.make_batch(5000, b, n_agent=a, n_pl=p, n_tl=t)
 dev = torch.device("cuda:0")
 eng = HipEngine(cfg)

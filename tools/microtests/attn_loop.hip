@@ -15,19 +15,24 @@
 #include <algorithm>
 #include <vector>
 
+#include "tb_rollout.hpp"
 #include "tb_device_xdl.hpp"
+#include "tb_step_common.hpp"
 
 using namespace tb;
 
 #include "attn_variants.hpp"
 
-template <int VAR>
-__global__ __launch_bounds__(NTHREADS) void k_attn(const xhalf* __restrict__ Kall, const xhalf* __restrict__ Vall, const float* __restrict__ kbias,
+template <int VAR, int NT = NTHREADS>
+__global__ __launch_bounds__(NT) void k_attn(const xhalf* __restrict__ Kall, const xhalf* __restrict__ Vall, const float* __restrict__ kbias,
                                                    const float* __restrict__ wdummy, int n_key_pad, int n_layers, int reps, float* __restrict__ out,
-                                                   long long* __restrict__ cyc) {
-    const int tid = threadIdx.x, wave = wave_of(tid), lane = tid & 63, kq = lane >> 4, m = lane & 15;
-    const int rt = blockIdx.x, g = blockIdx.y, n_rt = gridDim.x;
-    const size_t ls = (size_t)n_key_pad * H;  // fp16 per plane per (group, layer); K and V each hold NPL planes
+                                                   long long* __restrict__ cyc, int kv_share) {
+    const int tid = threadIdx.x, wave8 = wave_of(tid), wave = wave8 & 3, lane = tid & 63, kq = lane >> 4, m = lane & 15;
+    if (NT == 512) n_key_pad >>= 1;  // each wave of a pair walks half of the keys
+    int g, rt;
+    step_tile_map(g, rt);  // the row tiles of a group on ONE XCD, as in k_step_x
+    const int n_rt = gridDim.x;
+    const size_t ls = (size_t)(NT == 512 ? 2 * n_key_pad : n_key_pad) * H;  // fp16 per plane per (group, layer); K and V each hold NPL planes
     const int kstart = ((rt * (n_key_pad >> 5)) / n_rt) << 5;
     f32x4 q[2];
     q[0] = f32x4{0.01f * (m + 1), -0.02f * (kq + 1), 0.03f * wave, 0.005f * (lane & 7)};
@@ -38,8 +43,10 @@ __global__ __launch_bounds__(NTHREADS) void k_attn(const xhalf* __restrict__ Kal
     long long t_total = 0;
     for (int r = 0; r < reps; ++r) {
         for (int l = 0; l < n_layers; ++l) {
-            const xhalf* K0 = Kall + ((size_t)g * n_layers + l) * NPL * ls;
-            const xhalf* V0 = Vall + ((size_t)g * n_layers + l) * NPL * ls;
+            const int gk = kv_share ? 0 : g;
+            const size_t half_off = (NT == 512 && wave8 >= 4) ? (size_t)(n_key_pad >> 5) * KV_BLOCK_HALFS : 0;
+            const xhalf* K0 = Kall + ((size_t)gk * n_layers + l) * NPL * ls + half_off;
+            const xhalf* V0 = Vall + ((size_t)gk * n_layers + l) * NPL * ls + half_off;
             const float* kb = kbias + (size_t)g * n_key_pad;
             AttnPreX pre;
             f32x4 o[2];
@@ -56,7 +63,8 @@ __global__ __launch_bounds__(NTHREADS) void k_attn(const xhalf* __restrict__ Kal
             q[0] += o[0] * splat(1e-3f);  // dependent chain across layers, as in the real kernel
         }
     }
-    if (lane == 0) cyc[(blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave] = t_total;
+    if (lane == 0 && wave8 < 4) cyc[(blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave] = t_total;
+    if (wave8 >= 4) return;
     float* po = out + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * NTHREADS + tid) * 8;
     for (int i = 0; i < 4; ++i) {
         po[i] = acc[0][i];
@@ -64,13 +72,13 @@ __global__ __launch_bounds__(NTHREADS) void k_attn(const xhalf* __restrict__ Kal
     }
 }
 
-template <int VAR>
+template <int VAR, int NT = NTHREADS>
 static double run(const char* name, int n_rt, int n_group, int n_key_pad, int n_layers, int reps, const xhalf* K, const xhalf* V, const float* kb,
-                  const float* wd, float* out, long long* cyc, std::vector<float>* res) {
+                  const float* wd, float* out, long long* cyc, std::vector<float>* res, int kv_share = 0) {
     dim3 grid(n_rt, n_group);
-    hipLaunchKernelGGL(k_attn<VAR>, grid, dim3(NTHREADS), 0, 0, K, V, kb, wd, n_key_pad, n_layers, 1, out, cyc);  // warm
+    hipLaunchKernelGGL((k_attn<VAR, NT>), grid, dim3(NT), 0, 0, K, V, kb, wd, n_key_pad, n_layers, 1, out, cyc, kv_share);  // warm
     (void)hipDeviceSynchronize();
-    hipLaunchKernelGGL(k_attn<VAR>, grid, dim3(NTHREADS), 0, 0, K, V, kb, wd, n_key_pad, n_layers, reps, out, cyc);
+    hipLaunchKernelGGL((k_attn<VAR, NT>), grid, dim3(NT), 0, 0, K, V, kb, wd, n_key_pad, n_layers, reps, out, cyc, kv_share);
     if (hipDeviceSynchronize() != hipSuccess) {
         printf("%s: launch failed\n", name);
         return 0;
@@ -138,6 +146,10 @@ int main(int argc, char** argv) {
         run<0>("v0 attention_head_x (tb_device_xdl.hpp)", c.n_rt, c.n_group, c.keys, c.layers, reps, K, V, kb, wd, out, cyc, &ref);
         run<1>("v1 64 keys per iteration", c.n_rt, c.n_group, c.keys, c.layers, reps, K, V, kb, wd, out, cyc, &ref);
         run<3>("v3 v1 + rescale only when the max moved", c.n_rt, c.n_group, c.keys, c.layers, reps, K, V, kb, wd, out, cyc, &ref);
+        run<0, 512>("v0, 8 waves: 2 per head, half the keys each", c.n_rt, c.n_group, c.keys, c.layers, reps, K, V, kb, wd, out, cyc, nullptr);
+        run<1, 512>("v1, 8 waves: 2 per head, half the keys each", c.n_rt, c.n_group, c.keys, c.layers, reps, K, V, kb, wd, out, cyc, nullptr);
+        run<0>("v0, every group reads group 0's K/V (L2)", c.n_rt, c.n_group, c.keys, c.layers, reps, K, V, kb, wd, out, cyc, nullptr, 1);
+        run<1>("v1, every group reads group 0's K/V (L2)", c.n_rt, c.n_group, c.keys, c.layers, reps, K, V, kb, wd, out, cyc, nullptr, 1);
         (void)hipFree(K); (void)hipFree(V); (void)hipFree(kb); (void)hipFree(wd); (void)hipFree(out); (void)hipFree(cyc);
     }
     return 0;

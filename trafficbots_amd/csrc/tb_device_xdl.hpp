@@ -68,7 +68,7 @@ constexpr float XH_MAX = 65504.0f;
 // fp16 pair of four floats: v = h + 2^-11 l
 template <bool CHECK = true>
 __device__ __forceinline__ void split2(f32x4 v, xh4& h, xh4& l) {
-#ifndef TB_XDL_BF16
+#if !defined(TB_XDL_BF16) && !defined(TB_NO_RANGE_CHECK)
     if (CHECK) {
         const float m = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
         if (m >= XH_MAX) g_range_flag = 1u;

@@ -547,8 +547,11 @@ __device__ __forceinline__ void encw_commit(int tid, const EncWRegs& r, float* E
     }
 }
 
+// NT = threads of the workgroup: 256, or 512 (k_step_x8) where waves 4-7 only take part in the barriers
+template <int NT = 256>
 __device__ __forceinline__ void step_encode_inputs_lds(const RolloutP& p, int b, int row0, int n_real, int tid, const StepSmall& sm,
                                                        const float* ENCW, float* X) {
+    const bool act = NT == 256 || tid < 256;
     float* attr = sm.attr; float* ench = sm.ench; const RowSt* rst = sm.rst; const uint8_t* rowvalid = sm.rowvalid;
     const int* rtype = sm.rtype;
     // ---- agent attributes (sc_input.py:142-165): vel2, spd, yaw_rate, acc, size3, type one-hot3
@@ -566,9 +569,9 @@ __device__ __forceinline__ void step_encode_inputs_lds(const RolloutP& p, int b,
         a[8] = ty == 0 ? 1.f : 0.f; a[9] = ty == 1 ? 1.f : 0.f; a[10] = ty == 2 ? 1.f : 0.f;
     }
     __syncthreads();
-    const int row = tid >> 4, i = tid & 15, o0 = i * 2;
+    const int row = (tid >> 4) & 15, i = tid & 15, o0 = i * 2;
     // ---- pose PE (pose_pe.py:57-62, pos_emb.py:24-25,54-55): 48 sincos per row, 3 per thread
-    {
+    if (act) {
         const float px = rst[row].st[0], py = rst[row].st[1], pyaw = rst[row].st[2];
         float* xr = X + row * LDT + 32;
 #pragma unroll
@@ -590,7 +593,7 @@ __device__ __forceinline__ void step_encode_inputs_lds(const RolloutP& p, int b,
         }
     }
     // ---- InputPeEncoder MLP 11 -> 32 -> 32 (input_pe_encoder.py:52-54), 2 outputs per thread
-    {
+    if (act) {
         float s0 = ENCW[ENCW_B1 + o0], s1 = ENCW[ENCW_B1 + o0 + 1];
 #pragma unroll
         for (int k = 0; k < 11; ++k) {
@@ -602,7 +605,7 @@ __device__ __forceinline__ void step_encode_inputs_lds(const RolloutP& p, int b,
         ench[row * 32 + o0 + 1] = fmaxf(s1, 0.f);
     }
     __syncthreads();
-    {
+    if (act) {
         float s0 = ENCW[ENCW_B2 + o0], s1 = ENCW[ENCW_B2 + o0 + 1];
 #pragma unroll
         for (int k = 0; k < 32; ++k) {
@@ -616,7 +619,7 @@ __device__ __forceinline__ void step_encode_inputs_lds(const RolloutP& p, int b,
     }
     __syncthreads();
     // the PE part of invalid rows
-    for (int q = tid; q < TM * 24; q += 256) {
+    for (int q = tid; q < TM * 24; q += NT) {
         const int r = q / 24;
         if (!rowvalid[r]) st4(X + r * LDT + 32 + (q - r * 24) * 4, splat(0.f));
     }

@@ -508,6 +508,10 @@ __global__ __launch_bounds__(256) void k_pre_replicate(RolloutP p, int n_pre) {
     }
 }
 
+void launch_pre_replicate(const RolloutP& p, int n, hipStream_t s) {
+    hipLaunchKernelGGL(k_pre_replicate, dim3((unsigned)(n * p.n_scene * (p.k_rep - 1))), dim3(256), 0, s, p, n);
+}
+
 // A halves of steps t0 + 1 .. t0 + n from the ground truth of steps t0 .. t0 + n - 1, one launch (RolloutP::pre_mode)
 void launch_step_pre_x(const RolloutP& p0, int t0, int n, hipStream_t s) {
     RolloutP p = p0;
@@ -515,7 +519,7 @@ void launch_step_pre_x(const RolloutP& p0, int t0, int n, hipStream_t s) {
     p.pre_t0 = t0;
     dim3 grid(p.a_pad / TM, p.n_scene, n);
     hipLaunchKernelGGL(k_step_x<true>, grid, dim3(NTHREADS), STEPX_LDS_FLOATS * sizeof(float), s, p, t0, 0, 1);
-    if (p.k_rep > 1) hipLaunchKernelGGL(k_pre_replicate, dim3((unsigned)(n * p.n_scene * (p.k_rep - 1))), dim3(256), 0, s, p, n);
+    if (p.k_rep > 1) launch_pre_replicate(p, n, s);
 }
 
 }  // namespace TB_XNS
