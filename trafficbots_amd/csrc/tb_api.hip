@@ -29,14 +29,10 @@ hipError_t configure_rollout_kernels();
     void launch_step_pre_x(const RolloutP& p, int t0, int n, hipStream_t s);                                                      \
     void launch_kv_hoist_x(const float* W, const XLayerW* L3, const XLayerX* X3, const float* feat, const uint8_t* fvalid, int G, \
                            int n_tok, int n_pad, float* K, float* VT, float* kbias, int* nkey, hipStream_t s);                    \
-    void launch_step_x8(const RolloutP& p, int t, int do_c, int do_a, hipStream_t s);                                             \
-    hipError_t configure_stepx8_kernel();                                                                                         \
-    void launch_step_pre_x8(const RolloutP& p, int t0, int n, hipStream_t s);                                                     \
     }
 TB_DECLARE_XDL(xh)  // fp16 pairs (tb_stepx_kernels.hip)
 namespace xh {
 void launch_range_flag_take_step(unsigned int* out, hipStream_t s);
-void launch_range_flag_take_step8(unsigned int* out, hipStream_t s);
 }
 TB_DECLARE_XDL(xb)  // bf16       (tb_stepx_bf16_kernels.hip)
 int run_encode(struct ::tb_ctx* ctx, const tb_encode_io* io, hipStream_t s);
@@ -222,8 +218,28 @@ tb::XLayerX add_xlayer_x(Arena& a, Stage& s, const std::string& p) {
     return L;
 }
 
+// LayerNorm outputs feed the fp16-pair GEMMs unchecked (tb_device_xdl.hpp): |gamma x^ + beta| <= sqrt(127) max|gamma| + max|beta| must
+// stay inside the operand range
+void ln_range_ok(Stage& s, const std::string& p) {
+    auto g = s.get(p + ".weight", 128);
+    auto b = s.get(p + ".bias", 128);
+    if (!g || !b) return;
+    float mg = 0.f, mb = 0.f;
+    for (int i = 0; i < 128; ++i) {
+        mg = std::fmax(mg, std::fabs((*g)[i]));
+        mb = std::fmax(mb, std::fabs((*b)[i]));
+    }
+    if (11.27f * mg + mb < 65504.0f) return;
+    if (s.ok) tb_fail(s.ctx, "LayerNorm '%s': sqrt(127) max|weight| + max|bias| = %g is outside the fp16-pair operand range (< 65504)", p.c_str(),
+                      (double)(11.27f * mg + mb));
+    s.ok = false;
+}
+
 tb::XLayerW add_xlayer(Arena& a, Stage& s, const std::string& p) {
     tb::XLayerW L;
+    ln_range_ok(s, p + ".norm1");
+    ln_range_ok(s, p + ".norm_tgt");
+    ln_range_ok(s, p + ".norm2");
     L.ln1_g = add_plain(a, s, p + ".norm1.weight", 128);
     L.ln1_b = add_plain(a, s, p + ".norm1.bias", 128);
     L.lnt_g = add_plain(a, s, p + ".norm_tgt.weight", 128);
@@ -302,11 +318,7 @@ static void step_launch(const tb_ctx* ctx, const tb::RolloutP& rd, const tb::Rol
         tb::set_parity(w, t);
         p.valid_w = w.valid_w; p.vbias_w = w.vbias_w; p.kin_w = w.kin_w; p.vtin_w = w.vtin_w; p.x_mid_w = w.x_mid_w;
     }
-    if (ctx->step_kernel == 5)
-        tb::xb::launch_step_x8(p, t, do_c, do_a, s);
-    else if (ctx->step_kernel == 4)
-        tb::xh::launch_step_x8(p, t, do_c, do_a, s);
-    else if (ctx->step_kernel == 3)
+    if (ctx->step_kernel == 3)
         tb::xb::launch_step_x(p, t, do_c, do_a, s);
     else if (ctx->step_kernel == 2)
         tb::xh::launch_step_x(p, t, do_c, do_a, s);
@@ -329,14 +341,6 @@ int tb_create(const tb_config* cfg, tb_ctx** out) {
         return 1;
     }
     if (cfg->operand_precision == 1) c->step_kernel = 3;
-    if (const char* w8 = getenv("TB_STEP_WAVES")) {  // development switch: 8 = the 512-thread step kernel (k_step_x8), 4 = k_step_x
-        if (std::string(w8) == "8") c->step_kernel += 2;
-        else if (std::string(w8) != "4") {
-            fprintf(stderr, "trafficbots_hip: TB_STEP_WAVES must be 4 or 8\n");
-            delete c;
-            return 1;
-        }
-    }
     if (const char* w = getenv("TB_ENCODE_KERNEL")) {  // development switch between the scene-encoder attention kernels
         const std::string k = w;
         if (k == "fp32")
@@ -354,7 +358,7 @@ int tb_create(const tb_config* cfg, tb_ctx** out) {
         if (k == "fp32")
             c->step_kernel = 0;
         else if (k == "xdl")
-            ;  // (the default: k_step_x, or k_step_x8 with TB_STEP_WAVES=8)
+            c->step_kernel = 2;
         else {
             fprintf(stderr, "trafficbots_hip: TB_STEP_KERNEL must be fp32 or xdl\n");
             delete c;
@@ -394,8 +398,6 @@ int tb_finalize_weights(tb_ctx* ctx, tb_stream stream) {
     TB_HIP(ctx, tb::configure_rollout_kernels());
     TB_HIP(ctx, tb::xh::configure_stepx_kernel());
     TB_HIP(ctx, tb::xb::configure_stepx_kernel());
-    TB_HIP(ctx, tb::xh::configure_stepx8_kernel());
-    TB_HIP(ctx, tb::xb::configure_stepx8_kernel());
     TB_HIP(ctx, tb::configure_rule_kernels());
     TB_HIP(ctx, tb::xh::configure_encodex_kernels());
     Arena a;
@@ -685,7 +687,7 @@ static int rollout_setup(tb_ctx* ctx, const tb_rollout_io* io, tb::RolloutP& p) 
     memset(&p, 0, sizeof(p));
     p.W = ctx->d_arena;
     p.pw = ctx->pw;
-    p.px = (ctx->step_kernel == 3 || ctx->step_kernel == 5) ? ctx->pxb : ctx->px;
+    p.px = ctx->step_kernel == 3 ? ctx->pxb : ctx->px;
     p.n_scene = io->n_scene;
     p.k_rep = io->k_futures;
     p.n_inst = io->n_scene * io->k_futures;
@@ -761,7 +763,7 @@ static int rollout_setup(tb_ctx* ctx, const tb_rollout_io* io, tb::RolloutP& p) 
 // prologue: hoisted K/V of the map and of every history step's traffic lights; simulator init
 static void rollout_prologue(const tb_ctx* ctx, const tb::RolloutP& p, const tb_rollout_io* io, hipStream_t s) {
     if (ctx->step_kernel >= 2) {  // k_step_x reads K / V in XDL operand order (fp16 pairs or bf16)
-        const bool bf16k = ctx->step_kernel == 3 || ctx->step_kernel == 5;
+        const bool bf16k = ctx->step_kernel == 3;
         auto hoist = bf16k ? tb::xb::launch_kv_hoist_x : tb::xh::launch_kv_hoist_x;
         hoist(p.W, p.pw.as2pl, p.px.as2pl, p.map_feature, io->map_feature_valid, p.n_scene, p.n_pl, p.p_pad, p.kpl, p.vtpl, p.kbias_pl,
               p.nkey_pl, s);
@@ -803,9 +805,7 @@ extern "C" int tb_rollout(tb_ctx* ctx, const tb_rollout_io* io, tb_stream stream
     const int n_pre = ctx->n_pre;
     const int t_pre0 = step_start - 1;
     if (n_pre > 0) {
-        if (ctx->step_kernel == 5) tb::xb::launch_step_pre_x8(p, t_pre0, n_pre, s);
-        else if (ctx->step_kernel == 4) tb::xh::launch_step_pre_x8(p, t_pre0, n_pre, s);
-        else if (ctx->step_kernel == 3) tb::xb::launch_step_pre_x(p, t_pre0, n_pre, s);
+        if (ctx->step_kernel == 3) tb::xb::launch_step_pre_x(p, t_pre0, n_pre, s);
         else tb::xh::launch_step_pre_x(p, t_pre0, n_pre, s);
     }
     // ---- the sequential loop (waymo_motion.py:269): launch i runs C(start+i-1) then A(start+i); no host sync
@@ -949,7 +949,6 @@ extern "C" int tb_check_status(tb_ctx* ctx, tb_stream stream_) {
     if (!ctx->d_status) TB_HIP(ctx, hipMalloc((void**)&ctx->d_status, sizeof(unsigned int)));
     TB_HIP(ctx, hipMemsetAsync(ctx->d_status, 0, sizeof(unsigned int), s));
     tb::xh::launch_range_flag_take_step(ctx->d_status, s);
-    tb::xh::launch_range_flag_take_step8(ctx->d_status, s);
     tb::xh::launch_range_flag_take_encode(ctx->d_status, s);
     unsigned int h = 0;
     TB_HIP(ctx, hipMemcpyAsync(&h, ctx->d_status, sizeof(unsigned int), hipMemcpyDeviceToHost, s));

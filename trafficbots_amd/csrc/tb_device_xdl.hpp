@@ -57,23 +57,47 @@ constexpr float SPLIT_SCALE = 2048.0f, SPLIT_INV = 1.0f / 2048.0f;
 constexpr int P1 = NPL - 1;  // index of the low plane (aliases plane 0 in the single-plane build, where it is never used)
 
 // Range guard of the fp16-pair mode: an operand with |x| >= 65504 becomes inf in its high plane and NaN in its low one, and a
-// NaN does not always survive to the outputs (ReLU and the softmax clamp squash it), so the overflow is FLAGGED where it
-// happens: one sticky word per translation unit, fetched and cleared by tb_check_status (two v_max3 + one compare per four values
-// on the GEMM-input stores; the softmax probabilities, in [0, 1], are split unchecked).  The bf16 build has fp32's range.
+// NaN does not always survive to the outputs (ReLU and the softmax clamp squash it), so the overflow is FLAGGED: one sticky word
+// per translation unit, fetched and cleared by tb_check_status.  Two forms of the check on the GEMM-input stores:
+//   * `amax` given (the step kernels): the running max of |x| is kept in ONE register per thread -- two v_max3 per four values,
+//     no branch, no memory operation -- and compared once at the end of the launch.  (The first form, a conditional store of the
+//     flag at every site, cost 4 % of the fused launch: a possible VMEM store in the instruction stream makes every later
+//     `s_waitcnt vmcnt` of the weight prefetch conservative.)
+//   * no `amax` (the one-time encoders and hoists): the flag is stored where the overflow happens.
+// Unchecked by construction: the softmax probabilities (in [0, 1]), LayerNorm outputs (|x^| <= sqrt(127); gamma / beta are bounded
+// when the weights are loaded, tb_finalize_weights), GRU states (|h| <= 1).  The bf16 build has fp32's range.
 #ifndef TB_XDL_BF16
 static __device__ unsigned int g_range_flag;
 #endif
 constexpr float XH_MAX = 65504.0f;
 
 // fp16 pair of four floats: v = h + 2^-11 l
-template <bool CHECK = true>
-__device__ __forceinline__ void split2(f32x4 v, xh4& h, xh4& l) {
+// The two forms as argument types: RangeFlag (default: flag at the site) and RangeMax (accumulate; the caller flushes).
+struct RangeFlag {};
+struct RangeMax {
+    float v = 0.f;  // max |x| over the checked operands: one v_max3_f32 with |.| source modifiers per two values (a NaN operand is
+                    // skipped by max -- it can only follow an overflow or come in with the data -- the first overflow itself is caught)
+};
+__device__ __forceinline__ void range_note(const RangeFlag&, const f32x4& v) {
 #if !defined(TB_XDL_BF16) && !defined(TB_NO_RANGE_CHECK)
-    if (CHECK) {
-        const float m = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
-        if (m >= XH_MAX) g_range_flag = 1u;
-    }
+    const float m = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
+    if (m >= XH_MAX) g_range_flag = 1u;
+#else
+    (void)v;
 #endif
+}
+__device__ __forceinline__ void range_note(RangeMax& r, const f32x4& v) {
+#if !defined(TB_XDL_BF16) && !defined(TB_NO_RANGE_CHECK)
+    r.v = fmaxf(fmaxf(r.v, fabsf(v.x)), fabsf(v.y));
+    r.v = fmaxf(fmaxf(r.v, fabsf(v.z)), fabsf(v.w));
+#else
+    (void)r; (void)v;
+#endif
+}
+
+template <bool CHECK = true, class R = RangeFlag>
+__device__ __forceinline__ void split2(f32x4 v, xh4& h, xh4& l, R&& amax = R{}) {
+    if (CHECK) range_note(amax, v);
     h = xh4{(xhalf)v.x, (xhalf)v.y, (xhalf)v.z, (xhalf)v.w};
     if (NPL == 2) {
         const f32x4 r = (v - f32x4{(float)h.x, (float)h.y, (float)h.z, (float)h.w}) * splat(SPLIT_SCALE);
@@ -83,26 +107,38 @@ __device__ __forceinline__ void split2(f32x4 v, xh4& h, xh4& l) {
     }
 }
 
+// end of a step launch: raise the sticky flag if any checked operand of this thread left the range
+__device__ __forceinline__ void range_flush(const RangeMax& amax) {
+#if !defined(TB_XDL_BF16) && !defined(TB_NO_RANGE_CHECK)
+    if (amax.v >= XH_MAX) g_range_flag = 1u;
+#else
+    (void)amax;
+#endif
+}
+
 // store four consecutive features of one agent row into the two planes
-__device__ __forceinline__ void planes_store4(xhalf* P, int plane_stride, int ld, int row, int col, f32x4 v) {
+template <bool CHECK = true, class R = RangeFlag>
+__device__ __forceinline__ void planes_store4(xhalf* P, int plane_stride, int ld, int row, int col, f32x4 v, R&& amax = R{}) {
     xh4 h, l;
-    split2(v, h, l);
+    split2<CHECK>(v, h, l, amax);
     xhalf* p = P + row * ld + col;
     *reinterpret_cast<xh4*>(p) = h;
     if (NPL == 2) *reinterpret_cast<xh4*>(p + plane_stride) = l;
 }
 // C-layout helper: lane (kq, m) owns features tile*16 + kq*4 .. +3 of agent m
-__device__ __forceinline__ void planes_store_c(xhalf* P, int tile, int lane, f32x4 v) {
-    planes_store4(P, PLANE, LDP, lane & 15, tile * 16 + (lane >> 4) * 4, v);
+template <bool CHECK = true, class R = RangeFlag>
+__device__ __forceinline__ void planes_store_c(xhalf* P, int tile, int lane, f32x4 v, R&& amax = R{}) {
+    planes_store4<CHECK>(P, PLANE, LDP, lane & 15, tile * 16 + (lane >> 4) * 4, v, amax);
 }
 
 // [16][128] fp32 LDS tile -> planes (256 threads, 2 float4 each)
-__device__ __forceinline__ void tile_to_planes(const float* src, int lds_, xhalf* P, int tid) {
+template <bool CHECK = true, class R = RangeFlag>
+__device__ __forceinline__ void tile_to_planes(const float* src, int lds_, xhalf* P, int tid, R&& amax = R{}) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int idx = tid + i * NTHREADS;
         const int row = idx >> 5, c4 = (idx & 31) * 4;
-        planes_store4(P, PLANE, LDP, row, c4, lds4(src + row * lds_ + c4));
+        planes_store4<CHECK>(P, PLANE, LDP, row, c4, lds4(src + row * lds_ + c4), amax);
     }
 }
 
@@ -124,8 +160,8 @@ __device__ __forceinline__ void layernorm_planes(const float* src, int lds_, xha
     const float v = row16_sum((da.x * da.x + da.y * da.y) + (da.z * da.z + da.w * da.w) + (dc.x * dc.x + dc.y * dc.y) +
                               (dc.z * dc.z + dc.w * dc.w));
     const float rstd = 1.0f / sqrtf(v * (1.0f / 128.0f) + LN_EPS);
-    planes_store4(P, PLANE, LDP, row, c0, da * splat(rstd) * g0 + b0);
-    planes_store4(P, PLANE, LDP, row, c0 + 4, dc * splat(rstd) * g1 + b1);
+    planes_store4<false>(P, PLANE, LDP, row, c0, da * splat(rstd) * g0 + b0);  // (bounded by the parameters: checked at load time)
+    planes_store4<false>(P, PLANE, LDP, row, c0 + 4, dc * splat(rstd) * g1 + b1);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -315,11 +351,11 @@ __device__ __forceinline__ void v_load_x(VFragX& f, const xhalf* __restrict__ vf
 }
 
 // eight floats of a lane -> fp16 pair (B operand)
-template <bool CHECK = true>
-__device__ __forceinline__ void split8(const f32x4& a, const f32x4& b, xh8& h, xh8& l) {
+template <bool CHECK = true, class R = RangeFlag>
+__device__ __forceinline__ void split8(const f32x4& a, const f32x4& b, xh8& h, xh8& l, R&& amax = R{}) {
     xh4 h0, l0, h1, l1;
-    split2<CHECK>(a, h0, l0);
-    split2<CHECK>(b, h1, l1);
+    split2<CHECK>(a, h0, l0, amax);
+    split2<CHECK>(b, h1, l1, amax);
     h = xh8{h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
     l = xh8{l0.x, l0.y, l0.z, l0.w, l1.x, l1.y, l1.z, l1.w};
 }
@@ -384,17 +420,17 @@ __device__ __forceinline__ void attention_prefetch_x(AttnPreX& a, const xhalf* _
 
 // One head over n_key_pad keys with online softmax; q = this wave's Q^T accumulators.  Returns o (normalised) and whether
 // the row had no valid key.  Same recurrences as attention_head (tb_device.hpp); the two matrix products are fp16-pair.
-template <bool SELFMASK, bool ISSUE = true>
+template <bool SELFMASK, bool ISSUE = true, class R = RangeFlag>
 __device__ __forceinline__ bool attention_head_x(const f32x4 (&q)[2], AttnPreX& pre, const xhalf* __restrict__ Kh,
                                                  const xhalf* __restrict__ Vh, const float* __restrict__ keybias, int n_key_pad,
                                                  int kstart, int head, int lane, int self_key, f32x4 (&o)[2], WUnitX& un,
-                                                 const WNextX& nx, long long* prof = nullptr) {
+                                                 const WNextX& nx, long long* prof = nullptr, R&& amax = R{}) {
     const int kq = lane >> 4;
     const xhalf* kbase = Kh + head * (NPL * 1024) + lane * 8;
     const xhalf* vbase = Vh + head * (NPL * 1024) + lane * 8;
     const float* bbase = keybias + kq * 4;
     xh8 qh, ql;
-    split8(q[0], q[1], qh, ql);
+    split8(q[0], q[1], qh, ql, amax);
     f32x4 oh[2] = {splat(0.f), splat(0.f)}, oc[2] = {splat(0.f), splat(0.f)};
     KFragX kn = pre.kn;
     VFragX vc = pre.vc;
@@ -472,8 +508,9 @@ __device__ __forceinline__ bool attention_head_x(const f32x4 (&q)[2], AttnPreX& 
 // K / V accumulators of a 16-token tile -> global, fragment-major (see above).  ak / av : this wave's K / V tiles
 // (features (2 wave + t)*16 + 4 kq + r of token m); the wave is head `wave`.
 // `tok` = the key slot this lane's token goes to (its index, or its rank among the valid tokens when the hoist compacts)
+template <class R = RangeFlag>
 __device__ __forceinline__ void kv_store_key_x(xhalf* __restrict__ Kf, xhalf* __restrict__ Vf, int tok, int wave, int lane,
-                                               const f32x4 (&ak)[2], const f32x4 (&av)[2], bool real) {
+                                               const f32x4 (&ak)[2], const f32x4 (&av)[2], bool real, R&& amax = R{}) {
     const int kq = lane >> 4;
     const int j = tok & 31;
     xhalf* kblk = Kf + (size_t)(tok >> 5) * KV_BLOCK_HALFS + wave * (NPL * 1024);
@@ -483,11 +520,11 @@ __device__ __forceinline__ void kv_store_key_x(xhalf* __restrict__ Kf, xhalf* __
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
         xh4 h, l;
-        split2(real ? ak[t] : splat(0.f), h, l);
+        split2(real ? ak[t] : splat(0.f), h, l, amax);
         xhalf* pk = kblk + (kt * 64 + kq * 16 + krow) * 8 + t * 4;  // plane 0, tile kt
         *reinterpret_cast<xh4*>(pk) = h;
         if (NPL == 2) *reinterpret_cast<xh4*>(pk + 1024) = l;
-        split2(real ? av[t] : splat(0.f), h, l);
+        split2(real ? av[t] : splat(0.f), h, l, amax);
         xhalf* pv = vblk + (t * 64 + vq * 16 + kq * 4) * 8 + ve;    // plane 0, d tile t, rows 4 kq + r
         pv[0] = h.x; pv[8] = h.y; pv[16] = h.z; pv[24] = h.w;
         if (NPL == 2) {
@@ -501,12 +538,12 @@ __device__ __forceinline__ void kv_store_key_x(xhalf* __restrict__ Kf, xhalf* __
 // One pre-LN cross-attention layer, GEMMs and attention on XDL.
 //   X : [16][LDT] fp32 residual stream (LDS);  P1, P2 : plane buffers (LN output / attention output + FFN hidden)
 // ---------------------------------------------------------------------------------------------
-template <bool LNLDS = false, bool SELFMASK = false>
+template <bool LNLDS = false, bool SELFMASK = false, class R = RangeFlag>
 __device__ __forceinline__ void xattn_layer_x(const float* __restrict__ W, const XLayerW& L, const XLayerX& LX, float* X, xhalf* P1,
                                               xhalf* P2, const xhalf* __restrict__ Kmat, const xhalf* __restrict__ VT,
                                               const float* __restrict__ keybias, int n_key_pad, int kstart, int self_key0,
                                               const uint8_t* rowvalid, uint8_t* novalid_s, int tid, WUnitX& u, const WNextX& nxt,
-                                              const float* lnblk = nullptr, long long* prof = nullptr) {
+                                              const float* lnblk = nullptr, long long* prof = nullptr, R&& amax = R{}) {
     if (!LNLDS) lnblk = W + L.ln1_g;
     const int wave = wave_of(tid), lane = tid & 63;
     const int kq = lane >> 4, m = lane & 15;
@@ -526,10 +563,10 @@ __device__ __forceinline__ void xattn_layer_x(const float* __restrict__ W, const
     TB_XSTAMP(18);
     f32x4 o[2];
     const bool novalid = attention_head_x<SELFMASK>(q, apre, Kmat, VT, keybias, n_key_pad, kstart, wave, lane, self_key0 >= 0 ? self_key0 + m : -1, o, u2,
-                                          wstdx(W, LX.wo, W + L.bo, wave), prof);
+                                          wstdx(W, LX.wo, W + L.bo, wave), prof, amax);
     TB_XSTAMP(19);
-    planes_store_c(P2, 2 * wave, lane, o[0]);
-    planes_store_c(P2, 2 * wave + 1, lane, o[1]);
+    planes_store_c<false>(P2, 2 * wave, lane, o[0]);  // (a convex combination of V, which was checked when it was stored)
+    planes_store_c<false>(P2, 2 * wave + 1, lane, o[1]);
     if (wave == 0 && kq == 0) novalid_s[m] = novalid ? 1 : 0;
     __syncthreads();
     TB_XSTAMP(20);
@@ -552,8 +589,8 @@ __device__ __forceinline__ void xattn_layer_x(const float* __restrict__ W, const
     {
         f32x4 acc[2] = {u.b[0], u.b[1]};
         wmmax_pf(acc[0], acc[1], u, b1, PLANE, u2, wstdx(W, LX.w2, W + L.b2, wave), lane);
-        planes_store_c(P2, 2 * wave, lane, relu4(acc[0]));
-        planes_store_c(P2, 2 * wave + 1, lane, relu4(acc[1]));
+        planes_store_c(P2, 2 * wave, lane, relu4(acc[0]), amax);
+        planes_store_c(P2, 2 * wave + 1, lane, relu4(acc[1]), amax);
     }
     __syncthreads();
     TB_XSTAMP(23);
@@ -572,17 +609,19 @@ __device__ __forceinline__ void xattn_layer_x(const float* __restrict__ W, const
     TB_XSTAMP(24);
 }
 
+template <class R = RangeFlag>
 __device__ __forceinline__ void kv_store_x(xhalf* __restrict__ Kf, xhalf* __restrict__ Vf, int tok0, int wave, int lane,
-                                           const f32x4 (&ak)[2], const f32x4 (&av)[2], bool real) {
-    kv_store_key_x(Kf, Vf, tok0 + (lane & 15), wave, lane, ak, av, real);
+                                           const f32x4 (&ak)[2], const f32x4 (&av)[2], bool real, R&& amax = R{}) {
+    kv_store_key_x(Kf, Vf, tok0 + (lane & 15), wave, lane, ak, av, real, amax);
 }
 
 // The same layer when its target set has no valid key at all (a scene without a lit traffic light): every row is "all keys
 // invalid", the reference zeroes such a row's attention output after the out-projection, so x passes the attention
 // half unchanged and only x += FFN(LN2(x)) remains.  u = the FFN1 unit on entry.
-template <bool LNLDS = false>
+template <bool LNLDS = false, class R = RangeFlag>
 __device__ __forceinline__ void ffn_layer_x(const float* __restrict__ W, const XLayerW& L, const XLayerX& LX, float* X, xhalf* P1, xhalf* P2,
-                                            const uint8_t* rowvalid, int tid, WUnitX& u, const WNextX& nxt, const float* lnblk = nullptr) {
+                                            const uint8_t* rowvalid, int tid, WUnitX& u, const WNextX& nxt, const float* lnblk = nullptr,
+                                            R&& amax = R{}) {
     if (!LNLDS) lnblk = W + L.ln1_g;
     const int wave = wave_of(tid), lane = tid & 63;
     const int kq = lane >> 4, m = lane & 15;
@@ -594,8 +633,8 @@ __device__ __forceinline__ void ffn_layer_x(const float* __restrict__ W, const X
     {
         f32x4 acc[2] = {u.b[0], u.b[1]};
         wmmax_pf(acc[0], acc[1], u, b1, PLANE, u2, wstdx(W, LX.w2, W + L.b2, wave), lane);
-        planes_store_c(P2, 2 * wave, lane, relu4(acc[0]));
-        planes_store_c(P2, 2 * wave + 1, lane, relu4(acc[1]));
+        planes_store_c(P2, 2 * wave, lane, relu4(acc[0]), amax);
+        planes_store_c(P2, 2 * wave + 1, lane, relu4(acc[1]), amax);
     }
     __syncthreads();
     {
@@ -651,15 +690,16 @@ __device__ __forceinline__ void normalize_planes(const float* src, int lds_, xha
     const float v = row16_sum((da.x * da.x + da.y * da.y) + (da.z * da.z + da.w * da.w) + (dc.x * dc.x + dc.y * dc.y) +
                               (dc.z * dc.z + dc.w * dc.w));
     const float rstd = 1.0f / sqrtf(v * (1.0f / 128.0f) + LN_EPS);
-    planes_store4(P, PLANE, LDP, row, c0, da * splat(rstd));
-    planes_store4(P, PLANE, LDP, row, c0 + 4, dc * splat(rstd));
+    planes_store4<false>(P, PLANE, LDP, row, c0, da * splat(rstd));
+    planes_store4<false>(P, PLANE, LDP, row, c0 + 4, dc * splat(rstd));
 }
 
 // K/V of the tile for the three interaction layers from ONE normalisation (norm_tgt folded into kvf / bkvf, PolicyWX).
 // u holds the K unit of layer 0 on entry and `nxt` on exit; Kmat / VT point at layer 0, layer l at + 2 l ls (fp16).
+template <class R = RangeFlag>
 __device__ __forceinline__ void kv_project_shared_x(const float* __restrict__ W, const uint32_t (&kvf)[3], const uint32_t (&bkvf)[3],
                                                     const float* T, xhalf* P1, xhalf* __restrict__ Kmat, xhalf* __restrict__ VT, size_t ls,
-                                                    int tok0, int n_real_rows, int tid, WUnitX& u, const WNextX& nxt) {
+                                                    int tok0, int n_real_rows, int tid, WUnitX& u, const WNextX& nxt, R&& amax = R{}) {
     const int wave = wave_of(tid), lane = tid & 63;
     const int kq = lane >> 4, m = lane & 15;
     normalize_planes(T, LDT, P1, tid);
@@ -672,7 +712,7 @@ __device__ __forceinline__ void kv_project_shared_x(const float* __restrict__ W,
         wmmax_pf(ak[0], ak[1], u, b1, PLANE, u2, wnextx(W, kvf[l], W + bkvf[l], 8 + 2 * wave, 8 + 2 * wave + 1), lane);
         f32x4 av[2] = {u2.b[0], u2.b[1]};
         wmmax_pf(av[0], av[1], u2, b1, PLANE, u, l < 2 ? wstdx(W, kvf[l + 1], W + bkvf[l + 1], wave) : nxt, lane);
-        kv_store_x(Kmat + 2 * l * ls, VT + 2 * l * ls, tok0, wave, lane, ak, av, m < n_real_rows);
+        kv_store_x(Kmat + 2 * l * ls, VT + 2 * l * ls, tok0, wave, lane, ak, av, m < n_real_rows, amax);
     }
     __syncthreads();
 }
@@ -822,7 +862,7 @@ __device__ __forceinline__ void gru_layer_x(const float* __restrict__ W, const G
             const float ng = tanhf_(gin[t][q] + rg * ghn[t][q]);
             hn[q] = rv ? (1.0f - zg) * ng + zg * hold[q] : 0.f;
         }
-        if (OutP) planes_store_c(OutP, tile, lane, hn);
+        if (OutP) planes_store_c<false>(OutP, tile, lane, hn);  // (|h| <= 1)
         if (Out) st4(cptr(Out, LDT, tile, lane), hn);
         if (m < n_real_rows) st4(h_global + (size_t)m * H + tile * 16 + kq * 4, hn);
     }

@@ -25,7 +25,7 @@ struct tb_ctx {
     tb::PolicyWX pxb;  // bf16 packings (operand_precision = 1)
     tb::EncoderW ew;
     bool finalized = false;
-    int step_kernel = 2;  // 2: k_step_x (fp16-pair XDL MFMA, default)  3: k_step_x, bf16 operands (tb_config.operand_precision = 1)  4 / 5: the same two on 8 waves (k_step_x8, TB_STEP_WAVES=8)  0: k_step (fp32 MFMA, the A/B twin); TB_STEP_KERNEL overrides
+    int step_kernel = 2;  // 2: k_step_x (fp16-pair XDL MFMA, default)  3: k_step_x, bf16 operands (tb_config.operand_precision = 1)  0: k_step (fp32 MFMA, the A/B twin); TB_STEP_KERNEL overrides
     int encode_kernel = 1;  // 1: XDL attention blocks (tb_encodex_kernels.hip, default)  0: fp32-MFMA blocks; TB_ENCODE_KERNEL overrides
     // workspace
     char* d_ws = nullptr;

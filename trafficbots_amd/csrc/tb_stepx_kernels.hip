@@ -32,15 +32,16 @@ static_assert(STEPX_LDS_FLOATS * 4 <= 160 * 1024, "LDS budget");
 // u does not change during a rollout (only its mask does), so its half of the first Linear is hoisted: k_fuse_hoist_x leaves
 // PRE = W1[:, 128:256] u in the rollout workspace and the step multiplies only the x half (one weight unit instead of two).
 //   CP : planes of x ([16][LDPC] rows);  P2 : plane buffer for the hidden;  uw : in = the x half of W1 (carries b1)
+template <class R = RangeFlag>
 __device__ __forceinline__ void fuse_latent_goal_x(const float* __restrict__ W, uint32_t w2x, uint32_t b2, float* X, xhalf* CP, xhalf* P2,
                                                    const float* PRE, const uint8_t* zvalid, const uint8_t* rowvalid, int tid, WUnitX& uw,
-                                                   const WNextX& nxt) {
+                                                   const WNextX& nxt, R&& amax = R{}) {
     const int wave = wave_of(tid), lane = tid & 63, kq = lane >> 4, m = lane & 15;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int idx = tid + i * NTHREADS;
         const int r = idx >> 5, c4 = (idx & 31) * 4;
-        planes_store4(CP, PLANEC, LDPC, r, c4, lds4(X + r * LDT + c4));
+        planes_store4(CP, PLANEC, LDPC, r, c4, lds4(X + r * LDT + c4), amax);
     }
     __syncthreads();
     WUnitX u2;
@@ -53,8 +54,8 @@ __device__ __forceinline__ void fuse_latent_goal_x(const float* __restrict__ W, 
             acc[0] += lds4(cptr(const_cast<float*>(PRE), LDT, ta, lane));
             acc[1] += lds4(cptr(const_cast<float*>(PRE), LDT, tb_, lane));
         }
-        planes_store_c(P2, ta, lane, relu4(acc[0]));
-        planes_store_c(P2, tb_, lane, relu4(acc[1]));
+        planes_store_c(P2, ta, lane, relu4(acc[0]), amax);
+        planes_store_c(P2, tb_, lane, relu4(acc[1]), amax);
     }
     __syncthreads();
     {
@@ -156,6 +157,7 @@ __global__ __launch_bounds__(NTHREADS) void k_step_x(RolloutP p, int t, int do_c
     const int n_rt = gridDim.x;
 
     WUnitX u;
+    RangeMax amax;  // running max |x| of this thread's checked GEMM operands (tb_device_xdl.hpp: range guard)
 #ifdef TB_DEBUG_LATE_TILE  // experiment: row tile 1 of every instance starts ~200 us after its siblings
     if (rt == 1) {
         const long long t0 = clock64();
@@ -239,11 +241,11 @@ __global__ __launch_bounds__(NTHREADS) void k_step_x(RolloutP p, int t, int do_c
             const xhalf* K0 = reinterpret_cast<const xhalf*>(p.kin + ((size_t)n * 3) * ls);
             const xhalf* V0 = reinterpret_cast<const xhalf*>(p.vtin + ((size_t)n * 3) * ls);
             xattn_layer_x<true, true>(W, pw.inter[0], px.inter[0], X, PA, PB, K0, V0, kvd, nk_a, ks_a, row0, rowvalid, novalid_s, tid, u,
-                                xlayer_first_x(W, pw.inter[1], px.inter[1], wave), LN + 0 * 768);
+                                xlayer_first_x(W, pw.inter[1], px.inter[1], wave), LN + 0 * 768, nullptr, amax);
             xattn_layer_x<true, true>(W, pw.inter[1], px.inter[1], X, PA, PB, K0 + 2 * ls, V0 + 2 * ls, kvd, nk_a, ks_a, row0, rowvalid, novalid_s, tid,
-                                u, xlayer_first_x(W, pw.inter[2], px.inter[2], wave), LN + 1 * 768);
+                                u, xlayer_first_x(W, pw.inter[2], px.inter[2], wave), LN + 1 * 768, nullptr, amax);
             xattn_layer_x<true, true>(W, pw.inter[2], px.inter[2], X, PA, PB, K0 + 4 * ls, V0 + 4 * ls, kvd, nk_a, ks_a, row0, rowvalid,
-                                novalid_s, tid, u, gru_first_x(W, pw.gru[0], px.gru[0], wave), LN + 2 * 768);
+                                novalid_s, tid, u, gru_first_x(W, pw.gru[0], px.gru[0], wave), LN + 2 * 768, nullptr, amax);
         }
         TB_STAMP(2);
         // ---- 3-layer GRU, one step (agent_temporal.py:147-152).  planes: x0 = PA, h0 = PB, h1 = PD, out0 = PC, h2 -> PB, out1 = PA
@@ -251,12 +253,12 @@ __global__ __launch_bounds__(NTHREADS) void k_step_x(RolloutP p, int t, int do_c
             float* hg0 = p.hidden + (((size_t)0 * p.n_inst + n) * p.a_pad + row0) * H;
             float* hg1 = p.hidden + (((size_t)1 * p.n_inst + n) * p.a_pad + row0) * H;
             float* hg2 = p.hidden + (((size_t)2 * p.n_inst + n) * p.a_pad + row0) * H;
-            tile_to_planes(X, LDT, PA, tid);
-            tile_to_planes(Hs, LDT, PB, tid);
-            tile_to_planes(H1, LDT, PD, tid);
+            tile_to_planes(X, LDT, PA, tid, amax);
+            tile_to_planes<false>(Hs, LDT, PB, tid);  // (GRU states: |h| <= 1)
+            tile_to_planes<false>(H1, LDT, PD, tid);
             __syncthreads();
             gru_layer_x(W, pw.gru[0], px.gru[0], PA, PB, Hs, PC, nullptr, rowvalid, hg0, TM, tid, u, gru_first_x(W, pw.gru[1], px.gru[1], wave));
-            tile_to_planes(H2, LDT, PB, tid);  // (h0's planes are free after the barrier that closed layer 0)
+            tile_to_planes<false>(H2, LDT, PB, tid);  // (h0's planes are free after the barrier that closed layer 0)
             gru_layer_x(W, pw.gru[1], px.gru[1], PC, PD, H1, PA, nullptr, rowvalid, hg1, TM, tid, u, gru_first_x(W, pw.gru[2], px.gru[2], wave));
             gru_layer_x(W, pw.gru[2], px.gru[2], PA, PB, H2, nullptr, X, rowvalid, hg2, TM, tid, u,
                         wnextx(W, px.goal_out_w1, W + pw.goal_out_b1, 2 * wave, 2 * wave + 1, 8, 0));
@@ -264,7 +266,7 @@ __global__ __launch_bounds__(NTHREADS) void k_step_x(RolloutP p, int t, int do_c
         TB_STAMP(3);
         // ---- add_goal, add_latent (traffic_bots.py:240-241); concat planes = PC..PD, hidden = PB
         fuse_latent_goal_x(W, px.goal_out_w2, pw.goal_out_b2, X, PC, PB, GP, gvalid, rowvalid, tid, u,
-                           wnextx(W, px.lat_out_w1, W + pw.lat_out_b1, 2 * wave, 2 * wave + 1, 8, 0));
+                           wnextx(W, px.lat_out_w1, W + pw.lat_out_b1, 2 * wave, 2 * wave + 1, 8, 0), amax);
         const int my_ty = (lane < TM && rowvalid[lane]) ? rtype[lane] : -1;
         const bool has0 = __ballot(my_ty == 0) != 0, has1 = __ballot(my_ty == 1) != 0, has2 = __ballot(my_ty == 2) != 0;
         const WNextX after_head = do_a ? xlayer_first_x(W, pw.as2pl[0], px.as2pl[0], wave) : wstdx(W, px.head_w1[0], W + pw.head_b1[0], wave);
@@ -272,14 +274,14 @@ __global__ __launch_bounds__(NTHREADS) void k_step_x(RolloutP p, int t, int do_c
         const WNextX h1 = has1 ? wstdx(W, px.head_w1[1], W + pw.head_b1[1], wave) : h2;
         const WNextX h0 = has0 ? wstdx(W, px.head_w1[0], W + pw.head_b1[0], wave) : h1;
         TB_STAMP(4);
-        fuse_latent_goal_x(W, px.lat_out_w2, pw.lat_out_b2, X, PC, PB, LP, rowvalid, rowvalid, tid, u, h0);
+        fuse_latent_goal_x(W, px.lat_out_w2, pw.lat_out_b2, X, PC, PB, LP, rowvalid, rowvalid, tid, u, h0, amax);
         TB_STAMP(5);
         if (t == p.tap_step && p.tap_policy_feature)
             store_tile(p.tap_policy_feature + ((size_t)n * p.n_agent + row0) * H, X, LDT, n_real, tid);
 
         // ---- action head (action_head.py:69-75): first Linear of every type present, hidden tiles -> Hs / H1 / H2
         // (the GRU hidden copies are dead by now), then ONE reduction stage for the 128 -> 2 Linear of each row's own type
-        tile_to_planes(X, LDT, PA, tid);
+        tile_to_planes(X, LDT, PA, tid, amax);
         if (tid < 32) ubuf[tid] = 0.f;
         __syncthreads();
 #pragma unroll
@@ -328,7 +330,10 @@ __global__ __launch_bounds__(NTHREADS) void k_step_x(RolloutP p, int t, int do_c
         __syncthreads();
     }
     TB_STAMP(7);
-    if (!do_a) return;
+    if (!do_a) {
+        range_flush(amax);
+        return;
+    }
 
     // =================================== A(t+1) ===================================
     const int t1 = t + 1;
@@ -351,20 +356,20 @@ __global__ __launch_bounds__(NTHREADS) void k_step_x(RolloutP p, int t, int do_c
         const xhalf* V0 = reinterpret_cast<const xhalf*>(p.vtpl + ((size_t)b * 3) * ls);
         xattn_layer_x<true>(W, pw.as2pl[0], px.as2pl[0], X, PA, PB, K0, V0, kvd, nk_p, ks_p, -1, rowvalid, novalid_s, tid, u,
                             xlayer_first_x(W, pw.as2pl[1], px.as2pl[1], wave), LN + 3 * 768,
-                            p.prof + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 32);
+                            p.prof + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 32, amax);
         xattn_layer_x<true>(W, pw.as2pl[1], px.as2pl[1], X, PA, PB, K0 + 2 * ls, V0 + 2 * ls, kvd, nk_p, ks_p, -1, rowvalid, novalid_s, tid, u,
-                            xlayer_first_x(W, pw.as2pl[2], px.as2pl[2], wave), LN + 4 * 768);
+                            xlayer_first_x(W, pw.as2pl[2], px.as2pl[2], wave), LN + 4 * 768, nullptr, amax);
         xattn_layer_x<true>(W, pw.as2pl[2], px.as2pl[2], X, PA, PB, K0 + 4 * ls, V0 + 4 * ls, kvd, nk_p, ks_p, -1, rowvalid, novalid_s, tid,
-                            u, xlayer_first_x(W, pw.as2tl[0], px.as2tl[0], wave), LN + 5 * 768);
+                            u, xlayer_first_x(W, pw.as2tl[0], px.as2tl[0], wave), LN + 5 * 768, nullptr, amax);
     }
     TB_STAMP(9);
     if (tl_empty) {
         // (the Q unit requested above is dropped; one exposed unit load here keeps the common path free of any select)
         wloadx(u, wstdx(W, px.as2tl[0].w1, W + pw.as2tl[0].b1, wave), lane);
-        ffn_layer_x<true>(W, pw.as2tl[0], px.as2tl[0], X, PA, PB, rowvalid, tid, u, wstdx(W, px.as2tl[1].w1, W + pw.as2tl[1].b1, wave), LN + 6 * 768);
-        ffn_layer_x<true>(W, pw.as2tl[1], px.as2tl[1], X, PA, PB, rowvalid, tid, u, wstdx(W, px.as2tl[2].w1, W + pw.as2tl[2].b1, wave), LN + 7 * 768);
+        ffn_layer_x<true>(W, pw.as2tl[0], px.as2tl[0], X, PA, PB, rowvalid, tid, u, wstdx(W, px.as2tl[1].w1, W + pw.as2tl[1].b1, wave), LN + 6 * 768, amax);
+        ffn_layer_x<true>(W, pw.as2tl[1], px.as2tl[1], X, PA, PB, rowvalid, tid, u, wstdx(W, px.as2tl[2].w1, W + pw.as2tl[2].b1, wave), LN + 7 * 768, amax);
         ffn_layer_x<true>(W, pw.as2tl[2], px.as2tl[2], X, PA, PB, rowvalid, tid, u, wstdx(W, px.inter_kvf[0], W + px.inter_bkvf[0], wave),
-                          LN + 8 * 768);
+                          LN + 8 * 768, amax);
     } else {
         const float* kvd = p.kbias_tl + (size_t)g_tl * p.t_pad;
         const int nk_t = nk_t_raw;
@@ -373,11 +378,11 @@ __global__ __launch_bounds__(NTHREADS) void k_step_x(RolloutP p, int t, int do_c
         const xhalf* K0 = reinterpret_cast<const xhalf*>(p.ktl + ((size_t)g_tl * 3) * ls);
         const xhalf* V0 = reinterpret_cast<const xhalf*>(p.vttl + ((size_t)g_tl * 3) * ls);
         xattn_layer_x<true>(W, pw.as2tl[0], px.as2tl[0], X, PA, PB, K0, V0, kvd, nk_t, ks_t, -1, rowvalid, novalid_s, tid, u,
-                            xlayer_first_x(W, pw.as2tl[1], px.as2tl[1], wave), LN + 6 * 768);
+                            xlayer_first_x(W, pw.as2tl[1], px.as2tl[1], wave), LN + 6 * 768, nullptr, amax);
         xattn_layer_x<true>(W, pw.as2tl[1], px.as2tl[1], X, PA, PB, K0 + 2 * ls, V0 + 2 * ls, kvd, nk_t, ks_t, -1, rowvalid, novalid_s, tid, u,
-                            xlayer_first_x(W, pw.as2tl[2], px.as2tl[2], wave), LN + 7 * 768);
+                            xlayer_first_x(W, pw.as2tl[2], px.as2tl[2], wave), LN + 7 * 768, nullptr, amax);
         xattn_layer_x<true>(W, pw.as2tl[2], px.as2tl[2], X, PA, PB, K0 + 4 * ls, V0 + 4 * ls, kvd, nk_t, ks_t, -1, rowvalid, novalid_s, tid,
-                            u, wstdx(W, px.inter_kvf[0], W + px.inter_bkvf[0], wave), LN + 8 * 768);
+                            u, wstdx(W, px.inter_kvf[0], W + px.inter_bkvf[0], wave), LN + 8 * 768, nullptr, amax);
     }
     TB_STAMP(10);
     const size_t zslice = PRE ? (size_t)blockIdx.z * p.n_inst * p.a_pad * H : 0;  // floats per x_mid slice; K / V slices are 3x
@@ -387,9 +392,10 @@ __global__ __launch_bounds__(NTHREADS) void k_step_x(RolloutP p, int t, int do_c
         xhalf* K0 = reinterpret_cast<xhalf*>((PRE ? p.kin_pre + 3 * zslice : p.kin_w) + ((size_t)n * 3) * ls);
         xhalf* V0 = reinterpret_cast<xhalf*>((PRE ? p.vtin_pre + 3 * zslice : p.vtin_w) + ((size_t)n * 3) * ls);
         // (the last unit request points at a valid unit that nobody consumes: the launch ends here)
-        kv_project_shared_x(W, px.inter_kvf, px.inter_bkvf, X, PA, K0, V0, ls, row0, TM, tid, u, wstdx(W, px.inter_kvf[0], W + px.inter_bkvf[0], wave));
+        kv_project_shared_x(W, px.inter_kvf, px.inter_bkvf, X, PA, K0, V0, ls, row0, TM, tid, u, wstdx(W, px.inter_kvf[0], W + px.inter_bkvf[0], wave), amax);
     }
     TB_STAMP(11);
+    range_flush(amax);
 }
 
 template __global__ void k_step_x<false>(RolloutP, int, int, int);  // (emitted first: the launch of every simulation step)
