@@ -1,0 +1,74 @@
+"""gpurun_out/pmc_step/{fp32,bf16}/ (tools/gpu_pmc_step.sh) -> the small JSON bench.py reads (profiles/pmc_step_kernel.json): per fused
+launch of the step kernel, medians over the launches of the short profiled run.
+
+Normalisations (checked against each other on this kernel, see `checks`):
+  * FETCH_SIZE / WRITE_SIZE are KiB; FETCH_SIZE x 2 on gfx950 for wide coalesced reads (MI355X_MICROARCH.md, HBM section);
+  * SQ_WAVE_CYCLES counts resident waves in units of FOUR clocks: 4 x SQ_WAVE_CYCLES / waves = the launch's length in clocks
+    (matches kernel-trace duration x ~2.3 GHz);
+  * SQ_VALU_MFMA_BUSY_CYCLES is a plain clock count summed over SIMDs: / (SIMDs with a wave x launch clocks) = the fraction of the
+    launch during which a busy SIMD's matrix pipe executes (matches the instruction count: MFMAs per wave x 16 clocks)."""
+import csv
+import glob
+import json
+import os
+import statistics
+import sys
+
+root = sys.argv[1]
+out = {}
+for prec in ("fp32", "bf16"):
+    d = os.path.join(root, prec)
+    if not os.path.isdir(d):
+        continue
+    kern = "k_step_x<false>"
+    dur = []
+    for f in glob.glob(os.path.join(d, "stats", "**", "*kernel_trace.csv"), recursive=True):
+        for r in csv.DictReader(open(f, newline="")):
+            if kern in r.get("Kernel_Name", ""):
+                dur.append((float(r["End_Timestamp"]) - float(r["Start_Timestamp"])) / 1e3)
+    med = statistics.median(dur) if dur else None
+    fused = [x for x in dur if med and 0.75 * med < x < 1.5 * med]
+    cnt = {}
+    grid = {}
+    for f in glob.glob(os.path.join(d, "pmc_*", "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f, newline="")):
+            if kern not in r.get("Kernel_Name", ""):
+                continue
+            cnt.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+            if "Grid_Size" in r:
+                grid.setdefault("grid", []).append(float(r["Grid_Size"]))
+    m = {k: statistics.median(v) for k, v in cnt.items()}
+    rec = {"kernel": f"tb::{'xh' if prec == 'fp32' else 'xb'}::{kern}", "launches_profiled": len(dur),
+           "avg_fused_launch_us_kernel_trace": (sum(fused) / len(fused)) if fused else None, "counters_median_per_launch": m}
+    n_wg = 128  # B = 32 scenes x 4 row tiles
+    n_waves, n_simd_busy = n_wg * 4, n_wg * 4
+    if "FETCH_SIZE" in m:
+        rec["fetch_bytes_per_launch"] = m["FETCH_SIZE"] * 1024 * 2
+    if "WRITE_SIZE" in m:
+        rec["write_bytes_per_launch"] = m["WRITE_SIZE"] * 1024
+    if "SQ_WAVE_CYCLES" in m and "SQ_VALU_MFMA_BUSY_CYCLES" in m:
+        clocks = 4.0 * m["SQ_WAVE_CYCLES"] / n_waves
+        rec["launch_clocks_from_SQ_WAVE_CYCLES"] = clocks
+        rec["mfma_busy"] = m["SQ_VALU_MFMA_BUSY_CYCLES"] / (n_simd_busy * clocks)
+        rec["mfma_busy_chip_wide"] = m["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024 * clocks)
+        rec["mfma_busy_how"] = ("SQ_VALU_MFMA_BUSY_CYCLES / (512 SIMDs that hold a wave x launch clocks), launch clocks = 4 x SQ_WAVE_CYCLES / "
+                                "512 waves; chip-wide = / 1024 SIMDs; rocprofv3 --pmc pass of tools/gpu_pmc_step.sh")
+        if rec["avg_fused_launch_us_kernel_trace"]:
+            rec["checks"] = {"clock_GHz_implied": clocks / (rec["avg_fused_launch_us_kernel_trace"] * 1e3)}
+    if "TCC_HIT_sum" in m and "TCC_MISS_sum" in m:
+        rec["l2_hit_rate"] = m["TCC_HIT_sum"] / (m["TCC_HIT_sum"] + m["TCC_MISS_sum"])
+    if "TCP_TCC_READ_REQ_sum" in m:
+        rec["l1_to_l2_read_bytes_per_launch"] = m["TCP_TCC_READ_REQ_sum"] * 128
+    # dominant one-time encoder kernel (kernel stats of the same run)
+    enc = {}
+    for f in glob.glob(os.path.join(d, "stats", "**", "*kernel_stats.csv"), recursive=True):
+        for r in csv.DictReader(open(f, newline="")):
+            name = r.get("Name", "")
+            if "k_step_x" in name or "rollout" in name or "k_fuse_hoist" in name or "k_kv_hoist_x(" in name or "k_pre_replicate" in name:
+                continue
+            enc[name.split("(")[0]] = float(r.get("TotalDurationNs", 0))
+    if enc:
+        top = max(enc, key=enc.get)
+        rec["encode_dominant_kernel"] = f"{top} ({enc[top] / sum(enc.values()):.0%} of the encoder kernels' time)"
+    out[prec] = rec
+print(json.dumps(out, indent=1))
