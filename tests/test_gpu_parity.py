@@ -757,3 +757,29 @@ def test_zz_write_report():
     with open(os.path.join(ROOT, "gpurun_out", "parity_report.json"), "w") as f:
         json.dump(REPORT, f, indent=1, sort_keys=True)
     print(json.dumps(REPORT, indent=1, sort_keys=True))
+
+
+@pytest.mark.parametrize("shape", [dict(n_scene=32, n_agent=64, n_pl=256, n_tl=40), dict(n_scene=3, n_agent=20, n_pl=33, n_tl=5, p_late_spawn=0.4,
+                                                                                     p_invalid_agent=0.2)])
+def test_gru_helper_workgroups_do_not_change_results(shape, monkeypatch):
+    """Launches of at most 128 tiles run a second workgroup per tile on the idle CUs that computes b_hh + W_hh h of the three GRU layers
+    from the previous step's hidden state and hands it to the tile's workgroup through L2 (tb_device_xdl.hpp: gru_hh_helper).  A tile's
+    result must not depend on who computed that product: with the helpers off (TB_GRU_HELPER=0, every workgroup computes it itself --
+    also what a tile does when its helper is late) the rollout is BITWISE the same; so is the stepwise API."""
+    from trafficbots_amd import synth
+
+    shape = dict(shape)
+    n_scene = shape.pop("n_scene")
+    sd = synth.make_state_dict(7)
+    batch = synth.make_batch(8100, n_scene, **shape)
+    eps = torch.from_numpy(synth.make_latent_noise(3, n_scene, shape["n_agent"])).cuda()
+    outs = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("TB_GRU_HELPER", flag)
+        wm = _engine({"time_step_end": 60, "n_joint_future": 1}, sd)
+        outs[flag] = wm.test_step(batch, latent_eps=eps)["rollout_buffer"]
+    torch.cuda.synchronize()
+    a, b = outs["1"], outs["0"]
+    assert torch.isfinite(a.preds).all()
+    assert torch.equal(a.preds, b.preds), float((a.preds - b.preds).abs().max())
+    assert torch.equal(a.valid, b.valid) and torch.equal(a.final["final_hidden"], b.final["final_hidden"])

@@ -632,7 +632,7 @@ int tb_ensure_workspace(tb_ctx* ctx, size_t bytes) {
     return 0;
 }
 
-static void carve_rollout(tb::RolloutP& p, Carver& c) {
+static void carve_rollout(tb::RolloutP& p, Carver& c, bool with_gh) {
     const size_t B = p.n_scene, N = p.n_inst, NH = p.n_tl_hist;
     p.kpl = c.take<float>(B * 3 * p.p_pad * 128);
     p.vtpl = c.take<float>(B * 3 * 128 * p.p_pad);
@@ -671,6 +671,12 @@ static void carve_rollout(tb::RolloutP& p, Carver& c) {
     p.dest_geo = c.take<float>(N * p.a_pad * 80);
     p.dest_flag = c.take<int>(N * p.a_pad);
     p.prof = c.take<long long>(N * (p.a_pad / 16) * 32);
+    p.gh = nullptr;
+    p.gh_flag = nullptr;
+    if (with_gh) {  // the GRU helper workgroups are on, see rollout_setup
+        p.gh = c.take<float>(N * (p.a_pad / 16) * (size_t)18432);
+        p.gh_flag = c.take<unsigned int>(N * (p.a_pad / 16));
+    }
 }
 
 static int rollout_setup(tb_ctx* ctx, const tb_rollout_io* io, tb::RolloutP& p) {
@@ -749,11 +755,17 @@ static int rollout_setup(tb_ctx* ctx, const tb_rollout_io* io, tb::RolloutP& p) 
         n_pre = std::max(0, wp - (step_start - 1) + 1);
     }
     p.pre_t0 = n_pre;  // (carve_rollout reads the slice count here)
+    // GRU helper workgroups: a launch of at most 128 tiles leaves at least half of the 256 CUs idle (tb_rollout.hpp)
+    bool with_gh = false;
+    {
+        const char* e = getenv("TB_GRU_HELPER");
+        with_gh = ctx->step_kernel >= 2 && (size_t)p.n_inst * (p.a_pad / 16) <= 128 && !(e && e[0] == '0');
+    }
     Carver sizing{nullptr};
-    carve_rollout(p, sizing);
+    carve_rollout(p, sizing, with_gh);
     if (tb_ensure_workspace(ctx, sizing.off + 256)) return 1;
     Carver c{ctx->d_ws};
-    carve_rollout(p, c);
+    carve_rollout(p, c, with_gh);
     p.pre_t0 = 0;
     ctx->n_pre = n_pre;
     ctx->last_prof = p.prof;
@@ -773,6 +785,7 @@ static void rollout_prologue(const tb_ctx* ctx, const tb::RolloutP& p, const tb_
         // the constant half of add_goal / add_latent's first fusion Linear (reads what k_rollout_init just wrote)
         if (bf16k) tb::xb::launch_fuse_hoist_x(p, s);
         else tb::xh::launch_fuse_hoist_x(p, s);
+        if (p.gh_flag) (void)hipMemsetAsync(p.gh_flag, 0, sizeof(unsigned int) * (size_t)p.n_inst * (p.a_pad / 16), s);
         return;
     }
     tb::launch_kv_hoist(p.W, p.pw.as2pl, p.map_feature, io->map_feature_valid, p.n_scene, p.n_pl, p.p_pad, p.kpl, p.vtpl,

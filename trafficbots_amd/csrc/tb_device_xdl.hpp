@@ -869,6 +869,166 @@ __device__ __forceinline__ void gru_layer_x(const float* __restrict__ W, const G
     __syncthreads();
 }
 
+// ---------------------------------------------------------------------------------------------
+// GRU layer step of the STEP kernels with the hidden-side products kept apart:  gh_g = W_hh,g h  for the gates g = r, z, n
+// depends only on the previous step's hidden state, i.e. on data that exists when the launch starts, so at small batch sizes a
+// HELPER workgroup on an otherwise idle CU computes it while the tile's own workgroup runs the interaction block (gru_hh_helper),
+// and hands it over through L2.  Both forms add gh to the input-side accumulator in the same order, so a tile's result does not
+// depend on who computed gh (bitwise: tests/test_gpu_parity.py).
+//   gh layout (floats) per (instance, row tile): [layer 3][gate 3][wave 4][tile 2][lane 64][4]
+// ---------------------------------------------------------------------------------------------
+constexpr int GH_TILE_FLOATS = 3 * 3 * 4 * 2 * 64 * 4;  // 18432 = 72 KiB
+
+struct GruGH {
+    f32x4 g[3][2];  // W_hh,g h per [gate r, z, n][tile], WITHOUT its bias
+    f32x4 b[3][2];  // b_hh,g (added in the order of the single-accumulator form: (b_ih + W_ih x) + b_hh, then the hidden-side products)
+};
+
+// hand-off granules: 8-byte relaxed agent-scope atomics on both sides (`global_{load,store}_dwordx2 ... sc1`: L2-served / written
+// through, never from a stale L1 line); the flag follows the payload behind `s_waitcnt vmcnt(0)` + a workgroup barrier
+// (MI355X_MICROARCH.md, inter-workgroup visibility: "{8-B agent atomics both sides}")
+__device__ __forceinline__ void gh_store(float* __restrict__ dst, const f32x4& v) {
+    unsigned long long lo, hi;
+    const float a[2] = {v.x, v.y}, b[2] = {v.z, v.w};
+    __builtin_memcpy(&lo, a, 8);
+    __builtin_memcpy(&hi, b, 8);
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(dst), lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(dst) + 1, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ f32x4 gh_load(const float* __restrict__ src) {
+    const unsigned long long lo = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(src), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long hi = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(src) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    float a[2], b[2];
+    __builtin_memcpy(a, &lo, 8);
+    __builtin_memcpy(b, &hi, 8);
+    return f32x4{a[0], a[1], b[0], b[1]};
+}
+__device__ __forceinline__ void gh_load_layer(GruGH& gh, const float* __restrict__ gh_tile, const float* __restrict__ bhh, int layer, int wave,
+                                              int lane) {
+#pragma unroll
+    for (int g = 0; g < 3; ++g)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            gh.g[g][t] = gh_load(gh_tile + ((((size_t)(layer * 3 + g) * 4 + wave) * 2 + t) * 64 + lane) * 4);
+            gh.b[g][t] = ldg4(bhh + (g * 8 + 2 * wave + t) * 16 + (lane >> 4) * 4);
+        }
+}
+
+// the gate arithmetic + stores shared by both forms
+__device__ __forceinline__ void gru_finish_x(const f32x4 (&ri)[2], const f32x4 (&zi)[2], const f32x4 (&ni)[2], const GruGH& gh, const float* Hs,
+                                             xhalf* OutP, float* Out, const uint8_t* rowvalid, float* __restrict__ h_global, int n_real_rows, int wave,
+                                             int lane) {
+    const int kq = lane >> 4, m = lane & 15;
+    const bool rv = rowvalid[m] != 0;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int tile = 2 * wave + t;
+        const f32x4 hold = lds4(Hs + m * LDT + tile * 16 + kq * 4);
+        const f32x4 r = (ri[t] + gh.b[0][t]) + gh.g[0][t], z = (zi[t] + gh.b[1][t]) + gh.g[1][t];
+        f32x4 hn;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float rg = sigmoidf_(r[q]);
+            const float zg = sigmoidf_(z[q]);
+            const float ng = tanhf_(ni[t][q] + rg * (gh.b[2][t][q] + gh.g[2][t][q]));
+            hn[q] = rv ? (1.0f - zg) * ng + zg * hold[q] : 0.f;
+        }
+        if (OutP) planes_store_c<false>(OutP, tile, lane, hn);  // (|h| <= 1)
+        if (Out) st4(cptr(Out, LDT, tile, lane), hn);
+        if (m < n_real_rows) st4(h_global + (size_t)m * H + tile * 16 + kq * 4, hn);
+    }
+    __syncthreads();
+}
+
+// form 1: the workgroup computes gh itself -- six weight units; u = the W_ih r unit on entry, `nxt` on exit
+__device__ __forceinline__ void gru_layer_own_x(const float* __restrict__ W, const GruLayerW& G, const GruLayerX& GX, const xhalf* XinP,
+                                                const xhalf* HsP, const float* Hs, xhalf* OutP, float* Out, const uint8_t* rowvalid,
+                                                float* __restrict__ h_global, int n_real_rows, int tid, WUnitX& u, const WNextX& nxt) {
+    const int wave = wave_of(tid), lane = tid & 63;
+    const int kq = lane >> 4, m = lane & 15;
+    const int ta = 2 * wave, tb_ = 2 * wave + 1;
+    const xhalf* xr = XinP + m * LDP + kq * 8;
+    const xhalf* hr = HsP + m * LDP + kq * 8;
+    const float* bih = W + G.bih;
+    const float* bhh = W + G.bhh;
+    WUnitX u2;
+    GruGH gh;
+    f32x4 ri[2] = {u.b[0], u.b[1]};
+    wmmax_pf(ri[0], ri[1], u, xr, PLANE, u2, wnextx(W, GX.whh, bhh, ta, tb_), lane);
+    gh.b[0][0] = u2.b[0]; gh.b[0][1] = u2.b[1];
+    gh.g[0][0] = splat(0.f); gh.g[0][1] = splat(0.f);
+    wmmax_pf(gh.g[0][0], gh.g[0][1], u2, hr, PLANE, u, wnextx(W, GX.wih, bih, 8 + ta, 8 + tb_), lane);
+    f32x4 zi[2] = {u.b[0], u.b[1]};
+    wmmax_pf(zi[0], zi[1], u, xr, PLANE, u2, wnextx(W, GX.whh, bhh, 8 + ta, 8 + tb_), lane);
+    gh.b[1][0] = u2.b[0]; gh.b[1][1] = u2.b[1];
+    gh.g[1][0] = splat(0.f); gh.g[1][1] = splat(0.f);
+    wmmax_pf(gh.g[1][0], gh.g[1][1], u2, hr, PLANE, u, wnextx(W, GX.wih, bih, 16 + ta, 16 + tb_), lane);
+    f32x4 ni[2] = {u.b[0], u.b[1]};
+    wmmax_pf(ni[0], ni[1], u, xr, PLANE, u2, wnextx(W, GX.whh, bhh, 16 + ta, 16 + tb_), lane);
+    gh.b[2][0] = u2.b[0]; gh.b[2][1] = u2.b[1];
+    gh.g[2][0] = splat(0.f); gh.g[2][1] = splat(0.f);
+    wmmax_pf(gh.g[2][0], gh.g[2][1], u2, hr, PLANE, u, nxt, lane);
+    gru_finish_x(ri, zi, ni, gh, Hs, OutP, Out, rowvalid, h_global, n_real_rows, wave, lane);
+}
+
+// form 2: gh comes from the helper -- three weight units.  ua = the W_ih r unit on entry; the unit after the layer (`nxt`) lands in ub
+__device__ __forceinline__ void gru_layer_gh_x(const float* __restrict__ W, const GruLayerW& G, const GruLayerX& GX, const xhalf* XinP, const float* Hs,
+                                               xhalf* OutP, float* Out, const uint8_t* rowvalid, float* __restrict__ h_global, int n_real_rows,
+                                               int tid, WUnitX& ua, WUnitX& ub, const WNextX& nxt, const GruGH& gh) {
+    const int wave = wave_of(tid), lane = tid & 63;
+    const int kq = lane >> 4, m = lane & 15;
+    const int ta = 2 * wave, tb_ = 2 * wave + 1;
+    const xhalf* xr = XinP + m * LDP + kq * 8;
+    const float* bih = W + G.bih;
+    f32x4 ri[2] = {ua.b[0], ua.b[1]};
+    wmmax_pf(ri[0], ri[1], ua, xr, PLANE, ub, wnextx(W, GX.wih, bih, 8 + ta, 8 + tb_), lane);
+    f32x4 zi[2] = {ub.b[0], ub.b[1]};
+    wmmax_pf(zi[0], zi[1], ub, xr, PLANE, ua, wnextx(W, GX.wih, bih, 16 + ta, 16 + tb_), lane);
+    f32x4 ni[2] = {ua.b[0], ua.b[1]};
+    wmmax_pf(ni[0], ni[1], ua, xr, PLANE, ub, nxt, lane);
+    gru_finish_x(ri, zi, ni, gh, Hs, OutP, Out, rowvalid, h_global, n_real_rows, wave, lane);
+}
+
+// the helper workgroup: gh of the three layers from the previous step's hidden state (global, fp32), 9 weight units.
+//   smem : 3 plane buffers;  hidden_l = p.hidden + ((l * n_inst + n) * a_pad + row0) * H
+__device__ __forceinline__ void gru_hh_helper(const float* __restrict__ W, const GruLayerX (&GX)[3],
+                                              const float* __restrict__ h0, const float* __restrict__ h1, const float* __restrict__ h2,
+                                              float* __restrict__ gh_tile, unsigned int* __restrict__ flag, unsigned int token, xhalf* smem_planes,
+                                              int tid) {
+    const int wave = wave_of(tid), lane = tid & 63;
+    const int kq = lane >> 4, m = lane & 15;
+    const int ta = 2 * wave, tb_ = 2 * wave + 1;
+    xhalf* HP[3] = {smem_planes, smem_planes + NPL * PLANE, smem_planes + 2 * NPL * PLANE};
+    const float* hsrc[3] = {h0, h1, h2};
+    WUnitX ua, ub;
+    wloadx(ua, wnextx(W, GX[0].whh, nullptr, ta, tb_), lane);
+#pragma unroll
+    for (int l = 0; l < 3; ++l)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int idx = tid + i * NTHREADS;
+            const int row = idx >> 5, c4 = (idx & 31) * 4;
+            planes_store4<false>(HP[l], PLANE, LDP, row, c4, ldg4(hsrc[l] + (size_t)row * H + c4));  // (|h| <= 1)
+        }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        const int l = i / 3, g = i % 3;
+        const int ln = (i + 1) / 3, gn = (i + 1) % 3;
+        WUnitX& cur = (i & 1) ? ub : ua;
+        WUnitX& nx_ = (i & 1) ? ua : ub;
+        // (the tenth request re-reads the first unit: nobody consumes it)
+        const WNextX nn = i < 8 ? wnextx(W, GX[ln].whh, nullptr, gn * 8 + ta, gn * 8 + tb_) : wnextx(W, GX[0].whh, nullptr, ta, tb_);
+        f32x4 acc[2] = {splat(0.f), splat(0.f)};
+        wmmax_pf(acc[0], acc[1], cur, HP[l] + m * LDP + kq * 8, PLANE, nx_, nn, lane);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) gh_store(gh_tile + ((((size_t)(l * 3 + g) * 4 + wave) * 2 + t) * 64 + lane) * 4, acc[t]);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every wave's payload is at L2 before ...
+    __syncthreads();                                  // ... the workgroup ...
+    if (tid == 0) __hip_atomic_store(flag, token, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ... raises the tile's flag
+}
+
 }  // namespace TB_XNS
 using namespace TB_XNS;
 }  // namespace tb

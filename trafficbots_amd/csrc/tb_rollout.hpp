@@ -129,6 +129,11 @@ struct RolloutP {
     float* dest_geo;              // [N,a_pad,20,4] destination polyline nodes: px, py, unit dir x, unit dir y
     int* dest_flag;               // [N,a_pad] bit0: lane-type destination, bit1: road-edge destination
     long long* prof;              // [n_blocks][32] stage time stamps (only written by -DTB_PROFILE builds)
+    // GRU helper workgroups (tb_device_xdl.hpp: gru_hh_helper): when a launch has at most 128 tiles, a second workgroup per tile
+    // (blockIdx.z = 1, on a CU the launch leaves idle) computes b_hh + W_hh h of the three GRU layers from the previous step's hidden
+    // state and hands it to the tile's own workgroup through L2.  nullptr: every workgroup computes it itself.
+    float* gh;                    // [N * tiles][3 layers][3 gates][4 waves][2 tiles][64 lanes][4]
+    unsigned int* gh_flag;        // [N * tiles]  = step + 1 once the tile's gh of that step is complete (zeroed per rollout)
     // outputs
     float* preds;                 // [N,A,S,4]
     uint8_t* o_valid;

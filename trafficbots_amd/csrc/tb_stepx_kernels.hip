@@ -155,6 +155,14 @@ __global__ __launch_bounds__(NTHREADS) void k_step_x(RolloutP p, int t, int do_c
     const size_t base_row = (size_t)n * p.a_pad + row0;
     // staggered start of the key walks of the row tiles of one instance (attention_prefetch_x)
     const int n_rt = gridDim.x;
+    const int tile_id = n * n_rt + rt;
+    if (!PRE && blockIdx.z == 1) {
+        // ---- GRU helper of tile (n, rt): b_hh + W_hh h_{t-1} for the three layers, handed to the tile's workgroup (blockIdx.z = 0)
+        gru_hh_helper(W, px.gru, p.hidden + (((size_t)0 * p.n_inst + n) * p.a_pad + row0) * H,
+                      p.hidden + (((size_t)1 * p.n_inst + n) * p.a_pad + row0) * H, p.hidden + (((size_t)2 * p.n_inst + n) * p.a_pad + row0) * H,
+                      p.gh + (size_t)tile_id * GH_TILE_FLOATS, p.gh_flag + tile_id, (unsigned int)t + 1u, PA, tid);
+        return;
+    }
 
     WUnitX u;
     RangeMax amax;  // running max |x| of this thread's checked GEMM operands (tb_device_xdl.hpp: range guard)
@@ -253,15 +261,44 @@ __global__ __launch_bounds__(NTHREADS) void k_step_x(RolloutP p, int t, int do_c
             float* hg0 = p.hidden + (((size_t)0 * p.n_inst + n) * p.a_pad + row0) * H;
             float* hg1 = p.hidden + (((size_t)1 * p.n_inst + n) * p.a_pad + row0) * H;
             float* hg2 = p.hidden + (((size_t)2 * p.n_inst + n) * p.a_pad + row0) * H;
+            int* gh_ok = dflag + 16;  // (a free word of the small-state area)
+            if (tid == 0) {
+                // has the tile's helper workgroup delivered b_hh + W_hh h of this step?  A few polls, then the workgroup computes it
+                // itself (a helper that was not scheduled in time -- another stream's kernel on the CUs -- costs nothing but the polls)
+                int got = 0;
+                if (p.gh_flag) {
+                    const unsigned int tok = (unsigned int)t + 1u;
+                    for (int i = 0; i < 4 && !got; ++i) {
+                        got = __hip_atomic_load(p.gh_flag + tile_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == tok;
+                        if (!got) __builtin_amdgcn_s_sleep(32);
+                    }
+                }
+                *gh_ok = got;
+            }
             tile_to_planes(X, LDT, PA, tid, amax);
-            tile_to_planes<false>(Hs, LDT, PB, tid);  // (GRU states: |h| <= 1)
-            tile_to_planes<false>(H1, LDT, PD, tid);
             __syncthreads();
-            gru_layer_x(W, pw.gru[0], px.gru[0], PA, PB, Hs, PC, nullptr, rowvalid, hg0, TM, tid, u, gru_first_x(W, pw.gru[1], px.gru[1], wave));
-            tile_to_planes<false>(H2, LDT, PB, tid);  // (h0's planes are free after the barrier that closed layer 0)
-            gru_layer_x(W, pw.gru[1], px.gru[1], PC, PD, H1, PA, nullptr, rowvalid, hg1, TM, tid, u, gru_first_x(W, pw.gru[2], px.gru[2], wave));
-            gru_layer_x(W, pw.gru[2], px.gru[2], PA, PB, H2, nullptr, X, rowvalid, hg2, TM, tid, u,
-                        wnextx(W, px.goal_out_w1, W + pw.goal_out_b1, 2 * wave, 2 * wave + 1, 8, 0));
+            if (*gh_ok) {  // (workgroup-uniform)
+                const float* ght = p.gh + (size_t)tile_id * GH_TILE_FLOATS;
+                WUnitX ux;
+                GruGH gh;
+                gh_load_layer(gh, ght, W + pw.gru[0].bhh, 0, wave, lane);
+                gru_layer_gh_x(W, pw.gru[0], px.gru[0], PA, Hs, PC, nullptr, rowvalid, hg0, TM, tid, u, ux, gru_first_x(W, pw.gru[1], px.gru[1], wave), gh);
+                gh_load_layer(gh, ght, W + pw.gru[1].bhh, 1, wave, lane);
+                gru_layer_gh_x(W, pw.gru[1], px.gru[1], PC, H1, PA, nullptr, rowvalid, hg1, TM, tid, ux, u, gru_first_x(W, pw.gru[2], px.gru[2], wave), gh);
+                gh_load_layer(gh, ght, W + pw.gru[2].bhh, 2, wave, lane);
+                gru_layer_gh_x(W, pw.gru[2], px.gru[2], PA, H2, nullptr, X, rowvalid, hg2, TM, tid, u, ux,
+                               wnextx(W, px.goal_out_w1, W + pw.goal_out_b1, 2 * wave, 2 * wave + 1, 8, 0), gh);
+                u = ux;
+            } else {
+                tile_to_planes<false>(Hs, LDT, PB, tid);  // (GRU states: |h| <= 1)
+                tile_to_planes<false>(H1, LDT, PD, tid);
+                __syncthreads();
+                gru_layer_own_x(W, pw.gru[0], px.gru[0], PA, PB, Hs, PC, nullptr, rowvalid, hg0, TM, tid, u, gru_first_x(W, pw.gru[1], px.gru[1], wave));
+                tile_to_planes<false>(H2, LDT, PB, tid);  // (h0's planes are free after the barrier that closed layer 0)
+                gru_layer_own_x(W, pw.gru[1], px.gru[1], PC, PD, H1, PA, nullptr, rowvalid, hg1, TM, tid, u, gru_first_x(W, pw.gru[2], px.gru[2], wave));
+                gru_layer_own_x(W, pw.gru[2], px.gru[2], PA, PB, H2, nullptr, X, rowvalid, hg2, TM, tid, u,
+                                wnextx(W, px.goal_out_w1, W + pw.goal_out_b1, 2 * wave, 2 * wave + 1, 8, 0));
+            }
         }
         TB_STAMP(3);
         // ---- add_goal, add_latent (traffic_bots.py:240-241); concat planes = PC..PD, hidden = PB
@@ -487,8 +524,10 @@ hipError_t configure_stepx_kernel() {
                                (int)(STEPX_LDS_FLOATS * sizeof(float)));
 }
 
-void launch_step_x(const RolloutP& p, int t, int do_c, int do_a, hipStream_t s) {
-    dim3 grid(p.a_pad / TM, p.n_inst);
+void launch_step_x(const RolloutP& p0, int t, int do_c, int do_a, hipStream_t s) {
+    RolloutP p = p0;
+    if (!do_c) p.gh_flag = nullptr;  // (the GRU is in the C half)
+    dim3 grid(p.a_pad / TM, p.n_inst, p.gh_flag ? 2 : 1);
     hipLaunchKernelGGL(k_step_x<false>, grid, dim3(NTHREADS), STEPX_LDS_FLOATS * sizeof(float), s, p, t, do_c, do_a);
 }
 
