@@ -759,13 +759,16 @@ def test_zz_write_report():
     print(json.dumps(REPORT, indent=1, sort_keys=True))
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
 @pytest.mark.parametrize("shape", [dict(n_scene=32, n_agent=64, n_pl=256, n_tl=40), dict(n_scene=3, n_agent=20, n_pl=33, n_tl=5, p_late_spawn=0.4,
                                                                                      p_invalid_agent=0.2)])
-def test_gru_helper_workgroups_do_not_change_results(shape, monkeypatch):
-    """Launches of at most 128 tiles run a second workgroup per tile on the idle CUs that computes b_hh + W_hh h of the three GRU layers
-    from the previous step's hidden state and hands it to the tile's workgroup through L2 (tb_device_xdl.hpp: gru_hh_helper).  A tile's
-    result must not depend on who computed that product: with the helpers off (TB_GRU_HELPER=0, every workgroup computes it itself --
-    also what a tile does when its helper is late) the rollout is BITWISE the same; so is the stepwise API."""
+def test_helper_workgroups_do_not_change_results(shape, precision, monkeypatch):
+    """Launches of at most 128 tiles run a second workgroup per tile on the idle CUs.  It computes what depends only on the previous
+    launch's data -- the interaction K / V of layers 1, 2 from the stored x_mid (kv_helper_x), then W_hh h of the three GRU layers from
+    the hidden state (gru_hh_helper) -- and hands both to the tile workgroups through L2 (tb_device_xdl.hpp).  A tile's result must
+    not depend on who computed them: with the helpers off (TB_STEP_HELPERS=0) the rollout is BITWISE the same, and so it is when the
+    helpers start ~100 us late in every launch (the hand-off under uneven load: the tile workgroups must wait for the K / V flags and
+    fall back to their own W_hh h, never read early)."""
     from trafficbots_amd import synth
 
     shape = dict(shape)
@@ -774,12 +777,16 @@ def test_gru_helper_workgroups_do_not_change_results(shape, monkeypatch):
     batch = synth.make_batch(8100, n_scene, **shape)
     eps = torch.from_numpy(synth.make_latent_noise(3, n_scene, shape["n_agent"])).cuda()
     outs = {}
-    for flag in ("1", "0"):
-        monkeypatch.setenv("TB_GRU_HELPER", flag)
-        wm = _engine({"time_step_end": 60, "n_joint_future": 1}, sd)
-        outs[flag] = wm.test_step(batch, latent_eps=eps)["rollout_buffer"]
+    for name, flag, delay in (("on", "1", "0"), ("off", "0", "0"), ("late", "1", "220000")):
+        monkeypatch.setenv("TB_STEP_HELPERS", flag)
+        monkeypatch.setenv("TB_DEBUG_HELPER_DELAY", delay)
+        wm = _engine({"time_step_end": 60 if name != "late" else 24, "n_joint_future": 1, "operand_precision": precision}, sd)
+        outs[name] = wm.test_step(batch, latent_eps=eps)["rollout_buffer"]
+        wm.engine.check_status()  # (no hand-off time-out, no range overflow)
     torch.cuda.synchronize()
-    a, b = outs["1"], outs["0"]
+    a, b, c = outs["on"], outs["off"], outs["late"]
     assert torch.isfinite(a.preds).all()
     assert torch.equal(a.preds, b.preds), float((a.preds - b.preds).abs().max())
     assert torch.equal(a.valid, b.valid) and torch.equal(a.final["final_hidden"], b.final["final_hidden"])
+    n = c.preds.shape[-2]
+    assert torch.equal(a.preds[..., :n, :], c.preds), float((a.preds[..., :n, :] - c.preds).abs().max())

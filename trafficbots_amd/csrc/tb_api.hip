@@ -673,9 +673,11 @@ static void carve_rollout(tb::RolloutP& p, Carver& c, bool with_gh) {
     p.prof = c.take<long long>(N * (p.a_pad / 16) * 32);
     p.gh = nullptr;
     p.gh_flag = nullptr;
-    if (with_gh) {  // the GRU helper workgroups are on, see rollout_setup
+    p.kv_flag = nullptr;
+    if (with_gh) {  // the helper workgroups are on, see rollout_setup
         p.gh = c.take<float>(N * (p.a_pad / 16) * (size_t)18432);
-        p.gh_flag = c.take<unsigned int>(N * (p.a_pad / 16));
+        p.gh_flag = c.take<unsigned int>(N * (p.a_pad / 16) * 3);  // [tiles] GRU flags, then [tiles][2] K/V flags (one memset)
+        p.kv_flag = p.gh_flag + N * (p.a_pad / 16);
     }
 }
 
@@ -755,11 +757,21 @@ static int rollout_setup(tb_ctx* ctx, const tb_rollout_io* io, tb::RolloutP& p) 
         n_pre = std::max(0, wp - (step_start - 1) + 1);
     }
     p.pre_t0 = n_pre;  // (carve_rollout reads the slice count here)
-    // GRU helper workgroups: a launch of at most 128 tiles leaves at least half of the 256 CUs idle (tb_rollout.hpp)
+    // helper workgroups: a launch of at most 128 tiles leaves at least half of the 256 CUs idle (tb_rollout.hpp)
     bool with_gh = false;
     {
-        const char* e = getenv("TB_GRU_HELPER");
+        const char* e = getenv("TB_STEP_HELPERS");
+        if (!e) e = getenv("TB_GRU_HELPER");  // (the switch's first name)
         with_gh = ctx->step_kernel >= 2 && (size_t)p.n_inst * (p.a_pad / 16) <= 128 && !(e && e[0] == '0');
+    }
+    if (!ctx->d_status) {
+        TB_HIP(ctx, hipMalloc((void**)&ctx->d_status, 2 * sizeof(unsigned int)));
+        TB_HIP(ctx, hipMemset(ctx->d_status, 0, 2 * sizeof(unsigned int)));
+    }
+    p.sync_err = ctx->d_status + 1;
+    {
+        const char* e = getenv("TB_DEBUG_HELPER_DELAY");
+        p.dbg_helper_delay = e ? atoi(e) : 0;
     }
     Carver sizing{nullptr};
     carve_rollout(p, sizing, with_gh);
@@ -785,7 +797,7 @@ static void rollout_prologue(const tb_ctx* ctx, const tb::RolloutP& p, const tb_
         // the constant half of add_goal / add_latent's first fusion Linear (reads what k_rollout_init just wrote)
         if (bf16k) tb::xb::launch_fuse_hoist_x(p, s);
         else tb::xh::launch_fuse_hoist_x(p, s);
-        if (p.gh_flag) (void)hipMemsetAsync(p.gh_flag, 0, sizeof(unsigned int) * (size_t)p.n_inst * (p.a_pad / 16), s);
+        if (p.gh_flag) (void)hipMemsetAsync(p.gh_flag, 0, sizeof(unsigned int) * 3 * (size_t)p.n_inst * (p.a_pad / 16), s);
         return;
     }
     tb::launch_kv_hoist(p.W, p.pw.as2pl, p.map_feature, io->map_feature_valid, p.n_scene, p.n_pl, p.p_pad, p.kpl, p.vtpl,
@@ -959,13 +971,21 @@ extern "C" int tb_check_status(tb_ctx* ctx, tb_stream stream_) {
     if (!ctx) return 1;
     TB_HIP(ctx, hipSetDevice(ctx->device));
     hipStream_t s = (hipStream_t)stream_;
-    if (!ctx->d_status) TB_HIP(ctx, hipMalloc((void**)&ctx->d_status, sizeof(unsigned int)));
+    if (!ctx->d_status) {
+        TB_HIP(ctx, hipMalloc((void**)&ctx->d_status, 2 * sizeof(unsigned int)));
+        TB_HIP(ctx, hipMemsetAsync(ctx->d_status, 0, 2 * sizeof(unsigned int), s));
+    }
     TB_HIP(ctx, hipMemsetAsync(ctx->d_status, 0, sizeof(unsigned int), s));
     tb::xh::launch_range_flag_take_step(ctx->d_status, s);
     tb::xh::launch_range_flag_take_encode(ctx->d_status, s);
-    unsigned int h = 0;
-    TB_HIP(ctx, hipMemcpyAsync(&h, ctx->d_status, sizeof(unsigned int), hipMemcpyDeviceToHost, s));
+    unsigned int hw[2] = {0, 0};
+    TB_HIP(ctx, hipMemcpyAsync(hw, ctx->d_status, 2 * sizeof(unsigned int), hipMemcpyDeviceToHost, s));
+    TB_HIP(ctx, hipMemsetAsync(ctx->d_status + 1, 0, sizeof(unsigned int), s));
     TB_HIP(ctx, hipStreamSynchronize(s));
+    const unsigned int h = hw[0];
+    if (hw[1])
+        return tb_fail(ctx, "step kernel: a tile workgroup gave up waiting for its helper workgroup (the helpers of a launch are expected to be "
+                            "dispatched first); results since the last check are invalid -- set TB_STEP_HELPERS=0 and report");
     if (h)
         return tb_fail(ctx, "fp16-pair operand range exceeded: a GEMM / attention input of the %s%s%s reached |x| >= 65504 since the last "
                             "check (results of those calls are invalid; activations of this magnitude need operand_precision = bf16 or rescaled weights)",

@@ -699,7 +699,8 @@ __device__ __forceinline__ void normalize_planes(const float* src, int lds_, xha
 template <class R = RangeFlag>
 __device__ __forceinline__ void kv_project_shared_x(const float* __restrict__ W, const uint32_t (&kvf)[3], const uint32_t (&bkvf)[3],
                                                     const float* T, xhalf* P1, xhalf* __restrict__ Kmat, xhalf* __restrict__ VT, size_t ls,
-                                                    int tok0, int n_real_rows, int tid, WUnitX& u, const WNextX& nxt, R&& amax = R{}) {
+                                                    int tok0, int n_real_rows, int tid, WUnitX& u, const WNextX& nxt, R&& amax = R{},
+                                                    int n_layers = 3) {
     const int wave = wave_of(tid), lane = tid & 63;
     const int kq = lane >> 4, m = lane & 15;
     normalize_planes(T, LDT, P1, tid);
@@ -708,10 +709,11 @@ __device__ __forceinline__ void kv_project_shared_x(const float* __restrict__ W,
     WUnitX u2;
 #pragma unroll
     for (int l = 0; l < 3; ++l) {
+        if (l >= n_layers) break;  // (layers 1, 2 are the helper workgroup's when the launch has one: kv_helper_x)
         f32x4 ak[2] = {u.b[0], u.b[1]};
         wmmax_pf(ak[0], ak[1], u, b1, PLANE, u2, wnextx(W, kvf[l], W + bkvf[l], 8 + 2 * wave, 8 + 2 * wave + 1), lane);
         f32x4 av[2] = {u2.b[0], u2.b[1]};
-        wmmax_pf(av[0], av[1], u2, b1, PLANE, u, l < 2 ? wstdx(W, kvf[l + 1], W + bkvf[l + 1], wave) : nxt, lane);
+        wmmax_pf(av[0], av[1], u2, b1, PLANE, u, (l < 2 && l + 1 < n_layers) ? wstdx(W, kvf[l + 1], W + bkvf[l + 1], wave) : nxt, lane);
         kv_store_x(Kmat + 2 * l * ls, VT + 2 * l * ls, tok0, wave, lane, ak, av, m < n_real_rows, amax);
     }
     __syncthreads();
@@ -994,14 +996,14 @@ __device__ __forceinline__ void gru_layer_gh_x(const float* __restrict__ W, cons
 __device__ __forceinline__ void gru_hh_helper(const float* __restrict__ W, const GruLayerX (&GX)[3],
                                               const float* __restrict__ h0, const float* __restrict__ h1, const float* __restrict__ h2,
                                               float* __restrict__ gh_tile, unsigned int* __restrict__ flag, unsigned int token, xhalf* smem_planes,
-                                              int tid) {
+                                              int tid, WUnitX& ua, bool ua_loaded) {
     const int wave = wave_of(tid), lane = tid & 63;
     const int kq = lane >> 4, m = lane & 15;
     const int ta = 2 * wave, tb_ = 2 * wave + 1;
     xhalf* HP[3] = {smem_planes, smem_planes + NPL * PLANE, smem_planes + 2 * NPL * PLANE};
     const float* hsrc[3] = {h0, h1, h2};
-    WUnitX ua, ub;
-    wloadx(ua, wnextx(W, GX[0].whh, nullptr, ta, tb_), lane);
+    WUnitX ub;
+    if (!ua_loaded) wloadx(ua, wnextx(W, GX[0].whh, nullptr, ta, tb_), lane);
 #pragma unroll
     for (int l = 0; l < 3; ++l)
 #pragma unroll
@@ -1027,6 +1029,110 @@ __device__ __forceinline__ void gru_hh_helper(const float* __restrict__ W, const
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every wave's payload is at L2 before ...
     __syncthreads();                                  // ... the workgroup ...
     if (tid == 0) __hip_atomic_store(flag, token, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ... raises the tile's flag
+}
+
+// ---------------------------------------------------------------------------------------------
+// Interaction K / V of layers 1 and 2 on the helper workgroup.  The K / V of step t's interaction depend only on x_mid(t), which the
+// previous launch stored, so the tile's own workgroup projects layer 0 only (the one its siblings need first) at the end of A(t) and
+// the helper workgroup of launch t projects layers 1 and 2 from the stored x_mid while the tile workgroups run layer 0.
+//   payload: 8-byte relaxed agent-scope atomic stores (written through to L2 / memory), then `s_waitcnt vmcnt(0)` + barrier + flag;
+//   the consumers poll the flags of all row tiles of their instance (kv_wait_x), then read K / V with ordinary loads: no workgroup
+//   touches those lines earlier in the launch, so neither its L1 nor its L2 can hold an older copy.
+// V fragments interleave the keys of two row tiles inside 16 bytes: the helper transposes its tile's half through LDS (wave-private,
+// 2 KB per wave) and stores 8-byte granules.  Same arithmetic and the same bytes as kv_project_shared_x (bitwise: the tests).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void st8_wt(xhalf* dst, const xh4& v) {
+    unsigned long long u;
+    __builtin_memcpy(&u, &v, 8);
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(dst), u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <class R>
+__device__ __forceinline__ void kv_store_wt_x(xhalf* __restrict__ Kf, xhalf* __restrict__ Vf, int tok0, int wave, int lane, const f32x4 (&ak)[2],
+                                              const f32x4 (&av)[2], xhalf* vstage, R&& amax) {
+    const int kq = lane >> 4, m = lane & 15;
+    const int tok = tok0 + m, j = tok & 31;
+    xhalf* kblk = Kf + (size_t)(tok >> 5) * KV_BLOCK_HALFS + wave * (NPL * 1024);
+    xhalf* vblk = Vf + (size_t)(tok0 >> 5) * KV_BLOCK_HALFS + wave * (NPL * 1024);
+    const int kt = j >> 4, krow = j & 15;
+    const int vq = (j >> 2) & 3, e = j & 3;
+    xhalf* vs = vstage + wave * (NPL * 2 * 64 * 4);  // [plane][d tile][slot 64][4 keys of this row tile]
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        xh4 h, l;
+        split2(ak[t], h, l, amax);
+        xhalf* pk = kblk + (kt * 64 + kq * 16 + krow) * 8 + t * 4;
+        st8_wt(pk, h);
+        if (NPL == 2) st8_wt(pk + 1024, l);
+        split2(av[t], h, l, amax);
+        xhalf* ps = vs + ((t * 64) + vq * 16 + kq * 4) * 4 + e;
+        ps[0] = h.x; ps[4] = h.y; ps[8] = h.z; ps[12] = h.w;
+        if (NPL == 2) {
+            ps += 2 * 64 * 4;
+            ps[0] = l.x; ps[4] = l.y; ps[8] = l.z; ps[12] = l.w;
+        }
+    }
+    // (one wave: LDS operations complete in issue order; the fence below only stops the compiler from moving the reads up)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    const int half_off = ((tok0 >> 4) & 1) * 4;
+#pragma unroll
+    for (int pl = 0; pl < NPL; ++pl)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const xh4 v = *reinterpret_cast<const xh4*>(vs + ((pl * 2 + t) * 64 + lane) * 4);
+            st8_wt(vblk + pl * 1024 + (t * 64 + lane) * 8 + half_off, v);
+        }
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// T: [16][LDT] fp32 (LDS), P1: one plane buffer, vstage: 4 x NPL x 2 KB / 2 (LDS).  On exit `u` holds the unit `nxt`.
+template <class R>
+__device__ __forceinline__ void kv_helper_x(const float* __restrict__ W, const uint32_t (&kvf)[3], const uint32_t (&bkvf)[3],
+                                            const float* __restrict__ x_mid_tile, float* T, xhalf* P1, xhalf* vstage, xhalf* __restrict__ Kmat,
+                                            xhalf* __restrict__ VT, size_t ls, int tok0, unsigned int* __restrict__ flags, unsigned int token,
+                                            int tid, WUnitX& u, const WNextX& nxt, R&& amax) {
+    const int wave = wave_of(tid), lane = tid & 63;
+    const int kq = lane >> 4, m = lane & 15;
+    wloadx(u, wstdx(W, kvf[1], W + bkvf[1], wave), lane);
+    load_tile(T, LDT, x_mid_tile, TM, tid);
+    __syncthreads();
+    normalize_planes(T, LDT, P1, tid);
+    __syncthreads();
+    const xhalf* b1 = P1 + m * LDP + kq * 8;
+    WUnitX u2;
+#pragma unroll
+    for (int l = 1; l < 3; ++l) {
+        f32x4 ak[2] = {u.b[0], u.b[1]};
+        wmmax_pf(ak[0], ak[1], u, b1, PLANE, u2, wnextx(W, kvf[l], W + bkvf[l], 8 + 2 * wave, 8 + 2 * wave + 1), lane);
+        f32x4 av[2] = {u2.b[0], u2.b[1]};
+        wmmax_pf(av[0], av[1], u2, b1, PLANE, u, l < 2 ? wstdx(W, kvf[2], W + bkvf[2], wave) : nxt, lane);
+        kv_store_wt_x(Kmat + 2 * l * ls, VT + 2 * l * ls, tok0, wave, lane, ak, av, vstage, amax);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (this also waits for the next unit: the helper is not on the critical path)
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(flags + (l - 1), token, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// consumer side: wait until every row tile of the instance has raised its flag of `layer` (1 or 2) for this step.  The helpers are
+// dispatched in front of the tile workgroups (blockIdx.z = 0) and wait for nothing, so the wait is bounded; the bound only turns a
+// broken assumption into a reported error (RolloutP::sync_err -> tb_check_status) instead of a hang.
+__device__ __forceinline__ void kv_wait_x(const unsigned int* __restrict__ inst_flags, int n_rt, int layer, unsigned int token, int tid,
+                                          unsigned int* __restrict__ sync_err) {
+    if (tid < n_rt) {
+        const unsigned int* f = inst_flags + tid * 2 + (layer - 1);
+        int spins = 0;
+        while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != token) {
+            __builtin_amdgcn_s_sleep(8);
+            if (++spins > (1 << 18)) {
+                *sync_err = 1u;
+                break;
+            }
+        }
+    }
+    __syncthreads();
+    asm volatile("" ::: "memory");
 }
 
 }  // namespace TB_XNS

@@ -129,11 +129,15 @@ struct RolloutP {
     float* dest_geo;              // [N,a_pad,20,4] destination polyline nodes: px, py, unit dir x, unit dir y
     int* dest_flag;               // [N,a_pad] bit0: lane-type destination, bit1: road-edge destination
     long long* prof;              // [n_blocks][32] stage time stamps (only written by -DTB_PROFILE builds)
-    // GRU helper workgroups (tb_device_xdl.hpp: gru_hh_helper): when a launch has at most 128 tiles, a second workgroup per tile
-    // (blockIdx.z = 1, on a CU the launch leaves idle) computes b_hh + W_hh h of the three GRU layers from the previous step's hidden
-    // state and hands it to the tile's own workgroup through L2.  nullptr: every workgroup computes it itself.
+    // Helper workgroups (tb_device_xdl.hpp: kv_helper_x, gru_hh_helper): when a launch has at most 128 tiles, a second workgroup per
+    // tile (blockIdx.z = 0: dispatched first, on a CU the launch would leave idle) computes what depends only on data of the PREVIOUS
+    // launch -- the interaction K / V of layers 1, 2 from x_mid, then W_hh h of the three GRU layers from the hidden state -- and hands
+    // it to the tile workgroups (blockIdx.z = 1) through L2.  nullptr: the tile workgroups compute everything themselves.
     float* gh;                    // [N * tiles][3 layers][3 gates][4 waves][2 tiles][64 lanes][4]
     unsigned int* gh_flag;        // [N * tiles]  = step + 1 once the tile's gh of that step is complete (zeroed per rollout)
+    unsigned int* kv_flag;        // [N * tiles][2] = step + 1 once the tile's K / V of layer 1 / 2 of that step are stored
+    unsigned int* sync_err;       // one sticky word of the context: a tile workgroup gave up waiting for a helper (tb_check_status)
+    int dbg_helper_delay;         // test knob (env TB_DEBUG_HELPER_DELAY, clock64 ticks): the helpers start late, the hand-off runs uneven
     // outputs
     float* preds;                 // [N,A,S,4]
     uint8_t* o_valid;

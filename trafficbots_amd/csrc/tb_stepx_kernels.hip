@@ -156,11 +156,28 @@ __global__ __launch_bounds__(NTHREADS) void k_step_x(RolloutP p, int t, int do_c
     // staggered start of the key walks of the row tiles of one instance (attention_prefetch_x)
     const int n_rt = gridDim.x;
     const int tile_id = n * n_rt + rt;
-    if (!PRE && blockIdx.z == 1) {
-        // ---- GRU helper of tile (n, rt): b_hh + W_hh h_{t-1} for the three layers, handed to the tile's workgroup (blockIdx.z = 0)
+    const bool helpers = !PRE && gridDim.z == 2;
+    if (helpers && blockIdx.z == 0) {
+        // ---- helper of tile (n, rt) (RolloutP::gh): interaction K / V of layers 1, 2 of THIS step from the stored x_mid, then
+        // W_hh h_{t-1} of the three GRU layers; handed to the tile workgroups (blockIdx.z = 1) through L2
+        WUnitX uh;
+        RangeMax hmax;
+        if (p.dbg_helper_delay > 0) {  // (test knob: a late helper; the tile workgroups must wait, not read early)
+            const long long t0 = clock64();
+            while (clock64() - t0 < p.dbg_helper_delay) __builtin_amdgcn_s_sleep(32);
+        }
+        {
+            const size_t ls = (size_t)p.a_pad * H;
+            xhalf* K0 = reinterpret_cast<xhalf*>(p.kin + ((size_t)n * 3) * ls);
+            xhalf* V0 = reinterpret_cast<xhalf*>(p.vtin + ((size_t)n * 3) * ls);
+            kv_helper_x(W, px.inter_kvf, px.inter_bkvf, p.x_mid + base_row * H, X, PD, reinterpret_cast<xhalf*>(Hs), K0, V0, ls, row0,
+                        p.kv_flag + (size_t)tile_id * 2, (unsigned int)t + 1u, tid, uh, wnextx(W, px.gru[0].whh, nullptr, 2 * wave, 2 * wave + 1),
+                        hmax);
+        }
         gru_hh_helper(W, px.gru, p.hidden + (((size_t)0 * p.n_inst + n) * p.a_pad + row0) * H,
                       p.hidden + (((size_t)1 * p.n_inst + n) * p.a_pad + row0) * H, p.hidden + (((size_t)2 * p.n_inst + n) * p.a_pad + row0) * H,
-                      p.gh + (size_t)tile_id * GH_TILE_FLOATS, p.gh_flag + tile_id, (unsigned int)t + 1u, PA, tid);
+                      p.gh + (size_t)tile_id * GH_TILE_FLOATS, p.gh_flag + tile_id, (unsigned int)t + 1u, PA, tid, uh, true);
+        range_flush(hmax);
         return;
     }
 
@@ -250,8 +267,10 @@ __global__ __launch_bounds__(NTHREADS) void k_step_x(RolloutP p, int t, int do_c
             const xhalf* V0 = reinterpret_cast<const xhalf*>(p.vtin + ((size_t)n * 3) * ls);
             xattn_layer_x<true, true>(W, pw.inter[0], px.inter[0], X, PA, PB, K0, V0, kvd, nk_a, ks_a, row0, rowvalid, novalid_s, tid, u,
                                 xlayer_first_x(W, pw.inter[1], px.inter[1], wave), LN + 0 * 768, nullptr, amax);
+            if (helpers) kv_wait_x(p.kv_flag + (size_t)n * n_rt * 2, n_rt, 1, (unsigned int)t + 1u, tid, p.sync_err);
             xattn_layer_x<true, true>(W, pw.inter[1], px.inter[1], X, PA, PB, K0 + 2 * ls, V0 + 2 * ls, kvd, nk_a, ks_a, row0, rowvalid, novalid_s, tid,
                                 u, xlayer_first_x(W, pw.inter[2], px.inter[2], wave), LN + 1 * 768, nullptr, amax);
+            if (helpers) kv_wait_x(p.kv_flag + (size_t)n * n_rt * 2, n_rt, 2, (unsigned int)t + 1u, tid, p.sync_err);
             xattn_layer_x<true, true>(W, pw.inter[2], px.inter[2], X, PA, PB, K0 + 4 * ls, V0 + 4 * ls, kvd, nk_a, ks_a, row0, rowvalid,
                                 novalid_s, tid, u, gru_first_x(W, pw.gru[0], px.gru[0], wave), LN + 2 * 768, nullptr, amax);
         }
@@ -429,7 +448,9 @@ __global__ __launch_bounds__(NTHREADS) void k_step_x(RolloutP p, int t, int do_c
         xhalf* K0 = reinterpret_cast<xhalf*>((PRE ? p.kin_pre + 3 * zslice : p.kin_w) + ((size_t)n * 3) * ls);
         xhalf* V0 = reinterpret_cast<xhalf*>((PRE ? p.vtin_pre + 3 * zslice : p.vtin_w) + ((size_t)n * 3) * ls);
         // (the last unit request points at a valid unit that nobody consumes: the launch ends here)
-        kv_project_shared_x(W, px.inter_kvf, px.inter_bkvf, X, PA, K0, V0, ls, row0, TM, tid, u, wstdx(W, px.inter_kvf[0], W + px.inter_bkvf[0], wave), amax);
+        // (layers 1, 2 are left to the helper workgroups of the NEXT launch when this rollout runs with them)
+        kv_project_shared_x(W, px.inter_kvf, px.inter_bkvf, X, PA, K0, V0, ls, row0, TM, tid, u, wstdx(W, px.inter_kvf[0], W + px.inter_bkvf[0], wave), amax,
+                            (!PRE && p.kv_flag) ? 1 : 3);
     }
     TB_STAMP(11);
     range_flush(amax);
