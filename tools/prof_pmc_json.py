@@ -3,10 +3,11 @@ launch of the step kernel, medians over the launches of the short profiled run.
 
 Normalisations (checked against each other on this kernel, see `checks`):
   * FETCH_SIZE / WRITE_SIZE are KiB; FETCH_SIZE x 2 on gfx950 for wide coalesced reads (MI355X_MICROARCH.md, HBM section);
-  * SQ_WAVE_CYCLES counts resident waves in units of FOUR clocks: 4 x SQ_WAVE_CYCLES / waves = the launch's length in clocks
-    (matches kernel-trace duration x ~2.3 GHz);
-  * SQ_VALU_MFMA_BUSY_CYCLES is a plain clock count summed over SIMDs: / (SIMDs with a wave x launch clocks) = the fraction of the
-    launch during which a busy SIMD's matrix pipe executes (matches the instruction count: MFMAs per wave x 16 clocks)."""
+  * SQ_WAVE_CYCLES counts resident waves in units of FOUR clocks (round 1's launches, 512 waves for the whole launch:
+    4 x SQ_WAVE_CYCLES / 512 = kernel-trace duration x ~2.3 GHz); SQ_BUSY_CYCLES is summed over the 32 shader engines
+    (/ 32 = the same launch length);
+  * SQ_VALU_MFMA_BUSY_CYCLES is a plain clock count summed over SIMDs: / (SIMD clocks that hold a wave) = the fraction of the
+    occupied SIMD time during which the matrix pipe executes (matches the instruction count: MFMAs per wave x 16 clocks)."""
 import csv
 import glob
 import json
@@ -40,21 +41,24 @@ for prec in ("fp32", "bf16"):
     m = {k: statistics.median(v) for k, v in cnt.items()}
     rec = {"kernel": f"tb::{'xh' if prec == 'fp32' else 'xb'}::{kern}", "launches_profiled": len(dur),
            "avg_fused_launch_us_kernel_trace": (sum(fused) / len(fused)) if fused else None, "counters_median_per_launch": m}
-    n_wg = 128  # B = 32 scenes x 4 row tiles
-    n_waves, n_simd_busy = n_wg * 4, n_wg * 4
     if "FETCH_SIZE" in m:
         rec["fetch_bytes_per_launch"] = m["FETCH_SIZE"] * 1024 * 2
     if "WRITE_SIZE" in m:
         rec["write_bytes_per_launch"] = m["WRITE_SIZE"] * 1024
-    if "SQ_WAVE_CYCLES" in m and "SQ_VALU_MFMA_BUSY_CYCLES" in m:
-        clocks = 4.0 * m["SQ_WAVE_CYCLES"] / n_waves
-        rec["launch_clocks_from_SQ_WAVE_CYCLES"] = clocks
-        rec["mfma_busy"] = m["SQ_VALU_MFMA_BUSY_CYCLES"] / (n_simd_busy * clocks)
+    if "SQ_WAVE_CYCLES" in m and "SQ_VALU_MFMA_BUSY_CYCLES" in m and "SQ_BUSY_CYCLES" in m:
+        # the launch holds 128 tile workgroups for its whole length and 128 helper workgroups for ~1/5 of it (RolloutP::gh): the
+        # launch's length in clocks comes from SQ_BUSY_CYCLES (summed over the 32 shader engines), the occupied SIMD time from
+        # SQ_WAVE_CYCLES (one wave per SIMD, units of four clocks)
+        clocks = m["SQ_BUSY_CYCLES"] / 32.0
+        rec["launch_clocks_from_SQ_BUSY_CYCLES"] = clocks
+        rec["mfma_busy"] = m["SQ_VALU_MFMA_BUSY_CYCLES"] / (4.0 * m["SQ_WAVE_CYCLES"])
         rec["mfma_busy_chip_wide"] = m["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024 * clocks)
-        rec["mfma_busy_how"] = ("SQ_VALU_MFMA_BUSY_CYCLES / (512 SIMDs that hold a wave x launch clocks), launch clocks = 4 x SQ_WAVE_CYCLES / "
-                                "512 waves; chip-wide = / 1024 SIMDs; rocprofv3 --pmc pass of tools/gpu_pmc_step.sh")
+        rec["mfma_busy_how"] = ("SQ_VALU_MFMA_BUSY_CYCLES (plain clocks, summed over SIMDs) / (4 x SQ_WAVE_CYCLES) = share of the SIMD time "
+                                "that holds a wave (one wave per SIMD) in which the matrix pipe executes; chip-wide = / (1024 SIMDs x launch "
+                                "clocks), launch clocks = SQ_BUSY_CYCLES / 32 shader engines; rocprofv3 --pmc pass of tools/gpu_pmc_step.sh")
         if rec["avg_fused_launch_us_kernel_trace"]:
-            rec["checks"] = {"clock_GHz_implied": clocks / (rec["avg_fused_launch_us_kernel_trace"] * 1e3)}
+            rec["checks"] = {"clock_GHz_implied": clocks / (rec["avg_fused_launch_us_kernel_trace"] * 1e3),
+                             "simd_occupancy": 4.0 * m["SQ_WAVE_CYCLES"] / (1024 * clocks)}
     if "TCC_HIT_sum" in m and "TCC_MISS_sum" in m:
         rec["l2_hit_rate"] = m["TCC_HIT_sum"] / (m["TCC_HIT_sum"] + m["TCC_MISS_sum"])
     if "TCP_TCC_READ_REQ_sum" in m:

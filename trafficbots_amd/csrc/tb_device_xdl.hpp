@@ -41,6 +41,7 @@ constexpr int NPL = 2;              // planes per operand
 #endif
 typedef xhalf xh8 __attribute__((ext_vector_type(8)));
 typedef xhalf xh4 __attribute__((ext_vector_type(4)));
+typedef xhalf xh2 __attribute__((ext_vector_type(2)));
 
 constexpr int LDP = 136;            // fp16 per plane row for 128-wide inputs (272 B: 16 rows x b128 reads hit 64 distinct banks)
 constexpr int PLANE = TM * LDP;     // fp16 per plane
@@ -100,6 +101,21 @@ __device__ __forceinline__ void split2(f32x4 v, xh4& h, xh4& l, R&& amax = R{}) 
     if (CHECK) range_note(amax, v);
     h = xh4{(xhalf)v.x, (xhalf)v.y, (xhalf)v.z, (xhalf)v.w};
     if (NPL == 2) {
+#ifndef TB_XDL_BF16
+        // the rounded values are read back from the PACKED halves (one v_cvt_pk_f16_f32 per pair, then v_cvt_f32_f16 on word 0 / word 1):
+        // without the opaque copy the compiler converts every value a second time on its own (v_cvt_f16_f32) for the round trip
+        unsigned int w0, w1;
+        {
+            const xh2 a = xh2{h.x, h.y}, b = xh2{h.z, h.w};
+            __builtin_memcpy(&w0, &a, 4);
+            __builtin_memcpy(&w1, &b, 4);
+            asm("" : "+v"(w0), "+v"(w1));
+            xh2 a2, b2;
+            __builtin_memcpy(&a2, &w0, 4);
+            __builtin_memcpy(&b2, &w1, 4);
+            h = xh4{a2.x, a2.y, b2.x, b2.y};
+        }
+#endif
         const f32x4 r = (v - f32x4{(float)h.x, (float)h.y, (float)h.z, (float)h.w}) * splat(SPLIT_SCALE);
         l = xh4{(xhalf)r.x, (xhalf)r.y, (xhalf)r.z, (xhalf)r.w};
     } else {
