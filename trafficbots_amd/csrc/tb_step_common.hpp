@@ -267,6 +267,91 @@ __device__ __forceinline__ void step_epilogue(const RolloutP& p, int t, int n, i
 // agent's dynamics (uniform inside the group, free on a SIMD), the 20 destination nodes are split over the lanes and
 // OR-reduced with a ballot, lane 0 of the group writes.  All global loads are issued up front (clamped indices where the
 // reference reads nothing), so the stage pays one memory round trip instead of a chain of dependent ones.
+// ---- inputs of the epilogue (teacher-forcing source, sticky flags, map boundary, action log-std) and of the A half's attribute
+// stage (agent size) that do not depend on the step's own work: requested in the launch prologue's burst by threads 16 .. 48 and
+// parked in the LDS regions those stages only write later (attr: the epilogue's per-agent record, ench: sizes + tile constants),
+// so neither stage opens with a dependent round trip to memory.  (k_step_x; the fp32-MFMA twin keeps its own loads.)
+struct EpiRegs {
+    f32x4 hst, hax, sz, bd;
+    float ls[6];
+    int flags;
+};
+constexpr int EPI_FLAG_KILLED = 1, EPI_FLAG_OUTSIDE = 2, EPI_FLAG_DREACHED = 4, EPI_FLAG_OVR = 8, EPI_FLAG_GTV = 16;
+constexpr int EPI_ENCH_SIZE = 0, EPI_ENCH_BD = 48, EPI_ENCH_LS = 52;  // offsets (floats) inside StepSmall::ench
+
+struct TfSource {
+    const uint8_t* mask;
+    const uint8_t* gtv;
+    const float* state;
+    const float* vel;
+    const float* acc;
+    const float* yr;
+    bool in_hist;
+    size_t hi;
+};
+// teacher-forcing source of step t: step t of the per-scene history arrays, or the caller's per-instance arrays of a
+// tb_rollout_step_ex call (wave-uniform select of base pointers and index)
+__device__ __forceinline__ TfSource tf_source(const RolloutP& p, int t, int n, int b, int rowc) {
+    TfSource f;
+    const bool per_call = p.ovr_mask != nullptr;
+    f.in_hist = per_call || t < p.n_hist;
+    f.hi = per_call ? (size_t)n * p.n_agent + rowc : ((size_t)b * p.n_hist + min(t, p.n_hist - 1)) * p.n_agent + rowc;
+    f.mask = per_call ? p.ovr_mask : p.tf_mask;
+    f.gtv = per_call ? (p.ovr_gt_valid ? p.ovr_gt_valid : nullptr) : p.hist_valid;
+    f.state = per_call ? p.ovr_state : p.hist_state;
+    f.vel = per_call ? p.ovr_vel : p.hist_vel;
+    f.acc = per_call ? p.ovr_acc : p.hist_acc;
+    f.yr = per_call ? p.ovr_yaw_rate : p.hist_yaw_rate;
+    return f;
+}
+
+// threads 16 .. 31: the epilogue record of agent tid - 16; threads 32 .. 47: the size of agent tid - 32; thread 48: tile constants
+__device__ __forceinline__ void epi_issue(const RolloutP& p, int t, int n, int b, int row0, int n_real, int tid, bool do_c, EpiRegs& e) {
+    e.flags = 0;
+    e.hst = e.hax = e.sz = e.bd = splat(0.f);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) e.ls[i] = 0.f;
+    if (do_c && tid >= 16 && tid < 32) {
+        const int a = tid - 16, row = row0 + a, rowc = min(row, p.n_agent - 1);
+        const size_t si = (size_t)n * p.a_pad + row;
+        const TfSource f = tf_source(p, t, n, b, rowc);
+        const uint8_t k0 = p.killed[si], o0 = p.outside[si], d0 = p.dest_reached[si], m0 = f.mask[f.hi], g0 = f.gtv ? f.gtv[f.hi] : (uint8_t)0;
+        e.hst = ldg4(f.state + f.hi * 4);
+        e.hax = f32x4{f.vel[f.hi * 2], f.vel[f.hi * 2 + 1], f.acc[f.hi], f.yr[f.hi]};
+        e.flags = (k0 ? EPI_FLAG_KILLED : 0) | (o0 ? EPI_FLAG_OUTSIDE : 0) | (d0 ? EPI_FLAG_DREACHED : 0) | (m0 ? EPI_FLAG_OVR : 0) |
+                  (g0 ? EPI_FLAG_GTV : 0);
+    } else if (tid >= 32 && tid < 48) {
+        const int a = tid - 32;
+        if (a < n_real) {
+            const float* sp = p.agent_size + ((size_t)b * p.n_agent + row0 + a) * 3;
+            e.sz = f32x4{sp[0], sp[1], sp[2], 0.f};
+        }
+    } else if (do_c && tid == 48) {
+        e.bd = ldg4(p.map_boundary + (size_t)b * 4);
+#pragma unroll
+        for (int ty = 0; ty < 3; ++ty) {
+            e.ls[ty * 2] = p.W[p.pw.head_log_std[ty]];
+            e.ls[ty * 2 + 1] = p.W[p.pw.head_log_std[ty] + 1];
+        }
+    }
+}
+__device__ __forceinline__ void epi_commit(int tid, bool do_c, const EpiRegs& e, const StepSmall& sm) {
+    if (do_c && tid >= 16 && tid < 32) {
+        float* r = sm.attr + (tid - 16) * 16;
+        st4(r, e.hst);
+        st4(r + 4, e.hax);
+        reinterpret_cast<int*>(r)[8] = e.flags;
+    } else if (tid >= 32 && tid < 48) {
+        float* r = sm.ench + EPI_ENCH_SIZE + (tid - 32) * 3;
+        r[0] = e.sz.x; r[1] = e.sz.y; r[2] = e.sz.z;
+    } else if (do_c && tid == 48) {
+        st4(sm.ench + EPI_ENCH_BD, e.bd);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) sm.ench[EPI_ENCH_LS + i] = e.ls[i];
+    }
+}
+
+template <bool PREF = false>
 __device__ __forceinline__ void step_epilogue16(const RolloutP& p, int t, int n, int b, int row0, int n_real, int tid,
                                                 const StepSmall& sm, const float* DG) {
     const PolicyW& pw = p.pw;
@@ -278,23 +363,27 @@ __device__ __forceinline__ void step_epilogue16(const RolloutP& p, int t, int n,
     const int row = row0 + a;
     const int rowc = min(row, p.n_agent - 1);
     const size_t si = (size_t)n * p.a_pad + row;
-    // teacher-forcing source of this step: step t of the per-scene history arrays, or the caller's per-instance arrays of a
-    // tb_rollout_step_ex call (wave-uniform select of base pointers and index)
-    const bool per_call = p.ovr_mask != nullptr;
-    const bool in_hist = per_call || t < p.n_hist;
-    const size_t hi = per_call ? (size_t)n * p.n_agent + rowc : ((size_t)b * p.n_hist + min(t, p.n_hist - 1)) * p.n_agent + rowc;
-    const uint8_t* src_mask = per_call ? p.ovr_mask : p.tf_mask;
-    const uint8_t* src_gtv = per_call ? (p.ovr_gt_valid ? p.ovr_gt_valid : nullptr) : p.hist_valid;
-    const float* src_state = per_call ? p.ovr_state : p.hist_state;
-    const float* src_vel = per_call ? p.ovr_vel : p.hist_vel;
-    const float* src_acc = per_call ? p.ovr_acc : p.hist_acc;
-    const float* src_yr = per_call ? p.ovr_yaw_rate : p.hist_yaw_rate;
-    // ---- loads
-    const uint8_t killed0 = p.killed[si], outside0 = p.outside[si], dreached0 = p.dest_reached[si];
-    const uint8_t ovr0 = src_mask[hi], gtv0 = src_gtv ? src_gtv[hi] : (uint8_t)0;
-    const f32x4 hst = ldg4(src_state + hi * 4);
-    const f32x4 hax = f32x4{src_vel[hi * 2], src_vel[hi * 2 + 1], src_acc[hi], src_yr[hi]};
-    const f32x4 bd = ldg4(p.map_boundary + (size_t)b * 4);
+    const TfSource tf = tf_source(p, t, n, b, rowc);
+    const bool in_hist = tf.in_hist;
+    // ---- loads (PREF: the launch prologue fetched them, epi_issue / epi_commit)
+    uint8_t killed0, outside0, dreached0, ovr0, gtv0;
+    f32x4 hst, hax, bd;
+    if (PREF) {
+        const float* r = sm.attr + a * 16;
+        const int fl = reinterpret_cast<const int*>(r)[8];
+        killed0 = (fl & EPI_FLAG_KILLED) != 0; outside0 = (fl & EPI_FLAG_OUTSIDE) != 0; dreached0 = (fl & EPI_FLAG_DREACHED) != 0;
+        ovr0 = (fl & EPI_FLAG_OVR) != 0; gtv0 = (fl & EPI_FLAG_GTV) != 0;
+        hst = lds4(r);
+        hax = lds4(r + 4);
+        bd = lds4(sm.ench + EPI_ENCH_BD);
+    } else {
+        const size_t hi = tf.hi;
+        killed0 = p.killed[si]; outside0 = p.outside[si]; dreached0 = p.dest_reached[si];
+        ovr0 = tf.mask[hi]; gtv0 = tf.gtv ? tf.gtv[hi] : (uint8_t)0;
+        hst = ldg4(tf.state + hi * 4);
+        hax = f32x4{tf.vel[hi * 2], tf.vel[hi * 2 + 1], tf.acc[hi], tf.yr[hi]};
+        bd = ldg4(p.map_boundary + (size_t)b * 4);
+    }
     const int ty = rtype[a];
     const bool valid_old = rowvalid[a] != 0;
     const bool have = valid_old && ty >= 0;
@@ -322,7 +411,7 @@ __device__ __forceinline__ void step_epilogue16(const RolloutP& p, int t, int n,
     float alp = 0.f;
     if (valid_old) {
         for (int d = 0; d < 2; ++d) {
-            const float ls = (ty >= 0) ? W[pw.head_log_std[ty] + d] : 0.f;
+            const float ls = (ty >= 0) ? (PREF ? sm.ench[EPI_ENCH_LS + ty * 2 + d] : W[pw.head_log_std[ty] + d]) : 0.f;
             alp += -logf(expf(ls)) - 0.9189385332046727f;
         }
     }
@@ -550,7 +639,7 @@ __device__ __forceinline__ void encw_commit(int tid, const EncWRegs& r, float* E
 // NT = threads of the workgroup: 256, or 512 (k_step_x8) where waves 4-7 only take part in the barriers
 template <int NT = 256>
 __device__ __forceinline__ void step_encode_inputs_lds(const RolloutP& p, int b, int row0, int n_real, int tid, const StepSmall& sm,
-                                                       const float* ENCW, float* X) {
+                                                       const float* ENCW, float* X, bool size_in_lds = false) {
     const bool act = NT == 256 || tid < 256;
     float* attr = sm.attr; float* ench = sm.ench; const RowSt* rst = sm.rst; const uint8_t* rowvalid = sm.rowvalid;
     const int* rtype = sm.rtype;
@@ -560,7 +649,10 @@ __device__ __forceinline__ void step_encode_inputs_lds(const RolloutP& p, int b,
         float* a = attr + tid * 16;
         const int ty = rtype[tid];
         f32x4 sz = splat(0.f);
-        if (tid < n_real) {
+        if (size_in_lds) {  // (epi_commit; zero for rows past n_real)
+            const float* s = ench + EPI_ENCH_SIZE + tid * 3;
+            sz = f32x4{s[0], s[1], s[2], 0.f};
+        } else if (tid < n_real) {
             const float* s = p.agent_size + ((size_t)b * p.n_agent + row) * 3;
             sz = f32x4{s[0], s[1], s[2], 0.f};
         }

@@ -200,6 +200,7 @@ __global__ __launch_bounds__(NTHREADS) void k_step_x(RolloutP p, int t, int do_c
     uint8_t rs_v = 0, rs_g = 0, vb[4] = {0, 0, 0, 0};
     CInputs<NTHREADS> cin;
     EncWRegs encw;
+    EpiRegs epi;
     TB_SCHED_FENCE();
     wloadx(u, do_c ? xlayer_first_x(W, pw.inter[0], px.inter[0], wave) : xlayer_first_x(W, pw.as2pl[0], px.as2pl[0], wave), lane);
     if (tid < TM) {
@@ -229,8 +230,10 @@ __global__ __launch_bounds__(NTHREADS) void k_step_x(RolloutP p, int t, int do_c
     for (int sl = 0; sl < 9; ++sl)
         if (tid < 192) lnv[sl] = ldg4(W + lnbase[sl] + tid * 4);
     if (do_a) encw_issue(pw, W, tid, encw);
+    if (!PRE) epi_issue(p, t, n, b, row0, n_real, tid, do_c != 0, epi);
     TB_SCHED_FENCE();
     if (do_a) encw_commit(tid, encw, ENCW);
+    if (!PRE) epi_commit(tid, do_c != 0, epi, sm);
     if (tid < TM) {
         rtype[tid] = rs_ty;
         rst[tid].st[0] = rs_st.x; rst[tid].st[1] = rs_st.y; rst[tid].st[2] = rs_st.z; rst[tid].st[3] = rs_st.w;
@@ -339,6 +342,21 @@ __global__ __launch_bounds__(NTHREADS) void k_step_x(RolloutP p, int t, int do_c
         // (the GRU hidden copies are dead by now), then ONE reduction stage for the 128 -> 2 Linear of each row's own type
         tile_to_planes(X, LDT, PA, tid, amax);
         if (tid < 32) ubuf[tid] = 0.f;
+        // the second Linear's 16 weights of this thread's (row, output) pair are requested here, in front of the first Linears
+        // (row types and validity are known since the prologue): the reduction stage then starts without a round trip to L2
+        const int hp_pair = tid >> 3, hp_sub = tid & 7, hp_r = hp_pair >> 1, hp_o = hp_pair & 1;
+        const int hp_ty = rtype[hp_r];
+        const int hp_tyc = hp_ty < 0 ? 0 : hp_ty;
+        f32x4 hw[4];
+        float hb2;
+        {
+            const uint32_t w2o = hp_tyc == 0 ? pw.head_w2[0] : (hp_tyc == 1 ? pw.head_w2[1] : pw.head_w2[2]);
+            const uint32_t b2o = hp_tyc == 0 ? pw.head_b2[0] : (hp_tyc == 1 ? pw.head_b2[1] : pw.head_b2[2]);
+            const float* w2 = W + w2o + hp_o * H + hp_sub * 16;
+#pragma unroll
+            for (int k4 = 0; k4 < 4; ++k4) hw[k4] = ldg4(w2 + 4 * k4);
+            hb2 = W[b2o + hp_o];
+        }
         __syncthreads();
 #pragma unroll
         for (int ty = 0; ty < 3; ++ty) {
@@ -354,30 +372,27 @@ __global__ __launch_bounds__(NTHREADS) void k_step_x(RolloutP p, int t, int do_c
         __syncthreads();
         {
             // Linear(128 -> 2): 32 (row, output) pairs x 8 lanes, 16 k each, quad + half-row DPP reduction
-            const int pair = tid >> 3, sub = tid & 7, r = pair >> 1, o = pair & 1;
-            const int ty = rtype[r];
+            const int pair = hp_pair, sub = hp_sub, r = hp_r;
+            const int ty = hp_ty;
             const bool use = ty >= 0 && rowvalid[r];
-            const int tyc = ty < 0 ? 0 : ty;
+            const int tyc = hp_tyc;
             const float* hb = tyc == 0 ? Hs : (tyc == 1 ? H1 : H2);
-            const uint32_t w2o = tyc == 0 ? pw.head_w2[0] : (tyc == 1 ? pw.head_w2[1] : pw.head_w2[2]);
-            const uint32_t b2o = tyc == 0 ? pw.head_b2[0] : (tyc == 1 ? pw.head_b2[1] : pw.head_b2[2]);
-            const float* w2 = W + w2o + o * H + sub * 16;
             const float* xs = hb + r * LDT + sub * 16;
             float sacc = 0.f;
 #pragma unroll
             for (int k4 = 0; k4 < 4; ++k4) {
-                const f32x4 a4 = lds4(xs + 4 * k4), w4 = ldg4(w2 + 4 * k4);
+                const f32x4 a4 = lds4(xs + 4 * k4), w4 = hw[k4];
                 sacc = fmaf(a4.x, w4.x, sacc); sacc = fmaf(a4.y, w4.y, sacc);
                 sacc = fmaf(a4.z, w4.z, sacc); sacc = fmaf(a4.w, w4.w, sacc);
             }
             sacc += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sacc), 0xB1, 0xf, 0xf, true));
             sacc += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sacc), 0x4E, 0xf, 0xf, true));
             sacc += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, sacc), 0x141, 0xf, 0xf, true));
-            if (sub == 0 && use) ubuf[pair] = sacc + W[b2o + o];
+            if (sub == 0 && use) ubuf[pair] = sacc + hb2;
         }
         __syncthreads();
         TB_STAMP(6);
-        step_epilogue16(p, t, n, b, row0, n_real, tid, sm, DG);
+        step_epilogue16<true>(p, t, n, b, row0, n_real, tid, sm, DG);
         __syncthreads();
     } else {
 #pragma unroll
@@ -394,7 +409,7 @@ __global__ __launch_bounds__(NTHREADS) void k_step_x(RolloutP p, int t, int do_c
     // =================================== A(t+1) ===================================
     const int t1 = t + 1;
     TB_STAMP(30);
-    step_encode_inputs_lds(p, b, row0, n_real, tid, sm, ENCW, X);
+    step_encode_inputs_lds(p, b, row0, n_real, tid, sm, ENCW, X, !PRE);
     if (t1 == p.tap_step && p.tap_agent_feature)
         for (int k = 0; k < (PRE ? p.k_rep : 1); ++k)  // (the batched launch runs once per scene: same feature for its K futures)
             store_tile(p.tap_agent_feature + ((size_t)(n + k) * p.n_agent + row0) * H, X, LDT, n_real, tid);
