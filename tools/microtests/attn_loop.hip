@@ -55,7 +55,8 @@ __global__ __launch_bounds__(NT) void k_attn(const xhalf* __restrict__ Kall, con
             if (VAR == 0) attention_prefetch_x(pre, K0, V0, kb, n_key_pad, kstart, wave, lane);
             bool nov;
             if (VAR == 0) nov = attention_head_x<false>(q, pre, K0, V0, kb, n_key_pad, kstart, wave, lane, -1, o, un, nx);
-            else nov = attention_head_var<VAR>(q, pre, K0, V0, kb, n_key_pad, kstart, wave, lane, o, un, nx);
+            else if (VAR == 4) nov = attention_head_dual(q, K0, V0, kb, n_key_pad, kstart, wave, lane, o, un, nx);
+            else nov = attention_head_var<VAR == 4 ? 1 : VAR>(q, pre, K0, V0, kb, n_key_pad, kstart, wave, lane, o, un, nx);
             const long long t1 = clock64();
             t_total += t1 - t0;
             acc[0] += o[0] + splat(nov ? 1.f : 0.f) + un.w[0][0][0][0] * 0.f;
@@ -107,7 +108,7 @@ int main(int argc, char** argv) {
     const int reps = argc > 1 ? atoi(argv[1]) : 20;
     struct Cfg {
         int n_rt, n_group, keys, layers;
-    } cfgs[] = {{4, 32, 256, 3}, {8, 32, 1024, 3}, {4, 64, 256, 3}, {4, 32, 64, 3}};
+    } cfgs[] = {{4, 32, 256, 3}, {8, 32, 1024, 3}, {4, 32, 128, 3}};
     for (const Cfg& c : cfgs) {
         const size_t ls = (size_t)c.keys * H;
         const size_t nk = (size_t)c.n_group * c.layers * NPL * ls;
@@ -146,6 +147,7 @@ int main(int argc, char** argv) {
         run<0>("v0 attention_head_x (tb_device_xdl.hpp)", c.n_rt, c.n_group, c.keys, c.layers, reps, K, V, kb, wd, out, cyc, &ref);
         run<1>("v1 64 keys per iteration", c.n_rt, c.n_group, c.keys, c.layers, reps, K, V, kb, wd, out, cyc, &ref);
         run<3>("v3 v1 + rescale only when the max moved", c.n_rt, c.n_group, c.keys, c.layers, reps, K, V, kb, wd, out, cyc, &ref);
+        run<4>("v4 two softmax chains per wave", c.n_rt, c.n_group, c.keys, c.layers, reps, K, V, kb, wd, out, cyc, &ref);
         run<0, 512>("v0, 8 waves: 2 per head, half the keys each", c.n_rt, c.n_group, c.keys, c.layers, reps, K, V, kb, wd, out, cyc, nullptr);
         run<1, 512>("v1, 8 waves: 2 per head, half the keys each", c.n_rt, c.n_group, c.keys, c.layers, reps, K, V, kb, wd, out, cyc, nullptr);
         run<0>("v0, every group reads group 0's K/V (L2)", c.n_rt, c.n_group, c.keys, c.layers, reps, K, V, kb, wd, out, cyc, nullptr, 1);

@@ -156,5 +156,111 @@ __device__ __forceinline__ bool attention_head_var(const f32x4 (&q)[2], AttnPreX
     return novalid;
 }
 
+
+// ---- VAR 4: TWO independent online-softmax chains per wave (chain c walks blocks c * nblk/2 ...), interleaved in one instruction
+// stream and merged at the end: the instruction-level twin of two waves per SIMD.  nblk must be even and >= 4.
+__device__ __forceinline__ bool attention_head_dual(const f32x4 (&q)[2], const xhalf* __restrict__ Kh, const xhalf* __restrict__ Vh,
+                                                    const float* __restrict__ keybias, int n_key_pad, int kstart, int head, int lane,
+                                                    f32x4 (&o)[2], WUnitX& un, const WNextX& nx) {
+    const int kq = lane >> 4;
+    const xhalf* kbase = Kh + head * (NPL * 1024) + lane * 8;
+    const xhalf* vbase = Vh + head * (NPL * 1024) + lane * 8;
+    const float* bbase = keybias + kq * 4;
+    xh8 qh, ql;
+    split8(q[0], q[1], qh, ql);
+    const int nblk = n_key_pad >> 5, nh = nblk >> 1;
+    f32x4 oh[2][2], oc[2][2];
+    KFragX kn[2];
+    VFragX vc[2];
+    float run_max[2], run_sum[2], new_max[2], alpha[2], sv[2][8];
+    int kc[2], k1[2], k2[2];
+    TB_SCHED_FENCE();
+    {
+        KFragX k0[2];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            kc[c] = kwrap(kstart + c * nh * 32, n_key_pad);
+            k1[c] = kwrap(kc[c] + 32, n_key_pad);
+            k2[c] = kwrap(k1[c] + 32, n_key_pad);
+            k_load_x(k0[c], kbase, bbase, kc[c]);
+            v_load_x(vc[c], vbase, kc[c]);
+            k_load_x(kn[c], kbase, bbase, k1[c]);
+            oh[c][0] = oh[c][1] = oc[c][0] = oc[c][1] = splat(0.f);
+            run_max[c] = -INFINITY;
+            run_sum[c] = 0.f;
+        }
+        TB_SCHED_FENCE();
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            f32x4 s[2], cc[2];
+            attn_qk_x(k0[c], qh, ql, s, cc);
+            attn_stats_x<false>(s, cc, k0[c].kb, 0, -1, run_max[c], sv[c], new_max[c], alpha[c]);
+        }
+    }
+    const int i_issue = nh >= 2 ? nh - 2 : 0;
+    for (int i = 0; i < nh; ++i) {
+        int kn1[2], kld[2];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            kn1[c] = (i + 1 < nh) ? k1[c] : kc[c];
+            kld[c] = (i + 2 < nh) ? k2[c] : kc[c];
+        }
+        TB_SCHED_FENCE();
+        f32x4 ts[2][2], tc[2][2], nb[2][2];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            attn_qk_x(kn[c], qh, ql, ts[c], tc[c]);
+            nb[c][0] = kn[c].kb[0];
+            nb[c][1] = kn[c].kb[1];
+        }
+        TB_SCHED_FENCE();
+        xh8 ph[2], pl[2];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            k_load_x(kn[c], kbase, bbase, kld[c]);
+            float p[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) p[r] = exp2_neg(sv[c][r] - new_max[c]);
+            run_sum[c] = run_sum[c] * alpha[c] + (((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7])));
+            run_max[c] = new_max[c];
+            split8<false>(f32x4{p[0], p[1], p[2], p[3]}, f32x4{p[4], p[5], p[6], p[7]}, ph[c], pl[c]);
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+                oh[c][dt] *= splat(alpha[c]);
+                oc[c][dt] *= splat(alpha[c]);
+            }
+        }
+        if (i == i_issue) wloadx(un, nx, lane);
+        TB_SCHED_FENCE();
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+                if (NPL == 2) oc[c][dt] = mfma_h(vc[c].va[dt][0], pl[c], oc[c][dt]);
+                oh[c][dt] = mfma_h(vc[c].va[dt][0], ph[c], oh[c][dt]);
+                if (NPL == 2) oc[c][dt] = mfma_h(vc[c].va[dt][P1], ph[c], oc[c][dt]);
+            }
+        TB_SCHED_FENCE();
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            v_load_x(vc[c], vbase, kn1[c]);
+            attn_stats_x<false>(ts[c], tc[c], nb[c], 0, -1, run_max[c], sv[c], new_max[c], alpha[c]);
+            kc[c] = k1[c];
+            k1[c] = k2[c];
+            k2[c] = kwrap(k2[c] + 32, n_key_pad);
+        }
+        TB_SCHED_FENCE();
+    }
+    const float m = fmaxf(run_max[0], run_max[1]);
+    const float f0 = exp2_neg(run_max[0] - m), f1 = exp2_neg(run_max[1] - m);
+    const float rs = rows_sum(run_sum[0] * f0 + run_sum[1] * f1);
+    const bool novalid = !(rs > 0.f);
+    const float inv = novalid ? 0.f : 1.0f / rs;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+        o[dt] = ((oh[0][dt] + oc[0][dt] * splat(SPLIT_INV)) * splat(f0) + (oh[1][dt] + oc[1][dt] * splat(SPLIT_INV)) * splat(f1)) * splat(inv);
+    return novalid;
+}
+
 }  // namespace TB_XNS
 }  // namespace tb
