@@ -1134,9 +1134,14 @@ __device__ __forceinline__ void kv_helper_x(const float* __restrict__ W, const u
 // consumer side: wait until every row tile of the instance has raised its flag of `layer` (1 or 2) for this step.  The helpers are
 // dispatched in front of the tile workgroups (blockIdx.z = 0) and wait for nothing, so the wait is bounded; the bound only turns a
 // broken assumption into a reported error (RolloutP::sync_err -> tb_check_status) instead of a hang.
+// kv_peek_x requests the flags one layer early (the value rides in a register through that layer); kv_wait_x polls only if the
+// early value was not the token yet, so on the common path the wait is a compare and a barrier, not a round trip to L2.
+__device__ __forceinline__ unsigned int kv_peek_x(const unsigned int* __restrict__ inst_flags, int n_rt, int layer, int tid) {
+    return tid < n_rt ? __hip_atomic_load(inst_flags + tid * 2 + (layer - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+}
 __device__ __forceinline__ void kv_wait_x(const unsigned int* __restrict__ inst_flags, int n_rt, int layer, unsigned int token, int tid,
-                                          unsigned int* __restrict__ sync_err) {
-    if (tid < n_rt) {
+                                          unsigned int* __restrict__ sync_err, unsigned int seen) {
+    if (tid < n_rt && seen != token) {
         const unsigned int* f = inst_flags + tid * 2 + (layer - 1);
         int spins = 0;
         while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != token) {

@@ -263,17 +263,27 @@ __global__ __launch_bounds__(NTHREADS) void k_step_x(RolloutP p, int t, int do_c
         if (bypass) wloadx(u, gru_first_x(W, pw.gru[0], px.gru[0], wave), lane);
         __syncthreads();
         TB_STAMP(1);
+        unsigned int gh_seen = 0u;  // the GRU helper's flag, requested one interaction layer early (thread 0)
         if (!bypass) {
             const float* kvd = p.vbias + (size_t)n * p.a_pad;
             const size_t ls = (size_t)p.a_pad * H;
             const xhalf* K0 = reinterpret_cast<const xhalf*>(p.kin + ((size_t)n * 3) * ls);
             const xhalf* V0 = reinterpret_cast<const xhalf*>(p.vtin + ((size_t)n * 3) * ls);
+            const unsigned int* kvf = p.kv_flag + (size_t)n * n_rt * 2;
+            const unsigned int tok = (unsigned int)t + 1u;
+            unsigned int seen = helpers ? kv_peek_x(kvf, n_rt, 1, tid) : 0u;
             xattn_layer_x<true, true>(W, pw.inter[0], px.inter[0], X, PA, PB, K0, V0, kvd, nk_a, ks_a, row0, rowvalid, novalid_s, tid, u,
                                 xlayer_first_x(W, pw.inter[1], px.inter[1], wave), LN + 0 * 768, nullptr, amax);
-            if (helpers) kv_wait_x(p.kv_flag + (size_t)n * n_rt * 2, n_rt, 1, (unsigned int)t + 1u, tid, p.sync_err);
+            if (helpers) {
+                kv_wait_x(kvf, n_rt, 1, tok, tid, p.sync_err, seen);
+                seen = kv_peek_x(kvf, n_rt, 2, tid);
+            }
             xattn_layer_x<true, true>(W, pw.inter[1], px.inter[1], X, PA, PB, K0 + 2 * ls, V0 + 2 * ls, kvd, nk_a, ks_a, row0, rowvalid, novalid_s, tid,
                                 u, xlayer_first_x(W, pw.inter[2], px.inter[2], wave), LN + 1 * 768, nullptr, amax);
-            if (helpers) kv_wait_x(p.kv_flag + (size_t)n * n_rt * 2, n_rt, 2, (unsigned int)t + 1u, tid, p.sync_err);
+            if (helpers) {
+                kv_wait_x(kvf, n_rt, 2, tok, tid, p.sync_err, seen);
+                if (tid == 0) gh_seen = __hip_atomic_load(p.gh_flag + tile_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
             xattn_layer_x<true, true>(W, pw.inter[2], px.inter[2], X, PA, PB, K0 + 4 * ls, V0 + 4 * ls, kvd, nk_a, ks_a, row0, rowvalid,
                                 novalid_s, tid, u, gru_first_x(W, pw.gru[0], px.gru[0], wave), LN + 2 * 768, nullptr, amax);
         }
@@ -290,6 +300,7 @@ __global__ __launch_bounds__(NTHREADS) void k_step_x(RolloutP p, int t, int do_c
                 int got = 0;
                 if (p.gh_flag) {
                     const unsigned int tok = (unsigned int)t + 1u;
+                    got = gh_seen == tok;
                     for (int i = 0; i < 4 && !got; ++i) {
                         got = __hip_atomic_load(p.gh_flag + tile_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == tok;
                         if (!got) __builtin_amdgcn_s_sleep(32);
