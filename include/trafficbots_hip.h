@@ -128,6 +128,11 @@ typedef struct tb_rollout_io {
      * the steps up to W + 1 does not depend on the rollout: it is run as one batched launch that fills the chip.  Results are
      * bit-identical to W = 0, which is always allowed. */
     int32_t warm_start_steps;
+    /* optional (NULL = deterministic actions): standard-normal draws for `deterministic_action=False` (Dynamics.update,
+     * dynamics.py:77 -> MyDist.sample -> Normal.rsample, distributions.py:18-38): step s samples the unbounded action as
+     * mean + action_eps[:, :, s] * exp(log_std) and action_log_probs becomes Normal.log_prob of the sample (summed over the two
+     * action dims).  XDL step kernels only. */
+    const float* action_eps;       /* [N,A,S,2] */
 } tb_rollout_io;
 
 /* Replaces: WaymoMotion.rollout (+ per-step WaymoMotion.forward, TrafficBots.forward, ActionHead,

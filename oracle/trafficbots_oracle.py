@@ -402,8 +402,11 @@ class Oracle:
 
     def rollout(self, inp: Dict[str, Tensor], f: Dict[str, Tensor], z: Tensor, latent_mean: Tensor, dest: Tensor,
                 goal_valid: Tensor, k: int, step_end: int, tap_steps=(), gt: Optional[Dict[str, Tensor]] = None,
-                tf_cfg_name: str = "teacher_forcing_joint_future_pred", log_std_name: str = "prior") -> Dict[str, Tensor]:
-        """`WaymoMotion.rollout` + `forward` + `Dynamics` + always-on `TrafficRuleChecker` + buffer
+                tf_cfg_name: str = "teacher_forcing_joint_future_pred", log_std_name: str = "prior",
+                action_eps: Optional[Tensor] = None) -> Dict[str, Tensor]:
+        """`action_eps` [N, A, S, 2]: `deterministic_action=False` (`dynamics.py:77`): step s samples the unbounded action as
+        mean + eps[:, :, s] * exp(log_std) (`Normal.rsample`) and scores it with `Normal.log_prob` summed over the two dims.
+        `WaymoMotion.rollout` + `forward` + `Dynamics` + always-on `TrafficRuleChecker` + buffer
         (`waymo_motion.py:205-354,108-203`, `dynamics.py:50-167,187-228`,
         `traffic_rule_checker.py:77-98,101-119,364-410`), driven as `joint_future_pred` does
         (`waymo_motion.py:516-562`): every scene tensor repeated K times (instance n = b*K + k)."""
@@ -485,7 +488,14 @@ class Oracle:
                 taps[f"tap{t}/policy_feature"] = x.clone()
                 taps[f"tap{t}/hidden"] = h.clone()
             u = self.action_mean(x, valid, a_type)
-            alp = torch.full_like(state[:, :, 0], act_std_logp).masked_fill(~valid, 0)
+            if action_eps is None:
+                alp = torch.full_like(state[:, :, 0], act_std_logp).masked_fill(~valid, 0)
+            else:  # action_head.py:81-87: per-type log_std under (type & valid), 0 elsewhere; distributions.py:49
+                tmask = a_type & valid.unsqueeze(-1)
+                ls = sum(self.w[f"action_head.log_std.{i}"].to(d)[None, None, :] * tmask[:, :, [i]].to(d) for i in range(3))
+                dist = torch.distributions.Independent(torch.distributions.Normal(u, ls.exp()), 1)
+                u = u + _t(action_eps, d)[:, :, t - self.cfg["time_step_sim_start"]] * ls.exp()
+                alp = dist.log_prob(u).masked_fill(~valid, 0)
             act = torch.tanh(u)
             act = torch.stack([act[..., 0] * max_acc, act[..., 1] * max_yr], -1)
             act = act.masked_fill(~(has_type & valid).unsqueeze(-1), 0)
@@ -552,7 +562,8 @@ class Oracle:
 
     # ------------------------------------------------------------------ end to end
     def joint_future_pred(self, batch: Dict[str, np.ndarray], k: int, eps: Optional[np.ndarray], step_end: int,
-                          dest_override: Optional[np.ndarray] = None, tap_steps=(), use_gt: bool = False) -> Dict[str, Tensor]:
+                          dest_override: Optional[np.ndarray] = None, tap_steps=(), use_gt: bool = False,
+                          action_eps: Optional[np.ndarray] = None) -> Dict[str, Tensor]:
         """Prologue of `WaymoMotion.test_step` + `joint_future_pred` (`waymo_motion.py:902-933,478-572`).
         `eps` [N,A,16] are the standard-normal draws of the latent sample; `dest_override` [N,A]
         replaces the destination sample (instances k>0 are multinomial draws in the reference)."""
@@ -579,7 +590,7 @@ class Oracle:
         # validation_step leaves batch["agent/*"] = the 91-step ground truth in place (waymo_motion.py:538-545), which the kill
         # rule and goal_reached then see; test_step overwrites it with the history (:925-926)
         gt = self.preprocess_gt(batch) if use_gt else None
-        res = self.rollout(inp, f, z, mean, dest, goal_valid, k, step_end, tap_steps, gt=gt)
+        res = self.rollout(inp, f, z, mean, dest, goal_valid, k, step_end, tap_steps, gt=gt, action_eps=action_eps)
         # RolloutBuffer.flatten_repeat (`buffer.py:92-123`): [N,A,S,..] -> [B,A,K,S,..]
         for key in ("preds", "valid", "override_masks", "outside_map", "outside_map_this_step", "dest_reached",
                     "dest_reached_this_step", "action_log_probs", "latent_log_probs", "goal_reached", "goal_reached_this_step"):
@@ -597,7 +608,8 @@ class Oracle:
         return res
 
     def reactive_replay(self, batch: Dict[str, np.ndarray], step_end: int, tf_cfg_name: str = "teacher_forcing_reactive_replay",
-                        eps: Optional[np.ndarray] = None, rollout_prior: bool = False) -> Dict[str, Tensor]:
+                        eps: Optional[np.ndarray] = None, rollout_prior: bool = False,
+                        action_eps: Optional[np.ndarray] = None) -> Dict[str, Tensor]:
         """First half of `WaymoMotion.validation_step` (`waymo_motion.py:574-611`): posterior and prior personalities,
         destination prediction, then the episode replayed with the posterior MEAN as personality, the ground-truth
         destination as goal and `teacher_forcing_reactive_replay` (agents keep spawning from ground truth until step 90).
@@ -613,7 +625,8 @@ class Oracle:
         # training_step (`waymo_motion.py:384-400`): a SAMPLE (mean + std * eps) of the posterior, or of the prior
         mean, log_std, which = (prior_mean, prior_log_std, "prior") if rollout_prior else (post_mean, post_log_std, "post")
         z = mean.clone() if eps is None else mean + _t(eps, self.dtype) * log_std.exp()
-        res = self.rollout(inp, f, z, mean, dest, goal_valid, 1, step_end, gt=gt, tf_cfg_name=tf_cfg_name, log_std_name=which)
+        res = self.rollout(inp, f, z, mean, dest, goal_valid, 1, step_end, gt=gt, tf_cfg_name=tf_cfg_name, log_std_name=which,
+                           action_eps=action_eps)
         res.update(post_mean=post_mean, post_log_std=post_log_std, post_valid=post_valid, prior_mean=prior_mean,
                    prior_log_std=prior_log_std, prior_valid=prior_valid, dest_logits_raw=logits, goal_valid=goal_valid,
                    gt_dest=dest, gt_valid=gt["agent_valid"], gt_state=gt["agent_state"], agent_role=gt["agent_role"],

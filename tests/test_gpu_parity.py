@@ -38,6 +38,7 @@ REPORT = {}
 
 # simulation step up to which |hip - reference fp32| <= 1e-4 m is asserted flat (None = the whole horizon)
 FLAT_1E4_UNTIL = {"c1_plumbing": None, "small_k1": None, "degenerate": None, "val_small": None, "val_alt_losses": None,
+                  "stoch_actions": None,
                   "masks_k3": 60, "headline_2": 60, "headline_k6": 60, "val_masks": 60}
 
 
@@ -148,6 +149,40 @@ def test_against_reference_golden(name):
     rep["traj_xy_open_loop_max"] = float(per_step[:n_open].max())
     assert rep["traj_xy_open_loop_max"] <= 1e-5
     _closed_loop_check(name, preds, g, 3, rep)
+
+
+def test_sampled_actions_against_reference_golden():
+    """`deterministic_action=False` (`dynamics.py:77`; `training_deterministic_action` in the reference's config): every step samples its
+    action as mean + eps * exp(log_std) and scores it with Normal.log_prob.  Golden `stoch_actions` = the reference's
+    joint_future_pred with its rollout switched to sampled actions and the rsample draws replaced by synth.make_action_noise."""
+    from trafficbots_amd import synth
+
+    name = "stoch_actions"
+    g, meta = load_golden(name)
+    cfg, sd, batch, eps = golden_inputs(meta)
+    n = meta["n_scene"] * meta["k"]
+    n_step = meta["time_step_end"] - cfg["time_step_sim_start"] + 1
+    act = torch.from_numpy(synth.make_action_noise(meta["base_seed"] + 77, n, meta["scene"]["n_agent"], n_step)).cuda()
+    gs = torch.from_numpy(np.transpose(g["goal_sample"], (0, 2, 1)).copy())
+    wm = _engine({"time_step_end": meta["time_step_end"], "n_joint_future": meta["k"]}, sd)
+    out = wm.test_step(batch, latent_eps=torch.from_numpy(eps).cuda(), goal_sample=gs, action_eps=act)
+    torch.cuda.synchronize()
+    buf = out["rollout_buffer"]
+    rep = {"action_log_probs": float(np.abs(buf.action_log_probs.cpu().numpy() - g["action_log_probs"]).max()),
+           "latent_log_probs": float(np.abs(buf.latent_log_probs.cpu().numpy() - g["latent_log_probs"]).max())}
+    # log-prob of a sample: -(x - mu)^2 / (2 var) with std = e^-2 amplifies the rounding of x - mu by 1 / var ~ 3e3 (values reach ~ -10)
+    assert rep["action_log_probs"] <= 2e-4 and rep["latent_log_probs"] <= ONE_SHOT_TOL, rep
+    assert (buf.valid.cpu().numpy() == g["valid"]).all() and (buf.override_masks.cpu().numpy() == g["override_masks"]).all()
+    for k in ("outside_map", "outside_map_this_step", "dest_reached", "dest_reached_this_step"):
+        assert (buf.violations[k].cpu().numpy() == g[k]).all(), k
+    preds = buf.preds.cpu().numpy()
+    d = np.abs(preds - g["preds"]) * g["valid"][..., None]
+    rep["traj_xy_open_loop_max"] = float(d[..., :10, :2].max())
+    assert rep["traj_xy_open_loop_max"] <= 1e-5
+    _closed_loop_check(name, preds, g, 3, rep)
+    # and the deterministic rollout of the same inputs is a different one (the noise is really applied)
+    det = wm.test_step(batch, latent_eps=torch.from_numpy(eps).cuda(), goal_sample=gs)["rollout_buffer"].preds
+    assert float((det - buf.preds).abs().max()) > 1e-3
 
 
 @pytest.mark.parametrize("seed,scene", [
@@ -580,34 +615,38 @@ def test_validation_step_against_oracle_fresh_seed():
     _assert_closed_loop(bj.preds.cpu().numpy(), rj, rj64, "validation joint_future_pred")
 
 
-@pytest.mark.parametrize("rollout_prior", [False, True])
-def test_training_step_forward_against_oracle(rollout_prior):
+@pytest.mark.parametrize("rollout_prior,sampled_actions", [(False, False), (True, False), (False, True)])
+def test_training_step_forward_against_oracle(rollout_prior, sampled_actions):
     """Forward value of training_step (teacher_forcing_training, a SAMPLE of the posterior / prior personality, ground-truth
-    destination, TrainingMetrics.compute) against the oracles."""
+    destination, TrainingMetrics.compute) against the oracles; `sampled_actions` = the reference's
+    training_deterministic_action: false (`waymo_motion.py:398`) with explicit draws."""
     from oracle import training_oracle as TO
     from oracle.trafficbots_oracle import Oracle
     from trafficbots_amd import synth
     from trafficbots_amd.config import load_model_config
 
-    over = {"time_step_end": 60, "differentiable_reward.w_collision": 0.2}
+    over = {"time_step_end": 60, "differentiable_reward.w_collision": 0.2, "training_deterministic_action": not sampled_actions}
     scene = dict(n_agent=20, n_pl=48, n_tl=12, p_invalid_agent=0.2, p_late_spawn=0.3, p_future_spawn=0.5, p_future_exit=0.3, pos_range=60.0)
     sd = synth.make_state_dict(9800)
     batch = synth.make_val_batch(9801, 3, **scene)
     eps = synth.make_latent_noise(9802, 3, 20)
+    act = synth.make_action_noise(9803, 3, 20, 60) if sampled_actions else None
     wm = _engine(over, sd)
-    out = wm.training_step(batch, latent_eps=torch.from_numpy(eps).cuda(), rollout_prior=rollout_prior)
+    out = wm.training_step(batch, latent_eps=torch.from_numpy(eps).cuda(), rollout_prior=rollout_prior,
+                           action_eps=None if act is None else torch.from_numpy(act).cuda())
     torch.cuda.synchronize()
     cfg = load_model_config(overrides=over)
     r = Oracle(sd, cfg, dtype=torch.float32).reactive_replay(batch, 60, tf_cfg_name="teacher_forcing_training", eps=eps,
-                                                              rollout_prior=rollout_prior)
+                                                              rollout_prior=rollout_prior, action_eps=act)
     buf = out["rollout_buffer"]
     assert (buf.valid.cpu() == r["valid"]).all() and (buf.override_masks.cpu() == r["override_masks"]).all()
     assert r["override_masks"][:, :, 10:].sum() == 0  # teacher_forcing_training: nothing is forced after the warm start
     assert np.abs(buf.latent_sample.cpu().numpy() - (r["prior_mean"] if rollout_prior else r["post_mean"]).numpy()
                   - eps * float(np.exp(-1.0))).max() <= 1e-6
     r64 = Oracle(sd, cfg, dtype=torch.float64).reactive_replay(batch, 60, tf_cfg_name="teacher_forcing_training", eps=eps,
-                                                                rollout_prior=rollout_prior)
+                                                                rollout_prior=rollout_prior, action_eps=act)
     _assert_closed_loop(buf.preds.cpu().numpy(), r, r64, "training replay")
+    assert np.abs(buf.action_log_probs.cpu().numpy() - r["action_log_probs"].numpy()).max() <= (2e-4 if sampled_actions else 1e-6)
     gv, gs = r["gt_valid"][:, 1:61].transpose(1, 2), r["gt_state"][:, 1:61].transpose(1, 2)
     rew, rv = TO.differentiable_reward(buf.valid.cpu(), buf.preds.cpu(), gv, gs, r["agent_size"], cfg["differentiable_reward"])
     st = TO.training_metric_states(buf.valid.cpu(), rv, rew, buf.override_masks.cpu(), r["agent_role"], r["dest_logits_raw"], r["goal_valid"],

@@ -74,6 +74,14 @@ CASES = {
     ),
 }
 
+# `deterministic_action=False` (dynamics.py:77; the reference's training_deterministic_action switch): sampled actions, K=2,
+# late spawns / invalid agents; the per-step rsample draws are synth.make_action_noise(base_seed + 77, ...)
+CASES["stoch_actions"] = dict(
+    base_seed=8000, n_scene=2, k=2, weight_seed=8, time_step_end=50,
+    scene=dict(n_agent=12, n_pl=40, n_tl=40, p_invalid_agent=0.2, p_late_spawn=0.3, pos_range=120.0),
+    tap_steps=[], fp64=True, store_feats=False, action_noise=True,
+)
+
 CASES["rules_passive"] = dict(
     base_seed=7500, n_scene=2, k=1, weight_seed=9, time_step_end=70,
     scene=dict(n_agent=12, n_pl=60, n_tl=40, p_tl_valid=0.3, pos_range=40.0, spd_max=1.0),
@@ -111,10 +119,19 @@ def run_reference(case: dict, dtype=torch.float32, force_goal_sample=None) -> di
     import torch.distributions.normal as tdn
 
     orig_std_normal = tdn._standard_normal
+    n_step = case["time_step_end"] - cfg["time_step_sim_start"] + 1
+    act_eps = None
+    act_i = {"i": 0}
+    if case.get("action_noise"):
+        act_eps = torch.from_numpy(synth.make_action_noise(case["base_seed"] + 77, n_inst, sc["n_agent"], n_step)).to(dtype)
 
     def fake_std_normal(shape, dtype, device):
         if tuple(shape) == tuple(eps.shape):
             return eps.to(dtype)
+        if act_eps is not None and tuple(shape) == (n_inst, sc["n_agent"], 2):  # one action rsample per simulation step
+            i = act_i["i"]
+            act_i["i"] += 1
+            return act_eps[:, :, i].to(dtype)
         raise RuntimeError(f"unexpected rsample of shape {tuple(shape)}")
 
     taps = {}
@@ -174,11 +191,16 @@ def run_reference(case: dict, dtype=torch.float32, force_goal_sample=None) -> di
                     return _f.clone()
 
                 goal_pred.sample = forced_sample  # (instance attribute: joint_future_pred calls goal.sample(deterministic), :500)
+            if act_eps is not None:  # joint_future_pred calls rollout(deterministic_action=True) (waymo_motion.py:560)
+                orig_rollout = model.rollout
+                model.rollout = lambda *a_, **k_: orig_rollout(*a_, **{**k_, "deterministic_action": False})
             buf, goal_sample, goal_log_probs = model.joint_future_pred(
                 batch=batch, input_feature_dict=feats, latent=latent_prior, goal=goal_pred,
                 goal_valid=goal_valid, require_vis_dict=False,
             )
             h.remove()
+            if act_eps is not None:
+                assert act_i["i"] == n_step, (act_i["i"], n_step)
             if case.get("rule_flags"):
                 TrafficRuleChecker.check = orig_check
                 out["check_valid"] = torch.stack(check_in["valid"], 2)  # [N,A,S]

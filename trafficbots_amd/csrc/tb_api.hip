@@ -726,6 +726,8 @@ static int rollout_setup(tb_ctx* ctx, const tb_rollout_io* io, tb::RolloutP& p) 
     p.map_pos = io->map_pos;
     p.map_dir = io->map_dir;
     p.latent_z = io->latent_sample;
+    p.action_eps = io->action_eps;
+    if (io->action_eps && ctx->step_kernel < 2) return tb_fail(ctx, "tb_rollout: action_eps (sampled actions) needs the XDL step kernels");
     p.latent_mean = io->latent_mean;
     p.dest = io->dest;
     p.goal_valid0 = io->goal_valid;

@@ -87,6 +87,7 @@ struct RolloutP {
     const float* map_pos;         // [B,P,20,2]
     const float* map_dir;         // [B,P,20,2]
     // per instance inputs
+    const float* action_eps;      // [N,A,S,2] standard-normal draws of sampled actions, or nullptr (deterministic_action)
     const float* latent_z;        // [N,A,16]
     const float* latent_mean;     // [B,A,16]
     const int32_t* dest;          // [N,A]

@@ -273,7 +273,7 @@ __device__ __forceinline__ void step_epilogue(const RolloutP& p, int t, int n, i
 // so neither stage opens with a dependent round trip to memory.  (k_step_x; the fp32-MFMA twin keeps its own loads.)
 struct EpiRegs {
     f32x4 hst, hax, sz, bd;
-    float ls[6];
+    float ls[6], ae[2];
     int flags;
 };
 constexpr int EPI_FLAG_KILLED = 1, EPI_FLAG_OUTSIDE = 2, EPI_FLAG_DREACHED = 4, EPI_FLAG_OVR = 8, EPI_FLAG_GTV = 16;
@@ -308,6 +308,7 @@ __device__ __forceinline__ TfSource tf_source(const RolloutP& p, int t, int n, i
 // threads 16 .. 31: the epilogue record of agent tid - 16; threads 32 .. 47: the size of agent tid - 32; thread 48: tile constants
 __device__ __forceinline__ void epi_issue(const RolloutP& p, int t, int n, int b, int row0, int n_real, int tid, bool do_c, EpiRegs& e) {
     e.flags = 0;
+    e.ae[0] = e.ae[1] = 0.f;
     e.hst = e.hax = e.sz = e.bd = splat(0.f);
 #pragma unroll
     for (int i = 0; i < 6; ++i) e.ls[i] = 0.f;
@@ -318,6 +319,11 @@ __device__ __forceinline__ void epi_issue(const RolloutP& p, int t, int n, int b
         const uint8_t k0 = p.killed[si], o0 = p.outside[si], d0 = p.dest_reached[si], m0 = f.mask[f.hi], g0 = f.gtv ? f.gtv[f.hi] : (uint8_t)0;
         e.hst = ldg4(f.state + f.hi * 4);
         e.hax = f32x4{f.vel[f.hi * 2], f.vel[f.hi * 2 + 1], f.acc[f.hi], f.yr[f.hi]};
+        if (p.action_eps) {
+            const float* ap = p.action_eps + (((size_t)n * p.n_agent + rowc) * p.n_step_out + (t - p.step_start)) * 2;
+            e.ae[0] = ap[0];
+            e.ae[1] = ap[1];
+        }
         e.flags = (k0 ? EPI_FLAG_KILLED : 0) | (o0 ? EPI_FLAG_OUTSIDE : 0) | (d0 ? EPI_FLAG_DREACHED : 0) | (m0 ? EPI_FLAG_OVR : 0) |
                   (g0 ? EPI_FLAG_GTV : 0);
     } else if (tid >= 32 && tid < 48) {
@@ -341,6 +347,8 @@ __device__ __forceinline__ void epi_commit(int tid, bool do_c, const EpiRegs& e,
         st4(r, e.hst);
         st4(r + 4, e.hax);
         reinterpret_cast<int*>(r)[8] = e.flags;
+        r[9] = e.ae[0];
+        r[10] = e.ae[1];
     } else if (tid >= 32 && tid < 48) {
         float* r = sm.ench + EPI_ENCH_SIZE + (tid - 32) * 3;
         r[0] = e.sz.x; r[1] = e.sz.y; r[2] = e.sz.z;
@@ -368,8 +376,11 @@ __device__ __forceinline__ void step_epilogue16(const RolloutP& p, int t, int n,
     // ---- loads (PREF: the launch prologue fetched them, epi_issue / epi_commit)
     uint8_t killed0, outside0, dreached0, ovr0, gtv0;
     f32x4 hst, hax, bd;
+    float ae0 = 0.f, ae1 = 0.f;  // standard-normal draws of a sampled action (RolloutP::action_eps)
     if (PREF) {
         const float* r = sm.attr + a * 16;
+        ae0 = r[9];
+        ae1 = r[10];
         const int fl = reinterpret_cast<const int*>(r)[8];
         killed0 = (fl & EPI_FLAG_KILLED) != 0; outside0 = (fl & EPI_FLAG_OUTSIDE) != 0; dreached0 = (fl & EPI_FLAG_DREACHED) != 0;
         ovr0 = (fl & EPI_FLAG_OVR) != 0; gtv0 = (fl & EPI_FLAG_GTV) != 0;
@@ -383,6 +394,11 @@ __device__ __forceinline__ void step_epilogue16(const RolloutP& p, int t, int n,
         hst = ldg4(tf.state + hi * 4);
         hax = f32x4{tf.vel[hi * 2], tf.vel[hi * 2 + 1], tf.acc[hi], tf.yr[hi]};
         bd = ldg4(p.map_boundary + (size_t)b * 4);
+        if (p.action_eps) {
+            const float* ap = p.action_eps + (((size_t)n * p.n_agent + rowc) * p.n_step_out + (t - p.step_start)) * 2;
+            ae0 = ap[0];
+            ae1 = ap[1];
+        }
     }
     const int ty = rtype[a];
     const bool valid_old = rowvalid[a] != 0;
@@ -392,10 +408,19 @@ __device__ __forceinline__ void step_epilogue16(const RolloutP& p, int t, int n,
     const bool gv0 = gvalid[a] != 0;
     const int dfl = dflag[a];
     // ---- Dynamics.update + MultiPathPP (dynamics.py:74-119,194-228); tanh-bounded action, midpoint unicycle
+    // action_dist.sample(deterministic) (dynamics.py:77): the mean, or mean + eps * exp(log_std) (Normal.rsample) with the per-type
+    // log_std under (type & valid), 0 elsewhere (action_head.py:81-87)
+    const bool sampled = p.action_eps != nullptr;
+    float lsd[2], us[2] = {u0, u1};
+#pragma unroll
+    for (int d = 0; d < 2; ++d) {
+        lsd[d] = (valid_old && ty >= 0) ? (PREF ? sm.ench[EPI_ENCH_LS + ty * 2 + d] : W[pw.head_log_std[ty] + d]) : 0.f;
+        if (sampled) us[d] = fadd_(us[d], fmul_(d == 0 ? ae0 : ae1, expf(lsd[d])));
+    }
     float acc_ = 0.f, yr_ = 0.f;
     if (have) {
-        acc_ = fmul_(tanhf(u0), pw.max_acc[ty]);
-        yr_ = fmul_(tanhf(u1), pw.max_yaw_rate[ty]);
+        acc_ = fmul_(tanhf(us[0]), pw.max_acc[ty]);
+        yr_ = fmul_(tanhf(us[1]), pw.max_yaw_rate[ty]);
     }
     const float half_dt = 0.5f * pw.dt;
     const float v_t = fadd_(st.w, fmul_(half_dt, acc_));
@@ -408,11 +433,19 @@ __device__ __forceinline__ void step_epilogue16(const RolloutP& p, int t, int n,
     pred.z = fadd_(st.z, fmul_(pw.dt, yr_));
     pred.w = fadd_(st.w, fmul_(pw.dt, acc_));
     if (!have) pred = splat(0.f);
+    // action_dist.log_prob(sample), masked to 0 for invalid agents (dynamics.py:80; torch Normal.log_prob:
+    // -((x - mu)^2) / (2 var) - log(scale) - log(sqrt(2 pi)), summed over the two dims)
     float alp = 0.f;
     if (valid_old) {
+#pragma unroll
         for (int d = 0; d < 2; ++d) {
-            const float ls = (ty >= 0) ? (PREF ? sm.ench[EPI_ENCH_LS + ty * 2 + d] : W[pw.head_log_std[ty] + d]) : 0.f;
-            alp += -logf(expf(ls)) - 0.9189385332046727f;
+            const float sc = expf(lsd[d]);
+            if (sampled) {
+                const float dv = fadd_(us[d], -(d == 0 ? u0 : u1));
+                alp += fadd_(fadd_(-fmul_(dv, dv) / fmul_(2.f, fmul_(sc, sc)), -logf(sc)), -0.9189385332046727f);
+            } else {
+                alp += -logf(sc) - 0.9189385332046727f;
+            }
         }
     }
     // ---- teacher forcing / spawn (dynamics.py:132-149)

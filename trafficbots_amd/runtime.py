@@ -342,8 +342,10 @@ class HipEngine:
         gt: Optional[Dict[str, Tensor]] = None,
         latent_posterior: bool = False,
         warm_start_steps: int = 0,
+        action_eps: Optional[Tensor] = None,
     ) -> Dict[str, Tensor]:
-        """Closed-loop rollout of N = B*K instances (instance n uses scene n // K).  Returns the
+        """`action_eps` [N, A, S, 2] standard normal: sampled actions (`deterministic_action=False`, `dynamics.py:77`); None = the mean.
+        Closed-loop rollout of N = B*K instances (instance n uses scene n // K).  Returns the
         `RolloutBuffer` fields as [N, A, S, ...] tensors (`buffer.py:72-90`).  With `stepwise=True` only the
         prologue runs (`tb_rollout_begin`); advance with :meth:`rollout_step`, inspect with :meth:`rollout_state`.
         `gt` (:func:`gt_from_batch`) makes the full ground truth the source of initial state / overrides / the kill rule, as
@@ -431,8 +433,14 @@ class HipEngine:
         io.tap_agent_feature = hip.ptr(out.get("tap_agent_feature"), hip.c_f32p)
         io.check_state = hip.ptr(out.get("check_state"), hip.c_f32p)
         io.check_valid = hip.ptr(out.get("check_valid"), hip.c_u8p)
+        if action_eps is not None:
+            if stepwise:
+                raise NotImplementedError("sampled actions are built for the fused rollout, not for the stepwise API")
+            action_eps = action_eps.to(device=dev, dtype=f32).contiguous()
+            assert action_eps.shape == (n, a, n_step, 2), (tuple(action_eps.shape), (n, a, n_step, 2))
+        io.action_eps = hip.ptr(action_eps, hip.c_f32p)
         # keep the borrowed inputs alive until the stream work is done
-        out["_keepalive"] = (latent_sample, latent_mean, dest, goal_valid, mask_teacher_forcing, s, feats, gt)
+        out["_keepalive"] = (latent_sample, latent_mean, dest, goal_valid, mask_teacher_forcing, s, feats, gt, action_eps)
         if stepwise:
             self._check(self.lib.tb_rollout_begin(self._ctx, C.byref(io), self._stream()), "tb_rollout_begin")
             self._step_out = out

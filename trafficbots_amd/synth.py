@@ -339,6 +339,13 @@ def make_latent_noise(seed: int, n_inst: int, n_agent: int, latent_dim: int = 16
     return RawStream(seed).normal((n_inst, n_agent, latent_dim)).astype(np.float32)
 
 
+def make_action_noise(seed: int, n_inst: int, n_agent: int, n_step: int) -> np.ndarray:
+    """Standard-normal draws eps[N, A, S, 2] for stochastic actions (`deterministic_action=False`: the reference draws one
+    [N, A, 2] rsample per simulation step from torch's stream, `dynamics.py:77`, `distributions.py:18-38`; goldens pass them
+    explicitly, step s of the rollout takes eps[:, :, s])."""
+    return RawStream(seed).normal((n_step, n_inst, n_agent, 2)).astype(np.float32).transpose(1, 2, 0, 3).copy()
+
+
 # --------------------------------------------------------------------------------------
 # state_dict of the reference model for the default config (SURVEY.md Appendix B), in the
 # reference's parameter naming, so a reference checkpoint's state_dict loads unchanged.

@@ -296,21 +296,32 @@ class WaymoMotion:
         latent_posterior: bool = False,
         rule_checker_tl: Optional[Dict[str, Tensor]] = None,
         warm_start_steps: int = 0,
+        action_eps: Optional[Tensor] = None,
+        generator=None,
     ) -> RolloutBuffer:
-        """`WaymoMotion.rollout` (`waymo_motion.py:205-354`).  `gt` (the scene's "gt" dict) replaces the history as
+        """`deterministic_action=False` samples every step's action (`dynamics.py:77`): the standard-normal draws are `action_eps`
+        [N, A, S, 2] (explicit, as the goldens pass them) or, when None, drawn here with `torch.randn(generator=generator)` -- the
+        reference draws them step by step from torch's global stream, which no other implementation can replay.
+        `WaymoMotion.rollout` (`waymo_motion.py:205-354`).  `gt` (the scene's "gt" dict) replaces the history as
         `features["agent_valid" / "agent_state" / ...]`, the way validation and training call it (`:457-461`); with it and
         K = 1 the per-step `DifferentiableReward` is attached to the buffer (`:320-330`).  `stepwise=True` only initialises the simulator
         (`model.init`, `dynamics.init`, goal features: `waymo_motion.py:246-266`); drive it with :meth:`forward`.  `features` is the pre-processed scene merged
         with the encoder outputs (un-repeated: K futures share scene tensors, instance n uses scene n // K);
         `latent` / `goal` / `goal_valid` are per instance [N, ...] as in the reference."""
-        if not deterministic_action:
-            raise NotImplementedError("stochastic actions (training rollouts) are outside the built path")
         if require_vis_dict:
             raise NotImplementedError("visualisation dicts (attention weights) are outside the built path")
         if latent is None:  # the reference's `self.model.init(latent, deterministic)` + rollout without re-passing them
             latent, deterministic_latent = self.model.latent, self.model.deterministic
             latent_eps = latent_eps if latent_eps is not None else getattr(self.model, "_latent_eps", None)
         per_step = gt_sdc is not None  # what-if: the SDC's trajectory is forced at every step -> the loop is driven per step
+        if deterministic_action:
+            action_eps = None
+        else:
+            if stepwise or per_step:
+                raise NotImplementedError("sampled actions are built for the fused rollout (not stepwise / gt_sdc what-if)")
+            n_inst, n_ag = goal.shape[0], goal.shape[1]
+            if action_eps is None:
+                action_eps = torch.randn(n_inst, n_ag, step_end - step_start + 1, 2, device=self.device, generator=generator)
         if step_start != self.hparams["time_step_sim_start"]:
             raise NotImplementedError("step_start must equal time_step_sim_start")
         z = latent.sample(deterministic_latent, eps=latent_eps)
@@ -329,6 +340,7 @@ class WaymoMotion:
             features, features, z, mean_scene, goal, goal_valid, k_futures, step_end,
             mask_teacher_forcing=mask_teacher_forcing.to(torch.uint8).contiguous(), tap_step=tap_step, stepwise=stepwise or per_step,
             record_check_states=want_checks, gt=gt, latent_posterior=latent_posterior, warm_start_steps=warm_start_steps,
+            action_eps=action_eps,
         )
         if per_step:
             self._step_t = step_start
@@ -383,7 +395,8 @@ class WaymoMotion:
     def reactive_replay(self, batch: Dict[str, Tensor], input_feature_dict: Dict[str, Tensor], mask_teacher_forcing: Tensor,
                         latent: DiagGaussian, goal: Tensor, goal_valid: Tensor, deterministic_latent: bool = True,
                         deterministic_action: bool = True, require_vis_dict: bool = False, latent_eps: Optional[Tensor] = None,
-                        latent_is_posterior: bool = True, teacher_forcing_cfg: Optional[Dict] = None) -> RolloutBuffer:
+                        latent_is_posterior: bool = True, teacher_forcing_cfg: Optional[Dict] = None,
+                        action_eps: Optional[Tensor] = None, generator=None) -> RolloutBuffer:
         """`WaymoMotion.reactive_replay` (`waymo_motion.py:420-476`): the episode replayed from its ground truth (`batch` is the
         pre-processed validation scene, `batch["gt"]` its ground truth) with the given personality and goal; K = 1.  The
         personality is taken as a POSTERIOR for `latent_log_prob` (that is what validation / training pass, `:382-387,605`).
@@ -400,7 +413,7 @@ class WaymoMotion:
             deterministic_latent=deterministic_latent, deterministic_action=deterministic_action,
             step_start=self.hparams["time_step_sim_start"], step_end=self.hparams["time_step_end"], k_futures=1,
             gt=batch["gt"], latent_posterior=latent_is_posterior, require_vis_dict=require_vis_dict, rule_checker_tl=batch["gt"],
-            latent_eps=latent_eps, warm_start_steps=w,
+            latent_eps=latent_eps, warm_start_steps=w, action_eps=action_eps, generator=generator,
         )
 
     def finish_rollout(self) -> RolloutBuffer:
@@ -512,6 +525,7 @@ class WaymoMotion:
         goal_sample: Optional[Tensor] = None,
         generator=None,
         tap_step: int = -1,
+        action_eps: Optional[Tensor] = None,
     ) -> Tuple[RolloutBuffer, Tensor, Tensor]:
         """`WaymoMotion.joint_future_pred` (`waymo_motion.py:478-572`): K futures per scene, sample 0
         deterministic.  `batch` is the pre-processed scene.  The reference materialises every tensor K times
@@ -544,7 +558,8 @@ class WaymoMotion:
         mask_tf = teacher_forcing_mask(src_valid, tf.get("step_spawn_agent", 10), tf.get("step_warm_start", 10))
         buf = self.rollout(
             features, latent=latent, goal=goal_sample, goal_valid=goal_valid, mask_teacher_forcing=mask_tf,
-            deterministic_latent=deterministic, deterministic_action=True,
+            deterministic_latent=deterministic, deterministic_action=action_eps is None,  # (the reference passes True, :560)
+            action_eps=action_eps,
             step_start=self.hparams["time_step_sim_start"], step_end=self.hparams["time_step_end"],
             k_futures=k, latent_eps=latent_eps, tap_step=tap_step, gt=gt,
             warm_start_steps=self._warm_start_steps(tf, gt if gt is not None else batch),
@@ -555,9 +570,10 @@ class WaymoMotion:
         return buf, goal_sample, goal_log_probs
 
     def test_step(self, batch: Dict[str, Tensor], batch_idx: int = 0, latent_eps=None, goal_sample=None, generator=None,
-                  tap_step: int = -1) -> Dict[str, Tensor]:
+                  tap_step: int = -1, action_eps: Optional[Tensor] = None) -> Dict[str, Tensor]:
         """`WaymoMotion.test_step` (`waymo_motion.py:902-940`) up to and including `waymo_post_processing`; the submission writer
-        (`:942-949`) is out of scope.  Returns the buffer, the intermediate products and the post-processed `pred_dict`."""
+        (`:942-949`) is out of scope.  Returns the buffer, the intermediate products and the post-processed `pred_dict`.
+        `action_eps` (extension, [B*K, A, S, 2]): run the futures with SAMPLED actions instead of the reference's deterministic ones."""
         scene = self.pre_processing(batch)
         scene.pop("gt", None)  # batch["agent/*"] = batch["history/agent/*"] (waymo_motion.py:925-926)
         input_feature_dict = self.model.encode_input_features(scene)
@@ -567,7 +583,7 @@ class WaymoMotion:
         latent_mean, latent_valid = latent_prior.mean, latent_prior.valid  # (repeat_interleave_ below rebinds them)
         buf, gs, glp = self.joint_future_pred(
             scene, input_feature_dict, latent_prior, goal_pred, goal_valid, latent_eps=latent_eps, goal_sample=goal_sample,
-            generator=generator, tap_step=tap_step,
+            generator=generator, tap_step=tap_step, action_eps=action_eps,
         )
         scores = torch.exp(buf.latent_log_probs[..., 0] + glp)  # waymo_motion.py:936
         pred_dict = None
@@ -591,7 +607,8 @@ class WaymoMotion:
             self.engine.check_status()
 
     def training_step(self, batch: Dict[str, Tensor], batch_idx: int = 0, latent_eps: Optional[Tensor] = None,
-                      rollout_prior: bool = False, current_epoch: int = 0) -> Dict[str, object]:
+                      rollout_prior: bool = False, current_epoch: int = 0, action_eps: Optional[Tensor] = None,
+                      generator=None) -> Dict[str, object]:
         """Forward value of `WaymoMotion.training_step` (`waymo_motion.py:356-418`): the episode replayed under
         `teacher_forcing_training` with a SAMPLE of the posterior personality (or of the prior when `rollout_prior`, which the
         reference decides with `torch.rand(1) < p_training_rollout_prior`) and the ground-truth destination, then
@@ -600,8 +617,7 @@ class WaymoMotion:
         (the reference's eval-mode arithmetic), and there is no backward pass: this is the loss a validation of the training
         objective reports, not an optimisation step."""
         hp = self.hparams
-        if not hp.get("training_deterministic_action", True):
-            raise NotImplementedError("stochastic actions (training_deterministic_action=False) are outside the built path")
+        det_action = bool(hp.get("training_deterministic_action", True))  # False: sampled actions (`action_eps` or torch.randn)
         tf = hp["teacher_forcing_training"]
         if tf.get("step_horizon", 0) - tf.get("step_horizon_decrease_per_epoch", 0) * current_epoch > 0 or \
                 tf.get("prob_forcing_agent", 0) - tf.get("prob_forcing_agent_decrease_per_epoch", 0) * current_epoch > 0:
@@ -618,8 +634,9 @@ class WaymoMotion:
         latent = latent_prior if rollout_prior else latent_post
         mask_tf = teacher_forcing_mask(gt["agent_valid"].bool(), tf.get("step_spawn_agent", 10), tf.get("step_warm_start", 10))
         buf = self.reactive_replay(scene, input_feature_dict, mask_tf, latent, goal_gt, goal_valid,
-                                   deterministic_latent=latent_eps is None, deterministic_action=True, latent_eps=latent_eps,
-                                   latent_is_posterior=not rollout_prior, teacher_forcing_cfg=tf)
+                                   deterministic_latent=latent_eps is None, deterministic_action=det_action, latent_eps=latent_eps,
+                                   latent_is_posterior=not rollout_prior, teacher_forcing_cfg=tf, action_eps=action_eps,
+                                   generator=generator)
         gv, gs = self._gt_slices(gt, hp["time_step_sim_start"], hp["time_step_end"])
         raw = {"valid": buf.valid, "preds": buf.preds, "override_masks": buf.override_masks}
         _, _, states = self.engine.train_partials(
