@@ -251,8 +251,8 @@ int tb_encode_posterior(tb_ctx* ctx, const tb_posterior_io* io, tb_stream stream
  * (src/models/metrics/loss.py:9-32), BalancedKL forward value (:35-74) and TrainingMetrics.update
  * (src/models/metrics/training.py:62-139; group training_metrics, traffic_bots.yaml:208-219).  K = 1 (reactive_replay).
  * out[6], in this order: vae_kl_counter, vae_kl, diffbar_reward_counter, diffbar_reward, goal_loss, goal_counter -- the
- * states a multi-GPU run SUM-all-reduces; TrainingMetrics.compute() forms the ratios.  Not built: w_relevant_agent > 0 and
- * p_loss_for_irrelevant > 0.  Criteria: 0 SmoothL1Loss, 1 MSELoss, 2 L1Loss; angular_type: 0 null, 1 cast, 2 cosine, 3 vector. */
+ * states a multi-GPU run SUM-all-reduces; TrainingMetrics.compute() forms the ratios.  Not built: w_relevant_agent > 0 (the
+ * reference's own weighting there does not broadcast, training.py:124).  Criteria: 0 SmoothL1Loss, 1 MSELoss, 2 L1Loss; angular_type: 0 null, 1 cast, 2 cosine, 3 vector. */
 typedef struct tb_train_io {
     int32_t n_scene, n_agent, n_step, n_pl;
     /* differentiable_reward */
@@ -284,6 +284,10 @@ typedef struct tb_train_io {
     float* diffbar_rewards;         /* [B,A,S] */
     uint8_t* diffbar_rewards_valid; /* [B,A,S] */
     double* out;                    /* [6] device buffer */
+    /* optional, both or neither (p_loss_for_irrelevant > 0, training.py:85-89): pred_valid := (pred_valid & relevant) |
+     * irrelevant_draw, broadcast over the steps; relevant = agent_role.any(-1), irrelevant_draw = the caller's Bernoulli(p) draw */
+    const uint8_t* relevant;        /* [B,A] */
+    const uint8_t* irrelevant_draw; /* [B,A] */
 } tb_train_io;
 int tb_train_partials(tb_ctx* ctx, const tb_train_io* io, tb_stream stream);
 

@@ -103,12 +103,15 @@ def diag_gaussian_kl(q_mean: Tensor, q_log_std: Tensor, p_mean: Tensor, p_log_st
 def training_metric_states(pred_valid: Tensor, reward_valid: Tensor, reward: Tensor, override_masks: Tensor, agent_role: Tensor,
                            dest_logits: Tensor, goal_dist_valid: Tensor, gt_dest: Tensor, post_mean: Tensor,
                            post_log_std: Tensor, post_valid: Tensor, prior_mean: Tensor, prior_log_std: Tensor,
-                           prior_valid: Tensor, cfg: dict) -> Dict[str, float]:
+                           prior_valid: Tensor, cfg: dict, irrelevant_draw: Optional[Tensor] = None) -> Dict[str, float]:
     """`TrainingMetrics.update` (`training.py:62-139`) for one batch, starting from zeroed states.
     pred_valid / reward_valid / reward / override_masks: [B,A,S]; dest_logits [B,A,P] masked, un-normalised; goal_dist_valid =
-    `goal_pred.valid`; cfg = the `training_metrics` group.  The stochastic `p_loss_for_irrelevant` branch is not restated."""
-    assert cfg["p_loss_for_irrelevant"] <= 0
+    `goal_pred.valid`; cfg = the `training_metrics` group.  `irrelevant_draw` [B,A] = the Bernoulli(p_loss_for_irrelevant) draw the
+    reference takes from torch's stream (`:88`), passed explicitly."""
     pv = pred_valid.clone()
+    if cfg["p_loss_for_irrelevant"] > 0:
+        assert irrelevant_draw is not None
+        pv = (pv & agent_role.any(-1).unsqueeze(-1)) | irrelevant_draw.bool().reshape(*pv.shape[:2], 1)
     if not cfg["loss_for_teacher_forcing"]:
         pv = pv & ~override_masks
     if cfg["step_training_start"] > 0:

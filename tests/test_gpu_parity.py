@@ -38,7 +38,7 @@ REPORT = {}
 
 # simulation step up to which |hip - reference fp32| <= 1e-4 m is asserted flat (None = the whole horizon)
 FLAT_1E4_UNTIL = {"c1_plumbing": None, "small_k1": None, "degenerate": None, "val_small": None, "val_alt_losses": None,
-                  "stoch_actions": None,
+                  "stoch_actions": None, "val_irrelevant": None,
                   "masks_k3": 60, "headline_2": 60, "headline_k6": 60, "val_masks": 60}
 
 
@@ -484,7 +484,7 @@ def test_metric_partials_kernel():
 TRAIN_FIELDS = ("vae_kl_counter", "vae_kl", "diffbar_reward_counter", "diffbar_reward", "goal_loss", "goal_counter")
 
 
-@pytest.mark.parametrize("name", ["val_small", "val_masks", "val_alt_losses"])
+@pytest.mark.parametrize("name", ["val_small", "val_masks", "val_alt_losses", "val_irrelevant"])
 def test_validation_step_against_reference_golden(name):
     """SURVEY 8(f)-3 through the C ABI (tb_encode_posterior, tb_rollout driven by the 91-step ground truth, tb_train_partials,
     tb_rule_checks' goal_reached, tb_metric_partials) against what the imported reference's validation_step produced."""
@@ -495,7 +495,8 @@ def test_validation_step_against_reference_golden(name):
     over.update(meta["overrides"])
     wm = _engine(over, synth.make_state_dict(meta["weight_seed"]))
     batch = synth.make_val_batch(meta["base_seed"], meta["n_scene"], **meta["scene"])
-    out = wm.validation_step(batch)
+    irr = torch.from_numpy(g["irrelevant_draw"]).cuda() if "irrelevant_draw" in g.files else None  # (p_loss_for_irrelevant > 0)
+    out = wm.validation_step(batch, irrelevant_draw=irr)
     torch.cuda.synchronize()
     rr = out["reactive_replay"]
     buf = rr["rollout_buffer"]  # flattened [B,A,1,S,...]
@@ -540,7 +541,8 @@ def test_validation_step_against_reference_golden(name):
         raw, gv, gs, gt["agent_size"], dest_logits=out["dest_logits"], goal_valid=wm.pre_processing(batch)["agent_valid"].bool().any(1),
         gt_dest=gt["gt_dest"],
         post={"latent_mean": torch.from_numpy(g["post_mean"]).cuda(), "latent_valid": torch.from_numpy(g["post_valid"]).cuda()},
-        prior={"latent_mean": torch.from_numpy(g["prior_mean"]).cuda(), "latent_valid": torch.from_numpy(g["prior_valid"]).cuda()})
+        prior={"latent_mean": torch.from_numpy(g["prior_mean"]).cuda(), "latent_valid": torch.from_numpy(g["prior_valid"]).cuda()},
+        agent_role=gt["agent_role"], irrelevant_draw=irr)
     torch.cuda.synchronize()
     assert (rv2.bool().cpu().numpy() == g["diffbar_rewards_valid"]).all()
     assert np.allclose(rw2.cpu().numpy(), g["diffbar_rewards"], rtol=3e-6, atol=3e-6)

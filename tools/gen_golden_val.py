@@ -52,6 +52,14 @@ CASES = {
                    "training_metrics.kl_free_nats": -1, "training_metrics.step_training_start": 0},
         scene=dict(n_agent=12, n_pl=40, n_tl=40, pos_range=25.0, p_invalid_agent=0.1, p_future_exit=0.2), fp64=True,
     ),
+    # p_loss_for_irrelevant > 0 (training.py:85-89): agents without a role keep their loss terms only when a Bernoulli draw says so;
+    # the draw is fixed (synth stream) and stored, torch.bernoulli is replaced for the update call
+    "val_irrelevant": dict(
+        base_seed=14000, n_scene=3, weight_seed=8, time_step_end=60,
+        overrides={"training_metrics.p_loss_for_irrelevant": 0.4, "training_metrics.loss_for_teacher_forcing": False},
+        scene=dict(n_agent=14, n_pl=40, n_tl=40, p_invalid_agent=0.2, p_future_spawn=0.5, p_future_exit=0.3, pos_range=60.0), fp64=True,
+        irrelevant_seed=14001,
+    ),
 }
 
 TRAIN = ("vae_kl_counter", "vae_kl", "diffbar_reward_counter", "diffbar_reward", "goal_loss", "goal_counter")
@@ -111,10 +119,23 @@ def run_reference(case: dict, dtype=torch.float32) -> dict:
                 goal_reached=buf.violations["goal_reached"], dest_reached=buf.violations["dest_reached"],
                 agent_type=batch["ref/agent_type"])
             tm = model.train_metrics_reactive_replay
+            orig_bernoulli = torch.bernoulli
+            if case.get("irrelevant_seed") is not None:
+                p_irr = float(case["overrides"]["training_metrics.p_loss_for_irrelevant"])
+                draw = torch.from_numpy(
+                    (synth.RawStream(case["irrelevant_seed"]).u01((case["n_scene"], sc["n_agent"], 1)) < p_irr).astype(np.float32))
+                out["irrelevant_draw"] = draw[..., 0].bool()
+
+                def fake_bernoulli(probs, *a_, **k_):
+                    assert tuple(probs.shape) == tuple(draw.shape) and abs(float(probs.flatten()[0]) - p_irr) < 1e-6
+                    return draw.to(probs.dtype)
+
+                torch.bernoulli = fake_bernoulli
             tm.update(pred_valid=buf.valid.squeeze(2), diffbar_rewards_valid=buf.diffbar_rewards_valid.squeeze(2),
                diffbar_rewards=buf.diffbar_rewards.squeeze(2), override_masks=buf.override_masks.squeeze(2),
                agent_role=batch["ref/agent_role"], goal_valid=goal_valid, goal_pred=goal_pred, goal_gt=goal_gt,
                latent_post=latent_post, latent_prior=latent_prior)
+            torch.bernoulli = orig_bernoulli
             out.update(raw)
             out["post_mean"], out["post_valid"] = latent_post.mean.clone(), latent_post.valid.clone()
             out["prior_mean"], out["prior_valid"] = latent_prior.mean.clone(), latent_prior.valid.clone()

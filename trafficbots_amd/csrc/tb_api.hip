@@ -1030,6 +1030,8 @@ extern "C" int tb_train_partials(tb_ctx* ctx, const tb_train_io* io, tb_stream s
         io->angular_type < 0 || io->angular_type > 3)
         return tb_fail(ctx, "tb_train_partials: unknown criterion / angular_type");
     if ((io->gt_valid == nullptr) != (io->gt_states == nullptr)) return tb_fail(ctx, "tb_train_partials: gt_valid / gt_states must come together");
+    if ((io->relevant == nullptr) != (io->irrelevant_draw == nullptr))
+        return tb_fail(ctx, "tb_train_partials: relevant / irrelevant_draw must come together");
     const void* req[] = {io->pred_valid, io->pred_states, io->override_masks, io->agent_size, io->diffbar_rewards,
                          io->diffbar_rewards_valid, io->out};
     for (const void* q : req)

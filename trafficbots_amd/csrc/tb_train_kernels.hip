@@ -128,6 +128,7 @@ __global__ __launch_bounds__(256) void k_train_partials(tb_train_io io, const fl
         float r_sum = 0.f, r_cnt = 0.f;
         for (int s = 0; s < S; ++s) {
             bool pv = io.pred_valid[base + s] != 0;
+            if (io.irrelevant_draw) pv = (pv && io.relevant[row] != 0) || io.irrelevant_draw[row] != 0;  // training.py:85-89
             if (!io.loss_for_teacher_forcing) pv = pv && !io.override_masks[base + s];
             if (s < io.step_training_start) pv = false;
             any_pv |= pv;

@@ -128,6 +128,7 @@ class TbTrainIO(C.Structure):
         ("agent_size", c_f32p), ("dest_logits", c_f32p), ("goal_valid", c_u8p), ("gt_dest", c_i32p),
         ("post_mean", c_f32p), ("post_valid", c_u8p), ("prior_mean", c_f32p), ("prior_valid", c_u8p),
         ("diffbar_rewards", c_f32p), ("diffbar_rewards_valid", c_u8p), ("out", C.POINTER(C.c_double)),
+        ("relevant", c_u8p), ("irrelevant_draw", c_u8p),
     ]
 
 

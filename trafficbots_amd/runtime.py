@@ -263,16 +263,21 @@ class HipEngine:
 
     def train_partials(self, buf: Dict[str, Tensor], gt_valid: Optional[Tensor], gt_states: Optional[Tensor], agent_size: Tensor,
                        dest_logits: Optional[Tensor] = None, goal_valid: Optional[Tensor] = None, gt_dest: Optional[Tensor] = None,
-                       post: Optional[Dict[str, Tensor]] = None, prior: Optional[Dict[str, Tensor]] = None):
-        """Forward training losses of a replayed episode (`tb_train_partials`): the per-step `DifferentiableReward`
+                       post: Optional[Dict[str, Tensor]] = None, prior: Optional[Dict[str, Tensor]] = None,
+                       agent_role: Optional[Tensor] = None, irrelevant_draw: Optional[Tensor] = None, generator=None):
+        """`training_metrics.p_loss_for_irrelevant` = p > 0 (`training.py:85-89`): agents without a role lose their loss terms and a
+        Bernoulli(p) draw per agent gets them back for ALL steps; the draw is `irrelevant_draw` [B,A] (explicit, as the golden passes it)
+        or `torch.bernoulli(generator=generator)` here; `agent_role` [B,A,3] is required then.
+        Forward training losses of a replayed episode (`tb_train_partials`): the per-step `DifferentiableReward`
         (`rewards.py:33-131`, config group `differentiable_reward`) over the buffer `buf` (preds [B,A,S,4], valid,
         override_masks [B,A,S]; K = 1) against ground truth [B,A,S(,4)], and the six `TrainingMetrics` "sum" states
         (`training.py:62-139`, group `training_metrics`) as a float64 device vector in `TRAIN_FIELDS` order.
         Without destination logits / personalities only the rewards (and the two reward states) are produced.
         Returns (diffbar_rewards [B,A,S], diffbar_rewards_valid [B,A,S] uint8, states [6])."""
         rw, tm = self.cfg["differentiable_reward"], self.cfg["training_metrics"]
-        if tm["w_relevant_agent"] > 0 or tm["p_loss_for_irrelevant"] > 0:
-            raise NotImplementedError("training_metrics.w_relevant_agent / p_loss_for_irrelevant > 0 are not built")
+        if tm["w_relevant_agent"] > 0:
+            raise NotImplementedError("training_metrics.w_relevant_agent > 0 is not built (the reference's own weighting there does not "
+                                      "broadcast for n_agent != n_step, training.py:124)")
         dev, u8, f32 = self.device, torch.uint8, torch.float32
         b, a, n_step = buf["valid"].shape
         io = hip.TbTrainIO()
@@ -311,6 +316,12 @@ class HipEngine:
             gd = gt_dest.to(dev).to(torch.int32).contiguous()
             keep.append(gd)
             io.gt_dest = hip.ptr(gd, hip.c_i32p)
+        if tm["p_loss_for_irrelevant"] > 0 and (io.use_vae_kl or io.use_goal):  # (the reward-only call of rollout() has no losses to mask)
+            if agent_role is None:
+                raise ValueError("p_loss_for_irrelevant > 0 needs agent_role")
+            if irrelevant_draw is None:
+                irrelevant_draw = torch.bernoulli(torch.full((b, a), float(tm["p_loss_for_irrelevant"]), device=dev), generator=generator)
+            io.relevant, io.irrelevant_draw = c8(agent_role.bool().any(-1)), c8(irrelevant_draw.reshape(b, a).bool())
         if io.use_vae_kl:
             io.post_mean, io.post_valid = cf(post["latent_mean"]), c8(post["latent_valid"])
             io.prior_mean, io.prior_valid = cf(prior["latent_mean"]), c8(prior["latent_valid"])

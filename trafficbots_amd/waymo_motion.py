@@ -608,7 +608,7 @@ class WaymoMotion:
 
     def training_step(self, batch: Dict[str, Tensor], batch_idx: int = 0, latent_eps: Optional[Tensor] = None,
                       rollout_prior: bool = False, current_epoch: int = 0, action_eps: Optional[Tensor] = None,
-                      generator=None) -> Dict[str, object]:
+                      generator=None, irrelevant_draw: Optional[Tensor] = None) -> Dict[str, object]:
         """Forward value of `WaymoMotion.training_step` (`waymo_motion.py:356-418`): the episode replayed under
         `teacher_forcing_training` with a SAMPLE of the posterior personality (or of the prior when `rollout_prior`, which the
         reference decides with `torch.rand(1) < p_training_rollout_prior`) and the ground-truth destination, then
@@ -642,7 +642,8 @@ class WaymoMotion:
         _, _, states = self.engine.train_partials(
             raw, gv, gs, scene["agent_size"], dest_logits=self.model._enc["dest_logits"], goal_valid=goal_pred.valid, gt_dest=goal_gt,
             post={"latent_mean": latent_post.mean, "latent_valid": latent_post.valid},
-            prior={"latent_mean": latent_prior.mean, "latent_valid": latent_prior.valid})
+            prior={"latent_mean": latent_prior.mean, "latent_valid": latent_prior.valid},
+            agent_role=gt["agent_role"], irrelevant_draw=irrelevant_draw, generator=generator)
         self._check_range()
         m = TrainingMetrics("training", **hp["training_metrics"])
         m.update(states)
@@ -650,8 +651,8 @@ class WaymoMotion:
         return {"loss": out["training/loss"], "metrics_dict": out, "train_states": states, "rollout_buffer": buf,
                 "latent_post": latent_post, "latent_prior": latent_prior}
 
-    def validation_step(self, batch: Dict[str, Tensor], batch_idx: int = 0, latent_eps=None, goal_sample=None, generator=None
-                        ) -> Dict[str, object]:
+    def validation_step(self, batch: Dict[str, Tensor], batch_idx: int = 0, latent_eps=None, goal_sample=None, generator=None,
+                        irrelevant_draw: Optional[Tensor] = None) -> Dict[str, object]:
         """`WaymoMotion.validation_step` (`waymo_motion.py:574-735`) without the WOMD-metric ops, submission writers and videos:
         posterior / prior personalities and the destination prediction, `reactive_replay` (posterior mean, ground-truth
         destination, teacher_forcing_reactive_replay) with its error / traffic-rule / training metric states and post-processed
@@ -681,7 +682,8 @@ class WaymoMotion:
         _, _, train_states = self.engine.train_partials(
             raw, gv, gs, scene["agent_size"], dest_logits=self.model._enc["dest_logits"], goal_valid=goal_pred.valid, gt_dest=goal_gt,
             post={"latent_mean": latent_post.mean, "latent_valid": latent_post.valid},
-            prior={"latent_mean": prior_mean, "latent_valid": prior_valid})
+            prior={"latent_mean": prior_mean, "latent_valid": prior_valid},
+            agent_role=gt["agent_role"], irrelevant_draw=irrelevant_draw, generator=generator)
         buf.flatten_repeat(1)
         states = self.engine.metric_partials(buf.valid, buf.preds, buf.override_masks, buf.violations, scene["agent_type"],
                                              gt["agent_role"], gt_valid=gv, gt_states=gs, loss_for_teacher_forcing=False)
