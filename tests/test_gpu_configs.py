@@ -85,6 +85,39 @@ def test_config3_k6_bf16_at_batch_32():
     assert rep["scene0_fp32_vs_reference_xy_step11"] <= 1e-4
 
 
+def test_bf16_lean_carve_two_workgroups_per_cu_is_bitwise_identical(monkeypatch):
+    """With bf16 operands a launch of more than 256 tiles runs the LEAN carve of the step kernel (k_step_x<false, true>: no goal / latent
+    / LayerNorm-parameter tiles in LDS, < 80 KB and < 256 VGPRs), so that two workgroups share a CU.  It must not change a bit:
+    TB_STEP_LEAN=0 (the full carve at every size) against the default, at 288 tiles (12 scenes x 6 futures x 4 row tiles), and a
+    sub-batch that stays below the threshold (full carve) against its slice of the big batch (lean carve)."""
+    from trafficbots_amd import synth
+
+    sd = synth.make_state_dict(7)
+    batch = synth.make_batch(8600, 12, n_agent=64, n_pl=96, n_tl=20, p_invalid_agent=0.1, p_late_spawn=0.2)
+    eps = torch.from_numpy(synth.make_latent_noise(8601, 12 * 6, 64)).cuda()
+    gen = torch.Generator(device="cuda")
+    outs = {}
+    for name, flag in (("lean", "1"), ("full", "0")):
+        monkeypatch.setenv("TB_STEP_LEAN", flag)
+        wm = _wm(time_step_end=40, n_joint_future=6, operand_precision="bf16")
+        wm.load_state_dict(sd)
+        gen.manual_seed(5)
+        outs[name] = wm.test_step(batch, latent_eps=eps, generator=gen)
+    torch.cuda.synchronize()
+    a, b = outs["lean"]["rollout_buffer"], outs["full"]["rollout_buffer"]
+    assert torch.isfinite(a.preds).all()
+    assert torch.equal(a.preds, b.preds), float((a.preds - b.preds).abs().max())
+    assert torch.equal(a.valid, b.valid) and torch.equal(a.action_log_probs, b.action_log_probs)
+    # 3 scenes x 6 x 4 = 72 tiles: the full carve (with helper workgroups); same scenes, same destinations
+    monkeypatch.delenv("TB_STEP_LEAN")
+    sub = {k: v[:3] for k, v in batch.items()}
+    wm = _wm(time_step_end=40, n_joint_future=6, operand_precision="bf16")
+    wm.load_state_dict(sd)
+    gs = outs["lean"]["goal_sample"][:3].transpose(1, 2).contiguous()  # [B,A,K] -> [B,K,A]
+    c = wm.test_step(sub, latent_eps=eps[: 3 * 6], goal_sample=gs.cpu())["rollout_buffer"]
+    assert torch.equal(c.preds, a.preds[:3]), float((c.preds - a.preds[:3]).abs().max())
+
+
 @pytest.mark.parametrize("prec", ["fp32", "bf16"])
 def test_config4_stress_shape_170_steps(prec):
     """BASELINE configs[4] shape at its full horizon: A = 128, P = 1024, time_step_end = 170 (160 future steps), 4 scenes, both

@@ -93,7 +93,8 @@ struct CInputs {
     int df;
 };
 
-template <int NT>
+// NSRC = 4: without the goal / latent pre-activation tiles (the LEAN carve of k_step_x reads them where they are used)
+template <int NT, int NSRC = 6>
 __device__ __forceinline__ void c_inputs_issue(const RolloutP& p, int n, int row0, int tid, CInputs<NT>& c) {
     const size_t base_row = (size_t)n * p.a_pad + row0;
     const float* src[6] = {p.x_mid + base_row * H,
@@ -103,7 +104,7 @@ __device__ __forceinline__ void c_inputs_issue(const RolloutP& p, int n, int row
                            p.goal_pre + base_row * H,
                            p.lat_pre + base_row * H};
 #pragma unroll
-    for (int s = 0; s < 6; ++s)
+    for (int s = 0; s < NSRC; ++s)
 #pragma unroll
         for (int i = 0; i < CInputs<NT>::PER; ++i) {
             const int idx = tid + i * NT;
@@ -117,12 +118,12 @@ __device__ __forceinline__ void c_inputs_issue(const RolloutP& p, int n, int row
     c.df = tid < TM ? p.dest_flag[base_row + tid] : 0;
 }
 
-template <int NT>
+template <int NT, int NSRC = 6>
 __device__ __forceinline__ void c_inputs_commit(int tid, const CInputs<NT>& c, float* X, float* Hs, float* H1, float* H2, float* GP,
                                                 float* LP, float* DG, int* dflag) {
     float* dst[6] = {X, Hs, H1, H2, GP, LP};
 #pragma unroll
-    for (int s = 0; s < 6; ++s)
+    for (int s = 0; s < NSRC; ++s)
 #pragma unroll
         for (int i = 0; i < CInputs<NT>::PER; ++i) {
             const int idx = tid + i * NT;

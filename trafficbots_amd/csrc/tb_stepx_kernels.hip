@@ -16,14 +16,23 @@ constexpr int XO_H1 = XO_H + TM * LDT;
 constexpr int XO_H2 = XO_H1 + TM * LDT;
 constexpr int XO_GP = XO_H2 + TM * LDT;
 constexpr int XO_LP = XO_GP + TM * LDT;
-constexpr int XO_Y = XO_LP + TM * LDT;
-constexpr int XO_DG = XO_Y + TM * LDT;
+constexpr int XO_DG = XO_LP + TM * LDT;
 constexpr int XO_LN = XO_DG + TM * 80;
 constexpr int XO_SMALL = XO_LN + 9 * 768;
 constexpr int XO_ENCW = XO_SMALL + SMALL_FLOATS;  // InputPeEncoder weights + PE frequencies (transposed, step_encode_inputs_lds)
 constexpr int XO_PL = XO_ENCW + ENCW_FLOATS;    // 4 x [2][16][LDP] fp16
 constexpr int PLANES_FLOATS = PLANES_BYTES / 4;
 constexpr int STEPX_LDS_FLOATS = XO_PL + 4 * PLANES_FLOATS;
+// LEAN carve (k_step_x<., true>): no goal / latent pre-activation tiles (read from the rollout workspace where they are used) and no
+// LayerNorm parameter blocks (read from the weight arena by each LayerNorm): with one bf16 plane per operand the workgroup then needs
+// < 80 KB and < 256 VGPRs, so TWO workgroups share a CU when a launch has more tiles than the chip has CUs (K futures, 8-tile
+// instances): the weight-streaming GEMM phases of one run under the latency-bound attention / LayerNorm phases of the other.
+constexpr int XL_DG = XO_GP;
+constexpr int XL_SMALL = XL_DG + TM * 80;
+constexpr int XL_ENCW = XL_SMALL + SMALL_FLOATS;
+constexpr int XL_PL = XL_ENCW + ENCW_FLOATS;
+constexpr int STEPX_LEAN_LDS_FLOATS = XL_PL + 4 * PLANES_FLOATS;
+static_assert(XL_PL % 4 == 0, "plane buffers must be 16-byte aligned");
 static_assert(XO_PL % 4 == 0, "plane buffers must be 16-byte aligned");
 static_assert(NPL * PLANEC * 2 <= 2 * PLANES_BYTES, "concat planes must fit two plane buffers");
 static_assert(STEPX_LDS_FLOATS * 4 <= 160 * 1024, "LDS budget");
@@ -32,7 +41,7 @@ static_assert(STEPX_LDS_FLOATS * 4 <= 160 * 1024, "LDS budget");
 // u does not change during a rollout (only its mask does), so its half of the first Linear is hoisted: k_fuse_hoist_x leaves
 // PRE = W1[:, 128:256] u in the rollout workspace and the step multiplies only the x half (one weight unit instead of two).
 //   CP : planes of x ([16][LDPC] rows);  P2 : plane buffer for the hidden;  uw : in = the x half of W1 (carries b1)
-template <class R = RangeFlag>
+template <bool PRE_GLOBAL = false, class R = RangeFlag>
 __device__ __forceinline__ void fuse_latent_goal_x(const float* __restrict__ W, uint32_t w2x, uint32_t b2, float* X, xhalf* CP, xhalf* P2,
                                                    const float* PRE, const uint8_t* zvalid, const uint8_t* rowvalid, int tid, WUnitX& uw,
                                                    const WNextX& nxt, R&& amax = R{}) {
@@ -51,8 +60,13 @@ __device__ __forceinline__ void fuse_latent_goal_x(const float* __restrict__ W, 
         f32x4 acc[2] = {uw.b[0], uw.b[1]};
         wmmax_pf(acc[0], acc[1], uw, CP + m * LDPC + kq * 8, PLANEC, u2, wstdx(W, w2x, W + b2, wave), lane);
         if (zv) {
-            acc[0] += lds4(cptr(const_cast<float*>(PRE), LDT, ta, lane));
-            acc[1] += lds4(cptr(const_cast<float*>(PRE), LDT, tb_, lane));
+            if (PRE_GLOBAL) {  // PRE = the tile's rows in the rollout workspace ([16][128] fp32)
+                acc[0] += ldg4(PRE + (size_t)m * H + ta * 16 + kq * 4);
+                acc[1] += ldg4(PRE + (size_t)m * H + tb_ * 16 + kq * 4);
+            } else {
+                acc[0] += lds4(cptr(const_cast<float*>(PRE), LDT, ta, lane));
+                acc[1] += lds4(cptr(const_cast<float*>(PRE), LDT, tb_, lane));
+            }
         }
         planes_store_c(P2, ta, lane, relu4(acc[0]), amax);
         planes_store_c(P2, tb_, lane, relu4(acc[1]), amax);
@@ -110,7 +124,7 @@ void launch_fuse_hoist_x(const RolloutP& p, hipStream_t s) {
 }
 
 // PRE = the batched warm start (RolloutP::pre_mode): A half only, inputs from the ground truth, grid.z = steps
-template <bool PRE>
+template <bool PRE, bool LEAN = false>
 __global__ __launch_bounds__(NTHREADS) void k_step_x(RolloutP p, int t, int do_c, int do_a) {
     if (PRE) {
         do_c = 0;
@@ -121,16 +135,16 @@ __global__ __launch_bounds__(NTHREADS) void k_step_x(RolloutP p, int t, int do_c
     float* Hs = smem + XO_H;
     float* H1 = smem + XO_H1;
     float* H2 = smem + XO_H2;
-    float* GP = smem + XO_GP;
-    float* LP = smem + XO_LP;
-    float* DG = smem + XO_DG;
-    float* LN = smem + XO_LN;
-    float* ENCW = smem + XO_ENCW;
-    xhalf* PA = reinterpret_cast<xhalf*>(smem + XO_PL);
+    float* GP = LEAN ? nullptr : smem + XO_GP;
+    float* LP = LEAN ? nullptr : smem + XO_LP;
+    float* DG = smem + (LEAN ? XL_DG : XO_DG);
+    float* LN = LEAN ? nullptr : smem + XO_LN;
+    float* ENCW = smem + (LEAN ? XL_ENCW : XO_ENCW);
+    xhalf* PA = reinterpret_cast<xhalf*>(smem + (LEAN ? XL_PL : XO_PL));
     xhalf* PB = PA + NPL * PLANE;
     xhalf* PC = PB + NPL * PLANE;
     xhalf* PD = PC + NPL * PLANE;
-    const StepSmall sm = step_small(smem + XO_SMALL);
+    const StepSmall sm = step_small(smem + (LEAN ? XL_SMALL : XO_SMALL));
     RowSt* rst = sm.rst;
     float* ubuf = sm.ubuf;
     uint8_t* rowvalid = sm.rowvalid;
@@ -224,11 +238,13 @@ __global__ __launch_bounds__(NTHREADS) void k_step_x(RolloutP p, int t, int do_c
 #pragma unroll
         for (int i = 0; i < 4; ++i)
             if (i * 64 + lane < p.a_pad) vb[i] = p.valid[(size_t)n * p.a_pad + i * 64 + lane];  // (a_pad <= 256)
-        c_inputs_issue<NTHREADS>(p, n, row0, tid, cin);
+        c_inputs_issue<NTHREADS, LEAN ? 4 : 6>(p, n, row0, tid, cin);
     }
+    if (!LEAN) {
 #pragma unroll
-    for (int sl = 0; sl < 9; ++sl)
-        if (tid < 192) lnv[sl] = ldg4(W + lnbase[sl] + tid * 4);
+        for (int sl = 0; sl < 9; ++sl)
+            if (tid < 192) lnv[sl] = ldg4(W + lnbase[sl] + tid * 4);
+    }
     if (do_a) encw_issue(pw, W, tid, encw);
     if (!PRE) epi_issue(p, t, n, b, row0, n_real, tid, do_c != 0, epi);
     TB_SCHED_FENCE();
@@ -256,10 +272,12 @@ __global__ __launch_bounds__(NTHREADS) void k_step_x(RolloutP p, int t, int do_c
         // scenes keep their valid agents in the leading slots)
         const int nk_a = min(p.a_pad, max(32, (hi_valid + 31) & ~31));
         const int ks_a = ((rt * (nk_a >> 5)) / n_rt) << 5;
-        c_inputs_commit<NTHREADS>(tid, cin, X, Hs, H1, H2, GP, LP, DG, dflag);
+        c_inputs_commit<NTHREADS, LEAN ? 4 : 6>(tid, cin, X, Hs, H1, H2, GP, LP, DG, dflag);
+        if (!LEAN) {
 #pragma unroll
-        for (int sl = 0; sl < 9; ++sl)
-            if (tid < 192) st4(LN + sl * 768 + tid * 4, lnv[sl]);
+            for (int sl = 0; sl < 9; ++sl)
+                if (tid < 192) st4(LN + sl * 768 + tid * 4, lnv[sl]);
+        }
         if (bypass) wloadx(u, gru_first_x(W, pw.gru[0], px.gru[0], wave), lane);
         __syncthreads();
         TB_STAMP(1);
@@ -272,20 +290,20 @@ __global__ __launch_bounds__(NTHREADS) void k_step_x(RolloutP p, int t, int do_c
             const unsigned int* kvf = p.kv_flag + (size_t)n * n_rt * 2;
             const unsigned int tok = (unsigned int)t + 1u;
             unsigned int seen = helpers ? kv_peek_x(kvf, n_rt, 1, tid) : 0u;
-            xattn_layer_x<true, true>(W, pw.inter[0], px.inter[0], X, PA, PB, K0, V0, kvd, nk_a, ks_a, row0, rowvalid, novalid_s, tid, u,
-                                xlayer_first_x(W, pw.inter[1], px.inter[1], wave), LN + 0 * 768, nullptr, amax);
+            xattn_layer_x<!LEAN, true>(W, pw.inter[0], px.inter[0], X, PA, PB, K0, V0, kvd, nk_a, ks_a, row0, rowvalid, novalid_s, tid, u,
+                                xlayer_first_x(W, pw.inter[1], px.inter[1], wave), (LEAN ? nullptr : LN + 0 * 768), nullptr, amax);
             if (helpers) {
                 kv_wait_x(kvf, n_rt, 1, tok, tid, p.sync_err, seen);
                 seen = kv_peek_x(kvf, n_rt, 2, tid);
             }
-            xattn_layer_x<true, true>(W, pw.inter[1], px.inter[1], X, PA, PB, K0 + 2 * ls, V0 + 2 * ls, kvd, nk_a, ks_a, row0, rowvalid, novalid_s, tid,
-                                u, xlayer_first_x(W, pw.inter[2], px.inter[2], wave), LN + 1 * 768, nullptr, amax);
+            xattn_layer_x<!LEAN, true>(W, pw.inter[1], px.inter[1], X, PA, PB, K0 + 2 * ls, V0 + 2 * ls, kvd, nk_a, ks_a, row0, rowvalid, novalid_s, tid,
+                                u, xlayer_first_x(W, pw.inter[2], px.inter[2], wave), (LEAN ? nullptr : LN + 1 * 768), nullptr, amax);
             if (helpers) {
                 kv_wait_x(kvf, n_rt, 2, tok, tid, p.sync_err, seen);
                 if (tid == 0) gh_seen = __hip_atomic_load(p.gh_flag + tile_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            xattn_layer_x<true, true>(W, pw.inter[2], px.inter[2], X, PA, PB, K0 + 4 * ls, V0 + 4 * ls, kvd, nk_a, ks_a, row0, rowvalid,
-                                novalid_s, tid, u, gru_first_x(W, pw.gru[0], px.gru[0], wave), LN + 2 * 768, nullptr, amax);
+            xattn_layer_x<!LEAN, true>(W, pw.inter[2], px.inter[2], X, PA, PB, K0 + 4 * ls, V0 + 4 * ls, kvd, nk_a, ks_a, row0, rowvalid,
+                                novalid_s, tid, u, gru_first_x(W, pw.gru[0], px.gru[0], wave), (LEAN ? nullptr : LN + 2 * 768), nullptr, amax);
         }
         TB_STAMP(2);
         // ---- 3-layer GRU, one step (agent_temporal.py:147-152).  planes: x0 = PA, h0 = PB, h1 = PD, out0 = PC, h2 -> PB, out1 = PA
@@ -335,7 +353,7 @@ __global__ __launch_bounds__(NTHREADS) void k_step_x(RolloutP p, int t, int do_c
         }
         TB_STAMP(3);
         // ---- add_goal, add_latent (traffic_bots.py:240-241); concat planes = PC..PD, hidden = PB
-        fuse_latent_goal_x(W, px.goal_out_w2, pw.goal_out_b2, X, PC, PB, GP, gvalid, rowvalid, tid, u,
+        fuse_latent_goal_x<LEAN>(W, px.goal_out_w2, pw.goal_out_b2, X, PC, PB, LEAN ? p.goal_pre + base_row * H : GP, gvalid, rowvalid, tid, u,
                            wnextx(W, px.lat_out_w1, W + pw.lat_out_b1, 2 * wave, 2 * wave + 1, 8, 0), amax);
         const int my_ty = (lane < TM && rowvalid[lane]) ? rtype[lane] : -1;
         const bool has0 = __ballot(my_ty == 0) != 0, has1 = __ballot(my_ty == 1) != 0, has2 = __ballot(my_ty == 2) != 0;
@@ -344,7 +362,7 @@ __global__ __launch_bounds__(NTHREADS) void k_step_x(RolloutP p, int t, int do_c
         const WNextX h1 = has1 ? wstdx(W, px.head_w1[1], W + pw.head_b1[1], wave) : h2;
         const WNextX h0 = has0 ? wstdx(W, px.head_w1[0], W + pw.head_b1[0], wave) : h1;
         TB_STAMP(4);
-        fuse_latent_goal_x(W, px.lat_out_w2, pw.lat_out_b2, X, PC, PB, LP, rowvalid, rowvalid, tid, u, h0, amax);
+        fuse_latent_goal_x<LEAN>(W, px.lat_out_w2, pw.lat_out_b2, X, PC, PB, LEAN ? p.lat_pre + base_row * H : LP, rowvalid, rowvalid, tid, u, h0, amax);
         TB_STAMP(5);
         if (t == p.tap_step && p.tap_policy_feature)
             store_tile(p.tap_policy_feature + ((size_t)n * p.n_agent + row0) * H, X, LDT, n_real, tid);
@@ -406,9 +424,11 @@ __global__ __launch_bounds__(NTHREADS) void k_step_x(RolloutP p, int t, int do_c
         step_epilogue16<true>(p, t, n, b, row0, n_real, tid, sm, DG);
         __syncthreads();
     } else {
+        if (!LEAN) {
 #pragma unroll
-        for (int sl = 0; sl < 9; ++sl)
-            if (tid < 192) st4(LN + sl * 768 + tid * 4, lnv[sl]);
+            for (int sl = 0; sl < 9; ++sl)
+                if (tid < 192) st4(LN + sl * 768 + tid * 4, lnv[sl]);
+        }
         __syncthreads();
     }
     TB_STAMP(7);
@@ -436,22 +456,22 @@ __global__ __launch_bounds__(NTHREADS) void k_step_x(RolloutP p, int t, int do_c
         const size_t ls = (size_t)p.p_pad * H;
         const xhalf* K0 = reinterpret_cast<const xhalf*>(p.kpl + ((size_t)b * 3) * ls);
         const xhalf* V0 = reinterpret_cast<const xhalf*>(p.vtpl + ((size_t)b * 3) * ls);
-        xattn_layer_x<true>(W, pw.as2pl[0], px.as2pl[0], X, PA, PB, K0, V0, kvd, nk_p, ks_p, -1, rowvalid, novalid_s, tid, u,
-                            xlayer_first_x(W, pw.as2pl[1], px.as2pl[1], wave), LN + 3 * 768,
+        xattn_layer_x<!LEAN>(W, pw.as2pl[0], px.as2pl[0], X, PA, PB, K0, V0, kvd, nk_p, ks_p, -1, rowvalid, novalid_s, tid, u,
+                            xlayer_first_x(W, pw.as2pl[1], px.as2pl[1], wave), (LEAN ? nullptr : LN + 3 * 768),
                             p.prof + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 32, amax);
-        xattn_layer_x<true>(W, pw.as2pl[1], px.as2pl[1], X, PA, PB, K0 + 2 * ls, V0 + 2 * ls, kvd, nk_p, ks_p, -1, rowvalid, novalid_s, tid, u,
-                            xlayer_first_x(W, pw.as2pl[2], px.as2pl[2], wave), LN + 4 * 768, nullptr, amax);
-        xattn_layer_x<true>(W, pw.as2pl[2], px.as2pl[2], X, PA, PB, K0 + 4 * ls, V0 + 4 * ls, kvd, nk_p, ks_p, -1, rowvalid, novalid_s, tid,
-                            u, xlayer_first_x(W, pw.as2tl[0], px.as2tl[0], wave), LN + 5 * 768, nullptr, amax);
+        xattn_layer_x<!LEAN>(W, pw.as2pl[1], px.as2pl[1], X, PA, PB, K0 + 2 * ls, V0 + 2 * ls, kvd, nk_p, ks_p, -1, rowvalid, novalid_s, tid, u,
+                            xlayer_first_x(W, pw.as2pl[2], px.as2pl[2], wave), (LEAN ? nullptr : LN + 4 * 768), nullptr, amax);
+        xattn_layer_x<!LEAN>(W, pw.as2pl[2], px.as2pl[2], X, PA, PB, K0 + 4 * ls, V0 + 4 * ls, kvd, nk_p, ks_p, -1, rowvalid, novalid_s, tid,
+                            u, xlayer_first_x(W, pw.as2tl[0], px.as2tl[0], wave), (LEAN ? nullptr : LN + 5 * 768), nullptr, amax);
     }
     TB_STAMP(9);
     if (tl_empty) {
         // (the Q unit requested above is dropped; one exposed unit load here keeps the common path free of any select)
         wloadx(u, wstdx(W, px.as2tl[0].w1, W + pw.as2tl[0].b1, wave), lane);
-        ffn_layer_x<true>(W, pw.as2tl[0], px.as2tl[0], X, PA, PB, rowvalid, tid, u, wstdx(W, px.as2tl[1].w1, W + pw.as2tl[1].b1, wave), LN + 6 * 768, amax);
-        ffn_layer_x<true>(W, pw.as2tl[1], px.as2tl[1], X, PA, PB, rowvalid, tid, u, wstdx(W, px.as2tl[2].w1, W + pw.as2tl[2].b1, wave), LN + 7 * 768, amax);
-        ffn_layer_x<true>(W, pw.as2tl[2], px.as2tl[2], X, PA, PB, rowvalid, tid, u, wstdx(W, px.inter_kvf[0], W + px.inter_bkvf[0], wave),
-                          LN + 8 * 768, amax);
+        ffn_layer_x<!LEAN>(W, pw.as2tl[0], px.as2tl[0], X, PA, PB, rowvalid, tid, u, wstdx(W, px.as2tl[1].w1, W + pw.as2tl[1].b1, wave), (LEAN ? nullptr : LN + 6 * 768), amax);
+        ffn_layer_x<!LEAN>(W, pw.as2tl[1], px.as2tl[1], X, PA, PB, rowvalid, tid, u, wstdx(W, px.as2tl[2].w1, W + pw.as2tl[2].b1, wave), (LEAN ? nullptr : LN + 7 * 768), amax);
+        ffn_layer_x<!LEAN>(W, pw.as2tl[2], px.as2tl[2], X, PA, PB, rowvalid, tid, u, wstdx(W, px.inter_kvf[0], W + px.inter_bkvf[0], wave),
+                          (LEAN ? nullptr : LN + 8 * 768), amax);
     } else {
         const float* kvd = p.kbias_tl + (size_t)g_tl * p.t_pad;
         const int nk_t = nk_t_raw;
@@ -459,12 +479,12 @@ __global__ __launch_bounds__(NTHREADS) void k_step_x(RolloutP p, int t, int do_c
         const size_t ls = (size_t)p.t_pad * H;
         const xhalf* K0 = reinterpret_cast<const xhalf*>(p.ktl + ((size_t)g_tl * 3) * ls);
         const xhalf* V0 = reinterpret_cast<const xhalf*>(p.vttl + ((size_t)g_tl * 3) * ls);
-        xattn_layer_x<true>(W, pw.as2tl[0], px.as2tl[0], X, PA, PB, K0, V0, kvd, nk_t, ks_t, -1, rowvalid, novalid_s, tid, u,
-                            xlayer_first_x(W, pw.as2tl[1], px.as2tl[1], wave), LN + 6 * 768, nullptr, amax);
-        xattn_layer_x<true>(W, pw.as2tl[1], px.as2tl[1], X, PA, PB, K0 + 2 * ls, V0 + 2 * ls, kvd, nk_t, ks_t, -1, rowvalid, novalid_s, tid, u,
-                            xlayer_first_x(W, pw.as2tl[2], px.as2tl[2], wave), LN + 7 * 768, nullptr, amax);
-        xattn_layer_x<true>(W, pw.as2tl[2], px.as2tl[2], X, PA, PB, K0 + 4 * ls, V0 + 4 * ls, kvd, nk_t, ks_t, -1, rowvalid, novalid_s, tid,
-                            u, wstdx(W, px.inter_kvf[0], W + px.inter_bkvf[0], wave), LN + 8 * 768, nullptr, amax);
+        xattn_layer_x<!LEAN>(W, pw.as2tl[0], px.as2tl[0], X, PA, PB, K0, V0, kvd, nk_t, ks_t, -1, rowvalid, novalid_s, tid, u,
+                            xlayer_first_x(W, pw.as2tl[1], px.as2tl[1], wave), (LEAN ? nullptr : LN + 6 * 768), nullptr, amax);
+        xattn_layer_x<!LEAN>(W, pw.as2tl[1], px.as2tl[1], X, PA, PB, K0 + 2 * ls, V0 + 2 * ls, kvd, nk_t, ks_t, -1, rowvalid, novalid_s, tid, u,
+                            xlayer_first_x(W, pw.as2tl[2], px.as2tl[2], wave), (LEAN ? nullptr : LN + 7 * 768), nullptr, amax);
+        xattn_layer_x<!LEAN>(W, pw.as2tl[2], px.as2tl[2], X, PA, PB, K0 + 4 * ls, V0 + 4 * ls, kvd, nk_t, ks_t, -1, rowvalid, novalid_s, tid,
+                            u, wstdx(W, px.inter_kvf[0], W + px.inter_bkvf[0], wave), (LEAN ? nullptr : LN + 8 * 768), nullptr, amax);
     }
     TB_STAMP(10);
     const size_t zslice = PRE ? (size_t)blockIdx.z * p.n_inst * p.a_pad * H : 0;  // floats per x_mid slice; K / V slices are 3x
@@ -484,6 +504,9 @@ __global__ __launch_bounds__(NTHREADS) void k_step_x(RolloutP p, int t, int do_c
 
 template __global__ void k_step_x<false>(RolloutP, int, int, int);  // (emitted first: the launch of every simulation step)
 template __global__ void k_step_x<true>(RolloutP, int, int, int);
+#ifdef TB_XDL_BF16
+template __global__ void k_step_x<false, true>(RolloutP, int, int, int);
+#endif
 
 // K/V of the three layers of a cross-attention block for fixed targets (map polylines, TL stop points), in the XDL operand
 // order (tb_device_xdl.hpp): the fp16-pair twin of k_kv_hoist.  grid = (n_pad/16, G)
@@ -567,6 +590,11 @@ hipError_t configure_stepx_kernel() {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_step_x<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)(STEPX_LDS_FLOATS * sizeof(float)));
     if (e != hipSuccess) return e;
+#ifdef TB_XDL_BF16
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_step_x<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)(STEPX_LEAN_LDS_FLOATS * sizeof(float)));
+    if (e != hipSuccess) return e;
+#endif
     return hipFuncSetAttribute(reinterpret_cast<const void*>(k_step_x<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                (int)(STEPX_LDS_FLOATS * sizeof(float)));
 }
@@ -575,6 +603,16 @@ void launch_step_x(const RolloutP& p0, int t, int do_c, int do_a, hipStream_t s)
     RolloutP p = p0;
     if (!do_c) p.gh_flag = nullptr;  // (the GRU is in the C half)
     dim3 grid(p.a_pad / TM, p.n_inst, p.gh_flag ? 2 : 1);
+#ifdef TB_XDL_BF16
+    {
+        // more tiles than CUs: the LEAN carve lets two workgroups share a CU (same arithmetic, same results)
+        const char* e = getenv("TB_STEP_LEAN");  // development switch: 0 = always the full carve
+        if ((size_t)grid.x * grid.y > 256 && !(e && e[0] == '0')) {
+            hipLaunchKernelGGL((k_step_x<false, true>), grid, dim3(NTHREADS), STEPX_LEAN_LDS_FLOATS * sizeof(float), s, p, t, do_c, do_a);
+            return;
+        }
+    }
+#endif
     hipLaunchKernelGGL(k_step_x<false>, grid, dim3(NTHREADS), STEPX_LDS_FLOATS * sizeof(float), s, p, t, do_c, do_a);
 }
 
