@@ -85,9 +85,11 @@ def test_config3_k6_bf16_at_batch_32():
     assert rep["scene0_fp32_vs_reference_xy_step11"] <= 1e-4
 
 
-def test_bf16_lean_carve_two_workgroups_per_cu_is_bitwise_identical(monkeypatch):
-    """With bf16 operands a launch of more than 256 tiles runs the LEAN carve of the step kernel (k_step_x<false, true>: no goal / latent
-    / LayerNorm-parameter tiles in LDS, < 80 KB and < 256 VGPRs), so that two workgroups share a CU.  It must not change a bit:
+@pytest.mark.parametrize("prec", ["bf16", "fp32"])
+def test_lean_carve_two_workgroups_per_cu_is_bitwise_identical(prec, monkeypatch):
+    """A launch of more than 256 tiles runs the LEAN carve of the step kernel (k_step_x<false, true>: no goal / latent /
+    LayerNorm-parameter tiles in LDS -- with fp16-pair planes no destination geometry either, and the kernel compiled for 256 VGPRs --
+    i.e. < 80 KB), so that two workgroups share a CU.  It must not change a bit:
     TB_STEP_LEAN=0 (the full carve at every size) against the default, at 288 tiles (12 scenes x 6 futures x 4 row tiles), and a
     sub-batch that stays below the threshold (full carve) against its slice of the big batch (lean carve)."""
     from trafficbots_amd import synth
@@ -99,7 +101,7 @@ def test_bf16_lean_carve_two_workgroups_per_cu_is_bitwise_identical(monkeypatch)
     outs = {}
     for name, flag in (("lean", "1"), ("full", "0")):
         monkeypatch.setenv("TB_STEP_LEAN", flag)
-        wm = _wm(time_step_end=40, n_joint_future=6, operand_precision="bf16")
+        wm = _wm(time_step_end=40, n_joint_future=6, operand_precision=prec)
         wm.load_state_dict(sd)
         gen.manual_seed(5)
         outs[name] = wm.test_step(batch, latent_eps=eps, generator=gen)
@@ -111,7 +113,7 @@ def test_bf16_lean_carve_two_workgroups_per_cu_is_bitwise_identical(monkeypatch)
     # 3 scenes x 6 x 4 = 72 tiles: the full carve (with helper workgroups); same scenes, same destinations
     monkeypatch.delenv("TB_STEP_LEAN")
     sub = {k: v[:3] for k, v in batch.items()}
-    wm = _wm(time_step_end=40, n_joint_future=6, operand_precision="bf16")
+    wm = _wm(time_step_end=40, n_joint_future=6, operand_precision=prec)
     wm.load_state_dict(sd)
     gs = outs["lean"]["goal_sample"][:3].transpose(1, 2).contiguous()  # [B,A,K] -> [B,K,A]
     c = wm.test_step(sub, latent_eps=eps[: 3 * 6], goal_sample=gs.cpu())["rollout_buffer"]

@@ -94,7 +94,7 @@ struct CInputs {
 };
 
 // NSRC = 4: without the goal / latent pre-activation tiles (the LEAN carve of k_step_x reads them where they are used)
-template <int NT, int NSRC = 6>
+template <int NT, int NSRC = 6, bool DG_LDS = true>
 __device__ __forceinline__ void c_inputs_issue(const RolloutP& p, int n, int row0, int tid, CInputs<NT>& c) {
     const size_t base_row = (size_t)n * p.a_pad + row0;
     const float* src[6] = {p.x_mid + base_row * H,
@@ -113,12 +113,12 @@ __device__ __forceinline__ void c_inputs_issue(const RolloutP& p, int n, int row
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int idx = tid + i * NT;
-        c.g[i] = idx < TM * 20 ? ldg4(p.dest_geo + (base_row * 20 + idx) * 4) : splat(0.f);
+        c.g[i] = (DG_LDS && idx < TM * 20) ? ldg4(p.dest_geo + (base_row * 20 + idx) * 4) : splat(0.f);
     }
     c.df = tid < TM ? p.dest_flag[base_row + tid] : 0;
 }
 
-template <int NT, int NSRC = 6>
+template <int NT, int NSRC = 6, bool DG_LDS = true>
 __device__ __forceinline__ void c_inputs_commit(int tid, const CInputs<NT>& c, float* X, float* Hs, float* H1, float* H2, float* GP,
                                                 float* LP, float* DG, int* dflag) {
     float* dst[6] = {X, Hs, H1, H2, GP, LP};
@@ -132,7 +132,7 @@ __device__ __forceinline__ void c_inputs_commit(int tid, const CInputs<NT>& c, f
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int idx = tid + i * NT;
-        if (idx < TM * 20) st4(DG + idx * 4, c.g[i]);
+        if (DG_LDS && idx < TM * 20) st4(DG + idx * 4, c.g[i]);
     }
     if (tid < TM) dflag[tid] = c.df;
 }
@@ -360,7 +360,8 @@ __device__ __forceinline__ void epi_commit(int tid, bool do_c, const EpiRegs& e,
     }
 }
 
-template <bool PREF = false>
+// DGG: `DG` points at the tile's destination geometry in the rollout workspace (global) instead of its LDS copy
+template <bool PREF = false, bool DGG = false>
 __device__ __forceinline__ void step_epilogue16(const RolloutP& p, int t, int n, int b, int row0, int n_real, int tid,
                                                 const StepSmall& sm, const float* DG) {
     const PolicyW& pw = p.pw;
@@ -473,7 +474,7 @@ __device__ __forceinline__ void step_epilogue16(const RolloutP& p, int t, int n,
         bool pos = false, rot = false;
 #pragma unroll
         for (int k = sub; k < 20; k += 16) {
-            const f32x4 g = lds4(DG + (a * 20 + k) * 4);
+            const f32x4 g = DGG ? ldg4(DG + (a * 20 + k) * 4) : lds4(DG + (a * 20 + k) * 4);
             const float dx = fadd_(cur.x, -g.x), dy = fadd_(cur.y, -g.y);
             const float dist = sqrtf(fadd_(fmul_(dx, dx), fmul_(dy, dy)));
             pos |= dist < thresh;

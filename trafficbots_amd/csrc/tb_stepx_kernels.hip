@@ -27,8 +27,11 @@ constexpr int STEPX_LDS_FLOATS = XO_PL + 4 * PLANES_FLOATS;
 // LayerNorm parameter blocks (read from the weight arena by each LayerNorm): with one bf16 plane per operand the workgroup then needs
 // < 80 KB and < 256 VGPRs, so TWO workgroups share a CU when a launch has more tiles than the chip has CUs (K futures, 8-tile
 // instances): the weight-streaming GEMM phases of one run under the latency-bound attention / LayerNorm phases of the other.
+// (with fp16-pair planes the destination geometry leaves LDS as well -- the epilogue reads its 20 nodes per agent from the workspace --
+// and the kernel is compiled for two waves per SIMD, i.e. 256 VGPRs)
+constexpr bool XL_DG_GLOBAL = NPL == 2;
 constexpr int XL_DG = XO_GP;
-constexpr int XL_SMALL = XL_DG + TM * 80;
+constexpr int XL_SMALL = XL_DG + (XL_DG_GLOBAL ? 0 : TM * 80);
 constexpr int XL_ENCW = XL_SMALL + SMALL_FLOATS;
 constexpr int XL_PL = XL_ENCW + ENCW_FLOATS;
 constexpr int STEPX_LEAN_LDS_FLOATS = XL_PL + 4 * PLANES_FLOATS;
@@ -125,7 +128,7 @@ void launch_fuse_hoist_x(const RolloutP& p, hipStream_t s) {
 
 // PRE = the batched warm start (RolloutP::pre_mode): A half only, inputs from the ground truth, grid.z = steps
 template <bool PRE, bool LEAN = false>
-__global__ __launch_bounds__(NTHREADS) void k_step_x(RolloutP p, int t, int do_c, int do_a) {
+__global__ __launch_bounds__(NTHREADS, LEAN ? 2 : 1) void k_step_x(RolloutP p, int t, int do_c, int do_a) {
     if (PRE) {
         do_c = 0;
         do_a = 1;
@@ -238,7 +241,7 @@ __global__ __launch_bounds__(NTHREADS) void k_step_x(RolloutP p, int t, int do_c
 #pragma unroll
         for (int i = 0; i < 4; ++i)
             if (i * 64 + lane < p.a_pad) vb[i] = p.valid[(size_t)n * p.a_pad + i * 64 + lane];  // (a_pad <= 256)
-        c_inputs_issue<NTHREADS, LEAN ? 4 : 6>(p, n, row0, tid, cin);
+        c_inputs_issue<NTHREADS, LEAN ? 4 : 6, !(LEAN && XL_DG_GLOBAL)>(p, n, row0, tid, cin);
     }
     if (!LEAN) {
 #pragma unroll
@@ -272,7 +275,7 @@ __global__ __launch_bounds__(NTHREADS) void k_step_x(RolloutP p, int t, int do_c
         // scenes keep their valid agents in the leading slots)
         const int nk_a = min(p.a_pad, max(32, (hi_valid + 31) & ~31));
         const int ks_a = ((rt * (nk_a >> 5)) / n_rt) << 5;
-        c_inputs_commit<NTHREADS, LEAN ? 4 : 6>(tid, cin, X, Hs, H1, H2, GP, LP, DG, dflag);
+        c_inputs_commit<NTHREADS, LEAN ? 4 : 6, !(LEAN && XL_DG_GLOBAL)>(tid, cin, X, Hs, H1, H2, GP, LP, DG, dflag);
         if (!LEAN) {
 #pragma unroll
             for (int sl = 0; sl < 9; ++sl)
@@ -421,7 +424,8 @@ __global__ __launch_bounds__(NTHREADS) void k_step_x(RolloutP p, int t, int do_c
         }
         __syncthreads();
         TB_STAMP(6);
-        step_epilogue16<true>(p, t, n, b, row0, n_real, tid, sm, DG);
+        if (LEAN && XL_DG_GLOBAL) step_epilogue16<true, true>(p, t, n, b, row0, n_real, tid, sm, p.dest_geo + base_row * 80);
+        else step_epilogue16<true>(p, t, n, b, row0, n_real, tid, sm, DG);
         __syncthreads();
     } else {
         if (!LEAN) {
@@ -504,9 +508,7 @@ __global__ __launch_bounds__(NTHREADS) void k_step_x(RolloutP p, int t, int do_c
 
 template __global__ void k_step_x<false>(RolloutP, int, int, int);  // (emitted first: the launch of every simulation step)
 template __global__ void k_step_x<true>(RolloutP, int, int, int);
-#ifdef TB_XDL_BF16
 template __global__ void k_step_x<false, true>(RolloutP, int, int, int);
-#endif
 
 // K/V of the three layers of a cross-attention block for fixed targets (map polylines, TL stop points), in the XDL operand
 // order (tb_device_xdl.hpp): the fp16-pair twin of k_kv_hoist.  grid = (n_pad/16, G)
@@ -590,11 +592,9 @@ hipError_t configure_stepx_kernel() {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_step_x<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)(STEPX_LDS_FLOATS * sizeof(float)));
     if (e != hipSuccess) return e;
-#ifdef TB_XDL_BF16
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_step_x<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)(STEPX_LEAN_LDS_FLOATS * sizeof(float)));
     if (e != hipSuccess) return e;
-#endif
     return hipFuncSetAttribute(reinterpret_cast<const void*>(k_step_x<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                (int)(STEPX_LDS_FLOATS * sizeof(float)));
 }
@@ -603,7 +603,6 @@ void launch_step_x(const RolloutP& p0, int t, int do_c, int do_a, hipStream_t s)
     RolloutP p = p0;
     if (!do_c) p.gh_flag = nullptr;  // (the GRU is in the C half)
     dim3 grid(p.a_pad / TM, p.n_inst, p.gh_flag ? 2 : 1);
-#ifdef TB_XDL_BF16
     {
         // more tiles than CUs: the LEAN carve lets two workgroups share a CU (same arithmetic, same results)
         const char* e = getenv("TB_STEP_LEAN");  // development switch: 0 = always the full carve
@@ -612,7 +611,6 @@ void launch_step_x(const RolloutP& p0, int t, int do_c, int do_a, hipStream_t s)
             return;
         }
     }
-#endif
     hipLaunchKernelGGL(k_step_x<false>, grid, dim3(NTHREADS), STEPX_LDS_FLOATS * sizeof(float), s, p, t, do_c, do_a);
 }
 
