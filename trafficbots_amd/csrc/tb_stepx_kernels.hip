@@ -509,6 +509,7 @@ __global__ __launch_bounds__(NTHREADS, LEAN ? 2 : 1) void k_step_x(RolloutP p, i
 template __global__ void k_step_x<false>(RolloutP, int, int, int);  // (emitted first: the launch of every simulation step)
 template __global__ void k_step_x<true>(RolloutP, int, int, int);
 template __global__ void k_step_x<false, true>(RolloutP, int, int, int);
+template __global__ void k_step_x<true, true>(RolloutP, int, int, int);
 
 // K/V of the three layers of a cross-attention block for fixed targets (map polylines, TL stop points), in the XDL operand
 // order (tb_device_xdl.hpp): the fp16-pair twin of k_kv_hoist.  grid = (n_pad/16, G)
@@ -595,6 +596,9 @@ hipError_t configure_stepx_kernel() {
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_step_x<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)(STEPX_LEAN_LDS_FLOATS * sizeof(float)));
     if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_step_x<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)(STEPX_LEAN_LDS_FLOATS * sizeof(float)));
+    if (e != hipSuccess) return e;
     return hipFuncSetAttribute(reinterpret_cast<const void*>(k_step_x<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                (int)(STEPX_LDS_FLOATS * sizeof(float)));
 }
@@ -646,6 +650,15 @@ void launch_step_pre_x(const RolloutP& p0, int t0, int n, hipStream_t s) {
     p.pre_mode = 1;
     p.pre_t0 = t0;
     dim3 grid(p.a_pad / TM, p.n_scene, n);
+    {
+        // n x tiles workgroups: the LEAN carve (two workgroups per CU) whenever that is more than the chip has CUs
+        const char* e = getenv("TB_STEP_LEAN");
+        if ((size_t)grid.x * grid.y * grid.z > 256 && !(e && e[0] == '0')) {
+            hipLaunchKernelGGL((k_step_x<true, true>), grid, dim3(NTHREADS), STEPX_LEAN_LDS_FLOATS * sizeof(float), s, p, t0, 0, 1);
+            if (p.k_rep > 1) launch_pre_replicate(p, n, s);
+            return;
+        }
+    }
     hipLaunchKernelGGL(k_step_x<true>, grid, dim3(NTHREADS), STEPX_LDS_FLOATS * sizeof(float), s, p, t0, 0, 1);
     if (p.k_rep > 1) launch_pre_replicate(p, n, s);
 }
