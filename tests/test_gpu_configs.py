@@ -118,6 +118,17 @@ def test_lean_carve_two_workgroups_per_cu_is_bitwise_identical(prec, monkeypatch
     gs = outs["lean"]["goal_sample"][:3].transpose(1, 2).contiguous()  # [B,A,K] -> [B,K,A]
     c = wm.test_step(sub, latent_eps=eps[: 3 * 6], goal_sample=gs.cpu())["rollout_buffer"]
     assert torch.equal(c.preds, a.preds[:3]), float((c.preds - a.preds[:3]).abs().max())
+    # one-tile instances, most of them with a single valid agent (interaction bypass) or none, no lit traffic light: 44 x 7 = 308 tiles
+    batch2 = synth.make_batch(8700, 44, n_agent=9, n_pl=20, n_tl=6, p_invalid_agent=0.85, p_tl_valid=0.0)
+    eps2 = torch.from_numpy(synth.make_latent_noise(8701, 44 * 7, 9)).cuda()
+    res = {}
+    for name, flag in (("lean", "1"), ("full", "0")):
+        monkeypatch.setenv("TB_STEP_LEAN", flag)
+        wm = _wm(time_step_end=30, n_joint_future=7, operand_precision=prec)
+        wm.load_state_dict(sd)
+        gen.manual_seed(6)
+        res[name] = wm.test_step(batch2, latent_eps=eps2, generator=gen)["rollout_buffer"]
+    assert torch.equal(res["lean"].preds, res["full"].preds) and torch.equal(res["lean"].valid, res["full"].valid)
 
 
 @pytest.mark.parametrize("prec", ["fp32", "bf16"])
