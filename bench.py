@@ -40,6 +40,7 @@ H = 128
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense bf16 / fp16 MFMA peak (no sparsity)
 PEAK_HBM_GBS = 8000.0
+SHADER_CLK = 2.33e9  # Hz under the step kernel: SQ_BUSY_CYCLES / 32 / kernel-trace duration (tools/prof_pmc_json.py `checks`)
 PMC_FILE = os.path.join(ROOT, "profiles", "pmc_step_kernel.json")  # written by tools/gpu_pmc_step.sh (rocprofv3 --pmc passes)
 
 # the other BASELINE.json configurations measured as sub-records (32 scenes per GPU each)
@@ -77,7 +78,7 @@ def load_path(k_us, n_agent, n_pl, n_tl_keys, wbytes=4):
                                       # that the rollout prologue hoists (k_fuse_hoist_x); 4 B each as an fp16 pair, 2 B as bf16
     pad = lambda n: (n + 31) // 32 * 32  # noqa: E731
     kv_bytes = 3 * 2 * (pad(n_pl) + n_tl_keys + pad(n_agent)) * H * wbytes
-    clk = 2.1e9                       # s_memtime ticks per second observed on this kernel
+    clk = SHADER_CLK                  # shader clock under this kernel (SQ_BUSY_CYCLES / 32 shader engines / kernel-trace duration)
     per_clk = (w_bytes + kv_bytes) / (k_us * 1e-6 * clk)
     return {"bytes_per_workgroup_launch": w_bytes + kv_bytes, "weights": w_bytes, "kv": kv_bytes, "achieved_B_per_clk_per_CU": per_clk,
             "peak_B_per_clk_per_CU": 64.0, "frac": per_clk / 64.0}
@@ -438,7 +439,7 @@ def run_rank(args, rank: int, local_rank: int, world: int) -> None:
         planes = 2 if prec == "fp32" else 1
         # matrix-pipe occupancy from the kernel's structure and the measured launch time: MFMAs per wave x issue interval / launch cycles
         n_mfma = mfma_issue(N_AGENT, N_PL, tl_keys_eff, planes)
-        clk = 2.1e9
+        clk = SHADER_CLK
         mfma_busy_est = n_mfma * 16.0 / (k_us * 1e-6 * clk)
         pmc = None
         if os.path.exists(PMC_FILE):
@@ -478,7 +479,7 @@ def run_rank(args, rank: int, local_rank: int, world: int) -> None:
                          "mfma_busy": {
                              "estimated": mfma_busy_est,
                              "how": f"{n_mfma} v_mfma_f32_16x16x32 per wave per launch (kernel structure) x 16 cycles (4 passes of the XDL pipe) "
-                                    "/ launch cycles at 2.1 GHz = fraction of the launch during which a busy SIMD's matrix pipe executes; "
+                                    "/ launch cycles at 2.33 GHz (measured: profiles/pmc_step_kernel.json `checks`) = fraction of the launch during which a busy SIMD's matrix pipe executes; "
                                     "x 128/256 occupied CUs for the chip-wide figure",
                              "chip_wide_estimated": mfma_busy_est * min(1.0, 128.0 / 256.0),
                              "measured": (pmc or {}).get("mfma_busy"),
