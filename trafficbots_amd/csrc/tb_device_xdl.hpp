@@ -554,7 +554,7 @@ __device__ __forceinline__ void kv_store_key_x(xhalf* __restrict__ Kf, xhalf* __
 // One pre-LN cross-attention layer, GEMMs and attention on XDL.
 //   X : [16][LDT] fp32 residual stream (LDS);  P1, P2 : plane buffers (LN output / attention output + FFN hidden)
 // ---------------------------------------------------------------------------------------------
-template <bool LNLDS = false, bool SELFMASK = false, class R = RangeFlag>
+template <bool LNLDS = false, bool SELFMASK = false, bool WO_EARLY = true, class R = RangeFlag>
 __device__ __forceinline__ void xattn_layer_x(const float* __restrict__ W, const XLayerW& L, const XLayerX& LX, float* X, xhalf* P1,
                                               xhalf* P2, const xhalf* __restrict__ Kmat, const xhalf* __restrict__ VT,
                                               const float* __restrict__ keybias, int n_key_pad, int kstart, int self_key0,
@@ -567,19 +567,25 @@ __device__ __forceinline__ void xattn_layer_x(const float* __restrict__ W, const
     const xhalf* b1 = P1 + m * LDP + kq * 8;
     const xhalf* b2 = P2 + m * LDP + kq * 8;
     AttnPreX apre;
+    // the out-projection unit is requested HERE, in front of the LayerNorm: the Q unit has landed (it was requested a whole phase ago),
+    // the LayerNorm issues no vector-memory load, so the 16 requests stream beside its arithmetic and the K / V prefetch queues behind
+    // them.  (Requested from inside the key walk, as before, the wave sat ~1.5 k cycles in the request's own issue -- the
+    // vector-memory queue is shallow -- in the middle of the attention: bf16 68.2 -> 65.2 us per fused launch, fp16 pairs 96.1 -> 95.7.)
+    // (WO_EARLY = false keeps the request inside the key walk: the fp16-pair LEAN carve, capped at 256 VGPRs, spills less that way)
+    WUnitX u2;
+    if (WO_EARLY) wloadx(u2, wstdx(W, LX.wo, W + L.bo, wave), lane);
     layernorm_planes<LNLDS>(X, LDT, P1, lnblk, lnblk + 128, tid);
     // (after the LayerNorm: the vector-memory queue is still draining this layer's Q weights, a load issued earlier would
     // block the wave in front of the LayerNorm arithmetic instead of running beside it)
     attention_prefetch_x(apre, Kmat, VT, keybias, n_key_pad, kstart, wave, lane);
     __syncthreads();
     TB_XSTAMP(17);
-    WUnitX u2;
     f32x4 q[2] = {u.b[0], u.b[1]};
     wmmax(q[0], q[1], u, b1, PLANE);
     TB_XSTAMP(18);
     f32x4 o[2];
-    const bool novalid = attention_head_x<SELFMASK>(q, apre, Kmat, VT, keybias, n_key_pad, kstart, wave, lane, self_key0 >= 0 ? self_key0 + m : -1, o, u2,
-                                          wstdx(W, LX.wo, W + L.bo, wave), prof, amax);
+    const bool novalid = attention_head_x<SELFMASK, !WO_EARLY>(q, apre, Kmat, VT, keybias, n_key_pad, kstart, wave, lane,
+                                                           self_key0 >= 0 ? self_key0 + m : -1, o, u2, wstdx(W, LX.wo, W + L.bo, wave), prof, amax);
     TB_XSTAMP(19);
     planes_store_c<false>(P2, 2 * wave, lane, o[0]);  // (a convex combination of V, which was checked when it was stored)
     planes_store_c<false>(P2, 2 * wave + 1, lane, o[1]);
