@@ -567,13 +567,12 @@ __device__ __forceinline__ void xattn_layer_x(const float* __restrict__ W, const
     const xhalf* b1 = P1 + m * LDP + kq * 8;
     const xhalf* b2 = P2 + m * LDP + kq * 8;
     AttnPreX apre;
-    // the out-projection unit is requested HERE, in front of the LayerNorm: the Q unit has landed (it was requested a whole phase ago),
-    // the LayerNorm issues no vector-memory load, so the 16 requests stream beside its arithmetic and the K / V prefetch queues behind
-    // them.  (Requested from inside the key walk, as before, the wave sat ~1.5 k cycles in the request's own issue -- the
-    // vector-memory queue is shallow -- in the middle of the attention: bf16 68.2 -> 65.2 us per fused launch, fp16 pairs 96.1 -> 95.7.)
-    // (WO_EARLY = false keeps the request inside the key walk: the fp16-pair LEAN carve, capped at 256 VGPRs, spills less that way)
+    // The out-projection unit is requested BESIDE the Q projection (wmmax_pf interleaves its 16 requests with the MFMAs, behind the
+    // K / V prefetch of the first two key blocks).  Requested from inside the key walk, as at first, the wave sat ~1.5 k cycles in the
+    // request's own issue -- the per-wave vector-memory queue is shallow -- in the middle of the attention; requested in front of the
+    // LayerNorm it delayed the LayerNorm instead.  fp16 pairs 96.0 -> 92.6 us per fused launch, bf16 68.2 -> 64.6.
+    // (WO_EARLY = false keeps the request inside the key walk)
     WUnitX u2;
-    if (WO_EARLY) wloadx(u2, wstdx(W, LX.wo, W + L.bo, wave), lane);
     layernorm_planes<LNLDS>(X, LDT, P1, lnblk, lnblk + 128, tid);
     // (after the LayerNorm: the vector-memory queue is still draining this layer's Q weights, a load issued earlier would
     // block the wave in front of the LayerNorm arithmetic instead of running beside it)
@@ -581,7 +580,8 @@ __device__ __forceinline__ void xattn_layer_x(const float* __restrict__ W, const
     __syncthreads();
     TB_XSTAMP(17);
     f32x4 q[2] = {u.b[0], u.b[1]};
-    wmmax(q[0], q[1], u, b1, PLANE);
+    if (WO_EARLY) wmmax_pf(q[0], q[1], u, b1, PLANE, u2, wstdx(W, LX.wo, W + L.bo, wave), lane);
+    else wmmax(q[0], q[1], u, b1, PLANE);
     TB_XSTAMP(18);
     f32x4 o[2];
     const bool novalid = attention_head_x<SELFMASK, !WO_EARLY>(q, apre, Kmat, VT, keybias, n_key_pad, kstart, wave, lane,

@@ -293,19 +293,19 @@ __global__ __launch_bounds__(NTHREADS, LEAN ? 2 : 1) void k_step_x(RolloutP p, i
             const unsigned int* kvf = p.kv_flag + (size_t)n * n_rt * 2;
             const unsigned int tok = (unsigned int)t + 1u;
             unsigned int seen = helpers ? kv_peek_x(kvf, n_rt, 1, tid) : 0u;
-            xattn_layer_x<!LEAN, true, !(LEAN && NPL == 2)>(W, pw.inter[0], px.inter[0], X, PA, PB, K0, V0, kvd, nk_a, ks_a, row0, rowvalid, novalid_s, tid, u,
+            xattn_layer_x<!LEAN, true>(W, pw.inter[0], px.inter[0], X, PA, PB, K0, V0, kvd, nk_a, ks_a, row0, rowvalid, novalid_s, tid, u,
                                 xlayer_first_x(W, pw.inter[1], px.inter[1], wave), (LEAN ? nullptr : LN + 0 * 768), nullptr, amax);
             if (helpers) {
                 kv_wait_x(kvf, n_rt, 1, tok, tid, p.sync_err, seen);
                 seen = kv_peek_x(kvf, n_rt, 2, tid);
             }
-            xattn_layer_x<!LEAN, true, !(LEAN && NPL == 2)>(W, pw.inter[1], px.inter[1], X, PA, PB, K0 + 2 * ls, V0 + 2 * ls, kvd, nk_a, ks_a, row0, rowvalid, novalid_s, tid,
+            xattn_layer_x<!LEAN, true>(W, pw.inter[1], px.inter[1], X, PA, PB, K0 + 2 * ls, V0 + 2 * ls, kvd, nk_a, ks_a, row0, rowvalid, novalid_s, tid,
                                 u, xlayer_first_x(W, pw.inter[2], px.inter[2], wave), (LEAN ? nullptr : LN + 1 * 768), nullptr, amax);
             if (helpers) {
                 kv_wait_x(kvf, n_rt, 2, tok, tid, p.sync_err, seen);
                 if (tid == 0) gh_seen = __hip_atomic_load(p.gh_flag + tile_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            xattn_layer_x<!LEAN, true, !(LEAN && NPL == 2)>(W, pw.inter[2], px.inter[2], X, PA, PB, K0 + 4 * ls, V0 + 4 * ls, kvd, nk_a, ks_a, row0, rowvalid,
+            xattn_layer_x<!LEAN, true>(W, pw.inter[2], px.inter[2], X, PA, PB, K0 + 4 * ls, V0 + 4 * ls, kvd, nk_a, ks_a, row0, rowvalid,
                                 novalid_s, tid, u, gru_first_x(W, pw.gru[0], px.gru[0], wave), (LEAN ? nullptr : LN + 2 * 768), nullptr, amax);
         }
         TB_STAMP(2);
@@ -460,12 +460,12 @@ __global__ __launch_bounds__(NTHREADS, LEAN ? 2 : 1) void k_step_x(RolloutP p, i
         const size_t ls = (size_t)p.p_pad * H;
         const xhalf* K0 = reinterpret_cast<const xhalf*>(p.kpl + ((size_t)b * 3) * ls);
         const xhalf* V0 = reinterpret_cast<const xhalf*>(p.vtpl + ((size_t)b * 3) * ls);
-        xattn_layer_x<!LEAN, false, !(LEAN && NPL == 2)>(W, pw.as2pl[0], px.as2pl[0], X, PA, PB, K0, V0, kvd, nk_p, ks_p, -1, rowvalid, novalid_s, tid, u,
+        xattn_layer_x<!LEAN>(W, pw.as2pl[0], px.as2pl[0], X, PA, PB, K0, V0, kvd, nk_p, ks_p, -1, rowvalid, novalid_s, tid, u,
                             xlayer_first_x(W, pw.as2pl[1], px.as2pl[1], wave), (LEAN ? nullptr : LN + 3 * 768),
                             p.prof + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 32, amax);
-        xattn_layer_x<!LEAN, false, !(LEAN && NPL == 2)>(W, pw.as2pl[1], px.as2pl[1], X, PA, PB, K0 + 2 * ls, V0 + 2 * ls, kvd, nk_p, ks_p, -1, rowvalid, novalid_s, tid, u,
+        xattn_layer_x<!LEAN>(W, pw.as2pl[1], px.as2pl[1], X, PA, PB, K0 + 2 * ls, V0 + 2 * ls, kvd, nk_p, ks_p, -1, rowvalid, novalid_s, tid, u,
                             xlayer_first_x(W, pw.as2pl[2], px.as2pl[2], wave), (LEAN ? nullptr : LN + 4 * 768), nullptr, amax);
-        xattn_layer_x<!LEAN, false, !(LEAN && NPL == 2)>(W, pw.as2pl[2], px.as2pl[2], X, PA, PB, K0 + 4 * ls, V0 + 4 * ls, kvd, nk_p, ks_p, -1, rowvalid, novalid_s, tid,
+        xattn_layer_x<!LEAN>(W, pw.as2pl[2], px.as2pl[2], X, PA, PB, K0 + 4 * ls, V0 + 4 * ls, kvd, nk_p, ks_p, -1, rowvalid, novalid_s, tid,
                             u, xlayer_first_x(W, pw.as2tl[0], px.as2tl[0], wave), (LEAN ? nullptr : LN + 5 * 768), nullptr, amax);
     }
     TB_STAMP(9);
@@ -483,11 +483,11 @@ __global__ __launch_bounds__(NTHREADS, LEAN ? 2 : 1) void k_step_x(RolloutP p, i
         const size_t ls = (size_t)p.t_pad * H;
         const xhalf* K0 = reinterpret_cast<const xhalf*>(p.ktl + ((size_t)g_tl * 3) * ls);
         const xhalf* V0 = reinterpret_cast<const xhalf*>(p.vttl + ((size_t)g_tl * 3) * ls);
-        xattn_layer_x<!LEAN, false, !(LEAN && NPL == 2)>(W, pw.as2tl[0], px.as2tl[0], X, PA, PB, K0, V0, kvd, nk_t, ks_t, -1, rowvalid, novalid_s, tid, u,
+        xattn_layer_x<!LEAN>(W, pw.as2tl[0], px.as2tl[0], X, PA, PB, K0, V0, kvd, nk_t, ks_t, -1, rowvalid, novalid_s, tid, u,
                             xlayer_first_x(W, pw.as2tl[1], px.as2tl[1], wave), (LEAN ? nullptr : LN + 6 * 768), nullptr, amax);
-        xattn_layer_x<!LEAN, false, !(LEAN && NPL == 2)>(W, pw.as2tl[1], px.as2tl[1], X, PA, PB, K0 + 2 * ls, V0 + 2 * ls, kvd, nk_t, ks_t, -1, rowvalid, novalid_s, tid, u,
+        xattn_layer_x<!LEAN>(W, pw.as2tl[1], px.as2tl[1], X, PA, PB, K0 + 2 * ls, V0 + 2 * ls, kvd, nk_t, ks_t, -1, rowvalid, novalid_s, tid, u,
                             xlayer_first_x(W, pw.as2tl[2], px.as2tl[2], wave), (LEAN ? nullptr : LN + 7 * 768), nullptr, amax);
-        xattn_layer_x<!LEAN, false, !(LEAN && NPL == 2)>(W, pw.as2tl[2], px.as2tl[2], X, PA, PB, K0 + 4 * ls, V0 + 4 * ls, kvd, nk_t, ks_t, -1, rowvalid, novalid_s, tid,
+        xattn_layer_x<!LEAN>(W, pw.as2tl[2], px.as2tl[2], X, PA, PB, K0 + 4 * ls, V0 + 4 * ls, kvd, nk_t, ks_t, -1, rowvalid, novalid_s, tid,
                             u, wstdx(W, px.inter_kvf[0], W + px.inter_bkvf[0], wave), (LEAN ? nullptr : LN + 8 * 768), nullptr, amax);
     }
     TB_STAMP(10);
