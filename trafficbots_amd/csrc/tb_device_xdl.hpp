@@ -761,11 +761,11 @@ __device__ __forceinline__ void xattn_layer_x2(const float* __restrict__ W, cons
     __syncthreads();
     WUnitX u2;
     f32x4 q0[2] = {u.b[0], u.b[1]}, q1[2] = {u.b[0], u.b[1]};
-    wmmax(q0[0], q0[1], u, P1a + po, PLANE);
+    wmmax_pf(q0[0], q0[1], u, P1a + po, PLANE, u2, wstdx(W, LX.wo, W + L.bo, wave), lane);  // (the out-projection unit: see xattn_layer_x)
     wmmax(q1[0], q1[1], u, P1b + po, PLANE);
     f32x4 o0[2], o1[2];
-    const bool nov0 = attention_head_x<SELFMASK, true>(q0, apre, Kmat, VT, keybias, n_key_pad, 0, wave, lane, self_key0a >= 0 ? self_key0a + m : -1,
-                                                       o0, u2, wstdx(W, LX.wo, W + L.bo, wave));
+    const bool nov0 = attention_head_x<SELFMASK, false>(q0, apre, Kmat, VT, keybias, n_key_pad, 0, wave, lane, self_key0a >= 0 ? self_key0a + m : -1,
+                                                        o0, u2, wstdx(W, LX.wo, W + L.bo, wave));
     attention_prefetch_x(apre, Kmat, VT, keybias, n_key_pad, 0, wave, lane);
     const bool nov1 = attention_head_x<SELFMASK, false>(q1, apre, Kmat, VT, keybias, n_key_pad, 0, wave, lane, self_key0b >= 0 ? self_key0b + m : -1,
                                                         o1, u2, wstdx(W, LX.wo, W + L.bo, wave));
