@@ -573,10 +573,24 @@ __device__ __forceinline__ void xattn_layer_x(const float* __restrict__ W, const
     // LayerNorm it delayed the LayerNorm instead.  fp16 pairs 96.0 -> 92.6 us per fused launch, bf16 68.2 -> 64.6.
     // (WO_EARLY = false keeps the request inside the key walk)
     WUnitX u2;
+    // K / V prefetch of the first two key blocks.  With fp16 pairs (16 requests, 16 KB per wave) the first block's K fragments are
+    // requested in front of the LayerNorm arithmetic and the rest behind it: the vector-memory queue takes about that many without
+    // stalling the wave, so part of the burst runs beside the arithmetic (92.6 -> 92.0 us per fused launch); with one bf16 plane the
+    // whole burst is short and stays behind the LayerNorm (in front of it: 64.7 -> 65.2).
+    if (NPL == 2) {
+        TB_SCHED_FENCE();
+        k_load_x(apre.k0f, Kmat + wave * (NPL * 1024) + lane * 8, keybias + kq * 4, kstart);
+        TB_SCHED_FENCE();
+    }
     layernorm_planes<LNLDS>(X, LDT, P1, lnblk, lnblk + 128, tid);
-    // (after the LayerNorm: the vector-memory queue is still draining this layer's Q weights, a load issued earlier would
-    // block the wave in front of the LayerNorm arithmetic instead of running beside it)
-    attention_prefetch_x(apre, Kmat, VT, keybias, n_key_pad, kstart, wave, lane);
+    if (NPL == 2) {
+        TB_SCHED_FENCE();
+        v_load_x(apre.vc, VT + wave * (NPL * 1024) + lane * 8, kstart);
+        k_load_x(apre.kn, Kmat + wave * (NPL * 1024) + lane * 8, keybias + kq * 4, n_key_pad > 32 ? kwrap(kstart + 32, n_key_pad) : kstart);
+        TB_SCHED_FENCE();
+    } else {
+        attention_prefetch_x(apre, Kmat, VT, keybias, n_key_pad, kstart, wave, lane);
+    }
     __syncthreads();
     TB_XSTAMP(17);
     f32x4 q[2] = {u.b[0], u.b[1]};
