@@ -448,7 +448,7 @@ def run_rank(args, rank: int, local_rank: int, world: int) -> None:
             except Exception:
                 pmc = None
         shape_ok = (N_AGENT, N_PL, N_TL, B_PER_GPU) == (64, 256, 40, 32)
-        traffic = pmc["fetch_bytes_per_launch"] if (pmc and shape_ok) else None
+        traffic = pmc.get("fetch_bytes_per_launch") if (pmc and shape_ok) else None
         line = {
             "metric": "rollout scene-steps/sec (64 agents, 90 executed = 10 teacher-forced + 80 free steps)",
             "value": value, "unit": "scene-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -466,7 +466,7 @@ def run_rank(args, rank: int, local_rank: int, world: int) -> None:
             "kernel_us": {"k_step_fused": k_us, "n_fused": tm["n_fused"], "edge_launches_ms": tm["edge_ms"], "prologue_ms": tm["prologue_ms"],
                           "note": "per rollout: n_fused fused launches; edge_launches_ms = the batched warm-start launch (A halves of the "
                                   "teacher-forced steps, k_step_x<true>), their C-only launches and the last step's"},
-            "roofline": {"bound": "mfma", "kernel": "tb::xh::k_step_x<false> (the fused C(t)+A(t+1) launch of a simulation step)", "achieved": achieved,
+            "roofline": {"bound": "mfma", "kernel": "tb::xh::k_step_x<false, false> (PRE = LEAN = false: the fused C(t)+A(t+1) launch of a simulation step)", "achieved": achieved,
                          "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
                          "traffic": traffic,
                          "traffic_unit": "HBM-side bytes per launch: rocprofv3 --pmc FETCH_SIZE x 2 (gfx950 correction of the guide) from the "

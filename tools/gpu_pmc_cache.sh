@@ -19,7 +19,7 @@ import csv, glob, statistics, collections
 vals = collections.defaultdict(list)
 for f in glob.glob("gpurun_out/pmc_cache/*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        if "k_step_x<false>" in r.get("Kernel_Name", ""):
+        if "k_step_x<false, false>" in r.get("Kernel_Name", ""):
             vals[r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, v in sorted(vals.items()):
     print(f"{k:34s} n={len(v):4d} median {statistics.median(v):14.0f} max {max(v):14.0f}")

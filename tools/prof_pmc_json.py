@@ -21,7 +21,7 @@ for prec in ("fp32", "bf16"):
     d = os.path.join(root, prec)
     if not os.path.isdir(d):
         continue
-    kern = "k_step_x<false>"
+    kern = "k_step_x<false, false>"  # (PRE = false, LEAN = false: the fused launch of the headline shape)
     dur = []
     for f in glob.glob(os.path.join(d, "stats", "**", "*kernel_trace.csv"), recursive=True):
         for r in csv.DictReader(open(f, newline="")):
