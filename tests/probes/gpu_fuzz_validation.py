@@ -22,6 +22,7 @@ EDGE_A = [1, 2, 15, 16, 17, 31, 33, 48, 65]
 EDGE_P = [2, 16, 31, 33, 64, 65, 130]
 EDGE_T = [1, 2, 15, 33, 40]
 worst = 0.0
+n_outside = 0
 for ci in range(n_cases):
     a, p, t = int(rng.choice(EDGE_A)), int(rng.choice(EDGE_P)), int(rng.choice(EDGE_T))
     n_scene, step_end = int(rng.integers(1, 4)), int(rng.choice([15, 30, 90]))
@@ -100,5 +101,10 @@ for ci in range(n_cases):
           f"  {'ok' if not msgs else 'FAIL: ' + '; '.join(msgs)}", flush=True)
     if msgs:
         print(scene, over)
+        # FUZZ_KEEP_GOING=1: a case that is ONLY outside the closed-loop envelope (a statistical statement about a chaotic loop, see
+        # tests/probes/gpu_fuzz_case_detail.py) is counted and the run goes on; anything else still stops it
+        if os.environ.get("FUZZ_KEEP_GOING") and msgs == ["closed-loop envelope"]:
+            n_outside += 1
+            continue
         sys.exit(1)
-print(f"all {n_cases} cases ok; worst replay xy error {worst:.2e}")
+print(f"all {n_cases} cases ok; worst replay xy error {worst:.2e}" + (f"; {n_outside} outside the closed-loop envelope" if n_outside else ""))
