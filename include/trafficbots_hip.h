@@ -164,6 +164,13 @@ typedef struct tb_step_override {
     const float* acc;            /* [N,A]   state_override["acc"] */
     const float* yaw_rate;       /* [N,A]   state_override["yaw_rate"] */
     const uint8_t* gt_valid;     /* [N,A] or NULL */
+    /* `forward(action_override=, mask_action_override=)` (waymo_motion.py:116-117,174-175 -> Dynamics.update, dynamics.py:96-100): where
+     * action_mask[n,a] is set and the agent is valid BEFORE this step, the dynamics update of this step uses action[n,a] = (acceleration
+     * m/s^2, yaw rate rad/s) instead of the policy's tanh-bounded action; action_log_prob stays that of the policy's own action.  Both
+     * or neither.  Independent of the state override: with mask == NULL (and the four state arrays NULL) the step takes the teacher
+     * forcing bound at tb_rollout_begin, as tb_rollout_step does. */
+    const float* action;         /* [N,A,2] or NULL */
+    const uint8_t* action_mask;  /* [N,A]   or NULL */
 } tb_step_override;
 /* tb_rollout_step_ex(ctx, NULL, s) == tb_rollout_step(ctx, s) */
 int tb_rollout_step_ex(tb_ctx* ctx, const tb_step_override* ov, tb_stream stream);

@@ -403,8 +403,10 @@ class Oracle:
     def rollout(self, inp: Dict[str, Tensor], f: Dict[str, Tensor], z: Tensor, latent_mean: Tensor, dest: Tensor,
                 goal_valid: Tensor, k: int, step_end: int, tap_steps=(), gt: Optional[Dict[str, Tensor]] = None,
                 tf_cfg_name: str = "teacher_forcing_joint_future_pred", log_std_name: str = "prior",
-                action_eps: Optional[Tensor] = None) -> Dict[str, Tensor]:
-        """`action_eps` [N, A, S, 2]: `deterministic_action=False` (`dynamics.py:77`): step s samples the unbounded action as
+                action_eps: Optional[Tensor] = None, action_override=None) -> Dict[str, Tensor]:
+        """`action_override` = (action [N,A,S,2] physical units, mask [N,A,S]): the reference's `forward(action_override=,
+        mask_action_override=)` at every step (`dynamics.py:96-100`).
+        `action_eps` [N, A, S, 2]: `deterministic_action=False` (`dynamics.py:77`): step s samples the unbounded action as
         mean + eps[:, :, s] * exp(log_std) (`Normal.rsample`) and scores it with `Normal.log_prob` summed over the two dims.
         `WaymoMotion.rollout` + `forward` + `Dynamics` + always-on `TrafficRuleChecker` + buffer
         (`waymo_motion.py:205-354,108-203`, `dynamics.py:50-167,187-228`,
@@ -499,6 +501,10 @@ class Oracle:
             act = torch.tanh(u)
             act = torch.stack([act[..., 0] * max_acc, act[..., 1] * max_yr], -1)
             act = act.masked_fill(~(has_type & valid).unsqueeze(-1), 0)
+            if action_override is not None:  # dynamics.py:96-100 (after the per-type masking; only for valid agents)
+                s_i = t - self.cfg["time_step_sim_start"]
+                am = torch.as_tensor(action_override[1][:, :, s_i]).bool() & valid
+                act = torch.where(am.unsqueeze(-1), _t(action_override[0][:, :, s_i], d), act)
             # MultiPathPP.update (`dynamics.py:208-221`)
             a_, w_ = act[:, :, 0], act[:, :, 1]
             v_t = state[:, :, 3] + 0.5 * self.dt * a_
@@ -563,7 +569,7 @@ class Oracle:
     # ------------------------------------------------------------------ end to end
     def joint_future_pred(self, batch: Dict[str, np.ndarray], k: int, eps: Optional[np.ndarray], step_end: int,
                           dest_override: Optional[np.ndarray] = None, tap_steps=(), use_gt: bool = False,
-                          action_eps: Optional[np.ndarray] = None) -> Dict[str, Tensor]:
+                          action_eps: Optional[np.ndarray] = None, action_override=None) -> Dict[str, Tensor]:
         """Prologue of `WaymoMotion.test_step` + `joint_future_pred` (`waymo_motion.py:902-933,478-572`).
         `eps` [N,A,16] are the standard-normal draws of the latent sample; `dest_override` [N,A]
         replaces the destination sample (instances k>0 are multinomial draws in the reference)."""
@@ -590,7 +596,8 @@ class Oracle:
         # validation_step leaves batch["agent/*"] = the 91-step ground truth in place (waymo_motion.py:538-545), which the kill
         # rule and goal_reached then see; test_step overwrites it with the history (:925-926)
         gt = self.preprocess_gt(batch) if use_gt else None
-        res = self.rollout(inp, f, z, mean, dest, goal_valid, k, step_end, tap_steps, gt=gt, action_eps=action_eps)
+        res = self.rollout(inp, f, z, mean, dest, goal_valid, k, step_end, tap_steps, gt=gt, action_eps=action_eps,
+                           action_override=action_override)
         # RolloutBuffer.flatten_repeat (`buffer.py:92-123`): [N,A,S,..] -> [B,A,K,S,..]
         for key in ("preds", "valid", "override_masks", "outside_map", "outside_map_this_step", "dest_reached",
                     "dest_reached_this_step", "action_log_probs", "latent_log_probs", "goal_reached", "goal_reached_this_step"):

@@ -22,6 +22,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 
+import ensemble  # noqa: E402
 import ref_shim  # noqa: E402
 from trafficbots_amd import synth  # noqa: E402
 from trafficbots_amd.config import load_model_config  # noqa: E402
@@ -88,12 +89,35 @@ CASES["rules_passive"] = dict(
     tap_steps=[], fp64=False, store_feats=False, rule_flags=True,
 )
 
+# `forward(action_override=, mask_action_override=)` (waymo_motion.py:116-117,174-175 -> dynamics.py:96-100): the reference's rollout()
+# never passes them, so its forward is wrapped to add step s of synth.make_action_override(base_seed + 55, ...) to every call
+CASES["action_override"] = dict(
+    base_seed=8500, n_scene=2, k=2, weight_seed=9, time_step_end=40,
+    scene=dict(n_agent=12, n_pl=40, n_tl=40, p_invalid_agent=0.2, p_late_spawn=0.3, pos_range=120.0),
+    tap_steps=[], fp64=True, store_feats=False, action_override=True,
+)
+
+# the headline shape under three other weight distributions (synth.make_state_dict(mode=...)); one scene,
+# K = 2 (deterministic + one sampled personality), full taps
+for _i, _mode in enumerate(("normal", "sharp", "ln_gamma")):
+    CASES[f"headline_w_{_mode}"] = dict(
+        base_seed=9500 + 10 * _i, n_scene=1, k=2, weight_seed=21 + _i, weight_mode=_mode, time_step_end=90,
+        scene=dict(n_agent=64, n_pl=256, n_tl=40), tap_steps=[1, 11, 50], fp64=True, store_feats=True,
+    )
+
+# members of the measured rounding-noise ensemble (tools/ensemble.py) per closed-loop golden
+N_ENSEMBLE = 16
+ENSEMBLE_CASES = ("small_k1", "masks_k3", "degenerate", "headline_2", "headline_k6", "stoch_actions", "action_override",
+                  "headline_w_normal", "headline_w_sharp", "headline_w_ln_gamma")
+
 RULE_KEYS = ["collided", "collided_this_step", "run_road_edge", "run_road_edge_this_step", "run_red_light",
              "run_red_light_this_step", "passive", "passive_this_step"]
 
 
-def run_reference(case: dict, dtype=torch.float32, force_goal_sample=None) -> dict:
-    """`force_goal_sample` [B,A,K] (the fp32 run's destinations): the fp64 twin must follow the SAME sampled destinations -- the
+def run_reference(case: dict, dtype=torch.float32, force_goal_sample=None, perturb=None) -> dict:
+    """`perturb` = (seed, n_pad_scene): an ensemble member (tools/ensemble.py) -- agent slots, polylines and stop points of every scene
+    permuted, `n_pad_scene` further scenes appended; agent-indexed outputs come back in the ORIGINAL order and without the padding.
+    `force_goal_sample` [B,A,K] (the fp32 run's destinations): the fp64 twin must follow the SAME sampled destinations -- the
     multinomial draw of `DestCategorical.sample` depends on the dtype of the probabilities -- so the sampler is replaced by the stored
     indices for that run (argmax destinations of instance 0 are checked to agree anyway)."""
     over = {"time_step_end": case["time_step_end"], "n_joint_future": case["k"]}
@@ -104,17 +128,28 @@ def run_reference(case: dict, dtype=torch.float32, force_goal_sample=None) -> di
     sc = case["scene"]
     torch.set_default_dtype(torch.float32)
     model = ref_shim.build_reference(cfg, n_agent=sc["n_agent"], n_pl=sc["n_pl"], n_tl=sc.get("n_tl", 40))
-    sd = synth.make_state_dict(case["weight_seed"])
+    sd = synth.make_state_dict(case["weight_seed"], mode=case.get("weight_mode"))
     missing = model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()}, strict=True)
     assert not missing.missing_keys and not missing.unexpected_keys
     batch_np = synth.make_batch(case["base_seed"], case["n_scene"], **sc)
+    perm, n_pad = None, 0
+    if perturb is not None:
+        n_pad = int(perturb[1])
+        pad = synth.make_batch(case["base_seed"] + 555, n_pad, **sc) if n_pad else None
+        batch_np, perm = ensemble.permute_batch(batch_np, perturb[0], pad=pad)
     batch = {k: torch.from_numpy(v.copy()) for k, v in batch_np.items()}
     if dtype == torch.float64:
         model = model.double()
         batch = {k: (v.double() if v.dtype == torch.float32 else v) for k, v in batch.items()}
         torch.set_default_dtype(torch.float64)  # GRU zero state uses the default dtype (agent_temporal.py:131)
-    n_inst = case["n_scene"] * case["k"]
-    eps = torch.from_numpy(synth.make_latent_noise(case["base_seed"] + 99, n_inst, sc["n_agent"])).to(dtype)
+    n_keep = case["n_scene"] * case["k"]
+    n_inst = (case["n_scene"] + n_pad) * case["k"]
+    eps_np = synth.make_latent_noise(case["base_seed"] + 99, n_keep, sc["n_agent"])
+    if perm is not None:
+        eps_np = perm.agents_fwd(eps_np, case["k"])
+        if n_pad:
+            eps_np = np.concatenate([eps_np, synth.make_latent_noise(case["base_seed"] + 98, n_pad * case["k"], sc["n_agent"])], 0)
+    eps = torch.from_numpy(eps_np).to(dtype)
 
     import torch.distributions.normal as tdn
 
@@ -123,7 +158,12 @@ def run_reference(case: dict, dtype=torch.float32, force_goal_sample=None) -> di
     act_eps = None
     act_i = {"i": 0}
     if case.get("action_noise"):
-        act_eps = torch.from_numpy(synth.make_action_noise(case["base_seed"] + 77, n_inst, sc["n_agent"], n_step)).to(dtype)
+        act_np = synth.make_action_noise(case["base_seed"] + 77, n_keep, sc["n_agent"], n_step)
+        if perm is not None:
+            act_np = perm.agents_fwd(act_np, case["k"])
+            if n_pad:
+                act_np = np.concatenate([act_np, synth.make_action_noise(case["base_seed"] + 76, n_pad * case["k"], sc["n_agent"], n_step)], 0)
+        act_eps = torch.from_numpy(act_np).to(dtype)
 
     def fake_std_normal(shape, dtype, device):
         if tuple(shape) == tuple(eps.shape):
@@ -185,12 +225,34 @@ def run_reference(case: dict, dtype=torch.float32, force_goal_sample=None) -> di
 
                 TrafficRuleChecker.check = spy_check
             if force_goal_sample is not None:
-                forced = torch.from_numpy(np.ascontiguousarray(np.transpose(force_goal_sample, (0, 2, 1)))).reshape(n_inst, -1)
+                forced_np = np.ascontiguousarray(np.transpose(force_goal_sample, (0, 2, 1))).reshape(n_keep, -1)  # [N,A]
+                if perm is not None:
+                    forced_np = perm.dest_fwd(forced_np, case["k"])
+                    if n_pad:  # the padding scenes take their own argmax destinations
+                        own = goal_pred.distribution.logits.argmax(-1)[case["n_scene"]:]  # [pad,A]
+                        forced_np = np.concatenate([forced_np, own.repeat_interleave(case["k"], 0).numpy()], 0)
+                forced = torch.from_numpy(forced_np)
 
                 def forced_sample(deterministic, _f=forced):
                     return _f.clone()
 
                 goal_pred.sample = forced_sample  # (instance attribute: joint_future_pred calls goal.sample(deterministic), :500)
+            if case.get("action_override"):
+                ao_np, am_np = synth.make_action_override(case["base_seed"] + 55, n_keep, sc["n_agent"], n_step)
+                if perm is not None:
+                    ao_np, am_np = perm.agents_fwd(ao_np, case["k"]), perm.agents_fwd(am_np, case["k"])
+                    if n_pad:
+                        ao_np = np.concatenate([ao_np, np.zeros((n_pad * case["k"],) + ao_np.shape[1:], ao_np.dtype)], 0)
+                        am_np = np.concatenate([am_np, np.zeros((n_pad * case["k"],) + am_np.shape[1:], bool)], 0)
+                ao_t, am_t, ao_i = torch.from_numpy(ao_np).to(dtype), torch.from_numpy(am_np), {"i": 0}
+                orig_forward = model.forward
+
+                def forward_with_action_override(*a_, **k_):
+                    i = ao_i["i"]
+                    ao_i["i"] += 1
+                    return orig_forward(*a_, **{**k_, "action_override": ao_t[:, :, i], "mask_action_override": am_t[:, :, i]})
+
+                model.forward = forward_with_action_override
             if act_eps is not None:  # joint_future_pred calls rollout(deterministic_action=True) (waymo_motion.py:560)
                 orig_rollout = model.rollout
                 model.rollout = lambda *a_, **k_: orig_rollout(*a_, **{**k_, "deterministic_action": False})
@@ -227,12 +289,63 @@ def run_reference(case: dict, dtype=torch.float32, force_goal_sample=None) -> di
         final_hidden=model.model.hidden,
     )
     out.update(taps)
-    return {k: (v.detach().cpu().numpy() if torch.is_tensor(v) else v) for k, v in out.items()}
+    out = {k: (v.detach().cpu().numpy() if torch.is_tensor(v) else v) for k, v in out.items()}
+    if perm is not None:
+        out = _unpermute(out, perm, case["n_scene"], case["k"], sc["n_agent"])
+    return out
+
+
+def _unpermute(out: dict, perm, b: int, k: int, a: int) -> dict:
+    """Ensemble member -> the base run's ordering, for the keys the ensemble statistics use."""
+    res = {}
+    for key in ("preds", "valid"):  # [B+pad, A, K, S(,4)]
+        res[key] = perm.agents_back(out[key][:b], 1)
+    for key in ("final_state", "final_valid", "latent_sample"):  # [N+pad, A, ...]
+        res[key] = perm.agents_back(out[key][: b * k], k)
+    n_all = out["final_hidden"].shape[1] // a
+    hid = lambda h: np.stack([perm.agents_back(x.reshape(n_all, a, -1)[: b * k], k) for x in h], 0).reshape(h.shape[0], b * k * a, -1)  # noqa: E731
+    res["final_hidden"] = hid(out["final_hidden"])
+    for key, v in out.items():
+        if not key.startswith("tap"):
+            continue
+        res[key] = hid(v) if key.endswith("/hidden") else perm.agents_back(v[: b * k], k)
+    return res
+
+
+def run_ensemble(name: str, case: dict, r32: dict, r64: dict) -> dict:
+    """N_ENSEMBLE further fp32 runs of THE REFERENCE on mathematically equivalent re-orderings of the batch (tools/ensemble.py:
+    agent slots, polylines, stop points permuted per scene; every other member also at another batch size), destinations forced to the
+    base run's.  Stored (what the parity tests bound the HIP path with):
+      ens_d32 [M,S]    per member, per step: max |member - base fp32| over xy of the entries valid in both;
+      ens_d64 [M+1,S]  per member (row 0 = the base run): max |member - fp64 twin|;
+      ens_tap{s}/{policy_feature,hidden,agent_feature}, ens_final_hidden, ens_final_state: max over members of max |member - base|."""
+    step_axis = 3
+    d32, d64 = [], [ensemble.spread_per_step(r32["preds"], r64["preds"], r32["valid"] & r64["valid"], step_axis)]
+    scal = {}
+    flips = 0
+    for i in range(N_ENSEMBLE):
+        m = run_reference(case, torch.float32, force_goal_sample=r32["goal_sample"], perturb=(1000 * case["base_seed"] + i, (i % 2) * (1 + i // 4)))
+        both = m["valid"] & r32["valid"]
+        flips += int((m["valid"] != r32["valid"]).sum())
+        d32.append(ensemble.spread_per_step(m["preds"], r32["preds"], both, step_axis))
+        d64.append(ensemble.spread_per_step(m["preds"], r64["preds"], m["valid"] & r64["valid"], step_axis))
+        fv = (m["final_valid"] & r32["final_valid"])[..., None]
+        for key in [k for k in m if k.startswith("tap") and k.split("/")[1] in ("policy_feature", "hidden", "agent_feature")] + ["final_hidden"]:
+            scal["ens_" + key] = max(scal.get("ens_" + key, 0.0), float(np.abs(m[key] - r32[key]).max()))
+        scal["ens_final_state"] = max(scal.get("ens_final_state", 0.0), float((np.abs(m["final_state"] - r32["final_state"]) * fv).max()))
+    d32, d64 = np.stack(d32), np.stack(d64)
+    print(f"[{name}] ensemble of {N_ENSEMBLE}: max spread vs base fp32 {d32.max():.3e} (median member {np.median(d32.max(1)):.3e}); "
+          f"vs fp64 {d64[1:].max():.3e} (base {d64[0].max():.3e}); valid-flag flips {flips}; "
+          + ", ".join(f"{k[4:]} {v:.2e}" for k, v in sorted(scal.items())))
+    out = {"ens_d32": d32.astype(np.float32), "ens_d64": d64.astype(np.float32)}
+    out.update({k: np.float32(v) for k, v in scal.items()})
+    return out
 
 
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", nargs="*", default=None)
+    ap.add_argument("--no-ensemble", action="store_true")
     args = ap.parse_args()
     os.makedirs(GOLDEN_DIR, exist_ok=True)
     torch.set_num_threads(os.cpu_count())
@@ -272,6 +385,8 @@ def main() -> None:
             m = (r64["valid"] & r32["valid"])[..., None]
             print(f"[{name}] reference fp32 vs fp64 max|dxy| = {float((d * m).max()):.3e}; "
                   f"goal_sample equal: {bool((r64['goal_sample'] == r32['goal_sample']).all())}")
+        if name in ENSEMBLE_CASES and not args.no_ensemble:
+            save.update(run_ensemble(name, case, r32, r64))
         meta = {k: v for k, v in case.items()}
         save["meta_json"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
         path = os.path.join(GOLDEN_DIR, f"{name}.npz")

@@ -22,6 +22,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 
+import ensemble  # noqa: E402
 import ref_shim  # noqa: E402
 from trafficbots_amd import synth  # noqa: E402
 from trafficbots_amd.config import load_model_config  # noqa: E402
@@ -68,7 +69,12 @@ RULE = ("counter_agent", "counter_veh", "outside_map", "collided", "run_road_edg
         "dest_reached")
 
 
-def run_reference(case: dict, dtype=torch.float32) -> dict:
+N_ENSEMBLE = 16
+
+
+def run_reference(case: dict, dtype=torch.float32, perturb=None) -> dict:
+    """`perturb` = seed of an ensemble member (tools/ensemble.py: agent slots, polylines, stop points permuted per scene); only the
+    replayed trajectory comes back, in the original agent order."""
     over = {"time_step_end": case["time_step_end"], "n_joint_future": 1}
     over.update(case["overrides"])
     cfg = load_model_config(overrides=over)
@@ -77,7 +83,10 @@ def run_reference(case: dict, dtype=torch.float32) -> dict:
     model = ref_shim.build_reference(cfg, n_agent=sc["n_agent"], n_pl=sc["n_pl"], n_tl=sc.get("n_tl", 40))
     sd = synth.make_state_dict(case["weight_seed"])
     model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()}, strict=True)
-    batch = {k: torch.from_numpy(v.copy()) for k, v in synth.make_val_batch(case["base_seed"], case["n_scene"], **sc).items()}
+    batch_np, perm = synth.make_val_batch(case["base_seed"], case["n_scene"], **sc), None
+    if perturb is not None:
+        batch_np, perm = ensemble.permute_batch(batch_np, perturb)
+    batch = {k: torch.from_numpy(v.copy()) for k, v in batch_np.items()}
     if dtype == torch.float64:
         model = model.double()
         batch = {k: (v.double() if v.dtype == torch.float32 else v) for k, v in batch.items()}
@@ -106,6 +115,8 @@ def run_reference(case: dict, dtype=torch.float32) -> dict:
                        diffbar_rewards=buf.diffbar_rewards.clone(), diffbar_rewards_valid=buf.diffbar_rewards_valid.clone(),
                        latent_log_probs=buf.latent_log_probs.clone(), dest_reached=buf.violations["dest_reached"].clone(),
                        outside_map=buf.violations["outside_map"].clone(), goal_reached=buf.violations["goal_reached"].clone())
+            if perm is not None:
+                return {"preds": perm.agents_back(raw["preds"].numpy()), "valid": perm.agents_back(raw["valid"].numpy())}
             buf.flatten_repeat(1)
             s0 = cfg["time_step_sim_start"]
             model.err_metrics_reactive_replay.update(
@@ -170,6 +181,15 @@ def main() -> None:
             d = np.abs(r64["preds"][..., :2] - r32["preds"][..., :2].astype(np.float64)) * m
             print(f"[{name}] reference fp32 vs fp64: max|dxy| {d.max():.3e}; post_mean "
                   f"{np.abs(r64['post_mean'] - r32['post_mean']).max():.3e}")
+        if case["fp64"]:
+            d32, d64 = [], [ensemble.spread_per_step(r32["preds"], r64["preds"], r32["valid"] & r64["valid"], 2)]
+            for i in range(N_ENSEMBLE):
+                mem = run_reference(case, torch.float32, perturb=1000 * case["base_seed"] + i)
+                d32.append(ensemble.spread_per_step(mem["preds"], r32["preds"], mem["valid"] & r32["valid"], 2))
+                d64.append(ensemble.spread_per_step(mem["preds"], r64["preds"], mem["valid"] & r64["valid"], 2))
+            save["ens_d32"], save["ens_d64"] = np.stack(d32).astype(np.float32), np.stack(d64).astype(np.float32)
+            print(f"[{name}] ensemble of {N_ENSEMBLE}: max spread vs base fp32 {save['ens_d32'].max():.3e}, vs fp64 "
+                  f"{save['ens_d64'][1:].max():.3e} (base {save['ens_d64'][0].max():.3e})")
         save["meta_json"] = np.frombuffer(json.dumps(case).encode(), dtype=np.uint8)
         path = os.path.join(GOLDEN_DIR, f"{name}.npz")
         np.savez_compressed(path, **save)

@@ -950,15 +950,23 @@ extern "C" int tb_rollout_step_ex(tb_ctx* ctx, const tb_step_override* ov, tb_st
     tb::RolloutP p = ctx->step_p;
     if (ov) {
         if (ctx->step_kernel < 2) return tb_fail(ctx, "tb_rollout_step_ex: per-call overrides need the XDL step kernel (TB_STEP_KERNEL=fp32 is the A/B twin only)");
-        if (!ov->mask) return tb_fail(ctx, "tb_rollout_step_ex: tb_step_override.mask is NULL");
-        if (!ov->agent_state || !ov->vel || !ov->acc || !ov->yaw_rate)
-            return tb_fail(ctx, "tb_rollout_step_ex: agent_state / vel / acc / yaw_rate must all be given (they are read only where mask is set)");
-        p.ovr_mask = ov->mask;
-        p.ovr_state = ov->agent_state;
-        p.ovr_vel = ov->vel;
-        p.ovr_acc = ov->acc;
-        p.ovr_yaw_rate = ov->yaw_rate;
-        p.ovr_gt_valid = ov->gt_valid;
+        if ((ov->action == nullptr) != (ov->action_mask == nullptr))
+            return tb_fail(ctx, "tb_rollout_step_ex: action and action_mask go together");
+        if (!ov->mask && !ov->action_mask) return tb_fail(ctx, "tb_rollout_step_ex: tb_step_override holds neither a state mask nor an action mask");
+        if (ov->mask) {
+            if (!ov->agent_state || !ov->vel || !ov->acc || !ov->yaw_rate)
+                return tb_fail(ctx, "tb_rollout_step_ex: agent_state / vel / acc / yaw_rate must all be given (they are read only where mask is set)");
+            p.ovr_mask = ov->mask;
+            p.ovr_state = ov->agent_state;
+            p.ovr_vel = ov->vel;
+            p.ovr_acc = ov->acc;
+            p.ovr_yaw_rate = ov->yaw_rate;
+            p.ovr_gt_valid = ov->gt_valid;
+        } else if (ov->agent_state || ov->vel || ov->acc || ov->yaw_rate || ov->gt_valid) {
+            return tb_fail(ctx, "tb_rollout_step_ex: state arrays / gt_valid without tb_step_override.mask");
+        }
+        p.ovr_action = ov->action;
+        p.ovr_action_mask = ov->action_mask;
     }
     step_launch(ctx, p, p, t, /*do_c=*/1, /*do_a=*/t < ctx->step_end, (hipStream_t)stream_);
     ctx->step_next = t + 1;

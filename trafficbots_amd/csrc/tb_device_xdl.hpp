@@ -1159,8 +1159,11 @@ __device__ __forceinline__ void kv_helper_x(const float* __restrict__ W, const u
 __device__ __forceinline__ unsigned int kv_peek_x(const unsigned int* __restrict__ inst_flags, int n_rt, int layer, int tid) {
     return tid < n_rt ? __hip_atomic_load(inst_flags + tid * 2 + (layer - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
 }
+// A wait that gives up does NOT let the tile continue silently on stale K / V: it raises the context's sticky word
+// (tb_check_status) AND the tile's `poison` word in LDS, which makes the epilogue write NaN as this step's prediction and state -- the
+// NaN then spreads through the interaction to the whole instance, so any consumer of the trajectories sees it, checked or not.
 __device__ __forceinline__ void kv_wait_x(const unsigned int* __restrict__ inst_flags, int n_rt, int layer, unsigned int token, int tid,
-                                          unsigned int* __restrict__ sync_err, unsigned int seen) {
+                                          unsigned int* __restrict__ sync_err, unsigned int seen, int* poison) {
     if (tid < n_rt && seen != token) {
         const unsigned int* f = inst_flags + tid * 2 + (layer - 1);
         int spins = 0;
@@ -1168,6 +1171,7 @@ __device__ __forceinline__ void kv_wait_x(const unsigned int* __restrict__ inst_
             __builtin_amdgcn_s_sleep(8);
             if (++spins > (1 << 18)) {
                 *sync_err = 1u;
+                *poison = 1;
                 break;
             }
         }

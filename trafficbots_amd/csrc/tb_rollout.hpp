@@ -78,6 +78,10 @@ struct RolloutP {
     const float* ovr_acc;         // [N,A]
     const float* ovr_yaw_rate;    // [N,A]
     const uint8_t* ovr_gt_valid;  // [N,A], or nullptr = no ground truth: every agent that leaves the map is killed
+    // per-call action override (the reference's forward(action_override=, mask_action_override=), dynamics.py:96-100), independent of
+    // the state override above: where the mask is set and the agent is valid, the physical action replaces the policy's in THIS step
+    const float* ovr_action;      // [N,A,2] acc (m/s^2), yaw rate (rad/s)
+    const uint8_t* ovr_action_mask;  // [N,A], or nullptr
     const int32_t* agent_type;    // [B,A]
     const float* agent_size;      // [B,A,3]
     // rule checker geometry

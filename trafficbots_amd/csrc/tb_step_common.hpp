@@ -274,10 +274,11 @@ __device__ __forceinline__ void step_epilogue(const RolloutP& p, int t, int n, i
 // so neither stage opens with a dependent round trip to memory.  (k_step_x; the fp32-MFMA twin keeps its own loads.)
 struct EpiRegs {
     f32x4 hst, hax, sz, bd;
-    float ls[6], ae[2];
+    float ls[6], ae[2], ao[2];
     int flags;
 };
-constexpr int EPI_FLAG_KILLED = 1, EPI_FLAG_OUTSIDE = 2, EPI_FLAG_DREACHED = 4, EPI_FLAG_OVR = 8, EPI_FLAG_GTV = 16;
+constexpr int EPI_FLAG_KILLED = 1, EPI_FLAG_OUTSIDE = 2, EPI_FLAG_DREACHED = 4, EPI_FLAG_OVR = 8, EPI_FLAG_GTV = 16, EPI_FLAG_AOVR = 32;
+constexpr int EPI_POISON_WORD = 17;  // StepSmall::dflag[17]: a helper hand-off timed out in this launch (kv_wait_x) -> NaN out
 constexpr int EPI_ENCH_SIZE = 0, EPI_ENCH_BD = 48, EPI_ENCH_LS = 52;  // offsets (floats) inside StepSmall::ench
 
 struct TfSource {
@@ -309,7 +310,7 @@ __device__ __forceinline__ TfSource tf_source(const RolloutP& p, int t, int n, i
 // threads 16 .. 31: the epilogue record of agent tid - 16; threads 32 .. 47: the size of agent tid - 32; thread 48: tile constants
 __device__ __forceinline__ void epi_issue(const RolloutP& p, int t, int n, int b, int row0, int n_real, int tid, bool do_c, EpiRegs& e) {
     e.flags = 0;
-    e.ae[0] = e.ae[1] = 0.f;
+    e.ae[0] = e.ae[1] = e.ao[0] = e.ao[1] = 0.f;
     e.hst = e.hax = e.sz = e.bd = splat(0.f);
 #pragma unroll
     for (int i = 0; i < 6; ++i) e.ls[i] = 0.f;
@@ -325,8 +326,15 @@ __device__ __forceinline__ void epi_issue(const RolloutP& p, int t, int n, int b
             e.ae[0] = ap[0];
             e.ae[1] = ap[1];
         }
+        uint8_t am0 = 0;
+        if (p.ovr_action_mask) {  // per-call action override (tb_step_override.action / action_mask; dynamics.py:96-100)
+            const size_t ai = (size_t)n * p.n_agent + rowc;
+            am0 = p.ovr_action_mask[ai];
+            e.ao[0] = p.ovr_action[ai * 2];
+            e.ao[1] = p.ovr_action[ai * 2 + 1];
+        }
         e.flags = (k0 ? EPI_FLAG_KILLED : 0) | (o0 ? EPI_FLAG_OUTSIDE : 0) | (d0 ? EPI_FLAG_DREACHED : 0) | (m0 ? EPI_FLAG_OVR : 0) |
-                  (g0 ? EPI_FLAG_GTV : 0);
+                  (g0 ? EPI_FLAG_GTV : 0) | (am0 ? EPI_FLAG_AOVR : 0);
     } else if (tid >= 32 && tid < 48) {
         const int a = tid - 32;
         if (a < n_real) {
@@ -350,6 +358,8 @@ __device__ __forceinline__ void epi_commit(int tid, bool do_c, const EpiRegs& e,
         reinterpret_cast<int*>(r)[8] = e.flags;
         r[9] = e.ae[0];
         r[10] = e.ae[1];
+        r[11] = e.ao[0];
+        r[12] = e.ao[1];
     } else if (tid >= 32 && tid < 48) {
         float* r = sm.ench + EPI_ENCH_SIZE + (tid - 32) * 3;
         r[0] = e.sz.x; r[1] = e.sz.y; r[2] = e.sz.z;
@@ -379,11 +389,16 @@ __device__ __forceinline__ void step_epilogue16(const RolloutP& p, int t, int n,
     uint8_t killed0, outside0, dreached0, ovr0, gtv0;
     f32x4 hst, hax, bd;
     float ae0 = 0.f, ae1 = 0.f;  // standard-normal draws of a sampled action (RolloutP::action_eps)
+    float ao0 = 0.f, ao1 = 0.f;  // action override in physical units (RolloutP::ovr_action), applied where aovr
+    bool aovr = false;
     if (PREF) {
         const float* r = sm.attr + a * 16;
         ae0 = r[9];
         ae1 = r[10];
+        ao0 = r[11];
+        ao1 = r[12];
         const int fl = reinterpret_cast<const int*>(r)[8];
+        aovr = (fl & EPI_FLAG_AOVR) != 0;
         killed0 = (fl & EPI_FLAG_KILLED) != 0; outside0 = (fl & EPI_FLAG_OUTSIDE) != 0; dreached0 = (fl & EPI_FLAG_DREACHED) != 0;
         ovr0 = (fl & EPI_FLAG_OVR) != 0; gtv0 = (fl & EPI_FLAG_GTV) != 0;
         hst = lds4(r);
@@ -400,6 +415,12 @@ __device__ __forceinline__ void step_epilogue16(const RolloutP& p, int t, int n,
             const float* ap = p.action_eps + (((size_t)n * p.n_agent + rowc) * p.n_step_out + (t - p.step_start)) * 2;
             ae0 = ap[0];
             ae1 = ap[1];
+        }
+        if (p.ovr_action_mask) {
+            const size_t ai = (size_t)n * p.n_agent + rowc;
+            aovr = p.ovr_action_mask[ai] != 0;
+            ao0 = p.ovr_action[ai * 2];
+            ao1 = p.ovr_action[ai * 2 + 1];
         }
     }
     const int ty = rtype[a];
@@ -423,6 +444,12 @@ __device__ __forceinline__ void step_epilogue16(const RolloutP& p, int t, int n,
     if (have) {
         acc_ = fmul_(tanhf(us[0]), pw.max_acc[ty]);
         yr_ = fmul_(tanhf(us[1]), pw.max_yaw_rate[ty]);
+        // action_override (dynamics.py:96-100): where (mask & agent_valid) the physical action [acc m/s^2, yaw rate rad/s] replaces the
+        // policy's; action_log_prob stays that of the policy's own sample
+        if (aovr) {
+            acc_ = ao0;
+            yr_ = ao1;
+        }
     }
     const float half_dt = 0.5f * pw.dt;
     const float v_t = fadd_(st.w, fmul_(half_dt, acc_));
@@ -435,6 +462,7 @@ __device__ __forceinline__ void step_epilogue16(const RolloutP& p, int t, int n,
     pred.z = fadd_(st.z, fmul_(pw.dt, yr_));
     pred.w = fadd_(st.w, fmul_(pw.dt, acc_));
     if (!have) pred = splat(0.f);
+    if (dflag[EPI_POISON_WORD]) pred = splat(__builtin_nanf(""));  // stale interaction K / V were used: fail loudly, not plausibly
     // action_dist.log_prob(sample), masked to 0 for invalid agents (dynamics.py:80; torch Normal.log_prob:
     // -((x - mu)^2) / (2 var) - log(scale) - log(sqrt(2 pi)), summed over the two dims)
     float alp = 0.f;

@@ -253,6 +253,7 @@ __global__ __launch_bounds__(NTHREADS, LEAN ? 2 : 1) void k_step_x(RolloutP p, i
     TB_SCHED_FENCE();
     if (do_a) encw_commit(tid, encw, ENCW);
     if (!PRE) epi_commit(tid, do_c != 0, epi, sm);
+    if (tid == TM) dflag[EPI_POISON_WORD] = 0;
     if (tid < TM) {
         rtype[tid] = rs_ty;
         rst[tid].st[0] = rs_st.x; rst[tid].st[1] = rs_st.y; rst[tid].st[2] = rs_st.z; rst[tid].st[3] = rs_st.w;
@@ -296,13 +297,13 @@ __global__ __launch_bounds__(NTHREADS, LEAN ? 2 : 1) void k_step_x(RolloutP p, i
             xattn_layer_x<!LEAN, true>(W, pw.inter[0], px.inter[0], X, PA, PB, K0, V0, kvd, nk_a, ks_a, row0, rowvalid, novalid_s, tid, u,
                                 xlayer_first_x(W, pw.inter[1], px.inter[1], wave), (LEAN ? nullptr : LN + 0 * 768), nullptr, amax);
             if (helpers) {
-                kv_wait_x(kvf, n_rt, 1, tok, tid, p.sync_err, seen);
+                kv_wait_x(kvf, n_rt, 1, tok, tid, p.sync_err, seen, dflag + EPI_POISON_WORD);
                 seen = kv_peek_x(kvf, n_rt, 2, tid);
             }
             xattn_layer_x<!LEAN, true>(W, pw.inter[1], px.inter[1], X, PA, PB, K0 + 2 * ls, V0 + 2 * ls, kvd, nk_a, ks_a, row0, rowvalid, novalid_s, tid,
                                 u, xlayer_first_x(W, pw.inter[2], px.inter[2], wave), (LEAN ? nullptr : LN + 1 * 768), nullptr, amax);
             if (helpers) {
-                kv_wait_x(kvf, n_rt, 2, tok, tid, p.sync_err, seen);
+                kv_wait_x(kvf, n_rt, 2, tok, tid, p.sync_err, seen, dflag + EPI_POISON_WORD);
                 if (tid == 0) gh_seen = __hip_atomic_load(p.gh_flag + tile_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             xattn_layer_x<!LEAN, true>(W, pw.inter[2], px.inter[2], X, PA, PB, K0 + 4 * ls, V0 + 4 * ls, kvd, nk_a, ks_a, row0, rowvalid,

@@ -51,7 +51,8 @@ class TbRolloutIO(C.Structure):
 
 
 class TbStepOverride(C.Structure):
-    _fields_ = [("mask", c_u8p), ("agent_state", c_f32p), ("vel", c_f32p), ("acc", c_f32p), ("yaw_rate", c_f32p), ("gt_valid", c_u8p)]
+    _fields_ = [("mask", c_u8p), ("agent_state", c_f32p), ("vel", c_f32p), ("acc", c_f32p), ("yaw_rate", c_f32p), ("gt_valid", c_u8p),
+                ("action", c_f32p), ("action_mask", c_u8p)]
 
 
 class TbRuleIO(C.Structure):

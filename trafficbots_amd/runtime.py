@@ -455,8 +455,10 @@ class HipEngine:
         if stepwise:
             self._check(self.lib.tb_rollout_begin(self._ctx, C.byref(io), self._stream()), "tb_rollout_begin")
             self._step_out = out
+            self._step_open = True
         else:
             self._check(self.lib.tb_rollout(self._ctx, C.byref(io), self._stream()), "tb_rollout")
+            self._step_open = False  # (tb_rollout reuses the stepwise context of the library)
         return out
 
     def rule_checks(self, s: Dict[str, Tensor], check_state: Tensor, check_valid: Tensor, k_futures: int,
@@ -547,7 +549,9 @@ class HipEngine:
         """One simulation step of the rollout opened with `rollout(..., stepwise=True)` (`tb_rollout_step`).  `override`
         (`tb_rollout_step_ex`, per instance: "mask" [N,A], "agent_state" [N,A,4], "vel" [N,A,2], "acc" / "yaw_rate" [N,A(,1)],
         optional "gt_valid" [N,A]) replaces the history arrays as the teacher-forcing source of THIS step, the way the
-        reference's `forward(state_override=, mask_state_override=)` + `Dynamics.kill(gt_valid)` do."""
+        reference's `forward(state_override=, mask_state_override=)` + `Dynamics.kill(gt_valid)` do.  "action" [N,A,2] +
+        "action_mask" [N,A] (the reference's `action_override / mask_action_override`, `dynamics.py:96-100`) replace the policy's
+        physical action of this step for valid agents; they may come alone (no "mask": the bound teacher forcing applies)."""
         if override is None:
             self._check(self.lib.tb_rollout_step(self._ctx, self._stream()), "tb_rollout_step")
             return
@@ -561,12 +565,16 @@ class HipEngine:
             return t
 
         ov = hip.TbStepOverride()
-        ov.mask = hip.ptr(prep("mask", u8, (n, a)), hip.c_u8p)
-        ov.agent_state = hip.ptr(prep("agent_state", f32, (n, a, 4)), hip.c_f32p)
-        ov.vel = hip.ptr(prep("vel", f32, (n, a, 2)), hip.c_f32p)
-        ov.acc = hip.ptr(prep("acc", f32, (n, a)), hip.c_f32p)
-        ov.yaw_rate = hip.ptr(prep("yaw_rate", f32, (n, a)), hip.c_f32p)
-        ov.gt_valid = hip.ptr(prep("gt_valid", u8, (n, a)) if override.get("gt_valid") is not None else None, hip.c_u8p)
+        if override.get("mask") is not None:
+            ov.mask = hip.ptr(prep("mask", u8, (n, a)), hip.c_u8p)
+            ov.agent_state = hip.ptr(prep("agent_state", f32, (n, a, 4)), hip.c_f32p)
+            ov.vel = hip.ptr(prep("vel", f32, (n, a, 2)), hip.c_f32p)
+            ov.acc = hip.ptr(prep("acc", f32, (n, a)), hip.c_f32p)
+            ov.yaw_rate = hip.ptr(prep("yaw_rate", f32, (n, a)), hip.c_f32p)
+            ov.gt_valid = hip.ptr(prep("gt_valid", u8, (n, a)) if override.get("gt_valid") is not None else None, hip.c_u8p)
+        if override.get("action_mask") is not None:
+            ov.action = hip.ptr(prep("action", f32, (n, a, 2)), hip.c_f32p)
+            ov.action_mask = hip.ptr(prep("action_mask", u8, (n, a)), hip.c_u8p)
         self._step_keepalive = keep  # borrowed until the stream work is done (replaced by the next step's)
         self._check(self.lib.tb_rollout_step_ex(self._ctx, C.byref(ov), self._stream()), "tb_rollout_step_ex")
 

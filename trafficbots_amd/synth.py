@@ -12,7 +12,7 @@ from __future__ import annotations
 
 import math
 from collections import OrderedDict
-from typing import Dict, Tuple
+from typing import Dict, Optional, Tuple
 
 import numpy as np
 
@@ -350,6 +350,15 @@ def make_action_noise(seed: int, n_inst: int, n_agent: int, n_step: int) -> np.n
 # state_dict of the reference model for the default config, in the
 # reference's parameter naming, so a reference checkpoint's state_dict loads unchanged.
 # --------------------------------------------------------------------------------------
+def make_action_override(seed: int, n_inst: int, n_agent: int, n_step: int, p: float = 0.3):
+    """Per-step `action_override` [N,A,S,2] (acceleration within +-3 m/s^2, yaw rate within +-0.3 rad/s) and `mask_action_override`
+    [N,A,S] (Bernoulli(p)) for the reference's `forward(action_override=, mask_action_override=)` (`dynamics.py:96-100`)."""
+    rs = RawStream(seed)
+    act = np.stack([rs.uniform(-3.0, 3.0, (n_inst, n_agent, n_step)), rs.uniform(-0.3, 0.3, (n_inst, n_agent, n_step))], -1)
+    mask = rs.bernoulli(p, (n_inst, n_agent, n_step))
+    return act.astype(np.float32), mask
+
+
 def _tf_layer(prefix: str, spec: "OrderedDict[str, Tuple[int, ...]]", h: int = 128, d_ff: int = 128) -> None:
     spec[f"{prefix}.norm1.weight"] = (h,)
     spec[f"{prefix}.norm1.bias"] = (h,)
@@ -475,11 +484,22 @@ def _buffer_value(name: str, shape) -> np.ndarray:
     return np.repeat(freqs, 2).astype(np.float32)
 
 
-def make_state_dict(seed: int, gain: float = 1.0, h: int = 128) -> "OrderedDict[str, np.ndarray]":
+WEIGHT_MODES = (None, "normal", "sharp", "ln_gamma")
+
+
+def make_state_dict(seed: int, gain: float = 1.0, h: int = 128, mode: Optional[str] = None) -> "OrderedDict[str, np.ndarray]":
     """Random fp32 weights in reference naming.  Matrices/biases ~ U(+-gain/sqrt(fan_in)),
     LayerNorm gamma = 1 + 0.1 u, beta = 0.1 u (so LN affine paths are exercised), GRU tensors
     U(+-1/sqrt(hidden)); `log_std` parameters keep their config values; buffers keep their
-    defined values.  Filled in sorted-key order from one PCG64 raw stream."""
+    defined values.  Filled in sorted-key order from one PCG64 raw stream.
+
+    `mode` selects another weight distribution (parity evidence beyond the uniform init):
+      "normal"   matrices / biases / GRU tensors ~ N(0, 1/(3 fan_in)): the variance of the uniform init with Gaussian tails (Box-Muller
+                 on the same raw stream; with N(0, 1/fan_in) the closed loop is so chaotic that the reference's own fp32 and fp64
+                 runs end 0.12 m apart, which tests nothing);
+      "sharp"    every attention in_proj_weight / in_proj_bias x 3 (logits x 9: near one-hot softmax rows);
+      "ln_gamma" LayerNorm gamma ~ U(0.5, 3), beta ~ U(-0.5, 0.5) (large affine gains, as in trained checkpoints)."""
+    assert mode in WEIGHT_MODES, mode
     spec = state_dict_spec(h=h)
     rs = RawStream(seed)
     sd: "OrderedDict[str, np.ndarray]" = OrderedDict()
@@ -494,13 +514,17 @@ def make_state_dict(seed: int, gain: float = 1.0, h: int = 128) -> "OrderedDict[
         if name.endswith("log_std") or ".log_std." in name:
             sd[name] = np.full(shape, -2.0 if name.startswith("action_head") else -1.0, dtype=np.float32)
             continue
-        u = rs.uniform(-1.0, 1.0, shape)
+        u = rs.normal(shape) / math.sqrt(3.0) if mode == "normal" else rs.uniform(-1.0, 1.0, shape)
         is_ln = (
             ".norm" in name
             or (".mlp_in.fc_layers." in name and name.split(".")[-2] in ("1", "5", "9") and "add_goal" in name)
             or ("goal_predictor.mlp.fc_layers." in name and name.split(".")[-2] in ("1", "4"))
         )
-        if is_ln:
+        if is_ln and mode == "normal":
+            u = np.clip(u, -2.0, 2.0)
+        if is_ln and mode == "ln_gamma":
+            val = (1.75 + 1.25 * u) if name.endswith("weight") else 0.5 * u
+        elif is_ln:
             val = (1.0 + 0.1 * u) if name.endswith("weight") else 0.1 * u
         elif ".rnn." in name:
             val = u / math.sqrt(h)
@@ -512,6 +536,8 @@ def make_state_dict(seed: int, gain: float = 1.0, h: int = 128) -> "OrderedDict[
             wname = wname[: -len("bias")] + "weight" if wname.endswith(".bias") else wname
             fan_in = spec[wname][1]
             val = u * gain / math.sqrt(fan_in)
+        if mode == "sharp" and ("in_proj_weight" in name or "in_proj_bias" in name):
+            val = val * 3.0
         sd[name] = val.astype(np.float32)
     for name in spec.keys():
         for a, tgt in ALIASES.items():

@@ -449,12 +449,19 @@ class WaymoMotion:
           and fusion halves were hoisted there, the traffic-light step follows the step counter (`step_tl = min(step - 1, n - 1)`,
           `:291`), `goal_valid` is maintained by the navigator inside the kernel.  They are accepted for signature parity and
           checked for shape only.
-        * `action_override`, stochastic actions and `require_vis_dict` (attention weights) are outside the built path."""
-        if action_override is not None or mask_action_override is not None or require_vis_dict:
-            raise NotImplementedError("action overrides and vis dicts (attention weights) are outside the built path")
+        * `action_override` [N,A,2] (acceleration m/s^2, yaw rate rad/s) + `mask_action_override` [N,A] replace the policy's physical
+          action of this step for the agents that are valid before it (`Dynamics.update`, `dynamics.py:96-100`); `action_log_prob`
+          stays that of the policy's own action, as in the reference.
+        * Stochastic actions in stepwise mode and `require_vis_dict` (attention weights) are outside the built path."""
+        if require_vis_dict:
+            raise NotImplementedError("vis dicts (attention weights) are outside the fused step; see TrafficBots.forward(need_weights=True)")
+        if (action_override is None) != (mask_action_override is None):
+            raise ValueError("forward: action_override and mask_action_override go together")
         if not deterministic_action:
             raise NotImplementedError("stochastic actions are outside the built path")
         eng = self.engine
+        if not getattr(eng, "_step_open", False):
+            raise RuntimeError("forward: no stepwise rollout is open (call rollout(..., stepwise=True) first)")
         o = eng._step_out
         n, a = o["preds"].shape[:2]
         for name, ten, shape in (("map_feature", map_feature, (None, None, 128)), ("tl_feature", tl_feature, (None, None, 128)),
@@ -466,16 +473,22 @@ class WaymoMotion:
             if mask_state_override is None:
                 raise ValueError("forward: state_override needs mask_state_override")
             mask = mask_state_override
+            if not isinstance(mask, Tensor):
+                raise ValueError("forward: mask_state_override must be a tensor")
             if state_override is None:
+                # the reference passes state_override=None only with an all-False mask (waymo_motion.py:274-276) and would fail on
+                # `state_override[...]` otherwise: a host mask is checked, a device mask is forced to all-False instead of syncing
+                if mask.device.type == "cpu" and bool(mask.any()):
+                    raise ValueError("forward: mask_state_override is set somewhere but state_override is None")
                 z = torch.zeros(n, a, 4, device=self.device)
                 state_override = {"agent_state": z, "vel": z[..., :2], "acc": z[..., :1], "yaw_rate": z[..., :1]}
-                # (checked lazily by the kernel's semantics: with no state dict nothing may be forced)
-                if not isinstance(mask, Tensor) or (mask.device.type == "cpu" and bool(mask.any())):
-                    raise ValueError("forward: mask_state_override is set somewhere but state_override is None")
+                mask = torch.zeros(n, a, dtype=torch.uint8, device=self.device)
             override = {"mask": mask, "agent_state": state_override["agent_state"], "vel": state_override["vel"],
                         "acc": state_override["acc"], "yaw_rate": state_override["yaw_rate"], "gt_valid": gt_valid}
         elif gt_valid is not None:
             raise ValueError("forward: gt_valid goes with state_override / mask_state_override (the bound history supplies its own)")
+        if action_override is not None:
+            override = dict(override or {}, action=action_override, action_mask=mask_action_override)
         eng.rollout_step(override)
         st = eng.rollout_state()
         s_idx = self._step_t - self.hparams["time_step_sim_start"]
