@@ -228,6 +228,7 @@ def time_passes(c, k, step_end, steps, warmup, world, events=False):
     torch.cuda.synchronize()
     pass_ev = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)] if events else None
     t0 = time.perf_counter()
+    c0 = time.thread_time()
     if events:
         pass_ev[0].record()
     for i in range(steps):
@@ -236,14 +237,52 @@ def time_passes(c, k, step_end, steps, warmup, world, events=False):
         out = eng.rollout(scene, feats, z, enc["latent_mean"], dest, gv, k, step_end, out=out)
         if events:
             pass_ev[i + 1].record()
+    c1 = time.thread_time()  # CPU time the launching thread spent ENQUEUEING the passes (before it blocks in synchronize)
     torch.cuda.synchronize()
     _barrier(world)
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     tm = eng.get_timing()
+    tm["host_cpu_ms_per_pass"] = (c1 - c0) / steps * 1e3
     eng.set_timing(False)
+    # outside the timed region: the sticky device words (fp16-pair range, helper hand-off time-out).  A pass that tripped either is
+    # not a measurement -- tb_check_status raises
+    eng.check_status()
     pass_ms = [pass_ev[i].elapsed_time(pass_ev[i + 1]) for i in range(steps)] if events else None
     return elapsed, out, tm, pass_ms
+
+
+def sustained_leg(c, k, step_end, seconds):
+    """Back-to-back rollouts for >= `seconds` (NOT part of `value`): long enough for a 5-s `smi` sampler to see the GPU busy, and a
+    second, longer reading of the same throughput (clocks / temperature settled).  One synchronize per ~0.25 s of queued work."""
+    eng, scene, feats, z, enc, dest, gv = c["eng"], c["scene"], c["feats"], c["z"], c["enc"], c["dest"], c["gv"]
+    out = eng.rollout(scene, feats, z, enc["latent_mean"], dest, gv, k, step_end)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    n = 0
+    while time.perf_counter() - t0 < seconds:
+        for _ in range(32):
+            out = eng.rollout(scene, feats, z, enc["latent_mean"], dest, gv, k, step_end, out=out)
+        n += 32
+        torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    eng.check_status()
+    return {"seconds": dt, "passes": n, "ms_per_pass": dt / n * 1e3}
+
+
+def lib_sha256():
+    """SHA-256 of the HIP library this process runs (what profiles/pmc_step_kernel.json must have been collected on)."""
+    import hashlib
+
+    from trafficbots_amd import hip
+
+    path = getattr(hip, "LIB_PATH", None) or os.path.join(ROOT, "trafficbots_amd", "lib", "libtrafficbots_hip.so")
+    path = os.environ.get("TB_HIP_LIB", path)
+    h = hashlib.sha256()
+    with open(path, "rb") as f:
+        for blk in iter(lambda: f.read(1 << 20), b""):
+            h.update(blk)
+    return h.hexdigest()
 
 
 def golden_traj_err(sd_unused, dev):
@@ -282,10 +321,37 @@ def golden_traj_err(sd_unused, dev):
         "yaw_vs_reference_fp32": float(d32[..., 2].max()), "spd_vs_reference_fp32": float(d32[..., 3].max()),
         "xy_vs_reference_fp32_steps_1_to_60": float(per_step[:60].max()),
         "first_step_above_1e-4_vs_fp32": int(above[0]) + 1 if above.size else None,
+        # the measured rounding noise of the reference arithmetic itself: 16 fp32 runs of the reference on re-ordered batches
+        # (tools/ensemble.py, stored in the golden); the parity tests bound the HIP path per step by these, no multipliers
+        "reference_ensemble_max_spread_vs_its_fp32": float(g["ens_d32"].max()) if "ens_d32" in g.files else None,
+        "reference_ensemble_max_vs_its_fp64": float(g["ens_d64"].max()) if "ens_d64" in g.files else None,
+        "inside_reference_ensemble_every_step": (bool(
+            (per_step <= np.maximum(1e-4, np.maximum.accumulate(g["ens_d32"].max(0)))).all()
+            and (d64[..., :2].max(axis=(0, 1, 2, 4)) <= np.maximum(1e-4, np.maximum.accumulate(g["ens_d64"].max(0)))).all())
+            if "ens_d32" in g.files else None),
         "flags_equal": bool((buf.valid.cpu().numpy() == g["valid"]).all()
                             and (buf.violations["dest_reached"].cpu().numpy() == g["dest_reached"]).all()
                             and (buf.violations["outside_map"].cpu().numpy() == g["outside_map"]).all()),
     }
+
+
+_PMC_CACHE = None
+
+
+def _pmc_records():
+    """profiles/pmc_step_kernel.json (tools/gpu_pmc_step.sh): per-kernel PMC medians for the headline / K=6 / stress shapes, stamped
+    with the SHA-256 of the library they were collected on; `_matches_build` says whether that is the library being timed NOW."""
+    global _PMC_CACHE
+    if _PMC_CACHE is None:
+        rec = {}
+        if os.path.exists(PMC_FILE):
+            try:
+                rec = json.load(open(PMC_FILE))
+            except Exception:
+                rec = {}
+        rec["_matches_build"] = bool(rec.get("lib_sha256")) and rec.get("lib_sha256") == lib_sha256()
+        _PMC_CACHE = rec
+    return _PMC_CACHE
 
 
 def sub_record(name, spec, sd, dev, rank, world, steps, warmup):
@@ -303,6 +369,8 @@ def sub_record(name, spec, sd, dev, rank, world, steps, warmup):
     by = bytes_step(spec["a"], spec["p"], N_TL, 2 if spec["prec"] == "bf16" else 4) * n_inst
     tf = fl / (k_us * 1e-6) / 1e12
     gbs = by / (k_us * 1e-6) / 1e9
+    pmc_all = _pmc_records()
+    pmc = pmc_all.get(name) if pmc_all.get("_matches_build") else None
     rec = {
         "what": spec["what"], "operand_precision": spec["prec"], "scenes_per_gpu": B_PER_GPU, "k_futures": spec["k"], "n_agent": spec["a"],
         "n_pl": spec["p"], "sim_steps": spec["step_end"], "instances_per_gpu": n_inst, "n_gpus": world,
@@ -313,7 +381,12 @@ def sub_record(name, spec, sd, dev, rank, world, steps, warmup):
                      "frac_fp32_mfma_peak": tf / PEAK_FP32_MFMA_TFLOPS, "frac_bf16_mfma_peak": tf / PEAK_BF16_MFMA_TFLOPS,
                      "algorithmic_bytes_per_launch": by, "achieved_GBs_algorithmic": gbs, "frac_hbm_peak": gbs / PEAK_HBM_GBS,
                      "bound": "mfma (fp32 formulation)" if spec["prec"] == "fp32" else
-                              ("hbm" if gbs / PEAK_HBM_GBS > tf / PEAK_BF16_MFMA_TFLOPS else "mfma (bf16)")},
+                              ("hbm" if gbs / PEAK_HBM_GBS > tf / PEAK_BF16_MFMA_TFLOPS else "mfma (bf16)"),
+                     "traffic": (pmc or {}).get("fetch_bytes_per_launch"),
+                     "traffic_over_algorithmic": ((pmc["fetch_bytes_per_launch"] / by) if pmc and pmc.get("fetch_bytes_per_launch") else None),
+                     "mfma_busy_measured": (pmc or {}).get("mfma_busy"),
+                     "avg_launch_us_kernel_trace": (pmc or {}).get("avg_fused_launch_us_kernel_trace")},
+        "host_cpu_ms_per_pass": tm["host_cpu_ms_per_pass"],
         "finite": bool(red["finite_ranks"] == world),
     }
     del c
@@ -328,6 +401,9 @@ def run_rank(args, rank: int, local_rank: int, world: int) -> None:
         local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    from trafficbots_amd import shard as _shard
+
+    numa = _shard.bind_to_gpu_numa_node(local_rank)  # the launching thread stays on the GPU's NUMA node (best effort)
     if world > 1:
         import torch.distributed as dist
 
@@ -342,6 +418,11 @@ def run_rank(args, rank: int, local_rank: int, world: int) -> None:
     prec = args.operand_precision
     cfg = load_model_config(overrides={"time_step_end": STEP_END, "n_joint_future": 1, "operand_precision": prec})
     sd = synth.make_state_dict(7)
+    if args.only_config:  # (tools/gpu_pmc_step.sh: the rocprofv3 passes of the K=6 / stress shapes)
+        rec = sub_record(args.only_config, SUBCONFIGS[args.only_config], sd, dev, rank, world, args.config_steps, 1)
+        if rank == 0:
+            print(json.dumps({"only_config": args.only_config, **rec}), flush=True)
+        return
     # this rank's shard of the global batch: scenes [rank*32, rank*32+32) of the seeded stream (configs[2] layout)
     c = setup_case(cfg, sd, dev, rank, B_PER_GPU, N_AGENT, N_PL, 1)
     eng, scene, batch, enc = c["eng"], c["scene"], c["batch"], c["enc"]
@@ -367,6 +448,8 @@ def run_rank(args, rank: int, local_rank: int, world: int) -> None:
         print("pass_ms:", " ".join(f"{x:.2f}" for x in pass_ms), file=sys.stderr)
     pass_ms = sorted(pass_ms)
     k_us = tm["fused_ms"] / max(1, tm["n_fused"]) * 1e3  # average duration of one fused k_step launch (C(t)+A(t+1))
+    # ---- sustained leg (not `value`): >= args.sustain_seconds of back-to-back rollouts of the same workload
+    sustained = sustained_leg(c, 1, STEP_END, args.sustain_seconds) if args.sustain_seconds > 0 else None
 
     # ---- secondary measurement (not `value`): two independent 32-scene batches in flight on two HIP streams.  At 32 scenes a
     # rollout launches 128 workgroups (one per 16 agents) on a 256-CU chip; a second batch on another stream fills the rest.
@@ -409,7 +492,13 @@ def run_rank(args, rank: int, local_rank: int, world: int) -> None:
         k1(out["valid"]), k1(out["preds"]), k1(out["override_masks"]),
         {"outside_map": k1(out["outside_map"]), "dest_reached": k1(out["dest_reached"])},
         scene["agent_type"], torch.from_numpy(batch["history/agent/role"]))
-    red_all, elapsed = all_reduce_partials(torch.cat([part, ref_part]), elapsed, fields=PARTIAL_FIELDS + METRIC_FIELDS)
+    n_coll0 = _shard.N_COLLECTIVES
+    red_all, elapsed, ranks = all_reduce_partials(
+        torch.cat([part, ref_part]), elapsed, fields=PARTIAL_FIELDS + METRIC_FIELDS,
+        per_rank={"device_plus_1": local_rank + 1, "host_cpu_ms_per_pass": tm["host_cpu_ms_per_pass"],
+                  "numa_node_plus_1": (numa.get("node") if numa.get("node") is not None else -1) + 1,
+                  "sustained_ms_per_pass": sustained["ms_per_pass"] if sustained else 0.0})
+    n_coll_headline = _shard.N_COLLECTIVES - n_coll0
     red = {k: red_all[k] for k in PARTIAL_FIELDS}
     ref_metrics = {k: red_all[k] for k in METRIC_FIELDS}
     finite = bool(torch.isfinite(out["preds"]).all())
@@ -441,12 +530,7 @@ def run_rank(args, rank: int, local_rank: int, world: int) -> None:
         n_mfma = mfma_issue(N_AGENT, N_PL, tl_keys_eff, planes)
         clk = SHADER_CLK
         mfma_busy_est = n_mfma * 16.0 / (k_us * 1e-6 * clk)
-        pmc = None
-        if os.path.exists(PMC_FILE):
-            try:
-                pmc = json.load(open(PMC_FILE)).get(prec)
-            except Exception:
-                pmc = None
+        pmc = _pmc_records().get(prec) if _pmc_records().get("_matches_build") else None
         shape_ok = (N_AGENT, N_PL, N_TL, B_PER_GPU) == (64, 256, 40, 32)
         traffic = pmc.get("fetch_bytes_per_launch") if (pmc and shape_ok) else None
         line = {
@@ -461,6 +545,26 @@ def run_rank(args, rank: int, local_rank: int, world: int) -> None:
                        "scenes_per_gpu": B_PER_GPU, "n_agent": N_AGENT, "n_pl": N_PL, "n_tl": N_TL, "sim_steps": STEP_END,
                        "parallelism": f"scene-parallel x{world}"},
             "agent_steps_per_s": value * N_AGENT,
+            "ranks": {
+                "ranks_seen": int(sum(1 for x in ranks["elapsed_s"] if x > 0)), "elapsed_s": ranks["elapsed_s"],
+                "device": [int(x) - 1 for x in ranks["device_plus_1"]], "numa_node": [int(x) - 1 for x in ranks["numa_node_plus_1"]],
+                "host_cpu_ms_per_pass": ranks["host_cpu_ms_per_pass"],
+                "collectives_in_timed_passes": 0, "collectives_for_the_metric_reduction": n_coll_headline,
+                "note": "one process per GPU; elapsed_s = each rank's own clock around the same barrier-bracketed passes (value uses the max); "
+                        "host_cpu_ms_per_pass = CPU time the launching thread needs to enqueue one pass (91 launches) -- the host-side "
+                        "budget is ms_per_step; the rollout itself issues no collective, the metric / elapsed reduction is ONE all-reduce",
+            },
+            "host": {"numa": numa, "usable_cpus": usable_cpus(),
+                     "launch_thread_cpu_ms_per_pass": tm["host_cpu_ms_per_pass"],
+                     "margin": (elapsed / args.steps * 1e3) / max(1e-9, tm["host_cpu_ms_per_pass"]),
+                     "note": "margin = GPU time of a pass / CPU time the launching thread spends enqueueing it; N ranks need N such threads "
+                             "(N x launch_thread_cpu_ms_per_pass of CPU per ms_per_step of wall clock)"},
+            "sustained": (dict(sustained, value=world * B_PER_GPU * STEP_END * 1e3 / max(ranks["sustained_ms_per_pass"]),
+                               unit="scene-steps/s",
+                               note="back-to-back rollouts of the headline workload for >= --sustain-seconds after the timed region "
+                                    "(slowest rank's ms per pass); not `value`") if sustained else None),
+            "pmc_matches_build": _pmc_records().get("_matches_build", False),
+            "lib_sha256": lib_sha256(),
             "encode_ms": encode_ms,
             "pass_ms": {"min": pass_ms[0], "median": pass_ms[len(pass_ms) // 2], "max": pass_ms[-1]},
             "kernel_us": {"k_step_fused": k_us, "n_fused": tm["n_fused"], "edge_launches_ms": tm["edge_ms"], "prologue_ms": tm["prologue_ms"],
@@ -470,7 +574,9 @@ def run_rank(args, rank: int, local_rank: int, world: int) -> None:
                          "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
                          "traffic": traffic,
                          "traffic_unit": "HBM-side bytes per launch: rocprofv3 --pmc FETCH_SIZE x 2 (gfx950 correction of the guide) from the "
-                                         "PMC pass recorded in profiles/pmc_step_kernel.json (tools/gpu_pmc_step.sh; not collected at bench time)",
+                                         "PMC pass recorded in profiles/pmc_step_kernel.json (tools/gpu_pmc_step.sh; separate rocprofv3 --pmc passes, so not collected "
+                                         "in this process: the file carries the SHA-256 of the library it was collected on and is used only when "
+                                         "that is the library timed here -- `pmc_matches_build`; null otherwise)",
                          "flops_per_launch": fl, "avg_launch_us": k_us,
                          "note": "algorithmic fp32 flops = 176.1 MFLOP per scene-step (SURVEY 8(d)) x 32 scenes per launch, priced against "
                                  "the fp32-MFMA peak of the fp32 formulation; the kernel issues them as 3 fp16 MFMAs per product on the XDL "
@@ -553,15 +659,21 @@ def parse_args(argv=None):
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sustain-seconds", type=float, default=None,
+                    help="back-to-back rollouts after the timed region, outside `value` (default 12 s; 0 with --lean)")
     ap.add_argument("--lean", action="store_true", help="headline only: no sub-records, no golden error, no two-stream leg, no 1-thread CPU leg")
     ap.add_argument("--configs", nargs="*", default=None, help=f"sub-records to measure (default: all at 1 GPU); any of {list(SUBCONFIGS)}")
     ap.add_argument("--config-steps", type=int, default=5, help="timed passes per sub-record")
+    ap.add_argument("--only-config", default=None, help="profiling hook: run ONE sub-record alone (no headline leg) and print its record")
     ap.add_argument("--operand-precision", choices=["fp32", "bf16"], default="fp32",
                     help="bf16: BASELINE.json configs 4/5 operand precision (not the headline metric, which is fp32)")
     ap.add_argument("--cpu-baseline-worker", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--cpu-budget", type=float, default=15.0)
-    return ap.parse_args(argv)
+    args = ap.parse_args(argv)
+    if args.sustain_seconds is None:
+        args.sustain_seconds = 0.0 if args.lean else 12.0
+    return args
 
 
 def main():

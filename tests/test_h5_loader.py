@@ -330,3 +330,59 @@ def test_reader_and_restatement_match_the_references_own_datasets(tmp_path):
                 assert _digest(product[k]) == w, ("product reader", split, tag, k)
                 n_checked += 1
     assert n_checked == 69 + 38 + 27 + 69 + 38
+
+
+def _run(cmd):
+    import subprocess
+
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 0, f"{' '.join(cmd)}\n{r.stdout}"
+
+
+def test_reader_on_files_made_by_the_hdf5_command_line_tools(tmp_path):
+    """An INDEPENDENT writer: until here every file the reader saw came out of `tb_h5_writer_*`, so reader and
+    writer were each other's only witness.  This file is built with the HDF5 project's own tools -- `h5import` turns raw binary
+    arrays into datasets of `<episode>/<key>`, `h5repack` re-stores them chunked with the shuffle + gzip filters the packer uses
+    (`pack_h5_womd.py:378-392` -> h5py `compression="gzip", shuffle=True`) -- and must decode to the bytes it was made from, through
+    the reference-layout path and through the decoded (`tb_scene` layout) path; the repacked chunked file and the contiguous one agree.
+    Booleans are 8-bit integers here (h5import cannot make h5py's enum type; that convention is covered by the h5dump checks)."""
+    import shutil
+
+    tools = {t: shutil.which(t) or os.path.join(os.environ.get("TB_HDF5_PREFIX", "/opt/conda"), "bin", t) for t in ("h5import", "h5repack", "h5dump")}
+    if not all(os.path.exists(p) for p in tools.values()):
+        pytest.skip("HDF5 command-line tools not installed")
+    episodes, _ = synth.make_h5_episodes(4300, 3, **SCENE)
+    keys = ["history/agent/pos", "history/agent/valid", "history/agent/type", "history/agent/object_id", "map/pos", "map/valid",
+            "map/type", "history/tl_stop/state", "history/tl_stop/valid", "history/agent/yaw_bbox"]
+    plain = str(tmp_path / "cli_plain.h5")
+    for i, ep in enumerate(episodes):
+        for k in keys:
+            v = np.ascontiguousarray(ep[k])
+            raw = tmp_path / "raw.bin"
+            (v.view(np.uint8) if v.dtype == np.bool_ else v).tofile(raw)
+            cls, bits = {"float32": ("FP", 32), "int64": ("IN", 64), "bool": ("UIN", 8)}[str(v.dtype)]
+            cfg = tmp_path / "cfg.txt"
+            cfg.write_text(f"PATH {i}/{k}\nINPUT-CLASS {cls}\nINPUT-SIZE {bits}\nOUTPUT-CLASS {cls}\nOUTPUT-SIZE {bits}\n"
+                           f"RANK {v.ndim}\nDIMENSION-SIZES {' '.join(str(s) for s in v.shape)}\nOUTPUT-ARCHITECTURE NATIVE\n")
+            _run([tools["h5import"], str(raw), "-c", str(cfg), "-o", plain])
+    packed_like = str(tmp_path / "cli_gzip.h5")
+    _run([tools["h5repack"], "-f", "SHUF", "-f", "GZIP=4", plain, packed_like])
+    import subprocess
+    dump = subprocess.run([tools["h5dump"], "-pH", "-d", "/1/map/pos", packed_like], stdout=subprocess.PIPE, text=True).stdout
+    assert "CHUNKED" in dump and "SHUFFLE" in dump and "DEFLATE" in dump, dump  # (the repacked file really carries the filters)
+    for path in (plain, packed_like):
+        f = data_h5.PackedH5File(path)
+        for k in keys:
+            want = np.stack([ep[k] for ep in episodes])
+            kind = data_h5.reference_kind(k)
+            got = f.read_key([0, 1, 2], k, tuple(want.shape[1:]), kind).numpy()
+            got = got.view(np.bool_) if want.dtype == np.bool_ else got
+            assert got.dtype == want.dtype and np.array_equal(got, want), (path, k)
+        # the decoded forms of the hot path: one-hot -> class index, history slice of a longer tensor, squeezed yaw
+        ty = f.read_key([2, 0], "history/agent/type", (SCENE["n_agent"], 3), data_h5.ONEHOT_I32).numpy()
+        want_ty = np.stack([np.where(episodes[e]["history/agent/type"].any(-1), episodes[e]["history/agent/type"].argmax(-1), -1) for e in (2, 0)])
+        assert np.array_equal(ty, want_ty)
+        lead = f.read_key([1], "history/agent/pos", episodes[1]["history/agent/pos"].shape, data_h5.F32, n_lead=4).numpy()
+        assert np.array_equal(lead[0], episodes[1]["history/agent/pos"][:4])
+        yaw = f.read_key([1], "history/agent/yaw_bbox", episodes[1]["history/agent/yaw_bbox"].shape, data_h5.F32, squeeze=True).numpy()
+        assert np.array_equal(yaw[0], episodes[1]["history/agent/yaw_bbox"][..., 0])

@@ -77,6 +77,59 @@ def test_two_rank_gloo_matches_single_process():
     assert t == 2.0  # MAX over ranks of the elapsed time
 
 
+def _worker8(rank, world, port, n_global, q):
+    """one of 8 ranks: uneven shards (a rank may own NO scene), per-rank tails of the one all-reduce, collective count"""
+    import torch.distributed as dist
+
+    torch.set_num_threads(1)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from trafficbots_amd import shard
+
+    lo, hi = shard.shard_range(n_global, rank, world)
+    if hi > lo:
+        part = _partials_for(lo, hi)
+    else:  # an idle rank still takes part in the collective, with zero partials
+        part = torch.zeros(len(shard.PARTIAL_FIELDS), dtype=torch.float64)
+    n0 = shard.N_COLLECTIVES
+    red, t, ranks = shard.all_reduce_partials(part, elapsed_s=1.0 + 0.25 * rank, per_rank={"device_plus_1": rank + 1, "n_scene": hi - lo})
+    q.put((rank, red, t, ranks, shard.N_COLLECTIVES - n0))
+    dist.destroy_process_group()
+
+
+def test_eight_rank_gloo_uneven_shards_and_idle_rank():
+    """The 8-rank flow of BASELINE configs[2] on CPU (gloo): shard_range over 8 ranks for an uneven global batch (250 scenes: 31 or 32
+    per rank) and for fewer scenes than ranks (6 over 8: two idle ranks), ONE collective, every rank sees every rank's slot."""
+    from trafficbots_amd.shard import PARTIAL_FIELDS, shard_range
+
+    world = 8
+    blocks = [shard_range(250, r, world) for r in range(world)]
+    assert blocks[0] == (0, 32) and blocks[1] == (32, 64) and blocks[2] == (64, 95) and blocks[-1] == (219, 250)
+    assert all(b[1] == c[0] for b, c in zip(blocks, blocks[1:])) and sorted({hi - lo for lo, hi in blocks}) == [31, 32]
+    n_global = 6
+    assert [shard_range(n_global, r, world) for r in (5, 6, 7)] == [(5, 6), (6, 6), (6, 6)]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker8, args=(r, world, port, n_global, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=600) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    whole = _partials_for(0, n_global)
+    for rank, red, t, ranks, n_coll in got:
+        assert n_coll == 1, (rank, n_coll)
+        for i, k in enumerate(PARTIAL_FIELDS):
+            assert abs(red[k] - float(whole[i])) <= 1e-6 * max(1.0, abs(float(whole[i]))), (rank, k)
+        assert t == 1.0 + 0.25 * 7
+        assert ranks["elapsed_s"] == [1.0 + 0.25 * r for r in range(world)]
+        assert ranks["device_plus_1"] == [float(r + 1) for r in range(world)]
+        assert ranks["n_scene"] == [1.0] * 6 + [0.0, 0.0]
+
+
 def _val_states_for(lo, hi, batch=None):
     """TrainingMetrics sum-states of scenes [lo, hi) of a seeded validation batch, or of `batch` (oracles standing in for the GPU engine)."""
     import sys

@@ -106,7 +106,7 @@ for _i, _mode in enumerate(("normal", "sharp", "ln_gamma")):
     )
 
 # members of the measured rounding-noise ensemble (tools/ensemble.py) per closed-loop golden
-N_ENSEMBLE = 16
+N_ENSEMBLE = 32
 ENSEMBLE_CASES = ("small_k1", "masks_k3", "degenerate", "headline_2", "headline_k6", "stoch_actions", "action_override",
                   "headline_w_normal", "headline_w_sharp", "headline_w_ln_gamma")
 

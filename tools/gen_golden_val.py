@@ -69,7 +69,7 @@ RULE = ("counter_agent", "counter_veh", "outside_map", "collided", "run_road_edg
         "dest_reached")
 
 
-N_ENSEMBLE = 16
+N_ENSEMBLE = 32
 
 
 def run_reference(case: dict, dtype=torch.float32, perturb=None) -> dict:

@@ -35,6 +35,11 @@ namespace xh {
 void launch_range_flag_take_step(unsigned int* out, hipStream_t s);
 }
 TB_DECLARE_XDL(xb)  // bf16       (tb_stepx_bf16_kernels.hip)
+namespace xb3 {     // bf16, three workgroups per CU (tb_stepx_bf16w3_kernels.hip): launches of more than 512 row tiles
+void launch_step_x(const RolloutP& p, int t, int do_c, int do_a, hipStream_t s);
+hipError_t configure_stepx_kernel();
+void launch_step_pre_x(const RolloutP& p, int t0, int n, hipStream_t s);
+}
 int run_encode(struct ::tb_ctx* ctx, const tb_encode_io* io, hipStream_t s);
 int run_rule_checks(const tb_rule_io* io, int n_hist, int step_start, uint8_t* raw_ws, hipStream_t s);
 int run_encode_posterior(struct ::tb_ctx* ctx, const tb_posterior_io* io, hipStream_t s);
@@ -308,6 +313,13 @@ void tb_struct_sizes(int32_t out[9]) {
 
 const char* tb_version(void) { return "trafficbots_hip 0.2 (gfx950, fp16-pair XDL MFMA 16x16x32 with fp32 accumulate; fp32 MFMA 16x16x4 kernels selectable)"; }
 
+// bf16 launches of more than 512 row tiles (two per CU would need more than one dispatch round) take the three-per-CU carve
+// (tb::xb3, same results); TB_STEP_W3=0 keeps them on the two-per-CU carve (development / A-B switch)
+static bool w3_launch(size_t n_tiles) {
+    const char* e = getenv("TB_STEP_W3");  // (read per launch: the tests flip it inside one process)
+    return !(e && e[0] == '0') && n_tiles > 512;
+}
+
 // `rd` supplies what C(t) reads (normally the same struct as `wr`; the batched warm start substitutes its slices), `wr` what
 // the launch writes
 static void step_launch(const tb_ctx* ctx, const tb::RolloutP& rd, const tb::RolloutP& wr, int t, int do_c, int do_a, hipStream_t s) {
@@ -318,7 +330,9 @@ static void step_launch(const tb_ctx* ctx, const tb::RolloutP& rd, const tb::Rol
         tb::set_parity(w, t);
         p.valid_w = w.valid_w; p.vbias_w = w.vbias_w; p.kin_w = w.kin_w; p.vtin_w = w.vtin_w; p.x_mid_w = w.x_mid_w;
     }
-    if (ctx->step_kernel == 3)
+    if (ctx->step_kernel == 3 && w3_launch((size_t)(p.a_pad / tb::TM) * p.n_inst))
+        tb::xb3::launch_step_x(p, t, do_c, do_a, s);
+    else if (ctx->step_kernel == 3)
         tb::xb::launch_step_x(p, t, do_c, do_a, s);
     else if (ctx->step_kernel == 2)
         tb::xh::launch_step_x(p, t, do_c, do_a, s);
@@ -374,6 +388,7 @@ int tb_create(const tb_config* cfg, tb_ctx** out) {
 }
 
 void tb_destroy(tb_ctx* ctx) {
+    if (ctx && ctx->graph_exec) (void)hipGraphExecDestroy(ctx->graph_exec);
     if (!ctx) return;
     if (ctx->d_arena) (void)hipFree(ctx->d_arena);
     if (ctx->d_ws) (void)hipFree(ctx->d_ws);
@@ -398,6 +413,7 @@ int tb_finalize_weights(tb_ctx* ctx, tb_stream stream) {
     TB_HIP(ctx, tb::configure_rollout_kernels());
     TB_HIP(ctx, tb::xh::configure_stepx_kernel());
     TB_HIP(ctx, tb::xb::configure_stepx_kernel());
+    TB_HIP(ctx, tb::xb3::configure_stepx_kernel());
     TB_HIP(ctx, tb::configure_rule_kernels());
     TB_HIP(ctx, tb::xh::configure_encodex_kernels());
     Arena a;
@@ -809,11 +825,68 @@ static void rollout_prologue(const tb_ctx* ctx, const tb::RolloutP& p, const tb_
     tb::launch_rollout_init(p, s);
 }
 
+static int rollout_enqueue(tb_ctx* ctx, const tb_rollout_io* io, const tb::RolloutP& p, hipStream_t s);
+
+static unsigned long long fnv1a(const void* data, size_t n, unsigned long long h) {
+    const unsigned char* b = static_cast<const unsigned char*>(data);
+    for (size_t i = 0; i < n; ++i) {
+        h ^= b[i];
+        h *= 1099511628211ull;
+    }
+    return h;
+}
+
 extern "C" int tb_rollout(tb_ctx* ctx, const tb_rollout_io* io, tb_stream stream_) {
     tb::RolloutP p;
     if (rollout_setup(ctx, io, p)) return 1;
     hipStream_t s = (hipStream_t)stream_;
     ctx->step_active = false;
+    // ---- one hipGraph per rollout: every kernel argument of the launch sequence is a function of (p, io, the development switches),
+    // so a rollout with the same key replays the captured graph (bench loops, a serving loop over fixed buffers)
+    const char* ge = getenv("TB_ROLLOUT_GRAPH");
+    const bool use_graph = !(ge && ge[0] == '0') && !ctx->timing && ctx->step_kernel >= 2;
+    if (!use_graph) return rollout_enqueue(ctx, io, p, s);
+    unsigned long long key = fnv1a(&p, sizeof(p), 1469598103934665603ull);
+    key = fnv1a(io, sizeof(*io), key);
+    for (const char* name : {"TB_STEP_W3", "TB_STEP_W3G", "TB_STEP_LEAN", "TB_STEP_HELPERS", "TB_GRU_HELPER"}) {
+        const char* v = getenv(name);
+        key = fnv1a(v ? v : "-", v ? strlen(v) + 1 : 2, key);
+    }
+    if (ctx->graph_exec && key == ctx->graph_key) {
+        ++ctx->graph_hits;
+        TB_HIP(ctx, hipGraphLaunch(ctx->graph_exec, s));
+        return 0;
+    }
+    if (key != ctx->graph_seen) {  // first sight of this argument set: plain launches (a caller with fresh buffers per call never captures)
+        ctx->graph_seen = key;
+        return rollout_enqueue(ctx, io, p, s);
+    }
+    hipGraph_t graph = nullptr;
+    if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) != hipSuccess) {  // (a stream that cannot capture: plain launches)
+        (void)hipGetLastError();
+        return rollout_enqueue(ctx, io, p, s);
+    }
+    const int rc = rollout_enqueue(ctx, io, p, s);
+    const hipError_t ec = hipStreamEndCapture(s, &graph);
+    if (rc) {
+        if (graph) (void)hipGraphDestroy(graph);
+        return rc;
+    }
+    TB_HIP(ctx, ec);
+    if (ctx->graph_exec) {
+        (void)hipGraphExecDestroy(ctx->graph_exec);
+        ctx->graph_exec = nullptr;
+    }
+    const hipError_t ei = hipGraphInstantiate(&ctx->graph_exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    TB_HIP(ctx, ei);
+    ctx->graph_key = key;
+    ++ctx->graph_captures;
+    TB_HIP(ctx, hipGraphLaunch(ctx->graph_exec, s));
+    return 0;
+}
+
+static int rollout_enqueue(tb_ctx* ctx, const tb_rollout_io* io, const tb::RolloutP& p, hipStream_t s) {
     const int step_start = p.step_start;
     const int n_steps = p.n_step_out;
     const int n_launch = n_steps + 1;
@@ -832,7 +905,8 @@ extern "C" int tb_rollout(tb_ctx* ctx, const tb_rollout_io* io, tb_stream stream
     const int n_pre = ctx->n_pre;
     const int t_pre0 = step_start - 1;
     if (n_pre > 0) {
-        if (ctx->step_kernel == 3) tb::xb::launch_step_pre_x(p, t_pre0, n_pre, s);
+        if (ctx->step_kernel == 3 && w3_launch((size_t)(p.a_pad / tb::TM) * p.n_scene * n_pre)) tb::xb3::launch_step_pre_x(p, t_pre0, n_pre, s);
+        else if (ctx->step_kernel == 3) tb::xb::launch_step_pre_x(p, t_pre0, n_pre, s);
         else tb::xh::launch_step_pre_x(p, t_pre0, n_pre, s);
     }
     // ---- the sequential loop (waymo_motion.py:269): launch i runs C(start+i-1) then A(start+i); no host sync

@@ -23,7 +23,16 @@
 // Two builds of this header exist (one translation unit each): the default fp16-pair mode above (namespace tb::xh) and, with
 // -DTB_XDL_BF16 / tb_stepx_bf16_kernels.hip, a plain bf16 mode (namespace tb::xb): ONE bf16 plane per operand, fp32 accumulate --
 // the "bf16 MFMA inputs" configurations of BASELINE.json (configs 4/5); no fp32-parity claim there.
-#ifdef TB_XDL_BF16
+// A third build (-DTB_XDL_BF16 -DTB_XDL_W3 / tb_stepx_bf16w3_kernels.hip, namespace tb::xb3) is the bf16 mode carved for THREE
+// workgroups per CU (launches of more than 512 tiles, e.g. K = 6 futures x 32 scenes = 768): a weight unit is not prefetched into
+// registers one stage ahead -- `wloadx` only records WHERE the unit is (and fetches its bias), the GEMM that consumes it loads the
+// fragments itself -- which takes 32 of the 40 VGPRs of every unit in flight out of the kernel (<= 168 VGPRs = three waves per
+// SIMD); the latency the prefetch used to hide is hidden by the two other workgroups of the CU.
+#if defined(TB_XDL_W3) && defined(TB_XDL_BF16)
+#define TB_XNS xb3
+#elif defined(TB_XDL_W3)
+#define TB_XNS xh3   // (the fp16-pair twin of the same carve: two workgroups / wave groups per CU without spills, tb_stepx_w3_kernels.hip)
+#elif defined(TB_XDL_BF16)
 #define TB_XNS xb
 #else
 #define TB_XNS xh
@@ -183,11 +192,6 @@ __device__ __forceinline__ void layernorm_planes(const float* src, int lds_, xha
 // ---------------------------------------------------------------------------------------------
 // weight units: 2 output tiles x 4 chunks (128 k) x 2 planes = 16 fragments of 8 fp16 per lane (64 VGPRs) + bias
 // ---------------------------------------------------------------------------------------------
-struct WUnitX {
-    xh8 w[2][4][NPL];  // [tile][chunk][plane]
-    f32x4 b[2];
-};
-
 struct WNextX {
     const xhalf* wpk;   // packed Linear
     const float* bias;   // or nullptr
@@ -195,6 +199,18 @@ struct WNextX {
     int nchunk;          // chunks per output tile of this Linear (K / 32)
     int c0;              // first chunk of this unit
 };
+
+#ifdef TB_XDL_W3
+struct WUnitX {
+    WNextX at;           // where the unit's fragments are: loaded by the GEMM that consumes them
+    f32x4 b[2];
+};
+#else
+struct WUnitX {
+    xh8 w[2][4][NPL];  // [tile][chunk][plane]
+    f32x4 b[2];
+};
+#endif
 
 __device__ __forceinline__ WNextX wnextx(const float* arena, uint32_t off, const float* bias, int tile_a, int tile_b, int nchunk = 4,
                                           int c0 = 0) {
@@ -208,6 +224,55 @@ __device__ __forceinline__ const xh8* wfragx(const WNextX& n, int tile, int lane
     return reinterpret_cast<const xh8*>(n.wpk + ((size_t)(tile * n.nchunk + n.c0) * NPL) * 512 + lane * 8);
 }
 
+#ifdef TB_XDL_W3
+__device__ __forceinline__ void wloadx(WUnitX& u, const WNextX& n, int lane) {
+    const int bo = (lane >> 4) * 4;
+    u.at = n;
+    u.b[0] = n.bias ? ldg4(n.bias + n.tile_a * 16 + bo) : splat(0.f);
+    u.b[1] = n.bias ? ldg4(n.bias + n.tile_b * 16 + bo) : splat(0.f);
+}
+__device__ __forceinline__ xh8 ldsb8(const xhalf* p) { return *reinterpret_cast<const xh8*>(p); }
+// acc_{a,b} += unit . X^T: the unit's fragments are requested here, in front of the LDS reads of the B operand
+__device__ __forceinline__ void wmmax(f32x4& acc_a, f32x4& acc_b, const WUnitX& u, const xhalf* bp, int plane_stride) {
+    const int lane = threadIdx.x & 63;
+    const xh8* pa = wfragx(u.at, u.at.tile_a, lane);
+    const xh8* pb = wfragx(u.at, u.at.tile_b, lane);
+    xh8 wa[4][NPL], wb[4][NPL], x[4][NPL];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int p = 0; p < NPL; ++p) {
+            wa[c][p] = pa[(c * NPL + p) * 64];
+            wb[c][p] = pb[(c * NPL + p) * 64];
+        }
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int p = 0; p < NPL; ++p) x[c][p] = ldsb8(bp + p * plane_stride + c * 32);
+    f32x4 mid_a = splat(0.f), mid_b = splat(0.f);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        if (NPL == 2) {
+            mid_a = mfma_h(wa[c][0], x[c][P1], mid_a);
+            mid_b = mfma_h(wb[c][0], x[c][P1], mid_b);
+            mid_a = mfma_h(wa[c][P1], x[c][0], mid_a);
+            mid_b = mfma_h(wb[c][P1], x[c][0], mid_b);
+        }
+        acc_a = mfma_h(wa[c][0], x[c][0], acc_a);
+        acc_b = mfma_h(wb[c][0], x[c][0], acc_b);
+    }
+    if (NPL == 2) {
+        acc_a += mid_a * splat(SPLIT_INV);
+        acc_b += mid_b * splat(SPLIT_INV);
+    }
+}
+__device__ __forceinline__ void wmmax_pf(f32x4& acc_a, f32x4& acc_b, const WUnitX& u, const xhalf* bp, int plane_stride, WUnitX& un,
+                                         const WNextX& n, int lane) {
+    const WUnitX cur = u;  // (`un` may alias `u`)
+    wloadx(un, n, lane);
+    wmmax(acc_a, acc_b, cur, bp, plane_stride);
+}
+#else
 __device__ __forceinline__ void wloadx(WUnitX& u, const WNextX& n, int lane) {
     const xh8* pa = wfragx(n, n.tile_a, lane);
     const xh8* pb = wfragx(n, n.tile_b, lane);
@@ -309,6 +374,7 @@ __device__ __forceinline__ void wmmax(f32x4& acc_a, f32x4& acc_b, const WUnitX& 
         acc_b += mid_b * splat(SPLIT_INV);
     }
 }
+#endif  // TB_XDL_W3
 
 __device__ __forceinline__ WNextX xlayer_first_x(const float* W, const XLayerW& L, const XLayerX& LX, int wave) {
     return wstdx(W, LX.wq, W + L.bq, wave);
@@ -953,15 +1019,19 @@ __device__ __forceinline__ void gh_load_layer(GruGH& gh, const float* __restrict
 }
 
 // the gate arithmetic + stores shared by both forms
+// (Hs / hs_ld: the fp32 previous hidden state -- the tile's LDS copy, or with hs_ld = H the rows in the rollout workspace themselves)
 __device__ __forceinline__ void gru_finish_x(const f32x4 (&ri)[2], const f32x4 (&zi)[2], const f32x4 (&ni)[2], const GruGH& gh, const float* Hs,
                                              xhalf* OutP, float* Out, const uint8_t* rowvalid, float* __restrict__ h_global, int n_real_rows, int wave,
-                                             int lane) {
+                                             int lane, int hs_ld = LDT) {
     const int kq = lane >> 4, m = lane & 15;
     const bool rv = rowvalid[m] != 0;
+    f32x4 holdv[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) holdv[t] = lds4(Hs + m * hs_ld + (2 * wave + t) * 16 + kq * 4);
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
         const int tile = 2 * wave + t;
-        const f32x4 hold = lds4(Hs + m * LDT + tile * 16 + kq * 4);
+        const f32x4 hold = holdv[t];
         const f32x4 r = (ri[t] + gh.b[0][t]) + gh.g[0][t], z = (zi[t] + gh.b[1][t]) + gh.g[1][t];
         f32x4 hn;
 #pragma unroll
@@ -981,7 +1051,8 @@ __device__ __forceinline__ void gru_finish_x(const f32x4 (&ri)[2], const f32x4 (
 // form 1: the workgroup computes gh itself -- six weight units; u = the W_ih r unit on entry, `nxt` on exit
 __device__ __forceinline__ void gru_layer_own_x(const float* __restrict__ W, const GruLayerW& G, const GruLayerX& GX, const xhalf* XinP,
                                                 const xhalf* HsP, const float* Hs, xhalf* OutP, float* Out, const uint8_t* rowvalid,
-                                                float* __restrict__ h_global, int n_real_rows, int tid, WUnitX& u, const WNextX& nxt) {
+                                                float* __restrict__ h_global, int n_real_rows, int tid, WUnitX& u, const WNextX& nxt,
+                                                int hs_ld = LDT) {
     const int wave = wave_of(tid), lane = tid & 63;
     const int kq = lane >> 4, m = lane & 15;
     const int ta = 2 * wave, tb_ = 2 * wave + 1;
@@ -1006,7 +1077,7 @@ __device__ __forceinline__ void gru_layer_own_x(const float* __restrict__ W, con
     gh.b[2][0] = u2.b[0]; gh.b[2][1] = u2.b[1];
     gh.g[2][0] = splat(0.f); gh.g[2][1] = splat(0.f);
     wmmax_pf(gh.g[2][0], gh.g[2][1], u2, hr, PLANE, u, nxt, lane);
-    gru_finish_x(ri, zi, ni, gh, Hs, OutP, Out, rowvalid, h_global, n_real_rows, wave, lane);
+    gru_finish_x(ri, zi, ni, gh, Hs, OutP, Out, rowvalid, h_global, n_real_rows, wave, lane, hs_ld);
 }
 
 // form 2: gh comes from the helper -- three weight units.  ua = the W_ih r unit on entry; the unit after the layer (`nxt`) lands in ub

@@ -114,10 +114,21 @@ int32_t tb_h5_open(const char* path, tb_h5_file** out) {
     if (file < 0) return fail(TB_H5_ERR_IO, std::string("tb_h5_open: cannot open ") + path);
     int64_t len = -1;
     {
-        Hid a(H5Aopen(file, "data_len", H5P_DEFAULT), H5Aclose);
-        if (!a.ok() || H5Aread(a, H5T_NATIVE_INT64, &len) < 0 || len < 0) {
-            H5Fclose(file);
-            return fail(TB_H5_ERR_IO, std::string("tb_h5_open: no readable 'data_len' attribute in ") + path);
+        Hid a(H5Aexists(file, "data_len") > 0 ? H5Aopen(file, "data_len", H5P_DEFAULT) : -1, H5Aclose);
+        if (a.ok()) {
+            if (H5Aread(a, H5T_NATIVE_INT64, &len) < 0 || len < 0) {
+                H5Fclose(file);
+                return fail(TB_H5_ERR_IO, std::string("tb_h5_open: unreadable 'data_len' attribute in ") + path);
+            }
+        } else {
+            // a file without the packer's root attribute (e.g. re-assembled with the HDF5 command-line tools, which cannot write
+            // attributes): the episodes are the root groups "0" .. "n-1" -- count the consecutive ones
+            len = 0;
+            while (H5Lexists(file, std::to_string(len).c_str(), H5P_DEFAULT) > 0) ++len;
+            if (len == 0) {
+                H5Fclose(file);
+                return fail(TB_H5_ERR_IO, std::string("tb_h5_open: no 'data_len' attribute and no episode group \"0\" in ") + path);
+            }
         }
     }
     tb_h5_file* f = new tb_h5_file();

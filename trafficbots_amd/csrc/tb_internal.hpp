@@ -44,6 +44,12 @@ struct tb_ctx {
     int n_timed_steps = 0;
     std::vector<uint8_t> launch_kind;  // per step launch of the last tb_rollout: 2 fused, 1 one half, 0 skipped (tb_get_timing)
     int n_pre = 0;                     // batched warm-start slices of the rollout being set up
+    // one hipGraph per rollout (tb_rollout): the S + 1 step launches + prologue captured once and replayed while every kernel
+    // argument stays the same (same buffers, sizes, switches) -- the launching thread then spends microseconds per rollout instead of
+    // ~70 us per launch; TB_ROLLOUT_GRAPH=0 turns it off
+    hipGraphExec_t graph_exec = nullptr;
+    unsigned long long graph_key = 0, graph_seen = 0;  // key of the captured graph / of the previous call (capture on the second sight)
+    int graph_hits = 0, graph_captures = 0;
 };
 
 

@@ -29,8 +29,16 @@ constexpr int STEPX_LDS_FLOATS = XO_PL + 4 * PLANES_FLOATS;
 // instances): the weight-streaming GEMM phases of one run under the latency-bound attention / LayerNorm phases of the other.
 // (with fp16-pair planes the destination geometry leaves LDS as well -- the epilogue reads its 20 nodes per agent from the workspace --
 // and the kernel is compiled for two waves per SIMD, i.e. 256 VGPRs)
+// (the W3 build -- tb_stepx_bf16w3_kernels.hip, three workgroups per CU -- goes further: the GRU hidden tiles stay in the rollout
+// workspace (planes are made from there, the convex update reads its rows there) and ONE fp32 tile is kept as the action head's
+// third scratch buffer: 49 KB)
+#ifdef TB_XDL_W3
+constexpr bool W3 = true;
+#else
+constexpr bool W3 = false;
+#endif
 constexpr bool XL_DG_GLOBAL = NPL == 2;
-constexpr int XL_DG = XO_GP;
+constexpr int XL_DG = W3 ? XO_H1 : XO_GP;
 constexpr int XL_SMALL = XL_DG + (XL_DG_GLOBAL ? 0 : TM * 80);
 constexpr int XL_ENCW = XL_SMALL + SMALL_FLOATS;
 constexpr int XL_PL = XL_ENCW + ENCW_FLOATS;
@@ -89,6 +97,7 @@ __device__ __forceinline__ void fuse_latent_goal_x(const float* __restrict__ W, 
     __syncthreads();
 }
 
+#ifndef TB_XDL_W3
 // Rollout prologue: goal_pre / lat_pre (pre-activations of add_goal / add_latent's mlp_in, k_rollout_init) -> the hoisted half of
 // the fusion MLPs' first Linear, in place: PRE <- W1[:, 128:256] relu(PRE)  (no bias: b1 rides with the x half).  grid (a_pad/16, N)
 __global__ __launch_bounds__(NTHREADS) void k_fuse_hoist_x(RolloutP p) {
@@ -126,18 +135,30 @@ void launch_fuse_hoist_x(const RolloutP& p, hipStream_t s) {
     hipLaunchKernelGGL(k_fuse_hoist_x, grid, dim3(NTHREADS), TM * LDT * sizeof(float) + PLANES_BYTES, s, p);
 }
 
+#endif  // !TB_XDL_W3
+
 // PRE = the batched warm start (RolloutP::pre_mode): A half only, inputs from the ground truth, grid.z = steps
-template <bool PRE, bool LEAN = false>
-__global__ __launch_bounds__(NTHREADS, LEAN ? 2 : 1) void k_step_x(RolloutP p, int t, int do_c, int do_a) {
+// G = 3 (W3 build only): ONE workgroup of twelve waves = three groups of four, group g running this kernel's unchanged four-wave code
+// on its own LDS carve for the SAME row tile of three consecutive instances (futures 3j .. 3j+2 of a scene).  The workgroup barriers
+// keep the three groups in step, so they ask for the same weight fragments and the same map / traffic-light K / V blocks within a
+// few hundred cycles of each other and the CU's L1 fetches each line once: the per-CU vector-memory traffic of a K = 6 launch drops
+// from three copies of the weight set per step to one.  Requires n_inst % 3 == 0 and a barrier-uniform control flow across the
+// groups -- the one divergent branch, the single-agent interaction bypass, is run as "compute and discard" when the groups disagree.
+template <bool PRE, bool LEAN = false, int G = 1>
+__global__ __launch_bounds__(NTHREADS * G, G > 1 ? 1 : (LEAN ? (W3 ? 3 : 2) : 1)) void k_step_x(RolloutP p, int t, int do_c, int do_a) {
+    static_assert(!W3 || LEAN, "the W3 build holds the LEAN carve only");
+    static_assert(G == 1 || (W3 && !PRE), "wave groups: the W3 build's step launch only");
     if (PRE) {
         do_c = 0;
         do_a = 1;
     }
-    extern __shared__ __attribute__((aligned(16))) float smem[];
+    extern __shared__ __attribute__((aligned(16))) float smem_all[];
+    const int grp = G > 1 ? __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 8) : 0;
+    float* smem = smem_all + (G > 1 ? grp * STEPX_LEAN_LDS_FLOATS : 0);
     float* X = smem + XO_X;
     float* Hs = smem + XO_H;
-    float* H1 = smem + XO_H1;
-    float* H2 = smem + XO_H2;
+    float* H1 = W3 ? nullptr : smem + XO_H1;   // (W3: no LDS copies of the hidden state; Hs is the action head's scratch tile)
+    float* H2 = W3 ? nullptr : smem + XO_H2;
     float* GP = LEAN ? nullptr : smem + XO_GP;
     float* LP = LEAN ? nullptr : smem + XO_LP;
     float* DG = smem + (LEAN ? XL_DG : XO_DG);
@@ -156,9 +177,11 @@ __global__ __launch_bounds__(NTHREADS, LEAN ? 2 : 1) void k_step_x(RolloutP p, i
     int* rtype = sm.rtype;
     int* dflag = sm.dflag;
 
-    const int tid = threadIdx.x, wave = wave_of(tid), lane = tid & 63, kq = lane >> 4, m = lane & 15;
+    const int tid = G > 1 ? ((int)threadIdx.x & (NTHREADS - 1)) : (int)threadIdx.x;
+    const int wave = wave_of(tid), lane = tid & 63, kq = lane >> 4, m = lane & 15;
     int n, rt;
     step_tile_map(n, rt);
+    if (G > 1) n = n * G + grp;  // (gridDim.y = n_inst / G: instance triples)
     if (PRE) t = p.pre_t0 + (int)blockIdx.z;  // batched warm start: A(t + 1) of step t from the ground truth of step t
     // (the K futures of a scene share the ground truth: the batched launch runs once per SCENE, in the slot of future 0, and
     // k_pre_replicate copies the slices to the other futures)
@@ -173,7 +196,7 @@ __global__ __launch_bounds__(NTHREADS, LEAN ? 2 : 1) void k_step_x(RolloutP p, i
     // staggered start of the key walks of the row tiles of one instance (attention_prefetch_x)
     const int n_rt = gridDim.x;
     const int tile_id = n * n_rt + rt;
-    const bool helpers = !PRE && gridDim.z == 2;
+    const bool helpers = !W3 && !PRE && gridDim.z == 2;
     if (helpers && blockIdx.z == 0) {
         // ---- helper of tile (n, rt) (RolloutP::gh): interaction K / V of layers 1, 2 of THIS step from the stored x_mid, then
         // W_hh h_{t-1} of the three GRU layers; handed to the tile workgroups (blockIdx.z = 1) through L2
@@ -241,7 +264,7 @@ __global__ __launch_bounds__(NTHREADS, LEAN ? 2 : 1) void k_step_x(RolloutP p, i
 #pragma unroll
         for (int i = 0; i < 4; ++i)
             if (i * 64 + lane < p.a_pad) vb[i] = p.valid[(size_t)n * p.a_pad + i * 64 + lane];  // (a_pad <= 256)
-        c_inputs_issue<NTHREADS, LEAN ? 4 : 6, !(LEAN && XL_DG_GLOBAL)>(p, n, row0, tid, cin);
+        c_inputs_issue<NTHREADS, W3 ? 1 : (LEAN ? 4 : 6), !(LEAN && XL_DG_GLOBAL)>(p, n, row0, tid, cin);
     }
     if (!LEAN) {
 #pragma unroll
@@ -276,17 +299,27 @@ __global__ __launch_bounds__(NTHREADS, LEAN ? 2 : 1) void k_step_x(RolloutP p, i
         // scenes keep their valid agents in the leading slots)
         const int nk_a = min(p.a_pad, max(32, (hi_valid + 31) & ~31));
         const int ks_a = ((rt * (nk_a >> 5)) / n_rt) << 5;
-        c_inputs_commit<NTHREADS, LEAN ? 4 : 6, !(LEAN && XL_DG_GLOBAL)>(tid, cin, X, Hs, H1, H2, GP, LP, DG, dflag);
+        c_inputs_commit<NTHREADS, W3 ? 1 : (LEAN ? 4 : 6), !(LEAN && XL_DG_GLOBAL)>(tid, cin, X, Hs, H1, H2, GP, LP, DG, dflag);
         if (!LEAN) {
 #pragma unroll
             for (int sl = 0; sl < 9; ++sl)
                 if (tid < 192) st4(LN + sl * 768 + tid * 4, lnv[sl]);
         }
-        if (bypass) wloadx(u, gru_first_x(W, pw.gru[0], px.gru[0], wave), lane);
+        if (G == 1 && bypass) wloadx(u, gru_first_x(W, pw.gru[0], px.gru[0], wave), lane);
         __syncthreads();
         TB_STAMP(1);
         unsigned int gh_seen = 0u;  // the GRU helper's flag, requested one interaction layer early (thread 0)
-        if (!bypass) {
+        // (G > 1: the wave groups share the workgroup's barriers, so a group whose instance takes the single-agent bypass runs the
+        // three layers as well and puts its tile back afterwards: the scratch tile Hs is free until the action head, and the copy
+        // uses tile_to_planes' thread -> element map, the first reader of X after the block)
+        if (G > 1 && bypass) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int idx = tid + i * NTHREADS;
+                st4(Hs + (idx >> 5) * LDT + (idx & 31) * 4, lds4(X + (idx >> 5) * LDT + (idx & 31) * 4));
+            }
+        }
+        if (G > 1 || !bypass) {
             const float* kvd = p.vbias + (size_t)n * p.a_pad;
             const size_t ls = (size_t)p.a_pad * H;
             const xhalf* K0 = reinterpret_cast<const xhalf*>(p.kin + ((size_t)n * 3) * ls);
@@ -308,6 +341,13 @@ __global__ __launch_bounds__(NTHREADS, LEAN ? 2 : 1) void k_step_x(RolloutP p, i
             }
             xattn_layer_x<!LEAN, true>(W, pw.inter[2], px.inter[2], X, PA, PB, K0 + 4 * ls, V0 + 4 * ls, kvd, nk_a, ks_a, row0, rowvalid,
                                 novalid_s, tid, u, gru_first_x(W, pw.gru[0], px.gru[0], wave), (LEAN ? nullptr : LN + 2 * 768), nullptr, amax);
+        }
+        if (G > 1 && bypass) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int idx = tid + i * NTHREADS;
+                st4(X + (idx >> 5) * LDT + (idx & 31) * 4, lds4(Hs + (idx >> 5) * LDT + (idx & 31) * 4));
+            }
         }
         TB_STAMP(2);
         // ---- 3-layer GRU, one step (agent_temporal.py:147-152).  planes: x0 = PA, h0 = PB, h1 = PD, out0 = PC, h2 -> PB, out1 = PA
@@ -332,7 +372,7 @@ __global__ __launch_bounds__(NTHREADS, LEAN ? 2 : 1) void k_step_x(RolloutP p, i
             }
             tile_to_planes(X, LDT, PA, tid, amax);
             __syncthreads();
-            if (*gh_ok) {  // (workgroup-uniform)
+            if (!W3 && *gh_ok) {  // (workgroup-uniform)
                 const float* ght = p.gh + (size_t)tile_id * GH_TILE_FLOATS;
                 WUnitX ux;
                 GruGH gh;
@@ -345,14 +385,19 @@ __global__ __launch_bounds__(NTHREADS, LEAN ? 2 : 1) void k_step_x(RolloutP p, i
                                wnextx(W, px.goal_out_w1, W + pw.goal_out_b1, 2 * wave, 2 * wave + 1, 8, 0), gh);
                 u = ux;
             } else {
-                tile_to_planes<false>(Hs, LDT, PB, tid);  // (GRU states: |h| <= 1)
-                tile_to_planes<false>(H1, LDT, PD, tid);
+                // (W3: the previous hidden state is read where it lives, the rollout workspace -- rows of H floats)
+                const float* h0 = W3 ? hg0 : Hs;
+                const float* h1 = W3 ? hg1 : H1;
+                const float* h2 = W3 ? hg2 : H2;
+                const int hld = W3 ? H : LDT;
+                tile_to_planes<false>(h0, hld, PB, tid);  // (GRU states: |h| <= 1)
+                tile_to_planes<false>(h1, hld, PD, tid);
                 __syncthreads();
-                gru_layer_own_x(W, pw.gru[0], px.gru[0], PA, PB, Hs, PC, nullptr, rowvalid, hg0, TM, tid, u, gru_first_x(W, pw.gru[1], px.gru[1], wave));
-                tile_to_planes<false>(H2, LDT, PB, tid);  // (h0's planes are free after the barrier that closed layer 0)
-                gru_layer_own_x(W, pw.gru[1], px.gru[1], PC, PD, H1, PA, nullptr, rowvalid, hg1, TM, tid, u, gru_first_x(W, pw.gru[2], px.gru[2], wave));
-                gru_layer_own_x(W, pw.gru[2], px.gru[2], PA, PB, H2, nullptr, X, rowvalid, hg2, TM, tid, u,
-                                wnextx(W, px.goal_out_w1, W + pw.goal_out_b1, 2 * wave, 2 * wave + 1, 8, 0));
+                gru_layer_own_x(W, pw.gru[0], px.gru[0], PA, PB, h0, PC, nullptr, rowvalid, hg0, TM, tid, u, gru_first_x(W, pw.gru[1], px.gru[1], wave), hld);
+                tile_to_planes<false>(h2, hld, PB, tid);  // (h0's planes are free after the barrier that closed layer 0)
+                gru_layer_own_x(W, pw.gru[1], px.gru[1], PC, PD, h1, PA, nullptr, rowvalid, hg1, TM, tid, u, gru_first_x(W, pw.gru[2], px.gru[2], wave), hld);
+                gru_layer_own_x(W, pw.gru[2], px.gru[2], PA, PB, h2, nullptr, X, rowvalid, hg2, TM, tid, u,
+                                wnextx(W, px.goal_out_w1, W + pw.goal_out_b1, 2 * wave, 2 * wave + 1, 8, 0), hld);
             }
         }
         TB_STAMP(3);
@@ -374,6 +419,11 @@ __global__ __launch_bounds__(NTHREADS, LEAN ? 2 : 1) void k_step_x(RolloutP p, i
         // ---- action head (action_head.py:69-75): first Linear of every type present, hidden tiles -> Hs / H1 / H2
         // (the GRU hidden copies are dead by now), then ONE reduction stage for the 128 -> 2 Linear of each row's own type
         tile_to_planes(X, LDT, PA, tid, amax);
+        // (W3: the per-type hidden tiles go to the scratch tile, to X -- dead once its planes are made, behind the barrier below --
+        // and to the three plane buffers that are free here)
+        float* const HB0 = Hs;
+        float* const HB1 = W3 ? X : H1;
+        float* const HB2 = W3 ? reinterpret_cast<float*>(PB) : H2;
         if (tid < 32) ubuf[tid] = 0.f;
         // the second Linear's 16 weights of this thread's (row, output) pair are requested here, in front of the first Linears
         // (row types and validity are known since the prologue): the reduction stage then starts without a round trip to L2
@@ -398,7 +448,7 @@ __global__ __launch_bounds__(NTHREADS, LEAN ? 2 : 1) void k_step_x(RolloutP p, i
             WUnitX uh = u;
             f32x4 acc[2] = {uh.b[0], uh.b[1]};
             wmmax_pf(acc[0], acc[1], uh, PA + m * LDP + kq * 8, PLANE, u, ty == 0 ? h1 : (ty == 1 ? h2 : after_head), lane);
-            float* hb = ty == 0 ? Hs : (ty == 1 ? H1 : H2);
+            float* hb = ty == 0 ? HB0 : (ty == 1 ? HB1 : HB2);
             st4(cptr(hb, LDT, 2 * wave, lane), relu4(acc[0]));
             st4(cptr(hb, LDT, 2 * wave + 1, lane), relu4(acc[1]));
         }
@@ -409,7 +459,7 @@ __global__ __launch_bounds__(NTHREADS, LEAN ? 2 : 1) void k_step_x(RolloutP p, i
             const int ty = hp_ty;
             const bool use = ty >= 0 && rowvalid[r];
             const int tyc = hp_tyc;
-            const float* hb = tyc == 0 ? Hs : (tyc == 1 ? H1 : H2);
+            const float* hb = tyc == 0 ? HB0 : (tyc == 1 ? HB1 : HB2);
             const float* xs = hb + r * LDT + sub * 16;
             float sacc = 0.f;
 #pragma unroll
@@ -507,11 +557,20 @@ __global__ __launch_bounds__(NTHREADS, LEAN ? 2 : 1) void k_step_x(RolloutP p, i
     range_flush(amax);
 }
 
+#ifdef TB_XDL_W3
+template __global__ void k_step_x<false, true>(RolloutP, int, int, int);
+template __global__ void k_step_x<true, true>(RolloutP, int, int, int);
+template __global__ void k_step_x<false, true, 3>(RolloutP, int, int, int);
+static_assert(3 * STEPX_LEAN_LDS_FLOATS * 4 <= 160 * 1024, "three wave groups must fit one CU's LDS");
+#else
 template __global__ void k_step_x<false>(RolloutP, int, int, int);  // (emitted first: the launch of every simulation step)
 template __global__ void k_step_x<true>(RolloutP, int, int, int);
 template __global__ void k_step_x<false, true>(RolloutP, int, int, int);
 template __global__ void k_step_x<true, true>(RolloutP, int, int, int);
 
+#endif
+
+#ifndef TB_XDL_W3
 // K/V of the three layers of a cross-attention block for fixed targets (map polylines, TL stop points), in the XDL operand
 // order (tb_device_xdl.hpp): the fp16-pair twin of k_kv_hoist.  grid = (n_pad/16, G)
 // The VALID targets of a group are compacted to the front (softmax is order independent): nkey[g] = their count rounded up to a
@@ -579,7 +638,7 @@ void launch_kv_hoist_x(const float* W, const XLayerW* L3, const XLayerX* X3, con
     hipLaunchKernelGGL(k_kv_hoist_x, grid, dim3(NTHREADS), TM * LDT * sizeof(float) + PLANES_BYTES, s, W, L3[0], L3[1], L3[2], X3[0],
                        X3[1], X3[2], feat, fvalid, n_tok, n_pad, K, VT, kbias, nkey);
 }
-
+#endif  // !TB_XDL_W3
 
 // fp16-pair range flag of THIS translation unit (tb_device_xdl.hpp): OR it into *out and clear it (tb_check_status)
 #ifndef TB_XDL_BF16
@@ -590,6 +649,36 @@ __global__ void k_range_flag_take_step(unsigned int* out) {
 void launch_range_flag_take_step(unsigned int* out, hipStream_t s) { hipLaunchKernelGGL(k_range_flag_take_step, dim3(1), dim3(1), 0, s, out); }
 #endif
 
+#ifdef TB_XDL_W3
+hipError_t configure_stepx_kernel() {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_step_x<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)(STEPX_LEAN_LDS_FLOATS * sizeof(float)));
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_step_x<false, true, 3>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)(3 * STEPX_LEAN_LDS_FLOATS * sizeof(float)));
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(k_step_x<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)(STEPX_LEAN_LDS_FLOATS * sizeof(float)));
+}
+
+// (the caller -- tb_api.hip: step_launch -- picks this build for bf16 launches of more than 512 tiles)
+void launch_step_x(const RolloutP& p0, int t, int do_c, int do_a, hipStream_t s) {
+    RolloutP p = p0;
+    p.gh_flag = nullptr;  // (no helper workgroups: the launch fills the chip three times over)
+    {
+        // futures in multiples of three: twelve-wave workgroups, three futures of a scene in step (k_step_x<., ., 3>);
+        // TB_STEP_W3G=0 keeps the four-wave workgroups (development / A-B switch; same results)
+        const char* e = getenv("TB_STEP_W3G");
+        if (p.k_rep % 3 == 0 && p.n_inst % 3 == 0 && !(e && e[0] == '0')) {
+            dim3 grid3(p.a_pad / TM, p.n_inst / 3, 1);
+            hipLaunchKernelGGL((k_step_x<false, true, 3>), grid3, dim3(NTHREADS * 3), 3 * STEPX_LEAN_LDS_FLOATS * sizeof(float), s, p, t, do_c, do_a);
+            return;
+        }
+    }
+    dim3 grid(p.a_pad / TM, p.n_inst, 1);
+    hipLaunchKernelGGL((k_step_x<false, true>), grid, dim3(NTHREADS), STEPX_LEAN_LDS_FLOATS * sizeof(float), s, p, t, do_c, do_a);
+}
+#else
 hipError_t configure_stepx_kernel() {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_step_x<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)(STEPX_LDS_FLOATS * sizeof(float)));
@@ -618,6 +707,8 @@ void launch_step_x(const RolloutP& p0, int t, int do_c, int do_a, hipStream_t s)
     }
     hipLaunchKernelGGL(k_step_x<false>, grid, dim3(NTHREADS), STEPX_LDS_FLOATS * sizeof(float), s, p, t, do_c, do_a);
 }
+
+#endif  // TB_XDL_W3
 
 // slices of future 0 of every scene -> futures 1 .. K-1 (x_mid rows, K and V of the three layers).  grid (n_pre * n_scene * (K - 1))
 __global__ __launch_bounds__(256) void k_pre_replicate(RolloutP p, int n_pre) {
@@ -651,6 +742,10 @@ void launch_step_pre_x(const RolloutP& p0, int t0, int n, hipStream_t s) {
     p.pre_mode = 1;
     p.pre_t0 = t0;
     dim3 grid(p.a_pad / TM, p.n_scene, n);
+#ifdef TB_XDL_W3
+    hipLaunchKernelGGL((k_step_x<true, true>), grid, dim3(NTHREADS), STEPX_LEAN_LDS_FLOATS * sizeof(float), s, p, t0, 0, 1);
+    if (p.k_rep > 1) launch_pre_replicate(p, n, s);
+#else
     {
         // n x tiles workgroups: the LEAN carve (two workgroups per CU) whenever that is more than the chip has CUs
         const char* e = getenv("TB_STEP_LEAN");
@@ -662,6 +757,7 @@ void launch_step_pre_x(const RolloutP& p0, int t0, int n, hipStream_t s) {
     }
     hipLaunchKernelGGL(k_step_x<true>, grid, dim3(NTHREADS), STEPX_LDS_FLOATS * sizeof(float), s, p, t0, 0, 1);
     if (p.k_rep > 1) launch_pre_replicate(p, n, s);
+#endif
 }
 
 }  // namespace TB_XNS

@@ -36,7 +36,10 @@ def teacher_forcing_mask(valid: Tensor, step_spawn_agent: int = 10, step_warm_st
         m[:, 1:] |= sp
     if step_warm_start >= 0:
         m[:, : step_warm_start + 1] |= valid[:, : step_warm_start + 1]
-    m._tb_warm_start = int(step_warm_start)  # provenance for `warm_start_promise_holds` (a plain attribute on the tensor object)
+    # provenance for `warm_start_promise_holds`: the warm-start length AND the tensor's version counter at this point -- an in-place
+    # edit afterwards (`mask[:, 5, i] = False`, the reference's own `mask_state_override[:, 0] = True` idiom on a view) bumps the
+    # counter and voids the tag, so an edited mask is checked on its data like any caller-made one
+    m._tb_warm_start = (int(step_warm_start), m._version)
     return m
 
 
@@ -46,7 +49,8 @@ def warm_start_promise_holds(mask_teacher_forcing: Tensor, valid: Tensor, w: int
     (one device -> host read)."""
     if w <= 0:
         return True
-    if getattr(mask_teacher_forcing, "_tb_warm_start", -1) >= w:
+    tag = getattr(mask_teacher_forcing, "_tb_warm_start", None)
+    if tag is not None and tag[0] >= w and tag[1] == mask_teacher_forcing._version:
         return True
     m, v = mask_teacher_forcing[:, : w + 1].bool(), valid[:, : w + 1].bool().to(mask_teacher_forcing.device)
     return bool((m | ~v).all())
@@ -316,7 +320,13 @@ class HipEngine:
             gd = gt_dest.to(dev).to(torch.int32).contiguous()
             keep.append(gd)
             io.gt_dest = hip.ptr(gd, hip.c_i32p)
-        if tm["p_loss_for_irrelevant"] > 0 and (io.use_vae_kl or io.use_goal):  # (the reward-only call of rollout() has no losses to mask)
+        # p_loss_for_irrelevant masks the reward states as well (training.py:85-115): whenever the role / draw are supplied they are
+        # applied.  The reward-only call that rollout() makes (no role, no draw, no KL / goal terms) cannot apply them: it returns
+        # None for the states instead of unmasked numbers; the rewards themselves are per step and unaffected
+        states_valid = True
+        if tm["p_loss_for_irrelevant"] > 0 and not (io.use_vae_kl or io.use_goal) and agent_role is None and irrelevant_draw is None:
+            states_valid = False
+        elif tm["p_loss_for_irrelevant"] > 0:
             if agent_role is None:
                 raise ValueError("p_loss_for_irrelevant > 0 needs agent_role")
             if irrelevant_draw is None:
@@ -332,7 +342,7 @@ class HipEngine:
         io.out = C.cast(C.c_void_p(states.data_ptr()), C.POINTER(C.c_double))
         self._check(self.lib.tb_train_partials(self._ctx, C.byref(io), self._stream()), "tb_train_partials")
         self._train_keepalive = keep
-        return rewards, rvalid, states
+        return rewards, rvalid, (states if states_valid else None)
 
     # -------------------------------------------------------------------------------- rollout
     def rollout(
@@ -377,9 +387,20 @@ class HipEngine:
             tf = self.cfg["teacher_forcing_joint_future_pred"]
             if warm_start_steps == 0 and ag.get("warm_ok", False) and tf.get("step_warm_start", 10) >= 0:
                 warm_start_steps = min(int(tf.get("step_warm_start", 10)), self.n_hist - 1)
-            mask_teacher_forcing = teacher_forcing_mask(
-                ag["agent_valid"].bool(), tf.get("step_spawn_agent", 10), tf.get("step_warm_start", 10)
-            ).to(u8).contiguous()
+            # (the default mask of a caller that re-uses its buffers -- `out=` -- is made once: same device address on every pass, so
+            # tb_rollout can replay its captured graph; keyed by the validity tensor it was made from)
+            mkey = (ag["agent_valid"].data_ptr(), ag["agent_valid"]._version, tuple(ag["agent_valid"].shape),
+                    tf.get("step_spawn_agent", 10), tf.get("step_warm_start", 10))
+            cached = out.get("_default_tf_mask") if out is not None else None
+            if cached is not None and cached[0] == mkey:
+                mask_teacher_forcing = cached[1]
+            else:
+                mask_teacher_forcing = teacher_forcing_mask(
+                    ag["agent_valid"].bool(), tf.get("step_spawn_agent", 10), tf.get("step_warm_start", 10)
+                ).to(u8).contiguous()
+            default_mask = (mkey, mask_teacher_forcing)
+        else:
+            default_mask = None
         assert mask_teacher_forcing.shape == (b, nh, a)
         if out is None:
             out = {
@@ -451,6 +472,8 @@ class HipEngine:
             assert action_eps.shape == (n, a, n_step, 2), (tuple(action_eps.shape), (n, a, n_step, 2))
         io.action_eps = hip.ptr(action_eps, hip.c_f32p)
         # keep the borrowed inputs alive until the stream work is done
+        if default_mask is not None:
+            out["_default_tf_mask"] = default_mask
         out["_keepalive"] = (latent_sample, latent_mean, dest, goal_valid, mask_teacher_forcing, s, feats, gt, action_eps)
         if stepwise:
             self._check(self.lib.tb_rollout_begin(self._ctx, C.byref(io), self._stream()), "tb_rollout_begin")

@@ -431,7 +431,7 @@ class WaymoMotion:
                 action_override: Optional[Tensor] = None, mask_action_override: Optional[Tensor] = None,
                 state_override: Optional[Dict[str, Tensor]] = None, mask_state_override: Optional[Tensor] = None,
                 deterministic_action: bool = True, require_train_dict: bool = True, require_vis_dict: bool = False,
-                gt_valid: Optional[Tensor] = None):
+                gt_valid: Optional[Tensor] = None, _skip_state: bool = False):
         """One simulation step with the reference's signature, the stateful `WaymoMotion.forward` (`waymo_motion.py:108-203`):
         advances the simulator opened by `rollout(..., stepwise=True)` and returns `(agent_state, agent_valid, train_dict, vis_dict)`.
 
@@ -490,9 +490,11 @@ class WaymoMotion:
         if action_override is not None:
             override = dict(override or {}, action=action_override, action_mask=mask_action_override)
         eng.rollout_step(override)
-        st = eng.rollout_state()
         s_idx = self._step_t - self.hparams["time_step_sim_start"]
         self._step_t += 1
+        if _skip_state:  # (the per-step loops of this mirror read the state once at the end: no three D2D copies per step)
+            return None, None, {}, {}
+        st = eng.rollout_state()
         train_dict = {}
         if require_train_dict:
             train_dict = {
@@ -521,10 +523,10 @@ class WaymoMotion:
                   "acc": rep(src["agent_acc"][:, tt]).unsqueeze(-1).clone(), "yaw_rate": rep(src["agent_yaw_rate"][:, tt]).unsqueeze(-1).clone()}
             if gt_sdc is not None:
                 m[:, 0] = True
-                for k in so:
+                for k in gt_sdc.keys():  # (the reference iterates gt_sdc.keys(), waymo_motion.py:283-284: a dict with fewer keys is fine)
                     so[k][:, 0] = gt_sdc[k][:, t].to(self.device).to(so[k].dtype).reshape(so[k][:, 0].shape)
             gtv = rep(src["agent_valid"][:, t]) if in_src else None
-            self.forward(state_override=so, mask_state_override=m, gt_valid=gtv, require_train_dict=False)
+            self.forward(state_override=so, mask_state_override=m, gt_valid=gtv, require_train_dict=False, _skip_state=True)
 
     def joint_future_pred(
         self,
