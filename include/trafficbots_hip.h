@@ -298,6 +298,37 @@ typedef struct tb_train_io {
 } tb_train_io;
 int tb_train_partials(tb_ctx* ctx, const tb_train_io* io, tb_stream stream);
 
+/* -- the policy trunk as a stand-alone call, with attention weights ------------------------------------ */
+/* Replaces: TrafficBots.forward(agent_valid, agent_feature, map_valid, map_feature, tl_valid, tl_feature, goal_valid, goal_feature,
+ * need_weights) -> (policy_feature, latent_logp, attn_pl, attn_tl, attn_agent)  (src/models/traffic_bots.py:163-247) for the default
+ * configuration (interaction_first, add_goal_latent_first = False, no final MLP): 3 x agent->map, 3 x agent->traffic-light,
+ * 3 x agent<->agent attention (eye mask, single-agent bypass), one step of the 3-layer GRU, add_goal, add_latent.  With
+ * need_weights the reference returns the head-mean attention weights of the LAST layer of each block (attention.py:115-146,
+ * transformer.py:82-95, agent_interaction.py:61-93; rows without an admissible key and single-agent instances are zero) -- the
+ * attn_* pointers (NULL = not wanted).  The fused step kernel never materialises them; this call is the un-fused visualisation /
+ * debugging path (plain fp32 kernels over row-major copies of the weights, ~70 launches), and an on-device cross-check of the fused
+ * kernel.  `hidden` is read and overwritten (TrafficBots.hidden; zeros = the reference's `hidden = None`).  `latent_sample` is the
+ * personality drawn at TrafficBots.init time (latent_logp is the caller's: DiagGaussian.log_prob).  goal_feature / goal_valid NULL:
+ * no goal (add_goal is skipped, as the reference does for goal_feature = None).  All tensors per INSTANCE, device pointers. */
+typedef struct tb_forward_io {
+    int32_t n_inst, n_agent, n_pl, n_tl;
+    const uint8_t* agent_valid;    /* [N,A] */
+    const float* agent_feature;    /* [N,A,128] */
+    const uint8_t* map_valid;      /* [N,P] */
+    const float* map_feature;      /* [N,P,128] */
+    const uint8_t* tl_valid;       /* [N,T] */
+    const float* tl_feature;       /* [N,T,128] */
+    const uint8_t* goal_valid;     /* [N,A] or NULL */
+    const float* goal_feature;     /* [N,A,128] or NULL */
+    const float* latent_sample;    /* [N,A,16] */
+    float* hidden;                 /* [3,N,A,128] in / out */
+    float* policy_feature;         /* [N,A,128] out */
+    float* attn_pl;                /* [N,A,P] out or NULL */
+    float* attn_tl;                /* [N,A,T] out or NULL */
+    float* attn_agent;             /* [N,A,A] out or NULL */
+} tb_forward_io;
+int tb_forward(tb_ctx* ctx, const tb_forward_io* io, tb_stream stream);
+
 /* -- instrumentation ---------------------------------------------------------------------------------- */
 /* Per-launch durations (ms, HIP events recorded on `stream`) of the LAST tb_rollout when timing was enabled with
  * tb_set_timing(ctx, 1).  A rollout of S steps issues S+1 step launches: A(1) alone, S-1 fused launches
@@ -402,9 +433,9 @@ typedef struct tb_metric_io {
 int tb_metric_partials(tb_ctx* ctx, const tb_metric_io* io, tb_stream stream);
 
 /* sizeof() of the structs of this header as the library was compiled: out[0..5] = tb_config, tb_rollout_io, tb_encode_io,
- * tb_rule_io, tb_post_io, tb_metric_io; out[6] = the pointer size; out[7..8] = tb_posterior_io, tb_train_io -- lets a binding
+ * tb_rule_io, tb_post_io, tb_metric_io; out[6] = the pointer size; out[7..8] = tb_posterior_io, tb_train_io; out[9..10] = tb_step_override, tb_forward_io -- lets a binding
  * check its mirror of the layouts before the first call (no GPU needed). */
-void tb_struct_sizes(int32_t out[9]);
+void tb_struct_sizes(int32_t out[11]);
 
 #ifdef __cplusplus
 }

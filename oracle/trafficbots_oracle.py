@@ -91,8 +91,9 @@ class Oracle:
         return kv[..., :H], kv[..., H:]
 
     def tf_layer(self, prefix: str, src: Tensor, src_invalid: Tensor, tgt: Optional[Tensor], tgt_invalid: Tensor,
-                 attn_mask: Optional[Tensor] = None, kv=None) -> Tensor:
-        """One pre-LN `TransformerCrossAttention` layer incl. `Attention` (`transformer.py:189-239`,
+                 attn_mask: Optional[Tensor] = None, kv=None, need_weights: bool = False):
+        """(`need_weights`: also the head-mean attention weights [n, ns, nt], zero for rows without an admissible key, `attention.py:142-146`.)
+        One pre-LN `TransformerCrossAttention` layer incl. `Attention` (`transformer.py:189-239`,
         `attention.py:81-146`), eval mode.  src [n, ns, H]; tgt [n, nt, H]; masks True = invalid."""
         n, ns, _ = src.shape
         w_in = self.w[prefix + ".attn.in_proj_weight"]
@@ -112,6 +113,7 @@ class Oracle:
         attn = torch.matmul(q, k.transpose(-2, -1))
         attn = attn.masked_fill(inv.unsqueeze(1), float("-inf"))
         attn = torch.softmax(attn / math.sqrt(D_HEAD), dim=-1)
+        weights = attn.mean(1).masked_fill(no_tgt.unsqueeze(-1), 0) if need_weights else None
         out = torch.matmul(attn, v).transpose(1, 2).flatten(2, 3)
         out = F.linear(out, self.w[prefix + ".attn.out_proj_weight"], self.w[prefix + ".attn.out_proj_bias"])
         out = out.masked_fill(no_tgt.unsqueeze(-1), 0)
@@ -119,22 +121,30 @@ class Oracle:
         s2 = self._ln(src, prefix + ".norm2")
         s2 = self._lin(torch.relu(self._lin(s2, prefix + ".linear1")), prefix + ".linear2")
         src = src + s2
-        return src.masked_fill(src_invalid.unsqueeze(-1), 0.0)
+        src = src.masked_fill(src_invalid.unsqueeze(-1), 0.0)
+        return (src, weights) if need_weights else src
 
-    def tf_block(self, prefix: str, n_layer: int, src, src_invalid, tgt, tgt_invalid, attn_mask=None, kvs=None):
-        """`TransformerBlock.forward` (`transformer.py:82-92`): tgt is NOT updated between layers."""
+    def tf_block(self, prefix: str, n_layer: int, src, src_invalid, tgt, tgt_invalid, attn_mask=None, kvs=None, need_weights: bool = False):
+        """`TransformerBlock.forward` (`transformer.py:82-92`): tgt is NOT updated between layers; with `need_weights` the weights of the
+        LAST layer come back too (`:81-95`)."""
+        w = None
         for i in range(n_layer):
             src = self.tf_layer(f"{prefix}.layers.{i}", src, src_invalid, tgt, tgt_invalid, attn_mask,
-                                kv=None if kvs is None else kvs[i])
-        return src
+                                kv=None if kvs is None else kvs[i], need_weights=need_weights)
+            if need_weights:
+                src, w = src
+        return (src, w) if need_weights else src
 
-    def interaction(self, prefix: str, x: Tensor, valid: Tensor) -> Tensor:
+    def interaction(self, prefix: str, x: Tensor, valid: Tensor, need_weights: bool = False):
         """`MultiAgentTF.forward` (`agent_interaction.py:51-93`): tgt = block input, eye mask,
-        groups with exactly one valid agent pass through unchanged."""
+        groups with exactly one valid agent pass through unchanged (their weights are zero, `:81-84`)."""
         n, a, _ = x.shape
         eye = torch.eye(a, dtype=torch.bool).unsqueeze(0).expand(n, -1, -1)
         single = valid.sum(-1) == 1
-        y = self.tf_block(prefix + ".transformer", 3, x, ~valid, x, ~valid, attn_mask=eye)
+        y = self.tf_block(prefix + ".transformer", 3, x, ~valid, x, ~valid, attn_mask=eye, need_weights=need_weights)
+        if need_weights:
+            y, w = y
+            return torch.where(single[:, None, None], x, y), w.masked_fill(single[:, None, None], 0)
         return torch.where(single[:, None, None], x, y)
 
     def gru_step(self, prefix: str, x: Tensor, h: Tensor):
@@ -350,14 +360,25 @@ class Oracle:
             m[:, : sws + 1] |= valid[:, : sws + 1]
         return m
 
-    def policy_step(self, x, valid, map_f, map_inv, tl_f, tl_inv, goal_f, goal_valid, z, h, hoisted=None):
-        """`TrafficBots.forward` (`traffic_bots.py:205-241`) for one sim step."""
+    def policy_step(self, x, valid, map_f, map_inv, tl_f, tl_inv, goal_f, goal_valid, z, h, hoisted=None, need_weights: bool = False):
+        """`TrafficBots.forward` (`traffic_bots.py:205-241`) for one sim step; with `need_weights` a third return value
+        (attn_pl, attn_tl, attn_agent), the reference's `need_weights=True` outputs (`:173,210,218,229`)."""
         w = self.w
         kv_pl = hoisted["kv_pl"] if hoisted else None
         kv_tl = hoisted["kv_tl"] if hoisted else None
-        x = self.tf_block("model.transformer_as2pl", 3, x, ~valid, map_f, map_inv, kvs=kv_pl)
-        x = self.tf_block("model.transformer_as2tl", 3, x, ~valid, tl_f, tl_inv, kvs=kv_tl)
-        x = self.interaction("model.agent_interaction", x, valid)
+        x = self.tf_block("model.transformer_as2pl", 3, x, ~valid, map_f, map_inv, kvs=kv_pl, need_weights=need_weights)
+        attn = []
+        if need_weights:
+            x, w_ = x
+            attn.append(w_)
+        x = self.tf_block("model.transformer_as2tl", 3, x, ~valid, tl_f, tl_inv, kvs=kv_tl, need_weights=need_weights)
+        if need_weights:
+            x, w_ = x
+            attn.append(w_)
+        x = self.interaction("model.agent_interaction", x, valid, need_weights=need_weights)
+        if need_weights:
+            x, w_ = x
+            attn.append(w_)
         n, a, _ = x.shape
         o, h = self.gru_step("model.agent_temporal.rnn", x.reshape(n * a, H), h)
         inv = ~valid.reshape(n * a, 1)
@@ -380,7 +401,7 @@ class Oracle:
         hh = torch.relu(self._lin(hh, "model.add_latent.mlp_out.fc_layers.3"))
         hh = hh.masked_fill(~valid.unsqueeze(-1), 0) + x
         x = hh.masked_fill(~valid.unsqueeze(-1), 0)
-        return x, h
+        return (x, h, tuple(attn)) if need_weights else (x, h)
 
     def goal_mlp_in(self, goal_f: Tensor) -> Tensor:
         p = "model.add_goal.mlp_in.fc_layers"

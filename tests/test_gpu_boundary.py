@@ -365,3 +365,78 @@ def test_fp16_pair_operand_range(scale, expect):
         assert err_f <= 1e-5 and err_xy <= 1e-4, (err_f, err_xy)
     else:
         assert err_f <= 1e-4 and err_xy <= 1e-3, (err_f, err_xy)
+
+
+@pytest.mark.parametrize("case", ["masks", "degenerate"])
+def test_traffic_bots_forward_with_attention_weights_against_reference_golden(case):
+    """`TrafficBots.forward(agent_valid, agent_feature, map_valid, map_feature, tl_valid, tl_feature, goal_valid, goal_feature,
+    need_weights=True) -> (policy_feature, latent_logp, attn_pl, attn_tl, attn_agent)` (`traffic_bots.py:163-247`) through `tb_forward`
+    against tests/golden/forward_weights.npz -- the reference's own calls inside a rollout: inputs, recurrent state, all five outputs."""
+    import json
+    import os
+
+    from conftest import GOLDEN_DIR
+    from trafficbots_amd import synth
+    from trafficbots_amd.distributions import DiagGaussian
+    from trafficbots_amd.waymo_motion import WaymoMotion
+
+    g = np.load(os.path.join(GOLDEN_DIR, "forward_weights.npz"))
+    meta = json.loads(bytes(g[f"{case}/meta_json"]).decode())
+    wm = WaymoMotion(time_step_end=meta["time_step_end"], n_joint_future=meta["k"])
+    wm.load_state_dict(synth.make_state_dict(meta["weight_seed"]))
+    t = lambda k: torch.from_numpy(g[k]).cuda()  # noqa: E731
+    for s_ in meta["steps"]:
+        p = f"{case}/step{s_}/"
+        out = wm.engine.forward_trunk(t(p + "agent_valid"), t(p + "agent_feature"), t(p + "map_valid"), t(p + "map_feature"), t(p + "tl_valid"),
+                                      t(p + "tl_feature"), t(p + "goal_valid"), t(p + "goal_feature"), t(p + "latent_sample"),
+                                      None if bool(g[p + "hidden_in_is_none"]) else t(p + "hidden_in"), need_weights=True)
+        torch.cuda.synchronize()
+        v = g[p + "agent_valid"][..., None]
+        assert np.abs(out["policy_feature"].cpu().numpy() - g[p + "policy_feature"]).max() <= 2e-5
+        assert np.abs(out["hidden"].cpu().numpy() - g[p + "hidden_out"]).max() <= 2e-5
+        for key in ("attn_pl", "attn_tl", "attn_agent"):
+            got = out[key].cpu().numpy()
+            assert (np.abs(got - g[p + key]) * v).max() <= 2e-6, (s_, key)
+            assert (np.abs(got.sum(-1) - np.round(got.sum(-1))) * v[..., 0]).max() <= 1e-5  # rows sum to 1 (or 0: no admissible key / bypass)
+    # the mirror class, stateful like the reference: init -> forward (samples the personality, hidden None) -> forward (hidden carried)
+    p = f"{case}/step{meta['steps'][0]}/"
+    n, a = g[p + "agent_valid"].shape
+    lat = DiagGaussian(t(p + "latent_sample"), torch.full((16,), -1.0, device="cuda"), valid=t(p + "agent_valid"))
+    wm.model.init(lat, True)
+    args = [t(p + k) for k in ("agent_valid", "agent_feature", "map_valid", "map_feature", "tl_valid", "tl_feature", "goal_valid", "goal_feature")]
+    pf, logp, w_pl, w_tl, w_ag = wm.model(*args, need_weights=True)
+    assert logp.shape == (n, a) and w_pl.shape == (n, a, g[p + "map_valid"].shape[1]) and w_ag.shape == (n, a, a)
+    if bool(g[p + "hidden_in_is_none"]):
+        assert np.abs(pf.cpu().numpy() - g[p + "policy_feature"]).max() <= 2e-5
+    pf2, _, none_pl, _, _ = wm.model(*args)  # second call: the hidden state moved on, no weights asked for
+    assert none_pl is None and float((pf2 - pf).abs().max()) > 1e-4
+
+
+def test_unfused_forward_cross_checks_the_fused_step_kernel():
+    """Two independent device implementations of the same trunk: the policy feature the fused step kernel taps at step 1 (fp16-pair
+    MFMA, hoisted K / V, fused epilogues) against `tb_forward` (plain fp32 FMA kernels on the reference's row-major tensors) fed with
+    the fused kernel's own agent feature of that step."""
+    from trafficbots_amd import synth
+    from trafficbots_amd.waymo_motion import WaymoMotion
+
+    k = 2
+    sd = synth.make_state_dict(6)
+    batch = synth.make_batch(9900, 3, n_agent=20, n_pl=50, n_tl=12, p_invalid_agent=0.2, p_late_spawn=0.2, pos_range=120.0)
+    eps = torch.from_numpy(synth.make_latent_noise(9901, 3 * k, 20)).cuda()
+    wm = WaymoMotion(time_step_end=12, n_joint_future=k)
+    wm.load_state_dict(sd)
+    out = wm.test_step(batch, latent_eps=eps, generator=torch.Generator(device="cuda").manual_seed(1), tap_step=1)
+    buf, feats = out["rollout_buffer"], out["input_feature_dict"]
+    scene = wm.pre_processing(batch)
+    rep = lambda x: x.repeat_interleave(k, 0)  # noqa: E731
+    agent_valid = rep(scene["agent_valid"][:, 0].bool())                      # validity going into step 1 = history step 0
+    dest = out["goal_sample"].transpose(1, 2).reshape(3 * k, -1)             # [N,A]
+    map_f = rep(feats["map_feature"])
+    goal_feature = torch.gather(map_f, 1, dest.long().unsqueeze(-1).expand(-1, -1, 128))
+    goal_valid = rep(scene["agent_valid"].bool().any(1))
+    fw = wm.engine.forward_trunk(agent_valid, buf.taps["tap_agent_feature"], rep(feats["map_feature_valid"]), map_f,
+                                 rep(scene["tl_valid"][:, 0].bool()), rep(feats["tl_feature"][:, 0]), goal_valid, goal_feature,
+                                 buf.latent_sample, None)
+    torch.cuda.synchronize()
+    d = (fw["policy_feature"] - buf.taps["tap_policy_feature"]).abs() * agent_valid.unsqueeze(-1)
+    assert float(d.max()) <= 5e-6 * max(1.0, float(buf.taps["tap_policy_feature"].abs().max())), float(d.max())

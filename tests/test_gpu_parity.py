@@ -162,7 +162,10 @@ def _check_all_taps(name, g, meta, wm, sd, batch, eps, gs, rep):
     k, a = meta["k"], meta["scene"]["n_agent"]
     n = meta["n_scene"] * k
     ens = lambda key: float(g[key]) if key in g.files else 0.0  # noqa: E731
+    from tools import ensemble
+
     spread32 = np.maximum.accumulate(g["ens_d32"].max(0)) if "ens_d32" in g.files else None
+    bound32 = ensemble.prediction_bound(g["ens_d32"]) if "ens_d32" in g.files else None
     ens_xy = lambda s_: None if spread32 is None else float(spread32[min(s_, len(spread32)) - 1])  # noqa: E731
     closed = lambda s_: s_ > wm.hparams["time_step_current"] + 1  # noqa: E731  (the state of step s-1 already came from the policy)
     eps_t = torch.from_numpy(eps).cuda()
@@ -200,7 +203,7 @@ def _check_all_taps(name, g, meta, wm, sd, batch, eps, gs, rep):
             ref = g[f"tap{t}/state_in"]
             err = float((np.abs(prev["agent_state"].cpu().numpy() - ref) * v[..., None])[..., :2].max())
             rep[f"tap{t}/state_in_xy"] = err
-            assert err <= max(1e-4, ens("ens_final_state")), (name, t, "state_in", err)
+            assert err <= max(1e-4, 0.0 if bound32 is None else float(bound32[max(0, min(t - 1, len(bound32)) - 1)])), (name, t, "state_in", err)
             ref = g[f"tap{t}/hidden"].reshape(3, n, a, 128)
             err = float(np.abs(st["hidden"].cpu().numpy() - ref).max())
             rep[f"tap{t}/hidden"] = err
@@ -251,7 +254,13 @@ def test_against_reference_golden(name):
     assert (buf.final["final_valid"].bool().cpu().numpy() == fin_v).all()
     ens_fs = float(g["ens_final_state"]) if "ens_final_state" in g.files else 0.0
     rep["final_state_xy"] = float((np.abs(buf.final["final_state"].cpu().numpy() - g["final_state"]) * fin_v[..., None])[..., :2].max())
-    assert rep["final_state_xy"] <= max(1e-4, ens_fs), (name, rep["final_state_xy"], ens_fs)
+    if "ens_d32" in g.files:  # (the final state is the last step's post-override state: the closed-loop bound of that step)
+        from tools import ensemble
+
+        fs_bound = max(1e-4, float(ensemble.prediction_bound(g["ens_d32"])[-1]))
+    else:
+        fs_bound = 1e-4
+    assert rep["final_state_xy"] <= fs_bound, (name, rep["final_state_xy"], fs_bound)
     if "final_hidden" in g.files:
         fh = g["final_hidden"].reshape(buf.final["final_hidden"].shape)
         rep["final_hidden"] = float(np.abs(buf.final["final_hidden"].cpu().numpy() - fh).max())

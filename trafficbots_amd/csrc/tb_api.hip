@@ -45,6 +45,8 @@ int run_rule_checks(const tb_rule_io* io, int n_hist, int step_start, uint8_t* r
 int run_encode_posterior(struct ::tb_ctx* ctx, const tb_posterior_io* io, hipStream_t s);
 void launch_train_partials(const tb_train_io& io, const float* post_log_std, const float* prior_log_std, hipStream_t s);
 hipError_t configure_rule_kernels();
+size_t forward_scratch_floats(const tb_forward_io* io);  // tb_forward_kernels.hip
+const char* run_forward(const std::map<std::string, const float*>& raw, const tb_forward_io* io, float* scratch, hipStream_t s);
 void launch_post_process(const tb_post_io& io, hipStream_t s);
 void launch_metric_partials(const tb_metric_io& io, hipStream_t s);
 }  // namespace tb
@@ -299,7 +301,9 @@ tb::EncMlpW add_enc(Arena& a, Stage& s, const std::string& p, int attr_dim) {
 // ---------------------------------------------------------------------------------------------------
 extern "C" {
 
-void tb_struct_sizes(int32_t out[9]) {
+void tb_struct_sizes(int32_t out[11]) {
+    out[9] = (int32_t)sizeof(tb_step_override);
+    out[10] = (int32_t)sizeof(tb_forward_io);
     out[7] = (int32_t)sizeof(tb_posterior_io);
     out[8] = (int32_t)sizeof(tb_train_io);
     out[0] = (int32_t)sizeof(tb_config);
@@ -394,6 +398,8 @@ void tb_destroy(tb_ctx* ctx) {
     if (ctx->d_ws) (void)hipFree(ctx->d_ws);
     if (ctx->d_rule_ws) (void)hipFree(ctx->d_rule_ws);
     if (ctx->d_status) (void)hipFree(ctx->d_status);
+    if (ctx->d_raw) (void)hipFree(ctx->d_raw);
+    if (ctx->d_fw) (void)hipFree(ctx->d_fw);
     for (auto e : ctx->ev) (void)hipEventDestroy(e);
     delete ctx;
 }
@@ -591,9 +597,59 @@ int tb_finalize_weights(tb_ctx* ctx, tb_stream stream) {
     ctx->arena_floats = a.h.size();
     TB_HIP(ctx, hipMalloc((void**)&ctx->d_arena, a.h.size() * sizeof(float)));
     TB_HIP(ctx, hipMemcpyAsync(ctx->d_arena, a.h.data(), a.h.size() * sizeof(float), hipMemcpyHostToDevice, (hipStream_t)stream));
+    // row-major copies of the policy trunk's tensors for tb_forward (5.7 MB; tb_forward_kernels.hip)
+    {
+        std::vector<float> rawh;
+        std::vector<std::pair<std::string, size_t>> offs;
+        for (const auto& kv : ctx->staged) {
+            const std::string& k = kv.first;
+            if (k.rfind("model.transformer_as2pl.", 0) && k.rfind("model.transformer_as2tl.", 0) && k.rfind("model.agent_interaction.", 0) &&
+                k.rfind("model.agent_temporal.", 0) && k.rfind("model.add_goal.", 0) && k.rfind("model.add_latent.", 0))
+                continue;
+            offs.emplace_back(k, rawh.size());
+            rawh.insert(rawh.end(), kv.second.begin(), kv.second.end());
+            while (rawh.size() & 3) rawh.push_back(0.f);
+        }
+        if (ctx->d_raw) TB_HIP(ctx, hipFree(ctx->d_raw));
+        ctx->d_raw = nullptr;
+        ctx->raw.clear();
+        if (!rawh.empty()) {
+            TB_HIP(ctx, hipMalloc((void**)&ctx->d_raw, rawh.size() * sizeof(float)));
+            TB_HIP(ctx, hipMemcpy(ctx->d_raw, rawh.data(), rawh.size() * sizeof(float), hipMemcpyHostToDevice));
+            for (const auto& o : offs) ctx->raw[o.first] = ctx->d_raw + o.second;
+        }
+    }
     TB_HIP(ctx, hipStreamSynchronize((hipStream_t)stream));  // host staging buffer `a` dies at return
     ctx->staged.clear();
     ctx->finalized = true;
+    return 0;
+}
+
+extern "C" int tb_forward(tb_ctx* ctx, const tb_forward_io* io, tb_stream stream_) {
+    if (!ctx || !io) return 1;
+    if (!ctx->finalized) return tb_fail(ctx, "tb_forward: weights not finalized");
+    TB_HIP(ctx, hipSetDevice(ctx->device));
+    if (io->n_inst <= 0 || io->n_agent <= 0 || io->n_pl <= 0 || io->n_tl <= 0) return tb_fail(ctx, "tb_forward: empty dimension");
+    if (io->n_agent > 4096 || io->n_pl > 8192 || io->n_tl > 8192) return tb_fail(ctx, "tb_forward: more than 8192 keys per attention are not supported");
+    const void* need[] = {io->agent_valid, io->agent_feature, io->map_valid, io->map_feature, io->tl_valid, io->tl_feature, io->latent_sample,
+                          io->hidden, io->policy_feature};
+    for (const void* q : need)
+        if (!q) return tb_fail(ctx, "tb_forward: a required buffer pointer is NULL");
+    if ((io->goal_feature == nullptr) != (io->goal_valid == nullptr)) return tb_fail(ctx, "tb_forward: goal_feature and goal_valid go together");
+    const size_t nf = tb::forward_scratch_floats(io);
+    if (nf > ctx->fw_floats) {
+        if (ctx->d_fw) {
+            TB_HIP(ctx, hipDeviceSynchronize());
+            TB_HIP(ctx, hipFree(ctx->d_fw));
+            ctx->d_fw = nullptr;
+            ctx->fw_floats = 0;
+        }
+        TB_HIP(ctx, hipMalloc((void**)&ctx->d_fw, nf * sizeof(float)));
+        ctx->fw_floats = nf;
+    }
+    const char* missing = tb::run_forward(ctx->raw, io, ctx->d_fw, (hipStream_t)stream_);
+    if (missing) return tb_fail(ctx, "tb_forward: weight tensor %s was not loaded", missing);
+    TB_HIP(ctx, hipGetLastError());
     return 0;
 }
 
@@ -848,7 +904,7 @@ extern "C" int tb_rollout(tb_ctx* ctx, const tb_rollout_io* io, tb_stream stream
     if (!use_graph) return rollout_enqueue(ctx, io, p, s);
     unsigned long long key = fnv1a(&p, sizeof(p), 1469598103934665603ull);
     key = fnv1a(io, sizeof(*io), key);
-    for (const char* name : {"TB_STEP_W3", "TB_STEP_W3G", "TB_STEP_LEAN", "TB_STEP_HELPERS", "TB_GRU_HELPER"}) {
+    for (const char* name : {"TB_STEP_W3", "TB_STEP_LEAN", "TB_STEP_HELPERS", "TB_GRU_HELPER"}) {
         const char* v = getenv(name);
         key = fnv1a(v ? v : "-", v ? strlen(v) + 1 : 2, key);
     }

@@ -28,10 +28,11 @@
 // registers one stage ahead -- `wloadx` only records WHERE the unit is (and fetches its bias), the GEMM that consumes it loads the
 // fragments itself -- which takes 32 of the 40 VGPRs of every unit in flight out of the kernel (<= 168 VGPRs = three waves per
 // SIMD); the latency the prefetch used to hide is hidden by the two other workgroups of the CU.
-#if defined(TB_XDL_W3) && defined(TB_XDL_BF16)
+#if defined(TB_XDL_W3) && !defined(TB_XDL_BF16)
+#error "TB_XDL_W3 is a variant of the bf16 build (the fp16-pair twin was measured and lost: profiles/r03_experiments_not_kept.txt)"
+#endif
+#ifdef TB_XDL_W3
 #define TB_XNS xb3
-#elif defined(TB_XDL_W3)
-#define TB_XNS xh3   // (the fp16-pair twin of the same carve: two workgroups / wave groups per CU without spills, tb_stepx_w3_kernels.hip)
 #elif defined(TB_XDL_BF16)
 #define TB_XNS xb
 #else

@@ -47,6 +47,11 @@ struct tb_ctx {
     // one hipGraph per rollout (tb_rollout): the S + 1 step launches + prologue captured once and replayed while every kernel
     // argument stays the same (same buffers, sizes, switches) -- the launching thread then spends microseconds per rollout instead of
     // ~70 us per launch; TB_ROLLOUT_GRAPH=0 turns it off
+    // row-major fp32 copies of the policy-trunk tensors for tb_forward (the un-fused visualisation path), and its scratch
+    float* d_raw = nullptr;
+    std::map<std::string, const float*> raw;
+    float* d_fw = nullptr;
+    size_t fw_floats = 0;
     hipGraphExec_t graph_exec = nullptr;
     unsigned long long graph_key = 0, graph_seen = 0;  // key of the captured graph / of the previous call (capture on the second sight)
     int graph_hits = 0, graph_captures = 0;

@@ -37,6 +37,7 @@ constexpr bool W3 = true;
 #else
 constexpr bool W3 = false;
 #endif
+
 constexpr bool XL_DG_GLOBAL = NPL == 2;
 constexpr int XL_DG = W3 ? XO_H1 : XO_GP;
 constexpr int XL_SMALL = XL_DG + (XL_DG_GLOBAL ? 0 : TM * 80);
@@ -138,23 +139,14 @@ void launch_fuse_hoist_x(const RolloutP& p, hipStream_t s) {
 #endif  // !TB_XDL_W3
 
 // PRE = the batched warm start (RolloutP::pre_mode): A half only, inputs from the ground truth, grid.z = steps
-// G = 3 (W3 build only): ONE workgroup of twelve waves = three groups of four, group g running this kernel's unchanged four-wave code
-// on its own LDS carve for the SAME row tile of three consecutive instances (futures 3j .. 3j+2 of a scene).  The workgroup barriers
-// keep the three groups in step, so they ask for the same weight fragments and the same map / traffic-light K / V blocks within a
-// few hundred cycles of each other and the CU's L1 fetches each line once: the per-CU vector-memory traffic of a K = 6 launch drops
-// from three copies of the weight set per step to one.  Requires n_inst % 3 == 0 and a barrier-uniform control flow across the
-// groups -- the one divergent branch, the single-agent interaction bypass, is run as "compute and discard" when the groups disagree.
-template <bool PRE, bool LEAN = false, int G = 1>
-__global__ __launch_bounds__(NTHREADS * G, G > 1 ? 1 : (LEAN ? (W3 ? 3 : 2) : 1)) void k_step_x(RolloutP p, int t, int do_c, int do_a) {
+template <bool PRE, bool LEAN = false>
+__global__ __launch_bounds__(NTHREADS, LEAN ? (W3 ? 3 : 2) : 1) void k_step_x(RolloutP p, int t, int do_c, int do_a) {
     static_assert(!W3 || LEAN, "the W3 build holds the LEAN carve only");
-    static_assert(G == 1 || (W3 && !PRE), "wave groups: the W3 build's step launch only");
     if (PRE) {
         do_c = 0;
         do_a = 1;
     }
-    extern __shared__ __attribute__((aligned(16))) float smem_all[];
-    const int grp = G > 1 ? __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 8) : 0;
-    float* smem = smem_all + (G > 1 ? grp * STEPX_LEAN_LDS_FLOATS : 0);
+    extern __shared__ __attribute__((aligned(16))) float smem[];
     float* X = smem + XO_X;
     float* Hs = smem + XO_H;
     float* H1 = W3 ? nullptr : smem + XO_H1;   // (W3: no LDS copies of the hidden state; Hs is the action head's scratch tile)
@@ -177,11 +169,9 @@ __global__ __launch_bounds__(NTHREADS * G, G > 1 ? 1 : (LEAN ? (W3 ? 3 : 2) : 1)
     int* rtype = sm.rtype;
     int* dflag = sm.dflag;
 
-    const int tid = G > 1 ? ((int)threadIdx.x & (NTHREADS - 1)) : (int)threadIdx.x;
-    const int wave = wave_of(tid), lane = tid & 63, kq = lane >> 4, m = lane & 15;
+    const int tid = threadIdx.x, wave = wave_of(tid), lane = tid & 63, kq = lane >> 4, m = lane & 15;
     int n, rt;
     step_tile_map(n, rt);
-    if (G > 1) n = n * G + grp;  // (gridDim.y = n_inst / G: instance triples)
     if (PRE) t = p.pre_t0 + (int)blockIdx.z;  // batched warm start: A(t + 1) of step t from the ground truth of step t
     // (the K futures of a scene share the ground truth: the batched launch runs once per SCENE, in the slot of future 0, and
     // k_pre_replicate copies the slices to the other futures)
@@ -305,21 +295,11 @@ __global__ __launch_bounds__(NTHREADS * G, G > 1 ? 1 : (LEAN ? (W3 ? 3 : 2) : 1)
             for (int sl = 0; sl < 9; ++sl)
                 if (tid < 192) st4(LN + sl * 768 + tid * 4, lnv[sl]);
         }
-        if (G == 1 && bypass) wloadx(u, gru_first_x(W, pw.gru[0], px.gru[0], wave), lane);
+        if (bypass) wloadx(u, gru_first_x(W, pw.gru[0], px.gru[0], wave), lane);
         __syncthreads();
         TB_STAMP(1);
         unsigned int gh_seen = 0u;  // the GRU helper's flag, requested one interaction layer early (thread 0)
-        // (G > 1: the wave groups share the workgroup's barriers, so a group whose instance takes the single-agent bypass runs the
-        // three layers as well and puts its tile back afterwards: the scratch tile Hs is free until the action head, and the copy
-        // uses tile_to_planes' thread -> element map, the first reader of X after the block)
-        if (G > 1 && bypass) {
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int idx = tid + i * NTHREADS;
-                st4(Hs + (idx >> 5) * LDT + (idx & 31) * 4, lds4(X + (idx >> 5) * LDT + (idx & 31) * 4));
-            }
-        }
-        if (G > 1 || !bypass) {
+        if (!bypass) {
             const float* kvd = p.vbias + (size_t)n * p.a_pad;
             const size_t ls = (size_t)p.a_pad * H;
             const xhalf* K0 = reinterpret_cast<const xhalf*>(p.kin + ((size_t)n * 3) * ls);
@@ -341,13 +321,6 @@ __global__ __launch_bounds__(NTHREADS * G, G > 1 ? 1 : (LEAN ? (W3 ? 3 : 2) : 1)
             }
             xattn_layer_x<!LEAN, true>(W, pw.inter[2], px.inter[2], X, PA, PB, K0 + 4 * ls, V0 + 4 * ls, kvd, nk_a, ks_a, row0, rowvalid,
                                 novalid_s, tid, u, gru_first_x(W, pw.gru[0], px.gru[0], wave), (LEAN ? nullptr : LN + 2 * 768), nullptr, amax);
-        }
-        if (G > 1 && bypass) {
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int idx = tid + i * NTHREADS;
-                st4(X + (idx >> 5) * LDT + (idx & 31) * 4, lds4(Hs + (idx >> 5) * LDT + (idx & 31) * 4));
-            }
         }
         TB_STAMP(2);
         // ---- 3-layer GRU, one step (agent_temporal.py:147-152).  planes: x0 = PA, h0 = PB, h1 = PD, out0 = PC, h2 -> PB, out1 = PA
@@ -560,8 +533,6 @@ __global__ __launch_bounds__(NTHREADS * G, G > 1 ? 1 : (LEAN ? (W3 ? 3 : 2) : 1)
 #ifdef TB_XDL_W3
 template __global__ void k_step_x<false, true>(RolloutP, int, int, int);
 template __global__ void k_step_x<true, true>(RolloutP, int, int, int);
-template __global__ void k_step_x<false, true, 3>(RolloutP, int, int, int);
-static_assert(3 * STEPX_LEAN_LDS_FLOATS * 4 <= 160 * 1024, "three wave groups must fit one CU's LDS");
 #else
 template __global__ void k_step_x<false>(RolloutP, int, int, int);  // (emitted first: the launch of every simulation step)
 template __global__ void k_step_x<true>(RolloutP, int, int, int);
@@ -654,9 +625,6 @@ hipError_t configure_stepx_kernel() {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_step_x<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)(STEPX_LEAN_LDS_FLOATS * sizeof(float)));
     if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_step_x<false, true, 3>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)(3 * STEPX_LEAN_LDS_FLOATS * sizeof(float)));
-    if (e != hipSuccess) return e;
     return hipFuncSetAttribute(reinterpret_cast<const void*>(k_step_x<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                (int)(STEPX_LEAN_LDS_FLOATS * sizeof(float)));
 }
@@ -665,16 +633,6 @@ hipError_t configure_stepx_kernel() {
 void launch_step_x(const RolloutP& p0, int t, int do_c, int do_a, hipStream_t s) {
     RolloutP p = p0;
     p.gh_flag = nullptr;  // (no helper workgroups: the launch fills the chip three times over)
-    {
-        // futures in multiples of three: twelve-wave workgroups, three futures of a scene in step (k_step_x<., ., 3>);
-        // TB_STEP_W3G=0 keeps the four-wave workgroups (development / A-B switch; same results)
-        const char* e = getenv("TB_STEP_W3G");
-        if (p.k_rep % 3 == 0 && p.n_inst % 3 == 0 && !(e && e[0] == '0')) {
-            dim3 grid3(p.a_pad / TM, p.n_inst / 3, 1);
-            hipLaunchKernelGGL((k_step_x<false, true, 3>), grid3, dim3(NTHREADS * 3), 3 * STEPX_LEAN_LDS_FLOATS * sizeof(float), s, p, t, do_c, do_a);
-            return;
-        }
-    }
     dim3 grid(p.a_pad / TM, p.n_inst, 1);
     hipLaunchKernelGGL((k_step_x<false, true>), grid, dim3(NTHREADS), STEPX_LEAN_LDS_FLOATS * sizeof(float), s, p, t, do_c, do_a);
 }

@@ -55,6 +55,16 @@ class TbStepOverride(C.Structure):
                 ("action", c_f32p), ("action_mask", c_u8p)]
 
 
+class TbForwardIO(C.Structure):
+    _fields_ = [
+        ("n_inst", C.c_int32), ("n_agent", C.c_int32), ("n_pl", C.c_int32), ("n_tl", C.c_int32),
+        ("agent_valid", c_u8p), ("agent_feature", c_f32p), ("map_valid", c_u8p), ("map_feature", c_f32p),
+        ("tl_valid", c_u8p), ("tl_feature", c_f32p), ("goal_valid", c_u8p), ("goal_feature", c_f32p),
+        ("latent_sample", c_f32p), ("hidden", c_f32p), ("policy_feature", c_f32p),
+        ("attn_pl", c_f32p), ("attn_tl", c_f32p), ("attn_agent", c_f32p),
+    ]
+
+
 class TbRuleIO(C.Structure):
     _fields_ = [
         ("n_scene", C.c_int32), ("k_futures", C.c_int32), ("n_agent", C.c_int32), ("n_pl", C.c_int32), ("n_tl", C.c_int32),
@@ -137,6 +147,7 @@ EXPORTS = (
     "tb_create", "tb_destroy", "tb_last_error", "tb_version", "tb_load_weight", "tb_finalize_weights",
     "tb_rollout", "tb_rollout_begin", "tb_rollout_step", "tb_rollout_step_ex", "tb_check_status", "tb_rollout_state", "tb_encode_scene", "tb_set_timing", "tb_get_timing",
     "tb_rule_checks", "tb_post_process", "tb_metric_partials", "tb_struct_sizes", "tb_encode_posterior", "tb_train_partials",
+    "tb_forward",
 )
 
 _lib: Optional[C.CDLL] = None
@@ -196,10 +207,12 @@ def load() -> C.CDLL:
     lib.tb_train_partials.restype = C.c_int
     lib.tb_struct_sizes.argtypes = [C.POINTER(C.c_int32)]
     lib.tb_struct_sizes.restype = None
-    sizes = (C.c_int32 * 9)()
+    sizes = (C.c_int32 * 11)()
     lib.tb_struct_sizes(sizes)
     mine = [C.sizeof(x) for x in (TbConfig, TbRolloutIO, TbEncodeIO, TbRuleIO, TbPostIO, TbMetricIO)] + [C.sizeof(C.c_void_p)]
-    mine += [C.sizeof(TbPosteriorIO), C.sizeof(TbTrainIO)]
+    mine += [C.sizeof(TbPosteriorIO), C.sizeof(TbTrainIO), C.sizeof(TbStepOverride), C.sizeof(TbForwardIO)]
+    lib.tb_forward.argtypes = [C.c_void_p, C.POINTER(TbForwardIO), C.c_void_p]
+    lib.tb_forward.restype = C.c_int
     if list(sizes) != mine:
         raise RuntimeError(f"trafficbots_amd: ctypes struct layouts {mine} do not match the library's {list(sizes)} (stale build?)")
     lib.tb_set_timing.argtypes = [C.c_void_p, C.c_int]

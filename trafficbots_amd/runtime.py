@@ -601,6 +601,49 @@ class HipEngine:
         self._step_keepalive = keep  # borrowed until the stream work is done (replaced by the next step's)
         self._check(self.lib.tb_rollout_step_ex(self._ctx, C.byref(ov), self._stream()), "tb_rollout_step_ex")
 
+    def forward_trunk(self, agent_valid: Tensor, agent_feature: Tensor, map_valid: Tensor, map_feature: Tensor, tl_valid: Tensor,
+                      tl_feature: Tensor, goal_valid: Optional[Tensor], goal_feature: Optional[Tensor], latent_sample: Tensor,
+                      hidden: Optional[Tensor], need_weights: bool = False) -> Dict[str, Tensor]:
+        """`tb_forward`: the policy trunk of one step, un-fused, per instance (`TrafficBots.forward`, `traffic_bots.py:163-247`).
+        `hidden` [3, N*A, 128] or None (= zeros); returns policy_feature [N,A,128], the new hidden [3, N*A, 128] and, with
+        `need_weights`, the head-mean attention weights of the last layer of each block (attn_pl [N,A,P], attn_tl [N,A,T],
+        attn_agent [N,A,A])."""
+        dev, f32, u8 = self.device, torch.float32, torch.uint8
+        n, a = agent_valid.shape
+        p, t = map_valid.shape[1], tl_valid.shape[1]
+        keep = []
+
+        def c8(x):
+            x = x.to(dev).to(u8).contiguous()
+            keep.append(x)
+            return hip.ptr(x, hip.c_u8p)
+
+        def cf(x, shape):
+            x = x.to(dev).to(f32).contiguous()
+            assert tuple(x.shape) == tuple(shape), (tuple(x.shape), shape)
+            keep.append(x)
+            return hip.ptr(x, hip.c_f32p)
+
+        io = hip.TbForwardIO()
+        io.n_inst, io.n_agent, io.n_pl, io.n_tl = n, a, p, t
+        io.agent_valid, io.agent_feature = c8(agent_valid), cf(agent_feature, (n, a, 128))
+        io.map_valid, io.map_feature = c8(map_valid), cf(map_feature, (n, p, 128))
+        io.tl_valid, io.tl_feature = c8(tl_valid), cf(tl_feature, (n, t, 128))
+        if goal_feature is not None and goal_valid is not None:
+            io.goal_valid, io.goal_feature = c8(goal_valid), cf(goal_feature, (n, a, 128))
+        io.latent_sample = cf(latent_sample, (n, a, 16))
+        h = torch.zeros(3, n * a, 128, device=dev, dtype=f32) if hidden is None else hidden.to(dev).to(f32).reshape(3, n * a, 128).clone()
+        out = {"policy_feature": torch.empty(n, a, 128, device=dev, dtype=f32), "hidden": h}
+        io.hidden, io.policy_feature = hip.ptr(h, hip.c_f32p), hip.ptr(out["policy_feature"], hip.c_f32p)
+        if need_weights:
+            out["attn_pl"] = torch.empty(n, a, p, device=dev, dtype=f32)
+            out["attn_tl"] = torch.empty(n, a, t, device=dev, dtype=f32)
+            out["attn_agent"] = torch.empty(n, a, a, device=dev, dtype=f32)
+            io.attn_pl, io.attn_tl, io.attn_agent = (hip.ptr(out[k], hip.c_f32p) for k in ("attn_pl", "attn_tl", "attn_agent"))
+        self._check(self.lib.tb_forward(self._ctx, C.byref(io), self._stream()), "tb_forward")
+        self._fw_keepalive = keep
+        return out
+
     def check_status(self) -> None:
         """`tb_check_status`: synchronises the current stream and raises if an fp16-pair operand left the fp16 range since the
         last check (fp32-accurate mode only; see include/trafficbots_hip.h)."""

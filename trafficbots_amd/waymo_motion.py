@@ -203,11 +203,24 @@ class TrafficBots:
         self.latent_sample = None
         self.latent_logp = None
 
-    def forward(self, *args, **kwargs):
-        """`TrafficBots.forward` (`traffic_bots.py:163-247`) is not a separate entry point here: the policy trunk is fused with the
-        action head, the dynamics and the rule checks inside the step kernel and runs through `WaymoMotion.forward` / `rollout`."""
-        raise NotImplementedError("TrafficBots.forward is fused into the step kernel: drive WaymoMotion.forward / rollout "
-                                  "(tap_step exposes the policy feature of one step; attention weights are not produced)")
+    def forward(self, agent_valid: Tensor, agent_feature: Tensor, map_valid: Tensor, map_feature: Tensor, tl_valid: Tensor,
+                tl_feature: Tensor, goal_valid: Optional[Tensor], goal_feature: Optional[Tensor], need_weights: bool = False):
+        """`TrafficBots.forward` (`traffic_bots.py:163-247`) with the reference's signature and return value
+        `(policy_feature, latent_logp, attn_pl, attn_tl, attn_agent)`: one step of the policy trunk on per-instance tensors, un-fused
+        (`tb_forward`).  Stateful like the reference: the personality is sampled on the first call after `init(latent, deterministic)`
+        (`:196-199`; explicit `eps` if `init` got them) and `self.hidden` carries the GRU state from call to call.  With
+        `need_weights=True` the attention weights are the head-mean weights of the last layer of each block (None otherwise).
+        The rollout does NOT go through here -- its trunk is fused into the step kernel (`WaymoMotion.forward` / `rollout`); this is the
+        visualisation / debugging entry point and an on-device cross-check of that kernel."""
+        if getattr(self, "latent", None) is None:
+            raise RuntimeError("TrafficBots.forward: call init(latent, deterministic) first")
+        if self.latent_sample is None:
+            self.latent_sample = self.latent.sample(self.deterministic, eps=self._latent_eps)
+            self.latent_logp = self.latent.log_prob(self.latent_sample)
+        out = self.engine.forward_trunk(agent_valid, agent_feature, map_valid, map_feature, tl_valid, tl_feature, goal_valid, goal_feature,
+                                        self.latent_sample, self.hidden, need_weights=need_weights)
+        self.hidden = out["hidden"]
+        return out["policy_feature"], self.latent_logp, out.get("attn_pl"), out.get("attn_tl"), out.get("attn_agent")
 
     __call__ = forward
 
