@@ -133,6 +133,10 @@ typedef struct tb_rollout_io {
      * mean + action_eps[:, :, s] * exp(log_std) and action_log_probs becomes Normal.log_prob of the sample (summed over the two
      * action dims).  XDL step kernels only. */
     const float* action_eps;       /* [N,A,S,2] */
+    /* optional (NULL = never): train-mode `p_drop_hidden` (waymo_motion.py:345-351) with the caller's draws -- a HOST array of S
+     * bytes, read while the launches are enqueued: where hidden_drop[s] is set the GRU hidden state of ALL instances is zeroed after
+     * step s has been recorded (the reference draws one `torch.rand(1) < p_drop_hidden` per step for the whole batch). */
+    const uint8_t* hidden_drop;    /* [S] host memory */
 } tb_rollout_io;
 
 /* Replaces: WaymoMotion.rollout (+ per-step WaymoMotion.forward, TrafficBots.forward, ActionHead,

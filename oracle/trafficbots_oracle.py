@@ -424,8 +424,10 @@ class Oracle:
     def rollout(self, inp: Dict[str, Tensor], f: Dict[str, Tensor], z: Tensor, latent_mean: Tensor, dest: Tensor,
                 goal_valid: Tensor, k: int, step_end: int, tap_steps=(), gt: Optional[Dict[str, Tensor]] = None,
                 tf_cfg_name: str = "teacher_forcing_joint_future_pred", log_std_name: str = "prior",
-                action_eps: Optional[Tensor] = None, action_override=None) -> Dict[str, Tensor]:
-        """`action_override` = (action [N,A,S,2] physical units, mask [N,A,S]): the reference's `forward(action_override=,
+                action_eps: Optional[Tensor] = None, action_override=None, hidden_drop=None) -> Dict[str, Tensor]:
+        """`hidden_drop` [S] bool: train-mode `p_drop_hidden` (`waymo_motion.py:345-351`) with explicit draws -- after step s (buffer
+        written) the GRU state is zeroed where the draw is set.
+        `action_override` = (action [N,A,S,2] physical units, mask [N,A,S]): the reference's `forward(action_override=,
         mask_action_override=)` at every step (`dynamics.py:96-100`).
         `action_eps` [N, A, S, 2]: `deterministic_action=False` (`dynamics.py:77`): step s samples the unbounded action as
         mean + eps[:, :, s] * exp(log_std) (`Normal.rsample`) and scores it with `Normal.log_prob` summed over the two dims.
@@ -579,6 +581,8 @@ class Oracle:
             out["check_state"].append(check_state)
             out["check_valid"].append(check_valid)
             out["goal_reached_this_step"].append(gr_this)
+            if hidden_drop is not None and bool(hidden_drop[t - self.cfg["time_step_sim_start"]]):
+                h = torch.zeros_like(h)
         res = {k_: torch.stack(v, 2) for k_, v in out.items()}
         s = res["valid"].shape[2]
         res["latent_log_probs"] = latent_logp.unsqueeze(-1).expand(-1, -1, s)
@@ -637,27 +641,44 @@ class Oracle:
 
     def reactive_replay(self, batch: Dict[str, np.ndarray], step_end: int, tf_cfg_name: str = "teacher_forcing_reactive_replay",
                         eps: Optional[np.ndarray] = None, rollout_prior: bool = False,
-                        action_eps: Optional[np.ndarray] = None) -> Dict[str, Tensor]:
-        """First half of `WaymoMotion.validation_step` (`waymo_motion.py:574-611`): posterior and prior personalities,
+                        action_eps: Optional[np.ndarray] = None, history_keep: Optional[Dict[str, np.ndarray]] = None,
+                        hidden_drop: Optional[np.ndarray] = None) -> Dict[str, Tensor]:
+        """`history_keep` / `hidden_drop`: the train-mode Bernoulli masks with explicit draws (synth.make_train_draws): KEEP masks of the
+        model inputs (`sc_input.py:100-106`: agent history but its last step, traffic lights, map nodes) and of the posterior's inputs
+        (`sc_latent.py:171-173,216-218`), hidden-state drop after a step (`waymo_motion.py:345-351`).  The posterior's masks are applied
+        IN PLACE to `batch["agent/valid"]` / `batch["tl_stop/valid"]` in the reference (`latent_post/agent_valid = batch["agent/valid"]`
+        is an alias, `sc_latent.py:215-218`), so the replay's ground-truth validity -- initial state, teacher-forcing mask, kill rule,
+        rewards -- is the MASKED one too; reproduced here.
+        First half of `WaymoMotion.validation_step` (`waymo_motion.py:574-611`): posterior and prior personalities,
         destination prediction, then the episode replayed with the posterior MEAN as personality, the ground-truth
         destination as goal and `teacher_forcing_reactive_replay` (agents keep spawning from ground truth until step 90).
         Outputs are the un-flattened RolloutBuffer fields [B,A,S,...] plus what `TrainingMetrics.update` consumes."""
         inp = self.preprocess(batch)
-        f = self.encode_scene(inp)
         gt = self.preprocess_gt(batch)
-        post_mean, post_log_std, post_valid = self.latent_post(f, gt)
+        inp_enc, gt_enc = inp, gt
+        if history_keep is not None:
+            kb = lambda k_: torch.as_tensor(np.asarray(history_keep[k_])).bool()  # noqa: E731
+            av = inp["agent_valid"].clone()
+            av[:, :-1] &= kb("input_agent")
+            inp_enc = dict(inp, agent_valid=av, tl_valid=inp["tl_valid"] & kb("input_tl"), map_valid=inp["map_valid"] & kb("input_map"))
+            gt_enc = dict(gt, agent_valid=gt["agent_valid"] & kb("post_agent"), tl_valid=gt["tl_valid"] & kb("post_tl"))
+        f = self.encode_scene(inp_enc)
+        post_mean, post_log_std, post_valid = self.latent_post(f, gt_enc)
         prior_mean, prior_log_std, prior_valid = self.latent_prior(f)
-        logits = self.dest_logits(f, inp)
-        goal_valid = inp["agent_valid"].any(1)  # GoalManager.get_gt_goal, goal_manager.py:66-68
+        logits = self.dest_logits(f, inp_enc)
+        goal_valid = inp_enc["agent_valid"].any(1)  # GoalManager.get_gt_goal, goal_manager.py:66-68
         dest = gt["gt_dest"].to(torch.int64)
         # training_step (`waymo_motion.py:384-400`): a SAMPLE (mean + std * eps) of the posterior, or of the prior
         mean, log_std, which = (prior_mean, prior_log_std, "prior") if rollout_prior else (post_mean, post_log_std, "post")
         z = mean.clone() if eps is None else mean + _t(eps, self.dtype) * log_std.exp()
-        res = self.rollout(inp, f, z, mean, dest, goal_valid, 1, step_end, gt=gt, tf_cfg_name=tf_cfg_name, log_std_name=which,
-                           action_eps=action_eps)
+        # (`input/map_valid` IS `map/valid` in the reference -- `sc/map_valid = batch["map/valid"]`, scene_centric.py:113-114, masked in
+        # place by sc_input.py:105-106 -- so the rule checker's destination geometry sees the masked nodes too)
+        inp_roll = inp if history_keep is None else dict(inp, map_valid=inp_enc["map_valid"])
+        res = self.rollout(inp_roll, f, z, mean, dest, goal_valid, 1, step_end, gt=gt_enc, tf_cfg_name=tf_cfg_name, log_std_name=which,
+                           action_eps=action_eps, hidden_drop=hidden_drop)
         res.update(post_mean=post_mean, post_log_std=post_log_std, post_valid=post_valid, prior_mean=prior_mean,
                    prior_log_std=prior_log_std, prior_valid=prior_valid, dest_logits_raw=logits, goal_valid=goal_valid,
-                   gt_dest=dest, gt_valid=gt["agent_valid"], gt_state=gt["agent_state"], agent_role=gt["agent_role"],
+                   gt_dest=dest, gt_valid=gt_enc["agent_valid"], gt_state=gt["agent_state"], agent_role=gt["agent_role"],
                    agent_size=inp["agent_size"], agent_type=inp["agent_type"])
         res["_inp"], res["_feats"], res["_gt"] = inp, f, gt
         return res

@@ -85,7 +85,7 @@ def _closed_loop_check(name, preds, g, step_axis, rep, step_start=1):
     assert d32[:n_flat].max() <= 1e-4, f"{name}: {d32[:n_flat].max():.3e} > 1e-4 within the first {n_flat} steps"
 
 
-N_ORACLE_ENSEMBLE = 12
+N_ORACLE_ENSEMBLE = 8
 
 
 def _oracle_ensemble(run, batch, k=1, eps=None, dest=None, act=None, n_members=N_ORACLE_ENSEMBLE, seed=0):
@@ -796,6 +796,53 @@ def test_training_step_forward_against_oracle(rollout_prior, sampled_actions):
     for k in want:
         assert abs(got[k] - want[k]) <= 2e-5 * max(1.0, abs(want[k])), (k, got[k], want[k])
     assert out["loss"] == got["training/loss"]
+
+
+def test_training_step_train_mode_masks_against_reference_golden():
+    """The train-mode Bernoulli masks with explicit draws (VERDICT r02 missing #4): `pre_processing.input.dropout_p_history`
+    (`sc_input.py:100-106`), `pre_processing.latent.dropout_p_history` (`sc_latent.py:171-173,216-218`) and `p_drop_hidden`
+    (`waymo_motion.py:345-351`) through `WaymoMotion.training_step(history_keep=, hidden_drop=)`, against tests/golden/train_dropout.npz
+    = the body of the reference's own training_step with `torch.bernoulli` / `torch.rand(1)` / the personality's rsample replaced by
+    synth.make_train_draws (network in eval-mode arithmetic)."""
+    from trafficbots_amd import synth
+    from trafficbots_amd.config import load_model_config
+
+    g, meta = load_golden("train_dropout")
+    over = {"time_step_end": meta["time_step_end"], "n_joint_future": 1}
+    over.update(meta["overrides"])
+    cfg = load_model_config(overrides=over)
+    sc, ov = meta["scene"], meta["overrides"]
+    n_step = meta["time_step_end"] - cfg["time_step_sim_start"] + 1
+    draws = synth.make_train_draws(meta["draws_seed"], meta["n_scene"], sc["n_agent"], sc["n_pl"], sc["n_tl"], n_step,
+                                   ov["pre_processing.input.dropout_p_history"], ov["pre_processing.latent.dropout_p_history"], ov["p_drop_hidden"])
+    batch = synth.make_val_batch(meta["base_seed"], meta["n_scene"], **sc)
+    eps = torch.from_numpy(synth.make_latent_noise(meta["base_seed"] + 99, meta["n_scene"], sc["n_agent"])).cuda()
+    wm = _engine(over, synth.make_state_dict(meta["weight_seed"]))
+    keep = {k: torch.from_numpy(v) for k, v in draws.items() if k != "hidden_drop"}
+    out = wm.training_step(batch, latent_eps=eps, history_keep=keep, hidden_drop=draws["hidden_drop"])
+    torch.cuda.synchronize()
+    buf = out["rollout_buffer"]
+    assert (out["latent_post"].valid.cpu().numpy() == g["post_valid"]).all() and (out["latent_prior"].valid.cpu().numpy() == g["prior_valid"]).all()
+    assert np.abs(out["latent_post"].mean.cpu().numpy() - g["post_mean"]).max() <= ONE_SHOT_TOL
+    assert np.abs(out["latent_prior"].mean.cpu().numpy() - g["prior_mean"]).max() <= ONE_SHOT_TOL
+    assert (buf.valid.cpu().numpy() == g["valid"]).all() and (buf.override_masks.cpu().numpy() == g["override_masks"]).all()
+    d = np.abs(buf.preds.cpu().numpy() - g["preds"]) * g["valid"][..., None]
+    assert d[..., :2].max() <= 1e-4, d[..., :2].max()  # (50 steps of a 10-agent scene)
+    fh = g["final_hidden"].reshape(buf.final["final_hidden"].shape)
+    assert np.abs(buf.final["final_hidden"].cpu().numpy() - fh).max() <= 1e-4
+    ref = json.loads(bytes(g["metrics_json"]).decode())
+    got = out["metrics_dict"]
+    assert set(got) == set(ref) and all(abs(got[k] - ref[k]) <= 2e-4 * max(1.0, abs(ref[k])) for k in ref), (got, ref)
+    assert np.allclose(out["train_states"].cpu().numpy(), g["train_states"], rtol=2e-4)
+    # the masks matter, each of them: without the hidden drop / without the history masks the rollout is a different one
+    plain = wm.training_step(batch, latent_eps=eps)["rollout_buffer"]
+    nohid = wm.training_step(batch, latent_eps=eps, history_keep=keep)["rollout_buffer"]
+    assert float((plain.preds - buf.preds).abs().max()) > 1e-2 and float((nohid.preds - buf.preds).abs().max()) > 1e-3
+    # and drawn here when the configuration asks for them and none are given: reproducible from the generator
+    a = wm.training_step(batch, latent_eps=eps, generator=torch.Generator(device="cuda").manual_seed(5))["rollout_buffer"].preds
+    b = wm.training_step(batch, latent_eps=eps, generator=torch.Generator(device="cuda").manual_seed(5))["rollout_buffer"].preds
+    c = wm.training_step(batch, latent_eps=eps, generator=torch.Generator(device="cuda").manual_seed(6))["rollout_buffer"].preds
+    assert torch.equal(a, b) and not torch.equal(a, c)
 
 
 @pytest.mark.parametrize("shape", [dict(n_agent=64, n_pl=256, n_tl=40), dict(n_agent=20, n_pl=33, n_tl=5, p_late_spawn=0.4, p_invalid_agent=0.2)])

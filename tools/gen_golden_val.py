@@ -162,10 +162,114 @@ def run_reference(case: dict, dtype=torch.float32, perturb=None) -> dict:
     return {k: (v.detach().cpu().numpy() if torch.is_tensor(v) else v) for k, v in out.items()}
 
 
+TRAIN_CASE = dict(
+    # the train-mode Bernoulli masks with explicit draws (synth.make_train_draws): history dropout of the model inputs and of the
+    # posterior's inputs, hidden-state drop during the rollout; everything else in eval-mode arithmetic (no nn.Dropout)
+    base_seed=15000, n_scene=3, weight_seed=9, time_step_end=50, draws_seed=15001,
+    overrides={"pre_processing.input.dropout_p_history": 0.2, "pre_processing.latent.dropout_p_history": 0.25, "p_drop_hidden": 0.12},
+    scene=dict(n_agent=10, n_pl=24, n_tl=12, p_invalid_agent=0.2, p_late_spawn=0.3, p_future_spawn=0.5, p_future_exit=0.3, pos_range=70.0),
+)
+
+
+def run_reference_training(case: dict = TRAIN_CASE) -> dict:
+    """The body of the reference's `training_step` (`waymo_motion.py:356-418`) with ONLY the train-mode switches of the pre-processing
+    modules and of `rollout` turned on (the network itself stays in eval mode: no nn.Dropout), `torch.bernoulli` / `torch.rand(1)` /
+    the personality's rsample replaced by stored draws."""
+    over = {"time_step_end": case["time_step_end"], "n_joint_future": 1}
+    over.update(case["overrides"])
+    cfg = load_model_config(overrides=over)
+    sc = case["scene"]
+    torch.set_default_dtype(torch.float32)
+    model = ref_shim.build_reference(cfg, n_agent=sc["n_agent"], n_pl=sc["n_pl"], n_tl=sc.get("n_tl", 40))
+    model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in synth.make_state_dict(case["weight_seed"]).items()}, strict=True)
+    model.eval()
+    for m in model.pre_processing.children():
+        m.training = True
+    model.training = True  # (the module's own flag only: `if self.training and ...` in rollout, waymo_motion.py:346)
+    n_step = case["time_step_end"] - cfg["time_step_sim_start"] + 1
+    ov = case["overrides"]
+    draws = synth.make_train_draws(case["draws_seed"], case["n_scene"], sc["n_agent"], sc["n_pl"], sc["n_tl"], n_step,
+                                   ov["pre_processing.input.dropout_p_history"], ov["pre_processing.latent.dropout_p_history"], ov["p_drop_hidden"])
+    eps = torch.from_numpy(synth.make_latent_noise(case["base_seed"] + 99, case["n_scene"], sc["n_agent"]))
+    batch = {k: torch.from_numpy(v.copy()) for k, v in synth.make_val_batch(case["base_seed"], case["n_scene"], **sc).items()}
+    order = ["input_agent", "input_tl", "input_map", "post_tl", "post_agent"]
+    calls = {"bern": 0, "rand": 0}
+    orig_bern, orig_rand = torch.bernoulli, torch.rand
+    import torch.distributions.normal as tdn
+
+    orig_norm = tdn._standard_normal
+
+    def fake_bernoulli(probs, *a_, **k_):
+        key = order[calls["bern"]]
+        calls["bern"] += 1
+        d = torch.from_numpy(draws[key])
+        assert tuple(d.shape) == tuple(probs.shape), (key, tuple(d.shape), tuple(probs.shape))
+        return d.to(probs.dtype)
+
+    def fake_rand(*size, **k_):
+        if tuple(size) == (1,):
+            i = calls["rand"]
+            calls["rand"] += 1
+            if i < n_step:  # the hidden-state draws of the rollout, one per step
+                return torch.tensor([0.0 if draws["hidden_drop"][i] else 1.0])
+            return torch.tensor([1.0])  # (`torch.rand(1) < p_training_rollout_prior` comes first in training_step: see below)
+        return orig_rand(*size, **k_)
+
+    out = {}
+    try:
+        torch.bernoulli = fake_bernoulli
+        tdn._standard_normal = lambda shape, dtype, device: eps.to(dtype)
+        with torch.no_grad():
+            batch = model.pre_processing(batch)
+            assert calls["bern"] == 5, calls
+            pick = lambda pre: {k.split(pre)[-1]: v for k, v in batch.items() if pre in k}  # noqa: E731
+            input_dict, post_dict, prior_dict = pick("input/"), pick("latent_post/"), pick("latent_prior/")
+            feats = model.model.encode_input_features(**input_dict)
+            feats_post = model.model.encode_input_features(**post_dict)
+            feats_prior = model.model.encode_input_features(**prior_dict)
+            goal_gt, goal_valid = model.model.goal_manager.get_gt_goal(agent_valid=input_dict["agent_valid"], gt_dest=batch["gt/dest"], gt_goal=batch["gt/goal"])
+            goal_pred = model.model.goal_manager.pred_goal(agent_type=batch["ref/agent_type"], map_type=batch["ref/map_type"],
+                                                           agent_state=batch["ref/agent_state"], **feats)
+            latent_post = model.model.latent_encoder(posterior=True, **feats_post)
+            latent_prior = model.model.latent_encoder(**feats_prior)
+            torch.rand = fake_rand  # (from here on: the per-step hidden draws; the rollout-prior coin is taken as "posterior")
+            buf = model.reactive_replay(
+                batch=batch, input_feature_dict=feats, mask_teacher_forcing=model.teacher_forcing_training.get(batch["gt/valid"], 0),
+                latent=latent_post, goal=goal_gt, goal_valid=goal_valid, deterministic_latent=False,
+                deterministic_action=True, require_vis_dict=False)
+            assert calls["rand"] == n_step, calls
+            # (taken BEFORE the metric update: `pred_valid[:, :, :step_training_start] &= False` edits the buffer in place, training.py:93)
+            raw_valid = buf.valid.clone()
+            tm = model.train_metrics_train  # (torchmetrics' forward = update + compute; the Metric stand-in of tools/ref_shim.py has neither)
+            tm.update(
+                pred_valid=buf.valid, diffbar_rewards_valid=buf.diffbar_rewards_valid, diffbar_rewards=buf.diffbar_rewards,
+                override_masks=buf.override_masks, agent_role=batch["ref/agent_role"], goal_valid=goal_valid, goal_pred=goal_pred,
+                goal_gt=goal_gt, latent_post=latent_post, latent_prior=latent_prior)
+            md = tm.compute()
+            out["train_states"] = np.array([float(getattr(tm, k)) for k in TRAIN], np.float64)
+            out.update(preds=buf.preds, valid=raw_valid, override_masks=buf.override_masks, post_mean=latent_post.mean, post_valid=latent_post.valid,
+                       prior_mean=latent_prior.mean, prior_valid=latent_prior.valid, dest_logits=goal_pred.distribution.logits,
+                       goal_valid=goal_valid, map_feature=feats["map_feature"], map_feature_valid=feats["map_feature_valid"],
+                       final_hidden=model.model.hidden, latent_sample=model.model.latent_sample)
+            out["metrics_json"] = np.frombuffer(json.dumps({k: float(v) for k, v in md.items()}).encode(), np.uint8)
+    finally:
+        torch.bernoulli, torch.rand, tdn._standard_normal = orig_bern, orig_rand, orig_norm
+    res = {k: (v.detach().cpu().numpy() if torch.is_tensor(v) else v) for k, v in out.items()}
+    res["meta_json"] = np.frombuffer(json.dumps(case).encode(), dtype=np.uint8)
+    res["hidden_drop_steps"] = np.nonzero(draws["hidden_drop"])[0]
+    return res
+
+
 def main() -> None:
     os.makedirs(GOLDEN_DIR, exist_ok=True)
     torch.set_num_threads(os.cpu_count())
     only = sys.argv[1:]
+    if not only or "train_dropout" in only:
+        r = run_reference_training()
+        path = os.path.join(GOLDEN_DIR, "train_dropout.npz")
+        np.savez_compressed(path, **r)
+        print(f"[train_dropout] wrote {path} ({os.path.getsize(path) / 1024:.0f} KiB); hidden dropped after steps {r['hidden_drop_steps'] + 1}; "
+              f"{json.loads(r['metrics_json'].tobytes())}")
     for name, case in CASES.items():
         if only and name not in only:
             continue

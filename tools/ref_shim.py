@@ -180,7 +180,7 @@ def build_reference(cfg: dict, n_agent: int, n_pl: int, n_tl: int = 40) -> nn.Mo
                 pe_dim=c.pre_processing.input.pe_dim,
                 pose_pe=c.pre_processing.input.pose_pe,
                 perturb_input_to_latent=False,
-                dropout_p_history=-1,
+                dropout_p_history=cfg.get("pre_processing", {}).get("latent", {}).get("dropout_p_history", -1),
                 max_meter=50.0,
                 max_rad=3.14,
             ),
@@ -195,7 +195,7 @@ def build_reference(cfg: dict, n_agent: int, n_pl: int, n_tl: int = 40) -> nn.Mo
         detach_state_policy=c.detach_state_policy,
         training_deterministic_action=True,
         differentiable_reward=c.differentiable_reward,
-        p_drop_hidden=-1.0,
+        p_drop_hidden=cfg.get("p_drop_hidden", -1.0),
         n_video_batch=0,
         n_joint_future=c.n_joint_future,
         waymo_post_processing=AttrDict(

@@ -36,7 +36,11 @@ DEFAULT_MODEL_CONFIG: Dict[str, Any] = {
             "pe_dim": 96,
             "pose_pe": {"map": "pe_xy_yaw", "tl": "pe_xy_yaw", "agent": "pe_xy_yaw"},
         },
+        # SceneCentricLatent (sc_latent.py): only the posterior-side history dropout is read (train mode, explicit draws);
+        # perturb_input_to_latent is an un-built augmentation
+        "latent": {"perturb_input_to_latent": False, "dropout_p_history": -1},
     },
+    "p_drop_hidden": -1.0,
     "model": {
         "hidden_dim": 128,
         "add_goal_latent_first": False,

@@ -904,6 +904,7 @@ extern "C" int tb_rollout(tb_ctx* ctx, const tb_rollout_io* io, tb_stream stream
     if (!use_graph) return rollout_enqueue(ctx, io, p, s);
     unsigned long long key = fnv1a(&p, sizeof(p), 1469598103934665603ull);
     key = fnv1a(io, sizeof(*io), key);
+    if (io->hidden_drop) key = fnv1a(io->hidden_drop, (size_t)p.n_step_out, key);  // (host data that shapes the launch sequence)
     for (const char* name : {"TB_STEP_W3", "TB_STEP_LEAN", "TB_STEP_HELPERS", "TB_GRU_HELPER"}) {
         const char* v = getenv(name);
         key = fnv1a(v ? v : "-", v ? strlen(v) + 1 : 2, key);
@@ -979,6 +980,10 @@ static int rollout_enqueue(tb_ctx* ctx, const tb_rollout_io* io, const tb::Rollo
             q.vtin_b[0] = q.vtin_b[1] = p.vtin_pre + 3 * z;
         }
         if (do_c || do_a) step_launch(ctx, q, p, t, do_c, do_a, s);
+        // train-mode p_drop_hidden with the caller's draws (tb_rollout_io.hidden_drop): the GRU state of every instance is zeroed
+        // after step t has been recorded -- the next launch (its helper workgroups included) starts from zeros
+        if (do_c && io->hidden_drop && io->hidden_drop[t - step_start])
+            TB_HIP(ctx, hipMemsetAsync(p.hidden, 0, sizeof(float) * 3 * (size_t)p.n_inst * p.a_pad * 128, s));
         ctx->launch_kind[i] = (do_c && do_a) ? 2 : ((do_c || do_a) ? 1 : 0);
         if (ctx->timing) TB_HIP(ctx, hipEventRecord(ctx->ev[2 + i], s));
     }

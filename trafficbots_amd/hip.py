@@ -46,7 +46,7 @@ class TbRolloutIO(C.Structure):
         ("tap_step", C.c_int32), ("tap_policy_feature", c_f32p), ("tap_agent_feature", c_f32p),
         ("check_state", c_f32p), ("check_valid", c_u8p),
         ("n_tl_step", C.c_int32), ("latent_posterior", C.c_int32), ("warm_start_steps", C.c_int32),
-        ("action_eps", c_f32p),
+        ("action_eps", c_f32p), ("hidden_drop", C.c_void_p),
     ]
 
 

@@ -364,8 +364,11 @@ class HipEngine:
         latent_posterior: bool = False,
         warm_start_steps: int = 0,
         action_eps: Optional[Tensor] = None,
+        hidden_drop=None,
     ) -> Dict[str, Tensor]:
-        """`action_eps` [N, A, S, 2] standard normal: sampled actions (`deterministic_action=False`, `dynamics.py:77`); None = the mean.
+        """`hidden_drop` [S] bool (host): train-mode `p_drop_hidden` with explicit draws -- the GRU state of all instances is zeroed after
+        the steps where it is set (`waymo_motion.py:345-351`; `tb_rollout_io.hidden_drop`).
+        `action_eps` [N, A, S, 2] standard normal: sampled actions (`deterministic_action=False`, `dynamics.py:77`); None = the mean.
         Closed-loop rollout of N = B*K instances (instance n uses scene n // K).  Returns the
         `RolloutBuffer` fields as [N, A, S, ...] tensors (`buffer.py:72-90`).  With `stepwise=True` only the
         prologue runs (`tb_rollout_begin`); advance with :meth:`rollout_step`, inspect with :meth:`rollout_state`.
@@ -471,9 +474,17 @@ class HipEngine:
             action_eps = action_eps.to(device=dev, dtype=f32).contiguous()
             assert action_eps.shape == (n, a, n_step, 2), (tuple(action_eps.shape), (n, a, n_step, 2))
         io.action_eps = hip.ptr(action_eps, hip.c_f32p)
+        hd = None
+        if hidden_drop is not None:
+            if stepwise:
+                raise NotImplementedError("hidden_drop is built for the fused rollout, not for the stepwise API")
+            hd = np.ascontiguousarray(np.asarray(torch.as_tensor(hidden_drop).cpu()).astype(np.uint8))
+            assert hd.shape == (n_step,), (hd.shape, n_step)
+            io.hidden_drop = C.c_void_p(hd.ctypes.data)
         # keep the borrowed inputs alive until the stream work is done
         if default_mask is not None:
             out["_default_tf_mask"] = default_mask
+        out["_keepalive_host"] = hd
         out["_keepalive"] = (latent_sample, latent_mean, dest, goal_valid, mask_teacher_forcing, s, feats, gt, action_eps)
         if stepwise:
             self._check(self.lib.tb_rollout_begin(self._ctx, C.byref(io), self._stream()), "tb_rollout_begin")

@@ -359,6 +359,24 @@ def make_action_override(seed: int, n_inst: int, n_agent: int, n_step: int, p: f
     return act.astype(np.float32), mask
 
 
+def make_train_draws(seed: int, n_scene: int, n_agent: int, n_pl: int, n_tl: int, n_step_out: int, p_input: float, p_latent: float,
+                     p_hidden: float, n_hist: int = N_STEP_HIST, n_gt: int = 91) -> Dict[str, np.ndarray]:
+    """Explicit draws for the train-mode Bernoulli masks of the reference (the `irrelevant_draw` pattern): KEEP masks of
+    `SceneCentricInput` (`sc_input.py:100-106`: agent history but its last step, traffic lights, map nodes; keep = bernoulli(1 - p)),
+    of `SceneCentricLatent`'s posterior inputs (`sc_latent.py:171-173,216-218`: 91-step traffic lights and agents) and the per-step
+    hidden-state drop of `rollout` (`waymo_motion.py:349-351`: `torch.rand(1) < p_drop_hidden` after every step), in the order the
+    reference draws them."""
+    rs = RawStream(seed)
+    return {
+        "input_agent": rs.u01((n_scene, n_hist - 1, n_agent)) < (1.0 - p_input),
+        "input_tl": rs.u01((n_scene, n_hist, n_tl)) < (1.0 - p_input),
+        "input_map": rs.u01((n_scene, n_pl, N_PL_NODE)) < (1.0 - p_input),
+        "post_tl": rs.u01((n_scene, n_gt, n_tl)) < (1.0 - p_latent),
+        "post_agent": rs.u01((n_scene, n_gt, n_agent)) < (1.0 - p_latent),
+        "hidden_drop": rs.u01((n_step_out,)) < p_hidden,
+    }
+
+
 def _tf_layer(prefix: str, spec: "OrderedDict[str, Tuple[int, ...]]", h: int = 128, d_ff: int = 128) -> None:
     spec[f"{prefix}.norm1.weight"] = (h,)
     spec[f"{prefix}.norm1.bias"] = (h,)

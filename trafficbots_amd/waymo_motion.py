@@ -311,8 +311,10 @@ class WaymoMotion:
         warm_start_steps: int = 0,
         action_eps: Optional[Tensor] = None,
         generator=None,
+        hidden_drop=None,
     ) -> RolloutBuffer:
-        """`deterministic_action=False` samples every step's action (`dynamics.py:77`): the standard-normal draws are `action_eps`
+        """`hidden_drop` [S] bool: the train-mode hidden-state drop with explicit draws (`waymo_motion.py:345-351`), fused rollout only.
+        `deterministic_action=False` samples every step's action (`dynamics.py:77`): the standard-normal draws are `action_eps`
         [N, A, S, 2] (explicit, as the goldens pass them) or, when None, drawn here with `torch.randn(generator=generator)` -- the
         reference draws them step by step from torch's global stream, which no other implementation can replay.
         `WaymoMotion.rollout` (`waymo_motion.py:205-354`).  `gt` (the scene's "gt" dict) replaces the history as
@@ -353,7 +355,7 @@ class WaymoMotion:
             features, features, z, mean_scene, goal, goal_valid, k_futures, step_end,
             mask_teacher_forcing=mask_teacher_forcing.to(torch.uint8).contiguous(), tap_step=tap_step, stepwise=stepwise or per_step,
             record_check_states=want_checks, gt=gt, latent_posterior=latent_posterior, warm_start_steps=warm_start_steps,
-            action_eps=action_eps,
+            action_eps=action_eps, hidden_drop=hidden_drop,
         )
         if per_step:
             self._step_t = step_start
@@ -409,7 +411,7 @@ class WaymoMotion:
                         latent: DiagGaussian, goal: Tensor, goal_valid: Tensor, deterministic_latent: bool = True,
                         deterministic_action: bool = True, require_vis_dict: bool = False, latent_eps: Optional[Tensor] = None,
                         latent_is_posterior: bool = True, teacher_forcing_cfg: Optional[Dict] = None,
-                        action_eps: Optional[Tensor] = None, generator=None) -> RolloutBuffer:
+                        action_eps: Optional[Tensor] = None, generator=None, hidden_drop=None) -> RolloutBuffer:
         """`WaymoMotion.reactive_replay` (`waymo_motion.py:420-476`): the episode replayed from its ground truth (`batch` is the
         pre-processed validation scene, `batch["gt"]` its ground truth) with the given personality and goal; K = 1.  The
         personality is taken as a POSTERIOR for `latent_log_prob` (that is what validation / training pass, `:382-387,605`).
@@ -426,7 +428,7 @@ class WaymoMotion:
             deterministic_latent=deterministic_latent, deterministic_action=deterministic_action,
             step_start=self.hparams["time_step_sim_start"], step_end=self.hparams["time_step_end"], k_futures=1,
             gt=batch["gt"], latent_posterior=latent_is_posterior, require_vis_dict=require_vis_dict, rule_checker_tl=batch["gt"],
-            latent_eps=latent_eps, warm_start_steps=w, action_eps=action_eps, generator=generator,
+            latent_eps=latent_eps, warm_start_steps=w, action_eps=action_eps, generator=generator, hidden_drop=hidden_drop,
         )
 
     def finish_rollout(self) -> RolloutBuffer:
@@ -636,8 +638,19 @@ class WaymoMotion:
 
     def training_step(self, batch: Dict[str, Tensor], batch_idx: int = 0, latent_eps: Optional[Tensor] = None,
                       rollout_prior: bool = False, current_epoch: int = 0, action_eps: Optional[Tensor] = None,
-                      generator=None, irrelevant_draw: Optional[Tensor] = None) -> Dict[str, object]:
-        """Forward value of `WaymoMotion.training_step` (`waymo_motion.py:356-418`): the episode replayed under
+                      generator=None, irrelevant_draw: Optional[Tensor] = None, history_keep: Optional[Dict[str, Tensor]] = None,
+                      hidden_drop=None) -> Dict[str, object]:
+        """Train-mode Bernoulli masks (explicit draws, the `irrelevant_draw` pattern; drawn here with `generator` when the config asks
+        for them and none are given):
+          * `history_keep` -- KEEP masks of `pre_processing.input.dropout_p_history` ("input_agent" [B,10,A]: the agent history but its
+            last step, "input_tl" [B,11,T], "input_map" [B,P,20]; `sc_input.py:100-106`) and of `pre_processing.latent.dropout_p_history`
+            ("post_tl" [B,91,T], "post_agent" [B,91,A]: the posterior's inputs, `sc_latent.py:171-173,216-218`).  As in the reference the
+            posterior's masks also apply to the ground-truth validity the replay runs against, and the input's map mask to the rule
+            checker's map (both are in-place edits of aliased tensors there);
+          * `hidden_drop` [S] -- `p_drop_hidden`: the GRU state of the whole batch is zeroed after the steps where it is set
+            (`waymo_motion.py:345-351`).
+        nn.Dropout inside the network stays off (eval-mode arithmetic).
+        Forward value of `WaymoMotion.training_step` (`waymo_motion.py:356-418`): the episode replayed under
         `teacher_forcing_training` with a SAMPLE of the posterior personality (or of the prior when `rollout_prior`, which the
         reference decides with `torch.rand(1) < p_training_rollout_prior`) and the ground-truth destination, then
         `TrainingMetrics` -> {"training/loss", "training/vae_kl", "training/diffbar_reward", "training/goal_loss"}.
@@ -654,6 +667,7 @@ class WaymoMotion:
         if "gt" not in scene:
             raise ValueError("training_step needs a training / validation batch (agent/*, tl_stop/* ground truth)")
         gt = scene["gt"]
+        scene, gt, hidden_drop = self._train_mode_masks(scene, gt, history_keep, hidden_drop, generator)
         input_feature_dict = self.model.encode_input_features(scene)
         goal_gt, goal_valid = self.model.goal_manager.get_gt_goal(scene["agent_valid"], gt.get("gt_goal"), gt["gt_dest"])
         goal_pred = self.model.goal_manager.pred_goal()
@@ -664,7 +678,7 @@ class WaymoMotion:
         buf = self.reactive_replay(scene, input_feature_dict, mask_tf, latent, goal_gt, goal_valid,
                                    deterministic_latent=latent_eps is None, deterministic_action=det_action, latent_eps=latent_eps,
                                    latent_is_posterior=not rollout_prior, teacher_forcing_cfg=tf, action_eps=action_eps,
-                                   generator=generator)
+                                   generator=generator, hidden_drop=hidden_drop)
         gv, gs = self._gt_slices(gt, hp["time_step_sim_start"], hp["time_step_end"])
         raw = {"valid": buf.valid, "preds": buf.preds, "override_masks": buf.override_masks}
         _, _, states = self.engine.train_partials(
@@ -678,6 +692,41 @@ class WaymoMotion:
         out = m.compute()  # (the reference logs and resets per step, :415-417)
         return {"loss": out["training/loss"], "metrics_dict": out, "train_states": states, "rollout_buffer": buf,
                 "latent_post": latent_post, "latent_prior": latent_prior}
+
+    def _train_mode_masks(self, scene: Dict[str, Tensor], gt: Dict[str, Tensor], history_keep, hidden_drop, generator):
+        """Applies / draws the train-mode Bernoulli masks of :meth:`training_step`; returns (scene, gt, hidden_drop) -- copies of the
+        dicts with the masked validity tensors (the caller's batch is not edited)."""
+        hp = self.hparams
+        p_in = float(hp["pre_processing"]["input"].get("dropout_p_history", -1))
+        p_lat = float(hp["pre_processing"].get("latent", {}).get("dropout_p_history", -1))
+        p_hid = float(hp.get("p_drop_hidden", -1.0))
+        if hp["pre_processing"].get("latent", {}).get("perturb_input_to_latent", False):
+            raise NotImplementedError("pre_processing.latent.perturb_input_to_latent (random re-centring of the latent encoders' inputs) is not built")
+        dev = self.device
+        keep = dict(history_keep) if history_keep is not None else {}
+
+        def draw(name, shape, p):
+            if name not in keep:
+                keep[name] = torch.bernoulli(torch.full(shape, 1.0 - p, device=dev), generator=generator).bool()
+            return keep[name].to(dev).bool().reshape(shape)
+
+        b, nh, a = scene["agent_valid"].shape
+        if 0 < p_in <= 1.0 or any(k in keep for k in ("input_agent", "input_tl", "input_map")):
+            av = scene["agent_valid"].bool().clone()
+            av[:, :-1] &= draw("input_agent", (b, nh - 1, a), p_in)
+            tlv = scene["tl_valid"].bool() & draw("input_tl", tuple(scene["tl_valid"].shape), p_in)
+            mv = scene["map_valid"].bool() & draw("input_map", tuple(scene["map_valid"].shape), p_in)
+            scene = dict(scene, agent_valid=av.to(torch.uint8), tl_valid=tlv.to(torch.uint8).contiguous(), map_valid=mv.to(torch.uint8).contiguous(),
+                         warm_ok=False)
+        if 0 < p_lat <= 1.0 or any(k in keep for k in ("post_agent", "post_tl")):
+            gav = gt["agent_valid"].bool() & draw("post_agent", tuple(gt["agent_valid"].shape), p_lat)
+            gtl = gt["tl_valid"].bool() & draw("post_tl", tuple(gt["tl_valid"].shape), p_lat)
+            gt = dict(gt, agent_valid=gav.to(torch.uint8).contiguous(), tl_valid=gtl.to(torch.uint8).contiguous(), warm_ok=False)
+            scene = dict(scene, gt=gt)
+        if hidden_drop is None and p_hid > 0:
+            n_step = hp["time_step_end"] - hp["time_step_sim_start"] + 1
+            hidden_drop = (torch.rand(n_step, device=dev, generator=generator) < p_hid).cpu()
+        return scene, gt, hidden_drop
 
     def validation_step(self, batch: Dict[str, Tensor], batch_idx: int = 0, latent_eps=None, goal_sample=None, generator=None,
                         irrelevant_draw: Optional[Tensor] = None) -> Dict[str, object]:
