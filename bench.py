@@ -245,6 +245,7 @@ def time_passes(c, k, step_end, steps, warmup, world, events=False):
     elapsed = time.perf_counter() - t0
     tm = eng.get_timing()
     tm["host_cpu_ms_per_pass"] = (c1 - c0) / max(1, steps - 1) * 1e3  # (the last pass carries the event markers and is launched plainly)
+    tm["rollout_graph"] = eng.graph_stats()
     eng.set_timing(False)
     # outside the timed region: the sticky device words (fp16-pair range, helper hand-off time-out).  A pass that tripped either is
     # not a measurement -- tb_check_status raises
@@ -387,7 +388,7 @@ def sub_record(name, spec, sd, dev, rank, world, steps, warmup):
                      "traffic_over_algorithmic": ((pmc["fetch_bytes_per_launch"] / by) if pmc and pmc.get("fetch_bytes_per_launch") else None),
                      "mfma_busy_measured": (pmc or {}).get("mfma_busy"),
                      "avg_launch_us_kernel_trace": (pmc or {}).get("avg_fused_launch_us_kernel_trace")},
-        "host_cpu_ms_per_pass": tm["host_cpu_ms_per_pass"],
+        "host_cpu_ms_per_pass": tm["host_cpu_ms_per_pass"], "rollout_graph": tm["rollout_graph"],
         "finite": bool(red["finite_ranks"] == world),
     }
     del c
@@ -556,7 +557,7 @@ def run_rank(args, rank: int, local_rank: int, world: int) -> None:
                         "budget is ms_per_step; the rollout itself issues no collective, the metric / elapsed reduction is ONE all-reduce",
             },
             "host": {"numa": numa, "usable_cpus": usable_cpus(),
-                     "launch_thread_cpu_ms_per_pass": tm["host_cpu_ms_per_pass"],
+                     "launch_thread_cpu_ms_per_pass": tm["host_cpu_ms_per_pass"], "rollout_graph": tm["rollout_graph"],
                      "margin": (elapsed / args.steps * 1e3) / max(1e-9, tm["host_cpu_ms_per_pass"]),
                      "note": "margin = GPU time of a pass / CPU time the launching thread spends enqueueing it; N ranks need N such threads "
                              "(N x launch_thread_cpu_ms_per_pass of CPU per ms_per_step of wall clock)"},

@@ -340,6 +340,9 @@ int tb_forward(tb_ctx* ctx, const tb_forward_io* io, tb_stream stream);
  * (K/V hoists + init), out[3] = number of fused launches.  Timing inserts event records only (no host sync until
  * this query, which synchronises on the last event). */
 int tb_set_timing(tb_ctx* ctx, int enable);
+/* tb_rollout captures ONE hipGraph per rollout the second time it sees the same argument set (buffers, sizes, switches) and replays
+ * it afterwards (TB_ROLLOUT_GRAPH=0: never): out2[0] = rollouts captured, out2[1] = rollouts replayed, since tb_create. */
+int tb_graph_stats(tb_ctx* ctx, int32_t* out2);
 int tb_get_timing(tb_ctx* ctx, float* out4);
 
 /* Flag-gated traffic-rule checks over a recorded rollout.

@@ -81,17 +81,32 @@ for ci in range(n_cases):
         msgs.append(f"train states {got} vs {want}")
     if not np.isfinite(buf.preds.cpu().numpy()).all():
         msgs.append("non-finite preds")
-    if e_xy > 2.5e-4:
-        # dense or long cases: judge against the reference arithmetic's own fp32-vs-fp64 divergence (tests/test_gpu_parity.py
-        # _assert_closed_loop): |hip - fp64| <= max(1e-4, 1.5 noise) and |hip - fp32| <= max(1e-4, 2.5 noise) at every step
+    if e_xy > 1e-4:
+        # dense or long cases: judge against the MEASURED rounding noise of the oracle's own arithmetic on this case -- 8 fp32 runs on
+        # re-ordered batches (tools/ensemble.py), one-sided prediction bound at alpha = 5e-4, no multipliers (tests/test_gpu_parity.py
+        # _assert_closed_loop / _oracle_ensemble; round 2 used max(1e-4, 1.5 / 2.5 x one fp32-vs-fp64 run))
+        from tools import ensemble
+
         with torch.no_grad():
             r64 = Oracle(sd, cfg, torch.float64).reactive_replay(batch, step_end)
-        m = r["valid"].unsqueeze(-1).double()
-        noise = torch.cummax(((r["preds"].double() - r64["preds"]).abs() * m)[..., :2].amax((0, 1, 3)), 0).values
-        d64 = ((buf.preds[:, :, 0].cpu().double() - r64["preds"]).abs() * m)[..., :2].amax((0, 1, 3))
-        d32 = ((buf.preds[:, :, 0].cpu().double() - r["preds"].double()).abs() * m)[..., :2].amax((0, 1, 3))
-        ok = bool((d64 <= torch.clamp(1.5 * noise, min=1e-4)).all() and (d32 <= torch.clamp(2.5 * noise, min=1e-4)).all())
-        print(f"        envelope: ref fp32 vs fp64 {float(noise[-1]):.1e}, hip vs fp64 {float(d64.max()):.1e}, hip vs fp32 {float(d32.max()):.1e} -> {'inside' if ok else 'OUTSIDE'}")
+            mem32, mem64 = [], []
+            for mi in range(8):
+                pb, perm = ensemble.permute_batch({k_: np.asarray(v) for k_, v in batch.items()}, 7919 * (ci + 1) + mi)
+                rm = Oracle(sd, cfg, torch.float32).reactive_replay(pb, step_end)
+                mp, mv = perm.agents_back(rm["preds"].numpy()), perm.agents_back(rm["valid"].numpy())
+                mem32.append(ensemble.spread_per_step(mp, r["preds"].numpy(), mv & r["valid"].numpy(), 2))
+                mem64.append(ensemble.spread_per_step(mp, r64["preds"].numpy(), mv & r64["valid"].numpy(), 2))
+        v32, v64 = r["valid"].numpy(), r["valid"].numpy() & r64["valid"].numpy()
+        hp = buf.preds[:, :, 0].cpu().numpy()
+        d32 = ensemble.spread_per_step(hp, r["preds"].numpy(), v32, 2)
+        d64 = ensemble.spread_per_step(hp, r64["preds"].numpy(), v64, 2)
+        base64 = ensemble.spread_per_step(r["preds"].numpy(), r64["preds"].numpy(), v64, 2)
+        b64 = ensemble.prediction_bound(np.stack([base64] + mem64))
+        b32 = np.maximum(ensemble.prediction_bound(np.stack(mem32)), b64 + np.maximum.accumulate(base64))  # (triangle through the truth)
+        ok = bool((d64 <= np.maximum(1e-4, b64)).all() and (d32 <= np.maximum(1e-4, b32)).all())
+        print(f"        ensemble: oracle fp32 vs fp64 {base64.max():.1e} (members up to {np.stack(mem64).max():.1e}); hip vs fp64 {d64.max():.1e} "
+              f"(bound {b64.max():.1e}), hip vs fp32 {d32.max():.1e} (bound {b32.max():.1e}, members up to {np.stack(mem32).max():.1e}) -> "
+              f"{'inside' if ok else 'OUTSIDE'}")
         if not ok:
             msgs.append("closed-loop envelope")
     if e_post > 2e-5 or e_rew > 1e-5:

@@ -291,6 +291,8 @@ def test_rollout_graph_replay_is_bitwise_identical(monkeypatch):
             again = eng.rollout(scene, feats, z, enc["latent_mean"], dest, gv, k, 30, out=out)  # the first set once more
             torch.cuda.synchronize()
             eng.check_status()
+            gs = eng.graph_stats()
+            assert (gs["captured"] >= 1 and gs["replayed"] >= 3) if mode == "1" else gs == {"captured": 0, "replayed": 0}, (mode, gs)
             for sn in snaps[1:]:
                 assert torch.equal(sn, snaps[0])
             assert torch.equal(other["preds"], snaps[0]) and torch.equal(again["preds"], snaps[0])

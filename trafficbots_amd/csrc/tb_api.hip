@@ -393,6 +393,7 @@ int tb_create(const tb_config* cfg, tb_ctx** out) {
 
 void tb_destroy(tb_ctx* ctx) {
     if (ctx && ctx->graph_exec) (void)hipGraphExecDestroy(ctx->graph_exec);
+    if (ctx && ctx->cap_stream) (void)hipStreamDestroy(ctx->cap_stream);
     if (!ctx) return;
     if (ctx->d_arena) (void)hipFree(ctx->d_arena);
     if (ctx->d_ws) (void)hipFree(ctx->d_ws);
@@ -919,12 +920,19 @@ extern "C" int tb_rollout(tb_ctx* ctx, const tb_rollout_io* io, tb_stream stream
         return rollout_enqueue(ctx, io, p, s);
     }
     hipGraph_t graph = nullptr;
-    if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) != hipSuccess) {  // (a stream that cannot capture: plain launches)
+    // captured on a private stream (nothing runs there: the launches are only recorded), launched on the caller's -- which may be the
+    // legacy default stream, where a capture cannot begin
+    if (!ctx->cap_stream && hipStreamCreateWithFlags(&ctx->cap_stream, hipStreamNonBlocking) != hipSuccess) {
+        (void)hipGetLastError();
+        ctx->cap_stream = nullptr;
+        return rollout_enqueue(ctx, io, p, s);
+    }
+    if (hipStreamBeginCapture(ctx->cap_stream, hipStreamCaptureModeThreadLocal) != hipSuccess) {
         (void)hipGetLastError();
         return rollout_enqueue(ctx, io, p, s);
     }
-    const int rc = rollout_enqueue(ctx, io, p, s);
-    const hipError_t ec = hipStreamEndCapture(s, &graph);
+    const int rc = rollout_enqueue(ctx, io, p, ctx->cap_stream);
+    const hipError_t ec = hipStreamEndCapture(ctx->cap_stream, &graph);
     if (rc) {
         if (graph) (void)hipGraphDestroy(graph);
         return rc;
@@ -1149,6 +1157,14 @@ extern "C" int tb_rollout_state(tb_ctx* ctx, float* state, uint8_t* valid, float
 }
 
 // development aid (not in the public header): copy the stage time stamps of the last launch of a -DTB_PROFILE build
+// hipGraph statistics of the context: out[0] = rollouts captured, out[1] = rollouts replayed from a captured graph
+extern "C" int tb_graph_stats(tb_ctx* ctx, int32_t* out2) {
+    if (!ctx || !out2) return 1;
+    out2[0] = ctx->graph_captures;
+    out2[1] = ctx->graph_hits;
+    return 0;
+}
+
 extern "C" int tb_debug_read_prof(tb_ctx* ctx, long long* host_out, int n_blocks) {
     if (!ctx || !ctx->last_prof) return 1;
     TB_HIP(ctx, hipDeviceSynchronize());

@@ -53,6 +53,7 @@ struct tb_ctx {
     float* d_fw = nullptr;
     size_t fw_floats = 0;
     hipGraphExec_t graph_exec = nullptr;
+    hipStream_t cap_stream = nullptr;  // private stream the launch sequence is captured on (the caller's may be the legacy default stream, which cannot capture)
     unsigned long long graph_key = 0, graph_seen = 0;  // key of the captured graph / of the previous call (capture on the second sight)
     int graph_hits = 0, graph_captures = 0;
 };

@@ -147,7 +147,7 @@ EXPORTS = (
     "tb_create", "tb_destroy", "tb_last_error", "tb_version", "tb_load_weight", "tb_finalize_weights",
     "tb_rollout", "tb_rollout_begin", "tb_rollout_step", "tb_rollout_step_ex", "tb_check_status", "tb_rollout_state", "tb_encode_scene", "tb_set_timing", "tb_get_timing",
     "tb_rule_checks", "tb_post_process", "tb_metric_partials", "tb_struct_sizes", "tb_encode_posterior", "tb_train_partials",
-    "tb_forward",
+    "tb_forward", "tb_graph_stats",
 )
 
 _lib: Optional[C.CDLL] = None

@@ -655,6 +655,12 @@ class HipEngine:
         self._fw_keepalive = keep
         return out
 
+    def graph_stats(self) -> Dict[str, int]:
+        """`tb_graph_stats`: rollouts captured as a hipGraph / replayed from one by this engine."""
+        o = (C.c_int32 * 2)()
+        self._check(self.lib.tb_graph_stats(self._ctx, o), "tb_graph_stats")
+        return {"captured": int(o[0]), "replayed": int(o[1])}
+
     def check_status(self) -> None:
         """`tb_check_status`: synchronises the current stream and raises if an fp16-pair operand left the fp16 range since the
         last check (fp32-accurate mode only; see include/trafficbots_hip.h)."""
