@@ -1,6 +1,7 @@
 """Development probe (GPU box): per-step closed-loop distances of ONE case of gpu_fuzz_validation.py (FUZZ_SEED / FUZZ_ONLY as there):
-oracle fp32 vs fp64 (the arithmetic's own noise), HIP vs fp64, HIP vs fp32, with the helper workgroups on and off and with the
-fp32-MFMA twin kernel."""
+oracle fp32 vs fp64 (the arithmetic's own noise), an ensemble of FUZZ_MEMBERS (default 32) oracle fp32 runs on re-ordered batches
+(tools/ensemble.py) with its per-step prediction bounds, and HIP vs fp64 / vs fp32 with the helper workgroups on and off and with
+the fp32-MFMA twin kernel -- each with the step at which it first leaves a bound (if it does) and its rank among the members there."""
 import os
 import sys
 
@@ -44,10 +45,34 @@ batch = synth.make_val_batch(seed, n_scene, **scene)
 with torch.no_grad():
     r = Oracle(sd, cfg, torch.float32).reactive_replay(batch, step_end)
     r64 = Oracle(sd, cfg, torch.float64).reactive_replay(batch, step_end)
-m = r["valid"].unsqueeze(-1).double()
-noise = ((r["preds"].double() - r64["preds"]).abs() * m)[..., :2].amax((0, 1, 3))
+from tools import ensemble  # noqa: E402
+
+n_mem = int(os.environ.get("FUZZ_MEMBERS", "32"))
+r32p, r64p = r["preds"].numpy(), r64["preds"].numpy()
+v32, v64 = r["valid"].numpy(), r["valid"].numpy() & r64["valid"].numpy()
+base64 = ensemble.spread_per_step(r32p, r64p, v64, 2)
+mem32, mem64 = [], []
+with torch.no_grad():
+    for mi in range(n_mem):
+        pb, perm = ensemble.permute_batch({k_: np.asarray(v) for k_, v in batch.items()}, 7919 * (only + 1) + mi)
+        rm = Oracle(sd, cfg, torch.float32).reactive_replay(pb, step_end)
+        mp, mv = perm.agents_back(rm["preds"].numpy()), perm.agents_back(rm["valid"].numpy())
+        mem32.append(ensemble.spread_per_step(mp, r32p, mv & v32, 2))
+        mem64.append(ensemble.spread_per_step(mp, r64p, mv & v64, 2))
+mem32, mem64 = np.stack(mem32), np.stack([base64] + mem64)
+cm32, cm64 = np.maximum.accumulate(mem32, 1), np.maximum.accumulate(mem64, 1)
+fmt = lambda x: " ".join(f"{float(v):.1e}" for v in x[9::10])  # noqa: E731
 print(scene, over)
-print("step  ref32-vs-64 " + " ".join(f"{float(x):.1e}" for x in noise[9::10]))
+print(f"steps 10, 20, ... ; {n_mem} members")
+print(f"{'ref32 vs 64':28s} " + fmt(base64))
+for first in (8, n_mem):
+    b64 = ensemble.prediction_bound(mem64[: first + 1])
+    b32 = np.maximum(ensemble.prediction_bound(mem32[:first]), b64 + np.maximum.accumulate(base64))
+    print(f"{'bound vs 64, ' + str(first) + ' members':28s} " + fmt(b64))
+    print(f"{'bound vs 32, ' + str(first) + ' members':28s} " + fmt(b32))
+print(f"{'members vs 64: median':28s} " + fmt(np.median(cm64, 0)))
+print(f"{'members vs 64: max':28s} " + fmt(cm64.max(0)))
+print(f"{'members vs 32: max':28s} " + fmt(cm32.max(0)))
 for name, env in (("helpers on", {}), ("helpers off", {"TB_STEP_HELPERS": "0"}), ("fp32-MFMA twin", {"TB_STEP_KERNEL": "fp32"})):
     for k in ("TB_STEP_HELPERS", "TB_STEP_KERNEL"):
         os.environ.pop(k, None)
@@ -56,11 +81,24 @@ for name, env in (("helpers on", {}), ("helpers off", {"TB_STEP_HELPERS": "0"}),
     wm.load_state_dict(sd)
     buf = wm.validation_step(batch)["reactive_replay"]["rollout_buffer"]
     torch.cuda.synchronize()
-    pr = buf.preds[:, :, 0].cpu().double()
-    d64 = ((pr - r64["preds"]).abs() * m)[..., :2].amax((0, 1, 3))
-    d32 = ((pr - r["preds"].double()).abs() * m)[..., :2].amax((0, 1, 3))
-    cm = torch.cummax(noise, 0).values
-    ok = bool((d64 <= torch.clamp(1.5 * cm, min=1e-4)).all() and (d32 <= torch.clamp(2.5 * cm, min=1e-4)).all())
-    print(f"{name:15s} hip-vs-64  " + " ".join(f"{float(x):.1e}" for x in d64[9::10]) + f"   max {float(d64.max()):.2e}")
-    print(f"{'':15s} hip-vs-32  " + " ".join(f"{float(x):.1e}" for x in d32[9::10]) + f"   max {float(d32.max()):.2e}  -> {'inside' if ok else 'OUTSIDE'}")
-    print(f"{'':15s} flags equal: {bool((buf.valid[:, :, 0].cpu() == r['valid']).all())}")
+    hp = buf.preds[:, :, 0].cpu().numpy()
+    d64 = np.maximum.accumulate(ensemble.spread_per_step(hp, r64p, v64, 2))
+    d32 = np.maximum.accumulate(ensemble.spread_per_step(hp, r32p, v32, 2))
+    print(f"{name:15s} {'hip vs 64':12s} " + fmt(d64) + f"   max {d64.max():.2e}")
+    print(f"{'':15s} {'hip vs 32':12s} " + fmt(d32) + f"   max {d32.max():.2e}")
+    for first in (8, n_mem):
+        b64 = np.maximum(1e-4, ensemble.prediction_bound(mem64[: first + 1]))
+        b32 = np.maximum(1e-4, np.maximum(ensemble.prediction_bound(mem32[:first]), b64 + np.maximum.accumulate(base64)))
+        raw64 = ensemble.spread_per_step(hp, r64p, v64, 2)
+        raw32 = ensemble.spread_per_step(hp, r32p, v32, 2)
+        out64, out32 = np.nonzero(raw64 > b64)[0], np.nonzero(raw32 > b32)[0]
+        msg = []
+        for lab, o, raw, bb, cm in (("fp64", out64, raw64, b64, cm64[: first + 1]), ("fp32", out32, raw32, b32, cm32[:first])):
+            if len(o):
+                s0 = int(o[0])
+                worst = int(o[np.argmax(raw[o] / bb[o])])
+                msg.append(f"vs {lab}: {len(o)} steps outside, first at step {s0 + 1}, worst at step {worst + 1} ({raw[worst]:.2e} against {bb[worst]:.2e}; "
+                           f"{int((cm[:, worst] >= raw[worst]).sum())}/{cm.shape[0]} members at least as far)")
+        print(f"{'':15s} against the {first}-member bounds: " + ("inside" if not msg else "; ".join(msg)))
+    print(f"{'':15s} end rank vs fp64 {ensemble.rank_among(mem64, float(d64[-1]))}, vs fp32 {ensemble.rank_among(mem32, float(d32[-1]))}; "
+          f"flags equal: {bool((buf.valid[:, :, 0].cpu() == r['valid']).all())}")
