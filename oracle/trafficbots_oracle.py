@@ -39,14 +39,23 @@ def _t(x, dtype):
 
 
 class Oracle:
-    def __init__(self, state_dict: Dict[str, np.ndarray], cfg: dict, dtype=torch.float32, hoist: bool = False):
-        """`hoist=False` recomputes the loop-invariant map/TL K,V projections and the goal/latent
+    def __init__(self, state_dict: Dict[str, np.ndarray], cfg: dict, dtype=torch.float32, hoist: bool = False,
+                 exact_math: bool = False, gemm_order_seed: Optional[int] = None):
+        """`gemm_order_seed` (noise studies only): every Linear sums its products in another order -- the input features and the
+        weight columns go through the same random permutation (one per input width) -- so that members of an ensemble sample the
+        rounding of the matrix products too, not only that of the attention sums (tools/ensemble.py).
+        `exact_math=True` (noise studies only, tests/probes): cos / sin / softmax / sigmoid / tanh of the rollout are evaluated in
+        fp64 and rounded once to `dtype` -- another correct implementation of the same fp32 arithmetic, with a different libm.
+        `hoist=False` recomputes the loop-invariant map/TL K,V projections and the goal/latent
         `mlp_in` every step exactly as the reference does; `hoist=True` computes them
         once (same values) -- used where only the result matters."""
         self.dtype = dtype
         self.cfg = cfg
         self.w = {k: _t(v, dtype) for k, v in state_dict.items()}
         self.hoist = hoist
+        self.exact_math = exact_math and dtype != torch.float64
+        self._kperm: Dict[int, Tensor] = {}
+        self._kgen = None if gemm_order_seed is None else torch.Generator().manual_seed(int(gemm_order_seed))
         dyn = cfg["dynamics"]
         # type order veh=0, ped=1, cyc=2 (`dynamics.py:23-27`: instantiate(veh), (ped), (cyc))
         self.max_acc = torch.tensor([dyn["veh"]["max_acc"], dyn["ped"]["max_acc"], dyn["cyc"]["max_acc"]], dtype=dtype)
@@ -58,11 +67,24 @@ class Oracle:
         self.n_hist = self.t_cur + 1
 
     # ------------------------------------------------------------------ building blocks
+    def _m(self, fn, x: Tensor, *a, **k) -> Tensor:
+        """transcendental `fn` of x in the working precision (default: what torch's kernels do, as the reference) or via fp64"""
+        return fn(x.double(), *a, **k).to(x.dtype) if self.exact_math else fn(x, *a, **k)
+
+    def _linear(self, x: Tensor, w: Tensor, b: Optional[Tensor]) -> Tensor:
+        if self._kgen is not None:
+            k = w.shape[1]
+            if k not in self._kperm:
+                self._kperm[k] = torch.randperm(k, generator=self._kgen)
+            pm = self._kperm[k]
+            return F.linear(x[..., pm], w[:, pm], b)
+        return F.linear(x, w, b)
+
     def _ln(self, x: Tensor, prefix: str) -> Tensor:
         return F.layer_norm(x, (x.shape[-1],), self.w[prefix + ".weight"], self.w[prefix + ".bias"], LN_EPS)
 
     def _lin(self, x: Tensor, prefix: str) -> Tensor:
-        return F.linear(x, self.w[prefix + ".weight"], self.w[prefix + ".bias"])
+        return self._linear(x, self.w[prefix + ".weight"], self.w[prefix + ".bias"])
 
     def pose_pe(self, xy: Tensor, yaw: Tensor, who: str = "agent") -> Tensor:
         """`PosePE.forward` mode pe_xy_yaw (`src/utils/pose_pe.py:57-62`) with
@@ -72,7 +94,7 @@ class Oracle:
 
         def emb(v: Tensor, freqs: Tensor) -> Tensor:
             e = v.unsqueeze(-1) * freqs
-            return torch.cat([torch.cos(e[..., ::2]), torch.sin(e[..., 1::2])], dim=-1)
+            return torch.cat([self._m(torch.cos, e[..., ::2]), self._m(torch.sin, e[..., 1::2])], dim=-1)
 
         return torch.cat([emb(xy[..., 0], f_xy), emb(xy[..., 1], f_xy), emb(yaw, f_yaw)], dim=-1)
 
@@ -87,7 +109,7 @@ class Oracle:
         w_in = self.w[prefix + ".attn.in_proj_weight"]
         b_in = self.w[prefix + ".attn.in_proj_bias"]
         t = self._ln(tgt, prefix + ".norm_tgt")
-        kv = F.linear(t, w_in[H:], b_in[H:])
+        kv = self._linear(t, w_in[H:], b_in[H:])
         return kv[..., :H], kv[..., H:]
 
     def tf_layer(self, prefix: str, src: Tensor, src_invalid: Tensor, tgt: Optional[Tensor], tgt_invalid: Tensor,
@@ -99,7 +121,7 @@ class Oracle:
         w_in = self.w[prefix + ".attn.in_proj_weight"]
         b_in = self.w[prefix + ".attn.in_proj_bias"]
         s = self._ln(src, prefix + ".norm1")
-        q = F.linear(s, w_in[:H], b_in[:H])
+        q = self._linear(s, w_in[:H], b_in[:H])
         k, v = kv if kv is not None else self.kv_project(prefix, tgt)
         nt = k.shape[-2]
         inv = tgt_invalid.unsqueeze(1).expand(-1, ns, -1)
@@ -112,10 +134,10 @@ class Oracle:
         v = v.reshape(n, nt, N_HEAD, D_HEAD).transpose(1, 2)
         attn = torch.matmul(q, k.transpose(-2, -1))
         attn = attn.masked_fill(inv.unsqueeze(1), float("-inf"))
-        attn = torch.softmax(attn / math.sqrt(D_HEAD), dim=-1)
+        attn = self._m(torch.softmax, attn / math.sqrt(D_HEAD), dim=-1)
         weights = attn.mean(1).masked_fill(no_tgt.unsqueeze(-1), 0) if need_weights else None
         out = torch.matmul(attn, v).transpose(1, 2).flatten(2, 3)
-        out = F.linear(out, self.w[prefix + ".attn.out_proj_weight"], self.w[prefix + ".attn.out_proj_bias"])
+        out = self._linear(out, self.w[prefix + ".attn.out_proj_weight"], self.w[prefix + ".attn.out_proj_bias"])
         out = out.masked_fill(no_tgt.unsqueeze(-1), 0)
         src = src + out
         s2 = self._ln(src, prefix + ".norm2")
@@ -152,13 +174,13 @@ class Oracle:
         h_new = []
         inp = x
         for l in range(3):
-            gi = F.linear(inp, self.w[f"{prefix}.weight_ih_l{l}"], self.w[f"{prefix}.bias_ih_l{l}"])
-            gh = F.linear(h[l], self.w[f"{prefix}.weight_hh_l{l}"], self.w[f"{prefix}.bias_hh_l{l}"])
+            gi = self._linear(inp, self.w[f"{prefix}.weight_ih_l{l}"], self.w[f"{prefix}.bias_ih_l{l}"])
+            gh = self._linear(h[l], self.w[f"{prefix}.weight_hh_l{l}"], self.w[f"{prefix}.bias_hh_l{l}"])
             i_r, i_z, i_n = gi.chunk(3, -1)
             h_r, h_z, h_n = gh.chunk(3, -1)
-            r = torch.sigmoid(i_r + h_r)
-            z = torch.sigmoid(i_z + h_z)
-            nn_ = torch.tanh(i_n + r * h_n)
+            r = self._m(torch.sigmoid, i_r + h_r)
+            z = self._m(torch.sigmoid, i_z + h_z)
+            nn_ = self._m(torch.tanh, i_n + r * h_n)
             hl = (1 - z) * nn_ + z * h[l]
             h_new.append(hl)
             inp = hl
@@ -521,7 +543,7 @@ class Oracle:
                 dist = torch.distributions.Independent(torch.distributions.Normal(u, ls.exp()), 1)
                 u = u + _t(action_eps, d)[:, :, t - self.cfg["time_step_sim_start"]] * ls.exp()
                 alp = dist.log_prob(u).masked_fill(~valid, 0)
-            act = torch.tanh(u)
+            act = self._m(torch.tanh, u)
             act = torch.stack([act[..., 0] * max_acc, act[..., 1] * max_yr], -1)
             act = act.masked_fill(~(has_type & valid).unsqueeze(-1), 0)
             if action_override is not None:  # dynamics.py:96-100 (after the per-type masking; only for valid agents)
@@ -532,7 +554,7 @@ class Oracle:
             a_, w_ = act[:, :, 0], act[:, :, 1]
             v_t = state[:, :, 3] + 0.5 * self.dt * a_
             th_t = state[:, :, 2] + 0.5 * self.dt * w_
-            delta = torch.stack([v_t * torch.cos(th_t), v_t * torch.sin(th_t), w_, a_], -1)
+            delta = torch.stack([v_t * self._m(torch.cos, th_t), v_t * self._m(torch.sin, th_t), w_, a_], -1)
             new_state = (state + self.dt * delta).masked_fill(~(has_type & valid).unsqueeze(-1), 0)
             pred_state, pred_valid = new_state, valid
             state = new_state

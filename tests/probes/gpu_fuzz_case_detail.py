@@ -100,5 +100,17 @@ for name, env in (("helpers on", {}), ("helpers off", {"TB_STEP_HELPERS": "0"}),
                 msg.append(f"vs {lab}: {len(o)} steps outside, first at step {s0 + 1}, worst at step {worst + 1} ({raw[worst]:.2e} against {bb[worst]:.2e}; "
                            f"{int((cm[:, worst] >= raw[worst]).sum())}/{cm.shape[0]} members at least as far)")
         print(f"{'':15s} against the {first}-member bounds: " + ("inside" if not msg else "; ".join(msg)))
+    if name == "helpers on":  # who deviates, and what happened to them before
+        dev = (np.abs(hp.astype(np.float64) - r32p) * v32[..., None])[..., :2].max(-1)  # [B, A, S]
+        ovr = r["override_masks"].numpy()
+        for b_, a_ in sorted(((b_, a_) for b_ in range(dev.shape[0]) for a_ in range(dev.shape[1])), key=lambda t_: -dev[t_].max())[:4]:
+            d_ = dev[b_, a_]
+            first = int(np.argmax(d_ > 2e-5)) if (d_ > 2e-5).any() else -1
+            vv = v32[b_, a_].astype(int)
+            print(f"{'':15s} scene {b_} agent {a_}: max {d_.max():.2e}, first > 2e-5 at step {first + 1}; valid from step "
+                  f"{int(np.argmax(vv)) + 1 if vv.any() else -1} to {len(vv) - int(np.argmax(vv[::-1]))}, teacher-forced steps "
+                  f"{np.nonzero(ovr[b_, a_])[0][:3] + 1}..{np.nonzero(ovr[b_, a_])[0][-3:] + 1 if ovr[b_, a_].any() else ''}; "
+                  f"|x|,|y| at the end {np.abs(r32p[b_, a_, -1, :2]).round(1)}, speed {abs(float(r32p[b_, a_, -1, 3])):.2f}; "
+                  "dev at steps 40,45,..: " + " ".join(f"{x:.1e}" for x in d_[39::5]))
     print(f"{'':15s} end rank vs fp64 {ensemble.rank_among(mem64, float(d64[-1]))}, vs fp32 {ensemble.rank_among(mem32, float(d32[-1]))}; "
           f"flags equal: {bool((buf.valid[:, :, 0].cpu() == r['valid']).all())}")

@@ -125,9 +125,32 @@ __device__ __forceinline__ void split2(f32x4 v, xh4& h, xh4& l, R&& amax = R{}) 
             __builtin_memcpy(&b2, &w1, 4);
             h = xh4{a2.x, a2.y, b2.x, b2.y};
         }
-#endif
+        // l = fp16((v - h) * 2^11) in two mixed-precision fmas per value and nothing else: t = fma(h, -1, v) with h read as fp16 straight
+        // from its packed half (exact), then fp16(fma(t, 2^11, 0)) written into the low / high half of the result register
+        // (v_fma_mixlo / mixhi_f16: one rounding, as v_cvt_pk_f16_f32 of the exact product had).  Same bits as convert-back, subtract,
+        // scale, convert (v_cvt_f32_f16 + v_sub_f32 + v_mul_f32 per value + a v_cvt_pk per pair); the compiler does not form the mixed
+        // fmas from the C expression, so they are written out.
+        const float sc = SPLIT_SCALE;
+        float t0, t1, t2, t3;
+        unsigned int l0, l1;
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(t0) : "v"(w0), "v"(v.x));
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(t1) : "v"(w0), "v"(v.y));
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(t2) : "v"(w1), "v"(v.z));
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(t3) : "v"(w1), "v"(v.w));
+        asm("v_fma_mixlo_f16 %0, %1, %2, 0 op_sel_hi:[0,0,0]" : "=v"(l0) : "v"(t0), "s"(sc));
+        asm("v_fma_mixhi_f16 %0, %1, %2, 0 op_sel_hi:[0,0,0]" : "+v"(l0) : "v"(t1), "s"(sc));
+        asm("v_fma_mixlo_f16 %0, %1, %2, 0 op_sel_hi:[0,0,0]" : "=v"(l1) : "v"(t2), "s"(sc));
+        asm("v_fma_mixhi_f16 %0, %1, %2, 0 op_sel_hi:[0,0,0]" : "+v"(l1) : "v"(t3), "s"(sc));
+        {
+            xh2 a3, b3;
+            __builtin_memcpy(&a3, &l0, 4);
+            __builtin_memcpy(&b3, &l1, 4);
+            l = xh4{a3.x, a3.y, b3.x, b3.y};
+        }
+#else
         const f32x4 r = (v - f32x4{(float)h.x, (float)h.y, (float)h.z, (float)h.w}) * splat(SPLIT_SCALE);
         l = xh4{(xhalf)r.x, (xhalf)r.y, (xhalf)r.z, (xhalf)r.w};
+#endif
     } else {
         l = h;  // (unused)
     }
@@ -454,8 +477,12 @@ __device__ __forceinline__ void attn_qk_x(const KFragX& f, const xh8& qh, const 
     }
 }
 
-// 2^x for x <= 0; the clamp maps -inf (masked keys) and NaN (-inf - -inf: nothing valid yet) to an exact 0
-__device__ __forceinline__ float exp2_neg(float x) { return __builtin_amdgcn_exp2f(fmaxf(x, -160.f)); }
+// 2^x for x <= 0 (v_exp_f32: -inf and everything below -126 give an exact 0).  The running max of the online softmax starts at
+// RUN_MAX_NONE, a FINITE value below every logit, so that "nothing valid yet" never produces -inf - -inf = NaN: a masked key is
+// -inf - finite = -inf -> 0, and the correction factor of a row whose first valid key arrives is 2^(-3e38 - m) = 0 (times an
+// accumulator that is still 0).  Same bits as the earlier form, which clamped every argument at -160 instead (one v_max_f32 per key).
+constexpr float RUN_MAX_NONE = -3.0e38f;
+__device__ __forceinline__ float exp2_neg(float x) { return __builtin_amdgcn_exp2f(x); }
 
 template <bool SELFMASK>
 __device__ __forceinline__ void attn_stats_x(const f32x4 (&s)[2], const f32x4 (&c)[2], const f32x4 (&kb)[2], int kb0, int self_key,
@@ -469,7 +496,8 @@ __device__ __forceinline__ void attn_stats_x(const f32x4 (&s)[2], const f32x4 (&
         // seven instructions of the compensated exp_neg.  The exponent carries the rounding of the (logit x constant) product,
         // ~2^-24 |x| <= 1e-6 relative in p -- the same order as the rounding of logit x scale in the reference's own softmax;
         // closed-loop parity is unchanged within its noise (headline golden: 1.6e-4 vs fp32, 8.8e-5 vs fp64).
-        const float v = fmaf(raw[r] + crs[r] * SPLIT_INV, ATTN_SCALE * 1.44269504088896340736f, bias[r]);
+        // (crs * 2^-11 is exact, so the explicit fma has the bits of multiply-then-add; -ffp-contract=off would not form it)
+        const float v = fmaf(NPL == 2 ? fmaf(crs[r], SPLIT_INV, raw[r]) : raw[r], ATTN_SCALE * 1.44269504088896340736f, bias[r]);
         sv[r] = (SELFMASK && kb0 + 16 * (r >> 2) + (r & 3) == self_key) ? -INFINITY : v;  // eye mask of MultiAgentTF only
     }
     float tmax = fmaxf(fmaxf(fmaxf(sv[0], sv[1]), fmaxf(sv[2], sv[3])), fmaxf(fmaxf(sv[4], sv[5]), fmaxf(sv[6], sv[7])));
@@ -517,7 +545,7 @@ __device__ __forceinline__ bool attention_head_x(const f32x4 (&q)[2], AttnPreX& 
     f32x4 oh[2] = {splat(0.f), splat(0.f)}, oc[2] = {splat(0.f), splat(0.f)};
     KFragX kn = pre.kn;
     VFragX vc = pre.vc;
-    float run_max = -INFINITY, run_sum = 0.f, new_max, alpha, sv[8];
+    float run_max = RUN_MAX_NONE, run_sum = 0.f, new_max, alpha, sv[8];
     {
         f32x4 s[2], c[2];
         attn_qk_x(pre.k0f, qh, ql, s, c);
