@@ -55,7 +55,7 @@ mem32, mem64 = [], []
 with torch.no_grad():
     for mi in range(n_mem):
         pb, perm = ensemble.permute_batch({k_: np.asarray(v) for k_, v in batch.items()}, 7919 * (only + 1) + mi)
-        rm = Oracle(sd, cfg, torch.float32).reactive_replay(pb, step_end)
+        rm = Oracle(sd, cfg, torch.float32, gemm_order_seed=4001 * (only + 1) + mi).reactive_replay(pb, step_end)
         mp, mv = perm.agents_back(rm["preds"].numpy()), perm.agents_back(rm["valid"].numpy())
         mem32.append(ensemble.spread_per_step(mp, r32p, mv & v32, 2))
         mem64.append(ensemble.spread_per_step(mp, r64p, mv & v64, 2))

@@ -83,7 +83,7 @@ for ci in range(n_cases):
         msgs.append("non-finite preds")
     if e_xy > 1e-4:
         # dense or long cases: judge against the MEASURED rounding noise of the oracle's own arithmetic on this case -- 8 fp32 runs on
-        # re-ordered batches (tools/ensemble.py), one-sided prediction bound at alpha = 5e-4, no multipliers (tests/test_gpu_parity.py
+        # re-ordered batches with re-ordered Linear sums (tools/ensemble.py, Oracle(gemm_order_seed)), one-sided prediction bound at alpha = 5e-4, no multipliers (tests/test_gpu_parity.py
         # _assert_closed_loop / _oracle_ensemble; round 2 used max(1e-4, 1.5 / 2.5 x one fp32-vs-fp64 run))
         from tools import ensemble
 
@@ -92,7 +92,7 @@ for ci in range(n_cases):
             mem32, mem64 = [], []
             for mi in range(8):
                 pb, perm = ensemble.permute_batch({k_: np.asarray(v) for k_, v in batch.items()}, 7919 * (ci + 1) + mi)
-                rm = Oracle(sd, cfg, torch.float32).reactive_replay(pb, step_end)
+                rm = Oracle(sd, cfg, torch.float32, gemm_order_seed=4001 * (ci + 1) + mi).reactive_replay(pb, step_end)
                 mp, mv = perm.agents_back(rm["preds"].numpy()), perm.agents_back(rm["valid"].numpy())
                 mem32.append(ensemble.spread_per_step(mp, r["preds"].numpy(), mv & r["valid"].numpy(), 2))
                 mem64.append(ensemble.spread_per_step(mp, r64["preds"].numpy(), mv & r64["valid"].numpy(), 2))

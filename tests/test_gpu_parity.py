@@ -98,16 +98,17 @@ N_ORACLE_ENSEMBLE = 8
 
 
 def _oracle_ensemble(run, batch, k=1, eps=None, dest=None, act=None, n_members=N_ORACLE_ENSEMBLE, seed=0):
-    """The measured rounding-noise envelope for a case no golden covers: `run(batch, eps, dest, act)` -> {"preds" [N,A,S,4] or
-    [B,A,K,S,4] ..., "valid"} is the fp32 ORACLE; it is re-run on `n_members` permuted batches (tools/ensemble.py) and the outputs
-    un-permuted.  Returns the list of members' (preds, valid) as numpy arrays in the base ordering."""
+    """The measured rounding-noise envelope for a case no golden covers: `run(batch, eps, dest, act, gemm_order_seed)` -> {"preds"
+    [N,A,S,4] or [B,A,K,S,4] ..., "valid"} is the fp32 ORACLE; it is re-run on `n_members` permuted batches (tools/ensemble.py), each
+    with its own summation order inside the Linears too (Oracle(gemm_order_seed=...): the batch permutation alone only re-orders the
+    attention sums), and the outputs un-permuted.  Returns the list of members' (preds, valid) as numpy arrays in the base ordering."""
     from tools import ensemble
 
     members = []
     for i in range(n_members):
         pb, perm = ensemble.permute_batch({k_: np.asarray(v) for k_, v in batch.items()}, 7919 * (seed + 1) + i)
         r = run(pb, None if eps is None else perm.agents_fwd(eps, k), None if dest is None else perm.dest_fwd(dest, k),
-                None if act is None else perm.agents_fwd(act, k))
+                None if act is None else perm.agents_fwd(act, k), 4001 * (seed + 1) + i)
         p, v = r["preds"].numpy(), r["valid"].numpy()
         kk = k if p.shape[0] == perm.n_scene * k else 1  # [N,A,...] per instance or [B,A,K,...] per scene
         members.append((perm.agents_back(p, kk), perm.agents_back(v, kk)))
@@ -723,7 +724,7 @@ def test_validation_step_against_oracle_fresh_seed():
     for k in ("outside_map", "dest_reached", "goal_reached"):
         assert (buf.violations[k][:, :, 0].cpu().numpy() == r[k].numpy()).all(), k
     r64 = Oracle(sd, cfg, dtype=torch.float64).reactive_replay(batch, 90)
-    mem = _oracle_ensemble(lambda pb, e_, d_, a_: Oracle(sd, cfg, dtype=torch.float32).reactive_replay(pb, 90), batch, seed=1)
+    mem = _oracle_ensemble(lambda pb, e_, d_, a_, g_: Oracle(sd, cfg, dtype=torch.float32, gemm_order_seed=g_).reactive_replay(pb, 90), batch, seed=1)
     _assert_closed_loop(buf.preds[:, :, 0].cpu().numpy(), r, r64, "reactive replay", mem)
     gv = r["gt_valid"][:, 1:91].transpose(1, 2)
     gs = r["gt_state"][:, 1:91].transpose(1, 2)
@@ -756,7 +757,7 @@ def test_validation_step_against_oracle_fresh_seed():
     for k in ("outside_map", "dest_reached", "goal_reached"):
         assert (bj.violations[k].cpu().numpy() == rj[k].numpy()).all(), k
     rj64 = Oracle(sd, cfg, dtype=torch.float64).joint_future_pred(batch, 1, None, 90, dest_override=dest, use_gt=True)
-    mem = _oracle_ensemble(lambda pb, e_, d_, a_: Oracle(sd, cfg, dtype=torch.float32).joint_future_pred(pb, 1, None, 90, dest_override=d_, use_gt=True),
+    mem = _oracle_ensemble(lambda pb, e_, d_, a_, g_: Oracle(sd, cfg, dtype=torch.float32, gemm_order_seed=g_).joint_future_pred(pb, 1, None, 90, dest_override=d_, use_gt=True),
                            batch, dest=dest, seed=2)
     _assert_closed_loop(bj.preds.cpu().numpy(), rj, rj64, "validation joint_future_pred", mem)
 
@@ -791,7 +792,7 @@ def test_training_step_forward_against_oracle(rollout_prior, sampled_actions):
                   - eps * float(np.exp(-1.0))).max() <= 1e-6
     r64 = Oracle(sd, cfg, dtype=torch.float64).reactive_replay(batch, 60, tf_cfg_name="teacher_forcing_training", eps=eps,
                                                                 rollout_prior=rollout_prior, action_eps=act)
-    mem = _oracle_ensemble(lambda pb, e_, d_, a_: Oracle(sd, cfg, dtype=torch.float32).reactive_replay(
+    mem = _oracle_ensemble(lambda pb, e_, d_, a_, g_: Oracle(sd, cfg, dtype=torch.float32, gemm_order_seed=g_).reactive_replay(
         pb, 60, tf_cfg_name="teacher_forcing_training", eps=e_, rollout_prior=rollout_prior, action_eps=a_), batch, eps=eps, act=act, seed=3)
     _assert_closed_loop(buf.preds.cpu().numpy(), r, r64, f"training replay prior={rollout_prior} sampled={sampled_actions}", mem)
     assert np.abs(buf.action_log_probs.cpu().numpy() - r["action_log_probs"].numpy()).max() <= (2e-4 if sampled_actions else 1e-6)
