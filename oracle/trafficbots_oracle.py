@@ -55,6 +55,7 @@ class Oracle:
         self.hoist = hoist
         self.exact_math = exact_math and dtype != torch.float64
         self._kperm: Dict[int, Tensor] = {}
+        self._wperm: Dict[tuple, Tensor] = {}
         self._kgen = None if gemm_order_seed is None else torch.Generator().manual_seed(int(gemm_order_seed))
         dyn = cfg["dynamics"]
         # type order veh=0, ped=1, cyc=2 (`dynamics.py:23-27`: instantiate(veh), (ped), (cyc))
@@ -77,7 +78,10 @@ class Oracle:
             if k not in self._kperm:
                 self._kperm[k] = torch.randperm(k, generator=self._kgen)
             pm = self._kperm[k]
-            return F.linear(x[..., pm], w[:, pm], b)
+            key = (w.data_ptr(), w.shape[0], k)  # (weights are never modified: the permuted copy is made once per matrix)
+            if key not in self._wperm:
+                self._wperm[key] = w[:, pm].contiguous()
+            return F.linear(x[..., pm], self._wperm[key], b)
         return F.linear(x, w, b)
 
     def _ln(self, x: Tensor, prefix: str) -> Tensor:

@@ -2,7 +2,7 @@ import sys, numpy as np, torch
 sys.path.insert(0, '/root/repo')
 from trafficbots_amd import synth
 from trafficbots_amd.waymo_motion import WaymoMotion
-rng = np.random.default_rng(7)
+rng = np.random.default_rng(int(os.environ.get("FUZZ_SEED", "7")))
 for ci in range(16):
     a, p, t = int(rng.choice([1, 2, 15, 16, 17, 33, 64, 65])), int(rng.choice([1, 2, 31, 32, 33, 96, 130])), int(rng.choice([1, 2, 31, 33, 40]))
     k, b, se = int(rng.integers(1, 4)), int(rng.integers(1, 4)), 40
