@@ -14,6 +14,12 @@ GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # The CPU oracles work on matrices of a few dozen rows: with torch's default of one thread per core (128 on the GPU box's
+    # 256-core host) a 90-step oracle replay takes 7.5 s, with 8 threads 0.6 s (tests/probes/oracle_thread_timing.py).  Only the
+    # oracles run on the CPU here (bench.py's cpu_baseline sets its own thread count in its own process).
+    import torch
+
+    torch.set_num_threads(min(8, torch.get_num_threads()))
 
 
 def require_h5():

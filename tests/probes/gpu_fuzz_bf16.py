@@ -1,7 +1,8 @@
-import sys, numpy as np, torch
+import os, sys, numpy as np, torch
 sys.path.insert(0, '/root/repo')
 from trafficbots_amd import synth
 from trafficbots_amd.waymo_motion import WaymoMotion
+torch.set_num_threads(min(8, torch.get_num_threads()))  # (the CPU oracles: small matrices, see tests/probes/oracle_thread_timing.py)
 rng = np.random.default_rng(int(os.environ.get("FUZZ_SEED", "7")))
 for ci in range(16):
     a, p, t = int(rng.choice([1, 2, 15, 16, 17, 33, 64, 65])), int(rng.choice([1, 2, 31, 32, 33, 96, 130])), int(rng.choice([1, 2, 31, 33, 40]))

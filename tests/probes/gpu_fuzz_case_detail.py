@@ -15,6 +15,7 @@ from trafficbots_amd import synth  # noqa: E402
 from trafficbots_amd.config import load_model_config  # noqa: E402
 from trafficbots_amd.waymo_motion import WaymoMotion  # noqa: E402
 
+torch.set_num_threads(min(8, torch.get_num_threads()))  # (the CPU oracles: small matrices, see tests/probes/oracle_thread_timing.py)
 only = int(os.environ["FUZZ_ONLY"])
 rng = np.random.default_rng(int(os.environ.get("FUZZ_SEED", "777")))
 EDGE_A = [1, 2, 15, 16, 17, 31, 33, 48, 65]

@@ -18,6 +18,7 @@ from trafficbots_amd.config import load_model_config  # noqa: E402
 from trafficbots_amd.post_processing import WaymoPostProcessing  # noqa: E402
 from trafficbots_amd.runtime import METRIC_FIELDS, RULE_KEYS, HipEngine, scene_from_batch  # noqa: E402
 
+torch.set_num_threads(min(8, torch.get_num_threads()))  # (the CPU oracles: small matrices, see tests/probes/oracle_thread_timing.py)
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 12
 rng = np.random.default_rng(int(os.environ.get("FUZZ_SEED", "4242")))
 eng = HipEngine(load_model_config())
