@@ -67,8 +67,8 @@ print(scene, over)
 print(f"steps 10, 20, ... ; {n_mem} members")
 print(f"{'ref32 vs 64':28s} " + fmt(base64))
 for first in (8, n_mem):
-    b64 = ensemble.prediction_bound(mem64[: first + 1])
-    b32 = np.maximum(ensemble.prediction_bound(mem32[:first]), b64 + np.maximum.accumulate(base64))
+    q64, q32, cb = ensemble.prediction_bound(mem64[: first + 1]), ensemble.prediction_bound(mem32[:first]), np.maximum.accumulate(base64)
+    b64, b32 = np.maximum(q64, cb + q32), np.maximum(q32, cb + q64)  # (the two triangles of tests/test_gpu_parity.py)
     print(f"{'bound vs 64, ' + str(first) + ' members':28s} " + fmt(b64))
     print(f"{'bound vs 32, ' + str(first) + ' members':28s} " + fmt(b32))
 print(f"{'members vs 64: median':28s} " + fmt(np.median(cm64, 0)))
@@ -88,8 +88,8 @@ for name, env in (("helpers on", {}), ("helpers off", {"TB_STEP_HELPERS": "0"}),
     print(f"{name:15s} {'hip vs 64':12s} " + fmt(d64) + f"   max {d64.max():.2e}")
     print(f"{'':15s} {'hip vs 32':12s} " + fmt(d32) + f"   max {d32.max():.2e}")
     for first in (8, n_mem):
-        b64 = np.maximum(1e-4, ensemble.prediction_bound(mem64[: first + 1]))
-        b32 = np.maximum(1e-4, np.maximum(ensemble.prediction_bound(mem32[:first]), b64 + np.maximum.accumulate(base64)))
+        q64, q32, cb = ensemble.prediction_bound(mem64[: first + 1]), ensemble.prediction_bound(mem32[:first]), np.maximum.accumulate(base64)
+        b64, b32 = np.maximum(1e-4, np.maximum(q64, cb + q32)), np.maximum(1e-4, np.maximum(q32, cb + q64))
         raw64 = ensemble.spread_per_step(hp, r64p, v64, 2)
         raw32 = ensemble.spread_per_step(hp, r32p, v32, 2)
         out64, out32 = np.nonzero(raw64 > b64)[0], np.nonzero(raw32 > b32)[0]

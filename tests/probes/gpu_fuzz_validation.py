@@ -102,8 +102,8 @@ for ci in range(n_cases):
         d32 = ensemble.spread_per_step(hp, r["preds"].numpy(), v32, 2)
         d64 = ensemble.spread_per_step(hp, r64["preds"].numpy(), v64, 2)
         base64 = ensemble.spread_per_step(r["preds"].numpy(), r64["preds"].numpy(), v64, 2)
-        b64 = ensemble.prediction_bound(np.stack([base64] + mem64))
-        b32 = np.maximum(ensemble.prediction_bound(np.stack(mem32)), b64 + np.maximum.accumulate(base64))  # (triangle through the truth)
+        p64, p32, cb = ensemble.prediction_bound(np.stack([base64] + mem64)), ensemble.prediction_bound(np.stack(mem32)), np.maximum.accumulate(base64)
+        b64, b32 = np.maximum(p64, cb + p32), np.maximum(p32, cb + p64)  # (the two triangles of tests/test_gpu_parity.py)
         ok = bool((d64 <= np.maximum(1e-4, b64)).all() and (d32 <= np.maximum(1e-4, b32)).all())
         print(f"        ensemble: oracle fp32 vs fp64 {base64.max():.1e} (members up to {np.stack(mem64).max():.1e}); hip vs fp64 {d64.max():.1e} "
               f"(bound {b64.max():.1e}), hip vs fp32 {d32.max():.1e} (bound {b32.max():.1e}, members up to {np.stack(mem32).max():.1e}) -> "
