@@ -330,6 +330,35 @@ def test_rollout_graph_replay_is_bitwise_identical(monkeypatch):
         assert torch.equal(res[("1", prec)], res[("0", prec)])
 
 
+def test_encode_side_stream_is_bitwise_identical(monkeypatch):
+    """tb_encode_scene runs the agent / traffic-light token encoders and the destination predictor's GRU scan on a side stream beside
+    the map encoder (forked from / joined into the caller's stream with events); TB_ENCODE_SIDE=0 keeps everything on the caller's
+    stream.  Same kernels, same arguments: every product of the encoder is bit-identical, call after call (the side stream is
+    joined before the personality branch, so a second call cannot overtake the first one's workspace)."""
+    import bench
+    from trafficbots_amd import synth
+    from trafficbots_amd.config import load_model_config
+
+    sd = synth.make_state_dict(7)
+    cfg = load_model_config(overrides={"time_step_end": 30, "n_joint_future": 1})
+    got = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("TB_ENCODE_SIDE", mode)
+        c = bench.setup_case(cfg, sd, torch.device("cuda", 0), 0, 5, 48, 80, 1, seed=9900)
+        eng, scene = c["eng"], c["scene"]
+        encs = [eng.encode_scene(scene) for _ in range(3)]
+        torch.cuda.synchronize()
+        eng.check_status()
+        for e in encs[1:]:
+            for k_, v in encs[0].items():
+                if torch.is_tensor(v):
+                    assert torch.equal(v, e[k_]), (mode, k_)
+        got[mode] = {k_: v.clone() for k_, v in encs[0].items() if torch.is_tensor(v)}
+    assert set(got["1"]) == set(got["0"]) and len(got["1"]) >= 5
+    for k_, v in got["1"].items():
+        assert torch.equal(v, got["0"][k_]), k_
+
+
 def test_bench_sub_records_and_traj_err():
     """the default single-GPU command carries the configs[3] / configs[4] sub-records and the golden trajectory error"""
     ln = _run_bench(["--gpus", "1", "--config-steps", "2", "--configs", "k6_bf16", "stress_bf16"])

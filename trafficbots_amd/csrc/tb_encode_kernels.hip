@@ -613,6 +613,31 @@ int run_encode(struct ::tb_ctx* ctx, const tb_encode_io* io, hipStream_t s) {
     Carver c{ctx->d_ws};
     carve(c);
 
+    // ---- what does not need the map runs beside the map encoder: agent / traffic-light tokens and the destination predictor's GRU
+    // scan (128 workgroups) go to a side stream that forks from `s` here and joins it in front of the personality branch
+    hipStream_t s2 = s;
+    {
+        const char* e = getenv("TB_ENCODE_SIDE");
+        if (!(e && e[0] == '0')) {
+            if (!ctx->enc_stream) {
+                TB_HIP(ctx, hipStreamCreateWithFlags(&ctx->enc_stream, hipStreamNonBlocking));
+                TB_HIP(ctx, hipEventCreateWithFlags(&ctx->enc_fork, hipEventDisableTiming));
+                TB_HIP(ctx, hipEventCreateWithFlags(&ctx->enc_join, hipEventDisableTiming));
+            }
+            s2 = ctx->enc_stream;
+            TB_HIP(ctx, hipEventRecord(ctx->enc_fork, s));
+            TB_HIP(ctx, hipStreamWaitEvent(s2, ctx->enc_fork, 0));
+        }
+    }
+    auto dest_scan = [&](hipStream_t st) {
+        ScanP sp{};
+        sp.W = W;
+        for (int l = 0; l < 3; ++l) sp.gru[l] = ew.gru_dest[l];
+        sp.mode = 1; sp.B = B; sp.S = NH; sp.A = A; sp.x = io->agent_feature; sp.valid = io->agent_valid; sp.out_feat = tgt; sp.out_valid = tgtv;
+        for (int l = 0; l < 3; ++l) sp.grux[l] = ew.gru_dest_x[l];
+        if (ctx->encode_kernel == 1) xh::launch_gru_scan_x(sp, a_pad, st);
+        else hipLaunchKernelGGL(k_gru_scan, dim3(a_pad / TM, B), dim3(NTHREADS), (8 * TM * LDT + 16) * sizeof(float), st, sp);
+    };
     // ---- input features (sc_input.py:100-140 + input_pe_encoder.py:52-59)
     {
         TokP t{};
@@ -622,13 +647,17 @@ int run_encode(struct ::tb_ctx* ctx, const tb_encode_io* io, hipStream_t s) {
         t.acc = io->agent_acc; t.yaw_rate = io->agent_yaw_rate; t.cls = io->agent_type; t.size = io->agent_size;
         t.out = io->agent_feature;
         t.ext_attr = io->ext_agent_attr; t.ext_pe = io->ext_agent_pe;
-        hipLaunchKernelGGL(k_encode_tokens, dim3((t.n_tok + TM * TOK_GROUPS - 1) / (TM * TOK_GROUPS)), dim3(NTHREADS), 0, s, t);
+        hipLaunchKernelGGL(k_encode_tokens, dim3((t.n_tok + TM * TOK_GROUPS - 1) / (TM * TOK_GROUPS)), dim3(NTHREADS), 0, s2, t);
         TokP l{};
         l.W = W; l.pe_fxy = ew.pe_fxy; l.pe_fyaw = ew.pe_fyaw;
         l.kind = 1; l.mlp = ew.tl_enc; l.n_tok = B * NH * T; l.per_scene = NH * T; l.inner = T;
         l.valid = io->tl_valid; l.pos = io->tl_pos; l.dir = io->tl_dir; l.cls = io->tl_state; l.out = io->tl_feature;
         l.ext_attr = io->ext_tl_attr; l.ext_pe = io->ext_tl_pe;
-        hipLaunchKernelGGL(k_encode_tokens, dim3((l.n_tok + TM * TOK_GROUPS - 1) / (TM * TOK_GROUPS)), dim3(NTHREADS), 0, s, l);
+        hipLaunchKernelGGL(k_encode_tokens, dim3((l.n_tok + TM * TOK_GROUPS - 1) / (TM * TOK_GROUPS)), dim3(NTHREADS), 0, s2, l);
+        if (s2 != s) {
+            dest_scan(s2);
+            TB_HIP(ctx, hipEventRecord(ctx->enc_join, s2));
+        }
         TokP m{};
         m.W = W; m.pe_fxy = ew.pe_fxy; m.pe_fyaw = ew.pe_fyaw;
         m.kind = 2; m.mlp = ew.map_enc; m.n_tok = B * P * 20; m.per_scene = P * 20; m.inner = 20;
@@ -652,17 +681,12 @@ int run_encode(struct ::tb_ctx* ctx, const tb_encode_io* io, hipStream_t s) {
                   io->map_feature_valid, io->map_feature, P, 0, s);
     }
     // ---- personality prior
+    if (s2 != s) TB_HIP(ctx, hipStreamWaitEvent(s, ctx->enc_join, 0));
     launch_latent_branch(ctx->encode_kernel == 1, W, ew, 0, B, NH, A, P, T, io->agent_feature, io->agent_valid, io->tl_feature, io->tl_valid, io->map_feature,
                          io->map_feature_valid, lws, io->latent_mean, io->latent_valid, s);
     // ---- destination predictor
     {
-        ScanP sp{};
-        sp.W = W;
-        for (int l = 0; l < 3; ++l) sp.gru[l] = ew.gru_dest[l];
-        sp.mode = 1; sp.B = B; sp.S = NH; sp.A = A; sp.x = io->agent_feature; sp.valid = io->agent_valid; sp.out_feat = tgt; sp.out_valid = tgtv;
-        for (int l = 0; l < 3; ++l) sp.grux[l] = ew.gru_dest_x[l];
-        if (ctx->encode_kernel == 1) xh::launch_gru_scan_x(sp, a_pad, s);
-        else hipLaunchKernelGGL(k_gru_scan, dim3(a_pad / TM, B), dim3(NTHREADS), (8 * TM * LDT + 16) * sizeof(float), s, sp);
+        if (s2 == s) dest_scan(s);
         hipLaunchKernelGGL(k_linear_rows, dim3((B * P + TM - 1) / TM), dim3(NTHREADS), 0, s, W, ew.dest_w0_map, ew.dest_b0, 1,
                            io->map_feature, B * P, U);
         hipLaunchKernelGGL(k_linear_rows, dim3((B * A + TM - 1) / TM), dim3(NTHREADS), 0, s, W, ew.dest_w0_agent, 0u, 0, tgt, B * A, V);
