@@ -395,7 +395,6 @@ void tb_destroy(tb_ctx* ctx) {
     if (ctx && ctx->graph_exec) (void)hipGraphExecDestroy(ctx->graph_exec);
     if (ctx && ctx->cap_stream) (void)hipStreamDestroy(ctx->cap_stream);
     if (!ctx) return;
-    if (ctx->enc_stream) (void)hipStreamDestroy(ctx->enc_stream);
     if (ctx->enc_fork) (void)hipEventDestroy(ctx->enc_fork);
     if (ctx->enc_join) (void)hipEventDestroy(ctx->enc_join);
     if (ctx->d_arena) (void)hipFree(ctx->d_arena);

@@ -619,12 +619,15 @@ int run_encode(struct ::tb_ctx* ctx, const tb_encode_io* io, hipStream_t s) {
     {
         const char* e = getenv("TB_ENCODE_SIDE");
         if (!(e && e[0] == '0')) {
-            if (!ctx->enc_stream) {
-                TB_HIP(ctx, hipStreamCreateWithFlags(&ctx->enc_stream, hipStreamNonBlocking));
+            // (the context's ONE private stream, shared with the rollout's graph capture: a further stream per context shifted the
+            // runtime's stream -> hardware-queue assignment so that two rollouts on two caller streams no longer overlapped --
+            // bench.py's two_batches_in_flight fell from 597 k to 369 k scene-steps/s)
+            if (!ctx->cap_stream) TB_HIP(ctx, hipStreamCreateWithFlags(&ctx->cap_stream, hipStreamNonBlocking));
+            if (!ctx->enc_fork) {
                 TB_HIP(ctx, hipEventCreateWithFlags(&ctx->enc_fork, hipEventDisableTiming));
                 TB_HIP(ctx, hipEventCreateWithFlags(&ctx->enc_join, hipEventDisableTiming));
             }
-            s2 = ctx->enc_stream;
+            s2 = ctx->cap_stream;
             TB_HIP(ctx, hipEventRecord(ctx->enc_fork, s));
             TB_HIP(ctx, hipStreamWaitEvent(s2, ctx->enc_fork, 0));
         }

@@ -53,14 +53,13 @@ struct tb_ctx {
     float* d_fw = nullptr;
     size_t fw_floats = 0;
     hipGraphExec_t graph_exec = nullptr;
-    hipStream_t cap_stream = nullptr;  // private stream the launch sequence is captured on (the caller's may be the legacy default stream, which cannot capture)
+    hipStream_t cap_stream = nullptr;  // the context's private stream: the launch sequence is captured on it (the caller's may be the legacy default stream, which cannot capture), and tb_encode_scene forks its side work to it
     unsigned long long graph_key = 0, graph_seen = 0;  // key of the captured graph / of the previous call (capture on the second sight)
     int graph_hits = 0, graph_captures = 0;
     // tb_encode_scene: the agent / traffic-light token encoders and the destination predictor's GRU scan (128 workgroups: half the
     // chip, and independent of the map) run on a side stream beside the map encoder's chip-filling launches; forked from and joined
     // back into the caller's stream with events (TB_ENCODE_SIDE=0: everything on the caller's stream).  2.60 -> 2.40 ms per 32 scenes.
     // (A second fork -- the destination logits beside the personality branch -- gained nothing: 2.42 .. 2.51 ms.)
-    hipStream_t enc_stream = nullptr;
     hipEvent_t enc_fork = nullptr, enc_join = nullptr;
 };
 
