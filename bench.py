@@ -604,7 +604,7 @@ def run_rank(args, rank: int, local_rank: int, world: int) -> None:
                 "encode_ms": encode_ms, "achieved": flops_encode(N_AGENT, N_PL) * B_PER_GPU / (encode_ms * 1e-3) / 1e12,
                 "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                 "frac": flops_encode(N_AGENT, N_PL) * B_PER_GPU / (encode_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
-                "dominant_kernel": (pmc or {}).get("encode_dominant_kernel", "tb::xh::k_xattn_block_x2 (map densetnt block over B*P polylines x 20 nodes)"),
+                "dominant_kernel": (pmc or {}).get("encode_dominant_kernel", "tb::xh::k_xattn_block_plh (map densetnt block, head tiles of the B*P polylines)"),
                 "note": "SURVEY 8(d): F_map + F_dest + F_latent_prior per scene x 32 scenes / host-timed tb_encode_scene (all its launches, "
                         "one synchronize); one-time per batch, not part of `value`"},
             "max_abs_traj_err": None,

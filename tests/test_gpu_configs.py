@@ -359,6 +359,37 @@ def test_encode_side_stream_is_bitwise_identical(monkeypatch):
         assert torch.equal(v, got["0"][k_]), k_
 
 
+def test_packed_polyline_tiling_is_bitwise_identical(monkeypatch):
+    """The map encoder's polyline block on the packed tiling (per four polylines four 16-row head tiles + ONE tile with the four
+    tail nodes 16 .. 19 of each, instead of eight tiles of which four carry twelve padding rows: tb_encodex_kernels.hip
+    `launch_polyline_block_x`) against the padded tiling (TB_ENCODE_PACK=0): every row goes through the same arithmetic, so every
+    product of the encoder is bit-identical -- with invalid nodes, wholly invalid polylines and a polyline count that the packed path
+    does not take (G % 4 != 0: falls back) and a single scene of 8 polylines."""
+    from trafficbots_amd import synth
+    from trafficbots_amd.config import load_model_config
+    from trafficbots_amd.runtime import HipEngine, scene_from_batch
+
+    sd = synth.make_state_dict(7)
+    cfg = load_model_config(overrides={"time_step_end": 30, "n_joint_future": 1})
+    eng = HipEngine(cfg)
+    eng.load_state_dict(sd)
+    for n_scene, n_pl, seed, masks in ((8, 256, 9910, dict(p_invalid_pl=0.3, p_invalid_node=0.4)), (4, 256, 9913, {}),
+                                       (5, 260, 9911, dict(p_invalid_pl=0.3, p_invalid_node=0.4)), (3, 65, 9912, dict(p_invalid_node=0.5)), (1, 8, 9914, dict(p_invalid_node=0.5))):
+        batch = synth.make_batch(seed, n_scene, n_agent=48, n_pl=n_pl, n_tl=20, **masks)
+        scene = scene_from_batch(batch, torch.device("cuda", 0))
+        got = {}
+        for mode in ("1", "0"):
+            monkeypatch.setenv("TB_ENCODE_PACK", mode)
+            enc = eng.encode_scene(scene)
+            torch.cuda.synchronize()
+            eng.check_status()
+            got[mode] = {k_: v.clone() for k_, v in enc.items() if torch.is_tensor(v)}
+        assert torch.isfinite(got["1"]["map_feature"]).all()
+        if masks.get("p_invalid_pl"):
+            assert not bool(got["1"]["map_feature_valid"].all()) and bool(got["1"]["map_feature_valid"].any())
+        for k_, v in got["1"].items():
+            assert torch.equal(v, got["0"][k_]), (n_pl, k_)
+
 def test_bench_sub_records_and_traj_err():
     """the default single-GPU command carries the configs[3] / configs[4] sub-records and the golden trajectory error"""
     ln = _run_bench(["--gpus", "1", "--config-steps", "2", "--configs", "k6_bf16", "stress_bf16"])

@@ -858,7 +858,12 @@ __device__ __forceinline__ void xattn_layer_x2(const float* __restrict__ W, cons
                                                xhalf* P1a, xhalf* P1b, xhalf* P2a, xhalf* P2b, const xhalf* __restrict__ Kmat,
                                                const xhalf* __restrict__ VT, const float* __restrict__ keybias, int n_key_pad,
                                                int self_key0a, int self_key0b, const uint8_t* rowvalid0, const uint8_t* rowvalid1,
-                                               uint8_t* novalid_s0, uint8_t* novalid_s1, int tid, WUnitX& u, const WNextX& nxt) {
+                                               uint8_t* novalid_s0, uint8_t* novalid_s1, int tid, WUnitX& u, const WNextX& nxt,
+                                               const xhalf* __restrict__ Kmat1 = nullptr, const xhalf* __restrict__ VT1 = nullptr,
+                                               const float* __restrict__ keybias1 = nullptr) {
+    // (Kmat1 / VT1 / keybias1: the second tile's own key group -- the head tiles of two polylines share a workgroup, see
+    // k_xattn_block_plh; nullptr = both tiles belong to one group and walk the same keys)
+    if (!Kmat1) { Kmat1 = Kmat; VT1 = VT; keybias1 = keybias; }
     const float* lnblk = W + L.ln1_g;
     const int wave = wave_of(tid), lane = tid & 63;
     const int kq = lane >> 4, m = lane & 15;
@@ -875,8 +880,8 @@ __device__ __forceinline__ void xattn_layer_x2(const float* __restrict__ W, cons
     f32x4 o0[2], o1[2];
     const bool nov0 = attention_head_x<SELFMASK, false>(q0, apre, Kmat, VT, keybias, n_key_pad, 0, wave, lane, self_key0a >= 0 ? self_key0a + m : -1,
                                                         o0, u2, wstdx(W, LX.wo, W + L.bo, wave));
-    attention_prefetch_x(apre, Kmat, VT, keybias, n_key_pad, 0, wave, lane);
-    const bool nov1 = attention_head_x<SELFMASK, false>(q1, apre, Kmat, VT, keybias, n_key_pad, 0, wave, lane, self_key0b >= 0 ? self_key0b + m : -1,
+    attention_prefetch_x(apre, Kmat1, VT1, keybias1, n_key_pad, 0, wave, lane);
+    const bool nov1 = attention_head_x<SELFMASK, false>(q1, apre, Kmat1, VT1, keybias1, n_key_pad, 0, wave, lane, self_key0b >= 0 ? self_key0b + m : -1,
                                                         o1, u2, wstdx(W, LX.wo, W + L.bo, wave));
     planes_store_c(P2a, 2 * wave, lane, o0[0]);
     planes_store_c(P2a, 2 * wave + 1, lane, o0[1]);
@@ -935,7 +940,8 @@ __device__ __forceinline__ void xattn_layer_x2(const float* __restrict__ W, cons
 // K/V projection of TWO 16-token tiles of a group for one layer with each unit loaded once
 __device__ __forceinline__ void kv_project_tile_x2(const float* __restrict__ W, const XLayerW& L, const XLayerX& LX, const float* T0,
                                                    const float* T1, xhalf* P1a, xhalf* P1b, xhalf* __restrict__ Kmat, xhalf* __restrict__ VT,
-                                                   int tok0, int n_real0, int n_real1, int tid, WUnitX& u, const WNextX& nxt) {
+                                                   int tok0, int n_real0, int n_real1, int tid, WUnitX& u, const WNextX& nxt,
+                                                   xhalf* __restrict__ Kmat1 = nullptr, xhalf* __restrict__ VT1 = nullptr) {
     const int wave = wave_of(tid), lane = tid & 63;
     const int kq = lane >> 4, m = lane & 15;
     const float* lnblk = W + L.ln1_g;
@@ -951,7 +957,111 @@ __device__ __forceinline__ void kv_project_tile_x2(const float* __restrict__ W, 
     wmmax_pf(v0[0], v0[1], u2, P1a + po, PLANE, u, nxt, lane);
     wmmax(v1[0], v1[1], u2, P1b + po, PLANE);
     kv_store_x(Kmat, VT, tok0, wave, lane, k0, v0, m < n_real0);
-    kv_store_x(Kmat, VT, tok0 + TM, wave, lane, k1, v1, m < n_real1);
+    if (Kmat1) kv_store_x(Kmat1, VT1, tok0, wave, lane, k1, v1, m < n_real1);  // (the second tile is another group's: same token range)
+    else kv_store_x(Kmat, VT, tok0 + TM, wave, lane, k1, v1, m < n_real1);
+    __syncthreads();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Packed polyline tails (map encoder, 20 nodes per polyline = one 16-row head tile + 4 tail rows): the tail rows of FOUR consecutive
+// polylines share one 16-row tile -- row m belongs to group m >> 2 and is its node 16 + (m & 3) -- instead of four tiles with twelve
+// padding rows each.  Every row-wise stage (LayerNorm, the Linears) is unchanged; what differs is where a row's keys are:
+//   * K / V projection: each lane stores its token into ITS group's key block (slot 16 + (m & 3)) and zero-fills the slots 20 .. 31 of
+//     that block (masked keys must hold finite data);
+//   * attention: one 32-key walk per group, every row keeps the result of its own group's walk.
+// Same arithmetic per row as the padded tiling -> bitwise identical outputs (tests/test_gpu_configs.py).
+// `gstride`: fp16 elements between the key blocks of consecutive groups (same layer).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void kv_project_tile_xt(const float* __restrict__ W, const XLayerW& L, const XLayerX& LX, const float* T,
+                                                   xhalf* P1, xhalf* __restrict__ Kmat, xhalf* __restrict__ VT, size_t gstride, int tid,
+                                                   WUnitX& u, const WNextX& nxt) {
+    const int wave = wave_of(tid), lane = tid & 63;
+    const int kq = lane >> 4, m = lane & 15;
+    const float* lnblk = W + L.ln1_g;
+    layernorm_planes<false>(T, LDT, P1, lnblk + 256, lnblk + 384, tid);
+    __syncthreads();
+    const xhalf* b1 = P1 + m * LDP + kq * 8;
+    WUnitX u2;
+    f32x4 ak[2] = {u.b[0], u.b[1]};
+    wmmax_pf(ak[0], ak[1], u, b1, PLANE, u2, wnextx(W, LX.wkv, W + L.bkv, 8 + 2 * wave, 8 + 2 * wave + 1), lane);
+    f32x4 av[2] = {u2.b[0], u2.b[1]};
+    wmmax_pf(av[0], av[1], u2, b1, PLANE, u, nxt, lane);
+    xhalf* kg = Kmat + (size_t)(m >> 2) * gstride;
+    xhalf* vg = VT + (size_t)(m >> 2) * gstride;
+    kv_store_key_x(kg, vg, 16 + (m & 3), wave, lane, ak, av, true);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) kv_store_key_x(kg, vg, 20 + 4 * c + (m & 3), wave, lane, ak, av, false);
+    __syncthreads();
+}
+
+__device__ __forceinline__ void xattn_layer_xt(const float* __restrict__ W, const XLayerW& L, const XLayerX& LX, float* X, xhalf* P1,
+                                               xhalf* P2, const xhalf* __restrict__ Kmat, const xhalf* __restrict__ VT,
+                                               const float* __restrict__ keybias, size_t gstride, const uint8_t* rowvalid,
+                                               uint8_t* novalid_s, int tid, WUnitX& u, const WNextX& nxt) {
+    const float* lnblk = W + L.ln1_g;
+    const int wave = wave_of(tid), lane = tid & 63;
+    const int kq = lane >> 4, m = lane & 15;
+    const xhalf* b1 = P1 + m * LDP + kq * 8;
+    const xhalf* b2 = P2 + m * LDP + kq * 8;
+    AttnPreX apre;
+    WUnitX u2;
+    layernorm_planes<false>(X, LDT, P1, lnblk, lnblk + 128, tid);
+    attention_prefetch_x(apre, Kmat, VT, keybias, KEYPAD, 0, wave, lane);
+    __syncthreads();
+    f32x4 q[2] = {u.b[0], u.b[1]};
+    wmmax_pf(q[0], q[1], u, b1, PLANE, u2, wstdx(W, LX.wo, W + L.bo, wave), lane);
+    f32x4 osel[2] = {splat(0.f), splat(0.f)};
+    bool novsel = true;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const xhalf* kj = Kmat + (size_t)j * gstride;
+        const xhalf* vj = VT + (size_t)j * gstride;
+        const float* bj = keybias + j * KEYPAD;
+        if (j > 0) attention_prefetch_x(apre, kj, vj, bj, KEYPAD, 0, wave, lane);
+        f32x4 o[2];
+        const bool nov = attention_head_x<false, false>(q, apre, kj, vj, bj, KEYPAD, 0, wave, lane, -1, o, u2, wstdx(W, LX.wo, W + L.bo, wave));
+        if ((m >> 2) == j) {
+            osel[0] = o[0];
+            osel[1] = o[1];
+            novsel = nov;
+        }
+    }
+    planes_store_c<false>(P2, 2 * wave, lane, osel[0]);
+    planes_store_c<false>(P2, 2 * wave + 1, lane, osel[1]);
+    if (wave == 0 && kq == 0) novalid_s[m] = novsel ? 1 : 0;
+    __syncthreads();
+    {
+        f32x4 acc[2] = {u2.b[0], u2.b[1]};
+        wmmax_pf(acc[0], acc[1], u2, b2, PLANE, u, wstdx(W, LX.w1, W + L.b1, wave), lane);
+        const bool nv = novalid_s[m] != 0;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            float* px = cptr(X, LDT, 2 * wave + t, lane);
+            const f32x4 xo = lds4(px);
+            st4(px, nv ? xo : xo + acc[t]);
+        }
+    }
+    __syncthreads();
+    layernorm_planes<false>(X, LDT, P1, lnblk + 512, lnblk + 640, tid);
+    __syncthreads();
+    {
+        f32x4 acc[2] = {u.b[0], u.b[1]};
+        wmmax_pf(acc[0], acc[1], u, b1, PLANE, u2, wstdx(W, LX.w2, W + L.b2, wave), lane);
+        planes_store_c(P2, 2 * wave, lane, relu4(acc[0]));
+        planes_store_c(P2, 2 * wave + 1, lane, relu4(acc[1]));
+    }
+    __syncthreads();
+    {
+        f32x4 acc[2] = {u2.b[0], u2.b[1]};
+        wmmax_pf(acc[0], acc[1], u2, b2, PLANE, u, nxt, lane);
+        const bool rv = rowvalid[m] != 0;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            float* px = cptr(X, LDT, 2 * wave + t, lane);
+            const f32x4 xo = lds4(px);
+            st4(px, rv ? xo + acc[t] : splat(0.f));
+        }
+    }
     __syncthreads();
 }
 

@@ -80,6 +80,7 @@ void launch_range_flag_take_encode(unsigned int* out, hipStream_t s);
 void launch_kv_hoist_nx(const float* W, const XLayerW* L, const XLayerX* X, int n_layer, const float* feat, const uint8_t* fvalid, int G,
                         int n_tok, int n_pad, float* K, float* VT, float* kbias, hipStream_t s);
 void launch_xblock_x(const XBlockPX& p, int G, hipStream_t s);
+void launch_polyline_block_x(const XBlockPX& p, int G, float* K, float* VT, float* kbias, hipStream_t s);
 }  // namespace xh
 
 }  // namespace tb

@@ -481,11 +481,18 @@ static void run_block(bool xdl, const float* W, const XLayerW* L, const XLayerX*
                       int G, int n_tgt, int n_pad, float* K, float* VT, float* kbias, const float* src, const uint8_t* src_valid, float* dst,
                       int n_rows, int eye, hipStream_t s) {
     if (xdl) {
-        xh::launch_kv_hoist_nx(W, L, LX, n_layer, tgt, tgt_valid, G, n_tgt, n_pad, K, VT, kbias, s);
         XBlockPX x{};
         x.W = W; x.n_layer = n_layer;
         for (int l = 0; l < n_layer; ++l) { x.L[l] = L[l]; x.LX[l] = LX[l]; }
         x.src = src; x.src_valid = src_valid; x.dst = dst; x.K = K; x.VT = VT; x.kbias = kbias; x.n_rows = n_rows; x.n_pad = n_pad; x.eye = eye;
+        // the map encoder's polyline block (20 nodes, self-attention inside the polyline) runs on the packed tiling: no padding rows
+        const char* pe = getenv("TB_ENCODE_PACK");  // (read per call: the tests flip it inside one process)
+        const bool pack = !(pe && pe[0] == '0');
+        if (pack && n_tgt == 20 && n_rows == 20 && n_pad == 32 && tgt == src && tgt_valid == src_valid && !eye && G % 4 == 0) {
+            xh::launch_polyline_block_x(x, G, K, VT, kbias, s);
+            return;
+        }
+        xh::launch_kv_hoist_nx(W, L, LX, n_layer, tgt, tgt_valid, G, n_tgt, n_pad, K, VT, kbias, s);
         xh::launch_xblock_x(x, G, s);
         return;
     }

@@ -162,6 +162,166 @@ __global__ __launch_bounds__(NTHREADS) void k_kv_hoist_nx2(const float* __restri
         kv_project_tile_x2(W, l2, x2, T0, T1, P1a, P1b, K0 + 4 * ls, V0 + 4 * ls, tok0, n_real0, n_real1, tid, u, kvproj_first_x(W, l2, x2, wave));
 }
 
+// ---------------------------------------------------------------------------------------------
+// The map encoder's polyline block (20 nodes per polyline, 32 key slots, tgt = src) without its padding rows: per four polylines
+// four head tiles (nodes 0 .. 15; two polylines per workgroup share every weight unit) and ONE tail tile (nodes 16 .. 19 of all
+// four, tb_device_xdl.hpp "packed polyline tails") instead of eight tiles -- 5/8 of the row work.  Bitwise identical to the padded
+// tiling (TB_ENCODE_PACK=0).  G % 4 == 0.
+//   k_kv_hoist_plh / k_xattn_block_plh   grid (G / 2): head tiles of polylines 2 i, 2 i + 1
+//   k_kv_hoist_plt / k_xattn_block_plt   grid (G / 4): tail tile of polylines 4 i .. 4 i + 3
+// ---------------------------------------------------------------------------------------------
+constexpr int PL_NODES = 20;
+
+__global__ __launch_bounds__(NTHREADS) void k_kv_hoist_plh(const float* __restrict__ W, XLayerW l0, XLayerW l1, XLayerW l2, XLayerX x0,
+                                                          XLayerX x1, XLayerX x2, int n_layer, const float* __restrict__ feat,
+                                                          const uint8_t* __restrict__ fvalid, float* __restrict__ Kout,
+                                                          float* __restrict__ VTout, float* __restrict__ kbias) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* T0 = smem;
+    float* T1 = T0 + TM * LDT;
+    xhalf* P1a = reinterpret_cast<xhalf*>(T1 + TM * LDT);
+    xhalf* P1b = P1a + NPL * PLANE;
+    const int tid = threadIdx.x, wave = wave_of(tid), lane = tid & 63, g0 = blockIdx.x * 2, g1 = g0 + 1;
+    WUnitX u;
+    wloadx(u, kvproj_first_x(W, l0, x0, wave), lane);
+    load_tile(T0, LDT, feat + (size_t)g0 * PL_NODES * H, TM, tid);
+    load_tile(T1, LDT, feat + (size_t)g1 * PL_NODES * H, TM, tid);
+    if (tid < 2 * TM) {
+        const int g = g0 + (tid >> 4), k = tid & 15;
+        kbias[(size_t)g * KEYPAD + k] = fvalid[(size_t)g * PL_NODES + k] ? 0.f : -INFINITY;
+    }
+    __syncthreads();
+    const size_t ls = (size_t)KEYPAD * H;
+    xhalf* K0 = reinterpret_cast<xhalf*>(Kout + ((size_t)g0 * n_layer) * ls);
+    xhalf* V0 = reinterpret_cast<xhalf*>(VTout + ((size_t)g0 * n_layer) * ls);
+    xhalf* K1 = reinterpret_cast<xhalf*>(Kout + ((size_t)g1 * n_layer) * ls);
+    xhalf* V1 = reinterpret_cast<xhalf*>(VTout + ((size_t)g1 * n_layer) * ls);
+    kv_project_tile_x2(W, l0, x0, T0, T1, P1a, P1b, K0, V0, 0, TM, TM, tid, u, kvproj_first_x(W, l1, x1, wave), K1, V1);
+    if (n_layer > 1)
+        kv_project_tile_x2(W, l1, x1, T0, T1, P1a, P1b, K0 + 2 * ls, V0 + 2 * ls, 0, TM, TM, tid, u, kvproj_first_x(W, l2, x2, wave), K1 + 2 * ls,
+                           V1 + 2 * ls);
+    if (n_layer > 2)
+        kv_project_tile_x2(W, l2, x2, T0, T1, P1a, P1b, K0 + 4 * ls, V0 + 4 * ls, 0, TM, TM, tid, u, kvproj_first_x(W, l2, x2, wave), K1 + 4 * ls,
+                           V1 + 4 * ls);
+}
+
+// rows of a packed tail tile: row r <-> (polyline gq + (r >> 2), node 16 + (r & 3))
+__device__ __forceinline__ void load_tail_tile(float* dst, const float* __restrict__ src, int gq, int tid) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int idx = tid + i * NTHREADS;
+        const int row = idx >> 5, c4 = (idx & 31) * 4;
+        st4(dst + row * LDT + c4, ldg4(src + ((size_t)(gq + (row >> 2)) * PL_NODES + 16 + (row & 3)) * H + c4));
+    }
+}
+__device__ __forceinline__ void store_tail_tile(float* __restrict__ dst, const float* src, int gq, int tid) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int idx = tid + i * NTHREADS;
+        const int row = idx >> 5, c4 = (idx & 31) * 4;
+        st4(dst + ((size_t)(gq + (row >> 2)) * PL_NODES + 16 + (row & 3)) * H + c4, lds4(src + row * LDT + c4));
+    }
+}
+
+__global__ __launch_bounds__(NTHREADS) void k_kv_hoist_plt(const float* __restrict__ W, XLayerW l0, XLayerW l1, XLayerW l2, XLayerX x0,
+                                                          XLayerX x1, XLayerX x2, int n_layer, const float* __restrict__ feat,
+                                                          const uint8_t* __restrict__ fvalid, float* __restrict__ Kout,
+                                                          float* __restrict__ VTout, float* __restrict__ kbias) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* T = smem;
+    xhalf* P1 = reinterpret_cast<xhalf*>(smem + TM * LDT);
+    const int tid = threadIdx.x, wave = wave_of(tid), lane = tid & 63, gq = blockIdx.x * 4;
+    WUnitX u;
+    wloadx(u, kvproj_first_x(W, l0, x0, wave), lane);
+    load_tail_tile(T, feat, gq, tid);
+    if (tid < 4 * TM) {  // key slots 16 .. 31 of the four polylines: nodes 16 .. 19, then padding
+        const int g = gq + (tid >> 4), k = tid & 15;
+        kbias[(size_t)g * KEYPAD + 16 + k] = (k < 4 && fvalid[(size_t)g * PL_NODES + 16 + k]) ? 0.f : -INFINITY;
+    }
+    __syncthreads();
+    const size_t ls = (size_t)KEYPAD * H;
+    const size_t gstride = 2 * (size_t)n_layer * ls;
+    xhalf* K0 = reinterpret_cast<xhalf*>(Kout + ((size_t)gq * n_layer) * ls);
+    xhalf* V0 = reinterpret_cast<xhalf*>(VTout + ((size_t)gq * n_layer) * ls);
+    kv_project_tile_xt(W, l0, x0, T, P1, K0, V0, gstride, tid, u, kvproj_first_x(W, l1, x1, wave));
+    if (n_layer > 1) kv_project_tile_xt(W, l1, x1, T, P1, K0 + 2 * ls, V0 + 2 * ls, gstride, tid, u, kvproj_first_x(W, l2, x2, wave));
+    if (n_layer > 2) kv_project_tile_xt(W, l2, x2, T, P1, K0 + 4 * ls, V0 + 4 * ls, gstride, tid, u, kvproj_first_x(W, l2, x2, wave));
+}
+
+__global__ __launch_bounds__(NTHREADS) void k_xattn_block_plh(XBlockPX p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* X0 = smem;
+    float* X1 = X0 + TM * LDT;
+    xhalf* PA0 = reinterpret_cast<xhalf*>(X1 + TM * LDT);
+    xhalf* PA1 = PA0 + NPL * PLANE;
+    xhalf* PB0 = PA1 + NPL * PLANE;
+    xhalf* PB1 = PB0 + NPL * PLANE;
+    uint8_t* rowvalid = reinterpret_cast<uint8_t*>(PB1 + NPL * PLANE);  // [32]
+    uint8_t* novalid_s = rowvalid + 32;                                 // [32]
+    const int tid = threadIdx.x, wave = wave_of(tid), lane = tid & 63, g0 = blockIdx.x * 2, g1 = g0 + 1;
+    WUnitX u;
+    wloadx(u, xlayer_first_x(p.W, p.L[0], p.LX[0], wave), lane);
+    load_tile(X0, LDT, p.src + (size_t)g0 * PL_NODES * H, TM, tid);
+    load_tile(X1, LDT, p.src + (size_t)g1 * PL_NODES * H, TM, tid);
+    if (tid < 2 * TM) rowvalid[tid] = p.src_valid[(size_t)(g0 + (tid >> 4)) * PL_NODES + (tid & 15)];
+    __syncthreads();
+    const size_t ls = (size_t)KEYPAD * H;
+    const xhalf* K0 = reinterpret_cast<const xhalf*>(p.K + ((size_t)g0 * p.n_layer) * ls);
+    const xhalf* V0 = reinterpret_cast<const xhalf*>(p.VT + ((size_t)g0 * p.n_layer) * ls);
+    const xhalf* K1 = reinterpret_cast<const xhalf*>(p.K + ((size_t)g1 * p.n_layer) * ls);
+    const xhalf* V1 = reinterpret_cast<const xhalf*>(p.VT + ((size_t)g1 * p.n_layer) * ls);
+    const float* kb0 = p.kbias + (size_t)g0 * KEYPAD;
+    const float* kb1 = p.kbias + (size_t)g1 * KEYPAD;
+#pragma unroll 1
+    for (int l = 0; l < p.n_layer; ++l) {
+        const int ln = l + 1 < p.n_layer ? l + 1 : l;
+        xattn_layer_x2<false>(p.W, p.L[l], p.LX[l], X0, X1, PA0, PA1, PB0, PB1, K0 + 2 * l * ls, V0 + 2 * l * ls, kb0, KEYPAD, -1, -1, rowvalid,
+                              rowvalid + TM, novalid_s, novalid_s + TM, tid, u, xlayer_first_x(p.W, p.L[ln], p.LX[ln], wave), K1 + 2 * l * ls,
+                              V1 + 2 * l * ls, kb1);
+    }
+    store_tile(p.dst + (size_t)g0 * PL_NODES * H, X0, LDT, TM, tid);
+    store_tile(p.dst + (size_t)g1 * PL_NODES * H, X1, LDT, TM, tid);
+}
+
+__global__ __launch_bounds__(NTHREADS) void k_xattn_block_plt(XBlockPX p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* X = smem;
+    xhalf* PA = reinterpret_cast<xhalf*>(X + TM * LDT);
+    xhalf* PB = PA + NPL * PLANE;
+    uint8_t* rowvalid = reinterpret_cast<uint8_t*>(PB + NPL * PLANE);
+    uint8_t* novalid_s = rowvalid + 16;
+    const int tid = threadIdx.x, wave = wave_of(tid), lane = tid & 63, gq = blockIdx.x * 4;
+    WUnitX u;
+    wloadx(u, xlayer_first_x(p.W, p.L[0], p.LX[0], wave), lane);
+    load_tail_tile(X, p.src, gq, tid);
+    if (tid < TM) rowvalid[tid] = p.src_valid[(size_t)(gq + (tid >> 2)) * PL_NODES + 16 + (tid & 3)];
+    __syncthreads();
+    const size_t ls = (size_t)KEYPAD * H;
+    const size_t gstride = 2 * (size_t)p.n_layer * ls;
+    const xhalf* K0 = reinterpret_cast<const xhalf*>(p.K + ((size_t)gq * p.n_layer) * ls);
+    const xhalf* V0 = reinterpret_cast<const xhalf*>(p.VT + ((size_t)gq * p.n_layer) * ls);
+    const float* kb = p.kbias + (size_t)gq * KEYPAD;
+#pragma unroll 1
+    for (int l = 0; l < p.n_layer; ++l) {
+        const int ln = l + 1 < p.n_layer ? l + 1 : l;
+        xattn_layer_xt(p.W, p.L[l], p.LX[l], X, PA, PB, K0 + 2 * l * ls, V0 + 2 * l * ls, kb, gstride, rowvalid, novalid_s, tid, u,
+                       xlayer_first_x(p.W, p.L[ln], p.LX[ln], wave));
+    }
+    store_tail_tile(p.dst, X, gq, tid);
+}
+
+// hoist + block of the polyline encoder on the packed tiling; `p` as for launch_xblock_x (n_rows = 20, n_pad = 32, tgt = src)
+void launch_polyline_block_x(const XBlockPX& p, int G, float* K, float* VT, float* kbias, hipStream_t s) {
+    const int i1 = p.n_layer > 1 ? 1 : 0, i2 = p.n_layer > 2 ? 2 : 0;
+    const size_t lds1 = TM * LDT * sizeof(float) + 2 * PLANES_BYTES + 64, lds2 = 2 * TM * LDT * sizeof(float) + 4 * PLANES_BYTES + 64;
+    hipLaunchKernelGGL(k_kv_hoist_plh, dim3(G / 2), dim3(NTHREADS), 2 * TM * LDT * sizeof(float) + 2 * PLANES_BYTES, s, p.W, p.L[0], p.L[i1],
+                       p.L[i2], p.LX[0], p.LX[i1], p.LX[i2], p.n_layer, p.src, p.src_valid, K, VT, kbias);
+    hipLaunchKernelGGL(k_kv_hoist_plt, dim3(G / 4), dim3(NTHREADS), TM * LDT * sizeof(float) + PLANES_BYTES, s, p.W, p.L[0], p.L[i1], p.L[i2],
+                       p.LX[0], p.LX[i1], p.LX[i2], p.n_layer, p.src, p.src_valid, K, VT, kbias);
+    hipLaunchKernelGGL(k_xattn_block_plh, dim3(G / 2), dim3(NTHREADS), lds2, s, p);
+    hipLaunchKernelGGL(k_xattn_block_plt, dim3(G / 4), dim3(NTHREADS), lds1, s, p);
+}
+
 void launch_xblock_x(const XBlockPX& p, int G, hipStream_t s) {
     dim3 grid2((p.n_rows + 2 * TM - 1) / (2 * TM), G);
     if (p.n_rows > TM && (int)grid2.x * G >= 256) {  // two row tiles per workgroup share every weight unit -- when that still fills the chip
