@@ -989,8 +989,27 @@ __device__ __forceinline__ void kv_project_tile_xt(const float* __restrict__ W, 
     xhalf* kg = Kmat + (size_t)(m >> 2) * gstride;
     xhalf* vg = VT + (size_t)(m >> 2) * gstride;
     kv_store_key_x(kg, vg, 16 + (m & 3), wave, lane, ak, av, true);
+    // zero the key slots 20 .. 31 of the four key blocks with whole granules (this wave's head; lane group kq takes polyline kq):
+    // K -- key tile 1, rows 4 .. 15, all four feature quads: 48 granules of 16 B per plane, three per lane;
+    // V -- both d tiles, key quads 1 .. 3, elements 4 .. 7 (= keys 16 + 4 quad + e - 4) of d row m: six 8-byte stores per plane
+    {
+        xhalf* kz = Kmat + (size_t)kq * gstride + wave * (NPL * 1024);
+        xhalf* vz = VT + (size_t)kq * gstride + wave * (NPL * 1024);
+        const xh8 z8 = {};
+        const xh4 z4 = {};
 #pragma unroll
-    for (int c = 0; c < 3; ++c) kv_store_key_x(kg, vg, 20 + 4 * c + (m & 3), wave, lane, ak, av, false);
+        for (int pl = 0; pl < NPL; ++pl) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const int idx = m * 3 + c;  // 0 .. 47 -> (row 4 + idx / 4, feature quad idx % 4)
+                *reinterpret_cast<xh8*>(kz + pl * 1024 + (64 + (idx & 3) * 16 + 4 + (idx >> 2)) * 8) = z8;
+            }
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int vq = 1; vq < 4; ++vq) *reinterpret_cast<xh4*>(vz + pl * 1024 + (t * 64 + vq * 16 + m) * 8 + 4) = z4;
+        }
+    }
     __syncthreads();
 }
 

@@ -45,12 +45,15 @@ struct TokP {
 constexpr int TOK_GROUPS = 16;
 
 __global__ __launch_bounds__(NTHREADS) void k_encode_tokens(TokP p) {
-    __shared__ __attribute__((aligned(16))) float attr[TM][32];
+    // attributes / pose / validity of ALL TOK_GROUPS * 16 tokens of the workgroup, gathered by one thread per token in front of the
+    // loop: the per-group gather (16 threads, dependent global loads + the fp64 atan2, then a barrier) was a serial round trip per
+    // 16 tokens, sixteen times per workgroup.  Row stride 33: the gather writes one row per thread.
+    __shared__ float attr[TOK_GROUPS * TM][33];
     __shared__ __attribute__((aligned(16))) float hid[TM][32];
     __shared__ __attribute__((aligned(16))) float outt[TM][LDT];
     __shared__ float w1t[31 * 32], w2t[32 * 32], b1s[32], b2s[32], fxy[12], fyaw[24];
-    __shared__ float pose[TM][4];
-    __shared__ uint8_t rv[TM];
+    __shared__ float pose[TOK_GROUPS * TM][4];
+    __shared__ uint8_t rvall[TOK_GROUPS * TM];
     const int tid = threadIdx.x;
     const int attr_dim = p.kind == 0 ? 11 : (p.kind == 1 ? 5 : 31);
     for (int i = tid; i < attr_dim * 32; i += NTHREADS) w1t[i] = p.W[p.mlp.w1 + (i & 31) * attr_dim + (i >> 5)];
@@ -61,54 +64,56 @@ __global__ __launch_bounds__(NTHREADS) void k_encode_tokens(TokP p) {
     }
     if (tid < 12) fxy[tid] = p.W[p.pe_fxy + tid];
     if (tid >= 32 && tid < 56) fyaw[tid - 32] = p.W[p.pe_fyaw + tid - 32];
+    static_assert(TOK_GROUPS * TM == NTHREADS, "one gathered token per thread");
+    {
+        const int tk = blockIdx.x * TOK_GROUPS * TM + tid;
+        float* a = attr[tid];
+        for (int k = 0; k < 32; ++k) a[k] = 0.f;
+        float x = 0.f, y = 0.f, yw = 0.f;
+        uint8_t v = 0;
+        if (tk < p.n_tok && p.ext_attr) {
+            v = p.valid[tk];
+            for (int k = 0; k < attr_dim; ++k) a[k] = p.ext_attr[(size_t)tk * attr_dim + k];
+        } else if (tk < p.n_tok) {
+            v = p.valid[tk];
+            x = p.pos[(size_t)tk * 2];
+            y = p.pos[(size_t)tk * 2 + 1];
+            const int b = tk / p.per_scene, r = tk % p.inner;
+            if (p.kind == 0) {
+                yw = p.yaw[tk];
+                const int A = p.inner;
+                a[0] = p.vel[(size_t)tk * 2]; a[1] = p.vel[(size_t)tk * 2 + 1]; a[2] = p.spd[tk];
+                a[3] = p.yaw_rate[tk]; a[4] = p.acc[tk];
+                const float* sz = p.size + ((size_t)b * A + r) * 3;
+                a[5] = sz[0]; a[6] = sz[1]; a[7] = sz[2];
+                const int ty = p.cls[(size_t)b * A + r];
+                if (ty >= 0 && ty < 3) a[8 + ty] = 1.f;
+            } else {
+                yw = (float)atan2((double)p.dir[(size_t)tk * 2 + 1], (double)p.dir[(size_t)tk * 2]);  // pose_pe.py:61
+                if (p.kind == 1) {
+                    const int st = p.cls[tk];
+                    if (st >= 0 && st < 5) a[st] = 1.f;
+                } else {
+                    const int pl = tk / 20;  // global polyline index
+                    const int ty = p.cls[pl];
+                    if (ty >= 0 && ty < 11) a[ty] = 1.f;
+                    a[11 + r] = 1.f;  // node one-hot (sc_input.py:127-133)
+                }
+            }
+        }
+        pose[tid][0] = x; pose[tid][1] = y; pose[tid][2] = yw;
+        rvall[tid] = v;
+    }
     __syncthreads();
 #pragma unroll 1
     for (int g = 0; g < TOK_GROUPS; ++g) {
         const int tok0 = (blockIdx.x * TOK_GROUPS + g) * TM;
         if (tok0 >= p.n_tok) break;
-        if (tid < TM) {
-            const int tk = tok0 + tid;
-            float* a = attr[tid];
-            for (int k = 0; k < 32; ++k) a[k] = 0.f;
-            float x = 0.f, y = 0.f, yw = 0.f;
-            uint8_t v = 0;
-            if (tk < p.n_tok && p.ext_attr) {
-                v = p.valid[tk];
-                for (int k = 0; k < attr_dim; ++k) a[k] = p.ext_attr[(size_t)tk * attr_dim + k];
-            } else if (tk < p.n_tok) {
-                v = p.valid[tk];
-                x = p.pos[(size_t)tk * 2];
-                y = p.pos[(size_t)tk * 2 + 1];
-                const int b = tk / p.per_scene, r = tk % p.inner;
-                if (p.kind == 0) {
-                    yw = p.yaw[tk];
-                    const int A = p.inner;
-                    a[0] = p.vel[(size_t)tk * 2]; a[1] = p.vel[(size_t)tk * 2 + 1]; a[2] = p.spd[tk];
-                    a[3] = p.yaw_rate[tk]; a[4] = p.acc[tk];
-                    const float* sz = p.size + ((size_t)b * A + r) * 3;
-                    a[5] = sz[0]; a[6] = sz[1]; a[7] = sz[2];
-                    const int ty = p.cls[(size_t)b * A + r];
-                    if (ty >= 0 && ty < 3) a[8 + ty] = 1.f;
-                } else {
-                    yw = (float)atan2((double)p.dir[(size_t)tk * 2 + 1], (double)p.dir[(size_t)tk * 2]);  // pose_pe.py:61
-                    if (p.kind == 1) {
-                        const int st = p.cls[tk];
-                        if (st >= 0 && st < 5) a[st] = 1.f;
-                    } else {
-                        const int pl = tk / 20;  // global polyline index
-                        const int ty = p.cls[pl];
-                        if (ty >= 0 && ty < 11) a[ty] = 1.f;
-                        a[11 + r] = 1.f;  // node one-hot (sc_input.py:127-133)
-                    }
-                }
-            }
-            pose[tid][0] = x; pose[tid][1] = y; pose[tid][2] = yw;
-            rv[tid] = v;
-        }
-        __syncthreads();
+        const float (*attrg)[33] = attr + g * TM;
+        const uint8_t* rv = rvall + g * TM;
         {
             const int row = tid >> 4, i = tid & 15;
-            const float px = pose[row][0], py = pose[row][1], pyaw = pose[row][2];
+            const float px = pose[g * TM + row][0], py = pose[g * TM + row][1], pyaw = pose[g * TM + row][2];
             float* xr = outt[row] + 32;
             if (p.ext_pe) {  // (wave-uniform) the caller's PE: 96 floats per token, 6 per thread
                 const int tk = tok0 + row;
@@ -136,7 +141,7 @@ __global__ __launch_bounds__(NTHREADS) void k_encode_tokens(TokP p) {
             const int o0 = i * 2;
             float s0 = b1s[o0], s1 = b1s[o0 + 1];
             for (int k = 0; k < attr_dim; ++k) {
-                const float av = attr[row][k];
+                const float av = attrg[row][k];
                 s0 = fmaf(av, w1t[k * 32 + o0], s0);
                 s1 = fmaf(av, w1t[k * 32 + o0 + 1], s1);
             }
