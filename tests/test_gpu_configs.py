@@ -360,7 +360,8 @@ def test_encode_side_stream_is_bitwise_identical(monkeypatch):
 
 
 def test_packed_polyline_tiling_is_bitwise_identical(monkeypatch):
-    """The map encoder's polyline block on the packed tiling (per four polylines four 16-row head tiles + ONE tile with the four
+    """The map encoder's polyline block fused (TB_ENCODE_PACK=2, default: two polylines = three row tiles per workgroup, K / V in LDS:
+    `k_polyline_fused`) and on the packed tiling (per four polylines four 16-row head tiles + ONE tile with the four
     tail nodes 16 .. 19 of each, instead of eight tiles of which four carry twelve padding rows: tb_encodex_kernels.hip
     `launch_polyline_block_x`) against the padded tiling (TB_ENCODE_PACK=0): every row goes through the same arithmetic, so every
     product of the encoder is bit-identical -- with invalid nodes, wholly invalid polylines and a polyline count that the packed path
@@ -374,21 +375,22 @@ def test_packed_polyline_tiling_is_bitwise_identical(monkeypatch):
     eng = HipEngine(cfg)
     eng.load_state_dict(sd)
     for n_scene, n_pl, seed, masks in ((8, 256, 9910, dict(p_invalid_pl=0.3, p_invalid_node=0.4)), (4, 256, 9913, {}),
-                                       (5, 260, 9911, dict(p_invalid_pl=0.3, p_invalid_node=0.4)), (3, 65, 9912, dict(p_invalid_node=0.5)), (1, 8, 9914, dict(p_invalid_node=0.5))):
+                                       (5, 260, 9911, dict(p_invalid_pl=0.3, p_invalid_node=0.4)), (3, 65, 9912, dict(p_invalid_node=0.5)), (3, 66, 9915, dict(p_invalid_pl=0.2, p_invalid_node=0.5)), (1, 8, 9914, dict(p_invalid_node=0.5))):
         batch = synth.make_batch(seed, n_scene, n_agent=48, n_pl=n_pl, n_tl=20, **masks)
         scene = scene_from_batch(batch, torch.device("cuda", 0))
         got = {}
-        for mode in ("1", "0"):
+        for mode in ("2", "1", "0"):
             monkeypatch.setenv("TB_ENCODE_PACK", mode)
             enc = eng.encode_scene(scene)
             torch.cuda.synchronize()
             eng.check_status()
             got[mode] = {k_: v.clone() for k_, v in enc.items() if torch.is_tensor(v)}
-        assert torch.isfinite(got["1"]["map_feature"]).all()
+        assert torch.isfinite(got["2"]["map_feature"]).all()
         if masks.get("p_invalid_pl"):
             assert not bool(got["1"]["map_feature_valid"].all()) and bool(got["1"]["map_feature_valid"].any())
-        for k_, v in got["1"].items():
-            assert torch.equal(v, got["0"][k_]), (n_pl, k_)
+        for k_, v in got["0"].items():
+            assert torch.equal(v, got["1"][k_]), (n_pl, k_, "packed")
+            assert torch.equal(v, got["2"][k_]), (n_pl, k_, "fused")
 
 def test_bench_sub_records_and_traj_err():
     """the default single-GPU command carries the configs[3] / configs[4] sub-records and the golden trajectory error"""

@@ -213,6 +213,45 @@ __device__ __forceinline__ void layernorm_planes(const float* src, int lds_, xha
     planes_store4<false>(P, PLANE, LDP, row, c0 + 4, dc * splat(rstd) * g1 + b1);
 }
 
+// The same LayerNorm for N tiles at once (tile t at src + t * src_stride floats, its planes at P + t * p_stride fp16): the N
+// independent latency chains (LDS read -> two 16-lane reductions -> rsqrt -> pair split -> LDS write) are written side by side so
+// that they overlap in one wave's instruction stream; per tile the arithmetic and its order are those of layernorm_planes.
+template <int N>
+__device__ __forceinline__ void layernorm_planes_n(const float* src, int src_stride, xhalf* P, int p_stride, const float* __restrict__ g,
+                                                   const float* __restrict__ b, int tid) {
+    const int row = tid >> 4, c0 = (tid & 15) * 8;
+    f32x4 a[N], c[N];
+#pragma unroll
+    for (int t = 0; t < N; ++t) {
+        a[t] = lds4(src + t * src_stride + row * LDT + c0);
+        c[t] = lds4(src + t * src_stride + row * LDT + c0 + 4);
+    }
+    const f32x4 g0 = ldg4(g + c0), g1 = ldg4(g + c0 + 4), b0 = ldg4(b + c0), b1 = ldg4(b + c0 + 4);
+    float s[N];
+#pragma unroll
+    for (int t = 0; t < N; ++t) s[t] = (a[t].x + a[t].y) + (a[t].z + a[t].w) + (c[t].x + c[t].y) + (c[t].z + c[t].w);
+#pragma unroll
+    for (int t = 0; t < N; ++t) s[t] = row16_sum(s[t]);
+    f32x4 da[N], dc[N];
+    float v[N];
+#pragma unroll
+    for (int t = 0; t < N; ++t) {
+        const float mean = s[t] * (1.0f / 128.0f);
+        da[t] = a[t] - splat(mean);
+        dc[t] = c[t] - splat(mean);
+        v[t] = (da[t].x * da[t].x + da[t].y * da[t].y) + (da[t].z * da[t].z + da[t].w * da[t].w) + (dc[t].x * dc[t].x + dc[t].y * dc[t].y) +
+               (dc[t].z * dc[t].z + dc[t].w * dc[t].w);
+    }
+#pragma unroll
+    for (int t = 0; t < N; ++t) v[t] = row16_sum(v[t]);
+#pragma unroll
+    for (int t = 0; t < N; ++t) {
+        const float rstd = 1.0f / sqrtf(v[t] * (1.0f / 128.0f) + LN_EPS);
+        planes_store4<false>(P + t * p_stride, PLANE, LDP, row, c0, da[t] * splat(rstd) * g0 + b0);
+        planes_store4<false>(P + t * p_stride, PLANE, LDP, row, c0 + 4, dc[t] * splat(rstd) * g1 + b1);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // weight units: 2 output tiles x 4 chunks (128 k) x 2 planes = 16 fragments of 8 fp16 per lane (64 VGPRs) + bias
 // ---------------------------------------------------------------------------------------------

@@ -493,6 +493,12 @@ static void run_block(bool xdl, const float* W, const XLayerW* L, const XLayerX*
         // the map encoder's polyline block (20 nodes, self-attention inside the polyline) runs on the packed tiling: no padding rows
         const char* pe = getenv("TB_ENCODE_PACK");  // (read per call: the tests flip it inside one process)
         const bool pack = !(pe && pe[0] == '0');
+        // '2' (default): the fused kernel, K / V in LDS; '1': packed tiling with the K / V hoist through HBM; '0': padded tiling
+        const int pmode = pe ? pe[0] - '0' : 2;
+        if (pmode == 2 && n_tgt == 20 && n_rows == 20 && n_pad == 32 && tgt == src && tgt_valid == src_valid && !eye && G % 2 == 0) {
+            xh::launch_polyline_fused_x(x, G, s);
+            return;
+        }
         if (pack && n_tgt == 20 && n_rows == 20 && n_pad == 32 && tgt == src && tgt_valid == src_valid && !eye && G % 4 == 0) {
             xh::launch_polyline_block_x(x, G, K, VT, kbias, s);
             return;
@@ -598,7 +604,11 @@ int run_encode(struct ::tb_ctx* ctx, const tb_encode_io* io, hipStream_t s) {
     const int a_pad = padk(A), p_pad = padk(P), t_pad = padk(T);
     const int S3 = (NH - 1) / 5 + 1;  // steps {0,5,10} (latent_encoder.py:98-103)
     // map-encoder chunking bounds the per-polyline K/V scratch (3 layers x 32 keys x 128 x 2 x 4 B = 96 KiB / polyline)
-    const int scenes_per_chunk = std::max(1, std::min(B, (int)(((size_t)512 << 20) / ((size_t)P * 98304))));
+    // (the fused polyline kernel keeps K / V in LDS: no scratch, one launch over all polylines)
+    const char* pe_ = getenv("TB_ENCODE_PACK");
+    const bool fused_pl = ctx->encode_kernel == 1 && (pe_ ? pe_[0] == '2' : true) && P % 2 == 0;
+    const int scenes_per_chunk = fused_pl ? B : std::max(1, std::min(B, (int)(((size_t)512 << 20) / ((size_t)P * 98304))));
+    const size_t kv_scenes = fused_pl ? 0 : (size_t)scenes_per_chunk;
 
     float *nodef, *nodeo, *kn, *vtn, *kvn, *plf, *kps, *vtps, *kvps, *tgt, *U, *V;
     uint8_t* tgtv;
@@ -606,9 +616,9 @@ int run_encode(struct ::tb_ctx* ctx, const tb_encode_io* io, hipStream_t s) {
     auto carve = [&](Carver& c) {
         nodef = c.take<float>((size_t)B * P * 20 * 128);
         nodeo = c.take<float>((size_t)scenes_per_chunk * P * 20 * 128);
-        kn = c.take<float>((size_t)scenes_per_chunk * P * 3 * 32 * 128);
-        vtn = c.take<float>((size_t)scenes_per_chunk * P * 3 * 128 * 32);
-        kvn = c.take<float>((size_t)scenes_per_chunk * P * 32);
+        kn = c.take<float>(kv_scenes * P * 3 * 32 * 128);
+        vtn = c.take<float>(kv_scenes * P * 3 * 128 * 32);
+        kvn = c.take<float>(kv_scenes * P * 32);
         plf = c.take<float>((size_t)B * P * 128);
         kps = c.take<float>((size_t)B * p_pad * 128);
         vtps = c.take<float>((size_t)B * 128 * p_pad);

@@ -310,6 +310,188 @@ __global__ __launch_bounds__(NTHREADS) void k_xattn_block_plt(XBlockPX p) {
     store_tail_tile(p.dst, X, gq, tid);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Polyline block, FUSED: one workgroup = two polylines = three row tiles (head tile of each + one tile with the four tail nodes of
+// both), and the K / V of their 2 x 20 keys never leave the CU -- each layer projects them from the block input (tgt is fixed over the
+// layers: transformer_block.py) straight into two 32-key blocks in LDS, in the fragment-major layout the attention reads (the same
+// device functions, handed LDS pointers).  Against hoist + block kernels: no 96 KiB per polyline of K / V written to HBM and read
+// back (805 MB each way per 32 scenes), every weight unit applied to three tiles.  Same arithmetic per row: bitwise identical.
+// LDS: 3 fp32 tiles + 2 x 3 plane sets (the second doubles as the fp32 staging of the block input for LN_tgt) + 64 KB of K / V.
+// grid (G / 2); G % 2 == 0.
+// ---------------------------------------------------------------------------------------------
+constexpr int PLF_LDS_BYTES = 3 * TM * LDT * 4 + 6 * PLANES_BYTES + 4 * KV_BLOCK_HALFS * 2 + 64 * 4 + 128;
+static_assert(3 * TM * LDT * 4 <= 3 * PLANES_BYTES || NPL == 1, "the fp32 staging of the block input lives in the second plane sets");
+
+__global__ __launch_bounds__(NTHREADS) void k_polyline_fused(XBlockPX p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* X = smem;                                                   // [3][16][LDT]
+    xhalf* P1 = reinterpret_cast<xhalf*>(X + 3 * TM * LDT);            // [3] plane sets
+    xhalf* P2 = P1 + 3 * NPL * PLANE;                                  // [3] plane sets
+    // (bf16 build: one plane per set, the staging needs its own room behind the K / V blocks -- see the launch)
+    xhalf* KL = P2 + 3 * NPL * PLANE;                                  // K blocks of the two polylines
+    xhalf* VL = KL + 2 * KV_BLOCK_HALFS;                               // V blocks
+    float* kb = reinterpret_cast<float*>(VL + 2 * KV_BLOCK_HALFS);     // [2][32] additive key mask
+    uint8_t* rowvalid = reinterpret_cast<uint8_t*>(kb + 64);           // [48]
+    uint8_t* novalid_s = rowvalid + 48;                                // [48]
+    float* S = NPL == 2 ? reinterpret_cast<float*>(P2) : reinterpret_cast<float*>(novalid_s + 80);  // fp32 staging [3][16][LDT]
+    const int tid = threadIdx.x, wave = wave_of(tid), lane = tid & 63, kq = lane >> 4, m = lane & 15;
+    const int g0 = blockIdx.x * 2;
+    const int po = m * LDP + kq * 8;
+    constexpr int PS = NPL * PLANE;  // fp16 per plane set
+
+    // rows of the three tiles: tile 0 / 1 = nodes 0 .. 15 of polyline g0 / g0 + 1, tile 2 rows 0 .. 3 / 4 .. 7 = their nodes 16 .. 19
+    auto load3 = [&](float* D) {
+        load_tile(D, LDT, p.src + (size_t)g0 * PL_NODES * H, TM, tid);
+        load_tile(D + TM * LDT, LDT, p.src + (size_t)(g0 + 1) * PL_NODES * H, TM, tid);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int idx = tid + i * NTHREADS;
+            const int row = idx >> 5, c4 = (idx & 31) * 4;
+            st4(D + 2 * TM * LDT + row * LDT + c4,
+                row < 8 ? ldg4(p.src + ((size_t)(g0 + (row >> 2)) * PL_NODES + 16 + (row & 3)) * H + c4) : splat(0.f));
+        }
+    };
+    WUnitX u, u2;
+    wloadx(u, kvproj_first_x(p.W, p.L[0], p.LX[0], wave), lane);
+    load3(X);
+    if (tid < 48) {
+        const int t = tid >> 4, r = tid & 15;
+        rowvalid[tid] = t < 2 ? p.src_valid[(size_t)(g0 + t) * PL_NODES + r] : (r < 8 ? p.src_valid[(size_t)(g0 + (r >> 2)) * PL_NODES + 16 + (r & 3)] : 0);
+    } else if (tid >= 64 && tid < 128) {
+        const int pl = (tid - 64) >> 5, k = (tid - 64) & 31;
+        kb[tid - 64] = (k < PL_NODES && p.src_valid[(size_t)(g0 + pl) * PL_NODES + k]) ? 0.f : -INFINITY;
+    }
+    {   // key slots 20 .. 31 stay zero for the whole kernel (masked keys must hold finite data)
+        const xh8 z = {};
+        xh8* kv8 = reinterpret_cast<xh8*>(KL);
+        for (int i = tid; i < 4 * KV_BLOCK_HALFS / 8; i += NTHREADS) kv8[i] = z;
+    }
+    __syncthreads();
+
+    auto gemm3 = [&](WUnitX& ua, WUnitX& ub, const WNextX& next, const xhalf* P, f32x4 (&a)[3][2]) {
+#pragma unroll
+        for (int t = 0; t < 3; ++t) { a[t][0] = ua.b[0]; a[t][1] = ua.b[1]; }
+        wmmax_pf(a[0][0], a[0][1], ua, P + po, PLANE, ub, next, lane);
+        wmmax(a[1][0], a[1][1], ua, P + PS + po, PLANE);
+        wmmax(a[2][0], a[2][1], ua, P + 2 * PS + po, PLANE);
+    };
+
+#pragma unroll 1
+    for (int l = 0; l < p.n_layer; ++l) {
+        const XLayerW& L = p.L[l];
+        const XLayerX& LX = p.LX[l];
+        const float* lnblk = p.W + L.ln1_g;
+        // ---- K / V of the layer from the block input
+        load3(S);
+        __syncthreads();
+        layernorm_planes_n<3>(S, TM * LDT, P1, PS, lnblk + 256, lnblk + 384, tid);
+        __syncthreads();
+        {
+            f32x4 ak[3][2], av[3][2];
+            gemm3(u, u2, wnextx(p.W, LX.wkv, p.W + L.bkv, 8 + 2 * wave, 8 + 2 * wave + 1), P1, ak);
+            gemm3(u2, u, xlayer_first_x(p.W, L, LX, wave), P1, av);
+            kv_store_x(KL, VL, 0, wave, lane, ak[0], av[0], true);
+            kv_store_x(KL + KV_BLOCK_HALFS, VL + KV_BLOCK_HALFS, 0, wave, lane, ak[1], av[1], true);
+            if (m < 8) kv_store_key_x(KL + (m >> 2) * KV_BLOCK_HALFS, VL + (m >> 2) * KV_BLOCK_HALFS, 16 + (m & 3), wave, lane, ak[2], av[2], true);
+        }
+        __syncthreads();  // (the projections have read P1: LayerNorm 1 may overwrite it; K / V are in place)
+        // ---- the layer on the three tiles
+        layernorm_planes_n<3>(X, TM * LDT, P1, PS, lnblk, lnblk + 128, tid);
+        __syncthreads();
+        {
+            f32x4 q[3][2];
+            gemm3(u, u2, wstdx(p.W, LX.wo, p.W + L.bo, wave), P1, q);
+            AttnPreX apre;
+            f32x4 o[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const xhalf* kt = KL + t * KV_BLOCK_HALFS;
+                const xhalf* vt = VL + t * KV_BLOCK_HALFS;
+                attention_prefetch_x(apre, kt, vt, kb + t * KEYPAD, KEYPAD, 0, wave, lane);
+                const bool nov = attention_head_x<false, false>(q[t], apre, kt, vt, kb + t * KEYPAD, KEYPAD, 0, wave, lane, -1, o, u2,
+                                                                wstdx(p.W, LX.wo, p.W + L.bo, wave));
+                planes_store_c<false>(P2 + t * PS, 2 * wave, lane, o[0]);
+                planes_store_c<false>(P2 + t * PS, 2 * wave + 1, lane, o[1]);
+                if (wave == 0 && kq == 0) novalid_s[t * TM + m] = nov ? 1 : 0;
+            }
+            f32x4 osel[2] = {splat(0.f), splat(0.f)};
+            bool novsel = true;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const xhalf* kt = KL + j * KV_BLOCK_HALFS;
+                const xhalf* vt = VL + j * KV_BLOCK_HALFS;
+                attention_prefetch_x(apre, kt, vt, kb + j * KEYPAD, KEYPAD, 0, wave, lane);
+                const bool nov = attention_head_x<false, false>(q[2], apre, kt, vt, kb + j * KEYPAD, KEYPAD, 0, wave, lane, -1, o, u2,
+                                                                wstdx(p.W, LX.wo, p.W + L.bo, wave));
+                if ((m >> 2) == j) {
+                    osel[0] = o[0];
+                    osel[1] = o[1];
+                    novsel = nov;
+                }
+            }
+            planes_store_c<false>(P2 + 2 * PS, 2 * wave, lane, osel[0]);
+            planes_store_c<false>(P2 + 2 * PS, 2 * wave + 1, lane, osel[1]);
+            if (wave == 0 && kq == 0) novalid_s[2 * TM + m] = novsel ? 1 : 0;
+        }
+        __syncthreads();
+        {
+            f32x4 a[3][2];
+            gemm3(u2, u, wstdx(p.W, LX.w1, p.W + L.b1, wave), P2, a);
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                const bool nv = novalid_s[t * TM + m] != 0;
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    float* px = cptr(X + t * TM * LDT, LDT, 2 * wave + c, lane);
+                    const f32x4 xo = lds4(px);
+                    st4(px, nv ? xo : xo + a[t][c]);
+                }
+            }
+        }
+        __syncthreads();
+        layernorm_planes_n<3>(X, TM * LDT, P1, PS, lnblk + 512, lnblk + 640, tid);
+        __syncthreads();
+        {
+            f32x4 a[3][2];
+            gemm3(u, u2, wstdx(p.W, LX.w2, p.W + L.b2, wave), P1, a);
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                planes_store_c(P2 + t * PS, 2 * wave, lane, relu4(a[t][0]));
+                planes_store_c(P2 + t * PS, 2 * wave + 1, lane, relu4(a[t][1]));
+            }
+        }
+        __syncthreads();
+        {
+            f32x4 a[3][2];
+            const int ln = l + 1 < p.n_layer ? l + 1 : l;
+            gemm3(u2, u, kvproj_first_x(p.W, p.L[ln], p.LX[ln], wave), P2, a);
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                const bool rv = rowvalid[t * TM + m] != 0;
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    float* px = cptr(X + t * TM * LDT, LDT, 2 * wave + c, lane);
+                    st4(px, rv ? lds4(px) + a[t][c] : splat(0.f));
+                }
+            }
+        }
+        __syncthreads();
+    }
+    store_tile(p.dst + (size_t)g0 * PL_NODES * H, X, LDT, TM, tid);
+    store_tile(p.dst + (size_t)(g0 + 1) * PL_NODES * H, X + TM * LDT, LDT, TM, tid);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int idx = tid + i * NTHREADS;
+        const int row = idx >> 5, c4 = (idx & 31) * 4;
+        if (row < 8) st4(p.dst + ((size_t)(g0 + (row >> 2)) * PL_NODES + 16 + (row & 3)) * H + c4, lds4(X + 2 * TM * LDT + row * LDT + c4));
+    }
+}
+
+void launch_polyline_fused_x(const XBlockPX& p, int G, hipStream_t s) {
+    const size_t lds = PLF_LDS_BYTES + (NPL == 1 ? 3 * TM * LDT * 4 : 0);
+    hipLaunchKernelGGL(k_polyline_fused, dim3(G / 2), dim3(NTHREADS), lds, s, p);
+}
+
 // hoist + block of the polyline encoder on the packed tiling; `p` as for launch_xblock_x (n_rows = 20, n_pad = 32, tgt = src)
 void launch_polyline_block_x(const XBlockPX& p, int G, float* K, float* VT, float* kbias, hipStream_t s) {
     const int i1 = p.n_layer > 1 ? 1 : 0, i2 = p.n_layer > 2 ? 2 : 0;
@@ -535,6 +717,9 @@ __global__ void k_range_flag_take_encode(unsigned int* out) {
 void launch_range_flag_take_encode(unsigned int* out, hipStream_t s) { hipLaunchKernelGGL(k_range_flag_take_encode, dim3(1), dim3(1), 0, s, out); }
 
 hipError_t configure_encodex_kernels() {
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_polyline_fused), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                             PLF_LDS_BYTES + (NPL == 1 ? 3 * TM * LDT * 4 : 0));
+    if (e != hipSuccess) return e;
     return hipFuncSetAttribute(reinterpret_cast<const void*>(k_gru_scan_x), hipFuncAttributeMaxDynamicSharedMemorySize, SCANX_LDS_BYTES);
 }
 
