@@ -482,9 +482,10 @@ static void launch_xblock(const XBlockP& p, int G, hipStream_t s) {
 }
 
 // One attention block (K/V hoist of the targets + the source tiles through the layers) with either kernel family.
-static void run_block(bool xdl, const float* W, const XLayerW* L, const XLayerX* LX, int n_layer, const float* tgt, const uint8_t* tgt_valid,
+// Returns true when the block also did the node pooling asked for with pool_out / pool_valid (the fused polyline kernel).
+static bool run_block(bool xdl, const float* W, const XLayerW* L, const XLayerX* LX, int n_layer, const float* tgt, const uint8_t* tgt_valid,
                       int G, int n_tgt, int n_pad, float* K, float* VT, float* kbias, const float* src, const uint8_t* src_valid, float* dst,
-                      int n_rows, int eye, hipStream_t s) {
+                      int n_rows, int eye, hipStream_t s, float* pool_out = nullptr, uint8_t* pool_valid = nullptr) {
     if (xdl) {
         XBlockPX x{};
         x.W = W; x.n_layer = n_layer;
@@ -496,16 +497,17 @@ static void run_block(bool xdl, const float* W, const XLayerW* L, const XLayerX*
         // '2' (default): the fused kernel, K / V in LDS; '1': packed tiling with the K / V hoist through HBM; '0': padded tiling
         const int pmode = pe ? pe[0] - '0' : 2;
         if (pmode == 2 && n_tgt == 20 && n_rows == 20 && n_pad == 32 && tgt == src && tgt_valid == src_valid && !eye && G % 2 == 0) {
+            x.pool_out = pool_out; x.pool_valid = pool_valid;
             xh::launch_polyline_fused_x(x, G, s);
-            return;
+            return pool_out != nullptr;
         }
         if (pack && n_tgt == 20 && n_rows == 20 && n_pad == 32 && tgt == src && tgt_valid == src_valid && !eye && G % 4 == 0) {
             xh::launch_polyline_block_x(x, G, K, VT, kbias, s);
-            return;
+            return false;
         }
         xh::launch_kv_hoist_nx(W, L, LX, n_layer, tgt, tgt_valid, G, n_tgt, n_pad, K, VT, kbias, s);
         xh::launch_xblock_x(x, G, s);
-        return;
+        return false;
     }
     launch_kv_hoist_n(W, L, n_layer, tgt, tgt_valid, G, n_tgt, n_pad, K, VT, kbias, s);
     XBlockP x{};
@@ -513,6 +515,7 @@ static void run_block(bool xdl, const float* W, const XLayerW* L, const XLayerX*
     for (int l = 0; l < n_layer; ++l) x.L[l] = L[l];
     x.src = src; x.src_valid = src_valid; x.dst = dst; x.K = K; x.VT = VT; x.kbias = kbias; x.n_rows = n_rows; x.n_pad = n_pad; x.eye = eye;
     launch_xblock(x, G, s);
+    return false;
 }
 
 // Scratch of one latent-encoder pass (LatentEncoder.forward, latent_encoder.py:98-147) over S3 down-sampled steps.
@@ -696,7 +699,9 @@ int run_encode(struct ::tb_ctx* ctx, const tb_encode_io* io, hipStream_t s) {
         const int G = nb * P;
         const float* src = nodef + (size_t)b0 * P * 20 * 128;
         const uint8_t* sv = io->map_valid + (size_t)b0 * P * 20;
-        run_block(ctx->encode_kernel == 1, W, ew.densetnt, ew.densetnt_x, 3, src, sv, G, 20, 32, kn, vtn, kvn, src, sv, nodeo, 20, 0, s);
+        if (run_block(ctx->encode_kernel == 1, W, ew.densetnt, ew.densetnt_x, 3, src, sv, G, 20, 32, kn, vtn, kvn, src, sv, nodeo, 20, 0, s,
+                      plf + (size_t)b0 * P * 128, io->map_feature_valid + (size_t)b0 * P))
+            continue;
         const int nthr = G * 32;
         hipLaunchKernelGGL(k_pool_nodes, dim3((nthr + 255) / 256), dim3(256), 0, s, nodeo, sv, G, plf + (size_t)b0 * P * 128,
                            io->map_feature_valid + (size_t)b0 * P);

@@ -477,6 +477,22 @@ __global__ __launch_bounds__(NTHREADS) void k_polyline_fused(XBlockPX p) {
         }
         __syncthreads();
     }
+    if (p.pool_out) {  // MapEncoder: max over the valid nodes of the polyline (k_pool_nodes), one (polyline, feature) per thread
+        const int pl = tid >> 7, f = tid & 127;
+        float mx = -INFINITY;
+        bool any = false;
+#pragma unroll
+        for (int k = 0; k < PL_NODES; ++k) {
+            const int t = k < TM ? pl : 2, r = k < TM ? k : pl * 4 + (k - TM);
+            if (rowvalid[t * TM + r]) {
+                any = true;
+                mx = fmaxf(mx, X[(t * TM + r) * LDT + f]);
+            }
+        }
+        p.pool_out[(size_t)(g0 + pl) * H + f] = any ? mx : 0.f;
+        if (f == 0) p.pool_valid[g0 + pl] = any;
+        return;
+    }
     store_tile(p.dst + (size_t)g0 * PL_NODES * H, X, LDT, TM, tid);
     store_tile(p.dst + (size_t)(g0 + 1) * PL_NODES * H, X + TM * LDT, LDT, TM, tid);
 #pragma unroll
