@@ -355,9 +355,18 @@ __device__ __forceinline__ void wloadx(WUnitX& u, const WNextX& n, int lane) {
 
 __device__ __forceinline__ xh8 ldsb8(const xhalf* p) { return *reinterpret_cast<const xh8*>(p); }
 
+template <bool SWAP>
+__device__ __forceinline__ f32x4 mm_sw(const xh8& w, const xh8& x, const f32x4& acc) {
+    return SWAP ? mfma_h(x, w, acc) : mfma_h(w, x, acc);
+}
+
 // acc_{a,b} += unit . X^T from planes; requests the next unit in the MFMAs' shadow (two VMEM per three MFMAs).
 //   bp : this lane's B base = P + m*ld + kq*8 (+ chunk offset of the unit); plane_stride in fp16
 // Per chunk and tile three products; the two cross terms go to a second accumulator that is scaled by 2^-11 at the end.
+// SWAP: the MFMA operands change places, so the accumulators hold the TRANSPOSED tile -- lane (kq, m): tokens 4 kq + r of output
+// feature tile * 16 + m (the same dot products in the same order: same bits) -- which is the element order of a V fragment
+// (k_polyline_fused writes them with one 8-byte store per fragment half instead of four 2-byte scatters); the caller adds the bias.
+template <bool SWAP = false>
 __device__ __forceinline__ void wmmax_pf(f32x4& acc_a, f32x4& acc_b, const WUnitX& u, const xhalf* bp, int plane_stride, WUnitX& un,
                                          const WNextX& n, int lane) {
     const xh8* pa = wfragx(n, n.tile_a, lane);
@@ -382,13 +391,13 @@ __device__ __forceinline__ void wmmax_pf(f32x4& acc_a, f32x4& acc_b, const WUnit
             un.w[1][c][p] = pb[(c * NPL + p) * 64];
         }
         if (NPL == 2) {
-            mid_a = mfma_h(u.w[0][c][0], x[c][P1], mid_a);
-            mid_b = mfma_h(u.w[1][c][0], x[c][P1], mid_b);
-            mid_a = mfma_h(u.w[0][c][P1], x[c][0], mid_a);
-            mid_b = mfma_h(u.w[1][c][P1], x[c][0], mid_b);
+            mid_a = mm_sw<SWAP>(u.w[0][c][0], x[c][P1], mid_a);
+            mid_b = mm_sw<SWAP>(u.w[1][c][0], x[c][P1], mid_b);
+            mid_a = mm_sw<SWAP>(u.w[0][c][P1], x[c][0], mid_a);
+            mid_b = mm_sw<SWAP>(u.w[1][c][P1], x[c][0], mid_b);
         }
-        acc_a = mfma_h(u.w[0][c][0], x[c][0], acc_a);
-        acc_b = mfma_h(u.w[1][c][0], x[c][0], acc_b);
+        acc_a = mm_sw<SWAP>(u.w[0][c][0], x[c][0], acc_a);
+        acc_b = mm_sw<SWAP>(u.w[1][c][0], x[c][0], acc_b);
     }
     // pin the order: the LDS reads + 2 bias loads, then the weight loads spread under the MFMAs
     __builtin_amdgcn_sched_group_barrier(0x100, 4 * NPL, 0);
@@ -414,6 +423,7 @@ __device__ __forceinline__ void wmmax_pf(f32x4& acc_a, f32x4& acc_b, const WUnit
 }
 
 // the same unit without a follow-up request (the caller issues the next unit itself, see attention_head_x)
+template <bool SWAP = false>
 __device__ __forceinline__ void wmmax(f32x4& acc_a, f32x4& acc_b, const WUnitX& u, const xhalf* bp, int plane_stride) {
     xh8 x[4][NPL];
 #pragma unroll
@@ -424,13 +434,13 @@ __device__ __forceinline__ void wmmax(f32x4& acc_a, f32x4& acc_b, const WUnitX& 
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
         if (NPL == 2) {
-            mid_a = mfma_h(u.w[0][c][0], x[c][P1], mid_a);
-            mid_b = mfma_h(u.w[1][c][0], x[c][P1], mid_b);
-            mid_a = mfma_h(u.w[0][c][P1], x[c][0], mid_a);
-            mid_b = mfma_h(u.w[1][c][P1], x[c][0], mid_b);
+            mid_a = mm_sw<SWAP>(u.w[0][c][0], x[c][P1], mid_a);
+            mid_b = mm_sw<SWAP>(u.w[1][c][0], x[c][P1], mid_b);
+            mid_a = mm_sw<SWAP>(u.w[0][c][P1], x[c][0], mid_a);
+            mid_b = mm_sw<SWAP>(u.w[1][c][P1], x[c][0], mid_b);
         }
-        acc_a = mfma_h(u.w[0][c][0], x[c][0], acc_a);
-        acc_b = mfma_h(u.w[1][c][0], x[c][0], acc_b);
+        acc_a = mm_sw<SWAP>(u.w[0][c][0], x[c][0], acc_a);
+        acc_b = mm_sw<SWAP>(u.w[1][c][0], x[c][0], acc_b);
     }
     if (NPL == 2) {
         acc_a += mid_a * splat(SPLIT_INV);

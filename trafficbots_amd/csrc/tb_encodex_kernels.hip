@@ -382,17 +382,64 @@ __global__ __launch_bounds__(NTHREADS) void k_polyline_fused(XBlockPX p) {
         const XLayerX& LX = p.LX[l];
         const float* lnblk = p.W + L.ln1_g;
         // ---- K / V of the layer from the block input
-        load3(S);
-        __syncthreads();
-        layernorm_planes_n<3>(S, TM * LDT, P1, PS, lnblk + 256, lnblk + 384, tid);
+        if (l > 0) {  // (layer 0: X still holds the block input)
+            load3(S);
+            __syncthreads();
+        }
+        layernorm_planes_n<3>(l > 0 ? S : X, TM * LDT, P1, PS, lnblk + 256, lnblk + 384, tid);
         __syncthreads();
         {
             f32x4 ak[3][2], av[3][2];
             gemm3(u, u2, wnextx(p.W, LX.wkv, p.W + L.bkv, 8 + 2 * wave, 8 + 2 * wave + 1), P1, ak);
-            gemm3(u2, u, xlayer_first_x(p.W, L, LX, wave), P1, av);
-            kv_store_x(KL, VL, 0, wave, lane, ak[0], av[0], true);
-            kv_store_x(KL + KV_BLOCK_HALFS, VL + KV_BLOCK_HALFS, 0, wave, lane, ak[1], av[1], true);
-            if (m < 8) kv_store_key_x(KL + (m >> 2) * KV_BLOCK_HALFS, VL + (m >> 2) * KV_BLOCK_HALFS, 16 + (m & 3), wave, lane, ak[2], av[2], true);
+            // K: lane (kq, m) = token m, features 4 kq + r of the head's two feature tiles -> its 8-byte half of the key's K granule
+            auto k_store = [&](xhalf* kblk, int kt, int krow, const f32x4 (&a)[2]) {
+                xhalf* pk = kblk + wave * (NPL * 1024) + (kt * 64 + kq * 16 + krow) * 8;
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    xh4 h, lo;
+                    split2(a[t], h, lo);
+                    *reinterpret_cast<xh4*>(pk + t * 4) = h;
+                    if (NPL == 2) *reinterpret_cast<xh4*>(pk + t * 4 + 1024) = lo;
+                }
+            };
+            k_store(KL, 0, m, ak[0]);
+            k_store(KL + KV_BLOCK_HALFS, 0, m, ak[1]);
+            if (m < 8) k_store(KL + (m >> 2) * KV_BLOCK_HALFS, 1, m & 3, ak[2]);
+            // V with the MFMA operands swapped: lane (kq, m) holds tokens 4 kq + r of feature m of the head's two d tiles -- the element
+            // order of a V fragment half, one 8-byte store each (the token-major accumulators needed four 2-byte scatters per half, with
+            // 8-way LDS bank conflicts).  The bias enters as the initial accumulator, as in the other layout: same bits.
+            {
+                const float* bv = p.W + L.bkv + (8 + 2 * wave) * 16 + m;
+                const f32x4 ba = splat(bv[0]), bb = splat(bv[16]);
+#pragma unroll
+                for (int t = 0; t < 3; ++t) { av[t][0] = ba; av[t][1] = bb; }
+                wmmax_pf<true>(av[0][0], av[0][1], u2, P1 + po, PLANE, u, xlayer_first_x(p.W, L, LX, wave), lane);
+                wmmax<true>(av[1][0], av[1][1], u2, P1 + PS + po, PLANE);
+                wmmax<true>(av[2][0], av[2][1], u2, P1 + 2 * PS + po, PLANE);
+                auto v_store = [&](xhalf* vblk, int half, const f32x4 (&a)[2]) {
+                    xhalf* pv = vblk + wave * (NPL * 1024) + (kq * 16 + m) * 8 + half * 4;
+#pragma unroll
+                    for (int dt = 0; dt < 2; ++dt) {
+                        xh4 h, lo;
+                        split2(a[dt], h, lo);
+                        *reinterpret_cast<xh4*>(pv + dt * 512) = h;
+                        if (NPL == 2) *reinterpret_cast<xh4*>(pv + dt * 512 + 1024) = lo;
+                    }
+                };
+                v_store(VL, 0, av[0]);
+                v_store(VL + KV_BLOCK_HALFS, 0, av[1]);
+                // tail tile: lane group kq = 0 / 1 holds nodes 16 .. 19 of polyline 0 / 1 = keys 16 .. 19 = elements 4 .. 7 of key quad 0
+                if (kq < 2) {
+                    xhalf* pv = VL + kq * KV_BLOCK_HALFS + wave * (NPL * 1024) + m * 8 + 4;
+#pragma unroll
+                    for (int dt = 0; dt < 2; ++dt) {
+                        xh4 h, lo;
+                        split2(av[2][dt], h, lo);
+                        *reinterpret_cast<xh4*>(pv + dt * 512) = h;
+                        if (NPL == 2) *reinterpret_cast<xh4*>(pv + dt * 512 + 1024) = lo;
+                    }
+                }
+            }
         }
         __syncthreads();  // (the projections have read P1: LayerNorm 1 may overwrite it; K / V are in place)
         // ---- the layer on the three tiles
