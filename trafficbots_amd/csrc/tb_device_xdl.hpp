@@ -665,6 +665,44 @@ __device__ __forceinline__ bool attention_head_x(const f32x4 (&q)[2], AttnPreX& 
     return novalid;
 }
 
+// The same attention when the whole key set is ONE 32-key block (a polyline's 20 nodes, a scene's lit traffic lights): no walk, so no
+// second QK for a "next" block, no rescale, no re-loads -- and nothing that pins the schedule, so that two calls for independent
+// (query tile, key block) pairs interleave in one instruction stream.  Arithmetic and its order are those of attention_head_x with
+// n_key_pad = 32 (the correction factor it multiplies by is an exact 0 x 0): same bits.
+__device__ __forceinline__ bool attention_oneblock_x(const f32x4 (&q)[2], const xhalf* __restrict__ Kh, const xhalf* __restrict__ Vh,
+                                                     const float* __restrict__ keybias, int head, int lane, f32x4 (&o)[2]) {
+    const int kq = lane >> 4;
+    KFragX kf;
+    VFragX vf;
+    k_load_x(kf, Kh + head * (NPL * 1024) + lane * 8, keybias + kq * 4, 0);
+    v_load_x(vf, Vh + head * (NPL * 1024) + lane * 8, 0);
+    xh8 qh, ql;
+    split8(q[0], q[1], qh, ql);
+    f32x4 s[2], c[2];
+    attn_qk_x(kf, qh, ql, s, c);
+    float sv[8], new_max, alpha;
+    attn_stats_x<false>(s, c, kf.kb, kq * 4, -1, RUN_MAX_NONE, sv, new_max, alpha);
+    float pr[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) pr[r] = exp2_neg(sv[r] - new_max);
+    float run_sum = 0.f * alpha + (((pr[0] + pr[1]) + (pr[2] + pr[3])) + ((pr[4] + pr[5]) + (pr[6] + pr[7])));
+    xh8 ph, pl;
+    split8<false>(f32x4{pr[0], pr[1], pr[2], pr[3]}, f32x4{pr[4], pr[5], pr[6], pr[7]}, ph, pl);
+    f32x4 oh[2] = {splat(0.f), splat(0.f)}, oc[2] = {splat(0.f), splat(0.f)};
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) {
+        if (NPL == 2) oc[dt] = mfma_h(vf.va[dt][0], pl, oc[dt]);
+        oh[dt] = mfma_h(vf.va[dt][0], ph, oh[dt]);
+        if (NPL == 2) oc[dt] = mfma_h(vf.va[dt][P1], ph, oc[dt]);
+    }
+    run_sum = rows_sum(run_sum);
+    const bool novalid = !(run_sum > 0.f);
+    const float inv = novalid ? 0.f : 1.0f / run_sum;
+    o[0] = (oh[0] + oc[0] * splat(SPLIT_INV)) * splat(inv);
+    o[1] = (oh[1] + oc[1] * splat(SPLIT_INV)) * splat(inv);
+    return novalid;
+}
+
 // K / V accumulators of a 16-token tile -> global, fragment-major (see above).  ak / av : this wave's K / V tiles
 // (features (2 wave + t)*16 + 4 kq + r of token m); the wave is head `wave`.
 // `tok` = the key slot this lane's token goes to (its index, or its rank among the valid tokens when the hoist compacts)

@@ -448,37 +448,26 @@ __global__ __launch_bounds__(NTHREADS) void k_polyline_fused(XBlockPX p) {
         {
             f32x4 q[3][2];
             gemm3(u, u2, wstdx(p.W, LX.wo, p.W + L.bo, wave), P1, q);
-            AttnPreX apre;
-            f32x4 o[2];
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const xhalf* kt = KL + t * KV_BLOCK_HALFS;
-                const xhalf* vt = VL + t * KV_BLOCK_HALFS;
-                attention_prefetch_x(apre, kt, vt, kb + t * KEYPAD, KEYPAD, 0, wave, lane);
-                const bool nov = attention_head_x<false, false>(q[t], apre, kt, vt, kb + t * KEYPAD, KEYPAD, 0, wave, lane, -1, o, u2,
-                                                                wstdx(p.W, LX.wo, p.W + L.bo, wave));
-                planes_store_c<false>(P2 + t * PS, 2 * wave, lane, o[0]);
-                planes_store_c<false>(P2 + t * PS, 2 * wave + 1, lane, o[1]);
-                if (wave == 0 && kq == 0) novalid_s[t * TM + m] = nov ? 1 : 0;
+            // four one-block attentions (tile 0 / polyline 0, tile 1 / polyline 1, the tail tile against both), written without anything
+            // that pins the schedule so that their latency chains overlap
+            f32x4 o0[2], o1[2], oa[2], ob[2];
+            const bool n0 = attention_oneblock_x(q[0], KL, VL, kb, wave, lane, o0);
+            const bool n1 = attention_oneblock_x(q[1], KL + KV_BLOCK_HALFS, VL + KV_BLOCK_HALFS, kb + KEYPAD, wave, lane, o1);
+            const bool na = attention_oneblock_x(q[2], KL, VL, kb, wave, lane, oa);
+            const bool nb = attention_oneblock_x(q[2], KL + KV_BLOCK_HALFS, VL + KV_BLOCK_HALFS, kb + KEYPAD, wave, lane, ob);
+            planes_store_c<false>(P2, 2 * wave, lane, o0[0]);
+            planes_store_c<false>(P2, 2 * wave + 1, lane, o0[1]);
+            planes_store_c<false>(P2 + PS, 2 * wave, lane, o1[0]);
+            planes_store_c<false>(P2 + PS, 2 * wave + 1, lane, o1[1]);
+            const int grp = m >> 2;  // tail rows 0 .. 3 / 4 .. 7 belong to polyline 0 / 1, rows 8 .. 15 are padding
+            const f32x4 z = splat(0.f);
+            planes_store_c<false>(P2 + 2 * PS, 2 * wave, lane, grp == 0 ? oa[0] : (grp == 1 ? ob[0] : z));
+            planes_store_c<false>(P2 + 2 * PS, 2 * wave + 1, lane, grp == 0 ? oa[1] : (grp == 1 ? ob[1] : z));
+            if (wave == 0 && kq == 0) {
+                novalid_s[m] = n0 ? 1 : 0;
+                novalid_s[TM + m] = n1 ? 1 : 0;
+                novalid_s[2 * TM + m] = (grp == 0 ? na : (grp == 1 ? nb : true)) ? 1 : 0;
             }
-            f32x4 osel[2] = {splat(0.f), splat(0.f)};
-            bool novsel = true;
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const xhalf* kt = KL + j * KV_BLOCK_HALFS;
-                const xhalf* vt = VL + j * KV_BLOCK_HALFS;
-                attention_prefetch_x(apre, kt, vt, kb + j * KEYPAD, KEYPAD, 0, wave, lane);
-                const bool nov = attention_head_x<false, false>(q[2], apre, kt, vt, kb + j * KEYPAD, KEYPAD, 0, wave, lane, -1, o, u2,
-                                                                wstdx(p.W, LX.wo, p.W + L.bo, wave));
-                if ((m >> 2) == j) {
-                    osel[0] = o[0];
-                    osel[1] = o[1];
-                    novsel = nov;
-                }
-            }
-            planes_store_c<false>(P2 + 2 * PS, 2 * wave, lane, osel[0]);
-            planes_store_c<false>(P2 + 2 * PS, 2 * wave + 1, lane, osel[1]);
-            if (wave == 0 && kq == 0) novalid_s[2 * TM + m] = novsel ? 1 : 0;
         }
         __syncthreads();
         {
