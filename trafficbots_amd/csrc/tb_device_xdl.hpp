@@ -669,15 +669,12 @@ __device__ __forceinline__ bool attention_head_x(const f32x4 (&q)[2], AttnPreX& 
 // second QK for a "next" block, no rescale, no re-loads -- and nothing that pins the schedule, so that two calls for independent
 // (query tile, key block) pairs interleave in one instruction stream.  Arithmetic and its order are those of attention_head_x with
 // n_key_pad = 32 (the correction factor it multiplies by is an exact 0 x 0): same bits.
-__device__ __forceinline__ bool attention_oneblock_x(const f32x4 (&q)[2], const xhalf* __restrict__ Kh, const xhalf* __restrict__ Vh,
-                                                     const float* __restrict__ keybias, int head, int lane, f32x4 (&o)[2]) {
+template <class R = RangeFlag>
+__device__ __forceinline__ bool attention_oneblock_pre_x(const f32x4 (&q)[2], const KFragX& kf, const VFragX& vf, int lane, f32x4 (&o)[2],
+                                                         R&& amax = R{}) {
     const int kq = lane >> 4;
-    KFragX kf;
-    VFragX vf;
-    k_load_x(kf, Kh + head * (NPL * 1024) + lane * 8, keybias + kq * 4, 0);
-    v_load_x(vf, Vh + head * (NPL * 1024) + lane * 8, 0);
     xh8 qh, ql;
-    split8(q[0], q[1], qh, ql);
+    split8(q[0], q[1], qh, ql, amax);
     f32x4 s[2], c[2];
     attn_qk_x(kf, qh, ql, s, c);
     float sv[8], new_max, alpha;
@@ -701,6 +698,14 @@ __device__ __forceinline__ bool attention_oneblock_x(const f32x4 (&q)[2], const 
     o[0] = (oh[0] + oc[0] * splat(SPLIT_INV)) * splat(inv);
     o[1] = (oh[1] + oc[1] * splat(SPLIT_INV)) * splat(inv);
     return novalid;
+}
+__device__ __forceinline__ bool attention_oneblock_x(const f32x4 (&q)[2], const xhalf* __restrict__ Kh, const xhalf* __restrict__ Vh,
+                                                     const float* __restrict__ keybias, int head, int lane, f32x4 (&o)[2]) {
+    KFragX kf;
+    VFragX vf;
+    k_load_x(kf, Kh + head * (NPL * 1024) + lane * 8, keybias + (lane >> 4) * 4, 0);
+    v_load_x(vf, Vh + head * (NPL * 1024) + lane * 8, 0);
+    return attention_oneblock_pre_x(q, kf, vf, lane, o);
 }
 
 // K / V accumulators of a 16-token tile -> global, fragment-major (see above).  ak / av : this wave's K / V tiles
