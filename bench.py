@@ -430,13 +430,18 @@ def run_rank(args, rank: int, local_rank: int, world: int) -> None:
     eng, scene, batch, enc = c["eng"], c["scene"], c["batch"], c["enc"]
 
     # ---- one-time encoders (timed separately)
-    enc_t = []
+    enc_t, enc_g = [], []
     for _ in range(3):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t0 = time.time()
+        e0.record()
         eng.encode_scene(scene)
+        e1.record()
         torch.cuda.synchronize()
         enc_t.append((time.time() - t0) * 1e3)
-    encode_ms = sorted(enc_t)[1]  # median of three
+        enc_g.append(e0.elapsed_time(e1))
+    encode_ms = sorted(enc_t)[1]      # median of three: wall clock of one synchronous call (host enqueue + GPU + synchronize)
+    encode_gpu_ms = sorted(enc_g)[1]  # the same calls between two events on the caller's stream (the side stream is joined before the second)
 
     # a generation-2 collection of the interpreter (tens of ms with the weight / scene dicts alive) in the launching thread
     # starves the stream right after a synchronize, when nothing is queued ahead: collect now, keep the collector off while timing
@@ -568,6 +573,7 @@ def run_rank(args, rank: int, local_rank: int, world: int) -> None:
             "pmc_matches_build": _pmc_records().get("_matches_build", False),
             "lib_sha256": lib_sha256(),
             "encode_ms": encode_ms,
+            "encode_gpu_ms": encode_gpu_ms,
             "pass_ms": {"min": pass_ms[0], "median": pass_ms[len(pass_ms) // 2], "max": pass_ms[-1]},
             "kernel_us": {"k_step_fused": k_us, "n_fused": tm["n_fused"], "edge_launches_ms": tm["edge_ms"], "prologue_ms": tm["prologue_ms"],
                           "note": "per rollout: n_fused fused launches; edge_launches_ms = the batched warm-start launch (A halves of the "
