@@ -666,8 +666,14 @@ int run_encode(struct ::tb_ctx* ctx, const tb_encode_io* io, hipStream_t s) {
         if (ctx->encode_kernel == 1) xh::launch_gru_scan_x(sp, a_pad, st);
         else hipLaunchKernelGGL(k_gru_scan, dim3(a_pad / TM, B), dim3(NTHREADS), (8 * TM * LDT + 16) * sizeof(float), st, sp);
     };
-    // ---- input features (sc_input.py:100-140 + input_pe_encoder.py:52-59)
+    // ---- input features (sc_input.py:100-140 + input_pe_encoder.py:52-59); the map tokens first: they head the critical path
     {
+        TokP m{};
+        m.W = W; m.pe_fxy = ew.pe_fxy; m.pe_fyaw = ew.pe_fyaw;
+        m.kind = 2; m.mlp = ew.map_enc; m.n_tok = B * P * 20; m.per_scene = P * 20; m.inner = 20;
+        m.valid = io->map_valid; m.pos = io->map_pos; m.dir = io->map_dir; m.cls = io->map_type; m.out = nodef;
+        m.ext_attr = io->ext_map_attr; m.ext_pe = io->ext_map_pe;
+        hipLaunchKernelGGL(k_encode_tokens, dim3((m.n_tok + TM * TOK_GROUPS - 1) / (TM * TOK_GROUPS)), dim3(NTHREADS), 0, s, m);
         TokP t{};
         t.W = W; t.pe_fxy = ew.pe_fxy; t.pe_fyaw = ew.pe_fyaw;
         t.kind = 0; t.mlp = ew.agent_enc; t.n_tok = B * NH * A; t.per_scene = NH * A; t.inner = A;
@@ -686,12 +692,6 @@ int run_encode(struct ::tb_ctx* ctx, const tb_encode_io* io, hipStream_t s) {
             dest_scan(s2);
             TB_HIP(ctx, hipEventRecord(ctx->enc_join, s2));
         }
-        TokP m{};
-        m.W = W; m.pe_fxy = ew.pe_fxy; m.pe_fyaw = ew.pe_fyaw;
-        m.kind = 2; m.mlp = ew.map_enc; m.n_tok = B * P * 20; m.per_scene = P * 20; m.inner = 20;
-        m.valid = io->map_valid; m.pos = io->map_pos; m.dir = io->map_dir; m.cls = io->map_type; m.out = nodef;
-        m.ext_attr = io->ext_map_attr; m.ext_pe = io->ext_map_pe;
-        hipLaunchKernelGGL(k_encode_tokens, dim3((m.n_tok + TM * TOK_GROUPS - 1) / (TM * TOK_GROUPS)), dim3(NTHREADS), 0, s, m);
     }
     // ---- map encoder
     for (int b0 = 0; b0 < B; b0 += scenes_per_chunk) {

@@ -226,9 +226,9 @@ def load() -> C.CDLL:
 def ptr(t, ctype):
     """Device pointer of a contiguous torch tensor (or NULL for None) as a ctypes pointer."""
     if t is None:
-        return C.cast(None, ctype)
+        return ctype()  # NULL
     assert t.is_contiguous(), "tensor handed to the C ABI must be contiguous"
-    return C.cast(C.c_void_p(t.data_ptr()), ctype)
+    return C.cast(t.data_ptr(), ctype)
 
 
 def make_config(cfg: Dict) -> TbConfig:
