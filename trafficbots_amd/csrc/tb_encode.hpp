@@ -40,7 +40,7 @@ struct XBlockPX {
     const float* kbias;        // [G][n_pad] additive key mask
     int n_rows, n_pad;
     int eye;                   // MultiAgentTF: self key masked; groups with exactly one valid row pass through
-    // k_polyline_fused only: when set, the max over the valid nodes of each polyline (k_pool_nodes) is written here instead of `dst`
+    // k_polyline_fused only (required there): the max over the valid nodes of each polyline (k_pool_nodes); `dst` is not written
     float* pool_out;           // [G][128]
     uint8_t* pool_valid;       // [G]
 };

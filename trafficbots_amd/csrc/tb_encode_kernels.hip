@@ -496,10 +496,10 @@ static bool run_block(bool xdl, const float* W, const XLayerW* L, const XLayerX*
         const bool pack = !(pe && pe[0] == '0');
         // '2' (default): the fused kernel, K / V in LDS; '1': packed tiling with the K / V hoist through HBM; '0': padded tiling
         const int pmode = pe ? pe[0] - '0' : 2;
-        if (pmode == 2 && n_tgt == 20 && n_rows == 20 && n_pad == 32 && tgt == src && tgt_valid == src_valid && !eye && G % 2 == 0) {
+        if (pmode == 2 && pool_out && n_tgt == 20 && n_rows == 20 && n_pad == 32 && tgt == src && tgt_valid == src_valid && !eye && G % 2 == 0) {
             x.pool_out = pool_out; x.pool_valid = pool_valid;
             xh::launch_polyline_fused_x(x, G, s);
-            return pool_out != nullptr;
+            return true;
         }
         if (pack && n_tgt == 20 && n_rows == 20 && n_pad == 32 && tgt == src && tgt_valid == src_valid && !eye && G % 4 == 0) {
             xh::launch_polyline_block_x(x, G, K, VT, kbias, s);
@@ -618,7 +618,7 @@ int run_encode(struct ::tb_ctx* ctx, const tb_encode_io* io, hipStream_t s) {
     LatentWs lws;
     auto carve = [&](Carver& c) {
         nodef = c.take<float>((size_t)B * P * 20 * 128);
-        nodeo = c.take<float>((size_t)scenes_per_chunk * P * 20 * 128);
+        nodeo = c.take<float>(kv_scenes * P * 20 * 128);  // (node features after the block: the fused kernel pools them in place)
         kn = c.take<float>(kv_scenes * P * 3 * 32 * 128);
         vtn = c.take<float>(kv_scenes * P * 3 * 128 * 32);
         kvn = c.take<float>(kv_scenes * P * 32);

@@ -513,7 +513,8 @@ __global__ __launch_bounds__(NTHREADS) void k_polyline_fused(XBlockPX p) {
         }
         __syncthreads();
     }
-    if (p.pool_out) {  // MapEncoder: max over the valid nodes of the polyline (k_pool_nodes), one (polyline, feature) per thread
+    {   // MapEncoder: max over the valid nodes of the polyline (k_pool_nodes), one (polyline, feature) per thread; the node features
+        // themselves have no other consumer and are not written out
         const int pl = tid >> 7, f = tid & 127;
         float mx = -INFINITY;
         bool any = false;
@@ -527,15 +528,6 @@ __global__ __launch_bounds__(NTHREADS) void k_polyline_fused(XBlockPX p) {
         }
         p.pool_out[(size_t)(g0 + pl) * H + f] = any ? mx : 0.f;
         if (f == 0) p.pool_valid[g0 + pl] = any;
-        return;
-    }
-    store_tile(p.dst + (size_t)g0 * PL_NODES * H, X, LDT, TM, tid);
-    store_tile(p.dst + (size_t)(g0 + 1) * PL_NODES * H, X + TM * LDT, LDT, TM, tid);
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int idx = tid + i * NTHREADS;
-        const int row = idx >> 5, c4 = (idx & 31) * 4;
-        if (row < 8) st4(p.dst + ((size_t)(g0 + (row >> 2)) * PL_NODES + 16 + (row & 3)) * H + c4, lds4(X + 2 * TM * LDT + row * LDT + c4));
     }
 }
 
