@@ -137,6 +137,15 @@ typedef struct tb_rollout_io {
      * bytes, read while the launches are enqueued: where hidden_drop[s] is set the GRU hidden state of ALL instances is zeroed after
      * step s has been recorded (the reference draws one `torch.rand(1) < p_drop_hidden` per step for the whole batch). */
     const uint8_t* hidden_drop;    /* [S] host memory */
+    /* optional (round 4): draw the personalities INSIDE the rollout prologue (`MyDist.sample`, distributions.py:18-38, called by
+     * TrafficBots.forward on the first step, traffic_bots.py:196-199).  When latent_sample_out is non-NULL the prologue computes
+     *   z[n,a,:] = deterministic[n,a] ? latent_mean[n / K, a, :] : latent_mean[n / K, a, :] + latent_eps[n,a,:] * exp(log_std)
+     * (log_std of the prior, or of the posterior with latent_posterior), writes it to latent_sample_out, and uses it as the sample;
+     * `latent_sample` is then ignored and may be NULL.  latent_eps NULL = every agent takes the mean; latent_deterministic NULL =
+     * no agent is deterministic. */
+    const float* latent_eps;             /* [N,A,16] standard-normal draws, or NULL */
+    const uint8_t* latent_deterministic; /* [N,A] or NULL */
+    float* latent_sample_out;            /* [N,A,16] or NULL */
 } tb_rollout_io;
 
 /* Replaces: WaymoMotion.rollout (+ per-step WaymoMotion.forward, TrafficBots.forward, ActionHead,
@@ -439,10 +448,45 @@ typedef struct tb_metric_io {
 } tb_metric_io;
 int tb_metric_partials(tb_ctx* ctx, const tb_metric_io* io, tb_stream stream);
 
+/* -- the two samplers of joint_future_pred (waymo_motion.py:478-572) -------------------------------------------------------- */
+/* Replaces: DiagGaussian / MyDist.sample + log_prob (src/models/modules/distributions.py:18-59) on the personality distribution that
+ * LatentEncoder.forward returns (latent_encoder.py:70-147).  N = n_scene * k_futures, instance n uses the mean of scene n / k_futures
+ * (what `latent.repeat_interleave_(k_futures, 0)` materialises, waymo_motion.py:493). */
+typedef struct tb_latent_sample_io {
+    int32_t n_scene, k_futures, n_agent;
+    int32_t posterior;             /* nonzero: latent_post_dist.log_std, else latent_prior_dist.log_std */
+    const float* mean;             /* [B,A,16] */
+    const float* eps;              /* [N,A,16] standard-normal draws (Normal.rsample's), or NULL = every agent takes the mean */
+    const uint8_t* deterministic;  /* [N,A] or NULL: where set the agent takes the mean (the tensor form of `deterministic`) */
+    const float* forced;           /* [N,A,16] or NULL: score THIS sample instead of drawing one (log_prob(sample)) */
+    float* sample;                 /* [N,A,16] out, or NULL */
+    float* log_prob;               /* [N,A] out, or NULL: Independent(Normal).log_prob of the sample */
+} tb_latent_sample_io;
+int tb_latent_sample(tb_ctx* ctx, const tb_latent_sample_io* io, tb_stream stream);
+
+/* Replaces: DestCategorical.sample + log_prob (distributions.py:158-201) on the destination distribution of DestPredictor.forward
+ * (goal_manager.py:202-333): arg max of the probabilities where deterministic, a draw elsewhere, and the log-prob of the result.
+ * The draw is the inverse CDF of an EXPLICIT uniform number per (instance, agent) -- the reference calls torch.multinomial on torch's
+ * global stream, which no other implementation can replay (its goldens force `goal_sample` instead: `forced`). */
+typedef struct tb_dest_sample_io {
+    int32_t n_scene, k_futures, n_agent, n_pl;
+    /* 0: log_prob = logits - logsumexp(logits)  (Categorical(logits=), distributions.py:166-168)
+     * 1: the distribution after `repeat_interleave_` (:196-199), Categorical(probs=softmax): log(clamp(probs, eps, 1 - eps)) */
+    int32_t from_probs;
+    const float* dest_logits;      /* [B,A,P] masked, un-normalised (tb_encode_io.dest_logits) */
+    const float* uniform;          /* [N,A] draws in [0,1), or NULL = every agent takes the arg max */
+    const uint8_t* deterministic;  /* [N,A] or NULL */
+    const int32_t* forced;         /* [N,A] or NULL: score THESE destinations instead of choosing (log_prob(sample)) */
+    int32_t* sample;               /* [N,A] out, or NULL */
+    float* log_prob;               /* [N,A] out, or NULL */
+    float* probs;                  /* [B,A,P] out, or NULL: softmax(dest_logits) (DestCategorical.probs) */
+} tb_dest_sample_io;
+int tb_dest_sample(tb_ctx* ctx, const tb_dest_sample_io* io, tb_stream stream);
+
 /* sizeof() of the structs of this header as the library was compiled: out[0..5] = tb_config, tb_rollout_io, tb_encode_io,
- * tb_rule_io, tb_post_io, tb_metric_io; out[6] = the pointer size; out[7..8] = tb_posterior_io, tb_train_io; out[9..10] = tb_step_override, tb_forward_io -- lets a binding
- * check its mirror of the layouts before the first call (no GPU needed). */
-void tb_struct_sizes(int32_t out[11]);
+ * tb_rule_io, tb_post_io, tb_metric_io; out[6] = the pointer size; out[7..8] = tb_posterior_io, tb_train_io; out[9..10] = tb_step_override, tb_forward_io;
+ * out[11..12] = tb_latent_sample_io, tb_dest_sample_io -- lets a binding check its mirror of the layouts before the first call (no GPU needed). */
+void tb_struct_sizes(int32_t out[13]);
 
 #ifdef __cplusplus
 }

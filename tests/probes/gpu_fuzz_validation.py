@@ -83,15 +83,14 @@ for ci in range(n_cases):
     if not np.isfinite(buf.preds.cpu().numpy()).all():
         msgs.append("non-finite preds")
     if e_xy > 1e-4:
-        # dense or long cases: judge against the MEASURED rounding noise of the oracle's own arithmetic on this case -- 8 fp32 runs on
-        # re-ordered batches with re-ordered Linear sums (tools/ensemble.py, Oracle(gemm_order_seed)), one-sided prediction bound at alpha = 5e-4, no multipliers (tests/test_gpu_parity.py
-        # _assert_closed_loop / _oracle_ensemble; round 2 used max(1e-4, 1.5 / 2.5 x one fp32-vs-fp64 run))
+        # dense or long cases: the parity tests' ONE closed-loop rule (tools/ensemble.py::closed_loop_rule, frozen in round 4) against an
+        # ensemble measured on the spot: 16 fp32 oracle runs on re-ordered batches with re-ordered Linear sums (Oracle(gemm_order_seed))
         from tools import ensemble
 
         with torch.no_grad():
             r64 = Oracle(sd, cfg, torch.float64).reactive_replay(batch, step_end)
             mem32, mem64 = [], []
-            for mi in range(8):
+            for mi in range(16):
                 pb, perm = ensemble.permute_batch({k_: np.asarray(v) for k_, v in batch.items()}, 7919 * (ci + 1) + mi)
                 rm = Oracle(sd, cfg, torch.float32, gemm_order_seed=4001 * (ci + 1) + mi).reactive_replay(pb, step_end)
                 mp, mv = perm.agents_back(rm["preds"].numpy()), perm.agents_back(rm["valid"].numpy())
@@ -102,12 +101,11 @@ for ci in range(n_cases):
         d32 = ensemble.spread_per_step(hp, r["preds"].numpy(), v32, 2)
         d64 = ensemble.spread_per_step(hp, r64["preds"].numpy(), v64, 2)
         base64 = ensemble.spread_per_step(r["preds"].numpy(), r64["preds"].numpy(), v64, 2)
-        p64, p32, cb = ensemble.prediction_bound(np.stack([base64] + mem64)), ensemble.prediction_bound(np.stack(mem32)), np.maximum.accumulate(base64)
-        b64, b32 = np.maximum(p64, cb + p32), np.maximum(p32, cb + p64)  # (the two triangles of tests/test_gpu_parity.py)
-        ok = bool((d64 <= np.maximum(1e-4, b64)).all() and (d32 <= np.maximum(1e-4, b32)).all())
-        print(f"        ensemble: oracle fp32 vs fp64 {base64.max():.1e} (members up to {np.stack(mem64).max():.1e}); hip vs fp64 {d64.max():.1e} "
-              f"(bound {b64.max():.1e}), hip vs fp32 {d32.max():.1e} (bound {b32.max():.1e}, members up to {np.stack(mem32).max():.1e}) -> "
-              f"{'inside' if ok else 'OUTSIDE'}")
+        rr_ = ensemble.closed_loop_rule(d32, d64, np.stack(mem32), np.stack([base64] + mem64))
+        ok = rr_["ok"]
+        print(f"        ensemble: oracle fp32 vs fp64 {base64.max():.1e} (members up to {rr_['members_max_vs_fp64']:.1e}); hip vs fp64 {d64.max():.1e} "
+              f"(bound {rr_['bound_vs_fp64']:.1e}, rank {rr_['rank_vs_fp64']}), hip vs fp32 {d32.max():.1e} (bound {rr_['bound_vs_fp32']:.1e}, rank "
+              f"{rr_['rank_vs_fp32']}) -> {'inside' if ok else 'OUTSIDE'}")
         if not ok:
             msgs.append("closed-loop envelope")
     if e_post > 2e-5 or e_rew > 1e-5:

@@ -2,12 +2,13 @@
 `encode_input_features`, `model.init`, the stateful `forward(..., state_override=, mask_state_override=)` with the overrides applied
 per call, the what-if rollout (`gt_sdc`), and the range guard of the fp16-pair kernels (`tb_check_status`)."""
 import copy
+import os
 
 import numpy as np
 import pytest
 import torch
 
-from conftest import golden_inputs, load_golden
+from conftest import ROOT, golden_inputs, load_golden
 
 pytestmark = pytest.mark.gpu
 
@@ -252,9 +253,15 @@ def test_forward_action_override_against_reference_golden():
     assert np.abs(buf.action_log_probs.cpu().numpy() - g["action_log_probs"]).max() <= 2e-5  # (the policy's own action's, unchanged)
     d = np.abs(buf.preds.cpu().numpy() - g["preds"]) * g["valid"][..., None]
     assert d[..., :10, :2].max() <= 1e-5
-    spread = np.maximum.accumulate(g["ens_d32"].max(0))
+    # the one closed-loop rule (tools/ensemble.py::closed_loop_rule) against the golden's independent reference ensemble
+    from tools import ensemble
+
+    e = np.load(os.path.join(ROOT, "tests", "golden", "ensg", "action_override.npz"))
+    both = (g["valid"] & g["valid_fp64"])[..., None]
+    d64 = (np.abs(buf.preds.cpu().numpy().astype(np.float64) - g["preds_fp64"]) * both)[..., :2].max(axis=(0, 1, 2, 4))
     per_step = d[..., :2].max(axis=(0, 1, 2, 4))
-    assert (per_step <= np.maximum(1e-4, spread)).all(), (per_step.max(), spread.max())
+    r = ensemble.closed_loop_rule(per_step, d64, e["ensg_d32"], e["ensg_d64"], n_flat=per_step.shape[0])
+    assert r["ok"], {k_: v for k_, v in r.items() if k_ != "per_step"}
     plain = drive(False)
     assert float((plain.preds - buf.preds).abs().max()) > 0.05  # the override really steers
 

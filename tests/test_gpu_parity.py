@@ -6,32 +6,24 @@ Tolerances (fp32, stated per north_star):
   * one-shot products (encoder features, prior mean, destination logits, re-synced one-step policy
     feature): <= 2e-5 abs on O(1) values;
   * open-loop / teacher-forced steps (<= step 10): <= 1e-5 m;
-  * closed-loop xy over the 8 s horizon: north_star's target is <= 1e-4 m.  The rollout is chaotic: the
-    REFERENCE's own fp32 run differs from its fp64 run by up to 1.3e-4 m at step 90 on the headline shape
-    (fixtures `preds_fp64`), so two correct fp32 implementations cannot agree better than that noise.  The noise is MEASURED, not
-    chosen: every closed-loop golden carries an ensemble of 32 further fp32 runs of the reference on mathematically equivalent
-    re-orderings of the batch (agent slots / polylines / stop points permuted, other batch sizes: tools/ensemble.py,
-    `ens_d32` [32,S] = per-step max |member - base fp32|, `ens_d64` [33,S] = per-step max |member - fp64 twin|, row 0 = the base
-    run).  Asserted per step t, with spread(t) = tools/ensemble.py::prediction_bound of the members: the one-sided prediction limit
-    (alpha = 5e-4) of the log-normal fit to the members' running-max deviations -- width from the measured spread and the stated
-    significance level, no free multiplier (the plain max over M members fails a correct run with probability 1/(M+1) per case):
-        (a) |hip - reference fp64|(t) <= max(1e-4, B64(t), |base fp32 - fp64|(t) + B32(t))
-        (b) |hip - reference fp32|(t) <= max(1e-4, B32(t), |base fp32 - fp64|(t) + B64(t))
-            with B64 / B32 = the prediction limits of the members' distances to the fp64 twin / to the base fp32 run: no farther from
-            either anchor than a re-ordered run of the reference arithmetic is predicted to be, or than the triangle through the other
-            anchor allows.  The triangles are needed because the members are not independent of the base run: they share its GEMM
-            rounding (reference-made ensembles: only the attention / pooling sums are re-ordered -- their spread around the base
-            under-estimates the distance of an independent implementation) and they follow its rounding path for most of the horizon
-            (their distances to the truth are nearly one number: log-std 0.0 .. 0.25 over the goldens against 0.16 .. 0.58 for their
-            distances to the base -- a limit fitted to them alone is too narrow for a run that does not share that path; the suite's
-            oracle-made ensemble of the validation joint_future_pred showed it: all 9 members within 1 % of 7.3e-5 m at step 60,
-            HIP at 9.3e-5 m, 1.3e-4 at step 70 against a collapsed limit of 1.1e-4).  Measured terms only, no multipliers.
-        (c) north_star's flat bound where it is attainable: |hip - reference fp32|(t) <= 1e-4 over the WHOLE horizon on the
-            small shapes (<= 16 agents without dense interaction: c1_plumbing, small_k1, degenerate, val_small, val_alt_losses)
-            and for every step t <= 60 on the headline shape and the mask-heavy cases (FLAT_1E4_UNTIL below).
-    Measured values per step are written to gpurun_out/parity_report.json (`per_step`: hip vs spread).  Discrete outputs
-    (valid / override / kill / destination-reached flags) must be EQUAL.  Oracle-checked cases (no golden) measure the same
-    ensemble with the oracle on the spot (`_oracle_ensemble`).
+  * closed-loop xy over the 8 s horizon: north_star's target is <= 1e-4 m.  The rollout is chaotic: the REFERENCE's own fp32 run
+    differs from its fp64 run by up to 1.3e-4 m at step 90 on the headline shape (fixtures `preds_fp64`; 7.8e-4 m at step 170 of the
+    stress shape), so two correct fp32 implementations cannot agree better than that noise.  The noise is MEASURED and the acceptance
+    rule is ONE rule, frozen in round 4 before the HIP path was run against it: tools/ensemble.py::closed_loop_rule / suite_rule
+    (the text there is the specification).  In short: every closed-loop golden has a sidecar tests/golden/ensg/<name>.npz with 32
+    further fp32 runs of the imported reference that are INDEPENDENT of the base run -- channel-re-labelled weights
+    (tools/channel_perm.py: every Linear / LayerNorm / attention product sums in another order) on permuted batches -- and per step
+        (a) |hip - reference fp64|(t) <= max(1e-4, PB64(t))     (b) |hip - reference fp32|(t) <= max(1e-4, PB32(t))
+    with PB = the one-sided log-normal prediction limit (alpha = 1e-3) of the members' distances to that anchor -- no triangle terms,
+    no multipliers (round 3's rule had both) -- plus
+        (c) north_star's flat bound where it is attainable: |hip - reference fp32|(t) <= 1e-4 over the WHOLE horizon on the small
+            shapes and for every step t <= FLAT_1E4_UNTIL on the others,
+    and, over the whole suite (test_suite_level_closed_loop_parity): the number of cases in which HIP ends farther from the fp64 twin
+    than every member <= the 99 % binomial quantile, and the geometric mean of HIP / median member (distance to fp64) <= 1.5, so that a
+    2x regression turns the suite red even where each per-case bound still holds.
+    Measured values per step are written to gpurun_out/parity_report.json.  Discrete outputs (valid / override / kill /
+    destination-reached flags) must be EQUAL.  Oracle-checked cases (no golden) measure the same kind of ensemble with the oracle on the
+    spot (`_oracle_ensemble`: permuted batches + Oracle(gemm_order_seed=...), 16 members) and apply rules (a) and (b).
 """
 import json
 import os
@@ -52,7 +44,9 @@ REPORT = {}
 FLAT_1E4_UNTIL = {"c1_plumbing": None, "small_k1": None, "degenerate": None, "val_small": None, "val_alt_losses": None,
                   "stoch_actions": None, "val_irrelevant": None,
                   "masks_k3": 60, "headline_2": 60, "headline_k6": 60, "val_masks": 60,
-                  "headline_w_normal": 40, "headline_w_sharp": 40, "headline_w_ln_gamma": 40}
+                  "headline_w_normal": 40, "headline_w_sharp": 40, "headline_w_ln_gamma": 40, "action_override": None,
+                  "headline_8": 60, "stress_1": 40}
+SUITE = {}  # case -> tools/ensemble.py::closed_loop_rule output (reference-made ensembles only), judged by the suite-level test
 
 
 def _closed_loop_check(name, preds, g, step_axis, rep, step_start=1):
@@ -72,41 +66,23 @@ def _closed_loop_check(name, preds, g, step_axis, rep, step_start=1):
     n_flat = d32.shape[0] if until is None else min(d32.shape[0], until - step_start + 1)
     rep["traj_xy_max_flat_window"] = float(d32[:n_flat].max())
     REPORT[name] = rep
-    if "ens_d32" not in g.files:  # a horizon that ends inside the teacher-forced steps (c1_plumbing): nothing chaotic to measure
-        assert until is None and d32.max() <= 1e-4 and d64.max() <= 1e-4, f"{name}: {d32.max():.3e} / {d64.max():.3e}"
+    ensg_path = os.path.join(ROOT, "tests", "golden", "ensg", f"{name}.npz")
+    if not os.path.exists(ensg_path):  # a horizon that ends inside the teacher-forced steps (c1_plumbing): nothing chaotic to measure
+        assert name == "c1_plumbing" and until is None and d32.max() <= 1e-4 and d64.max() <= 1e-4, f"{name}: {d32.max():.3e} / {d64.max():.3e}"
         return
     from tools import ensemble
 
-    b64 = ensemble.prediction_bound(g["ens_d64"])
-    # (b)'s yardstick: the members' distance to the base run -- but a permuted member shares the base run's GEMM rounding (only the
-    # attention / pooling sums are re-ordered), so that spread UNDER-estimates the distance between two independent correct
-    # implementations (headline_k6: HIP is farther from the base than all 32 members, rank 0/32, while its rank against the fp64 truth
-    # is 12/33).  What an independent implementation that satisfies (a) can be asked for is the triangle through the truth,
-    # |hip - fp32| <= |hip - fp64| + |fp32 - fp64|: the bound is the larger of the two.
-    # The same holds the other way round for (a): every member follows the base run's rounding path for most of the horizon, so the
-    # members' distances to the fp64 truth are nearly one number (log-std 0.00 .. 0.25 over the goldens, against 0.16 .. 0.58 for their
-    # distances to the base run) and a prediction limit fitted to them is too narrow for a run that does not share that path: it may be
-    # as far from the truth as the base run is plus what separates two runs of the reference arithmetic.  Both triangles use measured
-    # terms only.
-    base64 = np.maximum.accumulate(g["ens_d64"][0].astype(np.float64))
-    b32 = ensemble.prediction_bound(g["ens_d32"])
-    spread64 = np.maximum(b64, base64 + b32)
-    spread32 = np.maximum(b32, b64 + base64)
-    rep["ens_pred_bound_vs_fp32_max"], rep["ens_pred_bound_vs_fp64_max"] = float(b32.max()), float(b64.max())
-    rep["ref_fp32_vs_fp64_xy_max"] = float(g["ens_d64"][0].max())
-    rep["ens_bound_vs_fp32_max"], rep["ens_bound_vs_fp64_max"] = float(spread32.max()), float(spread64.max())
-    rep["ens_max_vs_fp32"], rep["ens_max_vs_fp64"] = float(g["ens_d32"].max()), float(g["ens_d64"].max())
-    rep["rank_vs_fp32"], rep["rank_vs_fp64"] = ensemble.rank_among(g["ens_d32"], d32.max()), ensemble.rank_among(g["ens_d64"], d64.max())
-    rep["per_step"] = {"hip_vs_fp32": [float(f"{x:.3e}") for x in d32], "ens_bound_vs_fp32": [float(f"{x:.3e}") for x in spread32],
-                       "ens_max_vs_fp32": [float(f"{x:.3e}") for x in np.maximum.accumulate(g["ens_d32"].max(0))],
-                       "hip_vs_fp64": [float(f"{x:.3e}") for x in d64], "ens_bound_vs_fp64": [float(f"{x:.3e}") for x in spread64],
-                       "ens_max_vs_fp64": [float(f"{x:.3e}") for x in np.maximum.accumulate(g["ens_d64"].max(0))]}
-    assert (d64 <= np.maximum(1e-4, spread64)).all(), f"{name}: {d64.max():.3e} from fp64, outside the reference ensemble ({spread64.max():.3e})"
-    assert (d32 <= np.maximum(1e-4, spread32)).all(), f"{name}: {d32.max():.3e} from fp32, outside the reference ensemble ({spread32.max():.3e})"
-    assert d32[:n_flat].max() <= 1e-4, f"{name}: {d32[:n_flat].max():.3e} > 1e-4 within the first {n_flat} steps"
+    e = np.load(ensg_path)
+    assert float(e["equiv_fp64"]) < 1e-9 and int(e["flips"]) == 0, f"{name}: sidecar ensemble is not an ensemble of the same function"
+    r = ensemble.closed_loop_rule(d32, d64, e["ensg_d32"], e["ensg_d64"], n_flat)
+    rep.update({k: v for k, v in r.items()})
+    SUITE[name] = r
+    assert r["ok_vs_fp64"], f"{name}: {r['final_vs_fp64']:.3e} from fp64, outside the reference ensemble ({r['bound_vs_fp64']:.3e}; first at step {r['first_step_outside_vs_fp64']})"
+    assert r["ok_vs_fp32"], f"{name}: {r['final_vs_fp32']:.3e} from fp32, outside the reference ensemble ({r['bound_vs_fp32']:.3e}; first at step {r['first_step_outside_vs_fp32']})"
+    assert r["ok_flat"], f"{name}: {d32[:n_flat].max():.3e} > 1e-4 within the first {n_flat} steps"
 
 
-N_ORACLE_ENSEMBLE = 8
+N_ORACLE_ENSEMBLE = 16
 
 
 def _oracle_ensemble(run, batch, k=1, eps=None, dest=None, act=None, n_members=N_ORACLE_ENSEMBLE, seed=0):
@@ -141,21 +117,13 @@ def _assert_closed_loop(preds, r32, r64, what, members=None):
 
     from tools import ensemble
 
-    base64 = np.maximum.accumulate(dist(p32, p64, v32 & v64))
-    b64 = ensemble.prediction_bound(np.stack([dist(p32, p64, v32 & v64)] + [dist(m, p64, mv & v64) for m, mv in members]))
-    b32 = ensemble.prediction_bound(np.stack([dist(m, p32, mv & v32) for m, mv in members]))
-    spread64, spread32 = np.maximum(b64, base64 + b32), np.maximum(b32, b64 + base64)  # (the two triangles: see _closed_loop_check)
-    d64, d32 = dist(preds, p64, v32 & v64), dist(preds, p32, v32)
-    mem64 = np.maximum.accumulate(np.stack([dist(m, p64, mv & v64) for m, mv in members]), axis=1)
-    r3 = lambda a: [float(f"{x:.3e}") for x in a]  # noqa: E731
-    REPORT[f"oracle_ensemble/{what}"] = {"hip_vs_fp32": float(d32.max()), "spread_vs_fp32": float(spread32.max()),
-                                         "hip_vs_fp64": float(d64.max()), "spread_vs_fp64": float(spread64.max()),
-                                         "per_step": {"hip_vs_fp64": r3(d64), "bound_vs_fp64": r3(spread64), "base_fp32_vs_fp64": r3(base64),
-                                                      "members_median_vs_fp64": r3(np.median(mem64, 0)), "members_max_vs_fp64": r3(mem64.max(0)),
-                                                      "hip_vs_fp32": r3(d32), "bound_vs_fp32": r3(spread32)}}
-    assert (d64 <= np.maximum(1e-4, spread64)).all(), f"{what}: {d64.max():.3e} from fp64 (oracle ensemble {spread64.max():.3e})"
-    assert (d32 <= np.maximum(1e-4, spread32)).all(), f"{what}: {d32.max():.3e} from fp32 (oracle ensemble {spread32.max():.3e})"
-    return float(d32.max()), float(d64.max()), float(spread64.max())
+    ens64 = np.stack([dist(p32, p64, v32 & v64)] + [dist(m, p64, mv & v64) for m, mv in members])
+    ens32 = np.stack([dist(m, p32, mv & v32) for m, mv in members])
+    r = ensemble.closed_loop_rule(dist(preds, p32, v32), dist(preds, p64, v32 & v64), ens32, ens64)
+    REPORT[f"oracle_ensemble/{what}"] = r
+    assert r["ok_vs_fp64"], f"{what}: {r['final_vs_fp64']:.3e} from fp64 (oracle ensemble {r['bound_vs_fp64']:.3e}; first at step {r['first_step_outside_vs_fp64']})"
+    assert r["ok_vs_fp32"], f"{what}: {r['final_vs_fp32']:.3e} from fp32 (oracle ensemble {r['bound_vs_fp32']:.3e}; first at step {r['first_step_outside_vs_fp32']})"
+    return r["final_vs_fp32"], r["final_vs_fp64"], r["bound_vs_fp64"]
 
 
 def _engine(cfg_overrides, sd):
@@ -242,7 +210,7 @@ def _check_all_taps(name, g, meta, wm, sd, batch, eps, gs, rep):
 
 
 @pytest.mark.parametrize("name", ["c1_plumbing", "small_k1", "masks_k3", "degenerate", "headline_2", "headline_k6",
-                                  "headline_w_normal", "headline_w_sharp", "headline_w_ln_gamma"])
+                                  "headline_w_normal", "headline_w_sharp", "headline_w_ln_gamma", "headline_8", "stress_1"])
 def test_against_reference_golden(name):
     g, meta = load_golden(name)
     cfg, sd, batch, eps = golden_inputs(meta)
@@ -283,10 +251,11 @@ def test_against_reference_golden(name):
     assert (buf.final["final_valid"].bool().cpu().numpy() == fin_v).all()
     ens_fs = float(g["ens_final_state"]) if "ens_final_state" in g.files else 0.0
     rep["final_state_xy"] = float((np.abs(buf.final["final_state"].cpu().numpy() - g["final_state"]) * fin_v[..., None])[..., :2].max())
-    if "ens_d32" in g.files:  # (the final state is the last step's post-override state: the closed-loop bound of that step)
+    ensg_path = os.path.join(ROOT, "tests", "golden", "ensg", f"{name}.npz")
+    if os.path.exists(ensg_path):  # (the final state is the last step's post-override state: the closed-loop bound of that step)
         from tools import ensemble
 
-        fs_bound = max(1e-4, float(ensemble.prediction_bound(g["ens_d32"])[-1]))
+        fs_bound = max(1e-4, float(ensemble.prediction_bound(np.load(ensg_path)["ensg_d32"])[-1]))
     else:
         fs_bound = 1e-4
     assert rep["final_state_xy"] <= fs_bound, (name, rep["final_state_xy"], fs_bound)
@@ -1003,6 +972,25 @@ def test_empty_and_bad_inputs_fail_loudly():
         wm.load_state_dict(bad)
     with pytest.raises(NotImplementedError):
         WaymoMotion(**{"model.tf_cfg.n_head": 8})
+
+
+SUITE_CASES = ("small_k1", "masks_k3", "degenerate", "headline_2", "headline_k6", "headline_w_normal", "headline_w_sharp",
+               "headline_w_ln_gamma", "headline_8", "stress_1", "stoch_actions", "val_small", "val_masks", "val_alt_losses", "val_irrelevant")
+
+
+def test_suite_level_closed_loop_parity():
+    """VERDICT r03 task 1 (b): the per-case bounds are prediction limits of ONE further run and leave room for a path that sits at the
+    edge of every one of them; over the suite that is not allowed (tools/ensemble.py::suite_rule): the number of cases in which the HIP
+    path ends farther from the reference's fp64 twin than all 33 reference runs <= the 99 % binomial quantile for p = 1/34, and the
+    geometric mean over the cases of (HIP's final distance to fp64) / (the median member's) <= 1.5.  Runs after the golden tests of this
+    module (file order) and needs all of them."""
+    from tools import ensemble
+
+    missing = [c for c in SUITE_CASES if c not in SUITE]
+    assert not missing, f"suite-level rule needs the golden tests of this module to have run: missing {missing}"
+    r = ensemble.suite_rule({c: SUITE[c] for c in SUITE_CASES})
+    REPORT["suite_level"] = r
+    assert r["ok"], r
 
 
 def test_zz_write_report():

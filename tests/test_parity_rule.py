@@ -1,0 +1,95 @@
+"""CPU tests of the closed-loop acceptance rule (tools/ensemble.py::closed_loop_rule / suite_rule, frozen in round 4) and of the
+reference-made ensembles it refers to (tests/golden/ensg/*.npz from tools/gen_golden_ensg.py + tools/channel_perm.py)."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN_DIR, ROOT
+from tools import channel_perm, ensemble
+
+ENSG = ("small_k1", "masks_k3", "degenerate", "headline_2", "headline_k6", "stoch_actions", "action_override", "headline_w_normal",
+        "headline_w_sharp", "headline_w_ln_gamma", "headline_8", "stress_1", "val_small", "val_masks", "val_alt_losses", "val_irrelevant")
+
+
+@pytest.mark.parametrize("name", ENSG)
+def test_every_closed_loop_golden_has_an_independent_ensemble(name):
+    g = np.load(os.path.join(GOLDEN_DIR, f"{name}.npz"))
+    e = np.load(os.path.join(GOLDEN_DIR, "ensg", f"{name}.npz"))
+    n_step = g["preds"].shape[-2]
+    m = e["ensg_d32"].shape[0]
+    assert m >= 16 and e["ensg_d32"].shape == (m, n_step) and e["ensg_d64"].shape == (m + 1, n_step)
+    # the channel re-labelling is the same function (fp64: rounding only) and no member flips a validity flag
+    assert float(e["equiv_fp64"]) < 1e-9 and int(e["flips"]) == 0
+    # row 0 of ensg_d64 is the golden's own base run against its fp64 twin
+    both = (g["valid"] & g["valid_fp64"])[..., None]
+    step_axis = g["preds"].ndim - 2
+    ax = tuple(i for i in range(g["preds"].ndim) if i != step_axis)
+    base = (np.abs(g["preds"].astype(np.float64) - g["preds_fp64"]) * both)[..., :2].max(axis=ax)
+    assert np.allclose(e["ensg_d64"][0], base.astype(np.float32))
+    # the members are INDEPENDENT of the base run: beyond the first steps none of them reproduces it bit for bit
+    assert (np.maximum.accumulate(e["ensg_d32"], axis=1)[:, -1] > 0).all()
+
+
+def test_channel_permutation_is_a_relabelling_of_every_hidden_tensor():
+    from trafficbots_amd import synth
+
+    sd = synth.make_state_dict(7)
+    out, lay = channel_perm.permute_state_dict(sd, 123)
+    assert list(out) == list(sd)
+    changed = 0
+    for k, v in sd.items():
+        assert out[k].shape == v.shape and out[k].dtype == v.dtype
+        assert np.array_equal(np.sort(out[k], axis=None), np.sort(v, axis=None)), k  # the same numbers, re-ordered
+        changed += int(not np.array_equal(out[k], v))
+    assert changed >= 300  # (all transformer / GRU / MLP tensors; token-encoder MLPs, log_std vectors and buffers stay)
+    for p in lay.values():
+        assert sorted(p.tolist()) == list(range(128))
+    # q and k rows keep the head structure: a head's 32 rows stay together
+    w = "model.transformer_as2pl.layers.0.attn.in_proj_weight"
+    row_of = {tuple(sorted(r)): i for i, r in enumerate(sd[w][:128].tolist())}  # (a row's columns are re-ordered too)
+    heads = np.array([row_of[tuple(sorted(r))] // 32 for r in out[w][:128].tolist()]).reshape(4, 32)
+    assert (heads == heads[:, :1]).all() and sorted(heads[:, 0].tolist()) == [0, 1, 2, 3]
+
+
+def _fake(m=32, s=90, scale=1e-4, sd=0.25, seed=0):
+    rng = np.random.default_rng(seed)
+    t = np.linspace(0.05, 1.0, s) ** 2
+    return scale * t[None] * np.exp(sd * rng.standard_normal((m, 1)))
+
+
+def test_rule_accepts_an_exchangeable_run_and_rejects_a_far_one():
+    e32, e64 = _fake(32, seed=1), _fake(33, seed=2)
+    ok = ensemble.closed_loop_rule(_fake(1, seed=3)[0], _fake(1, seed=4)[0], e32, e64, n_flat=40)
+    assert ok["ok"] and ok["n_member"] == 32
+    far = ensemble.closed_loop_rule(_fake(1, seed=3)[0], 4.0 * _fake(1, seed=4)[0], e32, e64)
+    assert not far["ok_vs_fp64"] and far["ok_vs_fp32"] and far["first_step_outside_vs_fp64"] is not None
+    # the flat window is a hard 1e-4
+    flat = ensemble.closed_loop_rule(np.full(90, 1.2e-4), _fake(1, seed=4)[0], e32 * 3, e64, n_flat=10)
+    assert not flat["ok_flat"]
+    # below north_star's floor everything passes whatever the members do
+    tiny = ensemble.closed_loop_rule(np.full(90, 9e-5), np.full(90, 9e-5), 1e-6 + 0 * e32, 1e-6 + 0 * e64, n_flat=90)
+    assert tiny["ok"]
+
+
+def test_suite_rule_turns_red_on_a_two_fold_regression():
+    """VERDICT r03 task 1 (b): every per-case bound may still hold while the whole path is 2x the reference's own noise."""
+    def suite(factor):
+        recs = {}
+        for c in range(15):
+            e32, e64 = _fake(32, seed=10 + c), _fake(33, seed=40 + c)
+            recs[f"case{c}"] = ensemble.closed_loop_rule(_fake(1, seed=70 + c)[0], factor * _fake(1, seed=100 + c)[0], e32, e64)
+        return recs, ensemble.suite_rule(recs)
+
+    recs, s = suite(1.0)
+    assert s["ok"] and s["n_case"] == 15, s
+    recs2, s2 = suite(2.0)
+    assert sum(r["ok"] for r in recs2.values()) >= 5  # many cases are still inside their per-case prediction limits ...
+    assert not s2["ok"] and s2["geomean_ratio_to_median_vs_fp64"] > 1.5, s2  # ... but the suite is red
+
+
+def test_bench_and_tests_share_the_rule():
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert "closed_loop_rule" in src and "ens_d32" not in src
+    t = open(os.path.join(ROOT, "tests", "test_gpu_parity.py")).read()
+    assert "closed_loop_rule" in t and "suite_rule" in t and "base64 + b32" not in t

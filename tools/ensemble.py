@@ -103,7 +103,7 @@ def spread_per_step(member: np.ndarray, base: np.ndarray, valid: np.ndarray, ste
     return d[..., :2].max(axis=ax)
 
 
-def prediction_bound(devs: np.ndarray, alpha: float = 5e-4) -> np.ndarray:
+def prediction_bound(devs: np.ndarray, alpha: float = 1e-3) -> np.ndarray:
     """One-sided (1 - alpha) prediction bound, per simulation step, for the deviation of ONE MORE correct run, from the M member
     deviations `devs` [M, S] (per-step max-abs xy distance of each member to the same anchor).
 
@@ -113,8 +113,8 @@ def prediction_bound(devs: np.ndarray, alpha: float = 5e-4) -> np.ndarray:
     the members' distances to the fp64 truth was unremarkable: 15/17, 10/17, 9/17, 6/17, 3/17, 16/17, 12/17 ...).  The deviation of a
     chaotic rollout grows multiplicatively, so log(deviation) is close to normal across members; the bound is the standard prediction
     limit of a normal sample, exp(mean + t_{M-1, 1-alpha} * sqrt(1 + 1/M) * std) of the members' running-max deviations, made
-    monotone in t.  alpha = 5e-4 per case keeps the family-wise false-failure rate of the whole suite near 1 %.  No free multiplier:
-    the width comes from the measured spread of the reference's own arithmetic and the stated significance level."""
+    monotone in t.  The width comes from the measured spread of the reference's own arithmetic and the stated significance level
+    (ALPHA below: frozen in round 4 BEFORE the HIP path was measured against the new ensembles)."""
     from scipy import stats
 
     m = devs.shape[0]
@@ -130,3 +130,72 @@ def prediction_bound(devs: np.ndarray, alpha: float = 5e-4) -> np.ndarray:
 def rank_among(devs: np.ndarray, value: float) -> str:
     """"r/M": how many members end at least as far from the anchor as `value` (reported next to every bound)."""
     return f"{int((np.maximum.accumulate(devs, axis=1)[:, -1] >= value).sum())}/{devs.shape[0]}"
+
+
+# ----------------------------------------------------------------------------------------------------------------------------------
+# THE acceptance rule of the closed-loop parity tests (round 4; VERDICT r03 task 1 / ADVICE r03).  One rule, used by
+# tests/test_gpu_parity.py (goldens and oracle-checked cases), tests/probes and bench.py alike; frozen before the HIP path was run
+# against the ensembles it refers to.  The yardstick is an ensemble of INDEPENDENT correct fp32 runs of the reference arithmetic:
+# members that re-order the sums inside every Linear / LayerNorm / attention product (tools/channel_perm.py for the imported
+# reference -> tests/golden/ensg/*.npz; Oracle(gemm_order_seed=) for oracle-made ensembles) on top of the batch permutation.  With
+# such members neither triangle term of round 3 is needed, and none is used.
+#   per case, per simulation step t (running max over steps):
+#     (a) |hip - fp64 twin|(t)  <= max(FLOOR, PB(members' + base run's distances to the fp64 twin)(t))
+#     (b) |hip - base fp32|(t)  <= max(FLOOR, PB(members' distances to the base fp32 run)(t))
+#     (c) |hip - base fp32|(t)  <= FLOOR for every t <= flat_until (north_star's flat bound where it is attainable)
+#   with PB = prediction_bound(alpha = ALPHA) and FLOOR = north_star's 1e-4 m.
+#   per suite (suite_rule): over all cases with a reference-made ensemble,
+#     (S1) #cases in which HIP ends farther from the fp64 twin than EVERY member <= the 99 % binomial quantile for p = 1 / (M + 1);
+#     (S2) geometric mean over the cases of  HIP's final distance to fp64 / the median member's  <= 1.5
+#          (a 2x regression of the whole path turns the suite red even when every per-case bound still holds).
+ALPHA = 1e-3
+FLOOR = 1e-4
+SUITE_GEOMEAN_MAX = 1.5
+
+
+def closed_loop_rule(d32: np.ndarray, d64: np.ndarray, ens_d32: np.ndarray, ens_d64: np.ndarray, n_flat: int = 0) -> dict:
+    """d32 / d64 [S]: per-step max-abs xy distance of the run under test to the base fp32 run / the fp64 twin; ens_d32 [M,S] members vs
+    base fp32; ens_d64 [M(+1),S] members (and the base run) vs the fp64 twin; n_flat = number of leading steps under the flat bound.
+    Returns the verdict and everything that is reported next to it."""
+    b32, b64 = prediction_bound(ens_d32, ALPHA), prediction_bound(ens_d64, ALPHA)
+    lim32, lim64 = np.maximum(FLOOR, b32), np.maximum(FLOOR, b64)
+    r32, r64 = np.maximum.accumulate(d32.astype(np.float64)), np.maximum.accumulate(d64.astype(np.float64))
+    fin32, fin64 = np.maximum.accumulate(ens_d32, axis=1)[:, -1].astype(np.float64), np.maximum.accumulate(ens_d64, axis=1)[:, -1].astype(np.float64)
+    ok_a, ok_b = bool((r64 <= lim64).all()), bool((r32 <= lim32).all())
+    ok_c = bool(n_flat == 0 or r32[:n_flat].max() <= FLOOR)
+    tiny = 1e-12
+    return {
+        "ok": ok_a and ok_b and ok_c, "ok_vs_fp64": ok_a, "ok_vs_fp32": ok_b, "ok_flat": ok_c,
+        "final_vs_fp32": float(r32[-1]), "final_vs_fp64": float(r64[-1]),
+        "bound_vs_fp32": float(lim32[-1]), "bound_vs_fp64": float(lim64[-1]),
+        "members_median_vs_fp32": float(np.median(fin32)), "members_max_vs_fp32": float(fin32.max()),
+        "members_median_vs_fp64": float(np.median(fin64)), "members_max_vs_fp64": float(fin64.max()),
+        "ratio_to_median_vs_fp32": float(r32[-1] / max(np.median(fin32), tiny)), "ratio_to_median_vs_fp64": float(r64[-1] / max(np.median(fin64), tiny)),
+        "rank_vs_fp32": f"{int((fin32 >= r32[-1]).sum())}/{fin32.size}", "rank_vs_fp64": f"{int((fin64 >= r64[-1]).sum())}/{fin64.size}",
+        "beyond_all_members_vs_fp64": bool(r64[-1] > fin64.max()), "n_member": int(ens_d32.shape[0]),
+        "first_step_outside_vs_fp64": int(np.nonzero(r64 > lim64)[0][0]) if not ok_a else None,
+        "first_step_outside_vs_fp32": int(np.nonzero(r32 > lim32)[0][0]) if not ok_b else None,
+        "per_step": {"hip_vs_fp32": [float(f"{x:.3e}") for x in r32], "bound_vs_fp32": [float(f"{x:.3e}") for x in lim32],
+                     "hip_vs_fp64": [float(f"{x:.3e}") for x in r64], "bound_vs_fp64": [float(f"{x:.3e}") for x in lim64]},
+    }
+
+
+def suite_rule(records: dict) -> dict:
+    """(S1) / (S2) over `records` = {case: closed_loop_rule(...) output} of the cases whose distances are above the quantisation floor
+    (a case in which HIP and every member end within 2e-5 m of the truth carries no information about a ratio)."""
+    from scipy import stats
+
+    use = {k: r for k, r in records.items() if max(r["final_vs_fp64"], r["members_median_vs_fp64"]) > 2e-5}
+    n = len(use)
+    if n == 0:
+        return {"ok": True, "n_case": 0}
+    m = min(r["n_member"] for r in use.values()) + 1  # (+ the base run)
+    n_beyond = sum(r["beyond_all_members_vs_fp64"] for r in use.values())
+    q = int(stats.binom.ppf(0.99, n, 1.0 / (m + 1)))
+    geo = float(np.exp(np.mean([np.log(max(r["ratio_to_median_vs_fp64"], 1e-3)) for r in use.values()])))
+    geo32 = float(np.exp(np.mean([np.log(max(r["ratio_to_median_vs_fp32"], 1e-3)) for r in use.values()])))
+    return {"ok": bool(n_beyond <= q and geo <= SUITE_GEOMEAN_MAX), "n_case": n, "n_beyond_all_members_vs_fp64": int(n_beyond),
+            "binomial_99pct_quantile": q, "geomean_ratio_to_median_vs_fp64": geo, "geomean_max": SUITE_GEOMEAN_MAX,
+            "geomean_ratio_to_median_vs_fp32_reported_only": geo32,
+            "cases": {k: {"ratio_vs_fp64": r["ratio_to_median_vs_fp64"], "rank_vs_fp64": r["rank_vs_fp64"],
+                          "ratio_vs_fp32": r["ratio_to_median_vs_fp32"], "rank_vs_fp32": r["rank_vs_fp32"]} for k, r in use.items()}}

@@ -105,6 +105,18 @@ for _i, _mode in enumerate(("normal", "sharp", "ln_gamma")):
         scene=dict(n_agent=64, n_pl=256, n_tl=40), tap_steps=[1, 11, 50], fp64=True, store_feats=True,
     )
 
+# VERDICT r03 missing #5: eight scenes of the headline batch (the first eight scenes of the stream bench.py times: base_seed 5000) and one
+# scene of BASELINE configs[4]'s stress shape at its full horizon (A = 128, P = 1024, 170 steps).  Their rounding-noise ensembles are
+# the channel-re-labelled ones of tools/gen_golden_ensg.py (tests/golden/ensg/), not the batch-permutation-only `ens_*` arrays.
+CASES["headline_8"] = dict(
+    base_seed=5000, n_scene=8, k=1, weight_seed=7, time_step_end=90,
+    scene=dict(n_agent=64, n_pl=256, n_tl=40), tap_steps=[], fp64=True, store_feats=False,
+)
+CASES["stress_1"] = dict(
+    base_seed=15000, n_scene=1, k=1, weight_seed=7, time_step_end=170,
+    scene=dict(n_agent=128, n_pl=1024, n_tl=40), tap_steps=[], fp64=True, store_feats=False, n_ensg=16,
+)
+
 # members of the measured rounding-noise ensemble (tools/ensemble.py) per closed-loop golden
 N_ENSEMBLE = 32
 ENSEMBLE_CASES = ("small_k1", "masks_k3", "degenerate", "headline_2", "headline_k6", "stoch_actions", "action_override",
@@ -114,8 +126,10 @@ RULE_KEYS = ["collided", "collided_this_step", "run_road_edge", "run_road_edge_t
              "run_red_light_this_step", "passive", "passive_this_step"]
 
 
-def run_reference(case: dict, dtype=torch.float32, force_goal_sample=None, perturb=None) -> dict:
-    """`perturb` = (seed, n_pad_scene): an ensemble member (tools/ensemble.py) -- agent slots, polylines and stop points of every scene
+def run_reference(case: dict, dtype=torch.float32, force_goal_sample=None, perturb=None, channel_seed=None) -> dict:
+    """`channel_seed`: the member also runs on a channel-re-labelled copy of the weights (tools/channel_perm.py): the same function,
+    another summation order inside every Linear / LayerNorm / attention product.
+    `perturb` = (seed, n_pad_scene): an ensemble member (tools/ensemble.py) -- agent slots, polylines and stop points of every scene
     permuted, `n_pad_scene` further scenes appended; agent-indexed outputs come back in the ORIGINAL order and without the padding.
     `force_goal_sample` [B,A,K] (the fp32 run's destinations): the fp64 twin must follow the SAME sampled destinations -- the
     multinomial draw of `DestCategorical.sample` depends on the dtype of the probabilities -- so the sampler is replaced by the stored
@@ -129,6 +143,11 @@ def run_reference(case: dict, dtype=torch.float32, force_goal_sample=None, pertu
     torch.set_default_dtype(torch.float32)
     model = ref_shim.build_reference(cfg, n_agent=sc["n_agent"], n_pl=sc["n_pl"], n_tl=sc.get("n_tl", 40))
     sd = synth.make_state_dict(case["weight_seed"], mode=case.get("weight_mode"))
+    if channel_seed is not None:
+        import channel_perm
+
+        sd, layouts = channel_perm.permute_state_dict(sd, channel_seed)
+        channel_perm.install_hooks(model, layouts)
     missing = model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()}, strict=True)
     assert not missing.missing_keys and not missing.unexpected_keys
     batch_np = synth.make_batch(case["base_seed"], case["n_scene"], **sc)

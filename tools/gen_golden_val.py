@@ -72,8 +72,9 @@ RULE = ("counter_agent", "counter_veh", "outside_map", "collided", "run_road_edg
 N_ENSEMBLE = 32
 
 
-def run_reference(case: dict, dtype=torch.float32, perturb=None) -> dict:
-    """`perturb` = seed of an ensemble member (tools/ensemble.py: agent slots, polylines, stop points permuted per scene); only the
+def run_reference(case: dict, dtype=torch.float32, perturb=None, channel_seed=None) -> dict:
+    """`channel_seed`: the member also runs on a channel-re-labelled copy of the weights (tools/channel_perm.py).
+    `perturb` = seed of an ensemble member (tools/ensemble.py: agent slots, polylines, stop points permuted per scene); only the
     replayed trajectory comes back, in the original agent order."""
     over = {"time_step_end": case["time_step_end"], "n_joint_future": 1}
     over.update(case["overrides"])
@@ -82,6 +83,11 @@ def run_reference(case: dict, dtype=torch.float32, perturb=None) -> dict:
     torch.set_default_dtype(torch.float32)
     model = ref_shim.build_reference(cfg, n_agent=sc["n_agent"], n_pl=sc["n_pl"], n_tl=sc.get("n_tl", 40))
     sd = synth.make_state_dict(case["weight_seed"])
+    if channel_seed is not None:
+        import channel_perm
+
+        sd, layouts = channel_perm.permute_state_dict(sd, channel_seed)
+        channel_perm.install_hooks(model, layouts)
     model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()}, strict=True)
     batch_np, perm = synth.make_val_batch(case["base_seed"], case["n_scene"], **sc), None
     if perturb is not None:

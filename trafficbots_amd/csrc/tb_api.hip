@@ -49,6 +49,8 @@ size_t forward_scratch_floats(const tb_forward_io* io);  // tb_forward_kernels.h
 const char* run_forward(const std::map<std::string, const float*>& raw, const tb_forward_io* io, float* scratch, hipStream_t s);
 void launch_post_process(const tb_post_io& io, hipStream_t s);
 void launch_metric_partials(const tb_metric_io& io, hipStream_t s);
+void launch_latent_sample(const tb_latent_sample_io& io, const float* log_std, hipStream_t s);
+void launch_dest_sample(const tb_dest_sample_io& io, hipStream_t s);
 }  // namespace tb
 
 // ---------------------------------------------------------------------------------------------------
@@ -301,7 +303,9 @@ tb::EncMlpW add_enc(Arena& a, Stage& s, const std::string& p, int attr_dim) {
 // ---------------------------------------------------------------------------------------------------
 extern "C" {
 
-void tb_struct_sizes(int32_t out[11]) {
+void tb_struct_sizes(int32_t out[13]) {
+    out[11] = (int32_t)sizeof(tb_latent_sample_io);
+    out[12] = (int32_t)sizeof(tb_dest_sample_io);
     out[9] = (int32_t)sizeof(tb_step_override);
     out[10] = (int32_t)sizeof(tb_forward_io);
     out[7] = (int32_t)sizeof(tb_posterior_io);
@@ -800,7 +804,12 @@ static int rollout_setup(tb_ctx* ctx, const tb_rollout_io* io, tb::RolloutP& p) 
     p.map_type = io->map_type;
     p.map_pos = io->map_pos;
     p.map_dir = io->map_dir;
-    p.latent_z = io->latent_sample;
+    // the personality: given by the caller, or drawn by the prologue into the caller's latent_sample_out (k_rollout_init)
+    p.latent_draw = io->latent_sample_out != nullptr;
+    p.latent_z = p.latent_draw ? io->latent_sample_out : io->latent_sample;
+    p.o_latent_z = io->latent_sample_out;
+    p.latent_eps = io->latent_eps;
+    p.latent_det = io->latent_deterministic;
     p.action_eps = io->action_eps;
     if (io->action_eps && ctx->step_kernel < 2) return tb_fail(ctx, "tb_rollout: action_eps (sampled actions) needs the XDL step kernels");
     p.latent_mean = io->latent_mean;
@@ -1068,6 +1077,30 @@ extern "C" int tb_metric_partials(tb_ctx* ctx, const tb_metric_io* io, tb_stream
     for (const void* q : need)
         if (!q) return tb_fail(ctx, "tb_metric_partials: a required buffer pointer is NULL");
     tb::launch_metric_partials(*io, (hipStream_t)stream_);
+    TB_HIP(ctx, hipGetLastError());
+    return 0;
+}
+
+// ---- the samplers of joint_future_pred (tb_sample_kernels.hip) --------------------------------------------------------
+extern "C" int tb_latent_sample(tb_ctx* ctx, const tb_latent_sample_io* io, tb_stream stream_) {
+    if (!ctx || !io) return 1;
+    TB_HIP(ctx, hipSetDevice(ctx->device));
+    if (!ctx->finalized) return tb_fail(ctx, "tb_latent_sample: weights not finalized (the log_std vectors are parameters)");
+    if (io->n_scene <= 0 || io->n_agent <= 0 || io->k_futures <= 0) return tb_fail(ctx, "tb_latent_sample: empty dimension");
+    if (!io->mean) return tb_fail(ctx, "tb_latent_sample: mean is NULL");
+    if (!io->sample && !io->log_prob) return tb_fail(ctx, "tb_latent_sample: neither sample nor log_prob requested");
+    tb::launch_latent_sample(*io, ctx->d_arena + (io->posterior ? ctx->ew.post_log_std : ctx->pw.latent_log_std), (hipStream_t)stream_);
+    TB_HIP(ctx, hipGetLastError());
+    return 0;
+}
+
+extern "C" int tb_dest_sample(tb_ctx* ctx, const tb_dest_sample_io* io, tb_stream stream_) {
+    if (!ctx || !io) return 1;
+    TB_HIP(ctx, hipSetDevice(ctx->device));
+    if (io->n_scene <= 0 || io->n_agent <= 0 || io->k_futures <= 0 || io->n_pl <= 0) return tb_fail(ctx, "tb_dest_sample: empty dimension");
+    if (!io->dest_logits) return tb_fail(ctx, "tb_dest_sample: dest_logits is NULL");
+    if (!io->sample && !io->log_prob && !io->probs) return tb_fail(ctx, "tb_dest_sample: no output requested");
+    tb::launch_dest_sample(*io, (hipStream_t)stream_);
     TB_HIP(ctx, hipGetLastError());
     return 0;
 }

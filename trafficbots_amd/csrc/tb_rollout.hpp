@@ -92,7 +92,11 @@ struct RolloutP {
     const float* map_dir;         // [B,P,20,2]
     // per instance inputs
     const float* action_eps;      // [N,A,S,2] standard-normal draws of sampled actions, or nullptr (deterministic_action)
-    const float* latent_z;        // [N,A,16]
+    const float* latent_z;        // [N,A,16]  (== o_latent_z when the prologue draws it)
+    const float* latent_eps;      // [N,A,16] or NULL   } latent_draw: z = det ? mean : mean + eps * exp(log_std), written to o_latent_z
+    const uint8_t* latent_det;    // [N,A] or NULL      }
+    float* o_latent_z;            // [N,A,16] or NULL
+    int latent_draw;
     const float* latent_mean;     // [B,A,16]
     const int32_t* dest;          // [N,A]
     const uint8_t* goal_valid0;   // [N,A]

@@ -12,6 +12,7 @@
 // Weights stream as register units one unit ahead of the MFMAs (tb_device.hpp); the unit chain runs straight
 // through all stages of the launch.
 #include "tb_step_common.hpp"
+#include "tb_sample.hpp"
 
 namespace tb {
 
@@ -104,7 +105,19 @@ __global__ __launch_bounds__(NTHREADS) void k_rollout_init(RolloutP p) {
     // latent sample tile
     for (int i = tid; i < TM * 16; i += NTHREADS) {
         const int r = i >> 4, c = i & 15;
-        Z[r * 20 + c] = (r < n_real) ? p.latent_z[((size_t)n * p.n_agent + row0 + r) * 16 + c] : 0.f;
+        float z = 0.f;
+        if (r < n_real) {
+            const size_t zi = ((size_t)n * p.n_agent + row0 + r) * 16 + c;
+            if (p.latent_draw) {  // MyDist.sample (distributions.py:18-38) with the caller's draws: tb_rollout_io.latent_sample_out
+                const bool det = p.latent_eps == nullptr || (p.latent_det != nullptr && p.latent_det[(size_t)n * p.n_agent + row0 + r] != 0);
+                z = latent_draw(p.latent_mean[((size_t)b * p.n_agent + row0 + r) * 16 + c], det ? 0.f : p.latent_eps[zi],
+                                W[p.latent_log_std + c], det);
+                p.o_latent_z[zi] = z;
+            } else {
+                z = p.latent_z[zi];
+            }
+        }
+        Z[r * 20 + c] = z;
     }
     __syncthreads();
     // latent log prob: sum_d -((z-mu)^2)/(2 var) - log(std) - log(sqrt(2 pi))

@@ -47,7 +47,19 @@ class TbRolloutIO(C.Structure):
         ("check_state", c_f32p), ("check_valid", c_u8p),
         ("n_tl_step", C.c_int32), ("latent_posterior", C.c_int32), ("warm_start_steps", C.c_int32),
         ("action_eps", c_f32p), ("hidden_drop", C.c_void_p),
+        ("latent_eps", c_f32p), ("latent_deterministic", c_u8p), ("latent_sample_out", c_f32p),
     ]
+
+
+class TbLatentSampleIO(C.Structure):
+    _fields_ = [("n_scene", C.c_int32), ("k_futures", C.c_int32), ("n_agent", C.c_int32), ("posterior", C.c_int32),
+                ("mean", c_f32p), ("eps", c_f32p), ("deterministic", c_u8p), ("forced", c_f32p), ("sample", c_f32p), ("log_prob", c_f32p)]
+
+
+class TbDestSampleIO(C.Structure):
+    _fields_ = [("n_scene", C.c_int32), ("k_futures", C.c_int32), ("n_agent", C.c_int32), ("n_pl", C.c_int32), ("from_probs", C.c_int32),
+                ("dest_logits", c_f32p), ("uniform", c_f32p), ("deterministic", c_u8p), ("forced", c_i32p), ("sample", c_i32p),
+                ("log_prob", c_f32p), ("probs", c_f32p)]
 
 
 class TbStepOverride(C.Structure):
@@ -147,7 +159,7 @@ EXPORTS = (
     "tb_create", "tb_destroy", "tb_last_error", "tb_version", "tb_load_weight", "tb_finalize_weights",
     "tb_rollout", "tb_rollout_begin", "tb_rollout_step", "tb_rollout_step_ex", "tb_check_status", "tb_rollout_state", "tb_encode_scene", "tb_set_timing", "tb_get_timing",
     "tb_rule_checks", "tb_post_process", "tb_metric_partials", "tb_struct_sizes", "tb_encode_posterior", "tb_train_partials",
-    "tb_forward", "tb_graph_stats",
+    "tb_forward", "tb_graph_stats", "tb_latent_sample", "tb_dest_sample",
 )
 
 _lib: Optional[C.CDLL] = None
@@ -207,10 +219,15 @@ def load() -> C.CDLL:
     lib.tb_train_partials.restype = C.c_int
     lib.tb_struct_sizes.argtypes = [C.POINTER(C.c_int32)]
     lib.tb_struct_sizes.restype = None
-    sizes = (C.c_int32 * 11)()
+    lib.tb_latent_sample.argtypes = [C.c_void_p, C.POINTER(TbLatentSampleIO), C.c_void_p]
+    lib.tb_latent_sample.restype = C.c_int
+    lib.tb_dest_sample.argtypes = [C.c_void_p, C.POINTER(TbDestSampleIO), C.c_void_p]
+    lib.tb_dest_sample.restype = C.c_int
+    sizes = (C.c_int32 * 13)()
     lib.tb_struct_sizes(sizes)
     mine = [C.sizeof(x) for x in (TbConfig, TbRolloutIO, TbEncodeIO, TbRuleIO, TbPostIO, TbMetricIO)] + [C.sizeof(C.c_void_p)]
     mine += [C.sizeof(TbPosteriorIO), C.sizeof(TbTrainIO), C.sizeof(TbStepOverride), C.sizeof(TbForwardIO)]
+    mine += [C.sizeof(TbLatentSampleIO), C.sizeof(TbDestSampleIO)]
     lib.tb_forward.argtypes = [C.c_void_p, C.POINTER(TbForwardIO), C.c_void_p]
     lib.tb_forward.restype = C.c_int
     if list(sizes) != mine:
