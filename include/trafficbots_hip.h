@@ -454,7 +454,8 @@ int tb_metric_partials(tb_ctx* ctx, const tb_metric_io* io, tb_stream stream);
  * (what `latent.repeat_interleave_(k_futures, 0)` materialises, waymo_motion.py:493). */
 typedef struct tb_latent_sample_io {
     int32_t n_scene, k_futures, n_agent;
-    int32_t posterior;             /* nonzero: latent_post_dist.log_std, else latent_prior_dist.log_std */
+    int32_t posterior;             /* nonzero: latent_post_dist.log_std, else latent_prior_dist.log_std (when log_std is NULL) */
+    const float* log_std;          /* [16] device array, or NULL = the loaded parameter selected by `posterior` */
     const float* mean;             /* [B,A,16] */
     const float* eps;              /* [N,A,16] standard-normal draws (Normal.rsample's), or NULL = every agent takes the mean */
     const uint8_t* deterministic;  /* [N,A] or NULL: where set the agent takes the mean (the tensor form of `deterministic`) */

@@ -123,31 +123,31 @@ def test_teacher_forcing_mask_matches_oracle():
         assert (teacher_forcing_mask(valid.clone(), **cfg) == Oracle.teacher_forcing_mask(o, valid.clone(), cfg)).all()
 
 
-def test_distributions_against_torch():
-    from torch.distributions import Categorical, Independent, Normal
-
+def test_distributions_interface_and_no_host_fallback():
+    """The distribution mirrors keep the reference's surface (`mean`, `valid`, `repeat_interleave_`, `sample`, `log_prob`) but their
+    arithmetic lives in the HIP library (`tb_latent_sample`, `tb_dest_sample`; tests/test_gpu_boundary.py checks it against
+    torch.distributions): an object that is not bound to a device engine raises instead of computing on the host."""
     from trafficbots_amd.distributions import DestCategorical, DiagGaussian
 
     g = torch.Generator().manual_seed(1)
     mean, log_std = torch.randn(4, 5, 16, generator=g), torch.full((16,), -1.0)
-    d = DiagGaussian(mean, log_std)
-    eps = torch.randn(4, 5, 16, generator=g)
-    det = torch.zeros(4, 5, dtype=torch.bool)
-    det[::2] = True
-    z = d.sample(det, eps=eps)
-    assert torch.equal(z[0], mean[0]) and torch.allclose(z[1], mean[1] + eps[1] * log_std.exp())
-    ref = Independent(Normal(mean, log_std.exp()), 1).log_prob(z)
-    assert torch.allclose(d.log_prob(z), ref, atol=1e-5)
-    logits = torch.randn(3, 4, 9, generator=g)
-    logits[0, 0, :5] = float("-inf")
-    c = DestCategorical(logits=logits)
+    valid = torch.rand(4, 5, generator=g) > 0.3
+    d = DiagGaussian(mean, log_std, valid=valid)
+    d.repeat_interleave_(3, 0)
+    assert d.mean.shape == (12, 5, 16) and torch.equal(d.mean[3:6], mean[1:2].expand(3, -1, -1)) and torch.equal(d.valid, valid.repeat_interleave(3, 0))
+    eps, det = d._draws(torch.zeros(12, 5, dtype=torch.bool), None, torch.Generator().manual_seed(2))
+    assert eps.shape == (12, 5, 16) and det.shape == (12, 5)
+    assert d._draws(True, None, None) == (None, None)
+    with pytest.raises(RuntimeError, match="no host fallback"):
+        d.sample(True)
+    with pytest.raises(RuntimeError, match="no host fallback"):
+        d.log_prob(mean.repeat_interleave(3, 0))
+    c = DestCategorical(logits=torch.randn(3, 4, 9, generator=g), valid=torch.ones(3, 4, dtype=torch.bool))
     c.repeat_interleave_(2, 0)
-    t = Categorical(probs=Categorical(logits=logits).probs.repeat_interleave(2, 0))
-    s = c.sample(True)
-    assert torch.equal(s, t.probs.argmax(-1))
-    assert torch.allclose(c.log_prob(s), t.log_prob(s), atol=1e-6)
-    rnd = c.sample(False, generator=torch.Generator().manual_seed(3))
-    assert (rnd[0, 0] >= 5).all()  # never samples a masked polyline
+    assert c.valid.shape == (6, 4) and c._from_probs
+    for call in (lambda: c.sample(True), lambda: c.log_prob(torch.zeros(6, 4, dtype=torch.long)), lambda: c.probs):
+        with pytest.raises(RuntimeError, match="no host fallback"):
+            call()
 
 
 def test_rollout_buffer_flatten_repeat():

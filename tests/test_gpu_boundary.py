@@ -266,6 +266,76 @@ def test_forward_action_override_against_reference_golden():
     assert float((plain.preds - buf.preds).abs().max()) > 0.05  # the override really steers
 
 
+def test_device_samplers_against_torch_distributions():
+    """SURVEY 8 rows a9 / a10 on the device (`tb_latent_sample`, `tb_dest_sample`, csrc/tb_sample_kernels.hip) against
+    torch.distributions on the host -- what the reference's `DiagGaussian` / `DestCategorical` wrap (`distributions.py:40-59,158-201`)."""
+    from torch.distributions import Categorical, Independent, Normal
+
+    from trafficbots_amd import synth
+    from trafficbots_amd.distributions import DestCategorical, DiagGaussian
+    from trafficbots_amd.waymo_motion import WaymoMotion
+
+    wm = WaymoMotion(time_step_end=12, n_joint_future=1)
+    wm.load_state_dict(synth.make_state_dict(7))
+    gen = torch.Generator().manual_seed(1)
+    b, k, a, p = 3, 4, 21, 70
+    mean, log_std = torch.randn(b, a, 16, generator=gen), torch.linspace(-2.0, 0.5, 16)
+    eps = torch.randn(b * k, a, 16, generator=gen)
+    det = torch.rand(b * k, a, generator=gen) < 0.4
+    d = DiagGaussian(mean.cuda(), log_std.cuda(), engine=wm.engine)
+    d.repeat_interleave_(k, 0)
+    z = d.sample(det.cuda(), eps=eps.cuda()).cpu()
+    mean_n = mean.repeat_interleave(k, 0)
+    want = torch.where(det[..., None], mean_n, mean_n + eps * log_std.exp())
+    assert torch.equal(z[det], mean_n[det]) and (z - want).abs().max() <= 1e-6
+    assert torch.equal(d.sample(True).cpu(), mean_n)                       # bool forms: everybody the mean / everybody drawn
+    assert (d.sample(False, eps=eps.cuda()).cpu() - (mean_n + eps * log_std.exp())).abs().max() <= 1e-6
+    lp = d.log_prob(z.cuda()).cpu()
+    assert (lp - Independent(Normal(mean_n, log_std.exp()), 1).log_prob(z)).abs().max() <= 2e-4  # (values reach ~ -60: relative 3e-6)
+    # the parameter form: log_std NULL -> the loaded prior / posterior vectors
+    zp, lpp = wm.engine.latent_sample(mean.cuda(), k, eps=eps.cuda(), deterministic=det.cuda(), posterior=True)
+    ls_post = torch.from_numpy(synth.make_state_dict(7)["model.latent_encoder.latent_post_dist.log_std"])
+    assert (zp.cpu() - torch.where(det[..., None], mean_n, mean_n + eps * ls_post.exp())).abs().max() <= 1e-6
+    assert (lpp.cpu() - Independent(Normal(mean_n, ls_post.exp()), 1).log_prob(zp.cpu())).abs().max() <= 2e-4
+
+    # ---- destinations: masked logits as DestPredictor.forward leaves them (-inf for inadmissible polylines, zeros for invalid agents)
+    logits = 3.0 * torch.randn(b, a, p, generator=gen)
+    logits[torch.rand(b, a, p, generator=gen) < 0.5] = float("-inf")
+    logits[0, 0] = 0.0
+    logits[1, 2, 1:] = float("-inf")                                       # a single admissible polyline
+    logits[(logits == float("-inf")).all(-1)] = 0.0
+    c = DestCategorical(logits.cuda(), engine=wm.engine)
+    ref = Categorical(logits=logits)
+    assert torch.equal(c.sample(True).cpu(), ref.probs.argmax(-1))
+    assert (c.probs.cpu() - ref.probs).abs().max() <= 1e-6
+    s0 = c.sample(True)
+    assert (c.log_prob(s0).cpu() - ref.log_prob(s0.cpu())).abs().max() <= 2e-6          # Categorical(logits=): logits - logsumexp
+    c.repeat_interleave_(k, 0)
+    rep = Categorical(probs=ref.probs.repeat_interleave(k, 0))                           # what the reference holds after the repeat
+    u = torch.rand(b * k, a, generator=gen)
+    s = c.sample(det.cuda(), u=u.cuda()).cpu()
+    assert torch.equal(s[det], rep.probs.argmax(-1)[det])
+    pr = ref.probs.repeat_interleave(k, 0).double()
+    cdf = pr.cumsum(-1)
+    inv = (cdf > (u.double() * cdf[..., -1])[..., None]).float().argmax(-1)             # smallest j with cdf_j > u * total
+    differ = (s != inv) & ~det
+    if differ.any():  # only where u sits on a CDF step within fp32 rounding
+        gap = (cdf.gather(-1, torch.minimum(s, inv)[..., None])[..., 0] - u.double() * cdf[..., -1]).abs()
+        assert (gap[differ] <= 1e-5).all(), float(gap[differ].max())
+    assert (pr.gather(-1, s[..., None]) > 0).all(), "a masked polyline was sampled"
+    assert (c.log_prob(s.cuda()).cpu() - rep.log_prob(s)).abs().max() <= 2e-6
+    masked = torch.zeros(b * k, a, dtype=torch.long)                                    # index 0 is masked for many rows
+    lpm = c.log_prob(masked.cuda()).cpu()
+    assert (lpm - rep.log_prob(masked)).abs().max() <= 2e-6                              # clamped at log(eps), never -inf
+    # frequencies of many draws follow the probabilities (one row, 20000 uniforms through the K axis)
+    row = torch.tensor([[[0.0, 1.0, float("-inf"), 2.0, -1.0, 0.5]]])
+    many = DestCategorical(row.cuda(), engine=wm.engine)
+    many.repeat_interleave_(20000, 0)
+    draws = many.sample(False, generator=torch.Generator(device="cuda").manual_seed(5)).cpu().flatten()
+    freq = torch.bincount(draws, minlength=6).double() / draws.numel()
+    assert freq[2] == 0 and (freq - torch.softmax(row[0, 0], -1).double()).abs().max() <= 0.015
+
+
 def test_what_if_rollout_forces_the_sdc_trajectory():
     """`rollout(..., gt_sdc=...)` (`waymo_motion.py:279-284`): agent 0 is teacher-forced to the given trajectory at EVERY step, the
     other agents run closed loop around it."""

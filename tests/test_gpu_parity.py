@@ -233,6 +233,8 @@ def test_against_reference_golden(name):
         rep["dest_logits"] = float(np.abs(np.where(fin, lg - np.where(fin, g["dest_logits"], 0), 0)).max())
     rep["latent_mean"] = float(np.abs(out["latent_mean"].cpu().numpy() - g["latent_mean"]).max())
     assert (out["latent_valid"].cpu().numpy() == g["latent_valid"]).all()
+    # the personality the rollout prologue drew on the device (MyDist.sample with the golden's eps; K > 1: stochastic instances)
+    rep["latent_sample"] = float(np.abs(buf.latent_sample.cpu().numpy() - g["latent_sample"]).max())
     # deterministic destination of instance 0 equals the reference's unless its top-2 logits nearly tie
     own = out["dest_logits"].argmax(-1).cpu().numpy()
     diff = own != g["goal_sample"][:, :, 0]

@@ -1085,11 +1085,12 @@ extern "C" int tb_metric_partials(tb_ctx* ctx, const tb_metric_io* io, tb_stream
 extern "C" int tb_latent_sample(tb_ctx* ctx, const tb_latent_sample_io* io, tb_stream stream_) {
     if (!ctx || !io) return 1;
     TB_HIP(ctx, hipSetDevice(ctx->device));
-    if (!ctx->finalized) return tb_fail(ctx, "tb_latent_sample: weights not finalized (the log_std vectors are parameters)");
+    if (!io->log_std && !ctx->finalized) return tb_fail(ctx, "tb_latent_sample: weights not finalized (the log_std vectors are parameters)");
     if (io->n_scene <= 0 || io->n_agent <= 0 || io->k_futures <= 0) return tb_fail(ctx, "tb_latent_sample: empty dimension");
     if (!io->mean) return tb_fail(ctx, "tb_latent_sample: mean is NULL");
     if (!io->sample && !io->log_prob) return tb_fail(ctx, "tb_latent_sample: neither sample nor log_prob requested");
-    tb::launch_latent_sample(*io, ctx->d_arena + (io->posterior ? ctx->ew.post_log_std : ctx->pw.latent_log_std), (hipStream_t)stream_);
+    tb::launch_latent_sample(*io, io->log_std ? io->log_std : ctx->d_arena + (io->posterior ? ctx->ew.post_log_std : ctx->pw.latent_log_std),
+                             (hipStream_t)stream_);
     TB_HIP(ctx, hipGetLastError());
     return 0;
 }

@@ -53,7 +53,7 @@ class TbRolloutIO(C.Structure):
 
 class TbLatentSampleIO(C.Structure):
     _fields_ = [("n_scene", C.c_int32), ("k_futures", C.c_int32), ("n_agent", C.c_int32), ("posterior", C.c_int32),
-                ("mean", c_f32p), ("eps", c_f32p), ("deterministic", c_u8p), ("forced", c_f32p), ("sample", c_f32p), ("log_prob", c_f32p)]
+                ("log_std", c_f32p), ("mean", c_f32p), ("eps", c_f32p), ("deterministic", c_u8p), ("forced", c_f32p), ("sample", c_f32p), ("log_prob", c_f32p)]
 
 
 class TbDestSampleIO(C.Structure):

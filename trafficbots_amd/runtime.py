@@ -6,7 +6,7 @@ runs in `libtrafficbots_hip.so`.
 from __future__ import annotations
 
 import ctypes as C
-from typing import Dict, Optional
+from typing import Dict, Optional, Tuple
 
 import numpy as np
 import torch
@@ -349,7 +349,7 @@ class HipEngine:
         self,
         s: Dict[str, Tensor],
         feats: Dict[str, Tensor],
-        latent_sample: Tensor,
+        latent_sample: Optional[Tensor],
         latent_mean: Tensor,
         dest: Tensor,
         goal_valid: Tensor,
@@ -365,8 +365,13 @@ class HipEngine:
         warm_start_steps: int = 0,
         action_eps: Optional[Tensor] = None,
         hidden_drop=None,
+        latent_eps: Optional[Tensor] = None,
+        latent_deterministic: Optional[Tensor] = None,
     ) -> Dict[str, Tensor]:
-        """`hidden_drop` [S] bool (host): train-mode `p_drop_hidden` with explicit draws -- the GRU state of all instances is zeroed after
+        """`latent_sample=None`: the personalities are drawn by the rollout prologue itself (`MyDist.sample`, `distributions.py:18-38`;
+        `tb_rollout_io.latent_sample_out`): z = mean where `latent_deterministic` [N, A] is set (or for every agent when `latent_eps`
+        is None), mean + latent_eps * exp(log_std) elsewhere; the sample comes back as out["latent_sample"].
+        `hidden_drop` [S] bool (host): train-mode `p_drop_hidden` with explicit draws -- the GRU state of all instances is zeroed after
         the steps where it is set (`waymo_motion.py:345-351`; `tb_rollout_io.hidden_drop`).
         `action_eps` [N, A, S, 2] standard normal: sampled actions (`deterministic_action=False`, `dynamics.py:77`); None = the mean.
         Closed-loop rollout of N = B*K instances (instance n uses scene n // K).  Returns the
@@ -444,12 +449,27 @@ class HipEngine:
         io.map_type = hip.ptr(s["map_type"], hip.c_i32p)
         io.map_pos = hip.ptr(s["map_pos"], hip.c_f32p)
         io.map_dir = hip.ptr(s["map_dir"], hip.c_f32p)
-        latent_sample = latent_sample.to(f32).contiguous()
         latent_mean = latent_mean.to(f32).contiguous()
         dest = dest.to(torch.int32).contiguous()
         goal_valid = goal_valid.to(u8).contiguous()
-        assert latent_sample.shape == (n, a, 16) and dest.shape == (n, a) and goal_valid.shape == (n, a)
+        assert dest.shape == (n, a) and goal_valid.shape == (n, a)
         assert latent_mean.shape == (b, a, 16)
+        if latent_sample is None:  # drawn on the device by the prologue
+            if latent_eps is not None:
+                latent_eps = latent_eps.to(device=dev, dtype=f32).contiguous()
+                assert latent_eps.shape == (n, a, 16), (tuple(latent_eps.shape), (n, a, 16))
+            if latent_deterministic is not None:
+                latent_deterministic = latent_deterministic.to(device=dev, dtype=u8).contiguous()
+                assert latent_deterministic.shape == (n, a)
+            if "latent_sample" not in out:
+                out["latent_sample"] = torch.empty(n, a, 16, device=dev, dtype=f32)
+            io.latent_eps = hip.ptr(latent_eps, hip.c_f32p)
+            io.latent_deterministic = hip.ptr(latent_deterministic, hip.c_u8p)
+            io.latent_sample_out = hip.ptr(out["latent_sample"], hip.c_f32p)
+        else:
+            latent_sample = latent_sample.to(f32).contiguous()
+            assert latent_sample.shape == (n, a, 16)
+            out["latent_sample"] = latent_sample
         io.latent_sample = hip.ptr(latent_sample, hip.c_f32p)
         io.latent_mean = hip.ptr(latent_mean, hip.c_f32p)
         io.dest = hip.ptr(dest, hip.c_i32p)
@@ -485,7 +505,8 @@ class HipEngine:
         if default_mask is not None:
             out["_default_tf_mask"] = default_mask
         out["_keepalive_host"] = hd
-        out["_keepalive"] = (latent_sample, latent_mean, dest, goal_valid, mask_teacher_forcing, s, feats, gt, action_eps)
+        out["_keepalive"] = (latent_sample, latent_mean, dest, goal_valid, mask_teacher_forcing, s, feats, gt, action_eps, latent_eps,
+                             latent_deterministic)
         if stepwise:
             self._check(self.lib.tb_rollout_begin(self._ctx, C.byref(io), self._stream()), "tb_rollout_begin")
             self._step_out = out
@@ -494,6 +515,61 @@ class HipEngine:
             self._check(self.lib.tb_rollout(self._ctx, C.byref(io), self._stream()), "tb_rollout")
             self._step_open = False  # (tb_rollout reuses the stepwise context of the library)
         return out
+
+    # -------------------------------------------------------------------------------- the samplers of joint_future_pred
+    def latent_sample(self, mean: Tensor, k_futures: int = 1, eps: Optional[Tensor] = None, deterministic: Optional[Tensor] = None,
+                      forced: Optional[Tensor] = None, posterior: bool = False, want_sample: bool = True, want_log_prob: bool = True,
+                      log_std: Optional[Tensor] = None) -> Tuple[Optional[Tensor], Optional[Tensor]]:
+        """`tb_latent_sample`: `MyDist.sample` / `DiagGaussian.log_prob` (`distributions.py:18-59`) of the personality distribution with
+        the scene-level `mean` [B, A, 16] (instance n uses scene n // K); `log_std` [16] overrides the loaded prior / posterior parameter.
+        Returns (sample [N, A, 16], log_prob [N, A])."""
+        dev, f32 = self.device, torch.float32
+        mean = mean.to(device=dev, dtype=f32).contiguous()
+        b, a, _ = mean.shape
+        n = b * k_futures
+        io = hip.TbLatentSampleIO()
+        io.n_scene, io.k_futures, io.n_agent, io.posterior = b, k_futures, a, int(posterior)
+        eps = None if eps is None else eps.to(device=dev, dtype=f32).contiguous()
+        det = None if deterministic is None else deterministic.to(device=dev, dtype=torch.uint8).contiguous()
+        forced = None if forced is None else forced.to(device=dev, dtype=f32).contiguous()
+        for t_, shape in ((eps, (n, a, 16)), (det, (n, a)), (forced, (n, a, 16))):
+            assert t_ is None or tuple(t_.shape) == shape, (tuple(t_.shape), shape)
+        sample = torch.empty(n, a, 16, device=dev, dtype=f32) if want_sample else None
+        logp = torch.empty(n, a, device=dev, dtype=f32) if want_log_prob else None
+        io.mean, io.eps, io.deterministic = hip.ptr(mean, hip.c_f32p), hip.ptr(eps, hip.c_f32p), hip.ptr(det, hip.c_u8p)
+        io.forced, io.sample, io.log_prob = hip.ptr(forced, hip.c_f32p), hip.ptr(sample, hip.c_f32p), hip.ptr(logp, hip.c_f32p)
+        if log_std is not None:
+            log_std = log_std.to(device=dev, dtype=f32).expand(16).contiguous()
+            io.log_std = hip.ptr(log_std, hip.c_f32p)
+        self._check(self.lib.tb_latent_sample(self._ctx, C.byref(io), self._stream()), "tb_latent_sample")
+        self._keep_sampler = (mean, eps, det, forced, log_std)
+        return sample, logp
+
+    def dest_sample(self, dest_logits: Tensor, k_futures: int = 1, uniform: Optional[Tensor] = None, deterministic: Optional[Tensor] = None,
+                    forced: Optional[Tensor] = None, from_probs: bool = False, want_probs: bool = False
+                    ) -> Tuple[Tensor, Tensor, Optional[Tensor]]:
+        """`tb_dest_sample`: `DestCategorical.sample` / `log_prob` (`distributions.py:158-201`) on the masked destination logits
+        [B, A, P]: arg max where deterministic (or for everybody when `uniform` is None), the inverse CDF of `uniform` [N, A] elsewhere;
+        `forced` [N, A] scores given destinations instead.  Returns (sample [N, A] int32, log_prob [N, A], probs [B, A, P] or None)."""
+        dev, f32 = self.device, torch.float32
+        lg = dest_logits.to(device=dev, dtype=f32).contiguous()
+        b, a, p = lg.shape
+        n = b * k_futures
+        io = hip.TbDestSampleIO()
+        io.n_scene, io.k_futures, io.n_agent, io.n_pl, io.from_probs = b, k_futures, a, p, int(from_probs)
+        u = None if uniform is None else uniform.to(device=dev, dtype=f32).contiguous()
+        det = None if deterministic is None else deterministic.to(device=dev, dtype=torch.uint8).contiguous()
+        forced = None if forced is None else forced.to(device=dev, dtype=torch.int32).contiguous()
+        for t_ in (u, det, forced):
+            assert t_ is None or tuple(t_.shape) == (n, a), (tuple(t_.shape), (n, a))
+        sample = torch.empty(n, a, device=dev, dtype=torch.int32)
+        logp = torch.empty(n, a, device=dev, dtype=f32)
+        probs = torch.empty(b, a, p, device=dev, dtype=f32) if want_probs else None
+        io.dest_logits, io.uniform, io.deterministic = hip.ptr(lg, hip.c_f32p), hip.ptr(u, hip.c_f32p), hip.ptr(det, hip.c_u8p)
+        io.forced, io.sample, io.log_prob, io.probs = hip.ptr(forced, hip.c_i32p), hip.ptr(sample, hip.c_i32p), hip.ptr(logp, hip.c_f32p), hip.ptr(probs, hip.c_f32p)
+        self._check(self.lib.tb_dest_sample(self._ctx, C.byref(io), self._stream()), "tb_dest_sample")
+        self._keep_sampler = (lg, u, det, forced)
+        return sample, logp, probs
 
     def rule_checks(self, s: Dict[str, Tensor], check_state: Tensor, check_valid: Tensor, k_futures: int,
                     flags: Dict[str, bool], tl: Optional[Dict[str, Tensor]] = None, agent_goal: Optional[Tensor] = None

@@ -138,7 +138,7 @@ class _GoalManager:
     def pred_goal(self, **kwargs) -> DestCategorical:
         """`GoalManager.pred_goal` -> `DestPredictor.forward` (`goal_manager.py:78-82,202-333`).  The logits
         were produced together with the features by `encode_input_features`."""
-        return DestCategorical(logits=self._o._enc["dest_logits"], valid=self._o._scene["agent_valid"].bool().any(1))
+        return DestCategorical(logits=self._o._enc["dest_logits"], valid=self._o._scene["agent_valid"].bool().any(1), engine=self._o.engine)
 
     def get_gt_goal(self, agent_valid: Tensor, gt_goal: Optional[Tensor], gt_dest: Tensor) -> Tuple[Tensor, Tensor]:
         """`GoalManager.get_gt_goal`, goal_attr_mode "dest" (`goal_manager.py:50-75`)."""
@@ -199,6 +199,8 @@ class TrafficBots:
         recurrent state.  The sample itself is drawn when the simulator is opened (`WaymoMotion.rollout(..., latent=None)` picks it
         up); `eps` are the explicit standard-normal draws (the reference takes them from torch's global RNG)."""
         self.latent, self.deterministic, self._latent_eps = latent, deterministic, eps
+        if latent is not None and latent.engine is None:
+            latent.engine = self.engine  # (a distribution the caller made by hand is served by this model's device engine)
         self.hidden = None
         self.latent_sample = None
         self.latent_logp = None
@@ -232,8 +234,8 @@ class TrafficBots:
             if gt is None:
                 raise ValueError("latent_encoder(posterior=True) needs the ground truth (pre_processing(batch)['gt'])")
             post = self.engine.encode_posterior(gt, self._enc)
-            return DiagGaussian(post["latent_mean"], self._log_std_post, valid=post["latent_valid"].bool())
-        return DiagGaussian(self._enc["latent_mean"], self._log_std, valid=self._enc["latent_valid"].bool())
+            return DiagGaussian(post["latent_mean"], self._log_std_post, valid=post["latent_valid"].bool(), engine=self.engine)
+        return DiagGaussian(self._enc["latent_mean"], self._log_std, valid=self._enc["latent_valid"].bool(), engine=self.engine)
 
 
 class WaymoMotion:
@@ -339,12 +341,16 @@ class WaymoMotion:
                 action_eps = torch.randn(n_inst, n_ag, step_end - step_start + 1, 2, device=self.device, generator=generator)
         if step_start != self.hparams["time_step_sim_start"]:
             raise NotImplementedError("step_start must equal time_step_sim_start")
-        z = latent.sample(deterministic_latent, eps=latent_eps)
+        # the personality is drawn by the rollout prologue (MyDist.sample, distributions.py:18-38; tb_rollout_io.latent_sample_out)
+        z_eps, z_det = latent._draws(deterministic_latent, latent_eps, generator)
         b = features["agent_valid"].shape[0]
         if warm_start_steps > 0 and not warm_start_promise_holds(
                 mask_teacher_forcing, (gt if gt is not None else features)["agent_valid"], warm_start_steps):
             warm_start_steps = 0  # a caller-made mask that does not force every valid agent: step by step
-        mean_scene = latent.mean.reshape(b, k_futures, *latent.mean.shape[1:])[:, 0].contiguous()
+        if latent._k == k_futures:
+            mean_scene = latent._mean_scene
+        else:  # a per-instance distribution made by hand: the K instances of a scene share its mean (repeat_interleave_, :493)
+            mean_scene = latent.mean.reshape(b, k_futures, *latent.mean.shape[1:])[:, 0].contiguous()
         # traffic_rule_checker.enable_check_* (traffic_bots.yaml:240-244): the flag-gated checks do not feed back into the
         # simulation, they are evaluated on the recorded per-step states once the rollout is enqueued (tb_rule_checks)
         flags = self.hparams.get("traffic_rule_checker", {})
@@ -352,7 +358,7 @@ class WaymoMotion:
         agent_goal = gt.get("gt_goal") if gt is not None else None
         want_checks = any(bool(v) for k, v in flags.items() if k.startswith("enable_check_")) or agent_goal is not None
         out = self.engine.rollout(
-            features, features, z, mean_scene, goal, goal_valid, k_futures, step_end,
+            features, features, None, mean_scene, goal, goal_valid, k_futures, step_end, latent_eps=z_eps, latent_deterministic=z_det,
             mask_teacher_forcing=mask_teacher_forcing.to(torch.uint8).contiguous(), tap_step=tap_step, stepwise=stepwise or per_step,
             record_check_states=want_checks, gt=gt, latent_posterior=latent_posterior, warm_start_steps=warm_start_steps,
             action_eps=action_eps, hidden_drop=hidden_drop,
@@ -366,6 +372,7 @@ class WaymoMotion:
                 and gt["agent_valid"].shape[1] > step_end):
             gv, gs = self._gt_slices(gt, step_start, step_end)
             out["diffbar_rewards"], out["diffbar_rewards_valid"], _ = self.engine.train_partials(out, gv, gs, features["agent_size"])
+        z = out["latent_sample"]
         self._step_t = step_start
         self._rollout_meta = (step_start, step_end, z)
         self._rule_ctx = (features, k_futures, flags, rule_checker_tl, agent_goal) if want_checks else None
