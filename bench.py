@@ -95,6 +95,26 @@ def mfma_issue(n_agent, n_pl_keys, n_tl_keys, planes):
     return units + blocks * 4 * prod
 
 
+def xdl_pipe(n_mfma_per_wave, n_workgroup, k_us):
+    """Fraction of the chip's dense 16-bit MFMA peak (2.5 PFLOP/s) that the launch EXECUTES: every v_mfma_f32_16x16x32 is 16384
+    flops; 4 waves per workgroup.  (The fp32-accurate kernels issue 3 fp16 MFMAs per algorithmic product, the bf16 kernels 1.)"""
+    fl = n_mfma_per_wave * 4 * n_workgroup * 16384.0
+    return {"executed_flops_per_launch": fl, "achieved_TFLOPs": fl / (k_us * 1e-6) / 1e12, "peak_TFLOPs": PEAK_BF16_MFMA_TFLOPS,
+            "frac": fl / (k_us * 1e-6) / 1e12 / PEAK_BF16_MFMA_TFLOPS}
+
+
+def what_binds(mfma_busy, hbm_frac, xdl_frac, load_frac):
+    """`roofline.bound` from measurement, not from the formulation: "hbm" / "mfma" only when that resource is actually busy; below
+    30 % of both (matrix pipe busy share of the wave-resident SIMD time, or the executed share of the XDL peak when no PMC pass
+    matches this build; HBM-side bytes over the launch time) the launch is bound by its dependent-instruction chains in series with
+    the per-CU vector-load path (`load_path`)."""
+    busy = mfma_busy if mfma_busy is not None else xdl_frac
+    hbm = hbm_frac if hbm_frac is not None else 0.0
+    if busy < 0.30 and hbm < 0.30:
+        return "latency/load-path"
+    return "hbm" if hbm >= busy else "mfma"
+
+
 def usable_cpus() -> int:
     """Cores this process may really use: affinity mask capped by the cgroup CPU quota (os.cpu_count() reports the
     host's cores and oversubscribing OpenMP threads on a quota-limited container is catastrophically slow)."""
@@ -360,9 +380,35 @@ def _pmc_records():
                 rec = json.load(open(PMC_FILE))
             except Exception:
                 rec = {}
-        rec["_matches_build"] = bool(rec.get("lib_sha256")) and rec.get("lib_sha256") == lib_sha256()
+        # stamped with the fingerprint of the SOURCES + FLAGS the profiled library was built from (__graft_entry__.build_fingerprint):
+        # the .so itself is not reproducible byte for byte -- hipcc embeds a fresh __hip_cuid_* per invocation
+        import __graft_entry__ as ge
+
+        rec["_matches_build"] = bool(rec.get("src_sha256")) and rec.get("src_sha256") == ge.build_fingerprint() and not ge._stale()
         _PMC_CACHE = rec
     return _PMC_CACHE
+
+
+def sub_roofline(spec, c, fl, by, tf, gbs, k_us, n_inst, pmc):
+    """Roofline block of a sub-record: the fraction of the pipe that EXECUTES (XDL: 3 fp16 MFMAs per product for fp32-accurate
+    operands, 1 for bf16), of the per-CU load path and of HBM; `bound` from those measurements.  The nominal fp32-MFMA roof of SURVEY
+    8(d) is quoted for the fp32-accurate records only (it is the roof of the fp32 FORMULATION; the bf16 kernels do not run on it)."""
+    fp32 = spec["prec"] == "fp32"
+    n_wg = n_inst * ((spec["a"] + 15) // 16)
+    xdl = xdl_pipe(mfma_issue(spec["a"], spec["p"], c["tl_keys_eff"], 2 if fp32 else 1), n_wg, k_us)
+    lp = load_path(k_us, spec["a"], spec["p"], c["tl_keys_eff"], 4 if fp32 else 2)
+    traffic = (pmc or {}).get("fetch_bytes_per_launch")
+    hbm_frac = (traffic / (k_us * 1e-6) / 1e9 / PEAK_HBM_GBS) if traffic else gbs / PEAK_HBM_GBS
+    r = {"bound": what_binds((pmc or {}).get("mfma_busy"), hbm_frac, xdl["frac"], lp["frac"]),
+         "flops_per_launch": fl, "achieved_TFLOPs": tf, "xdl_pipe": xdl, "xdl_pipe_frac": xdl["frac"],
+         "load_path": lp, "load_path_frac": lp["frac"],
+         "algorithmic_bytes_per_launch": by, "achieved_GBs_algorithmic": gbs, "frac_hbm_peak": gbs / PEAK_HBM_GBS,
+         "traffic": traffic, "traffic_over_algorithmic": (traffic / by) if traffic else None, "hbm_frac_measured": hbm_frac if traffic else None,
+         "mfma_busy_measured": (pmc or {}).get("mfma_busy"),
+         "avg_launch_us_kernel_trace": (pmc or {}).get("avg_fused_launch_us_kernel_trace")}
+    if fp32:
+        r["frac_fp32_mfma_peak_nominal"] = tf / PEAK_FP32_MFMA_TFLOPS
+    return r
 
 
 def sub_record(name, spec, sd, dev, rank, world, steps, warmup):
@@ -388,15 +434,7 @@ def sub_record(name, spec, sd, dev, rank, world, steps, warmup):
         "value": world * n_inst * spec["step_end"] * steps / elapsed, "unit": "scene-steps/s", "passes": steps,
         "ms_per_pass": elapsed / steps * 1e3, "k_step_fused_us": k_us, "n_fused": tm["n_fused"],
         "workgroups_per_launch": n_inst * ((spec["a"] + 15) // 16),
-        "roofline": {"flops_per_launch": fl, "achieved_TFLOPs": tf,
-                     "frac_fp32_mfma_peak": tf / PEAK_FP32_MFMA_TFLOPS, "frac_bf16_mfma_peak": tf / PEAK_BF16_MFMA_TFLOPS,
-                     "algorithmic_bytes_per_launch": by, "achieved_GBs_algorithmic": gbs, "frac_hbm_peak": gbs / PEAK_HBM_GBS,
-                     "bound": "mfma (fp32 formulation)" if spec["prec"] == "fp32" else
-                              ("hbm" if gbs / PEAK_HBM_GBS > tf / PEAK_BF16_MFMA_TFLOPS else "mfma (bf16)"),
-                     "traffic": (pmc or {}).get("fetch_bytes_per_launch"),
-                     "traffic_over_algorithmic": ((pmc["fetch_bytes_per_launch"] / by) if pmc and pmc.get("fetch_bytes_per_launch") else None),
-                     "mfma_busy_measured": (pmc or {}).get("mfma_busy"),
-                     "avg_launch_us_kernel_trace": (pmc or {}).get("avg_fused_launch_us_kernel_trace")},
+        "roofline": sub_roofline(spec, c, fl, by, tf, gbs, k_us, n_inst, pmc),
         "host_cpu_ms_per_pass": tm["host_cpu_ms_per_pass"], "rollout_graph": tm["rollout_graph"],
         "finite": bool(red["finite_ranks"] == world),
     }
@@ -581,19 +619,29 @@ def run_rank(args, rank: int, local_rank: int, world: int) -> None:
                                     "(slowest rank's ms per pass); not `value`") if sustained else None),
             "pmc_matches_build": _pmc_records().get("_matches_build", False),
             "lib_sha256": lib_sha256(),
+            "src_sha256": __import__("__graft_entry__").build_fingerprint(),
             "encode_ms": encode_ms,
             "encode_gpu_ms": encode_gpu_ms,
             "pass_ms": {"min": pass_ms[0], "median": pass_ms[len(pass_ms) // 2], "max": pass_ms[-1]},
             "kernel_us": {"k_step_fused": k_us, "n_fused": tm["n_fused"], "edge_launches_ms": tm["edge_ms"], "prologue_ms": tm["prologue_ms"],
                           "note": "per rollout: n_fused fused launches; edge_launches_ms = the batched warm-start launch (A halves of the "
                                   "teacher-forced steps, k_step_x<true>), their C-only launches and the last step's"},
-            "roofline": {"bound": "mfma", "kernel": "tb::xh::k_step_x<false, false> (PRE = LEAN = false: the fused C(t)+A(t+1) launch of a simulation step)", "achieved": achieved,
+            "roofline": {"bound": what_binds((pmc or {}).get("mfma_busy"), (traffic / (k_us * 1e-6) / 1e9 / PEAK_HBM_GBS) if traffic else None,
+                                             xdl_pipe(n_mfma, B_PER_GPU * ((N_AGENT + 15) // 16), k_us)["frac"], 0.0),
+                         "bound_how": "from measurement (bench.py::what_binds): matrix pipe busy share and HBM share both below 30 % -> the "
+                                      "launch is bound by dependent-instruction chains in series with the per-CU vector-load path; `frac` "
+                                      "below stays the SURVEY 8(d) figure (algorithmic fp32 flops over the fp32-MFMA peak of the fp32 "
+                                      "formulation), `xdl_pipe_frac` / `load_path_frac` / `hbm` are the fractions of what executes",
+                         "xdl_pipe": xdl_pipe(n_mfma, B_PER_GPU * ((N_AGENT + 15) // 16), k_us),
+                         "xdl_pipe_frac": xdl_pipe(n_mfma, B_PER_GPU * ((N_AGENT + 15) // 16), k_us)["frac"],
+                         "load_path_frac": load_path(k_us, N_AGENT, N_PL, tl_keys_eff, 4 if prec == "fp32" else 2)["frac"],
+                         "kernel": "tb::xh::k_step_x<false, false> (PRE = LEAN = false: the fused C(t)+A(t+1) launch of a simulation step)", "achieved": achieved,
                          "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
                          "traffic": traffic,
                          "traffic_unit": "HBM-side bytes per launch: rocprofv3 --pmc FETCH_SIZE x 2 (gfx950 correction of the guide) from the "
                                          "PMC pass recorded in profiles/pmc_step_kernel.json (tools/gpu_pmc_step.sh; separate rocprofv3 --pmc passes, so not collected "
-                                         "in this process: the file carries the SHA-256 of the library it was collected on and is used only when "
-                                         "that is the library timed here -- `pmc_matches_build`; null otherwise)",
+                                         "in this process: the file carries the fingerprint of the sources + flags of the library it was collected on "
+                                         "and is used only when the library timed here was built from the same -- `pmc_matches_build`; null otherwise)",
                          "flops_per_launch": fl, "avg_launch_us": k_us,
                          "note": "algorithmic fp32 flops = 176.1 MFLOP per scene-step (SURVEY 8(d)) x 32 scenes per launch, priced against "
                                  "the fp32-MFMA peak of the fp32 formulation; the kernel issues them as 3 fp16 MFMAs per product on the XDL "
@@ -619,7 +667,7 @@ def run_rank(args, rank: int, local_rank: int, world: int) -> None:
                 "encode_ms": encode_ms, "achieved": flops_encode(N_AGENT, N_PL) * B_PER_GPU / (encode_ms * 1e-3) / 1e12,
                 "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                 "frac": flops_encode(N_AGENT, N_PL) * B_PER_GPU / (encode_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
-                "dominant_kernel": (pmc or {}).get("encode_dominant_kernel", "tb::xh::k_xattn_block_plh (map densetnt block, head tiles of the B*P polylines)"),
+                "dominant_kernel": (pmc or {}).get("encode_dominant_kernel", "tb::xh::k_polyline_fused (map densetnt block + node pooling, two polylines per workgroup)"),
                 "note": "SURVEY 8(d): F_map + F_dest + F_latent_prior per scene x 32 scenes / host-timed tb_encode_scene (all its launches, "
                         "one synchronize); one-time per batch, not part of `value`"},
             "max_abs_traj_err": None,

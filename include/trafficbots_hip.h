@@ -36,8 +36,11 @@ typedef struct tb_config {
     float max_yaw_rate[3];
     float action_log_std;        /* -2 (traffic_bots.yaml:138) */
     float latent_log_std;        /* -1 (traffic_bots.yaml:76); overwritten by the loaded parameter */
-    int32_t operand_precision;   /* 0 (default): fp32-accurate (fp16-pair MFMA operands, fp32 accumulate);
-                                  * 1: bf16 MFMA operands, fp32 accumulate -- BASELINE.json configs 4/5, no fp32-parity claim */
+    int32_t operand_precision;   /* 0 (default): fp32-accurate (fp16-pair MFMA operands, fp32 accumulate), with an AUTOMATIC fallback to
+                                  *    the exact-fp32 kernels when a loaded tensor or a run-time activation leaves the fp16-pair range
+                                  *    (|x| < 65504): tb_finalize_weights / tb_check_status / tb_precision_state;
+                                  * 1: bf16 MFMA operands, fp32 accumulate -- BASELINE.json configs 4/5, no fp32-parity claim;
+                                  * 2: exact fp32 from the start (fp32 MFMA kernels: fp32's range, about 2x slower per step) */
 } tb_config;
 
 /* -- lifecycle ----------------------------------------------------------------------------------- */
@@ -48,10 +51,17 @@ const char* tb_last_error(tb_ctx* ctx);
 /* Range check of the fp32-accurate mode (the one call of this header that SYNCHRONISES `stream`).  The XDL kernels carry an fp32
  * value as an fp16 pair, valid for |x| < 65504; a GEMM / attention operand beyond that raises a sticky device flag where it is
  * produced (the overflow would otherwise turn into inf / NaN that ReLU and the softmax clamp can squash silently).  Returns 0 when
- * no kernel queued on this device since the previous check raised it, non-zero otherwise (tb_last_error names the stage); the
- * flag is cleared either way.  The reference has no counterpart (its fp32 ops overflow at 3.4e38); operand_precision = 1 (bf16)
- * has fp32's range and never raises it. */
+ * no kernel queued on this device since the previous check raised it; the flag is cleared either way.
+ * Returns 3 when it was raised: the results of the calls since the previous check are invalid AND the context has switched itself
+ * to the exact-fp32 twins of the kernels that overflowed (fp32's range) -- re-issue those calls (the reference has no range limit,
+ * src/models/modules/mlp.py:20-85, so neither has this library: it only gets slower).  Any other non-zero value is a hard error
+ * (tb_last_error).  operand_precision = 1 (bf16) and 2 (exact fp32) have fp32's range and never raise the flag. */
 int tb_check_status(tb_ctx* ctx, tb_stream stream);
+/* Which kernels the context runs on: out[0] = step kernels, out[1] = scene encoders (0 fp16-pair XDL, 1 bf16, 2 exact fp32 MFMA);
+ * out[2] = why it left the configured ones (bit 0: a loaded tensor is outside the fp16-pair range, seen by tb_finalize_weights;
+ * bit 1: a run-time activation overflow, seen by tb_check_status).  tb_precision_note: the sentence naming the tensor / stage. */
+int tb_precision_state(tb_ctx* ctx, int32_t out[3]);
+const char* tb_precision_note(tb_ctx* ctx);
 /* Version / build info string (static storage). */
 const char* tb_version(void);
 
@@ -135,7 +145,8 @@ typedef struct tb_rollout_io {
     const float* action_eps;       /* [N,A,S,2] */
     /* optional (NULL = never): train-mode `p_drop_hidden` (waymo_motion.py:345-351) with the caller's draws -- a HOST array of S
      * bytes, read while the launches are enqueued: where hidden_drop[s] is set the GRU hidden state of ALL instances is zeroed after
-     * step s has been recorded (the reference draws one `torch.rand(1) < p_drop_hidden` per step for the whole batch). */
+     * step s has been recorded (the reference draws one `torch.rand(1) < p_drop_hidden` per step for the whole batch).
+     * tb_rollout ONLY: tb_rollout_begin fails when it is set (a stepwise caller zeroes the state between its own step calls). */
     const uint8_t* hidden_drop;    /* [S] host memory */
     /* optional (round 4): draw the personalities INSIDE the rollout prologue (`MyDist.sample`, distributions.py:18-38, called by
      * TrafficBots.forward on the first step, traffic_bots.py:196-199).  When latent_sample_out is non-NULL the prologue computes

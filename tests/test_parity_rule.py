@@ -93,3 +93,15 @@ def test_bench_and_tests_share_the_rule():
     assert "closed_loop_rule" in src and "ens_d32" not in src
     t = open(os.path.join(ROOT, "tests", "test_gpu_parity.py")).read()
     assert "closed_loop_rule" in t and "suite_rule" in t and "base64 + b32" not in t
+
+
+def test_rule_is_calibrated_on_the_references_own_runs():
+    """Leave-one-out on the 1008 member runs of the committed reference ensembles (tools/rule_calibration.py): a member is a correct
+    fp32 run by construction, so what the rule flags among them is its false-alarm rate.  Nominal alpha = 1e-3 -> ~1 expected; the rule
+    without its quantisation term flagged 6."""
+    from tools import rule_calibration
+
+    tot, flagged = rule_calibration.leave_one_out(ensemble.QUANT)
+    assert tot == 1008 and len(flagged) <= 3, flagged
+    tot0, flagged0 = rule_calibration.leave_one_out(0.0)
+    assert len(flagged0) > len(flagged)

@@ -143,13 +143,24 @@ def rank_among(devs: np.ndarray, value: float) -> str:
 #     (a) |hip - fp64 twin|(t)  <= max(FLOOR, PB(members' + base run's distances to the fp64 twin)(t))
 #     (b) |hip - base fp32|(t)  <= max(FLOOR, PB(members' distances to the base fp32 run)(t))
 #     (c) |hip - base fp32|(t)  <= FLOOR for every t <= flat_until (north_star's flat bound where it is attainable)
-#   with PB = prediction_bound(alpha = ALPHA) and FLOOR = north_star's 1e-4 m.
+#   with PB = prediction_bound(alpha = ALPHA) + QUANT and FLOOR = north_star's 1e-4 m.
+#   QUANT = 2^-16 m = one fp32 ulp of a coordinate in [128, 256) m (the maps extend to +-150 m): a max-abs distance between two fp32
+#   trajectories is only resolved to that.  History, kept because the rule was frozen before it was used: v1 (commit "Closed-loop parity
+#   guard tightened") had no QUANT term.  Its first GPU run (profiles/r04_rule_calibration.txt) had the HIP path outside on 2 of 20
+#   cases by 3 % and 5 % (headline_8: 2.877e-4 against 2.793e-4 at step 88; an oracle-made ensemble whose members all sit within 1 % of
+#   9.6e-5 m at step 63, HIP at 1.05e-4 m -- one ulp away) while the suite-level rule, ranks and ratios were unremarkable (geometric
+#   mean HIP / median member 0.98).  A leave-one-out test on the REFERENCE's own members (tools/rule_calibration.py: each of the 1008
+#   member runs of the 16 goldens judged by the rule fitted to the other members of its case -- no HIP number involved) showed v1's
+#   false-alarm rate at 6 of 1008 = 6x its nominal alpha, every excess between 1.01x and 1.24x: where the members' spread collapses
+#   below the resolution of the coordinates the log-normal limit is narrower than one ulp.  With QUANT the same test gives 2 of 1008.
+#   tests/test_parity_rule.py pins that calibration.
 #   per suite (suite_rule): over all cases with a reference-made ensemble,
 #     (S1) #cases in which HIP ends farther from the fp64 twin than EVERY member <= the 99 % binomial quantile for p = 1 / (M + 1);
 #     (S2) geometric mean over the cases of  HIP's final distance to fp64 / the median member's  <= 1.5
 #          (a 2x regression of the whole path turns the suite red even when every per-case bound still holds).
 ALPHA = 1e-3
 FLOOR = 1e-4
+QUANT = 2.0 ** -16
 SUITE_GEOMEAN_MAX = 1.5
 
 
@@ -157,7 +168,7 @@ def closed_loop_rule(d32: np.ndarray, d64: np.ndarray, ens_d32: np.ndarray, ens_
     """d32 / d64 [S]: per-step max-abs xy distance of the run under test to the base fp32 run / the fp64 twin; ens_d32 [M,S] members vs
     base fp32; ens_d64 [M(+1),S] members (and the base run) vs the fp64 twin; n_flat = number of leading steps under the flat bound.
     Returns the verdict and everything that is reported next to it."""
-    b32, b64 = prediction_bound(ens_d32, ALPHA), prediction_bound(ens_d64, ALPHA)
+    b32, b64 = prediction_bound(ens_d32, ALPHA) + QUANT, prediction_bound(ens_d64, ALPHA) + QUANT
     lim32, lim64 = np.maximum(FLOOR, b32), np.maximum(FLOOR, b64)
     r32, r64 = np.maximum.accumulate(d32.astype(np.float64)), np.maximum.accumulate(d64.astype(np.float64))
     fin32, fin64 = np.maximum.accumulate(ens_d32, axis=1)[:, -1].astype(np.float64), np.maximum.accumulate(ens_d64, axis=1)[:, -1].astype(np.float64)

@@ -1,6 +1,6 @@
 """gpurun_out/pmc_step/<name>/ (tools/gpu_pmc_step.sh) -> the small JSON bench.py reads (profiles/pmc_step_kernel.json): per fused
 launch of the step kernel, medians over the launches of the short profiled run, for the headline shape (`fp32`, `bf16`) and the
-BASELINE configs[3] / configs[4] shapes (`k6_*`, `stress_*`), stamped with the SHA-256 of the library the passes ran on.
+BASELINE configs[3] / configs[4] shapes (`k6_*`, `stress_*`), stamped with the fingerprint of the sources + flags of the library the passes ran on (and that file's own SHA-256).
 
 Normalisations (checked against each other on this kernel, see `checks`):
   * FETCH_SIZE / WRITE_SIZE are KiB; FETCH_SIZE x 2 on gfx950 for wide coalesced reads (MI355X_MICROARCH.md, HBM section);
@@ -20,7 +20,13 @@ import sys
 root = sys.argv[1]
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 lib = os.environ.get("TB_HIP_LIB") or os.path.join(ROOT, "trafficbots_amd", "lib", "libtrafficbots_hip.so")
-out = {"lib_sha256": hashlib.sha256(open(lib, "rb").read()).hexdigest() if os.path.exists(lib) else None,
+sys.path.insert(0, ROOT)
+import __graft_entry__ as _ge  # noqa: E402
+
+# src_sha256 = fingerprint of sources + flags (what bench.py's pmc_matches_build compares: a rebuild of equal sources gives equal device
+# code but never an equal .so -- hipcc embeds a fresh __hip_cuid_* per invocation); lib_sha256 is kept as a record of the file profiled
+out = {"src_sha256": _ge.build_fingerprint(),
+       "lib_sha256": hashlib.sha256(open(lib, "rb").read()).hexdigest() if os.path.exists(lib) else None,
        "collected_by": "tools/gpu_pmc_step.sh (rocprofv3 --kernel-trace --stats + separate --pmc passes over short bench.py runs)"}
 for name in sorted(os.listdir(root)):
     d = os.path.join(root, name)

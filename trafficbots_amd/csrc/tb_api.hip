@@ -146,6 +146,11 @@ std::vector<float> pack_xdl(const float* w, int n_out, int k) {
 struct Stage {
     tb_ctx* ctx;
     bool ok = true;
+    // fp16-pair range bookkeeping (xdl_range_ok / ln_range_ok): which kernel family the first out-of-range tensor belongs to
+    // (bit 0: step kernels, bit 1: scene encoders) and what it was; never an error by itself -- tb_finalize_weights decides
+    unsigned range_hit = 0;
+    unsigned range_scope = 3;  // family of the tensors being packed right now
+    std::string range_what;
     const std::vector<float>* get(const std::string& name, size_t numel) {
         auto it = ctx->staged.find(name);
         if (it == ctx->staged.end()) {
@@ -203,9 +208,12 @@ bool xdl_range_ok(Stage& s, const std::string& name, const float* w, size_t n) {
     float m = 0.f;
     for (size_t i = 0; i < n; ++i) m = std::fmax(m, std::fabs(w[i]));
     if (m < 65504.0f) return true;
-    if (s.ok) tb_fail(s.ctx, "weight '%s': max |w| = %g is outside the fp16-pair range of the fp32-accurate kernels (|w| < 65504); "
-                             "rescale the layer or use operand_precision = bf16", name.c_str(), (double)m);
-    s.ok = false;
+    if (!s.range_hit) {
+        char buf[512];
+        snprintf(buf, sizeof(buf), "weight '%s': max |w| = %g is outside the fp16-pair range of the fp32-accurate XDL kernels (|w| < 65504)", name.c_str(), (double)m);
+        s.range_what = buf;
+    }
+    s.range_hit |= s.range_scope;
     return false;
 }
 
@@ -239,9 +247,13 @@ void ln_range_ok(Stage& s, const std::string& p) {
         mb = std::fmax(mb, std::fabs((*b)[i]));
     }
     if (11.27f * mg + mb < 65504.0f) return;
-    if (s.ok) tb_fail(s.ctx, "LayerNorm '%s': sqrt(127) max|weight| + max|bias| = %g is outside the fp16-pair operand range (< 65504)", p.c_str(),
-                      (double)(11.27f * mg + mb));
-    s.ok = false;
+    if (!s.range_hit) {
+        char buf[512];
+        snprintf(buf, sizeof(buf), "LayerNorm '%s': sqrt(127) max|weight| + max|bias| = %g is outside the fp16-pair operand range (< 65504)", p.c_str(),
+                 (double)(11.27f * mg + mb));
+        s.range_what = buf;
+    }
+    s.range_hit |= s.range_scope;
 }
 
 tb::XLayerW add_xlayer(Arena& a, Stage& s, const std::string& p) {
@@ -357,13 +369,18 @@ int tb_create(const tb_config* cfg, tb_ctx** out) {
     }
     tb_ctx* c = new tb_ctx();
     c->cfg = *cfg;
-    if (cfg->operand_precision != 0 && cfg->operand_precision != 1) {
-        fprintf(stderr, "trafficbots_hip: tb_config.operand_precision must be 0 (fp32-accurate) or 1 (bf16 operands)\n");
+    if (cfg->operand_precision < 0 || cfg->operand_precision > 2) {
+        fprintf(stderr, "trafficbots_hip: tb_config.operand_precision must be 0 (fp32-accurate, fp16-pair XDL kernels with automatic fallback), "
+                        "1 (bf16 operands) or 2 (exact fp32: fp32 MFMA kernels)\n");
         delete c;
         return 1;
     }
     if (cfg->operand_precision == 1) c->step_kernel = 3;
-    if (const char* w = getenv("TB_ENCODE_KERNEL")) {  // development switch between the scene-encoder attention kernels
+    if (cfg->operand_precision == 2) {
+        c->step_kernel = 0;
+        c->encode_kernel = 0;
+    }
+    if (const char* w = cfg->operand_precision == 2 ? nullptr : getenv("TB_ENCODE_KERNEL")) {  // development switch between the scene-encoder attention kernels
         const std::string k = w;
         if (k == "fp32")
             c->encode_kernel = 0;
@@ -375,7 +392,7 @@ int tb_create(const tb_config* cfg, tb_ctx** out) {
             return 1;
         }
     }
-    if (const char* w = cfg->operand_precision == 1 ? nullptr : getenv("TB_STEP_KERNEL")) {  // development switch between the fp32-accurate step kernels
+    if (const char* w = cfg->operand_precision != 0 ? nullptr : getenv("TB_STEP_KERNEL")) {  // development switch between the fp32-accurate step kernels
         const std::string k = w;
         if (k == "fp32")
             c->step_kernel = 0;
@@ -596,6 +613,18 @@ int tb_finalize_weights(tb_ctx* ctx, tb_stream stream) {
         ew.dest_b2 = add_plain(a, s, p + "6.bias", 1);
     }
     if (!s.ok) return 1;
+    // ---- fp16-pair range of the loaded tensors: the reference has no range limit (src/models/modules/mlp.py:20-85), so a checkpoint
+    // outside it is not refused -- the context falls back to the exact-fp32 twins (fp32 MFMA step kernel k_step, fp32-MFMA encoder
+    // blocks), which have fp32's range, and says so (tb_precision_state; once on stderr)
+    if (s.range_hit && ctx->cfg.operand_precision != 2) {
+        ctx->encode_kernel = 0;
+        if (ctx->cfg.operand_precision == 0) ctx->step_kernel = 0;
+        ctx->precision_reason |= 1;
+        ctx->precision_note = s.range_what + (ctx->cfg.operand_precision == 0
+                                  ? ": this context runs on the exact-fp32 kernels (fp32 MFMA; about 2x slower per step, same results class)"
+                                  : ": the scene encoders of this context run on their exact-fp32 kernels (the bf16 step kernels have fp32's range)");
+        fprintf(stderr, "trafficbots_hip: %s\n", ctx->precision_note.c_str());
+    }
 
     if (ctx->d_arena) {
         TB_HIP(ctx, hipFree(ctx->d_arena));
@@ -638,6 +667,7 @@ extern "C" int tb_forward(tb_ctx* ctx, const tb_forward_io* io, tb_stream stream
     TB_HIP(ctx, hipSetDevice(ctx->device));
     if (io->n_inst <= 0 || io->n_agent <= 0 || io->n_pl <= 0 || io->n_tl <= 0) return tb_fail(ctx, "tb_forward: empty dimension");
     if (io->n_agent > 4096 || io->n_pl > 8192 || io->n_tl > 8192) return tb_fail(ctx, "tb_forward: more than 8192 keys per attention are not supported");
+    if (io->n_inst > 65535) return tb_fail(ctx, "tb_forward: more than 65535 instances per call (grid.y) are not supported");
     const void* need[] = {io->agent_valid, io->agent_feature, io->map_valid, io->map_feature, io->tl_valid, io->tl_feature, io->latent_sample,
                           io->hidden, io->policy_feature};
     for (const void* q : need)
@@ -895,13 +925,12 @@ static void rollout_prologue(const tb_ctx* ctx, const tb::RolloutP& p, const tb_
 
 static int rollout_enqueue(tb_ctx* ctx, const tb_rollout_io* io, const tb::RolloutP& p, hipStream_t s);
 
-static unsigned long long fnv1a(const void* data, size_t n, unsigned long long h) {
+// every launch-shaping development switch read below this call (step_launch, rollout_prologue): part of the graph key
+static const char* const kGraphEnv[] = {"TB_STEP_W3", "TB_STEP_LEAN", "TB_STEP_HELPERS", "TB_GRU_HELPER", "TB_DEBUG_HELPER_DELAY", "TB_STEP_KERNEL"};
+
+static void key_append(std::vector<unsigned char>& k, const void* data, size_t n) {
     const unsigned char* b = static_cast<const unsigned char*>(data);
-    for (size_t i = 0; i < n; ++i) {
-        h ^= b[i];
-        h *= 1099511628211ull;
-    }
-    return h;
+    k.insert(k.end(), b, b + n);
 }
 
 extern "C" int tb_rollout(tb_ctx* ctx, const tb_rollout_io* io, tb_stream stream_) {
@@ -910,52 +939,61 @@ extern "C" int tb_rollout(tb_ctx* ctx, const tb_rollout_io* io, tb_stream stream
     hipStream_t s = (hipStream_t)stream_;
     ctx->step_active = false;
     // ---- one hipGraph per rollout: every kernel argument of the launch sequence is a function of (p, io, the development switches),
-    // so a rollout with the same key replays the captured graph (bench loops, a serving loop over fixed buffers)
+    // so a rollout with the same argument bytes replays the captured graph (bench loops, a serving loop over fixed buffers)
     const char* ge = getenv("TB_ROLLOUT_GRAPH");
     const bool use_graph = !(ge && ge[0] == '0') && !ctx->timing && ctx->step_kernel >= 2;
     if (!use_graph) return rollout_enqueue(ctx, io, p, s);
-    unsigned long long key = fnv1a(&p, sizeof(p), 1469598103934665603ull);
-    key = fnv1a(io, sizeof(*io), key);
-    if (io->hidden_drop) key = fnv1a(io->hidden_drop, (size_t)p.n_step_out, key);  // (host data that shapes the launch sequence)
-    for (const char* name : {"TB_STEP_W3", "TB_STEP_LEAN", "TB_STEP_HELPERS", "TB_GRU_HELPER"}) {
+    std::vector<unsigned char> key;
+    key.reserve(sizeof(p) + sizeof(*io) + 256);
+    key_append(key, &p, sizeof(p));
+    key_append(key, io, sizeof(*io));
+    if (io->hidden_drop) key_append(key, io->hidden_drop, (size_t)p.n_step_out);  // (host data that shapes the launch sequence)
+    for (const char* name : kGraphEnv) {
         const char* v = getenv(name);
-        key = fnv1a(v ? v : "-", v ? strlen(v) + 1 : 2, key);
+        key_append(key, v ? v : "-", v ? strlen(v) + 1 : 2);
     }
     if (ctx->graph_exec && key == ctx->graph_key) {
         ++ctx->graph_hits;
         TB_HIP(ctx, hipGraphLaunch(ctx->graph_exec, s));
         return 0;
     }
+    if (key == ctx->graph_nocapture) return rollout_enqueue(ctx, io, p, s);  // its capture failed once: plain launches from then on
     if (key != ctx->graph_seen) {  // first sight of this argument set: plain launches (a caller with fresh buffers per call never captures)
         ctx->graph_seen = key;
         return rollout_enqueue(ctx, io, p, s);
     }
+    // a capture / instantiate failure is not the caller's problem: the error is cleared, the argument set is marked, and the rollout
+    // runs as plain launches on the caller's stream -- now and on every later call
+    auto fallback = [&]() {
+        (void)hipGetLastError();
+        ctx->graph_nocapture = key;
+        return rollout_enqueue(ctx, io, p, s);
+    };
     hipGraph_t graph = nullptr;
     // captured on a private stream (nothing runs there: the launches are only recorded), launched on the caller's -- which may be the
     // legacy default stream, where a capture cannot begin
     if (!ctx->cap_stream && hipStreamCreateWithFlags(&ctx->cap_stream, hipStreamNonBlocking) != hipSuccess) {
-        (void)hipGetLastError();
         ctx->cap_stream = nullptr;
-        return rollout_enqueue(ctx, io, p, s);
+        return fallback();
     }
-    if (hipStreamBeginCapture(ctx->cap_stream, hipStreamCaptureModeThreadLocal) != hipSuccess) {
-        (void)hipGetLastError();
-        return rollout_enqueue(ctx, io, p, s);
-    }
+    if (hipStreamBeginCapture(ctx->cap_stream, hipStreamCaptureModeThreadLocal) != hipSuccess) return fallback();
     const int rc = rollout_enqueue(ctx, io, p, ctx->cap_stream);
     const hipError_t ec = hipStreamEndCapture(ctx->cap_stream, &graph);
-    if (rc) {
+    if (rc || ec != hipSuccess || !graph) {
         if (graph) (void)hipGraphDestroy(graph);
-        return rc;
+        return fallback();
     }
-    TB_HIP(ctx, ec);
     if (ctx->graph_exec) {
         (void)hipGraphExecDestroy(ctx->graph_exec);
         ctx->graph_exec = nullptr;
+        ctx->graph_key.clear();
     }
     const hipError_t ei = hipGraphInstantiate(&ctx->graph_exec, graph, nullptr, nullptr, 0);
     (void)hipGraphDestroy(graph);
-    TB_HIP(ctx, ei);
+    if (ei != hipSuccess || !ctx->graph_exec) {
+        ctx->graph_exec = nullptr;
+        return fallback();
+    }
     ctx->graph_key = key;
     ++ctx->graph_captures;
     TB_HIP(ctx, hipGraphLaunch(ctx->graph_exec, s));
@@ -1110,6 +1148,8 @@ extern "C" int tb_dest_sample(tb_ctx* ctx, const tb_dest_sample_io* io, tb_strea
 extern "C" int tb_rollout_begin(tb_ctx* ctx, const tb_rollout_io* io, tb_stream stream_) {
     tb::RolloutP p;
     if (rollout_setup(ctx, io, p)) return 1;
+    // (tb_rollout-only fields: refused here rather than silently ignored -- ADVICE r03)
+    if (io->hidden_drop) return tb_fail(ctx, "tb_rollout_begin: hidden_drop is honoured by tb_rollout only (zero the hidden state between tb_rollout_step calls yourself)");
     hipStream_t s = (hipStream_t)stream_;
     rollout_prologue(ctx, p, io, s);
     step_launch(ctx, p, p, p.step_start - 1, /*do_c=*/0, /*do_a=*/1, s);  // A(sim_start)
@@ -1175,10 +1215,20 @@ extern "C" int tb_check_status(tb_ctx* ctx, tb_stream stream_) {
     if (hw[1])
         return tb_fail(ctx, "step kernel: a tile workgroup gave up waiting for its helper workgroup (the helpers of a launch are expected to be "
                             "dispatched first); results since the last check are invalid -- set TB_STEP_HELPERS=0 and report");
-    if (h)
-        return tb_fail(ctx, "fp16-pair operand range exceeded: a GEMM / attention input of the %s%s%s reached |x| >= 65504 since the last "
-                            "check (results of those calls are invalid; activations of this magnitude need operand_precision = bf16 or rescaled weights)",
-                       (h & 1u) ? "step kernels" : "", (h == 3u) ? " and the " : "", (h & 2u) ? "scene encoders" : "");
+    if (h) {
+        // The results of the calls since the last check are invalid, and the context switches ITSELF to the exact-fp32 twins of the
+        // kernels that overflowed (fp32's range): the caller re-issues those calls -- the host mirror does it automatically
+        // (WaymoMotion(check_range=True)).  Return code 3 tells this case apart from a hard error.
+        if ((h & 1u) && ctx->step_kernel == 2) ctx->step_kernel = 0;
+        if (h & 2u) ctx->encode_kernel = 0;
+        ctx->precision_reason |= 2;
+        tb_fail(ctx, "fp16-pair operand range exceeded: a GEMM / attention input of the %s%s%s reached |x| >= 65504 since the last "
+                     "check; the results of those calls are invalid.  The context has switched to the exact-fp32 kernels (fp32 MFMA, fp32's range, "
+                     "about 2x slower per step): re-issue the calls",
+                (h & 1u) ? "step kernels" : "", (h == 3u) ? " and the " : "", (h & 2u) ? "scene encoders" : "");
+        ctx->precision_note = ctx->err;
+        return 3;
+    }
     return 0;
 }
 
@@ -1191,6 +1241,16 @@ extern "C" int tb_rollout_state(tb_ctx* ctx, float* state, uint8_t* valid, float
     TB_HIP(ctx, hipGetLastError());
     return 0;
 }
+
+// which kernels this context runs on, and why (header)
+extern "C" int tb_precision_state(tb_ctx* ctx, int32_t* out3) {
+    if (!ctx || !out3) return 1;
+    out3[0] = ctx->step_kernel == 3 ? 1 : (ctx->step_kernel == 2 ? 0 : 2);
+    out3[1] = ctx->encode_kernel == 1 ? 0 : 2;
+    out3[2] = ctx->precision_reason;
+    return 0;
+}
+extern "C" const char* tb_precision_note(tb_ctx* ctx) { return ctx ? ctx->precision_note.c_str() : ""; }
 
 // development aid (not in the public header): copy the stage time stamps of the last launch of a -DTB_PROFILE build
 // hipGraph statistics of the context: out[0] = rollouts captured, out[1] = rollouts replayed from a captured graph

@@ -245,9 +245,17 @@ const char* run_forward(const std::map<std::string, const float*>& raw, const tb
         lin(s_ln, H, w_in, H, b_in, q, H, R, H, H, 0);
         ln(tgt, pre + ".norm_tgt", t_ln, N * T);
         lin(t_ln, H, ok ? w_in + (size_t)H * H : nullptr, H, ok ? b_in + H : nullptr, kv, 2 * H, N * T, H, 2 * H, 0);
-        if (ok)
-            hipLaunchKernelGGL(k_attention, dim3(A, N), dim3(128), (H + NH * T + 8) * sizeof(float), s, q, kv, kv + H, 2 * H, tgt_valid, A, T, eye,
-                               att, wout, no_tgt);
+        if (ok) {
+            // up to 8192 keys: 4 x T logits in LDS = 131.6 KB of gfx950's 160 KB -- above the 64 KB a kernel gets without asking
+            const size_t lds = (H + NH * T + 8) * sizeof(float);
+            static bool big_lds = false;
+            if (lds > 48 * 1024 && !big_lds) {
+                ok = hipFuncSetAttribute(reinterpret_cast<const void*>(k_attention), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int)((H + NH * 8192 + 8) * sizeof(float))) == hipSuccess;
+                big_lds = ok;
+            }
+            if (ok) hipLaunchKernelGGL(k_attention, dim3(A, N), dim3(128), lds, s, q, kv, kv + H, 2 * H, tgt_valid, A, T, eye, att, wout, no_tgt);
+        }
         lin(att, H, W(pre + ".attn.out_proj_weight"), H, W(pre + ".attn.out_proj_bias"), o, H, R, H, H, 0);
         if (ok) hipLaunchKernelGGL(k_residual, ew, dim3(256), 0, s, x, o, no_tgt, (const uint8_t*)nullptr, R);
         ln(x, pre + ".norm2", s_ln, R);

@@ -26,6 +26,8 @@ struct tb_ctx {
     tb::EncoderW ew;
     bool finalized = false;
     int step_kernel = 2;  // 2: k_step_x (fp16-pair XDL MFMA, default)  3: k_step_x, bf16 operands (tb_config.operand_precision = 1)  0: k_step (fp32 MFMA, the A/B twin); TB_STEP_KERNEL overrides
+    int precision_reason = 0;    // bit 0: a loaded tensor is outside the fp16-pair range; bit 1: an activation overflowed at run time
+    std::string precision_note;  // the sentence that goes with it (tb_precision_note)
     int encode_kernel = 1;  // 1: XDL attention blocks (tb_encodex_kernels.hip, default)  0: fp32-MFMA blocks; TB_ENCODE_KERNEL overrides
     // workspace
     char* d_ws = nullptr;
@@ -54,7 +56,10 @@ struct tb_ctx {
     size_t fw_floats = 0;
     hipGraphExec_t graph_exec = nullptr;
     hipStream_t cap_stream = nullptr;  // the context's private stream: the launch sequence is captured on it (the caller's may be the legacy default stream, which cannot capture), and tb_encode_scene forks its side work to it
-    unsigned long long graph_key = 0, graph_seen = 0;  // key of the captured graph / of the previous call (capture on the second sight)
+    // full argument bytes (RolloutP, tb_rollout_io, hidden_drop, the launch-shaping switches) of the captured graph / of the previous
+    // call (capture on the second sight) / of an argument set whose capture failed (never tried again): compared byte for byte, a hash
+    // alone could replay a graph bound to other buffers
+    std::vector<unsigned char> graph_key, graph_seen, graph_nocapture;
     int graph_hits = 0, graph_captures = 0;
     // tb_encode_scene: the agent / traffic-light token encoders and the destination predictor's GRU scan (128 workgroups: half the
     // chip, and independent of the map) run on a side stream beside the map encoder's chip-filling launches; forked from and joined

@@ -159,7 +159,7 @@ EXPORTS = (
     "tb_create", "tb_destroy", "tb_last_error", "tb_version", "tb_load_weight", "tb_finalize_weights",
     "tb_rollout", "tb_rollout_begin", "tb_rollout_step", "tb_rollout_step_ex", "tb_check_status", "tb_rollout_state", "tb_encode_scene", "tb_set_timing", "tb_get_timing",
     "tb_rule_checks", "tb_post_process", "tb_metric_partials", "tb_struct_sizes", "tb_encode_posterior", "tb_train_partials",
-    "tb_forward", "tb_graph_stats", "tb_latent_sample", "tb_dest_sample",
+    "tb_forward", "tb_graph_stats", "tb_latent_sample", "tb_dest_sample", "tb_precision_state", "tb_precision_note",
 )
 
 _lib: Optional[C.CDLL] = None
@@ -232,6 +232,10 @@ def load() -> C.CDLL:
     lib.tb_forward.restype = C.c_int
     if list(sizes) != mine:
         raise RuntimeError(f"trafficbots_amd: ctypes struct layouts {mine} do not match the library's {list(sizes)} (stale build?)")
+    lib.tb_precision_state.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
+    lib.tb_precision_state.restype = C.c_int
+    lib.tb_precision_note.argtypes = [C.c_void_p]
+    lib.tb_precision_note.restype = C.c_char_p
     lib.tb_set_timing.argtypes = [C.c_void_p, C.c_int]
     lib.tb_set_timing.restype = C.c_int
     lib.tb_get_timing.argtypes = [C.c_void_p, c_f32p]
@@ -259,8 +263,10 @@ def make_config(cfg: Dict) -> TbConfig:
         c.max_yaw_rate[i] = float(dyn[k]["max_yaw_rate"])
     c.action_log_std = float(cfg["action_head"]["log_std"])
     c.latent_log_std = float(cfg["model"]["latent_encoder"]["latent_prior"]["log_std"])
-    prec = str(cfg.get("operand_precision", "fp32"))  # not a key of the reference: "fp32" (default) or "bf16" (BASELINE configs 4/5)
-    if prec not in ("fp32", "bf16"):
-        raise ValueError(f"operand_precision must be 'fp32' or 'bf16', got {prec!r}")
-    c.operand_precision = 1 if prec == "bf16" else 0
+    # not a key of the reference: "fp32" (default: fp16-pair XDL kernels, automatic fallback to the exact kernels when a tensor or an
+    # activation leaves their range), "bf16" (BASELINE configs 4/5), "fp32_exact" (fp32 MFMA kernels from the start)
+    prec = str(cfg.get("operand_precision", "fp32"))
+    if prec not in ("fp32", "bf16", "fp32_exact"):
+        raise ValueError(f"operand_precision must be 'fp32', 'bf16' or 'fp32_exact', got {prec!r}")
+    c.operand_precision = {"fp32": 0, "bf16": 1, "fp32_exact": 2}[prec]
     return c

@@ -396,17 +396,19 @@ class HipEngine:
             if warm_start_steps == 0 and ag.get("warm_ok", False) and tf.get("step_warm_start", 10) >= 0:
                 warm_start_steps = min(int(tf.get("step_warm_start", 10)), self.n_hist - 1)
             # (the default mask of a caller that re-uses its buffers -- `out=` -- is made once: same device address on every pass, so
-            # tb_rollout can replay its captured graph; keyed by the validity tensor it was made from)
-            mkey = (ag["agent_valid"].data_ptr(), ag["agent_valid"]._version, tuple(ag["agent_valid"].shape),
-                    tf.get("step_spawn_agent", 10), tf.get("step_warm_start", 10))
+            # tb_rollout can replay its captured graph; keyed by the validity tensor it was made from -- the object and its version)
+            # tensor IDENTITY, not its address: the entry holds the validity tensor itself (a freed tensor's address can be handed to
+            # the next batch by the caching allocator with the same version counter -- ADVICE r03)
+            src = ag["agent_valid"]
+            mkey = (src._version, tf.get("step_spawn_agent", 10), tf.get("step_warm_start", 10))
             cached = out.get("_default_tf_mask") if out is not None else None
-            if cached is not None and cached[0] == mkey:
+            if cached is not None and cached[2] is src and cached[0] == mkey:
                 mask_teacher_forcing = cached[1]
             else:
                 mask_teacher_forcing = teacher_forcing_mask(
                     ag["agent_valid"].bool(), tf.get("step_spawn_agent", 10), tf.get("step_warm_start", 10)
                 ).to(u8).contiguous()
-            default_mask = (mkey, mask_teacher_forcing)
+            default_mask = (mkey, mask_teacher_forcing, src)
         else:
             default_mask = None
         assert mask_teacher_forcing.shape == (b, nh, a)
@@ -737,10 +739,25 @@ class HipEngine:
         self._check(self.lib.tb_graph_stats(self._ctx, o), "tb_graph_stats")
         return {"captured": int(o[0]), "replayed": int(o[1])}
 
-    def check_status(self) -> None:
-        """`tb_check_status`: synchronises the current stream and raises if an fp16-pair operand left the fp16 range since the
-        last check (fp32-accurate mode only; see include/trafficbots_hip.h)."""
-        self._check(self.lib.tb_check_status(self._ctx, self._stream()), "tb_check_status")
+    def check_status(self, raise_on_range: bool = True) -> bool:
+        """`tb_check_status`: synchronises the current stream.  If an fp16-pair operand left the fp16 range since the last check the
+        results of the calls in between are invalid and the CONTEXT HAS SWITCHED to the exact-fp32 kernels (include/trafficbots_hip.h):
+        raises (default) or, with `raise_on_range=False`, returns True so that the caller can re-issue them.  Hard errors (a helper
+        hand-off time-out) always raise."""
+        rc = self.lib.tb_check_status(self._ctx, self._stream())
+        if rc == 3 and not raise_on_range:
+            return True
+        self._check(rc, "tb_check_status")
+        return False
+
+    def precision_state(self) -> Dict[str, object]:
+        """`tb_precision_state`: the kernels this context runs on ("fp16_pair" / "bf16" / "fp32_exact") and why it left the configured
+        ones (a loaded tensor outside the fp16-pair range / a run-time activation overflow)."""
+        o = (C.c_int32 * 3)()
+        self._check(self.lib.tb_precision_state(self._ctx, o), "tb_precision_state")
+        names = {0: "fp16_pair", 1: "bf16", 2: "fp32_exact"}
+        return {"step": names[int(o[0])], "encode": names[int(o[1])], "weight_out_of_range": bool(o[2] & 1),
+                "activation_overflow": bool(o[2] & 2), "note": (self.lib.tb_precision_note(self._ctx) or b"").decode()}
 
     def rollout_state(self) -> Dict[str, Tensor]:
         """Current simulator state of the stepwise rollout: `Dynamics.agent_state / agent_valid`, `TrafficBots.hidden`."""
