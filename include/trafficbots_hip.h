@@ -117,7 +117,10 @@ typedef struct tb_rollout_io {
     uint8_t* final_valid;          /* [N,A] */
     float* final_hidden;           /* [3,N,A,128] */
     /* optional debug taps (NULL to skip): policy feature of one step */
-    int32_t tap_step;              /* absolute step whose policy feature to capture, or -1 */
+    int32_t tap_step;              /* absolute step whose policy feature to capture, -1 = none, -2 = every step (the buffers then hold
+                                    * the latest: after tb_rollout_begin / each tb_rollout_step, tap_agent_feature is the agent feature
+                                    * the NEXT step's policy reads -- what a stepwise caller needs to ask tb_forward for that step's
+                                    * attention weights, require_vis_dict of waymo_motion.py:167,191-201) */
     float* tap_policy_feature;     /* [N,A,128] */
     float* tap_agent_feature;      /* [N,A,128] */
     /* optional (NULL to skip): the post-override simulator state of every step, i.e. what the reference passes to
@@ -157,6 +160,10 @@ typedef struct tb_rollout_io {
     const float* latent_eps;             /* [N,A,16] standard-normal draws, or NULL */
     const uint8_t* latent_deterministic; /* [N,A] or NULL */
     float* latent_sample_out;            /* [N,A,16] or NULL */
+    /* optional (NULL to skip): the physical action (acceleration m/s^2, yaw rate rad/s) applied at every step -- after the tanh bound
+     * and after an action override, 0 for agents that are invalid before the step: `vis_dict["action"]` of WaymoMotion.forward
+     * (waymo_motion.py:191-194; Dynamics.update, dynamics.py:82-100) */
+    float* actions;                      /* [N,A,S,2] */
 } tb_rollout_io;
 
 /* Replaces: WaymoMotion.rollout (+ per-step WaymoMotion.forward, TrafficBots.forward, ActionHead,

@@ -40,8 +40,15 @@ def _t(x, dtype):
 
 class Oracle:
     def __init__(self, state_dict: Dict[str, np.ndarray], cfg: dict, dtype=torch.float32, hoist: bool = False,
-                 exact_math: bool = False, gemm_order_seed: Optional[int] = None):
-        """`gemm_order_seed` (noise studies only): every Linear sums its products in another order -- the input features and the
+                 exact_math: bool = False, gemm_order_seed: Optional[int] = None, operand_round: Optional[str] = None):
+        """`operand_round="bf16"` (VERDICT r03 task 1 (d)): the arithmetic of the library's `operand_precision = "bf16"` mode -- inside the
+        ROLLOUT every matrix-product operand of the per-step policy (both operands of the transformer / GRU / fusion / action-head
+        Linears that run on the matrix pipe, Q, K, V and the un-normalised softmax weights exp(logit - max)) is rounded to bf16
+        (round-to-nearest-even), products and sums stay in `dtype`; LayerNorm, softmax statistics, gate / activation functions, the
+        recurrent and simulator state, the small attribute MLP, the 128 -> 2 head and the once-per-rollout `mlp_in` of goal / latent
+        stay unrounded, and so do the scene encoders (they keep fp32-accurate operands in either mode).  With dtype=float64 this is the
+        "truth" of that arithmetic (rounded operands, exact accumulation).
+        `gemm_order_seed` (noise studies only): every Linear sums its products in another order -- the input features and the
         weight columns go through the same random permutation (one per input width) -- so that members of an ensemble sample the
         rounding of the matrix products too, not only that of the attention sums (tools/ensemble.py).
         `exact_math=True` (noise studies only, tests/probes): cos / sin / softmax / sigmoid / tanh of the rollout are evaluated in
@@ -57,6 +64,9 @@ class Oracle:
         self._kperm: Dict[int, Tensor] = {}
         self._wperm: Dict[tuple, Tensor] = {}
         self._kgen = None if gemm_order_seed is None else torch.Generator().manual_seed(int(gemm_order_seed))
+        assert operand_round in (None, "bf16")
+        self.operand_round = operand_round
+        self._rnd = False  # True while `rollout` runs in operand_round mode
         dyn = cfg["dynamics"]
         # type order veh=0, ped=1, cyc=2 (`dynamics.py:23-27`: instantiate(veh), (ped), (cyc))
         self.max_acc = torch.tensor([dyn["veh"]["max_acc"], dyn["ped"]["max_acc"], dyn["cyc"]["max_acc"]], dtype=dtype)
@@ -72,7 +82,18 @@ class Oracle:
         """transcendental `fn` of x in the working precision (default: what torch's kernels do, as the reference) or via fp64"""
         return fn(x.double(), *a, **k).to(x.dtype) if self.exact_math else fn(x, *a, **k)
 
-    def _linear(self, x: Tensor, w: Tensor, b: Optional[Tensor]) -> Tensor:
+    @staticmethod
+    def _bf16(x: Tensor) -> Tensor:
+        return x.to(torch.bfloat16).to(x.dtype)
+
+    def _linear(self, x: Tensor, w: Tensor, b: Optional[Tensor], mfma: bool = True) -> Tensor:
+        """`mfma=False`: a Linear the library evaluates outside the matrix pipe (never operand-rounded)."""
+        if self._rnd and mfma:
+            x = self._bf16(x)
+            key = ("bf16", w.data_ptr(), w.shape[0], w.shape[1])
+            if key not in self._wperm:
+                self._wperm[key] = self._bf16(w)
+            w = self._wperm[key]
         if self._kgen is not None:
             k = w.shape[1]
             if k not in self._kperm:
@@ -87,8 +108,12 @@ class Oracle:
     def _ln(self, x: Tensor, prefix: str) -> Tensor:
         return F.layer_norm(x, (x.shape[-1],), self.w[prefix + ".weight"], self.w[prefix + ".bias"], LN_EPS)
 
+    # Linears of the rollout that stay off the matrix pipe in the library (VALU fp32 / once-per-rollout fp32 prologue)
+    _NO_MFMA = ("model.agent_encoder.", "model.add_goal.mlp_in.", "model.add_latent.mlp_in.")
+
     def _lin(self, x: Tensor, prefix: str) -> Tensor:
-        return self._linear(x, self.w[prefix + ".weight"], self.w[prefix + ".bias"])
+        off = prefix.startswith(self._NO_MFMA) or (prefix.startswith("action_head.") and prefix.endswith("fc_layers.2"))
+        return self._linear(x, self.w[prefix + ".weight"], self.w[prefix + ".bias"], mfma=not off)
 
     def pose_pe(self, xy: Tensor, yaw: Tensor, who: str = "agent") -> Tensor:
         """`PosePE.forward` mode pe_xy_yaw (`src/utils/pose_pe.py:57-62`) with
@@ -136,11 +161,21 @@ class Oracle:
         q = q.view(n, ns, N_HEAD, D_HEAD).transpose(1, 2)
         k = k.reshape(n, nt, N_HEAD, D_HEAD).transpose(1, 2)
         v = v.reshape(n, nt, N_HEAD, D_HEAD).transpose(1, 2)
-        attn = torch.matmul(q, k.transpose(-2, -1))
-        attn = attn.masked_fill(inv.unsqueeze(1), float("-inf"))
-        attn = self._m(torch.softmax, attn / math.sqrt(D_HEAD), dim=-1)
+        if self._rnd:
+            # bf16 operands of the two attention products: Q, K; then the UN-NORMALISED weights e = exp(logit - max) and V, the row sum
+            # of the unrounded e dividing afterwards (the library's online softmax normalises once, at the end)
+            lg = torch.matmul(self._bf16(q), self._bf16(k).transpose(-2, -1)) / math.sqrt(D_HEAD)
+            lg = lg.masked_fill(inv.unsqueeze(1), float("-inf"))
+            e = torch.exp(lg - lg.amax(-1, keepdim=True))
+            den = e.sum(-1, keepdim=True)
+            attn = e / den
+            out = (torch.matmul(self._bf16(e), self._bf16(v)) / den).transpose(1, 2).flatten(2, 3)
+        else:
+            attn = torch.matmul(q, k.transpose(-2, -1))
+            attn = attn.masked_fill(inv.unsqueeze(1), float("-inf"))
+            attn = self._m(torch.softmax, attn / math.sqrt(D_HEAD), dim=-1)
+            out = torch.matmul(attn, v).transpose(1, 2).flatten(2, 3)
         weights = attn.mean(1).masked_fill(no_tgt.unsqueeze(-1), 0) if need_weights else None
-        out = torch.matmul(attn, v).transpose(1, 2).flatten(2, 3)
         out = self._linear(out, self.w[prefix + ".attn.out_proj_weight"], self.w[prefix + ".attn.out_proj_bias"])
         out = out.masked_fill(no_tgt.unsqueeze(-1), 0)
         src = src + out
@@ -447,7 +482,15 @@ class Oracle:
             mean = mean + y.masked_fill(~(a_type[:, :, i] & valid).unsqueeze(-1), 0)
         return mean
 
-    def rollout(self, inp: Dict[str, Tensor], f: Dict[str, Tensor], z: Tensor, latent_mean: Tensor, dest: Tensor,
+    def rollout(self, *args, **kwargs) -> Dict[str, Tensor]:
+        """`_rollout` with the operand rounding of `operand_round` switched on for its duration (the scene encoders stay unrounded)."""
+        self._rnd = self.operand_round == "bf16"
+        try:
+            return self._rollout(*args, **kwargs)
+        finally:
+            self._rnd = False
+
+    def _rollout(self, inp: Dict[str, Tensor], f: Dict[str, Tensor], z: Tensor, latent_mean: Tensor, dest: Tensor,
                 goal_valid: Tensor, k: int, step_end: int, tap_steps=(), gt: Optional[Dict[str, Tensor]] = None,
                 tf_cfg_name: str = "teacher_forcing_joint_future_pred", log_std_name: str = "prior",
                 action_eps: Optional[Tensor] = None, action_override=None, hidden_drop=None) -> Dict[str, Tensor]:

@@ -336,6 +336,52 @@ def test_device_samplers_against_torch_distributions():
     assert freq[2] == 0 and (freq - torch.softmax(row[0, 0], -1).double()).abs().max() <= 0.015
 
 
+def test_require_vis_dict_against_reference_golden():
+    """`joint_future_pred(..., require_vis_dict=True)` -> `rollout` -> `forward(require_vis_dict=True)` (`waymo_motion.py:167,191-201,305`):
+    per step the applied action, the navigator's goal validity and the head-mean attention weights of the three blocks, served by the
+    un-fused `tb_forward` next to the fused step launches.  Golden `vis_dict` = the reference's own buffer (`RolloutBuffer.vis_dicts`
+    after `finish` + `flatten_repeat`); the trajectories of the per-step-driven rollout equal the fused rollout's bit for bit."""
+    from trafficbots_amd.waymo_motion import WaymoMotion
+
+    g, meta = load_golden("vis_dict")
+    cfg, sd, batch, eps = golden_inputs(meta)
+    wm = WaymoMotion(time_step_end=meta["time_step_end"], n_joint_future=meta["k"])
+    wm.load_state_dict(sd)
+    gs = torch.from_numpy(np.transpose(g["goal_sample"], (0, 2, 1)).copy())
+    eps_t = torch.from_numpy(eps).cuda()
+
+    def run(vis):
+        scene = wm.pre_processing(batch)
+        scene.pop("gt", None)
+        feats = wm.model.encode_input_features(scene)
+        buf, _, _ = wm.joint_future_pred(scene, feats, wm.model.latent_encoder(), wm.model.goal_manager.pred_goal(),
+                                         scene["agent_valid"].bool().any(1), require_vis_dict=vis, latent_eps=eps_t, goal_sample=gs)
+        torch.cuda.synchronize()
+        return buf
+
+    buf = run(True)
+    fused = run(False)
+    assert torch.equal(buf.preds, fused.preds) and torch.equal(buf.valid, fused.valid) and not fused.vis_dicts
+    assert (buf.valid.cpu().numpy() == g["valid"]).all()
+    assert np.abs(buf.preds.cpu().numpy() - g["preds"]).max() <= 2e-5
+    v = g["valid"]  # [B,A,K,S]: validity BEFORE each step = the rows the reference computes weights for
+    assert set(buf.vis_dicts) == {"action", "goal_valid", "attn_weights_to_pl", "attn_weights_to_tl", "attn_weights_to_agent"}
+    for key, tol in (("action", 2e-5), ("attn_weights_to_pl", 5e-6), ("attn_weights_to_tl", 5e-6), ("attn_weights_to_agent", 5e-6)):
+        got, ref = buf.vis_dicts[key].numpy(), g["vis/" + key]
+        assert got.shape == ref.shape, (key, got.shape, ref.shape)
+        assert (np.abs(got - ref) * v[..., None]).max() <= tol, (key, float((np.abs(got - ref) * v[..., None]).max()))
+    assert (buf.vis_dicts["goal_valid"].numpy() == g["vis/goal_valid"]).all()
+    w = buf.vis_dicts["attn_weights_to_pl"].numpy()
+    assert (np.abs(w.sum(-1) - np.round(w.sum(-1))) * v).max() <= 1e-5  # rows sum to 1 (or 0: no admissible key)
+    # the reference's call form: forward(require_vis_dict=True) on a simulator that was not opened for it raises
+    scene = wm.pre_processing(batch)
+    scene.pop("gt", None)
+    wm.model.encode_input_features(scene)
+    with pytest.raises(NotImplementedError):
+        wm.rollout(dict(scene), None, gs.reshape(-1, gs.shape[-1]).cuda(), scene["agent_valid"].bool().any(1).repeat_interleave(meta["k"], 0),
+                   scene["agent_valid"].bool(), require_vis_dict=True, stepwise=True, k_futures=meta["k"])
+
+
 def test_what_if_rollout_forces_the_sdc_trajectory():
     """`rollout(..., gt_sdc=...)` (`waymo_motion.py:279-284`): agent 0 is teacher-forced to the given trajectory at EVERY step, the
     other agents run closed loop around it."""

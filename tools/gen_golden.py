@@ -440,16 +440,65 @@ def gen_forward_weights() -> None:
           + ", ".join(f"{k}: max {float(np.abs(v).max()):.3f}" for k, v in save.items() if k.endswith("attn_agent") or k.endswith("attn_tl")))
 
 
+VIS_CASE = dict(base_seed=9800, n_scene=2, k=2, weight_seed=8, time_step_end=16,
+                scene=dict(n_agent=12, n_pl=40, n_tl=40, p_invalid_agent=0.25, p_late_spawn=0.3, p_invalid_pl=0.2, pos_range=120.0))
+
+
+def gen_vis_dict() -> None:
+    """tests/golden/vis_dict.npz: the reference's `joint_future_pred(..., require_vis_dict=True)` (`waymo_motion.py:167,191-201,305`):
+    per step the applied action, the navigator's goal validity and the head-mean attention weights of the three blocks, as
+    `RolloutBuffer.finish` + `flatten_repeat` leave them ([B, A, K, S, ...], `buffer.py:89-90,118-123`)."""
+    case = VIS_CASE
+    cfg = load_model_config(overrides={"time_step_end": case["time_step_end"], "n_joint_future": case["k"]})
+    sc = case["scene"]
+    torch.set_default_dtype(torch.float32)
+    model = ref_shim.build_reference(cfg, n_agent=sc["n_agent"], n_pl=sc["n_pl"], n_tl=sc.get("n_tl", 40))
+    sd = synth.make_state_dict(case["weight_seed"])
+    model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()}, strict=True)
+    batch = {k: torch.from_numpy(v.copy()) for k, v in synth.make_batch(case["base_seed"], case["n_scene"], **sc).items()}
+    eps = torch.from_numpy(synth.make_latent_noise(case["base_seed"] + 99, case["n_scene"] * case["k"], sc["n_agent"]))
+    import torch.distributions.normal as tdn
+
+    orig = tdn._standard_normal
+    tdn._standard_normal = lambda shape, dtype, device: eps.to(dtype)
+    try:
+        torch.manual_seed(case["base_seed"])
+        with torch.no_grad():
+            batch = model.pre_processing(batch)
+            input_dict = {k.split("input/")[-1]: v for k, v in batch.items() if "input/" in k}
+            prior_dict = {k.split("latent_prior/")[-1]: v for k, v in batch.items() if "latent_prior/" in k}
+            feats = model.model.encode_input_features(**input_dict)
+            goal_pred = model.model.goal_manager.pred_goal(agent_type=batch["ref/agent_type"], map_type=batch["ref/map_type"],
+                                                           agent_state=batch["ref/agent_state"], **feats)
+            latent_prior = model.model.latent_encoder(**model.model.encode_input_features(**prior_dict))
+            for k in ["valid", "vel", "acc", "yaw_rate", "pos", "yaw_bbox", "spd", "size"]:
+                batch[f"agent/{k}"] = batch[f"history/agent/{k}"]
+            buf, goal_sample, _ = model.joint_future_pred(batch=batch, input_feature_dict=feats, latent=latent_prior, goal=goal_pred,
+                                                          goal_valid=input_dict["agent_valid"].any(1), require_vis_dict=True)
+    finally:
+        tdn._standard_normal = orig
+    save = {"vis/" + k: v.numpy() for k, v in buf.vis_dicts.items()}
+    save.update(preds=buf.preds.numpy(), valid=buf.valid.numpy(), goal_sample=goal_sample.numpy(),
+                meta_json=np.frombuffer(json.dumps(case).encode(), dtype=np.uint8))
+    path = os.path.join(GOLDEN_DIR, "vis_dict.npz")
+    np.savez_compressed(path, **save)
+    print(f"[vis_dict] wrote {path} ({os.path.getsize(path) / 1024:.0f} KiB): " + ", ".join(f"{k} {tuple(v.shape)}" for k, v in save.items() if k.startswith("vis/")))
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", nargs="*", default=None)
     ap.add_argument("--no-ensemble", action="store_true")
     ap.add_argument("--forward-weights", action="store_true", help="only tests/golden/forward_weights.npz")
+    ap.add_argument("--vis-dict", action="store_true", help="only tests/golden/vis_dict.npz")
     args = ap.parse_args()
     os.makedirs(GOLDEN_DIR, exist_ok=True)
     torch.set_num_threads(os.cpu_count())
     if args.forward_weights:
         gen_forward_weights()
+        return
+    if args.vis_dict:
+        gen_vis_dict()
         return
 
     # reference state_dict key/shape list (pins trafficbots_amd.synth.state_dict_spec)
@@ -498,6 +547,7 @@ def main() -> None:
               f"outside {r32['outside_map'][..., -1].mean():.3f}")
     if not args.only:
         gen_forward_weights()
+        gen_vis_dict()
 
 
 if __name__ == "__main__":

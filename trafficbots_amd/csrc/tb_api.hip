@@ -857,6 +857,7 @@ static int rollout_setup(tb_ctx* ctx, const tb_rollout_io* io, tb::RolloutP& p) 
     p.o_check_state = io->check_state;
     p.o_check_valid = io->check_valid;
     p.tap_step = io->tap_step;
+    p.o_action = io->actions;
     p.tap_policy_feature = io->tap_policy_feature;
     p.tap_agent_feature = io->tap_agent_feature;
     const void* required[] = {p.map_feature, io->map_feature_valid, p.tl_feature, io->tl_feature_valid, p.hist_valid, p.hist_state,

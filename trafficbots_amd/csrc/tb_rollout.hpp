@@ -159,7 +159,8 @@ struct RolloutP {
     float* o_latent_logp;         // [N,A]
     float* o_check_state;         // [N,A,S,4] post-override state of every step (optional)
     uint8_t* o_check_valid;       // [N,A,S]
-    int tap_step;
+    int tap_step;                 // absolute step to tap, -1 = none, -2 = every step (the buffers hold the latest one)
+    float* o_action;              // [N,A,S,2] or NULL: the physical action applied at every step
     float* tap_policy_feature;    // [N,A,128]
     float* tap_agent_feature;     // [N,A,128]
 };

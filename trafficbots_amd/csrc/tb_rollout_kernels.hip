@@ -378,7 +378,7 @@ __global__ __launch_bounds__(NTHREADS) void k_step(RolloutP p, int t, int do_c, 
         TB_STAMP(4);
         fuse_latent_goal(W, pw.lat_out_w1, pw.lat_out_w2, pw.lat_out_b2, X, CAT, S2, LP, rowvalid, rowvalid, tid, u, h0);
         TB_STAMP(5);
-        if (t == p.tap_step && p.tap_policy_feature)
+        if ((t == p.tap_step || p.tap_step == -2) && p.tap_policy_feature)
             store_tile(p.tap_policy_feature + ((size_t)n * p.n_agent + row0) * H, X, LDT, n_real, tid);
 
         if (tid < 32) ubuf[tid] = 0.f;
@@ -427,7 +427,7 @@ __global__ __launch_bounds__(NTHREADS) void k_step(RolloutP p, int t, int do_c, 
     // =================================== A(t+1) ===================================
     const int t1 = t + 1;
     step_encode_inputs<NTHREADS>(p, t, n, b, row0, n_real, tid, sm, X);
-    if (t1 == p.tap_step && p.tap_agent_feature)
+    if ((t1 == p.tap_step || p.tap_step == -2) && p.tap_agent_feature)
         store_tile(p.tap_agent_feature + ((size_t)n * p.n_agent + row0) * H, X, LDT, n_real, tid);
 
     TB_STAMP(8);

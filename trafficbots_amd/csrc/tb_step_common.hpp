@@ -261,6 +261,10 @@ __device__ __forceinline__ void step_epilogue(const RolloutP& p, int t, int n, i
         p.o_dest_reached[oi] = dreached;
         p.o_dest_reached_this[oi] = dr_this;
         p.o_action_logp[oi] = alp;
+        if (p.o_action) {  // vis_dict["action"] (waymo_motion.py:191-194): the physical action applied this step, 0 for invalid agents
+            p.o_action[oi * 2 + 0] = acc_;
+            p.o_action[oi * 2 + 1] = yr_;
+        }
     }
 }
 
@@ -550,6 +554,10 @@ __device__ __forceinline__ void step_epilogue16(const RolloutP& p, int t, int n,
         p.o_dest_reached[oi] = dreached;
         p.o_dest_reached_this[oi] = dr_this;
         p.o_action_logp[oi] = alp;
+        if (p.o_action) {  // vis_dict["action"] (waymo_motion.py:191-194): the physical action applied this step, 0 for invalid agents
+            p.o_action[oi * 2 + 0] = acc_;
+            p.o_action[oi * 2 + 1] = yr_;
+        }
     }
 }
 

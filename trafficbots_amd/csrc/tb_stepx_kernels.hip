@@ -386,7 +386,7 @@ __global__ __launch_bounds__(NTHREADS, LEAN ? (W3 ? 3 : 2) : 1) void k_step_x(Ro
         TB_STAMP(4);
         fuse_latent_goal_x<LEAN>(W, px.lat_out_w2, pw.lat_out_b2, X, PC, PB, LEAN ? p.lat_pre + base_row * H : LP, rowvalid, rowvalid, tid, u, h0, amax);
         TB_STAMP(5);
-        if (t == p.tap_step && p.tap_policy_feature)
+        if ((t == p.tap_step || p.tap_step == -2) && p.tap_policy_feature)
             store_tile(p.tap_policy_feature + ((size_t)n * p.n_agent + row0) * H, X, LDT, n_real, tid);
 
         // ---- action head (action_head.py:69-75): first Linear of every type present, hidden tiles -> Hs / H1 / H2
@@ -469,7 +469,7 @@ __global__ __launch_bounds__(NTHREADS, LEAN ? (W3 ? 3 : 2) : 1) void k_step_x(Ro
     const int t1 = t + 1;
     TB_STAMP(30);
     step_encode_inputs_lds(p, b, row0, n_real, tid, sm, ENCW, X, !PRE);
-    if (t1 == p.tap_step && p.tap_agent_feature)
+    if ((t1 == p.tap_step || p.tap_step == -2) && p.tap_agent_feature)
         for (int k = 0; k < (PRE ? p.k_rep : 1); ++k)  // (the batched launch runs once per scene: same feature for its K futures)
             store_tile(p.tap_agent_feature + ((size_t)(n + k) * p.n_agent + row0) * H, X, LDT, n_real, tid);
     TB_STAMP(8);

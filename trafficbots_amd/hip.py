@@ -47,7 +47,7 @@ class TbRolloutIO(C.Structure):
         ("check_state", c_f32p), ("check_valid", c_u8p),
         ("n_tl_step", C.c_int32), ("latent_posterior", C.c_int32), ("warm_start_steps", C.c_int32),
         ("action_eps", c_f32p), ("hidden_drop", C.c_void_p),
-        ("latent_eps", c_f32p), ("latent_deterministic", c_u8p), ("latent_sample_out", c_f32p),
+        ("latent_eps", c_f32p), ("latent_deterministic", c_u8p), ("latent_sample_out", c_f32p), ("actions", c_f32p),
     ]
 
 

@@ -367,6 +367,7 @@ class HipEngine:
         hidden_drop=None,
         latent_eps: Optional[Tensor] = None,
         latent_deterministic: Optional[Tensor] = None,
+        record_actions: bool = False,
     ) -> Dict[str, Tensor]:
         """`latent_sample=None`: the personalities are drawn by the rollout prologue itself (`MyDist.sample`, `distributions.py:18-38`;
         `tb_rollout_io.latent_sample_out`): z = mean where `latent_deterministic` [N, A] is set (or for every agent when `latent_eps`
@@ -424,7 +425,9 @@ class HipEngine:
             for name in ("valid", "override_masks", "outside_map", "outside_map_this_step", "dest_reached",
                          "dest_reached_this_step"):
                 out[name] = torch.empty(n, a, n_step, device=dev, dtype=u8)
-            if tap_step >= 0:
+            if record_actions:  # vis_dict["action"]: the physical action applied at every step
+                out["actions"] = torch.zeros(n, a, n_step, 2, device=dev, dtype=f32)
+            if tap_step >= 0 or tap_step == -2:  # (-2: every step, the buffers hold the latest)
                 out["tap_policy_feature"] = torch.zeros(n, a, 128, device=dev, dtype=f32)
                 out["tap_agent_feature"] = torch.zeros(n, a, 128, device=dev, dtype=f32)
             if record_check_states:  # what TrafficRuleChecker.check is handed every step (input of `rule_checks`)
@@ -486,6 +489,7 @@ class HipEngine:
         io.final_valid = hip.ptr(out.get("final_valid"), hip.c_u8p)
         io.final_hidden = hip.ptr(out.get("final_hidden"), hip.c_f32p)
         io.tap_step = tap_step
+        io.actions = hip.ptr(out.get("actions"), hip.c_f32p)
         io.tap_policy_feature = hip.ptr(out.get("tap_policy_feature"), hip.c_f32p)
         io.tap_agent_feature = hip.ptr(out.get("tap_agent_feature"), hip.c_f32p)
         io.check_state = hip.ptr(out.get("check_state"), hip.c_f32p)

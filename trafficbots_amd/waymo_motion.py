@@ -125,6 +125,7 @@ class RolloutBuffer:
         self.action_log_probs = fr(self.action_log_probs)
         if torch.is_tensor(self.diffbar_rewards):
             self.diffbar_rewards, self.diffbar_rewards_valid = fr(self.diffbar_rewards), fr(self.diffbar_rewards_valid)
+        self.vis_dicts = {k: fr(v) for k, v in self.vis_dicts.items()}  # (`buffer.py:118-123`)
 
 
 class _GoalManager:
@@ -359,12 +360,14 @@ class WaymoMotion:
         (`model.init`, `dynamics.init`, goal features: `waymo_motion.py:246-266`); drive it with :meth:`forward`.  `features` is the pre-processed scene merged
         with the encoder outputs (un-repeated: K futures share scene tensors, instance n uses scene n // K);
         `latent` / `goal` / `goal_valid` are per instance [N, ...] as in the reference."""
-        if require_vis_dict:
-            raise NotImplementedError("visualisation dicts (attention weights) are outside the built path")
+        if require_vis_dict and (stepwise or not deterministic_action or hidden_drop is not None):
+            raise NotImplementedError("require_vis_dict drives the loop per step itself: not with stepwise=True / sampled actions / hidden_drop")
         if latent is None:  # the reference's `self.model.init(latent, deterministic)` + rollout without re-passing them
             latent, deterministic_latent = self.model.latent, self.model.deterministic
             latent_eps = latent_eps if latent_eps is not None else getattr(self.model, "_latent_eps", None)
-        per_step = gt_sdc is not None  # what-if: the SDC's trajectory is forced at every step -> the loop is driven per step
+        # what-if (the SDC's trajectory is forced at every step) and require_vis_dict (every step's attention weights come from the
+        # un-fused tb_forward, `:167,191-201`) drive the loop per step
+        per_step = gt_sdc is not None or require_vis_dict
         if deterministic_action:
             action_eps = None
         else:
@@ -393,13 +396,23 @@ class WaymoMotion:
         want_checks = any(bool(v) for k, v in flags.items() if k.startswith("enable_check_")) or agent_goal is not None
         out = self.engine.rollout(
             features, features, None, mean_scene, goal, goal_valid, k_futures, step_end, latent_eps=z_eps, latent_deterministic=z_det,
-            mask_teacher_forcing=mask_teacher_forcing.to(torch.uint8).contiguous(), tap_step=tap_step, stepwise=stepwise or per_step,
+            mask_teacher_forcing=mask_teacher_forcing.to(torch.uint8).contiguous(), tap_step=-2 if require_vis_dict else tap_step,
+            stepwise=stepwise or per_step,
             record_check_states=want_checks, gt=gt, latent_posterior=latent_posterior, warm_start_steps=warm_start_steps,
-            action_eps=action_eps, hidden_drop=hidden_drop,
+            action_eps=action_eps, hidden_drop=hidden_drop, record_actions=require_vis_dict,
         )
+        self._vis = None
+        if require_vis_dict:  # what `forward(require_vis_dict=True)` needs from step to step
+            rep = (lambda x: x.repeat_interleave(k_futures, 0)) if k_futures > 1 else (lambda x: x)
+            map_f = rep(features["map_feature"])
+            self._vis = {"k": k_futures, "z": out["latent_sample"], "goal_valid": goal_valid.to(self.device).bool().clone(),
+                         "map_feature": map_f, "map_valid": rep(features["map_feature_valid"].bool()),
+                         "goal_feature": torch.gather(map_f, 1, goal.to(self.device).long().clamp(0, map_f.shape[1] - 1).unsqueeze(-1).expand(-1, -1, 128)),
+                         "tl_feature": features["tl_feature"], "tl_valid": features["tl_valid"].bool(), "rep": rep, "collected": []}
         if per_step:
             self._step_t = step_start
-            self._rollout_with_per_step_overrides(features, mask_teacher_forcing, k_futures, step_start, step_end, gt, gt_sdc)
+            self._rollout_with_per_step_overrides(features, mask_teacher_forcing, k_futures, step_start, step_end, gt, gt_sdc,
+                                                  require_vis_dict=require_vis_dict)
             st = self.engine.rollout_state()
             out["final_state"], out["final_valid"], out["final_hidden"] = st["agent_state"], st["agent_valid"], st["hidden"]
         if (gt is not None and k_futures == 1 and not stepwise and self.hparams["training_metrics"]["w_diffbar_reward"] > 0
@@ -430,6 +443,9 @@ class WaymoMotion:
         buf.final = {k: out[k] for k in ("final_state", "final_valid", "final_hidden")}
         buf.taps = {k: out[k] for k in ("tap_policy_feature", "tap_agent_feature") if k in out}
         buf.latent_sample = z
+        vis = getattr(self, "_vis", None)
+        if vis is not None and vis["collected"]:  # `RolloutBuffer.finish`: torch.stack(..., dim=2) (`buffer.py:89-90`)
+            buf.vis_dicts = {k_: torch.stack([d[k_] for d in vis["collected"]], dim=2) for k_ in vis["collected"][0]}
         if "diffbar_rewards" in out:
             buf.diffbar_rewards, buf.diffbar_rewards_valid = out["diffbar_rewards"], out["diffbar_rewards_valid"].bool()
         return buf
@@ -508,9 +524,13 @@ class WaymoMotion:
         * `action_override` [N,A,2] (acceleration m/s^2, yaw rate rad/s) + `mask_action_override` [N,A] replace the policy's physical
           action of this step for the agents that are valid before it (`Dynamics.update`, `dynamics.py:96-100`); `action_log_prob`
           stays that of the policy's own action, as in the reference.
-        * Stochastic actions in stepwise mode and `require_vis_dict` (attention weights) are outside the built path."""
-        if require_vis_dict:
-            raise NotImplementedError("vis dicts (attention weights) are outside the fused step; see TrafficBots.forward(need_weights=True)")
+        * `require_vis_dict=True` (`:167,191-201`; the rollout must have been opened by `rollout(..., require_vis_dict=True)` or the loop
+          driven through it): the fused step never materialises attention weights, so the step's `TrafficBots.forward` is ALSO run
+          un-fused (`tb_forward`, need_weights) on the simulator's current inputs -- validity and GRU state of `tb_rollout_state`, the
+          agent feature the fused launch of the previous step left in the every-step tap, the traffic lights of `step_tl`, the
+          navigator's goal validity -- and `vis_dict` = {"action", "goal_valid", "attn_weights_to_pl / _tl / _agent"} on the host, as
+          the reference returns it.  Visualisation path: ~70 small launches + 5 device-to-host copies per step.
+        * Stochastic actions in stepwise mode are outside the built path."""
         if (action_override is None) != (mask_action_override is None):
             raise ValueError("forward: action_override and mask_action_override go together")
         if not deterministic_action:
@@ -545,9 +565,30 @@ class WaymoMotion:
             raise ValueError("forward: gt_valid goes with state_override / mask_state_override (the bound history supplies its own)")
         if action_override is not None:
             override = dict(override or {}, action=action_override, action_mask=mask_action_override)
+        vis = getattr(self, "_vis", None)
+        fw = None
+        if require_vis_dict:
+            if vis is None or "tap_agent_feature" not in o:
+                raise RuntimeError("forward(require_vis_dict=True): open the simulator with rollout(..., require_vis_dict=True)")
+            st0 = eng.rollout_state()
+            step_tl = min(self._step_t - 1, vis["tl_valid"].shape[1] - 1)  # `waymo_motion.py:291`
+            fw = eng.forward_trunk(st0["agent_valid"].bool(), o["tap_agent_feature"], vis["map_valid"], vis["map_feature"],
+                                   vis["rep"](vis["tl_valid"][:, step_tl]), vis["rep"](vis["tl_feature"][:, step_tl]), vis["goal_valid"],
+                                   vis["goal_feature"], vis["z"], st0["hidden"].flatten(1, 2), need_weights=True)
         eng.rollout_step(override)
         s_idx = self._step_t - self.hparams["time_step_sim_start"]
         self._step_t += 1
+        vis_dict = {}
+        if require_vis_dict:
+            vis_dict = {"action": o["actions"][:, :, s_idx].cpu(), "goal_valid": vis["goal_valid"].cpu(),
+                        "attn_weights_to_pl": fw["attn_pl"].cpu(), "attn_weights_to_tl": fw["attn_tl"].cpu(),
+                        "attn_weights_to_agent": fw["attn_agent"].cpu()}
+            # the navigator (`GoalManager.disable_goal_reached`, goal_manager.py:155-162) for the next step: goals of agents that are
+            # gone or have reached their destination are switched off (flag logic on recorded outputs, no arithmetic)
+            st1 = eng.rollout_state()
+            vis["goal_valid"] = vis["goal_valid"] & st1["agent_valid"].bool() & ~o["dest_reached"][:, :, s_idx].bool()
+            if _skip_state:
+                return None, None, {}, vis_dict
         if _skip_state:  # (the per-step loops of this mirror read the state once at the end: no three D2D copies per step)
             return None, None, {}, {}
         st = eng.rollout_state()
@@ -558,11 +599,11 @@ class WaymoMotion:
                 "pred_valid": o["valid"][:, :, s_idx].bool(), "pred_state": o["preds"][:, :, s_idx],
             }
         self.model.hidden = st["hidden"].flatten(1, 2)
-        return st["agent_state"], st["agent_valid"].bool(), train_dict, {}
+        return st["agent_state"], st["agent_valid"].bool(), train_dict, vis_dict
 
     def _rollout_with_per_step_overrides(self, features: Dict[str, Tensor], mask_teacher_forcing: Tensor, k_futures: int,
                                          step_start: int, step_end: int, gt: Optional[Dict[str, Tensor]],
-                                         gt_sdc: Optional[Dict[str, Tensor]]) -> None:
+                                         gt_sdc: Optional[Dict[str, Tensor]], require_vis_dict: bool = False) -> None:
         """The reference's loop (`waymo_motion.py:269-306`) over `forward(state_override=..., mask_state_override=...)` for a
         simulator already opened with `stepwise=True`: per step the override of step t of the teacher-forcing source, plus -- the
         what-if motion prediction of `gt_sdc` ({"agent_state" [N,S,4], "vel" [N,S,2], "acc" / "yaw_rate" [N,S,1]}) -- agent 0 forced
@@ -582,7 +623,10 @@ class WaymoMotion:
                 for k in gt_sdc.keys():  # (the reference iterates gt_sdc.keys(), waymo_motion.py:283-284: a dict with fewer keys is fine)
                     so[k][:, 0] = gt_sdc[k][:, t].to(self.device).to(so[k].dtype).reshape(so[k][:, 0].shape)
             gtv = rep(src["agent_valid"][:, t]) if in_src else None
-            self.forward(state_override=so, mask_state_override=m, gt_valid=gtv, require_train_dict=False, _skip_state=True)
+            vd = self.forward(state_override=so, mask_state_override=m, gt_valid=gtv, require_train_dict=False, _skip_state=True,
+                              require_vis_dict=require_vis_dict)[3]
+            if require_vis_dict:
+                self._vis["collected"].append(vd)
 
     def joint_future_pred(
         self,
@@ -633,7 +677,7 @@ class WaymoMotion:
             action_eps=action_eps,
             step_start=self.hparams["time_step_sim_start"], step_end=self.hparams["time_step_end"],
             k_futures=k, latent_eps=latent_eps, tap_step=tap_step, gt=gt,
-            warm_start_steps=self._warm_start_steps(tf, gt if gt is not None else batch),
+            warm_start_steps=self._warm_start_steps(tf, gt if gt is not None else batch), require_vis_dict=require_vis_dict,
         )
         buf.flatten_repeat(k)
         goal_log_probs = goal_log_probs.view(b, k, a).transpose(1, 2)
