@@ -205,8 +205,15 @@ def cpu_baseline(n_threads: int = 0, budget_s: float = 15.0, timeout_s: float = 
 
 
 # ------------------------------------------------------------------------------------------------------------------
+def _dist_on(world) -> bool:
+    """The process group is used when there is more than one rank -- or, under a launcher (WORLD_SIZE / RANK / MASTER_* set), when
+    TB_BENCH_FORCE_DIST=1 asks for it at world size 1: RCCL init, the barriers and the ONE packed all-reduce then run on the real
+    backend of a 1-GPU box (tests/test_gpu_configs.py::test_bench_one_rank_through_rccl)."""
+    return world > 1 or (os.environ.get("TB_BENCH_FORCE_DIST") == "1" and "RANK" in os.environ and "MASTER_ADDR" in os.environ)
+
+
 def _barrier(world):
-    if world > 1:
+    if _dist_on(world):
         import torch.distributed as dist
 
         dist.barrier()
@@ -453,7 +460,7 @@ def run_rank(args, rank: int, local_rank: int, world: int) -> None:
     from trafficbots_amd import shard as _shard
 
     numa = _shard.bind_to_gpu_numa_node(local_rank)  # the launching thread stays on the GPU's NUMA node (best effort)
-    if world > 1:
+    if _dist_on(world):
         import torch.distributed as dist
 
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -690,7 +697,7 @@ def run_rank(args, rank: int, local_rank: int, world: int) -> None:
             if not args.lean:
                 line["cpu_baseline_1thread"] = cpu_baseline(1, 8.0, 120.0)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if _dist_on(world):
         import torch.distributed as dist
 
         dist.barrier()

@@ -355,6 +355,30 @@ def test_bench_plain_command_spawns_its_ranks():
     REPORT["bench_gloo_dry_run"] = {"n1_value": one["value"], "n2_value_two_ranks_one_gpu": two["value"]}
 
 
+def test_bench_one_rank_through_rccl():
+    """The driver's multi-GPU command line with ONE rank on the real backend: `python -m torch.distributed.run --nproc-per-node 1
+    bench.py --gpus 1` with TB_BENCH_FORCE_DIST=1 initialises the RCCL process group (backend "nccl", device_id), runs the barriers
+    around the timed passes and the ONE packed float64 SUM all-reduce of trafficbots_amd/shard.py on the device -- the same code the
+    N = 2, 4, 8 runs take (scene shards, per-rank tails), minus the peers a 1-GPU box does not have.  The line must equal the plain
+    single-process run in everything but time."""
+    env = dict(os.environ, TB_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "TB_BENCH_BACKEND"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                        "--master-port", "29571", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
+                        "--no-cpu-baseline", "--lean"], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    ln = json.loads(lines[0])
+    plain = _run_bench(["--gpus", "1", "--lean"])
+    assert ln["n_gpus"] == 1 and ln["ranks"]["ranks_seen"] == 1
+    assert ln["ranks"]["collectives_for_the_metric_reduction"] == 1 and ln["ranks"]["collectives_in_timed_passes"] == 0
+    assert plain["ranks"]["collectives_for_the_metric_reduction"] == 0  # (no process group: nothing to reduce)
+    assert ln["checks"] == plain["checks"] and ln["reference_metric_states"] == plain["reference_metric_states"]
+    REPORT["bench_one_rank_rccl"] = {"value": ln["value"], "plain_value": plain["value"], "ranks": ln["ranks"]}
+
+
 def test_rollout_graph_replay_is_bitwise_identical(monkeypatch):
     """tb_rollout captures ONE hipGraph per rollout the second time it sees the same argument set (same buffers, sizes, switches) and
     replays it afterwards (the launching thread spends microseconds per rollout instead of ~70 us per launch -- eight ranks share

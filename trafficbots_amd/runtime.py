@@ -280,8 +280,12 @@ class HipEngine:
         Returns (diffbar_rewards [B,A,S], diffbar_rewards_valid [B,A,S] uint8, states [6])."""
         rw, tm = self.cfg["differentiable_reward"], self.cfg["training_metrics"]
         if tm["w_relevant_agent"] > 0:
-            raise NotImplementedError("training_metrics.w_relevant_agent > 0 is not built (the reference's own weighting there does not "
-                                      "broadcast for n_agent != n_step, training.py:124)")
+            raise NotImplementedError(
+                "training_metrics.w_relevant_agent > 0 is rejected: the reference builds w_mask_rel [n_batch, n_agent] "
+                "(src/models/metrics/training.py:95-97) and multiplies the reward tensor [n_batch, n_agent, n_step] by "
+                "w_mask_rel.unsqueeze(1) = [n_batch, 1, n_agent] (training.py:124), which only broadcasts when n_step == n_agent and then "
+                "weights step s by agent s's relevance -- there is no defined behaviour to reproduce (the default config has 0, "
+                "configs/model/traffic_bots.yaml:216)")
         dev, u8, f32 = self.device, torch.uint8, torch.float32
         b, a, n_step = buf["valid"].shape
         io = hip.TbTrainIO()

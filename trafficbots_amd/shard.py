@@ -88,7 +88,10 @@ def all_reduce_partials(partial: Tensor, elapsed_s: float, fields=PARTIAL_FIELDS
 
     global N_COLLECTIVES
     extra = list(per_rank.items()) if per_rank else []
-    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+    import os
+
+    forced = os.environ.get("TB_BENCH_FORCE_DIST") == "1"  # (world size 1 through the real backend: a 1-GPU box's RCCL smoke test)
+    if not (dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or forced)):
         res = {k: float(partial[i]) for i, k in enumerate(fields)}, float(elapsed_s)
         return res + ({"elapsed_s": [float(elapsed_s)], **{k: [float(v)] for k, v in extra}},) if per_rank is not None else res
     world, rank = dist.get_world_size(), dist.get_rank()
