@@ -4,7 +4,8 @@
 //   MODE 0  the way they do today: every compute wave requests the NEXT unit's sixteen 1-KiB fragments into registers while it
 //           multiplies the current one (register prefetch, one unit ahead);
 //   MODE 1  from an LDS ring filled by a FIFTH wave with LDS-DMA (global_load_lds_dwordx4): five 16-KB slots (one slot = one compute
-//           wave's quarter of a unit: 80 KB, what is free next to the 79 KB carve of the fp16-pair kernel), no register buffers.
+//           wave's quarter of a unit: 80 KB, what is free next to the 79 KB carve of the fp16-pair kernel; an eight-slot ring = two
+//           units of run-ahead is measured next to it: what the bf16 build's half-size units would get), no register buffers.
 // The point of MODE 1 is the synchronisation, because the step kernel has ~200 workgroup barriers per step on data-dependent paths and
 // s_barrier is workgroup-wide: the loader wave does not know the consumers' control flow -- it LOOPS on s_barrier (issue what fits,
 // arrive, repeat), so every consumer barrier is matched whichever one it is; a slot is released by the consumer's progress counter
@@ -27,7 +28,7 @@ typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 typedef float f4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u4 __attribute__((ext_vector_type(4)));
 
-constexpr int UNIT_BYTES = 65536, QUARTER = 16384, NFRAG = 16, NSLOT = 5;
+constexpr int UNIT_BYTES = 65536, QUARTER = 16384, NFRAG = 16;
 constexpr int LDP = 136, PLANE = 16 * LDP;  // fp16 per plane row / per plane
 constexpr unsigned POISON = 0xFFFFFFFFu;
 
@@ -72,7 +73,7 @@ __device__ __forceinline__ void store_planes(_Float16* P, int tile, int lane, f4
     *reinterpret_cast<h4*>(p + PLANE) = l;
 }
 
-template <int MODE, int MAXQ>
+template <int MODE, int NSLOT>
 __global__ __launch_bounds__(MODE == 0 ? 256 : 320) void k_chain(const char* __restrict__ W, int n_units, int gap_iters, float* __restrict__ out,
                                                                     long long* __restrict__ cyc) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -100,8 +101,8 @@ __global__ __launch_bounds__(MODE == 0 ? 256 : 320) void k_chain(const char* __r
         const int total_q = n_units * 4;
         int g = 0;
         for (int tick = 0; tick < (1 << 22); ++tick) {
-            int issued = 0;
-            while (g < total_q && issued < MAXQ) {
+            while (g < total_q) {  // everything that fits: a consumer may be polling for any of it, and the barrier below cannot
+                                   // complete before all of them have their data
                 const int need = g - NSLOT;  // the quarter that occupied this slot before
                 if (need >= 0 && __builtin_amdgcn_readfirstlane(ctrl[need & 3]) <= (need >> 2)) break;
                 const char* src = W + (size_t)(g >> 2) * UNIT_BYTES + (size_t)(g & 3) * QUARTER + lane * 16;
@@ -109,7 +110,6 @@ __global__ __launch_bounds__(MODE == 0 ? 256 : 320) void k_chain(const char* __r
 #pragma unroll
                 for (int i = 0; i < NFRAG; ++i) glds16(src + i * 1024, dst + i * 1024);
                 ++g;
-                ++issued;
             }
             __builtin_amdgcn_s_barrier();
             if (__builtin_amdgcn_readfirstlane(ctrl[4])) break;
@@ -203,11 +203,11 @@ __global__ __launch_bounds__(MODE == 0 ? 256 : 320) void k_chain(const char* __r
     o[3] = sum[3];
 }
 
-template <int MODE, int MAXQ>
+template <int MODE, int NSLOT>
 static double run(const char* dW, int n_units, int gap, int n_wg, float* dout, long long* dcyc, std::vector<float>& hout) {
     const size_t lds = (MODE == 1 ? NSLOT * QUARTER : 0) + 4 * PLANE * 2 + 64;
-    CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_chain<MODE, MAXQ>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    for (int r = 0; r < 3; ++r) hipLaunchKernelGGL((k_chain<MODE, MAXQ>), dim3(n_wg), dim3(MODE == 0 ? 256 : 320), lds, 0, dW, n_units, gap, dout, dcyc);
+    CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_chain<MODE, NSLOT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    for (int r = 0; r < 3; ++r) hipLaunchKernelGGL((k_chain<MODE, NSLOT>), dim3(n_wg), dim3(MODE == 0 ? 256 : 320), lds, 0, dW, n_units, gap, dout, dcyc);
     CHECK(hipDeviceSynchronize());
     std::vector<long long> c(n_wg);
     CHECK(hipMemcpy(c.data(), dcyc, n_wg * sizeof(long long), hipMemcpyDeviceToHost));
@@ -215,6 +215,7 @@ static double run(const char* dW, int n_units, int gap, int n_wg, float* dout, l
     CHECK(hipMemcpy(hout.data(), dout, hout.size() * sizeof(float), hipMemcpyDeviceToHost));
     std::sort(c.begin(), c.end());
     if (c[0] < 0) printf("  (MODE %d: a consumer gave up waiting for its slot in %d workgroups)\n", MODE, (int)std::count(c.begin(), c.end(), -1LL));
+    // (one time unit of clock64() / s_memtime = one cycle of the 100 MHz reference clock x ... on this part: compare columns, not absolutes)
     return (double)c[n_wg / 2] / n_units;
 }
 
@@ -234,12 +235,12 @@ int main(int argc, char** argv) {
     CHECK(hipMalloc((void**)&dout, (size_t)n_wg * 256 * 4 * sizeof(float)));
     CHECK(hipMalloc((void**)&dcyc, n_wg * sizeof(long long)));
     printf("%d units of 64 KB (fp16 pairs: 24 MFMA 16x16x32 per wave and unit), %d workgroups, s_memtime ticks per unit (median workgroup)\n", n_units, n_wg);
-    printf("%-12s %-34s %-34s %-34s\n", "gap iters", "MODE 0 register prefetch (4 waves)", "MODE 1 loader wave, 1 quarter/tick", "MODE 1 loader wave, 2 quarters/tick");
-    for (int gap : {0, 64, 128, 256, 1024}) {
+    printf("%-12s %-34s %-34s %-34s\n", "gap iters", "MODE 0 register prefetch (4 waves)", "MODE 1 loader wave, 5 x 16 KB ring", "MODE 1 loader wave, 8 x 16 KB ring");
+    for (int gap : {0, 12, 24, 48, 224}) {  // ~40 ticks per iteration: ~0 / 0.5 k / 1 k / 2 k / 9 k cycles (LayerNorm ~1-2 k, a 256-key walk ~9 k)
         std::vector<float> r0, r1, r2;
-        const double c0 = run<0, 1>(dW, n_units, gap, n_wg, dout, dcyc, r0);
-        const double c1 = run<1, 1>(dW, n_units, gap, n_wg, dout, dcyc, r1);
-        const double c2 = run<1, 2>(dW, n_units, gap, n_wg, dout, dcyc, r2);
+        const double c0 = run<0, 5>(dW, n_units, gap, n_wg, dout, dcyc, r0);
+        const double c1 = run<1, 5>(dW, n_units, gap, n_wg, dout, dcyc, r1);
+        const double c2 = run<1, 8>(dW, n_units, gap, n_wg, dout, dcyc, r2);
         const bool same = memcmp(r0.data(), r1.data(), r0.size() * 4) == 0 && memcmp(r0.data(), r2.data(), r0.size() * 4) == 0;
         printf("%-12d %-34.0f %-34.0f %-34.0f %s\n", gap, c0, c1, c2, same ? "bit-identical" : "RESULTS DIFFER");
     }
