@@ -175,6 +175,11 @@ def load() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    # torch's own HIP runtime must be in the process BEFORE this library is dlopened: the wheel bundles its libamdhip64, and a process
+    # that loads the system's copy first (this library's DT_NEEDED) and torch's afterwards ends up with two runtimes of which the second
+    # sees no device ("no HIP device visible" from tb_create after `build(); smoke()` in one interpreter, round 4).  With torch first the
+    # loader resolves this library's libamdhip64 to the one already loaded.
+    import torch  # noqa: F401
     if not os.path.exists(_LIB_PATH):
         raise RuntimeError(
             f"trafficbots_amd: HIP library not built ({_LIB_PATH} missing). There is no CPU fallback; "
