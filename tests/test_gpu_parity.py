@@ -314,6 +314,30 @@ def test_sampled_actions_against_reference_golden():
     # and the deterministic rollout of the same inputs is a different one (the noise is really applied)
     det = wm.test_step(batch, latent_eps=torch.from_numpy(eps).cuda(), goal_sample=gs)["rollout_buffer"].preds
     assert float((det - buf.preds).abs().max()) > 1e-3
+    # the same sampled rollout driven step by step through the stateful forward() (round 4): bit-identical to the fused launches
+    from trafficbots_amd.runtime import teacher_forcing_mask
+
+    k, a = meta["k"], meta["scene"]["n_agent"]
+    scene = wm.pre_processing(batch)
+    scene.pop("gt", None)
+    f = wm.model.encode_input_features(scene)
+    latent = wm.model.latent_encoder()
+    wm.model.goal_manager.pred_goal()
+    latent.repeat_interleave_(k, 0)
+    detl = torch.zeros(n, a, dtype=torch.bool, device="cuda")
+    detl[::k] = True
+    feats = dict(scene, map_feature=f["map_feature"], map_feature_valid=f["map_feature_valid"].to(torch.uint8), tl_feature=f["tl_feature"])
+    gv = scene["agent_valid"].bool().any(1).repeat_interleave(k, 0)
+    wm.rollout(feats, latent, gs.reshape(n, a).cuda(), gv, teacher_forcing_mask(scene["agent_valid"].bool()), deterministic_latent=detl,
+               deterministic_action=False, action_eps=act, step_end=meta["time_step_end"], k_futures=k, latent_eps=torch.from_numpy(eps).cuda(),
+               stepwise=True)
+    with pytest.raises(ValueError):
+        wm.forward(deterministic_action=True)  # (the mode is bound when the simulator is opened)
+    for _ in range(n_step):
+        wm.forward(deterministic_action=False)
+    sw = wm.finish_rollout()
+    sw.flatten_repeat(k)
+    assert torch.equal(sw.preds, buf.preds) and torch.equal(sw.action_log_probs, buf.action_log_probs)
 
 
 @pytest.mark.parametrize("seed,scene", [

@@ -498,9 +498,7 @@ class HipEngine:
         io.tap_agent_feature = hip.ptr(out.get("tap_agent_feature"), hip.c_f32p)
         io.check_state = hip.ptr(out.get("check_state"), hip.c_f32p)
         io.check_valid = hip.ptr(out.get("check_valid"), hip.c_u8p)
-        if action_eps is not None:
-            if stepwise:
-                raise NotImplementedError("sampled actions are built for the fused rollout, not for the stepwise API")
+        if action_eps is not None:  # (fused or stepwise: the step kernel indexes the draws by the step it runs)
             action_eps = action_eps.to(device=dev, dtype=f32).contiguous()
             assert action_eps.shape == (n, a, n_step, 2), (tuple(action_eps.shape), (n, a, n_step, 2))
         io.action_eps = hip.ptr(action_eps, hip.c_f32p)
@@ -515,6 +513,7 @@ class HipEngine:
         if default_mask is not None:
             out["_default_tf_mask"] = default_mask
         out["_keepalive_host"] = hd
+        out["_sampled_actions"] = action_eps is not None
         out["_keepalive"] = (latent_sample, latent_mean, dest, goal_valid, mask_teacher_forcing, s, feats, gt, action_eps, latent_eps,
                              latent_deterministic)
         if stepwise:

@@ -371,8 +371,6 @@ class WaymoMotion:
         if deterministic_action:
             action_eps = None
         else:
-            if stepwise or per_step:
-                raise NotImplementedError("sampled actions are built for the fused rollout (not stepwise / gt_sdc what-if)")
             n_inst, n_ag = goal.shape[0], goal.shape[1]
             if action_eps is None:
                 action_eps = torch.randn(n_inst, n_ag, step_end - step_start + 1, 2, device=self.device, generator=generator)
@@ -502,7 +500,7 @@ class WaymoMotion:
                 tl_valid: Optional[Tensor] = None, goal_feature: Optional[Tensor] = None, goal_valid: Optional[Tensor] = None,
                 action_override: Optional[Tensor] = None, mask_action_override: Optional[Tensor] = None,
                 state_override: Optional[Dict[str, Tensor]] = None, mask_state_override: Optional[Tensor] = None,
-                deterministic_action: bool = True, require_train_dict: bool = True, require_vis_dict: bool = False,
+                deterministic_action: Optional[bool] = None, require_train_dict: bool = True, require_vis_dict: bool = False,
                 gt_valid: Optional[Tensor] = None, _skip_state: bool = False):
         """One simulation step with the reference's signature, the stateful `WaymoMotion.forward` (`waymo_motion.py:108-203`):
         advances the simulator opened by `rollout(..., stepwise=True)` and returns `(agent_state, agent_valid, train_dict, vis_dict)`.
@@ -530,15 +528,20 @@ class WaymoMotion:
           agent feature the fused launch of the previous step left in the every-step tap, the traffic lights of `step_tl`, the
           navigator's goal validity -- and `vis_dict` = {"action", "goal_valid", "attn_weights_to_pl / _tl / _agent"} on the host, as
           the reference returns it.  Visualisation path: ~70 small launches + 5 device-to-host copies per step.
-        * Stochastic actions in stepwise mode are outside the built path."""
+        * Sampled actions (`deterministic_action=False`) work step by step as well: open the simulator with
+          `rollout(..., deterministic_action=False, action_eps=..., stepwise=True)`; step s takes the draws `action_eps[:, :, s]`."""
         if (action_override is None) != (mask_action_override is None):
             raise ValueError("forward: action_override and mask_action_override go together")
-        if not deterministic_action:
-            raise NotImplementedError("stochastic actions are outside the built path")
         eng = self.engine
         if not getattr(eng, "_step_open", False):
             raise RuntimeError("forward: no stepwise rollout is open (call rollout(..., stepwise=True) first)")
         o = eng._step_out
+        # `deterministic_action` (`:120`, `Dynamics.update(deterministic=)`): the draws of a sampled rollout are bound when the simulator is
+        # opened (`rollout(deterministic_action=False, action_eps=...)`, one [2]-vector per instance, agent and step), so a call can only
+        # confirm the mode, not switch it; None = as opened
+        if deterministic_action is not None and bool(deterministic_action) == bool(o.get("_sampled_actions", False)):
+            raise ValueError("forward: deterministic_action must match the mode the simulator was opened with "
+                             "(rollout(..., deterministic_action=False, action_eps=...) binds the draws of a sampled rollout)")
         n, a = o["preds"].shape[:2]
         for name, ten, shape in (("map_feature", map_feature, (None, None, 128)), ("tl_feature", tl_feature, (None, None, 128)),
                                  ("goal_feature", goal_feature, (n, a, 128)), ("goal_valid", goal_valid, (n, a))):
