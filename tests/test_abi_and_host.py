@@ -34,7 +34,8 @@ def test_struct_layouts_match_header_field_order():
     from trafficbots_amd import hip
 
     header = open(os.path.join(ROOT, "include", "trafficbots_hip.h")).read()
-    for cname, cls in (("tb_rollout_io", hip.TbRolloutIO), ("tb_encode_io", hip.TbEncodeIO), ("tb_config", hip.TbConfig)):
+    for cname, cls in (("tb_rollout_io", hip.TbRolloutIO), ("tb_encode_io", hip.TbEncodeIO), ("tb_config", hip.TbConfig),
+                       ("tb_latent_sample_io", hip.TbLatentSampleIO), ("tb_dest_sample_io", hip.TbDestSampleIO)):
         body = header[header.index(f"typedef struct {cname} {{"):header.index(f"}} {cname};")]
         body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
         names = []
