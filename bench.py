@@ -367,7 +367,7 @@ def _closed_loop_rule_fields(d32, d64):
 
     e = np.load(path)
     r = ensemble.closed_loop_rule(d32, d64, e["ensg_d32"], e["ensg_d64"], n_flat=60)
-    return {"rule": "tools/ensemble.py::closed_loop_rule (alpha = 1e-3 prediction limit of 32 independent reference runs, no triangle terms; flat 1e-4 to step 60)",
+    return {"rule": "tools/ensemble.py::closed_loop_rule (alpha = 1e-3 prediction limit of 32 independent reference runs + one fp32 ulp of the coordinates, no triangle terms; flat 1e-4 to step 60)",
             "inside_reference_ensemble_every_step": r["ok"],
             **{k: r[k] for k in ("bound_vs_fp32", "bound_vs_fp64", "members_median_vs_fp32", "members_max_vs_fp32", "members_median_vs_fp64",
                                  "members_max_vs_fp64", "ratio_to_median_vs_fp32", "ratio_to_median_vs_fp64", "rank_vs_fp32", "rank_vs_fp64")}}
