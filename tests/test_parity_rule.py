@@ -105,3 +105,20 @@ def test_rule_is_calibrated_on_the_references_own_runs():
     assert tot == 1008 and len(flagged) <= 3, flagged
     tot0, flagged0 = rule_calibration.leave_one_out(0.0)
     assert len(flagged0) > len(flagged)
+
+
+def test_bench_roofline_helpers_say_what_binds():
+    """bench.py: `roofline.bound` comes from measurement (VERDICT r03 task 5) and no printed fraction can exceed 1 for a kernel that
+    does its work: the XDL-pipe fraction is EXECUTED MFMA flops over the 16-bit dense peak, the load path bytes over 64 B/clk/CU."""
+    import bench
+
+    assert bench.what_binds(0.135, 0.12, 0.07, 0.40) == "latency/load-path"       # the headline launch of round 4
+    assert bench.what_binds(None, None, 0.07, 0.40) == "latency/load-path"        # no PMC pass for this build: executed XDL share
+    assert bench.what_binds(0.45, 0.10, 0.4, 0.2) == "mfma" and bench.what_binds(0.10, 0.55, 0.1, 0.2) == "hbm"
+    n = bench.mfma_issue(64, 256, 32, 2)                                           # fp16 pairs: 3 MFMAs per product
+    assert n == 65 * 8 * 3 + 3 * (8 + 1 + 2) * 4 * 3
+    x = bench.xdl_pipe(n, 128, 89.7)
+    assert 0.05 < x["frac"] < 0.10 and x["executed_flops_per_launch"] == n * 4 * 128 * 16384.0
+    lp = bench.load_path(89.7, 64, 256, 32, 4)
+    assert 0.3 < lp["frac"] < 0.5 and lp["weights"] == 65 * 128 * 128 * 4
+    assert bench.mfma_issue(64, 256, 32, 1) * 3 == n                               # bf16: one MFMA per product
