@@ -173,10 +173,12 @@ def closed_loop_rule(d32: np.ndarray, d64: np.ndarray, ens_d32: np.ndarray, ens_
     r32, r64 = np.maximum.accumulate(d32.astype(np.float64)), np.maximum.accumulate(d64.astype(np.float64))
     fin32, fin64 = np.maximum.accumulate(ens_d32, axis=1)[:, -1].astype(np.float64), np.maximum.accumulate(ens_d64, axis=1)[:, -1].astype(np.float64)
     ok_a, ok_b = bool((r64 <= lim64).all()), bool((r32 <= lim32).all())
+    # (reported, not asserted: the verdict of the rule as it was first frozen, without the quantisation term)
+    ok_v1 = bool((r64 <= np.maximum(FLOOR, b64 - QUANT)).all() and (r32 <= np.maximum(FLOOR, b32 - QUANT)).all())
     ok_c = bool(n_flat == 0 or r32[:n_flat].max() <= FLOOR)
     tiny = 1e-12
     return {
-        "ok": ok_a and ok_b and ok_c, "ok_vs_fp64": ok_a, "ok_vs_fp32": ok_b, "ok_flat": ok_c,
+        "ok": ok_a and ok_b and ok_c, "ok_vs_fp64": ok_a, "ok_vs_fp32": ok_b, "ok_flat": ok_c, "ok_without_quantisation_term": ok_v1 and ok_c,
         "final_vs_fp32": float(r32[-1]), "final_vs_fp64": float(r64[-1]),
         "bound_vs_fp32": float(lim32[-1]), "bound_vs_fp64": float(lim64[-1]),
         "members_median_vs_fp32": float(np.median(fin32)), "members_max_vs_fp32": float(fin32.max()),
