@@ -599,6 +599,7 @@ def run_rank(args, rank: int, local_rank: int, world: int) -> None:
             "value": value, "unit": "scene-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": ("f32 (fp16-pair operands on the XDL MFMA, fp32 accumulate; fp32 everywhere else)" if prec == "fp32"
+                      else "f32 (exact: fp32 MFMA 16x16x4 kernels, the fallback of the fp16-pair path; NOT the default)" if prec == "fp32_exact"
                       else "bf16 MFMA operands, fp32 accumulate and state (BASELINE configs 4/5 precision; NOT the headline fp32 metric)"),
             "data": "synthetic",
             "config": {"workload": "BASELINE.json configs[1]: 32 synthetic WOMD-shaped scenes per GPU, 64 agents, 256 polylines, "
@@ -737,7 +738,7 @@ def parse_args(argv=None):
     ap.add_argument("--configs", nargs="*", default=None, help=f"sub-records to measure (default: all at 1 GPU); any of {list(SUBCONFIGS)}")
     ap.add_argument("--config-steps", type=int, default=5, help="timed passes per sub-record")
     ap.add_argument("--only-config", default=None, help="profiling hook: run ONE sub-record alone (no headline leg) and print its record")
-    ap.add_argument("--operand-precision", choices=["fp32", "bf16"], default="fp32",
+    ap.add_argument("--operand-precision", choices=["fp32", "bf16", "fp32_exact"], default="fp32",
                     help="bf16: BASELINE.json configs 4/5 operand precision (not the headline metric, which is fp32)")
     ap.add_argument("--cpu-baseline-worker", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
