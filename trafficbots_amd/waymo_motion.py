@@ -244,7 +244,9 @@ def _range_fallback(fn):
     instead of failing: `tb_check_status` reports the overflow, the context has then switched itself (fp32 MFMA kernels, fp32's range)
     and the step is issued again -- the reference has no range limit (`src/models/modules/mlp.py:20-85`), so a checkpoint that trips
     the guard still gets an fp32-accurate result, only slower (the warning states the measured slowdown).  Metric holders are restored
-    to their state before the invalid run.  `check_range = False` skips the check (and the fallback)."""
+    to their state before the invalid run; random numbers the step draws itself from a `generator` are drawn AGAIN for the re-run (pass
+    explicit draws -- `latent_eps`, `goal_sample`, `action_eps`, `irrelevant_draw`, `history_keep` -- where the run must be repeatable).
+    `check_range = False` skips the check (and the fallback)."""
     import copy
     import functools
     import time
