@@ -283,6 +283,47 @@ def test_against_reference_golden(name):
     _closed_loop_check(name, preds, g, 3, rep)
 
 
+@pytest.mark.parametrize("name", ["small_k1", "masks_k3", "headline_2"])
+def test_exact_fp32_kernels_against_reference_golden(name):
+    """`operand_precision="fp32_exact"` -- the fp32 MFMA step kernel and the fp32-MFMA encoder blocks that a context falls back to when a
+    tensor or an activation leaves the fp16-pair range (round 4: a product path, not a development switch) -- against the same reference
+    goldens and the same closed-loop rule as the default kernels (per case; the suite-level statistics are the default path's)."""
+    g, meta = load_golden(name)
+    cfg, sd, batch, eps = golden_inputs(meta)
+    gs = torch.from_numpy(np.transpose(g["goal_sample"], (0, 2, 1)).copy())
+    wm = _engine({"time_step_end": meta["time_step_end"], "n_joint_future": meta["k"], "operand_precision": "fp32_exact"}, sd)
+    st = wm.engine.precision_state()
+    assert st["step"] == "fp32_exact" and st["encode"] == "fp32_exact" and not st["weight_out_of_range"]
+    out = wm.test_step(batch, latent_eps=torch.from_numpy(eps).cuda(), goal_sample=gs)
+    torch.cuda.synchronize()
+    buf = out["rollout_buffer"]
+    rep = {}
+    if "map_feature" in g.files:
+        f = out["input_feature_dict"]
+        rep["map_feature"] = float(np.abs(f["map_feature"].cpu().numpy() - g["map_feature"]).max())
+        rep["agent_feature_cur"] = float(np.abs(f["agent_feature"][:, -1].cpu().numpy() - g["agent_feature_cur"]).max())
+    rep["latent_mean"] = float(np.abs(out["latent_mean"].cpu().numpy() - g["latent_mean"]).max())
+    rep["goal_log_probs"] = float(np.abs(out["goal_log_probs"].cpu().numpy() - g["goal_log_probs"]).max())
+    rep["action_log_probs"] = float(np.abs(buf.action_log_probs.cpu().numpy() - g["action_log_probs"]).max())
+    for k, v in rep.items():
+        assert v <= ONE_SHOT_TOL, f"{name}: {k} max-abs {v:.3e}"
+    assert (buf.valid.cpu().numpy() == g["valid"]).all() and (buf.override_masks.cpu().numpy() == g["override_masks"]).all()
+    for k in ("outside_map", "dest_reached"):
+        assert (buf.violations[k].cpu().numpy() == g[k]).all(), k
+    preds = buf.preds.cpu().numpy()
+    d = np.abs(preds - g["preds"]) * g["valid"][..., None]
+    assert d[..., :2].max(axis=(0, 1, 2, 4))[:10].max() <= 1e-5
+    suite_before, report_before = dict(SUITE), REPORT.get(name)
+    try:
+        _closed_loop_check(name, preds, g, 3, rep)
+    finally:  # (the report entry and the suite-level statistics of `name` stay the default kernels')
+        REPORT[f"fp32_exact/{name}"] = REPORT.pop(name, rep)
+        if report_before is not None:
+            REPORT[name] = report_before
+        SUITE.clear()
+        SUITE.update(suite_before)
+
+
 def test_sampled_actions_against_reference_golden():
     """`deterministic_action=False` (`dynamics.py:77`; `training_deterministic_action` in the reference's config): every step samples its
     action as mean + eps * exp(log_std) and scores it with Normal.log_prob.  Golden `stoch_actions` = the reference's
