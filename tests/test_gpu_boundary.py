@@ -203,8 +203,11 @@ def test_forward_applies_per_call_state_overrides():
     assert torch.equal(st1["agent_valid"].bool() & ~st0["agent_valid"].bool(), torch.zeros_like(st0["agent_valid"]).bool())  # no spawn
 
 
-def test_forward_action_override_against_reference_golden():
-    """`forward(action_override=, mask_action_override=)` (`waymo_motion.py:116-117,174-175` -> `Dynamics.update`, `dynamics.py:96-100`)
+@pytest.mark.parametrize("precision", ["fp32", "fp32_exact"])
+def test_forward_action_override_against_reference_golden(precision):
+    """(`precision="fp32_exact"`: the exact-fp32 step kernel serves the per-call overrides as well since round 5 -- the context a
+    range hit falls back to must not refuse a call the default kernels take.)
+    `forward(action_override=, mask_action_override=)` (`waymo_motion.py:116-117,174-175` -> `Dynamics.update`, `dynamics.py:96-100`)
     through `tb_rollout_step_ex`: golden `action_override` = the reference's joint_future_pred with its `forward` wrapped to add step s of
     synth.make_action_override to every call (the bound teacher forcing applies unchanged)."""
     from trafficbots_amd import synth
@@ -218,8 +221,9 @@ def test_forward_action_override_against_reference_golden():
     n_step = step_end - cfg["time_step_sim_start"] + 1
     ao, am = synth.make_action_override(meta["base_seed"] + 55, n, a, n_step)
     ao, am = torch.from_numpy(ao).cuda(), torch.from_numpy(am).cuda()
-    wm = WaymoMotion(time_step_end=step_end, n_joint_future=k)
+    wm = WaymoMotion(time_step_end=step_end, n_joint_future=k, operand_precision=precision)
     wm.load_state_dict(sd)
+    assert wm.engine.precision_state()["step"] == ("fp16_pair" if precision == "fp32" else "fp32_exact")
     scene = wm.pre_processing(batch)
     scene.pop("gt", None)
     f = wm.model.encode_input_features(scene)

@@ -324,8 +324,11 @@ def test_exact_fp32_kernels_against_reference_golden(name):
         SUITE.update(suite_before)
 
 
-def test_sampled_actions_against_reference_golden():
-    """`deterministic_action=False` (`dynamics.py:77`; `training_deterministic_action` in the reference's config): every step samples its
+@pytest.mark.parametrize("precision", ["fp32", "fp32_exact"])
+def test_sampled_actions_against_reference_golden(precision):
+    """(`precision="fp32_exact"`, round 5: sampled actions on the exact-fp32 step kernel -- the kernels a range hit falls back to take
+    every call the default kernels take.)
+    `deterministic_action=False` (`dynamics.py:77`; `training_deterministic_action` in the reference's config): every step samples its
     action as mean + eps * exp(log_std) and scores it with Normal.log_prob.  Golden `stoch_actions` = the reference's
     joint_future_pred with its rollout switched to sampled actions and the rsample draws replaced by synth.make_action_noise."""
     from trafficbots_amd import synth
@@ -337,7 +340,8 @@ def test_sampled_actions_against_reference_golden():
     n_step = meta["time_step_end"] - cfg["time_step_sim_start"] + 1
     act = torch.from_numpy(synth.make_action_noise(meta["base_seed"] + 77, n, meta["scene"]["n_agent"], n_step)).cuda()
     gs = torch.from_numpy(np.transpose(g["goal_sample"], (0, 2, 1)).copy())
-    wm = _engine({"time_step_end": meta["time_step_end"], "n_joint_future": meta["k"]}, sd)
+    wm = _engine({"time_step_end": meta["time_step_end"], "n_joint_future": meta["k"], "operand_precision": precision}, sd)
+    assert wm.engine.precision_state()["step"] == ("fp16_pair" if precision == "fp32" else "fp32_exact")
     out = wm.test_step(batch, latent_eps=torch.from_numpy(eps).cuda(), goal_sample=gs, action_eps=act)
     torch.cuda.synchronize()
     buf = out["rollout_buffer"]
@@ -352,7 +356,16 @@ def test_sampled_actions_against_reference_golden():
     d = np.abs(preds - g["preds"]) * g["valid"][..., None]
     rep["traj_xy_open_loop_max"] = float(d[..., :10, :2].max())
     assert rep["traj_xy_open_loop_max"] <= 1e-5
-    _closed_loop_check(name, preds, g, 3, rep)
+    suite_before, report_before = dict(SUITE), REPORT.get(name)
+    try:
+        _closed_loop_check(name, preds, g, 3, rep)
+    finally:
+        if precision != "fp32":  # (the report entry and the suite-level statistics of `name` stay the default kernels')
+            REPORT[f"{precision}/{name}"] = REPORT.pop(name, rep)
+            if report_before is not None:
+                REPORT[name] = report_before
+            SUITE.clear()
+            SUITE.update(suite_before)
     # and the deterministic rollout of the same inputs is a different one (the noise is really applied)
     det = wm.test_step(batch, latent_eps=torch.from_numpy(eps).cuda(), goal_sample=gs)["rollout_buffer"].preds
     assert float((det - buf.preds).abs().max()) > 1e-3

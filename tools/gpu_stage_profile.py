@@ -72,3 +72,7 @@ for nm, a_, b_ in (("blk0 phase A (QK next || exp)", 25, 26), ("blk0 phase B (PV
     v = st[:, b_] - st[:, a_]
     print(f"    as2pl[0]/attention {nm:34s} {np.median(v):8.0f}  [{v.min():7.0f} .. {v.max():7.0f}]")
 print(f"    as2pl[0]/attention prologue (loads + first QK + stats) {np.median(st[:, 25] - st[:, 18]):8.0f}")
+if os.environ.get("TB_STEP_AW", "1") != "0" and a * b // 16 > 128 and p >= 512 and os.environ.get("TB_PRECISION") == "bf16":
+    # the assist carve (tb::xba): stamp 25 = the main wave's own half of the walk is done (in front of the merge barrier)
+    v, w = st[:, 25] - st[:, 18], st[:, 19] - st[:, 25]
+    print(f"    as2pl[0]/assist carve: main wave 0's own blocks {np.median(v):8.0f} [{v.min():7.0f} .. {v.max():7.0f}]; merge barrier + merge {np.median(w):8.0f} [{w.min():7.0f} .. {w.max():7.0f}]")

@@ -87,7 +87,19 @@ class _Metric(nn.Module):
         super().__init__()
 
     def add_state(self, name, default, dist_reduce_fx=None):
+        self.__dict__.setdefault("_tb_defaults", {})[name] = default.clone() if torch.is_tensor(default) else default
         setattr(self, name, default)
+
+    # torchmetrics' `Metric.forward` on a freshly reset metric = update on zero states + compute, and `reset` = back to the
+    # defaults: what `training_step` uses (`waymo_motion.py:403-417`; tools/train_reference.py)
+    def reset(self):
+        for name, default in self.__dict__.get("_tb_defaults", {}).items():
+            setattr(self, name, default.clone() if torch.is_tensor(default) else default)
+
+    def forward(self, *a, **k):
+        self.reset()
+        self.update(*a, **k)
+        return self.compute()
 
 
 class _Dummy:

@@ -40,6 +40,10 @@ void launch_step_x(const RolloutP& p, int t, int do_c, int do_a, hipStream_t s);
 hipError_t configure_stepx_kernel();
 void launch_step_pre_x(const RolloutP& p, int t0, int n, hipStream_t s);
 }
+namespace xba {     // bf16, eight-wave workgroups with assist waves (tb_stepx_bf16aw_kernels.hip): one workgroup per CU over >= 512 polylines
+void launch_step_x(const RolloutP& p, int t, int do_c, int do_a, hipStream_t s);
+hipError_t configure_stepx_kernel();
+}
 int run_encode(struct ::tb_ctx* ctx, const tb_encode_io* io, hipStream_t s);
 int run_rule_checks(const tb_rule_io* io, int n_hist, int step_start, uint8_t* raw_ws, hipStream_t s);
 int run_encode_posterior(struct ::tb_ctx* ctx, const tb_posterior_io* io, hipStream_t s);
@@ -340,6 +344,17 @@ static bool w3_launch(size_t n_tiles) {
     return !(e && e[0] == '0') && n_tiles > 512;
 }
 
+// bf16 launches of one workgroup per CU (129 .. 256 row tiles: too many for helper workgroups, too few for a second dispatch round)
+// whose A half walks >= 512 map polylines run eight-wave workgroups: four assist waves take every other key block of the
+// map-attention walks (tb::xba; tb_device_xdl.hpp "Assist waves").  The two halves of a walk are merged in a fixed order, so the
+// result is deterministic, but it is not the bit pattern of the four-wave kernel (another summation order of the same softmax).
+// TB_STEP_AW=0 keeps such launches on the four-wave kernel (development / A-B switch).
+static bool aw_launch(const tb::RolloutP& p, int do_a) {
+    const char* e = getenv("TB_STEP_AW");
+    const size_t n_tiles = (size_t)(p.a_pad / tb::TM) * p.n_inst;
+    return !(e && e[0] == '0') && do_a && n_tiles > 128 && n_tiles <= 256 && p.p_pad >= 512;
+}
+
 // `rd` supplies what C(t) reads (normally the same struct as `wr`; the batched warm start substitutes its slices), `wr` what
 // the launch writes
 static void step_launch(const tb_ctx* ctx, const tb::RolloutP& rd, const tb::RolloutP& wr, int t, int do_c, int do_a, hipStream_t s) {
@@ -352,6 +367,8 @@ static void step_launch(const tb_ctx* ctx, const tb::RolloutP& rd, const tb::Rol
     }
     if (ctx->step_kernel == 3 && w3_launch((size_t)(p.a_pad / tb::TM) * p.n_inst))
         tb::xb3::launch_step_x(p, t, do_c, do_a, s);
+    else if (ctx->step_kernel == 3 && aw_launch(p, do_a))
+        tb::xba::launch_step_x(p, t, do_c, do_a, s);
     else if (ctx->step_kernel == 3)
         tb::xb::launch_step_x(p, t, do_c, do_a, s);
     else if (ctx->step_kernel == 2)
@@ -444,6 +461,7 @@ int tb_finalize_weights(tb_ctx* ctx, tb_stream stream) {
     TB_HIP(ctx, tb::xh::configure_stepx_kernel());
     TB_HIP(ctx, tb::xb::configure_stepx_kernel());
     TB_HIP(ctx, tb::xb3::configure_stepx_kernel());
+    TB_HIP(ctx, tb::xba::configure_stepx_kernel());
     TB_HIP(ctx, tb::configure_rule_kernels());
     TB_HIP(ctx, tb::xh::configure_encodex_kernels());
     Arena a;
@@ -841,7 +859,6 @@ static int rollout_setup(tb_ctx* ctx, const tb_rollout_io* io, tb::RolloutP& p) 
     p.latent_eps = io->latent_eps;
     p.latent_det = io->latent_deterministic;
     p.action_eps = io->action_eps;
-    if (io->action_eps && ctx->step_kernel < 2) return tb_fail(ctx, "tb_rollout: action_eps (sampled actions) needs the XDL step kernels");
     p.latent_mean = io->latent_mean;
     p.dest = io->dest;
     p.goal_valid0 = io->goal_valid;
@@ -927,7 +944,7 @@ static void rollout_prologue(const tb_ctx* ctx, const tb::RolloutP& p, const tb_
 static int rollout_enqueue(tb_ctx* ctx, const tb_rollout_io* io, const tb::RolloutP& p, hipStream_t s);
 
 // every launch-shaping development switch read below this call (step_launch, rollout_prologue): part of the graph key
-static const char* const kGraphEnv[] = {"TB_STEP_W3", "TB_STEP_LEAN", "TB_STEP_HELPERS", "TB_GRU_HELPER", "TB_DEBUG_HELPER_DELAY", "TB_STEP_KERNEL"};
+static const char* const kGraphEnv[] = {"TB_STEP_W3", "TB_STEP_AW", "TB_STEP_LEAN", "TB_STEP_HELPERS", "TB_GRU_HELPER", "TB_DEBUG_HELPER_DELAY", "TB_STEP_KERNEL"};
 
 static void key_append(std::vector<unsigned char>& k, const void* data, size_t n) {
     const unsigned char* b = static_cast<const unsigned char*>(data);
@@ -1169,7 +1186,6 @@ extern "C" int tb_rollout_step_ex(tb_ctx* ctx, const tb_step_override* ov, tb_st
     const int t = ctx->step_next;
     tb::RolloutP p = ctx->step_p;
     if (ov) {
-        if (ctx->step_kernel < 2) return tb_fail(ctx, "tb_rollout_step_ex: per-call overrides need the XDL step kernel (TB_STEP_KERNEL=fp32 is the A/B twin only)");
         if ((ov->action == nullptr) != (ov->action_mask == nullptr))
             return tb_fail(ctx, "tb_rollout_step_ex: action and action_mask go together");
         if (!ov->mask && !ov->action_mask) return tb_fail(ctx, "tb_rollout_step_ex: tb_step_override holds neither a state mask nor an action mask");
@@ -1220,7 +1236,12 @@ extern "C" int tb_check_status(tb_ctx* ctx, tb_stream stream_) {
         // The results of the calls since the last check are invalid, and the context switches ITSELF to the exact-fp32 twins of the
         // kernels that overflowed (fp32's range): the caller re-issues those calls -- the host mirror does it automatically
         // (WaymoMotion(check_range=True)).  Return code 3 tells this case apart from a hard error.
-        if ((h & 1u) && ctx->step_kernel == 2) ctx->step_kernel = 0;
+        if ((h & 1u) && ctx->step_kernel == 2) {
+            ctx->step_kernel = 0;
+            // an open stepwise rollout was begun by the XDL prologue: its hoisted K / V and fusion buffers are in XDL operand order,
+            // which the exact kernel cannot read -- the rollout is closed, tb_rollout_step then fails with "call tb_rollout_begin"
+            ctx->step_active = false;
+        }
         if (h & 2u) ctx->encode_kernel = 0;
         ctx->precision_reason |= 2;
         tb_fail(ctx, "fp16-pair operand range exceeded: a GEMM / attention input of the %s%s%s reached |x| >= 65504 since the last "

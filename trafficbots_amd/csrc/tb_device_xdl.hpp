@@ -31,7 +31,12 @@
 #if defined(TB_XDL_W3) && !defined(TB_XDL_BF16)
 #error "TB_XDL_W3 is a variant of the bf16 build (the fp16-pair twin was measured and lost: profiles/r03_experiments_not_kept.txt)"
 #endif
-#ifdef TB_XDL_W3
+#if defined(TB_XDL_AW) && (!defined(TB_XDL_BF16) || defined(TB_XDL_W3))
+#error "TB_XDL_AW is a variant of the plain bf16 build (one workgroup per CU, 213 VGPRs: two waves per SIMD fit)"
+#endif
+#ifdef TB_XDL_AW
+#define TB_XNS xba
+#elif defined(TB_XDL_W3)
 #define TB_XNS xb3
 #elif defined(TB_XDL_BF16)
 #define TB_XNS xb
@@ -665,6 +670,141 @@ __device__ __forceinline__ bool attention_head_x(const f32x4 (&q)[2], AttnPreX& 
     return novalid;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Assist waves (round 5; the TB_XDL_AW build, tb_stepx_bf16aw_kernels.hip): a step workgroup of EIGHT waves.  Waves 0-3 run the
+// step as before; wave 4 + w sits on the SIMD of wave w and takes every second key block of head w's walk over the map polylines
+// (1024 polylines = 32 blocks per layer: 43 % of a stress-shape launch is this walk at one wave per SIMD, bound by the latency of
+// its own dependent chain and of two K / V requests in flight).  Two waves per SIMD interleave their chains and double the
+// requests in flight.  The split is STATIC (block sequence index even / odd), so the result does not depend on timing; the two
+// un-normalised online-softmax states are merged once per layer through LDS.
+//   LDS prefix of the AW build (in front of the step carve): 16 words of control + one partial state per (wave, lane)
+// Synchronisation: every __syncthreads() of the main waves is a hardware barrier of all eight waves, and the number of barriers
+// in front of a map-attention layer depends on the data (interaction bypass, ...), so the main waves COUNT their barriers (thread 0
+// adds 1 to an LDS word in front of each: aw_sync, tb_stepx_kernels.hip) and post a command "at barrier number X: layer l" /
+// "exit"; an assist wave loops on s_barrier, counts its own, and acts when the posted number is its count.  (A bare "do it now"
+// word cannot work: an assist wave that reads it late cannot tell whether it was written in front of the barrier it just left.)
+// ---------------------------------------------------------------------------------------------
+#ifdef TB_XDL_AW
+constexpr int AW_WORDS = 16;                                   // control words (floats of LDS)
+constexpr int AW_PART_LD = 12;                                 // floats per lane of a partial state: o[2] (8), max, sum, pad
+constexpr int AW_PREFIX = AW_WORDS + 4 * 64 * AW_PART_LD;      // floats in front of the step kernel's carve
+constexpr unsigned AW_OP_EXIT = 255u;
+#else
+constexpr int AW_PREFIX = 0;
+#endif
+
+struct AttnPartX {
+    f32x4 o[2];    // un-normalised O^T accumulators, relative to m
+    float m, s;    // running max (log2 units; uniform over the four lanes of a row) and this lane's share of the running sum
+};
+
+#ifdef TB_XDL_AW
+// The key walk of attention_head_x restricted to the blocks of sequence index s0, s0 + 2, ... (sequence index s = key block
+// kwrap(kstart + 32 s)): `kfirst` = first key of this wave's first block, `nblk` = how many blocks it takes (may be 0).
+// pre: k0f / vc = the first block, kn = the second one (kfirst + 64, wrapped).  Single-plane (bf16) operands only.
+__device__ __forceinline__ void attention_walk2_x(const xh8& qh, AttnPreX& pre, const xhalf* __restrict__ Kh, const xhalf* __restrict__ Vh,
+                                                  const float* __restrict__ keybias, int n_key_pad, int kfirst, int nblk, int head,
+                                                  int lane, AttnPartX& out) {
+    static_assert(NPL == 1, "assist waves exist in the bf16 build only");
+    const int kq = lane >> 4;
+    const xhalf* kbase = Kh + head * (NPL * 1024) + lane * 8;
+    const xhalf* vbase = Vh + head * (NPL * 1024) + lane * 8;
+    const float* bbase = keybias + kq * 4;
+    f32x4 oh[2] = {splat(0.f), splat(0.f)};
+    float run_max = RUN_MAX_NONE, run_sum = 0.f, new_max = RUN_MAX_NONE, alpha = 1.f, sv[8];
+    if (nblk > 0) {
+        KFragX kn = pre.kn;
+        VFragX vc = pre.vc;
+        {
+            f32x4 s[2], c[2];
+            attn_qk_x(pre.k0f, qh, qh, s, c);
+            attn_stats_x<false>(s, c, pre.k0f.kb, kfirst + kq * 4, -1, run_max, sv, new_max, alpha);
+        }
+        int kc = kfirst, k1 = kwrap(kfirst + 64, n_key_pad), k2 = kwrap(k1 + 64, n_key_pad);
+        for (int i = 0; i < nblk; ++i) {
+            const int kn1 = (i + 1 < nblk) ? k1 : kc;
+            const int kld = (i + 2 < nblk) ? k2 : kc;
+            TB_SCHED_FENCE();
+            f32x4 ts[2], tc[2];
+            in_vgpr(oh[0]); in_vgpr(oh[1]);
+            attn_qk_x(kn, qh, qh, ts, tc);
+            in_vgpr(ts[0]); in_vgpr(ts[1]);
+            const f32x4 nb[2] = {kn.kb[0], kn.kb[1]};
+            TB_SCHED_FENCE();
+            k_load_x(kn, kbase, bbase, kld);
+            float p[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) p[r] = exp2_neg(sv[r] - new_max);
+            run_sum = run_sum * alpha + (((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7])));
+            run_max = new_max;
+            xh8 ph, pl;
+            split8<false>(f32x4{p[0], p[1], p[2], p[3]}, f32x4{p[4], p[5], p[6], p[7]}, ph, pl);
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) oh[dt] *= splat(alpha);
+            TB_SCHED_FENCE();
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) oh[dt] = mfma_h(vc.va[dt][0], ph, oh[dt]);
+            TB_SCHED_FENCE();
+            v_load_x(vc, vbase, kn1);
+            in_vgpr(oh[0]); in_vgpr(oh[1]);
+            attn_stats_x<false>(ts, tc, nb, kn1 + kq * 4, -1, run_max, sv, new_max, alpha);  // (unused after the last block)
+            TB_SCHED_FENCE();
+            kc = k1;
+            k1 = k2;
+            k2 = kwrap(k2 + 64, n_key_pad);
+        }
+    }
+    out.o[0] = oh[0];
+    out.o[1] = oh[1];
+    out.m = run_max;
+    out.s = run_sum;
+}
+
+// prefetch for attention_walk2_x: the wave's first block (K, V) and its second block (K)
+__device__ __forceinline__ void attention_prefetch2_x(AttnPreX& a, const xhalf* __restrict__ Kh, const xhalf* __restrict__ Vh,
+                                                      const float* __restrict__ keybias, int n_key_pad, int kfirst, int nblk, int head,
+                                                      int lane) {
+    const int kq = lane >> 4;
+    const xhalf* kbase = Kh + head * (NPL * 1024) + lane * 8;
+    const xhalf* vbase = Vh + head * (NPL * 1024) + lane * 8;
+    const float* bbase = keybias + kq * 4;
+    TB_SCHED_FENCE();
+    k_load_x(a.k0f, kbase, bbase, kfirst);
+    v_load_x(a.vc, vbase, kfirst);
+    k_load_x(a.kn, kbase, bbase, nblk > 1 ? kwrap(kfirst + 64, n_key_pad) : kfirst);
+    TB_SCHED_FENCE();
+}
+
+// two partial states of one row set -> the normalised attention output (merged in the order main, assist)
+__device__ __forceinline__ bool attention_merge2_x(const AttnPartX& a, const AttnPartX& b, f32x4 (&o)[2]) {
+    const float mx = fmaxf(a.m, b.m);
+    const float fa = exp2_neg(a.m - mx), fb = exp2_neg(b.m - mx);
+    float s = a.s * fa + b.s * fb;
+    s = rows_sum(s);
+    const bool novalid = !(s > 0.f);
+    const float inv = novalid ? 0.f : 1.0f / s;
+    o[0] = (a.o[0] * splat(fa) + b.o[0] * splat(fb)) * splat(inv);
+    o[1] = (a.o[1] * splat(fa) + b.o[1] * splat(fb)) * splat(inv);
+    return novalid;
+}
+
+__device__ __forceinline__ unsigned int* aw_words() {
+    extern __shared__ __attribute__((aligned(16))) float smem_all[];
+    return reinterpret_cast<unsigned int*>(smem_all);
+}
+__device__ __forceinline__ float* aw_part(int wave, int lane) {
+    extern __shared__ __attribute__((aligned(16))) float smem_all[];
+    return smem_all + AW_WORDS + (wave * 64 + lane) * AW_PART_LD;
+}
+// main waves, thread 0: "at the NEXT barrier: op" (the count of barriers so far is this thread's own word 0)
+__device__ __forceinline__ void aw_post(unsigned int op) {
+    unsigned int* w = aw_words();
+    const unsigned int c = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __hip_atomic_store(w + 2, op, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __hip_atomic_store(w + 1, c + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+#endif  // TB_XDL_AW
+
 // The same attention when the whole key set is ONE 32-key block (a polyline's 20 nodes, a scene's lit traffic lights): no walk, so no
 // second QK for a "next" block, no rescale, no re-loads -- and nothing that pins the schedule, so that two calls for independent
 // (query tile, key block) pairs interleave in one instruction stream.  Arithmetic and its order are those of attention_head_x with
@@ -741,13 +881,21 @@ __device__ __forceinline__ void kv_store_key_x(xhalf* __restrict__ Kf, xhalf* __
 // One pre-LN cross-attention layer, GEMMs and attention on XDL.
 //   X : [16][LDT] fp32 residual stream (LDS);  P1, P2 : plane buffers (LN output / attention output + FFN hidden)
 // ---------------------------------------------------------------------------------------------
-template <bool LNLDS = false, bool SELFMASK = false, bool WO_EARLY = true, class R = RangeFlag>
+// AW (the TB_XDL_AW build): the partner assist wave of every main wave takes the odd key blocks of this layer (`aw_op` = the layer's
+// index for the assist waves, posted for the LayerNorm barrier below)
+template <bool LNLDS = false, bool SELFMASK = false, bool WO_EARLY = true, bool AW = false, class R = RangeFlag>
 __device__ __forceinline__ void xattn_layer_x(const float* __restrict__ W, const XLayerW& L, const XLayerX& LX, float* X, xhalf* P1,
                                               xhalf* P2, const xhalf* __restrict__ Kmat, const xhalf* __restrict__ VT,
                                               const float* __restrict__ keybias, int n_key_pad, int kstart, int self_key0,
                                               const uint8_t* rowvalid, uint8_t* novalid_s, int tid, WUnitX& u, const WNextX& nxt,
-                                              const float* lnblk = nullptr, long long* prof = nullptr, R&& amax = R{}) {
+                                              const float* lnblk = nullptr, long long* prof = nullptr, R&& amax = R{}, int aw_op = 0) {
     if (!LNLDS) lnblk = W + L.ln1_g;
+#ifdef TB_XDL_AW
+    if (AW && tid == 0) aw_post((unsigned int)aw_op);
+#else
+    static_assert(!AW, "assist waves: TB_XDL_AW build only");
+    (void)aw_op;
+#endif
     const int wave = wave_of(tid), lane = tid & 63;
     const int kq = lane >> 4, m = lane & 15;
     TB_XSTAMP(16);
@@ -776,6 +924,10 @@ __device__ __forceinline__ void xattn_layer_x(const float* __restrict__ W, const
         k_load_x(apre.kn, Kmat + wave * (NPL * 1024) + lane * 8, keybias + kq * 4, n_key_pad > 32 ? kwrap(kstart + 32, n_key_pad) : kstart);
         TB_SCHED_FENCE();
     } else {
+#ifdef TB_XDL_AW
+        if (AW) attention_prefetch2_x(apre, Kmat, VT, keybias, n_key_pad, kstart, ((n_key_pad >> 5) + 1) >> 1, wave, lane);
+        else
+#endif
         attention_prefetch_x(apre, Kmat, VT, keybias, n_key_pad, kstart, wave, lane);
     }
     __syncthreads();
@@ -785,8 +937,26 @@ __device__ __forceinline__ void xattn_layer_x(const float* __restrict__ W, const
     else wmmax(q[0], q[1], u, b1, PLANE);
     TB_XSTAMP(18);
     f32x4 o[2];
-    const bool novalid = attention_head_x<SELFMASK, !WO_EARLY>(q, apre, Kmat, VT, keybias, n_key_pad, kstart, wave, lane,
-                                                           self_key0 >= 0 ? self_key0 + m : -1, o, u2, wstdx(W, LX.wo, W + L.bo, wave), prof, amax);
+    bool novalid;
+#ifdef TB_XDL_AW
+    if (AW) {
+        // this wave: block sequence indices 0, 2, 4, ...; the assist wave on the same SIMD: 1, 3, 5, ... (aw_assist_layer_x)
+        xh8 qh, ql;
+        split8(q[0], q[1], qh, ql, amax);
+        AttnPartX mine, theirs;
+        attention_walk2_x(qh, apre, Kmat, VT, keybias, n_key_pad, kstart, ((n_key_pad >> 5) + 1) >> 1, wave, lane, mine);
+        TB_XSTAMP(25);
+        __syncthreads();  // the assist waves have written their states
+        const float* ps = aw_part(wave, lane);
+        theirs.o[0] = lds4(ps);
+        theirs.o[1] = lds4(ps + 4);
+        theirs.m = ps[8];
+        theirs.s = ps[9];
+        novalid = attention_merge2_x(mine, theirs, o);
+    } else
+#endif
+    novalid = attention_head_x<SELFMASK, !WO_EARLY>(q, apre, Kmat, VT, keybias, n_key_pad, kstart, wave, lane,
+                                                    self_key0 >= 0 ? self_key0 + m : -1, o, u2, wstdx(W, LX.wo, W + L.bo, wave), prof, amax);
     TB_XSTAMP(19);
     planes_store_c<false>(P2, 2 * wave, lane, o[0]);  // (a convex combination of V, which was checked when it was stored)
     planes_store_c<false>(P2, 2 * wave + 1, lane, o[1]);
@@ -831,6 +1001,32 @@ __device__ __forceinline__ void xattn_layer_x(const float* __restrict__ W, const
     __syncthreads();
     TB_XSTAMP(24);
 }
+
+#ifdef TB_XDL_AW
+// Assist wave `wave` (0..3 = the head / the main wave it shares a SIMD with) for one map-attention layer, entered right behind
+// the layer's LayerNorm barrier: the same Q projection from the same planes (the wave's own copy of the weight unit, `u`: loaded
+// while it waited), the odd key blocks, its state to LDS.  The caller runs the barrier that publishes the state.
+__device__ __forceinline__ void aw_assist_layer_x(const WUnitX& u, const xhalf* P1, const xhalf* __restrict__ Kmat, const xhalf* __restrict__ VT,
+                                                  const float* __restrict__ keybias, int n_key_pad, int kstart, int wave, int lane) {
+    const int kq = lane >> 4, m = lane & 15;
+    const int nb = n_key_pad >> 5;
+    const int nblk = nb >> 1;
+    const int kfirst = kwrap(kstart + 32, n_key_pad);
+    AttnPreX apre;
+    attention_prefetch2_x(apre, Kmat, VT, keybias, n_key_pad, kfirst, nblk, wave, lane);
+    f32x4 q[2] = {u.b[0], u.b[1]};
+    wmmax(q[0], q[1], u, P1 + m * LDP + kq * 8, PLANE);
+    xh8 qh, ql;
+    split8<false>(q[0], q[1], qh, ql);
+    AttnPartX st;
+    attention_walk2_x(qh, apre, Kmat, VT, keybias, n_key_pad, kfirst, nblk, wave, lane, st);
+    float* ps = aw_part(wave, lane);
+    st4(ps, st.o[0]);
+    st4(ps + 4, st.o[1]);
+    ps[8] = st.m;
+    ps[9] = st.s;
+}
+#endif
 
 template <class R = RangeFlag>
 __device__ __forceinline__ void kv_store_x(xhalf* __restrict__ Kf, xhalf* __restrict__ Vf, int tok0, int wave, int lane,

@@ -324,6 +324,7 @@ __global__ __launch_bounds__(NTHREADS) void k_step(RolloutP p, int t, int do_c, 
         rowvalid[tid] = p.valid[si];
         gvalid[tid] = p.goal_valid[si];
     }
+    if (tid == TM) dflag[EPI_POISON_WORD] = 0;  // (read by step_epilogue16; this kernel has no helper hand-off that could raise it)
     TB_STAMP(13);
 
     if (do_c) {
@@ -415,7 +416,9 @@ __global__ __launch_bounds__(NTHREADS) void k_step(RolloutP p, int t, int do_c, 
         TB_STAMP(6);
 
         // ---- per-agent epilogue
-        step_epilogue(p, t, n, b, row0, n_real, tid, sm, DG);
+        // (the 16-lanes-per-agent epilogue of the XDL kernels, loads included: sampled actions -- RolloutP::action_eps -- and the
+        // per-call state / action overrides of tb_rollout_step_ex are served by the exact-fp32 kernel as well)
+        step_epilogue16<false>(p, t, n, b, row0, n_real, tid, sm, DG);
         __syncthreads();
     } else {
         wload(u, xlayer_first(W, pw.as2pl[0], wave), lane);

@@ -2,6 +2,21 @@
 // (fp16-pair operands, fp32 accumulate, tb_device_xdl.hpp).  Tiling, global layouts, attention (fp32 MFMA QK / PV with
 // online softmax), LayerNorm, GRU gate math, dynamics and rule checks are those of k_step; GEMM inputs live in LDS as
 // two fp16 planes instead of one fp32 tile.
+#ifdef TB_XDL_AW
+// The assist-wave build (tb_stepx_bf16aw_kernels.hip; tb_device_xdl.hpp "Assist waves"): every barrier of the main waves is
+// counted -- thread 0 adds 1 to LDS word 0 in front of it -- so that a command to the assist waves can name the barrier it is for.
+// (In front of every project header: no __syncthreads() of the step's device code may stay uncounted.)
+#include <hip/hip_runtime.h>
+namespace tb {
+__device__ __forceinline__ void aw_sync() {
+    extern __shared__ __attribute__((aligned(16))) float smem_all[];
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(reinterpret_cast<unsigned int*>(smem_all), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __syncthreads();
+}
+__device__ __forceinline__ void aw_bare_sync() { __syncthreads(); }
+}  // namespace tb
+#define __syncthreads() ::tb::aw_sync()
+#endif
 #include "tb_rollout.hpp"
 #include "tb_device_xdl.hpp"
 #include "tb_step_common.hpp"
@@ -38,6 +53,12 @@ constexpr bool W3 = true;
 constexpr bool W3 = false;
 #endif
 
+#ifdef TB_XDL_AW
+constexpr bool AWB = true;   // this translation unit builds the eight-wave kernel only
+#else
+constexpr bool AWB = false;
+#endif
+
 constexpr bool XL_DG_GLOBAL = NPL == 2;
 constexpr int XL_DG = W3 ? XO_H1 : XO_GP;
 constexpr int XL_SMALL = XL_DG + (XL_DG_GLOBAL ? 0 : TM * 80);
@@ -47,7 +68,7 @@ constexpr int STEPX_LEAN_LDS_FLOATS = XL_PL + 4 * PLANES_FLOATS;
 static_assert(XL_PL % 4 == 0, "plane buffers must be 16-byte aligned");
 static_assert(XO_PL % 4 == 0, "plane buffers must be 16-byte aligned");
 static_assert(NPL * PLANEC * 2 <= 2 * PLANES_BYTES, "concat planes must fit two plane buffers");
-static_assert(STEPX_LDS_FLOATS * 4 <= 160 * 1024, "LDS budget");
+static_assert((STEPX_LDS_FLOATS + AW_PREFIX) * 4 <= 160 * 1024, "LDS budget");
 
 // add_goal / add_latent fusion MLP (add_latent_goal.py:57-77): h = relu(W2 relu(W1 [x ; u] + b1) + b2), u = relu(mask(pre)).
 // u does not change during a rollout (only its mask does), so its half of the first Linear is hoisted: k_fuse_hoist_x leaves
@@ -98,7 +119,7 @@ __device__ __forceinline__ void fuse_latent_goal_x(const float* __restrict__ W, 
     __syncthreads();
 }
 
-#ifndef TB_XDL_W3
+#if !defined(TB_XDL_W3) && !defined(TB_XDL_AW)
 // Rollout prologue: goal_pre / lat_pre (pre-activations of add_goal / add_latent's mlp_in, k_rollout_init) -> the hoisted half of
 // the fusion MLPs' first Linear, in place: PRE <- W1[:, 128:256] relu(PRE)  (no bias: b1 rides with the x half).  grid (a_pad/16, N)
 __global__ __launch_bounds__(NTHREADS) void k_fuse_hoist_x(RolloutP p) {
@@ -136,17 +157,76 @@ void launch_fuse_hoist_x(const RolloutP& p, hipStream_t s) {
     hipLaunchKernelGGL(k_fuse_hoist_x, grid, dim3(NTHREADS), TM * LDT * sizeof(float) + PLANES_BYTES, s, p);
 }
 
-#endif  // !TB_XDL_W3
+#endif  // !TB_XDL_W3 && !TB_XDL_AW
 
 // PRE = the batched warm start (RolloutP::pre_mode): A half only, inputs from the ground truth, grid.z = steps
+#ifdef TB_XDL_AW
+// The assist waves of a step workgroup (threads 256 .. 511; tb_device_xdl.hpp "Assist waves"): loop on the workgroup barrier, count,
+// and when the main waves' posted barrier number comes up take the odd key blocks of that map-attention layer.
+__device__ __forceinline__ void aw_assist_waves(const RolloutP& p, int do_a, const xhalf* PA) {
+    const int tid = (int)threadIdx.x - NTHREADS, wave = wave_of(tid), lane = tid & 63;
+    int n, rt;
+    step_tile_map(n, rt);
+    const int b = n / p.k_rep, n_rt = gridDim.x;
+    const float* W = p.W;
+    const volatile unsigned int* aw = aw_words();
+    WUnitX u;
+    if (do_a) wloadx(u, xlayer_first_x(W, p.pw.as2pl[0], p.px.as2pl[0], wave), lane);  // (held while the C half runs)
+    const int nk_p = do_a ? max(32, p.nkey_pl[b]) : 32;
+    const int ks_p = ((rt * (nk_p >> 5)) / n_rt) << 5;
+    const float* kvd = p.kbias_pl + (size_t)b * p.p_pad;
+    const size_t ls = (size_t)p.p_pad * H;
+    const xhalf* K0 = reinterpret_cast<const xhalf*>(p.kpl + ((size_t)b * 3) * ls);
+    const xhalf* V0 = reinterpret_cast<const xhalf*>(p.vtpl + ((size_t)b * 3) * ls);
+    unsigned int n_seen = 0u;
+    for (;;) {
+        aw_bare_sync();
+        // (a step has ~200 barriers: the bound turns any mismatch between the two counts into wrong numbers instead of four waves
+        // that spin on the barrier among themselves after the main waves have left)
+        if (++n_seen > 8192u) return;
+        if (aw[1] != n_seen) continue;
+        const unsigned int op = aw[2];
+        if (op > 2u) return;
+#ifdef TB_AW_DEBUG  // timing experiments (wrong results): TB_DEBUG_HELPER_DELAY bit 0 = no priority, bit 1 = the assist waves skip their blocks
+        if (!(p.dbg_helper_delay & 1)) __builtin_amdgcn_s_setprio(1);
+        aw_assist_layer_x(u, PA, K0 + 2 * op * ls, V0 + 2 * op * ls, kvd, (p.dbg_helper_delay & 2) ? 32 : nk_p, ks_p, wave, lane);
+#else
+        __builtin_amdgcn_s_setprio(1);
+        aw_assist_layer_x(u, PA, K0 + 2 * op * ls, V0 + 2 * op * ls, kvd, nk_p, ks_p, wave, lane);
+#endif
+        __builtin_amdgcn_s_setprio(0);
+        if (op < 2u) {
+            if (op == 0u) wloadx(u, xlayer_first_x(W, p.pw.as2pl[1], p.px.as2pl[1], wave), lane);
+            else wloadx(u, xlayer_first_x(W, p.pw.as2pl[2], p.px.as2pl[2], wave), lane);
+        }
+        aw_bare_sync();  // publishes the state (the main waves' merge barrier)
+        ++n_seen;
+    }
+}
+#endif
+
 template <bool PRE, bool LEAN = false>
-__global__ __launch_bounds__(NTHREADS, LEAN ? (W3 ? 3 : 2) : 1) void k_step_x(RolloutP p, int t, int do_c, int do_a) {
+__global__ __launch_bounds__(AWB ? 2 * NTHREADS : NTHREADS, LEAN ? (W3 ? 3 : 2) : 1) void k_step_x(RolloutP p, int t, int do_c, int do_a) {
     static_assert(!W3 || LEAN, "the W3 build holds the LEAN carve only");
+    static_assert(!AWB || (!PRE && !LEAN), "the assist-wave build holds the full carve of the step launch only");
     if (PRE) {
         do_c = 0;
         do_a = 1;
     }
-    extern __shared__ __attribute__((aligned(16))) float smem[];
+    extern __shared__ __attribute__((aligned(16))) float smem_all[];
+    float* const smem = smem_all + AW_PREFIX;
+#ifdef TB_XDL_AW
+    if (threadIdx.x == 0) {  // barrier count and "no command"
+        unsigned int* w = aw_words();
+        w[0] = 0u;
+        w[1] = 0u;
+        w[2] = AW_OP_EXIT;
+    }
+    if (threadIdx.x >= NTHREADS) {
+        aw_assist_waves(p, do_a, reinterpret_cast<const xhalf*>(smem + XO_PL));
+        return;
+    }
+#endif
     float* X = smem + XO_X;
     float* Hs = smem + XO_H;
     float* H1 = W3 ? nullptr : smem + XO_H1;   // (W3: no LDS copies of the hidden state; Hs is the action head's scratch tile)
@@ -186,7 +266,7 @@ __global__ __launch_bounds__(NTHREADS, LEAN ? (W3 ? 3 : 2) : 1) void k_step_x(Ro
     // staggered start of the key walks of the row tiles of one instance (attention_prefetch_x)
     const int n_rt = gridDim.x;
     const int tile_id = n * n_rt + rt;
-    const bool helpers = !W3 && !PRE && gridDim.z == 2;
+    const bool helpers = !W3 && !AWB && !PRE && gridDim.z == 2;
     if (helpers && blockIdx.z == 0) {
         // ---- helper of tile (n, rt) (RolloutP::gh): interaction K / V of layers 1, 2 of THIS step from the stored x_mid, then
         // W_hh h_{t-1} of the three GRU layers; handed to the tile workgroups (blockIdx.z = 1) through L2
@@ -461,6 +541,10 @@ __global__ __launch_bounds__(NTHREADS, LEAN ? (W3 ? 3 : 2) : 1) void k_step_x(Ro
     }
     TB_STAMP(7);
     if (!do_a) {
+#ifdef TB_XDL_AW
+        if (tid == 0) aw_post(AW_OP_EXIT);
+        __syncthreads();  // (the assist waves leave behind this barrier)
+#endif
         range_flush(amax);
         return;
     }
@@ -484,14 +568,17 @@ __global__ __launch_bounds__(NTHREADS, LEAN ? (W3 ? 3 : 2) : 1) void k_step_x(Ro
         const size_t ls = (size_t)p.p_pad * H;
         const xhalf* K0 = reinterpret_cast<const xhalf*>(p.kpl + ((size_t)b * 3) * ls);
         const xhalf* V0 = reinterpret_cast<const xhalf*>(p.vtpl + ((size_t)b * 3) * ls);
-        xattn_layer_x<!LEAN>(W, pw.as2pl[0], px.as2pl[0], X, PA, PB, K0, V0, kvd, nk_p, ks_p, -1, rowvalid, novalid_s, tid, u,
+        xattn_layer_x<!LEAN, false, true, AWB>(W, pw.as2pl[0], px.as2pl[0], X, PA, PB, K0, V0, kvd, nk_p, ks_p, -1, rowvalid, novalid_s, tid, u,
                             xlayer_first_x(W, pw.as2pl[1], px.as2pl[1], wave), (LEAN ? nullptr : LN + 3 * 768),
-                            p.prof + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 32, amax);
-        xattn_layer_x<!LEAN>(W, pw.as2pl[1], px.as2pl[1], X, PA, PB, K0 + 2 * ls, V0 + 2 * ls, kvd, nk_p, ks_p, -1, rowvalid, novalid_s, tid, u,
-                            xlayer_first_x(W, pw.as2pl[2], px.as2pl[2], wave), (LEAN ? nullptr : LN + 4 * 768), nullptr, amax);
-        xattn_layer_x<!LEAN>(W, pw.as2pl[2], px.as2pl[2], X, PA, PB, K0 + 4 * ls, V0 + 4 * ls, kvd, nk_p, ks_p, -1, rowvalid, novalid_s, tid,
-                            u, xlayer_first_x(W, pw.as2tl[0], px.as2tl[0], wave), (LEAN ? nullptr : LN + 5 * 768), nullptr, amax);
+                            p.prof + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 32, amax, 0);
+        xattn_layer_x<!LEAN, false, true, AWB>(W, pw.as2pl[1], px.as2pl[1], X, PA, PB, K0 + 2 * ls, V0 + 2 * ls, kvd, nk_p, ks_p, -1, rowvalid, novalid_s, tid, u,
+                            xlayer_first_x(W, pw.as2pl[2], px.as2pl[2], wave), (LEAN ? nullptr : LN + 4 * 768), nullptr, amax, 1);
+        xattn_layer_x<!LEAN, false, true, AWB>(W, pw.as2pl[2], px.as2pl[2], X, PA, PB, K0 + 4 * ls, V0 + 4 * ls, kvd, nk_p, ks_p, -1, rowvalid, novalid_s, tid,
+                            u, xlayer_first_x(W, pw.as2tl[0], px.as2tl[0], wave), (LEAN ? nullptr : LN + 5 * 768), nullptr, amax, 2);
     }
+#ifdef TB_XDL_AW
+    if (tid == 0) aw_post(AW_OP_EXIT);  // the assist waves leave behind the next barrier (the first one of the traffic-light block)
+#endif
     TB_STAMP(9);
     if (tl_empty) {
         // (the Q unit requested above is dropped; one exposed unit load here keeps the common path free of any select)
@@ -530,7 +617,9 @@ __global__ __launch_bounds__(NTHREADS, LEAN ? (W3 ? 3 : 2) : 1) void k_step_x(Ro
     range_flush(amax);
 }
 
-#ifdef TB_XDL_W3
+#ifdef TB_XDL_AW
+template __global__ void k_step_x<false, false>(RolloutP, int, int, int);
+#elif defined(TB_XDL_W3)
 template __global__ void k_step_x<false, true>(RolloutP, int, int, int);
 template __global__ void k_step_x<true, true>(RolloutP, int, int, int);
 #else
@@ -541,7 +630,7 @@ template __global__ void k_step_x<true, true>(RolloutP, int, int, int);
 
 #endif
 
-#ifndef TB_XDL_W3
+#if !defined(TB_XDL_W3) && !defined(TB_XDL_AW)
 // K/V of the three layers of a cross-attention block for fixed targets (map polylines, TL stop points), in the XDL operand
 // order (tb_device_xdl.hpp): the fp16-pair twin of k_kv_hoist.  grid = (n_pad/16, G)
 // The VALID targets of a group are compacted to the front (softmax is order independent): nkey[g] = their count rounded up to a
@@ -609,7 +698,7 @@ void launch_kv_hoist_x(const float* W, const XLayerW* L3, const XLayerX* X3, con
     hipLaunchKernelGGL(k_kv_hoist_x, grid, dim3(NTHREADS), TM * LDT * sizeof(float) + PLANES_BYTES, s, W, L3[0], L3[1], L3[2], X3[0],
                        X3[1], X3[2], feat, fvalid, n_tok, n_pad, K, VT, kbias, nkey);
 }
-#endif  // !TB_XDL_W3
+#endif  // !TB_XDL_W3 && !TB_XDL_AW
 
 // fp16-pair range flag of THIS translation unit (tb_device_xdl.hpp): OR it into *out and clear it (tb_check_status)
 #ifndef TB_XDL_BF16
@@ -620,7 +709,23 @@ __global__ void k_range_flag_take_step(unsigned int* out) {
 void launch_range_flag_take_step(unsigned int* out, hipStream_t s) { hipLaunchKernelGGL(k_range_flag_take_step, dim3(1), dim3(1), 0, s, out); }
 #endif
 
-#ifdef TB_XDL_W3
+#ifdef TB_XDL_AW
+hipError_t configure_stepx_kernel() {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(k_step_x<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)((STEPX_LDS_FLOATS + AW_PREFIX) * sizeof(float)));
+}
+
+// (the caller -- tb_api.hip: step_launch -- picks this build for bf16 launches of 129 .. 256 tiles that run an A half over >= 512 map
+// polylines: one workgroup per CU, no helper workgroups, long key walks)
+void launch_step_x(const RolloutP& p0, int t, int do_c, int do_a, hipStream_t s) {
+    RolloutP p = p0;
+    p.gh_flag = nullptr;
+    dim3 grid(p.a_pad / TM, p.n_inst, 1);
+    hipLaunchKernelGGL((k_step_x<false, false>), grid, dim3(2 * NTHREADS), (STEPX_LDS_FLOATS + AW_PREFIX) * sizeof(float), s, p, t, do_c, do_a);
+}
+}  // namespace TB_XNS
+}  // namespace tb
+#elif defined(TB_XDL_W3)
 hipError_t configure_stepx_kernel() {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_step_x<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)(STEPX_LEAN_LDS_FLOATS * sizeof(float)));
@@ -668,6 +773,7 @@ void launch_step_x(const RolloutP& p0, int t, int do_c, int do_a, hipStream_t s)
 
 #endif  // TB_XDL_W3
 
+#ifndef TB_XDL_AW
 // slices of future 0 of every scene -> futures 1 .. K-1 (x_mid rows, K and V of the three layers).  grid (n_pre * n_scene * (K - 1))
 __global__ __launch_bounds__(256) void k_pre_replicate(RolloutP p, int n_pre) {
     const int km1 = p.k_rep - 1;
@@ -720,3 +826,4 @@ void launch_step_pre_x(const RolloutP& p0, int t0, int n, hipStream_t s) {
 
 }  // namespace TB_XNS
 }  // namespace tb
+#endif  // !TB_XDL_AW

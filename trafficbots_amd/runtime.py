@@ -752,6 +752,8 @@ class HipEngine:
         raises (default) or, with `raise_on_range=False`, returns True so that the caller can re-issue them.  Hard errors (a helper
         hand-off time-out) always raise."""
         rc = self.lib.tb_check_status(self._ctx, self._stream())
+        if rc == 3:
+            self._step_open = False  # the library closed an open stepwise rollout when it switched kernels (tb_api.hip)
         if rc == 3 and not raise_on_range:
             return True
         self._check(rc, "tb_check_status")
