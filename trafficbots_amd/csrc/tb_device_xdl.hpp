@@ -698,83 +698,258 @@ struct AttnPartX {
     float m, s;    // running max (log2 units; uniform over the four lanes of a row) and this lane's share of the running sum
 };
 
-#ifdef TB_XDL_AW
-// The key walk of attention_head_x restricted to the blocks of sequence index s0, s0 + 2, ... (sequence index s = key block
-// kwrap(kstart + 32 s)): `kfirst` = first key of this wave's first block, `nblk` = how many blocks it takes (may be 0).
-// pre: k0f / vc = the first block, kn = the second one (kfirst + 64, wrapped).  Single-plane (bf16) operands only.
-__device__ __forceinline__ void attention_walk2_x(const xh8& qh, AttnPreX& pre, const xhalf* __restrict__ Kh, const xhalf* __restrict__ Vh,
-                                                  const float* __restrict__ keybias, int n_key_pad, int kfirst, int nblk, int head,
-                                                  int lane, AttnPartX& out) {
-    static_assert(NPL == 1, "assist waves exist in the bf16 build only");
+#ifdef TB_XDL_BF16
+// ---------------------------------------------------------------------------------------------
+// The key walk of the bf16 builds (round 5): the online softmax with a LAZY reference exponent.  With two or three waves per SIMD
+// (assist waves, the W3 carve) the walk is bound by VALU issue -- ~75 vector instructions per 32-key block, of which ~30 serve the
+// running maximum: two cross-lane reductions with their wait states, the correction factor, the rescale of eight accumulators and
+// of the running sum -- although the maximum moves in a handful of blocks only.  Here a row keeps a REFERENCE exponent `ref`
+// (uniform over its four lanes) that is moved only when a block holds a logit above ref + 8 (wave-uniform branch on a ballot):
+// p = 2^(logit - ref) may then reach 2^8, which bf16 / fp32 hold as well as values below 1, and the normalisation by the running sum
+// takes it out again.  The valid keys of a group sit in front of the masked ones (the hoist compacts them), so a walk is a run of
+// FULL blocks (no key bias: no loads for it, the scale folds into the exponent, p = 2^(fma(raw, c, -ref))) plus at most one block
+// with masked keys, which is taken LAST: the loop over the full blocks is straight-line code (~36 vector instructions per block)
+// apart from the reference update, the last two or three blocks go through a general step.  Mathematically the softmax of
+// attention_head_x; other roundings and another summation order (no bit-parity claim exists for bf16 operands).
+//   A wave's blocks (LeanSeq): nF full blocks at kwrap(k0 + 32 STEP j, R), then the partial block at kP (if kP >= 0).
+//   STEP = 1: every block of the group;  2: every other one (assist waves: the main wave takes the even full blocks, the assist
+//   wave the odd ones and the partial block).
+// ---------------------------------------------------------------------------------------------
+constexpr float LEAN_THR = 8.0f;
+constexpr float LEAN_SC = ATTN_SCALE * 1.44269504088896340736f;
+
+struct LeanSeq {
+    int R;    // keys of the group's full blocks (a multiple of 32)
+    int k0;   // first key of this wave's first full block
+    int nF;   // number of full blocks this wave takes
+    int kP;   // first key of the block with masked keys if this wave takes it, else -1
+};
+// n_key_pad = the group's keys rounded up to whole blocks (at least one block), n_valid = its valid keys; kstart = where the walk
+// of this workgroup starts (any multiple of 32 below n_key_pad; row tiles of an instance start apart).  part: 0 = the whole walk,
+// 1 = the main wave's half, 2 = the assist wave's half.
+__device__ __forceinline__ LeanSeq lean_seq(int n_key_pad, int n_valid, int kstart, int part) {
+    const int nb = n_key_pad >> 5;
+    const int nFt = min(n_valid >> 5, nb);
+    LeanSeq q;
+    q.R = nFt << 5;
+    const int ks = kstart < q.R ? kstart : 0;
+    const bool hasP = nFt < nb;
+    if (part == 0) {
+        q.k0 = ks; q.nF = nFt; q.kP = hasP ? q.R : -1;
+    } else if (part == 1) {
+        q.k0 = ks; q.nF = (nFt + 1) >> 1; q.kP = -1;
+    } else {
+        q.k0 = kwrap(ks + 32, max(q.R, 32)); q.nF = nFt >> 1; q.kP = hasP ? q.R : -1;
+    }
+    return q;
+}
+template <int STEP>
+__device__ __forceinline__ int lean_addr(const LeanSeq& q, int j) { return j < q.nF ? kwrap(q.k0 + 32 * STEP * j, q.R) : q.kP; }
+__device__ __forceinline__ int lean_count(const LeanSeq& q) { return q.nF + (q.kP >= 0 ? 1 : 0); }
+
+// K fragments of a block / its key bias (read only when the block has masked keys)
+__device__ __forceinline__ void k_load_lean_x(KFragX& f, const xhalf* __restrict__ kfb, int k0) {
+    const xhalf* p = kfb + (size_t)(k0 >> 5) * KV_BLOCK_HALFS;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) f.ka[t][0] = *reinterpret_cast<const xh8*>(p + t * 512);
+}
+__device__ __forceinline__ void kb_load_lean_x(KFragX& f, const float* __restrict__ bbase, int k0) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) f.kb[t] = ldg4(bbase + k0 + 16 * t);
+}
+
+__device__ __forceinline__ float max8_x(const float (&r)[8]) {
+    return fmaxf(fmaxf(fmaxf(r[0], r[1]), fmaxf(r[2], r[3])), fmaxf(fmaxf(r[4], r[5]), fmaxf(r[6], r[7])));
+}
+
+// State of a walk.  The logits of a block are kept RELATIVE to the row's reference exponent (v = logit - ref, log2 units): the
+// exponentials take them as they are, "a logit more than 2^8 above the reference" is a compare with a constant, and the maximum is
+// taken over fma results (on raw MFMA results the compiler would first canonicalise each input: one v_max x, x apiece).
+struct LeanState {
+    f32x4 oh[2];
+    float nref;      // - reference exponent (uniform over the four lanes of a row)
+    float run_sum;   // this lane's share of the sum of p
+};
+
+// the reference moves by d >= 0 where a block's largest relative logit `lm` exceeds 8
+__device__ __forceinline__ void lean_ref_x(float lm, float (&v)[8], LeanState& st) {
+    if (__builtin_amdgcn_ballot_w64(lm > LEAN_THR) != 0ull) {  // (wave-uniform; rows that do not move get d = 0: factors of exactly 1)
+        const float d = fmaxf(rows_max(lm), 0.f);
+        const float alpha = exp2_neg(-d);
+        st.oh[0] *= splat(alpha);
+        st.oh[1] *= splat(alpha);
+        st.run_sum *= alpha;
+        st.nref -= d;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] -= d;
+    }
+}
+// logits of a FULL block (no key bias), relative to the reference
+__device__ __forceinline__ void lean_stats_full_x(const f32x4 (&s)[2], float (&v)[8], LeanState& st) {
+    const float raw[8] = {s[0].x, s[0].y, s[0].z, s[0].w, s[1].x, s[1].y, s[1].z, s[1].w};
+#pragma unroll
+    for (int r = 0; r < 8; ++r) v[r] = fmaf(raw[r], LEAN_SC, st.nref);
+    lean_ref_x(max8_x(v), v, st);
+}
+// logits of a block with masked keys
+__device__ __forceinline__ void lean_stats_part_x(const f32x4 (&s)[2], const f32x4 (&kb)[2], float (&v)[8], LeanState& st) {
+    const float raw[8] = {s[0].x, s[0].y, s[0].z, s[0].w, s[1].x, s[1].y, s[1].z, s[1].w};
+    const float bias[8] = {kb[0].x, kb[0].y, kb[0].z, kb[0].w, kb[1].x, kb[1].y, kb[1].z, kb[1].w};
+#pragma unroll
+    for (int r = 0; r < 8; ++r) v[r] = fmaf(raw[r], LEAN_SC, bias[r]) + st.nref;
+    lean_ref_x(max8_x(v), v, st);
+}
+// the first block of a walk sets the reference: its row maximum (a finite stand-in when every key of the block is masked: then
+// every p of the block is 2^-inf = 0)
+__device__ __forceinline__ void lean_stats_first_x(const f32x4 (&s)[2], const f32x4 (&kb)[2], bool part, float (&v)[8], LeanState& st) {
+    const float raw[8] = {s[0].x, s[0].y, s[0].z, s[0].w, s[1].x, s[1].y, s[1].z, s[1].w};
+    if (part) {
+        const float bias[8] = {kb[0].x, kb[0].y, kb[0].z, kb[0].w, kb[1].x, kb[1].y, kb[1].z, kb[1].w};
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] = fmaf(raw[r], LEAN_SC, bias[r]);
+    } else {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] = raw[r] * LEAN_SC;
+    }
+    const float ref = fmaxf(rows_max(max8_x(v)), RUN_MAX_NONE);
+    st.nref = -ref;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) v[r] -= ref;
+}
+// exponentials of the current block -> running sum, P^T as a B operand
+__device__ __forceinline__ xh8 lean_exp_x(const float (&v)[8], LeanState& st) {
+    float p[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) p[r] = exp2_neg(v[r]);
+    st.run_sum += ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
+    xh8 ph, pl;
+    split8<false>(f32x4{p[0], p[1], p[2], p[3]}, f32x4{p[4], p[5], p[6], p[7]}, ph, pl);
+    return ph;
+}
+
+// One step in the run of full blocks: exponentials and P V of block j (full; `vcur` from the previous step), Q K and statistics of
+// block j + 1 (full) -> `vnext`, K of block j + 2 (full) and V of block j + 1 requested.  Straight-line code.
+__device__ __forceinline__ void lean_step_full_x(const xh8& qh, const xhalf* kbase, const xhalf* vbase, int k_next, int k_nn,
+                                                 const float (&vcur)[8], float (&vnext)[8], KFragX& kn, VFragX& vc, LeanState& st) {
+    TB_SCHED_FENCE();
+    f32x4 ts[2], tc[2];
+    in_vgpr(st.oh[0]); in_vgpr(st.oh[1]);
+    attn_qk_x(kn, qh, qh, ts, tc);  // QK of the next block (XDL) under the exponentials of this one
+    in_vgpr(ts[0]); in_vgpr(ts[1]);
+    TB_SCHED_FENCE();
+    k_load_lean_x(kn, kbase, k_nn);
+    const xh8 ph = lean_exp_x(vcur, st);
+    TB_SCHED_FENCE();
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) st.oh[dt] = mfma_h(vc.va[dt][0], ph, st.oh[dt]);
+    TB_SCHED_FENCE();
+    v_load_x(vc, vbase, k_next);
+    in_vgpr(st.oh[0]); in_vgpr(st.oh[1]);
+    lean_stats_full_x(ts, vnext, st);
+    TB_SCHED_FENCE();
+}
+
+// The last steps of a walk (at most three): any of "block j has masked keys", "there is a block j + 1 / j + 2", "it has masked keys".
+// `v` holds block j's logits on entry and block j + 1's on exit.
+template <int STEP>
+__device__ __forceinline__ void lean_step_any_x(int j, const LeanSeq& q, const xh8& qh, const xhalf* kbase, const xhalf* vbase,
+                                                const float* bbase, float (&v)[8], KFragX& kn, VFragX& vc, LeanState& st) {
+    const int n_tot = lean_count(q);
+    const bool has_next = j + 1 < n_tot, next_part = j + 1 >= q.nF, has_nn = j + 2 < n_tot, nn_part = j + 2 >= q.nF;
+    f32x4 ts[2] = {splat(0.f), splat(0.f)}, tc[2];
+    TB_SCHED_FENCE();
+    if (has_next) attn_qk_x(kn, qh, qh, ts, tc);
+    const f32x4 nb[2] = {kn.kb[0], kn.kb[1]};
+    TB_SCHED_FENCE();
+    if (has_nn) {
+        k_load_lean_x(kn, kbase, lean_addr<STEP>(q, j + 2));
+        if (nn_part) kb_load_lean_x(kn, bbase, lean_addr<STEP>(q, j + 2));
+    }
+    TB_SCHED_FENCE();
+    const xh8 ph = lean_exp_x(v, st);
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) st.oh[dt] = mfma_h(vc.va[dt][0], ph, st.oh[dt]);
+    TB_SCHED_FENCE();
+    if (has_next) {
+        v_load_x(vc, vbase, lean_addr<STEP>(q, j + 1));
+        if (next_part) lean_stats_part_x(ts, nb, v, st);
+        else lean_stats_full_x(ts, v, st);
+    }
+    TB_SCHED_FENCE();
+}
+
+// prefetch for attention_walk_lean_x: K (+ bias) and V of the wave's first block, K (+ bias) of its second one
+template <int STEP>
+__device__ __forceinline__ void attention_prefetch_lean_x(AttnPreX& a, const xhalf* __restrict__ Kh, const xhalf* __restrict__ Vh,
+                                                          const float* __restrict__ keybias, const LeanSeq& q, int head, int lane) {
     const int kq = lane >> 4;
     const xhalf* kbase = Kh + head * (NPL * 1024) + lane * 8;
     const xhalf* vbase = Vh + head * (NPL * 1024) + lane * 8;
     const float* bbase = keybias + kq * 4;
-    f32x4 oh[2] = {splat(0.f), splat(0.f)};
-    float run_max = RUN_MAX_NONE, run_sum = 0.f, new_max = RUN_MAX_NONE, alpha = 1.f, sv[8];
-    if (nblk > 0) {
+    const int n_tot = lean_count(q);
+    TB_SCHED_FENCE();
+    if (n_tot > 0) {
+        const int a0 = lean_addr<STEP>(q, 0);
+        k_load_lean_x(a.k0f, kbase, a0);
+        if (q.nF == 0) kb_load_lean_x(a.k0f, bbase, a0);
+        v_load_x(a.vc, vbase, a0);
+        if (n_tot > 1) {
+            const int a1 = lean_addr<STEP>(q, 1);
+            k_load_lean_x(a.kn, kbase, a1);
+            if (q.nF <= 1) kb_load_lean_x(a.kn, bbase, a1);
+        }
+    }
+    TB_SCHED_FENCE();
+}
+
+template <int STEP>
+__device__ __forceinline__ void attention_walk_lean_x(const xh8& qh, AttnPreX& pre, const xhalf* __restrict__ Kh, const xhalf* __restrict__ Vh,
+                                                      const float* __restrict__ keybias, const LeanSeq& q, int head, int lane, AttnPartX& out) {
+    const int kq = lane >> 4;
+    const xhalf* kbase = Kh + head * (NPL * 1024) + lane * 8;
+    const xhalf* vbase = Vh + head * (NPL * 1024) + lane * 8;
+    const float* bbase = keybias + kq * 4;
+    LeanState st;
+    st.oh[0] = splat(0.f); st.oh[1] = splat(0.f);
+    st.nref = -RUN_MAX_NONE; st.run_sum = 0.f;
+    const int n_tot = lean_count(q);
+    if (n_tot > 0) {
         KFragX kn = pre.kn;
         VFragX vc = pre.vc;
+        float va[8], vb[8];
         {
             f32x4 s[2], c[2];
             attn_qk_x(pre.k0f, qh, qh, s, c);
-            attn_stats_x<false>(s, c, pre.k0f.kb, kfirst + kq * 4, -1, run_max, sv, new_max, alpha);
+            lean_stats_first_x(s, pre.k0f.kb, q.nF == 0, va, st);
         }
-        int kc = kfirst, k1 = kwrap(kfirst + 64, n_key_pad), k2 = kwrap(k1 + 64, n_key_pad);
-        for (int i = 0; i < nblk; ++i) {
-            const int kn1 = (i + 1 < nblk) ? k1 : kc;
-            const int kld = (i + 2 < nblk) ? k2 : kc;
-            TB_SCHED_FENCE();
-            f32x4 ts[2], tc[2];
-            in_vgpr(oh[0]); in_vgpr(oh[1]);
-            attn_qk_x(kn, qh, qh, ts, tc);
-            in_vgpr(ts[0]); in_vgpr(ts[1]);
-            const f32x4 nb[2] = {kn.kb[0], kn.kb[1]};
-            TB_SCHED_FENCE();
-            k_load_x(kn, kbase, bbase, kld);
-            float p[8];
-#pragma unroll
-            for (int r = 0; r < 8; ++r) p[r] = exp2_neg(sv[r] - new_max);
-            run_sum = run_sum * alpha + (((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7])));
-            run_max = new_max;
-            xh8 ph, pl;
-            split8<false>(f32x4{p[0], p[1], p[2], p[3]}, f32x4{p[4], p[5], p[6], p[7]}, ph, pl);
-#pragma unroll
-            for (int dt = 0; dt < 2; ++dt) oh[dt] *= splat(alpha);
-            TB_SCHED_FENCE();
-#pragma unroll
-            for (int dt = 0; dt < 2; ++dt) oh[dt] = mfma_h(vc.va[dt][0], ph, oh[dt]);
-            TB_SCHED_FENCE();
-            v_load_x(vc, vbase, kn1);
-            in_vgpr(oh[0]); in_vgpr(oh[1]);
-            attn_stats_x<false>(ts, tc, nb, kn1 + kq * 4, -1, run_max, sv, new_max, alpha);  // (unused after the last block)
-            TB_SCHED_FENCE();
-            kc = k1;
-            k1 = k2;
-            k2 = kwrap(k2 + 64, n_key_pad);
+        // steps whose blocks j, j + 1, j + 2 are all full, two per iteration with the logit arrays swapped (the MFMA results of one
+        // block are consumed where they are: no copies across the back edge)
+        int j = 0;
+        for (; j + 3 < q.nF; j += 2) {
+            const int k1 = lean_addr<STEP>(q, j + 1), k2 = lean_addr<STEP>(q, j + 2), k3 = lean_addr<STEP>(q, j + 3);
+            lean_step_full_x(qh, kbase, vbase, k1, k2, va, vb, kn, vc, st);
+            lean_step_full_x(qh, kbase, vbase, k2, k3, vb, va, kn, vc, st);
         }
+        for (; j < n_tot; ++j) lean_step_any_x<STEP>(j, q, qh, kbase, vbase, bbase, va, kn, vc, st);
     }
-    out.o[0] = oh[0];
-    out.o[1] = oh[1];
-    out.m = run_max;
-    out.s = run_sum;
+    out.o[0] = st.oh[0];
+    out.o[1] = st.oh[1];
+    out.m = -st.nref;
+    out.s = st.run_sum;
 }
 
-// prefetch for attention_walk2_x: the wave's first block (K, V) and its second block (K)
-__device__ __forceinline__ void attention_prefetch2_x(AttnPreX& a, const xhalf* __restrict__ Kh, const xhalf* __restrict__ Vh,
-                                                      const float* __restrict__ keybias, int n_key_pad, int kfirst, int nblk, int head,
-                                                      int lane) {
-    const int kq = lane >> 4;
-    const xhalf* kbase = Kh + head * (NPL * 1024) + lane * 8;
-    const xhalf* vbase = Vh + head * (NPL * 1024) + lane * 8;
-    const float* bbase = keybias + kq * 4;
-    TB_SCHED_FENCE();
-    k_load_x(a.k0f, kbase, bbase, kfirst);
-    v_load_x(a.vc, vbase, kfirst);
-    k_load_x(a.kn, kbase, bbase, nblk > 1 ? kwrap(kfirst + 64, n_key_pad) : kfirst);
-    TB_SCHED_FENCE();
+// one state -> the normalised attention output
+__device__ __forceinline__ bool attention_finish_lean_x(const AttnPartX& a, f32x4 (&o)[2]) {
+    const float s = rows_sum(a.s);
+    const bool novalid = !(s > 0.f);
+    const float inv = novalid ? 0.f : 1.0f / s;
+    o[0] = a.o[0] * splat(inv);
+    o[1] = a.o[1] * splat(inv);
+    return novalid;
 }
+#endif  // TB_XDL_BF16
 
+#ifdef TB_XDL_AW
 // two partial states of one row set -> the normalised attention output (merged in the order main, assist)
 __device__ __forceinline__ bool attention_merge2_x(const AttnPartX& a, const AttnPartX& b, f32x4 (&o)[2]) {
     const float mx = fmaxf(a.m, b.m);
@@ -888,7 +1063,10 @@ __device__ __forceinline__ void xattn_layer_x(const float* __restrict__ W, const
                                               xhalf* P2, const xhalf* __restrict__ Kmat, const xhalf* __restrict__ VT,
                                               const float* __restrict__ keybias, int n_key_pad, int kstart, int self_key0,
                                               const uint8_t* rowvalid, uint8_t* novalid_s, int tid, WUnitX& u, const WNextX& nxt,
-                                              const float* lnblk = nullptr, long long* prof = nullptr, R&& amax = R{}, int aw_op = 0) {
+                                              const float* lnblk = nullptr, long long* prof = nullptr, R&& amax = R{}, int aw_op = 0,
+                                              int n_valid_keys = -1) {
+    // n_valid_keys (bf16 builds, attention_walk_lean_x; required there unless SELFMASK): the group's count of valid keys -- they sit in
+    // front of the masked ones and n_key_pad is that count rounded up to whole blocks (at least one block)
     if (!LNLDS) lnblk = W + L.ln1_g;
 #ifdef TB_XDL_AW
     if (AW && tid == 0) aw_post((unsigned int)aw_op);
@@ -924,8 +1102,8 @@ __device__ __forceinline__ void xattn_layer_x(const float* __restrict__ W, const
         k_load_x(apre.kn, Kmat + wave * (NPL * 1024) + lane * 8, keybias + kq * 4, n_key_pad > 32 ? kwrap(kstart + 32, n_key_pad) : kstart);
         TB_SCHED_FENCE();
     } else {
-#ifdef TB_XDL_AW
-        if (AW) attention_prefetch2_x(apre, Kmat, VT, keybias, n_key_pad, kstart, ((n_key_pad >> 5) + 1) >> 1, wave, lane);
+#ifdef TB_XDL_BF16
+        if (!SELFMASK) attention_prefetch_lean_x<AW ? 2 : 1>(apre, Kmat, VT, keybias, lean_seq(n_key_pad, n_valid_keys, kstart, AW ? 1 : 0), wave, lane);
         else
 #endif
         attention_prefetch_x(apre, Kmat, VT, keybias, n_key_pad, kstart, wave, lane);
@@ -938,13 +1116,15 @@ __device__ __forceinline__ void xattn_layer_x(const float* __restrict__ W, const
     TB_XSTAMP(18);
     f32x4 o[2];
     bool novalid;
+#ifdef TB_XDL_BF16
+    static_assert(WO_EARLY || SELFMASK, "the lean walk of the bf16 builds issues no weight request from inside the walk");
 #ifdef TB_XDL_AW
     if (AW) {
         // this wave: block sequence indices 0, 2, 4, ...; the assist wave on the same SIMD: 1, 3, 5, ... (aw_assist_layer_x)
         xh8 qh, ql;
         split8(q[0], q[1], qh, ql, amax);
         AttnPartX mine, theirs;
-        attention_walk2_x(qh, apre, Kmat, VT, keybias, n_key_pad, kstart, ((n_key_pad >> 5) + 1) >> 1, wave, lane, mine);
+        attention_walk_lean_x<2>(qh, apre, Kmat, VT, keybias, lean_seq(n_key_pad, n_valid_keys, kstart, 1), wave, lane, mine);
         TB_XSTAMP(25);
         __syncthreads();  // the assist waves have written their states
         const float* ps = aw_part(wave, lane);
@@ -953,6 +1133,14 @@ __device__ __forceinline__ void xattn_layer_x(const float* __restrict__ W, const
         theirs.m = ps[8];
         theirs.s = ps[9];
         novalid = attention_merge2_x(mine, theirs, o);
+    } else
+#endif
+    if (!SELFMASK) {
+        xh8 qh, ql;
+        split8(q[0], q[1], qh, ql, amax);
+        AttnPartX st;
+        attention_walk_lean_x<1>(qh, apre, Kmat, VT, keybias, lean_seq(n_key_pad, n_valid_keys, kstart, 0), wave, lane, st);
+        novalid = attention_finish_lean_x(st, o);
     } else
 #endif
     novalid = attention_head_x<SELFMASK, !WO_EARLY>(q, apre, Kmat, VT, keybias, n_key_pad, kstart, wave, lane,
@@ -1006,20 +1194,17 @@ __device__ __forceinline__ void xattn_layer_x(const float* __restrict__ W, const
 // Assist wave `wave` (0..3 = the head / the main wave it shares a SIMD with) for one map-attention layer, entered right behind
 // the layer's LayerNorm barrier: the same Q projection from the same planes (the wave's own copy of the weight unit, `u`: loaded
 // while it waited), the odd key blocks, its state to LDS.  The caller runs the barrier that publishes the state.
-__device__ __forceinline__ void aw_assist_layer_x(const WUnitX& u, const xhalf* P1, const xhalf* __restrict__ Kmat, const xhalf* __restrict__ VT,
-                                                  const float* __restrict__ keybias, int n_key_pad, int kstart, int wave, int lane) {
+// `apre`: the K / V fragments of the wave's first two blocks, requested while it waited as well (attention_prefetch_lean_x<2>).
+__device__ __forceinline__ void aw_assist_layer_x(const WUnitX& u, AttnPreX& apre, const xhalf* P1, const xhalf* __restrict__ Kmat,
+                                                  const xhalf* __restrict__ VT, const float* __restrict__ keybias, const LeanSeq& sq, int wave,
+                                                  int lane) {
     const int kq = lane >> 4, m = lane & 15;
-    const int nb = n_key_pad >> 5;
-    const int nblk = nb >> 1;
-    const int kfirst = kwrap(kstart + 32, n_key_pad);
-    AttnPreX apre;
-    attention_prefetch2_x(apre, Kmat, VT, keybias, n_key_pad, kfirst, nblk, wave, lane);
     f32x4 q[2] = {u.b[0], u.b[1]};
     wmmax(q[0], q[1], u, P1 + m * LDP + kq * 8, PLANE);
     xh8 qh, ql;
     split8<false>(q[0], q[1], qh, ql);
     AttnPartX st;
-    attention_walk2_x(qh, apre, Kmat, VT, keybias, n_key_pad, kfirst, nblk, wave, lane, st);
+    attention_walk_lean_x<2>(qh, apre, Kmat, VT, keybias, sq, wave, lane, st);
     float* ps = aw_part(wave, lane);
     st4(ps, st.o[0]);
     st4(ps + 4, st.o[1]);

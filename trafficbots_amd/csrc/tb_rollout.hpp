@@ -43,6 +43,10 @@ struct PolicyWX {
     uint32_t head_w1[3];
 };
 
+// RolloutP::nkey_pl / nkey_tl entries (written by k_kv_hoist_x)
+__host__ __device__ inline int nkey_walk(int packed) { return packed & 0xFFFF; }
+__host__ __device__ inline int nkey_valid(int packed) { return packed >> 16; }
+
 struct RolloutP {
     const float* W;  // weight arena
     PolicyW pw;
@@ -56,7 +60,8 @@ struct RolloutP {
     // hoisted keys/values
     float* kpl;                   // [B,3,p_pad,128]
     float* vtpl;                  // [B,3,128,p_pad]
-    int* nkey_pl;                 // [B]      keys the XDL step kernel walks per scene (valid polylines compacted, whole blocks)
+    int* nkey_pl;                 // [B]      keys the XDL step kernel walks per scene (valid polylines compacted, whole blocks) in the low
+                                  //          16 bits, the exact count of valid keys in the high 16 (nkey_walk / nkey_valid)
     int* nkey_tl;                 // [B*NH]   likewise per (scene, traffic-light step)
     float* kbias_pl;              // [B,p_pad]   additive key mask: 0 valid, -inf invalid / padding
     float* ktl;                   // [B*NH,3,t_pad,128]

@@ -172,12 +172,22 @@ __device__ __forceinline__ void aw_assist_waves(const RolloutP& p, int do_a, con
     const volatile unsigned int* aw = aw_words();
     WUnitX u;
     if (do_a) wloadx(u, xlayer_first_x(W, p.pw.as2pl[0], p.px.as2pl[0], wave), lane);  // (held while the C half runs)
-    const int nk_p = do_a ? max(32, p.nkey_pl[b]) : 32;
+    const int nkw_p = do_a ? p.nkey_pl[b] : 0;
+    const int nk_p = max(32, nkey_walk(nkw_p)), nv_p = nkey_valid(nkw_p);
     const int ks_p = ((rt * (nk_p >> 5)) / n_rt) << 5;
     const float* kvd = p.kbias_pl + (size_t)b * p.p_pad;
     const size_t ls = (size_t)p.p_pad * H;
     const xhalf* K0 = reinterpret_cast<const xhalf*>(p.kpl + ((size_t)b * 3) * ls);
     const xhalf* V0 = reinterpret_cast<const xhalf*>(p.vtpl + ((size_t)b * 3) * ls);
+    // what the wave needs first in a layer -- its copy of the Q unit, the K / V fragments of its first two blocks -- is requested
+    // while it waits for that layer (layer 0: while the C half runs), so that behind the barrier it only reads LDS and computes
+#ifdef TB_AW_DEBUG  // timing experiments (wrong results): TB_DEBUG_HELPER_DELAY bit 0 = no priority, bit 1 = the assist waves skip their blocks
+    const LeanSeq sq = lean_seq((p.dbg_helper_delay & 2) ? 32 : nk_p, (p.dbg_helper_delay & 2) ? 32 : nv_p, ks_p, 2);
+#else
+    const LeanSeq sq = lean_seq(nk_p, nv_p, ks_p, 2);
+#endif
+    AttnPreX apre;
+    if (do_a) attention_prefetch_lean_x<2>(apre, K0, V0, kvd, sq, wave, lane);
     unsigned int n_seen = 0u;
     for (;;) {
         aw_bare_sync();
@@ -187,17 +197,16 @@ __device__ __forceinline__ void aw_assist_waves(const RolloutP& p, int do_a, con
         if (aw[1] != n_seen) continue;
         const unsigned int op = aw[2];
         if (op > 2u) return;
-#ifdef TB_AW_DEBUG  // timing experiments (wrong results): TB_DEBUG_HELPER_DELAY bit 0 = no priority, bit 1 = the assist waves skip their blocks
-        if (!(p.dbg_helper_delay & 1)) __builtin_amdgcn_s_setprio(1);
-        aw_assist_layer_x(u, PA, K0 + 2 * op * ls, V0 + 2 * op * ls, kvd, (p.dbg_helper_delay & 2) ? 32 : nk_p, ks_p, wave, lane);
-#else
-        __builtin_amdgcn_s_setprio(1);
-        aw_assist_layer_x(u, PA, K0 + 2 * op * ls, V0 + 2 * op * ls, kvd, nk_p, ks_p, wave, lane);
+#ifdef TB_AW_DEBUG
+        if (!(p.dbg_helper_delay & 1))
 #endif
+        __builtin_amdgcn_s_setprio(1);
+        aw_assist_layer_x(u, apre, PA, K0 + 2 * op * ls, V0 + 2 * op * ls, kvd, sq, wave, lane);
         __builtin_amdgcn_s_setprio(0);
         if (op < 2u) {
             if (op == 0u) wloadx(u, xlayer_first_x(W, p.pw.as2pl[1], p.px.as2pl[1], wave), lane);
             else wloadx(u, xlayer_first_x(W, p.pw.as2pl[2], p.px.as2pl[2], wave), lane);
+            attention_prefetch_lean_x<2>(apre, K0 + 2 * (op + 1) * ls, V0 + 2 * (op + 1) * ls, kvd, sq, wave, lane);
         }
         aw_bare_sync();  // publishes the state (the main waves' merge barrier)
         ++n_seen;
@@ -559,22 +568,24 @@ __global__ __launch_bounds__(AWB ? 2 * NTHREADS : NTHREADS, LEAN ? (W3 ? 3 : 2) 
     TB_STAMP(8);
     const int g_tl = b * p.n_tl_hist + min(t1 - 1, p.n_tl_hist - 1);
     // no lit traffic light at this step (the hoist counted the valid keys): as2tl keeps only its FFN halves
-    const int nk_t_raw = p.nkey_tl[g_tl];
+    const int nkw_t = p.nkey_tl[g_tl];
+    const int nk_t_raw = nkey_walk(nkw_t), nv_t = nkey_valid(nkw_t);
     const bool tl_empty = nk_t_raw == 0;
     {
         const float* kvd = p.kbias_pl + (size_t)b * p.p_pad;
-        const int nk_p = max(32, p.nkey_pl[b]);  // valid polylines, compacted to the front by the hoist, rounded up to whole key blocks
+        const int nkw_p = p.nkey_pl[b];
+        const int nk_p = max(32, nkey_walk(nkw_p)), nv_p = nkey_valid(nkw_p);  // valid polylines, compacted to the front by the hoist, rounded up to whole key blocks
         const int ks_p = ((rt * (nk_p >> 5)) / n_rt) << 5;
         const size_t ls = (size_t)p.p_pad * H;
         const xhalf* K0 = reinterpret_cast<const xhalf*>(p.kpl + ((size_t)b * 3) * ls);
         const xhalf* V0 = reinterpret_cast<const xhalf*>(p.vtpl + ((size_t)b * 3) * ls);
         xattn_layer_x<!LEAN, false, true, AWB>(W, pw.as2pl[0], px.as2pl[0], X, PA, PB, K0, V0, kvd, nk_p, ks_p, -1, rowvalid, novalid_s, tid, u,
                             xlayer_first_x(W, pw.as2pl[1], px.as2pl[1], wave), (LEAN ? nullptr : LN + 3 * 768),
-                            p.prof + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 32, amax, 0);
+                            p.prof + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 32, amax, 0, nv_p);
         xattn_layer_x<!LEAN, false, true, AWB>(W, pw.as2pl[1], px.as2pl[1], X, PA, PB, K0 + 2 * ls, V0 + 2 * ls, kvd, nk_p, ks_p, -1, rowvalid, novalid_s, tid, u,
-                            xlayer_first_x(W, pw.as2pl[2], px.as2pl[2], wave), (LEAN ? nullptr : LN + 4 * 768), nullptr, amax, 1);
+                            xlayer_first_x(W, pw.as2pl[2], px.as2pl[2], wave), (LEAN ? nullptr : LN + 4 * 768), nullptr, amax, 1, nv_p);
         xattn_layer_x<!LEAN, false, true, AWB>(W, pw.as2pl[2], px.as2pl[2], X, PA, PB, K0 + 4 * ls, V0 + 4 * ls, kvd, nk_p, ks_p, -1, rowvalid, novalid_s, tid,
-                            u, xlayer_first_x(W, pw.as2tl[0], px.as2tl[0], wave), (LEAN ? nullptr : LN + 5 * 768), nullptr, amax, 2);
+                            u, xlayer_first_x(W, pw.as2tl[0], px.as2tl[0], wave), (LEAN ? nullptr : LN + 5 * 768), nullptr, amax, 2, nv_p);
     }
 #ifdef TB_XDL_AW
     if (tid == 0) aw_post(AW_OP_EXIT);  // the assist waves leave behind the next barrier (the first one of the traffic-light block)
@@ -595,11 +606,11 @@ __global__ __launch_bounds__(AWB ? 2 * NTHREADS : NTHREADS, LEAN ? (W3 ? 3 : 2) 
         const xhalf* K0 = reinterpret_cast<const xhalf*>(p.ktl + ((size_t)g_tl * 3) * ls);
         const xhalf* V0 = reinterpret_cast<const xhalf*>(p.vttl + ((size_t)g_tl * 3) * ls);
         xattn_layer_x<!LEAN>(W, pw.as2tl[0], px.as2tl[0], X, PA, PB, K0, V0, kvd, nk_t, ks_t, -1, rowvalid, novalid_s, tid, u,
-                            xlayer_first_x(W, pw.as2tl[1], px.as2tl[1], wave), (LEAN ? nullptr : LN + 6 * 768), nullptr, amax);
+                            xlayer_first_x(W, pw.as2tl[1], px.as2tl[1], wave), (LEAN ? nullptr : LN + 6 * 768), nullptr, amax, 0, nv_t);
         xattn_layer_x<!LEAN>(W, pw.as2tl[1], px.as2tl[1], X, PA, PB, K0 + 2 * ls, V0 + 2 * ls, kvd, nk_t, ks_t, -1, rowvalid, novalid_s, tid, u,
-                            xlayer_first_x(W, pw.as2tl[2], px.as2tl[2], wave), (LEAN ? nullptr : LN + 7 * 768), nullptr, amax);
+                            xlayer_first_x(W, pw.as2tl[2], px.as2tl[2], wave), (LEAN ? nullptr : LN + 7 * 768), nullptr, amax, 0, nv_t);
         xattn_layer_x<!LEAN>(W, pw.as2tl[2], px.as2tl[2], X, PA, PB, K0 + 4 * ls, V0 + 4 * ls, kvd, nk_t, ks_t, -1, rowvalid, novalid_s, tid,
-                            u, wstdx(W, px.inter_kvf[0], W + px.inter_bkvf[0], wave), (LEAN ? nullptr : LN + 8 * 768), nullptr, amax);
+                            u, wstdx(W, px.inter_kvf[0], W + px.inter_bkvf[0], wave), (LEAN ? nullptr : LN + 8 * 768), nullptr, amax, 0, nv_t);
     }
     TB_STAMP(10);
     const size_t zslice = PRE ? (size_t)blockIdx.z * p.n_inst * p.a_pad * H : 0;  // floats per x_mid slice; K / V slices are 3x
@@ -680,7 +691,8 @@ __global__ __launch_bounds__(NTHREADS) void k_kv_hoist_x(const float* __restrict
         slot[tid] = (sl >= 0 && tid < n_real) ? sl + cnt_s[0] : -1;
         kbias[(size_t)g * n_pad + tok0 + tid] = (tok0 + tid < n_valid) ? 0.f : -INFINITY;
     }
-    if (tid == 0 && blockIdx.x == 0) nkey[g] = (n_valid + 31) & ~31;  // 0: the group has no valid target at all
+    // low half: the keys to walk (0: the group has no valid target at all); high half: the exact count of valid keys (nkey_walk / nkey_valid)
+    if (tid == 0 && blockIdx.x == 0) nkey[g] = ((n_valid + 31) & ~31) | (n_valid << 16);
     __syncthreads();
     const size_t ls = (size_t)n_pad * H;  // floats per (group, layer) = fp16 per plane
     xhalf* K0 = reinterpret_cast<xhalf*>(Kout + ((size_t)g * 3) * ls);
