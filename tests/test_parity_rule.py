@@ -1,4 +1,5 @@
-"""CPU tests of the closed-loop acceptance rule (tools/ensemble.py::closed_loop_rule / suite_rule, frozen in round 4) and of the
+"""CPU tests of the closed-loop acceptance rule (tools/ensemble.py::closed_loop_rule / suite_rule: written in round 4, amended once
+AFTER the first measurement -- the quantisation term, see the history there -- and pinned by hash since round 5) and of the
 reference-made ensembles it refers to (tests/golden/ensg/*.npz from tools/gen_golden_ensg.py + tools/channel_perm.py)."""
 import os
 
@@ -9,7 +10,8 @@ from conftest import GOLDEN_DIR, ROOT
 from tools import channel_perm, ensemble
 
 ENSG = ("small_k1", "masks_k3", "degenerate", "headline_2", "headline_k6", "stoch_actions", "action_override", "headline_w_normal",
-        "headline_w_sharp", "headline_w_ln_gamma", "headline_8", "stress_1", "val_small", "val_masks", "val_alt_losses", "val_irrelevant")
+        "headline_w_sharp", "headline_w_ln_gamma", "headline_8", "stress_1", "val_small", "val_masks", "val_alt_losses", "val_irrelevant",
+        "headline_w_trained", "val_trained")
 
 
 @pytest.mark.parametrize("name", ENSG)
@@ -122,3 +124,23 @@ def test_bench_roofline_helpers_say_what_binds():
     lp = bench.load_path(89.7, 64, 256, 32, 4)
     assert 0.3 < lp["frac"] < 0.5 and lp["weights"] == 65 * 128 * 128 * 4
     assert bench.mfma_issue(64, 256, 32, 1) * 3 == n                               # bf16: one MFMA per product
+
+
+def test_the_rule_is_pinned():
+    """VERDICT r04 task 4 (a): the constants and the CODE of the acceptance rule are pinned.  Any edit of `prediction_bound`,
+    `closed_loop_rule` or `suite_rule` (docstrings and comments aside: the hash is over the syntax tree) or of ALPHA / FLOOR / QUANT /
+    SUITE_GEOMEAN_MAX turns this test red and has to be argued where the rule's history is kept (tools/ensemble.py), not slipped in."""
+    import ast
+    import hashlib
+
+    assert (ensemble.ALPHA, ensemble.FLOOR, ensemble.QUANT, ensemble.SUITE_GEOMEAN_MAX) == (1e-3, 1e-4, 2.0 ** -16, 1.5)
+    tree = ast.parse(open(os.path.join(ROOT, "tools", "ensemble.py")).read())
+    h = hashlib.sha256()
+    for fn in tree.body:
+        if isinstance(fn, ast.FunctionDef) and fn.name in ("prediction_bound", "closed_loop_rule", "suite_rule"):
+            for n in ast.walk(fn):  # drop docstrings
+                if isinstance(n, ast.FunctionDef) and n.body and isinstance(n.body[0], ast.Expr) and isinstance(getattr(n.body[0], "value", None), ast.Constant) \
+                        and isinstance(n.body[0].value.value, str):
+                    n.body = n.body[1:] or [ast.Pass()]
+            h.update(ast.dump(fn).encode())
+    assert h.hexdigest() == "11f3cfed4f79c1389c67821550f88ddfc503dfe9c2ae8aa63cf4a0b943136617", h.hexdigest()

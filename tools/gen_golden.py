@@ -117,6 +117,13 @@ CASES["stress_1"] = dict(
     scene=dict(n_agent=128, n_pl=1024, n_tl=40), tap_steps=[], fp64=True, store_feats=False, n_ensg=16,
 )
 
+# VERDICT r04 missing #4: weights with TRAINED statistics -- tests/golden/trained_state_dict.npz, 500 optimizer steps of the reference's
+# own training_step on synthetic episodes (tools/train_reference.py) -- at the headline shape, K = 2, full taps
+CASES["headline_w_trained"] = dict(
+    base_seed=9600, n_scene=1, k=2, weight_file="trained_state_dict.npz", time_step_end=90,
+    scene=dict(n_agent=64, n_pl=256, n_tl=40), tap_steps=[1, 11, 50], fp64=True, store_feats=True,
+)
+
 # members of the measured rounding-noise ensemble (tools/ensemble.py) per closed-loop golden
 N_ENSEMBLE = 32
 ENSEMBLE_CASES = ("small_k1", "masks_k3", "degenerate", "headline_2", "headline_k6", "stoch_actions", "action_override",
@@ -142,7 +149,7 @@ def run_reference(case: dict, dtype=torch.float32, force_goal_sample=None, pertu
     sc = case["scene"]
     torch.set_default_dtype(torch.float32)
     model = ref_shim.build_reference(cfg, n_agent=sc["n_agent"], n_pl=sc["n_pl"], n_tl=sc.get("n_tl", 40))
-    sd = synth.make_state_dict(case["weight_seed"], mode=case.get("weight_mode"))
+    sd = synth.case_state_dict(case)
     if channel_seed is not None:
         import channel_perm
 

@@ -63,6 +63,13 @@ CASES = {
     ),
 }
 
+# the validation step on the trained-statistics weights (tools/train_reference.py; trained on episodes of this kind)
+CASES["val_trained"] = dict(
+    base_seed=16000, n_scene=3, weight_file="trained_state_dict.npz", time_step_end=90, overrides={},
+    scene=dict(n_agent=16, n_pl=48, n_tl=40, p_invalid_agent=0.2, p_late_spawn=0.2, p_invalid_pl=0.1, pos_range=60.0,
+               p_future_spawn=0.3, p_future_exit=0.2), fp64=True,
+)
+
 TRAIN = ("vae_kl_counter", "vae_kl", "diffbar_reward_counter", "diffbar_reward", "goal_loss", "goal_counter")
 ERR = ("err_counter", "err_pos_meter", "err_rot_deg", "err_spd_m_per_s")
 RULE = ("counter_agent", "counter_veh", "outside_map", "collided", "run_road_edge", "run_red_light", "passive", "goal_reached",
@@ -82,7 +89,7 @@ def run_reference(case: dict, dtype=torch.float32, perturb=None, channel_seed=No
     sc = case["scene"]
     torch.set_default_dtype(torch.float32)
     model = ref_shim.build_reference(cfg, n_agent=sc["n_agent"], n_pl=sc["n_pl"], n_tl=sc.get("n_tl", 40))
-    sd = synth.make_state_dict(case["weight_seed"])
+    sd = synth.case_state_dict(case)
     if channel_seed is not None:
         import channel_perm
 

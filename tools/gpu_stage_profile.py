@@ -27,15 +27,18 @@ eng.load_state_dict(sd)
 s = scene_from_batch(batch, dev)
 enc = eng.encode_scene(s)
 feats = {"map_feature": enc["map_feature"], "map_feature_valid": enc["map_feature_valid"], "tl_feature": enc["tl_feature"]}
-z = enc["latent_mean"].clone()
-dest = enc["dest_logits"].argmax(-1).to(torch.int32)
-gv = s["agent_valid"].bool().any(1).to(torch.uint8)
+k = int(os.environ.get("AB_K", 1))  # futures per scene (BASELINE configs[3]: 6)
+z = enc["latent_mean"].repeat_interleave(k, 0).contiguous()
+if k > 1:
+    z = z + 0.3 * torch.from_numpy(synth.make_latent_noise(1, b * k, a)).to(z.device)
+dest = enc["dest_logits"].argmax(-1).to(torch.int32).repeat_interleave(k, 0).contiguous()
+gv = s["agent_valid"].bool().any(1).to(torch.uint8).repeat_interleave(k, 0).contiguous()
 out = None
 for step_end in (90, 50):  # the stamps kept are those of the LAST launch that ran both halves: use step_end-1 ... see below
-    out = eng.rollout(s, feats, z, enc["latent_mean"], dest, gv, 1, step_end)
+    out = eng.rollout(s, feats, z, enc["latent_mean"], dest, gv, k, step_end)
 torch.cuda.synchronize()
 # last launch = C(S) only; stamps 0..7 of it are overwritten, stamps 8..11 are those of the previous (fused) launch
-n_blocks = b * (a // 16)
+n_blocks = b * k * (a // 16)
 buf = (C.c_longlong * (32 * n_blocks))()
 eng.lib.tb_debug_read_prof.argtypes = [C.c_void_p, C.POINTER(C.c_longlong), C.c_int]
 rc = eng.lib.tb_debug_read_prof(eng._ctx, buf, n_blocks)

@@ -698,9 +698,8 @@ struct AttnPartX {
     float m, s;    // running max (log2 units; uniform over the four lanes of a row) and this lane's share of the running sum
 };
 
-#ifdef TB_XDL_BF16
 // ---------------------------------------------------------------------------------------------
-// The key walk of the bf16 builds (round 5): the online softmax with a LAZY reference exponent.  With two or three waves per SIMD
+// The lean key walk (round 5; first built for the bf16 builds, where it is always used; -DTB_LEAN_FP16 = the fp16-pair builds too): the online softmax with a LAZY reference exponent.  With two or three waves per SIMD
 // (assist waves, the W3 carve) the walk is bound by VALU issue -- ~75 vector instructions per 32-key block, of which ~30 serve the
 // running maximum: two cross-lane reductions with their wait states, the correction factor, the rescale of eight accumulators and
 // of the running sum -- although the maximum moves in a handful of blocks only.  Here a row keeps a REFERENCE exponent `ref`
@@ -751,7 +750,9 @@ __device__ __forceinline__ int lean_count(const LeanSeq& q) { return q.nF + (q.k
 __device__ __forceinline__ void k_load_lean_x(KFragX& f, const xhalf* __restrict__ kfb, int k0) {
     const xhalf* p = kfb + (size_t)(k0 >> 5) * KV_BLOCK_HALFS;
 #pragma unroll
-    for (int t = 0; t < 2; ++t) f.ka[t][0] = *reinterpret_cast<const xh8*>(p + t * 512);
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int pl = 0; pl < NPL; ++pl) f.ka[t][pl] = *reinterpret_cast<const xh8*>(p + (pl * 2 + t) * 512);
 }
 __device__ __forceinline__ void kb_load_lean_x(KFragX& f, const float* __restrict__ bbase, int k0) {
 #pragma unroll
@@ -766,7 +767,7 @@ __device__ __forceinline__ float max8_x(const float (&r)[8]) {
 // exponentials take them as they are, "a logit more than 2^8 above the reference" is a compare with a constant, and the maximum is
 // taken over fma results (on raw MFMA results the compiler would first canonicalise each input: one v_max x, x apiece).
 struct LeanState {
-    f32x4 oh[2];
+    f32x4 oh[2], oc[2];   // O^T accumulators: high products / cross products of the fp16 pairs (oc unused with one plane)
     float nref;      // - reference exponent (uniform over the four lanes of a row)
     float run_sum;   // this lane's share of the sum of p
 };
@@ -778,6 +779,10 @@ __device__ __forceinline__ void lean_ref_x(float lm, float (&v)[8], LeanState& s
         const float alpha = exp2_neg(-d);
         st.oh[0] *= splat(alpha);
         st.oh[1] *= splat(alpha);
+        if (NPL == 2) {
+            st.oc[0] *= splat(alpha);
+            st.oc[1] *= splat(alpha);
+        }
         st.run_sum *= alpha;
         st.nref -= d;
 #pragma unroll
@@ -785,15 +790,24 @@ __device__ __forceinline__ void lean_ref_x(float lm, float (&v)[8], LeanState& s
     }
 }
 // logits of a FULL block (no key bias), relative to the reference
-__device__ __forceinline__ void lean_stats_full_x(const f32x4 (&s)[2], float (&v)[8], LeanState& st) {
-    const float raw[8] = {s[0].x, s[0].y, s[0].z, s[0].w, s[1].x, s[1].y, s[1].z, s[1].w};
+// raw scores of a block: high products + 2^-11 cross products (fp16 pairs)
+__device__ __forceinline__ void lean_raw_x(const f32x4 (&s)[2], const f32x4 (&c)[2], float (&raw)[8]) {
+    const float a[8] = {s[0].x, s[0].y, s[0].z, s[0].w, s[1].x, s[1].y, s[1].z, s[1].w};
+    const float b[8] = {c[0].x, c[0].y, c[0].z, c[0].w, c[1].x, c[1].y, c[1].z, c[1].w};
+#pragma unroll
+    for (int r = 0; r < 8; ++r) raw[r] = NPL == 2 ? fmaf(b[r], SPLIT_INV, a[r]) : a[r];
+}
+__device__ __forceinline__ void lean_stats_full_x(const f32x4 (&s)[2], const f32x4 (&c)[2], float (&v)[8], LeanState& st) {
+    float raw[8];
+    lean_raw_x(s, c, raw);
 #pragma unroll
     for (int r = 0; r < 8; ++r) v[r] = fmaf(raw[r], LEAN_SC, st.nref);
     lean_ref_x(max8_x(v), v, st);
 }
 // logits of a block with masked keys
-__device__ __forceinline__ void lean_stats_part_x(const f32x4 (&s)[2], const f32x4 (&kb)[2], float (&v)[8], LeanState& st) {
-    const float raw[8] = {s[0].x, s[0].y, s[0].z, s[0].w, s[1].x, s[1].y, s[1].z, s[1].w};
+__device__ __forceinline__ void lean_stats_part_x(const f32x4 (&s)[2], const f32x4 (&c)[2], const f32x4 (&kb)[2], float (&v)[8], LeanState& st) {
+    float raw[8];
+    lean_raw_x(s, c, raw);
     const float bias[8] = {kb[0].x, kb[0].y, kb[0].z, kb[0].w, kb[1].x, kb[1].y, kb[1].z, kb[1].w};
 #pragma unroll
     for (int r = 0; r < 8; ++r) v[r] = fmaf(raw[r], LEAN_SC, bias[r]) + st.nref;
@@ -801,8 +815,10 @@ __device__ __forceinline__ void lean_stats_part_x(const f32x4 (&s)[2], const f32
 }
 // the first block of a walk sets the reference: its row maximum (a finite stand-in when every key of the block is masked: then
 // every p of the block is 2^-inf = 0)
-__device__ __forceinline__ void lean_stats_first_x(const f32x4 (&s)[2], const f32x4 (&kb)[2], bool part, float (&v)[8], LeanState& st) {
-    const float raw[8] = {s[0].x, s[0].y, s[0].z, s[0].w, s[1].x, s[1].y, s[1].z, s[1].w};
+__device__ __forceinline__ void lean_stats_first_x(const f32x4 (&s)[2], const f32x4 (&c)[2], const f32x4 (&kb)[2], bool part, float (&v)[8],
+                                                   LeanState& st) {
+    float raw[8];
+    lean_raw_x(s, c, raw);
     if (part) {
         const float bias[8] = {kb[0].x, kb[0].y, kb[0].z, kb[0].w, kb[1].x, kb[1].y, kb[1].z, kb[1].w};
 #pragma unroll
@@ -817,48 +833,58 @@ __device__ __forceinline__ void lean_stats_first_x(const f32x4 (&s)[2], const f3
     for (int r = 0; r < 8; ++r) v[r] -= ref;
 }
 // exponentials of the current block -> running sum, P^T as a B operand
-__device__ __forceinline__ xh8 lean_exp_x(const float (&v)[8], LeanState& st) {
+__device__ __forceinline__ void lean_exp_x(const float (&v)[8], LeanState& st, xh8& ph, xh8& pl) {
     float p[8];
 #pragma unroll
     for (int r = 0; r < 8; ++r) p[r] = exp2_neg(v[r]);
     st.run_sum += ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
-    xh8 ph, pl;
-    split8<false>(f32x4{p[0], p[1], p[2], p[3]}, f32x4{p[4], p[5], p[6], p[7]}, ph, pl);
-    return ph;
+    split8<false>(f32x4{p[0], p[1], p[2], p[3]}, f32x4{p[4], p[5], p[6], p[7]}, ph, pl);  // (p <= 2^8: inside the fp16 range)
+}
+// O^T += V^T P^T of the current block
+__device__ __forceinline__ void lean_pv_x(const VFragX& vc, const xh8& ph, const xh8& pl, LeanState& st) {
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) {
+        if (NPL == 2) st.oc[dt] = mfma_h(vc.va[dt][0], pl, st.oc[dt]);
+        st.oh[dt] = mfma_h(vc.va[dt][0], ph, st.oh[dt]);
+        if (NPL == 2) st.oc[dt] = mfma_h(vc.va[dt][P1], ph, st.oc[dt]);
+    }
 }
 
 // One step in the run of full blocks: exponentials and P V of block j (full; `vcur` from the previous step), Q K and statistics of
 // block j + 1 (full) -> `vnext`, K of block j + 2 (full) and V of block j + 1 requested.  Straight-line code.
-__device__ __forceinline__ void lean_step_full_x(const xh8& qh, const xhalf* kbase, const xhalf* vbase, int k_next, int k_nn,
+__device__ __forceinline__ void lean_step_full_x(const xh8& qh, const xh8& ql, const xhalf* kbase, const xhalf* vbase, int k_next, int k_nn,
                                                  const float (&vcur)[8], float (&vnext)[8], KFragX& kn, VFragX& vc, LeanState& st) {
     TB_SCHED_FENCE();
     f32x4 ts[2], tc[2];
     in_vgpr(st.oh[0]); in_vgpr(st.oh[1]);
-    attn_qk_x(kn, qh, qh, ts, tc);  // QK of the next block (XDL) under the exponentials of this one
+    if (NPL == 2) { in_vgpr(st.oc[0]); in_vgpr(st.oc[1]); }
+    attn_qk_x(kn, qh, ql, ts, tc);  // QK of the next block (XDL) under the exponentials of this one
     in_vgpr(ts[0]); in_vgpr(ts[1]);
+    if (NPL == 2) { in_vgpr(tc[0]); in_vgpr(tc[1]); }
     TB_SCHED_FENCE();
     k_load_lean_x(kn, kbase, k_nn);
-    const xh8 ph = lean_exp_x(vcur, st);
+    xh8 ph, pl;
+    lean_exp_x(vcur, st, ph, pl);
     TB_SCHED_FENCE();
-#pragma unroll
-    for (int dt = 0; dt < 2; ++dt) st.oh[dt] = mfma_h(vc.va[dt][0], ph, st.oh[dt]);
+    lean_pv_x(vc, ph, pl, st);
     TB_SCHED_FENCE();
     v_load_x(vc, vbase, k_next);
     in_vgpr(st.oh[0]); in_vgpr(st.oh[1]);
-    lean_stats_full_x(ts, vnext, st);
+    if (NPL == 2) { in_vgpr(st.oc[0]); in_vgpr(st.oc[1]); }
+    lean_stats_full_x(ts, tc, vnext, st);
     TB_SCHED_FENCE();
 }
 
 // The last steps of a walk (at most three): any of "block j has masked keys", "there is a block j + 1 / j + 2", "it has masked keys".
 // `v` holds block j's logits on entry and block j + 1's on exit.
 template <int STEP>
-__device__ __forceinline__ void lean_step_any_x(int j, const LeanSeq& q, const xh8& qh, const xhalf* kbase, const xhalf* vbase,
+__device__ __forceinline__ void lean_step_any_x(int j, const LeanSeq& q, const xh8& qh, const xh8& ql, const xhalf* kbase, const xhalf* vbase,
                                                 const float* bbase, float (&v)[8], KFragX& kn, VFragX& vc, LeanState& st) {
     const int n_tot = lean_count(q);
     const bool has_next = j + 1 < n_tot, next_part = j + 1 >= q.nF, has_nn = j + 2 < n_tot, nn_part = j + 2 >= q.nF;
-    f32x4 ts[2] = {splat(0.f), splat(0.f)}, tc[2];
+    f32x4 ts[2] = {splat(0.f), splat(0.f)}, tc[2] = {splat(0.f), splat(0.f)};
     TB_SCHED_FENCE();
-    if (has_next) attn_qk_x(kn, qh, qh, ts, tc);
+    if (has_next) attn_qk_x(kn, qh, ql, ts, tc);
     const f32x4 nb[2] = {kn.kb[0], kn.kb[1]};
     TB_SCHED_FENCE();
     if (has_nn) {
@@ -866,20 +892,21 @@ __device__ __forceinline__ void lean_step_any_x(int j, const LeanSeq& q, const x
         if (nn_part) kb_load_lean_x(kn, bbase, lean_addr<STEP>(q, j + 2));
     }
     TB_SCHED_FENCE();
-    const xh8 ph = lean_exp_x(v, st);
-#pragma unroll
-    for (int dt = 0; dt < 2; ++dt) st.oh[dt] = mfma_h(vc.va[dt][0], ph, st.oh[dt]);
+    xh8 ph, pl;
+    lean_exp_x(v, st, ph, pl);
+    lean_pv_x(vc, ph, pl, st);
     TB_SCHED_FENCE();
     if (has_next) {
         v_load_x(vc, vbase, lean_addr<STEP>(q, j + 1));
-        if (next_part) lean_stats_part_x(ts, nb, v, st);
-        else lean_stats_full_x(ts, v, st);
+        if (next_part) lean_stats_part_x(ts, tc, nb, v, st);
+        else lean_stats_full_x(ts, tc, v, st);
     }
     TB_SCHED_FENCE();
 }
 
-// prefetch for attention_walk_lean_x: K (+ bias) and V of the wave's first block, K (+ bias) of its second one
-template <int STEP>
+// prefetch for attention_walk_lean_x: K (+ bias) and V of the wave's first block, K (+ bias) of its second one.  PART 1 = the first
+// block's K only, 2 = the rest, 3 = everything (with fp16 pairs the first K goes in front of the LayerNorm, xattn_layer_x)
+template <int STEP, int PART = 3>
 __device__ __forceinline__ void attention_prefetch_lean_x(AttnPreX& a, const xhalf* __restrict__ Kh, const xhalf* __restrict__ Vh,
                                                           const float* __restrict__ keybias, const LeanSeq& q, int head, int lane) {
     const int kq = lane >> 4;
@@ -890,27 +917,33 @@ __device__ __forceinline__ void attention_prefetch_lean_x(AttnPreX& a, const xha
     TB_SCHED_FENCE();
     if (n_tot > 0) {
         const int a0 = lean_addr<STEP>(q, 0);
-        k_load_lean_x(a.k0f, kbase, a0);
-        if (q.nF == 0) kb_load_lean_x(a.k0f, bbase, a0);
-        v_load_x(a.vc, vbase, a0);
-        if (n_tot > 1) {
-            const int a1 = lean_addr<STEP>(q, 1);
-            k_load_lean_x(a.kn, kbase, a1);
-            if (q.nF <= 1) kb_load_lean_x(a.kn, bbase, a1);
+        if (PART & 1) {
+            k_load_lean_x(a.k0f, kbase, a0);
+            if (q.nF == 0) kb_load_lean_x(a.k0f, bbase, a0);
+        }
+        if (PART & 2) {
+            v_load_x(a.vc, vbase, a0);
+            if (n_tot > 1) {
+                const int a1 = lean_addr<STEP>(q, 1);
+                k_load_lean_x(a.kn, kbase, a1);
+                if (q.nF <= 1) kb_load_lean_x(a.kn, bbase, a1);
+            }
         }
     }
     TB_SCHED_FENCE();
 }
 
 template <int STEP>
-__device__ __forceinline__ void attention_walk_lean_x(const xh8& qh, AttnPreX& pre, const xhalf* __restrict__ Kh, const xhalf* __restrict__ Vh,
-                                                      const float* __restrict__ keybias, const LeanSeq& q, int head, int lane, AttnPartX& out) {
+__device__ __forceinline__ void attention_walk_lean_x(const xh8& qh, const xh8& ql, AttnPreX& pre, const xhalf* __restrict__ Kh,
+                                                      const xhalf* __restrict__ Vh, const float* __restrict__ keybias, const LeanSeq& q, int head,
+                                                      int lane, AttnPartX& out) {
     const int kq = lane >> 4;
     const xhalf* kbase = Kh + head * (NPL * 1024) + lane * 8;
     const xhalf* vbase = Vh + head * (NPL * 1024) + lane * 8;
     const float* bbase = keybias + kq * 4;
     LeanState st;
     st.oh[0] = splat(0.f); st.oh[1] = splat(0.f);
+    st.oc[0] = splat(0.f); st.oc[1] = splat(0.f);
     st.nref = -RUN_MAX_NONE; st.run_sum = 0.f;
     const int n_tot = lean_count(q);
     if (n_tot > 0) {
@@ -919,21 +952,21 @@ __device__ __forceinline__ void attention_walk_lean_x(const xh8& qh, AttnPreX& p
         float va[8], vb[8];
         {
             f32x4 s[2], c[2];
-            attn_qk_x(pre.k0f, qh, qh, s, c);
-            lean_stats_first_x(s, pre.k0f.kb, q.nF == 0, va, st);
+            attn_qk_x(pre.k0f, qh, ql, s, c);
+            lean_stats_first_x(s, c, pre.k0f.kb, q.nF == 0, va, st);
         }
         // steps whose blocks j, j + 1, j + 2 are all full, two per iteration with the logit arrays swapped (the MFMA results of one
         // block are consumed where they are: no copies across the back edge)
         int j = 0;
         for (; j + 3 < q.nF; j += 2) {
             const int k1 = lean_addr<STEP>(q, j + 1), k2 = lean_addr<STEP>(q, j + 2), k3 = lean_addr<STEP>(q, j + 3);
-            lean_step_full_x(qh, kbase, vbase, k1, k2, va, vb, kn, vc, st);
-            lean_step_full_x(qh, kbase, vbase, k2, k3, vb, va, kn, vc, st);
+            lean_step_full_x(qh, ql, kbase, vbase, k1, k2, va, vb, kn, vc, st);
+            lean_step_full_x(qh, ql, kbase, vbase, k2, k3, vb, va, kn, vc, st);
         }
-        for (; j < n_tot; ++j) lean_step_any_x<STEP>(j, q, qh, kbase, vbase, bbase, va, kn, vc, st);
+        for (; j < n_tot; ++j) lean_step_any_x<STEP>(j, q, qh, ql, kbase, vbase, bbase, va, kn, vc, st);
     }
-    out.o[0] = st.oh[0];
-    out.o[1] = st.oh[1];
+    out.o[0] = NPL == 2 ? st.oh[0] + st.oc[0] * splat(SPLIT_INV) : st.oh[0];
+    out.o[1] = NPL == 2 ? st.oh[1] + st.oc[1] * splat(SPLIT_INV) : st.oh[1];
     out.m = -st.nref;
     out.s = st.run_sum;
 }
@@ -947,7 +980,6 @@ __device__ __forceinline__ bool attention_finish_lean_x(const AttnPartX& a, f32x
     o[1] = a.o[1] * splat(inv);
     return novalid;
 }
-#endif  // TB_XDL_BF16
 
 #ifdef TB_XDL_AW
 // two partial states of one row set -> the normalised attention output (merged in the order main, assist)
@@ -1058,7 +1090,9 @@ __device__ __forceinline__ void kv_store_key_x(xhalf* __restrict__ Kf, xhalf* __
 // ---------------------------------------------------------------------------------------------
 // AW (the TB_XDL_AW build): the partner assist wave of every main wave takes the odd key blocks of this layer (`aw_op` = the layer's
 // index for the assist waves, posted for the LayerNorm barrier below)
-template <bool LNLDS = false, bool SELFMASK = false, bool WO_EARLY = true, bool AW = false, class R = RangeFlag>
+// COMPACT: the group's valid keys sit in front of the masked ones and `n_valid_keys` is their count (what the hoists of the step
+// kernel produce): the attention then takes the lean walk (attention_walk_lean_x) in the bf16 builds (and with -DTB_LEAN_FP16)
+template <bool LNLDS = false, bool SELFMASK = false, bool WO_EARLY = true, bool AW = false, bool COMPACT = false, class R = RangeFlag>
 __device__ __forceinline__ void xattn_layer_x(const float* __restrict__ W, const XLayerW& L, const XLayerX& LX, float* X, xhalf* P1,
                                               xhalf* P2, const xhalf* __restrict__ Kmat, const xhalf* __restrict__ VT,
                                               const float* __restrict__ keybias, int n_key_pad, int kstart, int self_key0,
@@ -1090,23 +1124,31 @@ __device__ __forceinline__ void xattn_layer_x(const float* __restrict__ W, const
     // requested in front of the LayerNorm arithmetic and the rest behind it: the vector-memory queue takes about that many without
     // stalling the wave, so part of the burst runs beside the arithmetic (92.6 -> 92.0 us per fused launch); with one bf16 plane the
     // whole burst is short and stays behind the LayerNorm (in front of it: 64.7 -> 65.2).
+#if defined(TB_XDL_BF16) || defined(TB_LEAN_FP16)
+    constexpr bool LEANW = COMPACT && !SELFMASK;  // the lean walk for the attention over compacted key groups (map, traffic lights)
+#else
+    constexpr bool LEANW = false;
+#endif
     if (NPL == 2) {
-        TB_SCHED_FENCE();
-        k_load_x(apre.k0f, Kmat + wave * (NPL * 1024) + lane * 8, keybias + kq * 4, kstart);
-        TB_SCHED_FENCE();
+        if (LEANW) attention_prefetch_lean_x<1, 1>(apre, Kmat, VT, keybias, lean_seq(n_key_pad, n_valid_keys, kstart, 0), wave, lane);
+        else {
+            TB_SCHED_FENCE();
+            k_load_x(apre.k0f, Kmat + wave * (NPL * 1024) + lane * 8, keybias + kq * 4, kstart);
+            TB_SCHED_FENCE();
+        }
     }
     layernorm_planes<LNLDS>(X, LDT, P1, lnblk, lnblk + 128, tid);
     if (NPL == 2) {
-        TB_SCHED_FENCE();
-        v_load_x(apre.vc, VT + wave * (NPL * 1024) + lane * 8, kstart);
-        k_load_x(apre.kn, Kmat + wave * (NPL * 1024) + lane * 8, keybias + kq * 4, n_key_pad > 32 ? kwrap(kstart + 32, n_key_pad) : kstart);
-        TB_SCHED_FENCE();
+        if (LEANW) attention_prefetch_lean_x<1, 2>(apre, Kmat, VT, keybias, lean_seq(n_key_pad, n_valid_keys, kstart, 0), wave, lane);
+        else {
+            TB_SCHED_FENCE();
+            v_load_x(apre.vc, VT + wave * (NPL * 1024) + lane * 8, kstart);
+            k_load_x(apre.kn, Kmat + wave * (NPL * 1024) + lane * 8, keybias + kq * 4, n_key_pad > 32 ? kwrap(kstart + 32, n_key_pad) : kstart);
+            TB_SCHED_FENCE();
+        }
     } else {
-#ifdef TB_XDL_BF16
-        if (!SELFMASK) attention_prefetch_lean_x<AW ? 2 : 1>(apre, Kmat, VT, keybias, lean_seq(n_key_pad, n_valid_keys, kstart, AW ? 1 : 0), wave, lane);
-        else
-#endif
-        attention_prefetch_x(apre, Kmat, VT, keybias, n_key_pad, kstart, wave, lane);
+        if (LEANW) attention_prefetch_lean_x<AW ? 2 : 1>(apre, Kmat, VT, keybias, lean_seq(n_key_pad, n_valid_keys, kstart, AW ? 1 : 0), wave, lane);
+        else attention_prefetch_x(apre, Kmat, VT, keybias, n_key_pad, kstart, wave, lane);
     }
     __syncthreads();
     TB_XSTAMP(17);
@@ -1116,15 +1158,15 @@ __device__ __forceinline__ void xattn_layer_x(const float* __restrict__ W, const
     TB_XSTAMP(18);
     f32x4 o[2];
     bool novalid;
-#ifdef TB_XDL_BF16
-    static_assert(WO_EARLY || SELFMASK, "the lean walk of the bf16 builds issues no weight request from inside the walk");
+    static_assert(!LEANW || WO_EARLY, "the lean walk issues no weight request from inside the walk");
+    static_assert(!AW || LEANW, "assist waves split the lean walk");
 #ifdef TB_XDL_AW
     if (AW) {
         // this wave: block sequence indices 0, 2, 4, ...; the assist wave on the same SIMD: 1, 3, 5, ... (aw_assist_layer_x)
         xh8 qh, ql;
         split8(q[0], q[1], qh, ql, amax);
         AttnPartX mine, theirs;
-        attention_walk_lean_x<2>(qh, apre, Kmat, VT, keybias, lean_seq(n_key_pad, n_valid_keys, kstart, 1), wave, lane, mine);
+        attention_walk_lean_x<2>(qh, ql, apre, Kmat, VT, keybias, lean_seq(n_key_pad, n_valid_keys, kstart, 1), wave, lane, mine);
         TB_XSTAMP(25);
         __syncthreads();  // the assist waves have written their states
         const float* ps = aw_part(wave, lane);
@@ -1135,14 +1177,13 @@ __device__ __forceinline__ void xattn_layer_x(const float* __restrict__ W, const
         novalid = attention_merge2_x(mine, theirs, o);
     } else
 #endif
-    if (!SELFMASK) {
+    if (LEANW) {
         xh8 qh, ql;
         split8(q[0], q[1], qh, ql, amax);
         AttnPartX st;
-        attention_walk_lean_x<1>(qh, apre, Kmat, VT, keybias, lean_seq(n_key_pad, n_valid_keys, kstart, 0), wave, lane, st);
+        attention_walk_lean_x<1>(qh, ql, apre, Kmat, VT, keybias, lean_seq(n_key_pad, n_valid_keys, kstart, 0), wave, lane, st);
         novalid = attention_finish_lean_x(st, o);
     } else
-#endif
     novalid = attention_head_x<SELFMASK, !WO_EARLY>(q, apre, Kmat, VT, keybias, n_key_pad, kstart, wave, lane,
                                                     self_key0 >= 0 ? self_key0 + m : -1, o, u2, wstdx(W, LX.wo, W + L.bo, wave), prof, amax);
     TB_XSTAMP(19);
@@ -1204,7 +1245,7 @@ __device__ __forceinline__ void aw_assist_layer_x(const WUnitX& u, AttnPreX& apr
     xh8 qh, ql;
     split8<false>(q[0], q[1], qh, ql);
     AttnPartX st;
-    attention_walk_lean_x<2>(qh, apre, Kmat, VT, keybias, sq, wave, lane, st);
+    attention_walk_lean_x<2>(qh, ql, apre, Kmat, VT, keybias, sq, wave, lane, st);
     float* ps = aw_part(wave, lane);
     st4(ps, st.o[0]);
     st4(ps + 4, st.o[1]);

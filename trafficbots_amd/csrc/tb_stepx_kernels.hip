@@ -579,12 +579,12 @@ __global__ __launch_bounds__(AWB ? 2 * NTHREADS : NTHREADS, LEAN ? (W3 ? 3 : 2) 
         const size_t ls = (size_t)p.p_pad * H;
         const xhalf* K0 = reinterpret_cast<const xhalf*>(p.kpl + ((size_t)b * 3) * ls);
         const xhalf* V0 = reinterpret_cast<const xhalf*>(p.vtpl + ((size_t)b * 3) * ls);
-        xattn_layer_x<!LEAN, false, true, AWB>(W, pw.as2pl[0], px.as2pl[0], X, PA, PB, K0, V0, kvd, nk_p, ks_p, -1, rowvalid, novalid_s, tid, u,
+        xattn_layer_x<!LEAN, false, true, AWB, true>(W, pw.as2pl[0], px.as2pl[0], X, PA, PB, K0, V0, kvd, nk_p, ks_p, -1, rowvalid, novalid_s, tid, u,
                             xlayer_first_x(W, pw.as2pl[1], px.as2pl[1], wave), (LEAN ? nullptr : LN + 3 * 768),
                             p.prof + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 32, amax, 0, nv_p);
-        xattn_layer_x<!LEAN, false, true, AWB>(W, pw.as2pl[1], px.as2pl[1], X, PA, PB, K0 + 2 * ls, V0 + 2 * ls, kvd, nk_p, ks_p, -1, rowvalid, novalid_s, tid, u,
+        xattn_layer_x<!LEAN, false, true, AWB, true>(W, pw.as2pl[1], px.as2pl[1], X, PA, PB, K0 + 2 * ls, V0 + 2 * ls, kvd, nk_p, ks_p, -1, rowvalid, novalid_s, tid, u,
                             xlayer_first_x(W, pw.as2pl[2], px.as2pl[2], wave), (LEAN ? nullptr : LN + 4 * 768), nullptr, amax, 1, nv_p);
-        xattn_layer_x<!LEAN, false, true, AWB>(W, pw.as2pl[2], px.as2pl[2], X, PA, PB, K0 + 4 * ls, V0 + 4 * ls, kvd, nk_p, ks_p, -1, rowvalid, novalid_s, tid,
+        xattn_layer_x<!LEAN, false, true, AWB, true>(W, pw.as2pl[2], px.as2pl[2], X, PA, PB, K0 + 4 * ls, V0 + 4 * ls, kvd, nk_p, ks_p, -1, rowvalid, novalid_s, tid,
                             u, xlayer_first_x(W, pw.as2tl[0], px.as2tl[0], wave), (LEAN ? nullptr : LN + 5 * 768), nullptr, amax, 2, nv_p);
     }
 #ifdef TB_XDL_AW
@@ -605,11 +605,11 @@ __global__ __launch_bounds__(AWB ? 2 * NTHREADS : NTHREADS, LEAN ? (W3 ? 3 : 2) 
         const size_t ls = (size_t)p.t_pad * H;
         const xhalf* K0 = reinterpret_cast<const xhalf*>(p.ktl + ((size_t)g_tl * 3) * ls);
         const xhalf* V0 = reinterpret_cast<const xhalf*>(p.vttl + ((size_t)g_tl * 3) * ls);
-        xattn_layer_x<!LEAN>(W, pw.as2tl[0], px.as2tl[0], X, PA, PB, K0, V0, kvd, nk_t, ks_t, -1, rowvalid, novalid_s, tid, u,
+        xattn_layer_x<!LEAN, false, true, false, true>(W, pw.as2tl[0], px.as2tl[0], X, PA, PB, K0, V0, kvd, nk_t, ks_t, -1, rowvalid, novalid_s, tid, u,
                             xlayer_first_x(W, pw.as2tl[1], px.as2tl[1], wave), (LEAN ? nullptr : LN + 6 * 768), nullptr, amax, 0, nv_t);
-        xattn_layer_x<!LEAN>(W, pw.as2tl[1], px.as2tl[1], X, PA, PB, K0 + 2 * ls, V0 + 2 * ls, kvd, nk_t, ks_t, -1, rowvalid, novalid_s, tid, u,
+        xattn_layer_x<!LEAN, false, true, false, true>(W, pw.as2tl[1], px.as2tl[1], X, PA, PB, K0 + 2 * ls, V0 + 2 * ls, kvd, nk_t, ks_t, -1, rowvalid, novalid_s, tid, u,
                             xlayer_first_x(W, pw.as2tl[2], px.as2tl[2], wave), (LEAN ? nullptr : LN + 7 * 768), nullptr, amax, 0, nv_t);
-        xattn_layer_x<!LEAN>(W, pw.as2tl[2], px.as2tl[2], X, PA, PB, K0 + 4 * ls, V0 + 4 * ls, kvd, nk_t, ks_t, -1, rowvalid, novalid_s, tid,
+        xattn_layer_x<!LEAN, false, true, false, true>(W, pw.as2tl[2], px.as2tl[2], X, PA, PB, K0 + 4 * ls, V0 + 4 * ls, kvd, nk_t, ks_t, -1, rowvalid, novalid_s, tid,
                             u, wstdx(W, px.inter_kvf[0], W + px.inter_bkvf[0], wave), (LEAN ? nullptr : LN + 8 * 768), nullptr, amax, 0, nv_t);
     }
     TB_STAMP(10);

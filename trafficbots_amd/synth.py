@@ -562,3 +562,16 @@ def make_state_dict(seed: int, gain: float = 1.0, h: int = 128, mode: Optional[s
             if name.startswith(a):
                 sd[name] = sd[tgt + name[len(a):]]
     return OrderedDict((k, sd[k]) for k in spec.keys())
+
+
+def case_state_dict(case: dict) -> "OrderedDict[str, np.ndarray]":
+    """Weights of a golden case (tests/golden/*.npz `meta_json`, tools/gen_golden*.py CASES): regenerated from `weight_seed` (+
+    `weight_mode`), or -- `weight_file` -- read from a committed `state_dict` under tests/golden/ (the trained-statistics weights that
+    tools/train_reference.py produced with the reference's own `training_step`; data, not regenerable from a seed)."""
+    if case.get("weight_file"):
+        import os
+
+        path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", case["weight_file"])
+        z = np.load(path)
+        return OrderedDict((k, np.ascontiguousarray(z[k])) for k in z.files)
+    return make_state_dict(case["weight_seed"], mode=case.get("weight_mode"))
