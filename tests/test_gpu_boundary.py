@@ -511,6 +511,24 @@ def test_fp16_pair_operand_range(scale, expect):
         assert err_f <= 1e-4 and err_xy <= 1e-3, (err_f, err_xy)
 
 
+def test_a_downgraded_context_gets_its_kernels_back_with_in_range_weights():
+    """the switch to the exact-fp32 kernels was sticky -- a later `tb_finalize_weights` with in-range weights never
+    restored the XDL kernels.  Every load now starts from the configured selection; and a switch that happens while a stepwise
+    rollout is open closes that rollout (its workspace holds XDL-ordered K / V the exact kernel cannot read)."""
+    from trafficbots_amd import synth
+    from trafficbots_amd.waymo_motion import WaymoMotion
+
+    sd = synth.make_state_dict(5)
+    big = {k: (v * 1e7 if k.endswith("transformer_as2pl.layers.0.linear2.weight") else v) for k, v in sd.items()}
+    wm = WaymoMotion(time_step_end=20, n_joint_future=1)
+    wm.load_state_dict(big)
+    st = wm.engine.precision_state()
+    assert st["step"] == "fp32_exact" and st["weight_out_of_range"]
+    wm.load_state_dict(sd)
+    st = wm.engine.precision_state()
+    assert st["step"] == "fp16_pair" and st["encode"] == "fp16_pair" and not st["weight_out_of_range"], st
+
+
 @pytest.mark.parametrize("case", ["masks", "degenerate"])
 def test_traffic_bots_forward_with_attention_weights_against_reference_golden(case):
     """`TrafficBots.forward(agent_valid, agent_feature, map_valid, map_feature, tl_valid, tl_feature, goal_valid, goal_feature,

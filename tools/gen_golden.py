@@ -114,7 +114,7 @@ CASES["headline_8"] = dict(
 )
 CASES["stress_1"] = dict(
     base_seed=15000, n_scene=1, k=1, weight_seed=7, time_step_end=170,
-    scene=dict(n_agent=128, n_pl=1024, n_tl=40), tap_steps=[], fp64=True, store_feats=False, n_ensg=16,
+    scene=dict(n_agent=128, n_pl=1024, n_tl=40), tap_steps=[], fp64=True, store_feats=False, n_ensg=32,
 )
 
 # VERDICT r04 missing #4: weights with TRAINED statistics -- tests/golden/trained_state_dict.npz, 500 optimizer steps of the reference's

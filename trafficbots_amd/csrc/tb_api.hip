@@ -349,10 +349,16 @@ static bool w3_launch(size_t n_tiles) {
 // map-attention walks (tb::xba; tb_device_xdl.hpp "Assist waves").  The two halves of a walk are merged in a fixed order, so the
 // result is deterministic, but it is not the bit pattern of the four-wave kernel (another summation order of the same softmax).
 // TB_STEP_AW=0 keeps such launches on the four-wave kernel (development / A-B switch).
+// TB_STEP_AW=2 (test switch): such launches of ANY size up to 256 tiles take the assist carve -- the rollout then runs without helper
+// workgroups (aw_forced, rollout_setup) -- so that a one-scene case the CPU oracle can follow exercises it.
+static bool aw_forced() {
+    const char* e = getenv("TB_STEP_AW");
+    return e && e[0] == '2';
+}
 static bool aw_launch(const tb::RolloutP& p, int do_a) {
     const char* e = getenv("TB_STEP_AW");
     const size_t n_tiles = (size_t)(p.a_pad / tb::TM) * p.n_inst;
-    return !(e && e[0] == '0') && do_a && n_tiles > 128 && n_tiles <= 256 && p.p_pad >= 512;
+    return !(e && e[0] == '0') && do_a && (n_tiles > 128 || aw_forced()) && n_tiles <= 256 && p.p_pad >= 512;
 }
 
 // `rd` supplies what C(t) reads (normally the same struct as `wr`; the batched warm start substitutes its slices), `wr` what
@@ -425,6 +431,8 @@ int tb_create(const tb_config* cfg, tb_ctx** out) {
         delete c;
         return 2;
     }
+    c->step_kernel0 = c->step_kernel;
+    c->encode_kernel0 = c->encode_kernel;
     *out = c;
     return 0;
 }
@@ -634,6 +642,13 @@ int tb_finalize_weights(tb_ctx* ctx, tb_stream stream) {
     // ---- fp16-pair range of the loaded tensors: the reference has no range limit (src/models/modules/mlp.py:20-85), so a checkpoint
     // outside it is not refused -- the context falls back to the exact-fp32 twins (fp32 MFMA step kernel k_step, fp32-MFMA encoder
     // blocks), which have fp32's range, and says so (tb_precision_state; once on stderr)
+    // (every load starts from the configured kernels: a context that was downgraded -- by an earlier checkpoint or by a run-time
+    // overflow under it -- gets the XDL kernels back with in-range weights; an open stepwise rollout belongs to the old weights)
+    ctx->step_kernel = ctx->step_kernel0;
+    ctx->encode_kernel = ctx->encode_kernel0;
+    ctx->precision_reason = 0;
+    ctx->precision_note.clear();
+    ctx->step_active = false;
     if (s.range_hit && ctx->cfg.operand_precision != 2) {
         ctx->encode_kernel = 0;
         if (ctx->cfg.operand_precision == 0) ctx->step_kernel = 0;
@@ -897,6 +912,7 @@ static int rollout_setup(tb_ctx* ctx, const tb_rollout_io* io, tb::RolloutP& p) 
         const char* e = getenv("TB_STEP_HELPERS");
         if (!e) e = getenv("TB_GRU_HELPER");  // (the switch's first name)
         with_gh = ctx->step_kernel >= 2 && (size_t)p.n_inst * (p.a_pad / 16) <= 128 && !(e && e[0] == '0');
+        if (ctx->step_kernel == 3 && aw_forced() && p.p_pad >= 512) with_gh = false;  // (test switch: the assist carve has no helpers)
     }
     if (!ctx->d_status) {
         TB_HIP(ctx, hipMalloc((void**)&ctx->d_status, 2 * sizeof(unsigned int)));

@@ -248,12 +248,11 @@ const char* run_forward(const std::map<std::string, const float*>& raw, const tb
         if (ok) {
             // up to 8192 keys: 4 x T logits in LDS = 131.6 KB of gfx950's 160 KB -- above the 64 KB a kernel gets without asking
             const size_t lds = (H + NH * T + 8) * sizeof(float);
-            static bool big_lds = false;
-            if (lds > 48 * 1024 && !big_lds) {
+            // (set on every call that needs it: the attribute belongs to the CURRENT device's copy of the function, a process-wide
+            // "done" flag would leave a second GPU of the process without it; the call is a host-side table update)
+            if (lds > 48 * 1024)
                 ok = hipFuncSetAttribute(reinterpret_cast<const void*>(k_attention), hipFuncAttributeMaxDynamicSharedMemorySize,
                                          (int)((H + NH * 8192 + 8) * sizeof(float))) == hipSuccess;
-                big_lds = ok;
-            }
             if (ok) hipLaunchKernelGGL(k_attention, dim3(A, N), dim3(128), lds, s, q, kv, kv + H, 2 * H, tgt_valid, A, T, eye, att, wout, no_tgt);
         }
         lin(att, H, W(pre + ".attn.out_proj_weight"), H, W(pre + ".attn.out_proj_bias"), o, H, R, H, H, 0);

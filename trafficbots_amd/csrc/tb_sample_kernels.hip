@@ -104,6 +104,9 @@ __global__ __launch_bounds__(64) void k_dest_sample(tb_dest_sample_io io) {
         }
         pick = found;
     }
+    // (a row of NaN logits has no maximum and no mass: best = P, found = -1.  torch.argmax / multinomial would still return an index
+    // inside the row, and the sample is used as a polyline index downstream: clamp)
+    pick = min(max(pick, 0), P - 1);
     if (lane == 0) {
         if (io.sample != nullptr) io.sample[i] = pick;
         if (io.log_prob != nullptr) {
