@@ -104,7 +104,8 @@ def test_rule_is_calibrated_on_the_references_own_runs():
     from tools import rule_calibration
 
     tot, flagged = rule_calibration.leave_one_out(ensemble.QUANT)
-    assert tot == 1008 and len(flagged) <= 3, flagged
+    # (1008 member runs in round 4; 1170 since round 5: stress_1 has 32 members and the two trained-weights goldens their own ensembles)
+    assert tot == 1170 and len(flagged) <= 3, (tot, flagged)
     tot0, flagged0 = rule_calibration.leave_one_out(0.0)
     assert len(flagged0) > len(flagged)
 
