@@ -1067,6 +1067,7 @@ static int rollout_enqueue(tb_ctx* ctx, const tb_rollout_io* io, const tb::Rollo
         if (do_c && t - 1 - t_pre0 < n_pre && t - 1 >= t_pre0) {  // C(t) consumes slice t-1-t_pre0 of the batched results
             const size_t z = (size_t)(t - 1 - t_pre0) * p.n_inst * p.a_pad * 128;
             q.x_mid = p.x_mid_pre + z;
+            q.pre_shared = p.k_rep > 1;  // (the slices exist once per scene, in the slot of future 0: no replication)
             q.kin_b[0] = q.kin_b[1] = p.kin_pre + 3 * z;     // (read side only: step_launch picks by parity, the write side is restored below)
             q.vtin_b[0] = q.vtin_b[1] = p.vtin_pre + 3 * z;
         }

@@ -452,6 +452,73 @@ __device__ __forceinline__ void wmmax(f32x4& acc_a, f32x4& acc_b, const WUnitX& 
         acc_b += mid_b * splat(SPLIT_INV);
     }
 }
+
+#ifndef TB_XDL_W3
+// ---------------------------------------------------------------------------------------------
+// ONE-tile weight units (round 5, the eight-wave polyline encoder k_polyline_fused8): wave w of eight owns output tile w of a
+// 128 -> 128 Linear, so a unit is 1 output tile x 4 chunks x NPL planes = 8 fragments (32 VGPRs with fp16 pairs) + bias.  The
+// products of an output element are taken in the order of wmmax (per chunk: the two cross products, then the high product; the cross
+// sum scaled once at the end): the same bits as the two-tile units give.
+// ---------------------------------------------------------------------------------------------
+struct WNext1X {
+    const xhalf* wpk;
+    const float* bias;   // or nullptr
+    int tile, nchunk, c0;
+};
+struct WUnit1X {
+    xh8 w[4][NPL];  // [chunk][plane]
+    f32x4 b;
+};
+__device__ __forceinline__ WNext1X wnext1x(const float* arena, uint32_t off, const float* bias, int tile, int nchunk = 4, int c0 = 0) {
+    return WNext1X{reinterpret_cast<const xhalf*>(arena + off), bias, tile, nchunk, c0};
+}
+__device__ __forceinline__ const xh8* wfrag1x(const WNext1X& n, int lane) {
+    return reinterpret_cast<const xh8*>(n.wpk + ((size_t)(n.tile * n.nchunk + n.c0) * NPL) * 512 + lane * 8);
+}
+__device__ __forceinline__ void wload1x(WUnit1X& u, const WNext1X& n, int lane) {
+    const xh8* pa = wfrag1x(n, lane);
+    TB_SCHED_FENCE();
+    u.b = n.bias ? ldg4(n.bias + n.tile * 16 + (lane >> 4) * 4) : splat(0.f);
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int p = 0; p < NPL; ++p) u.w[c][p] = pa[(c * NPL + p) * 64];
+    TB_SCHED_FENCE();
+}
+// acc += unit . X^T for one row tile (bp: this lane's B base, see wmmax_pf)
+template <bool SWAP = false>
+__device__ __forceinline__ void wmma1x(f32x4& acc, const WUnit1X& u, const xhalf* bp, int plane_stride) {
+    xh8 x[4][NPL];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int p = 0; p < NPL; ++p) x[c][p] = ldsb8(bp + p * plane_stride + c * 32);
+    f32x4 mid = splat(0.f);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        if (NPL == 2) {
+            mid = mm_sw<SWAP>(u.w[c][0], x[c][P1], mid);
+            mid = mm_sw<SWAP>(u.w[c][P1], x[c][0], mid);
+        }
+        acc = mm_sw<SWAP>(u.w[c][0], x[c][0], acc);
+    }
+    if (NPL == 2) acc += mid * splat(SPLIT_INV);
+}
+// the same with the request for the next unit issued in front of the MFMAs (a one-tile unit, or -- wmma1x_pf2 -- a two-tile unit);
+// with two waves per SIMD the exact interleaving matters less than at one: the loads are pinned in front, the partner wave computes
+template <bool SWAP = false>
+__device__ __forceinline__ void wmma1x_pf(f32x4& acc, const WUnit1X& u, const xhalf* bp, int plane_stride, WUnit1X& un, const WNext1X& n,
+                                          int lane) {  // (`un` must not be `u`)
+    wload1x(un, n, lane);
+    wmma1x<SWAP>(acc, u, bp, plane_stride);
+}
+template <bool SWAP = false>
+__device__ __forceinline__ void wmma1x_pf2(f32x4& acc, const WUnit1X& u, const xhalf* bp, int plane_stride, WUnitX& un, const WNextX& n,
+                                           int lane) {
+    wloadx(un, n, lane);
+    wmma1x<SWAP>(acc, u, bp, plane_stride);
+}
+#endif  // !TB_XDL_W3
 #endif  // TB_XDL_W3
 
 __device__ __forceinline__ WNextX xlayer_first_x(const float* W, const XLayerW& L, const XLayerX& LX, int wave) {
@@ -971,6 +1038,80 @@ __device__ __forceinline__ void attention_walk_lean_x(const xh8& qh, const xh8& 
     out.s = st.run_sum;
 }
 
+// The lean walk for key groups that are NOT compacted (the interaction: key slot = agent index, any agent may be invalid, and the
+// eye mask of MultiAgentTF hides a row's own key): every block reads its key bias, the lazy reference is the same.  Blocks
+// kwrap(kstart + 32 j, n_key_pad), j = 0 .. n_key_pad / 32 - 1; pre = attention_prefetch_x's (K + bias and V of block 0, K + bias of block 1).
+template <bool SELFMASK>
+__device__ __forceinline__ void lean_stats_m_x(const f32x4 (&s)[2], const f32x4 (&c)[2], const f32x4 (&kb)[2], int kb0, int self_key, bool first,
+                                               float (&v)[8], LeanState& st) {
+    float raw[8];
+    lean_raw_x(s, c, raw);
+    const float bias[8] = {kb[0].x, kb[0].y, kb[0].z, kb[0].w, kb[1].x, kb[1].y, kb[1].z, kb[1].w};
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const float l = fmaf(raw[r], LEAN_SC, bias[r]);
+        v[r] = (SELFMASK && kb0 + 16 * (r >> 2) + (r & 3) == self_key) ? -INFINITY : l;
+    }
+    if (first) {
+        const float ref = fmaxf(rows_max(max8_x(v)), RUN_MAX_NONE);
+        st.nref = -ref;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] -= ref;
+    } else {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] += st.nref;
+        lean_ref_x(max8_x(v), v, st);
+    }
+}
+template <bool SELFMASK>
+__device__ __forceinline__ void attention_walk_leanm_x(const xh8& qh, const xh8& ql, AttnPreX& pre, const xhalf* __restrict__ Kh,
+                                                       const xhalf* __restrict__ Vh, const float* __restrict__ keybias, int n_key_pad, int kstart,
+                                                       int head, int lane, int self_key, AttnPartX& out) {
+    const int kq = lane >> 4;
+    const xhalf* kbase = Kh + head * (NPL * 1024) + lane * 8;
+    const xhalf* vbase = Vh + head * (NPL * 1024) + lane * 8;
+    const float* bbase = keybias + kq * 4;
+    LeanState st;
+    st.oh[0] = splat(0.f); st.oh[1] = splat(0.f);
+    st.oc[0] = splat(0.f); st.oc[1] = splat(0.f);
+    st.nref = -RUN_MAX_NONE; st.run_sum = 0.f;
+    KFragX kn = pre.kn;
+    VFragX vc = pre.vc;
+    float v[8];
+    {
+        f32x4 s[2], c[2];
+        attn_qk_x(pre.k0f, qh, ql, s, c);
+        lean_stats_m_x<SELFMASK>(s, c, pre.k0f.kb, kstart + kq * 4, self_key, true, v, st);
+    }
+    const int nblk = n_key_pad >> 5;
+    int k1 = kwrap(kstart + 32, n_key_pad), k2 = kwrap(k1 + 32, n_key_pad);
+    for (int i = 0; i < nblk; ++i) {
+        const bool has_next = i + 1 < nblk, has_nn = i + 2 < nblk;
+        f32x4 ts[2] = {splat(0.f), splat(0.f)}, tc[2] = {splat(0.f), splat(0.f)};
+        TB_SCHED_FENCE();
+        if (has_next) attn_qk_x(kn, qh, ql, ts, tc);  // QK of the next block under the exponentials of this one
+        const f32x4 nb[2] = {kn.kb[0], kn.kb[1]};
+        TB_SCHED_FENCE();
+        if (has_nn) k_load_x(kn, kbase, bbase, k2);
+        xh8 ph, pl;
+        lean_exp_x(v, st, ph, pl);
+        TB_SCHED_FENCE();
+        lean_pv_x(vc, ph, pl, st);
+        TB_SCHED_FENCE();
+        if (has_next) {
+            v_load_x(vc, vbase, k1);
+            lean_stats_m_x<SELFMASK>(ts, tc, nb, k1 + kq * 4, self_key, false, v, st);
+        }
+        TB_SCHED_FENCE();
+        k1 = k2;
+        k2 = kwrap(k2 + 32, n_key_pad);
+    }
+    out.o[0] = NPL == 2 ? st.oh[0] + st.oc[0] * splat(SPLIT_INV) : st.oh[0];
+    out.o[1] = NPL == 2 ? st.oh[1] + st.oc[1] * splat(SPLIT_INV) : st.oh[1];
+    out.m = -st.nref;
+    out.s = st.run_sum;
+}
+
 // one state -> the normalised attention output
 __device__ __forceinline__ bool attention_finish_lean_x(const AttnPartX& a, f32x4 (&o)[2]) {
     const float s = rows_sum(a.s);
@@ -1018,10 +1159,18 @@ __device__ __forceinline__ void aw_post(unsigned int op) {
 // n_key_pad = 32 (the correction factor it multiplies by is an exact 0 x 0): same bits.
 template <class R = RangeFlag>
 __device__ __forceinline__ bool attention_oneblock_pre_x(const f32x4 (&q)[2], const KFragX& kf, const VFragX& vf, int lane, f32x4 (&o)[2],
-                                                         R&& amax = R{}) {
-    const int kq = lane >> 4;
+                                                         R&& amax = R{});
+__device__ __forceinline__ bool attention_oneblock_q_x(const xh8& qh, const xh8& ql, const KFragX& kf, const VFragX& vf, int lane, f32x4 (&o)[2]);
+template <class R>
+__device__ __forceinline__ bool attention_oneblock_pre_x(const f32x4 (&q)[2], const KFragX& kf, const VFragX& vf, int lane, f32x4 (&o)[2],
+                                                         R&& amax) {
     xh8 qh, ql;
     split8(q[0], q[1], qh, ql, amax);
+    return attention_oneblock_q_x(qh, ql, kf, vf, lane, o);
+}
+// (the same with Q already split: a caller that runs several attentions on one Q splits it once)
+__device__ __forceinline__ bool attention_oneblock_q_x(const xh8& qh, const xh8& ql, const KFragX& kf, const VFragX& vf, int lane, f32x4 (&o)[2]) {
+    const int kq = lane >> 4;
     f32x4 s[2], c[2];
     attn_qk_x(kf, qh, ql, s, c);
     float sv[8], new_max, alpha;
@@ -1126,8 +1275,10 @@ __device__ __forceinline__ void xattn_layer_x(const float* __restrict__ W, const
     // whole burst is short and stays behind the LayerNorm (in front of it: 64.7 -> 65.2).
 #if defined(TB_XDL_BF16) || defined(TB_LEAN_FP16)
     constexpr bool LEANW = COMPACT && !SELFMASK;  // the lean walk for the attention over compacted key groups (map, traffic lights)
+    // ... and, with WO_EARLY, the lean walk over un-compacted groups (attention_walk_leanm_x) for the interaction of the step kernel
+    constexpr bool LEANM = SELFMASK && WO_EARLY;
 #else
-    constexpr bool LEANW = false;
+    constexpr bool LEANW = false, LEANM = false;
 #endif
     if (NPL == 2) {
         if (LEANW) attention_prefetch_lean_x<1, 1>(apre, Kmat, VT, keybias, lean_seq(n_key_pad, n_valid_keys, kstart, 0), wave, lane);
@@ -1182,6 +1333,12 @@ __device__ __forceinline__ void xattn_layer_x(const float* __restrict__ W, const
         split8(q[0], q[1], qh, ql, amax);
         AttnPartX st;
         attention_walk_lean_x<1>(qh, ql, apre, Kmat, VT, keybias, lean_seq(n_key_pad, n_valid_keys, kstart, 0), wave, lane, st);
+        novalid = attention_finish_lean_x(st, o);
+    } else if (LEANM) {
+        xh8 qh, ql;
+        split8(q[0], q[1], qh, ql, amax);
+        AttnPartX st;
+        attention_walk_leanm_x<SELFMASK>(qh, ql, apre, Kmat, VT, keybias, n_key_pad, kstart, wave, lane, self_key0 >= 0 ? self_key0 + m : -1, st);
         novalid = attention_finish_lean_x(st, o);
     } else
     novalid = attention_head_x<SELFMASK, !WO_EARLY>(q, apre, Kmat, VT, keybias, n_key_pad, kstart, wave, lane,

@@ -531,9 +531,216 @@ __global__ __launch_bounds__(NTHREADS) void k_polyline_fused(XBlockPX p) {
     }
 }
 
-void launch_polyline_fused_x(const XBlockPX& p, int G, hipStream_t s) {
+// ---------------------------------------------------------------------------------------------
+// k_polyline_fused8 (round 5): the same workgroup -- two polylines, three row tiles, K / V in LDS -- on EIGHT waves, two per SIMD.
+// k_polyline_fused is issue-bound at one wave per SIMD (profiles/r03_stage_profile_polyline_fused.txt: six three-tile GEMM phases of
+// 72 MFMAs in six dependent chains, three-tile LayerNorms of ~100 VALU instructions per thread and tile, 300 VGPRs), and its 143 KB of
+// LDS admit no second workgroup.  Here wave w owns ONE output tile (16 features) of every Linear for the three row tiles -- a unit
+// is 32 VGPRs instead of 64, a GEMM phase 36 MFMAs per wave instead of 72, a LayerNorm pass 1.5 tiles per thread instead of 3 -- and
+// the second wave of a SIMD computes while the first waits.  The Q projection is the exception: the two waves of a head (2 h, 2 h + 1)
+// each take BOTH feature tiles of the head for their own rows (wave 2 h + s: head tile s and the tail tile) with the two-tile unit, so
+// that a wave holds the whole Q^T of the attentions it runs (its polyline's head tile and tail rows) and nothing is exchanged; the
+// tail tile's Q is computed twice (48 instead of 36 MFMAs in that phase).  Every output element is produced by the same
+// instruction sequence as in k_polyline_fused: bit-identical (test_packed_polyline_tiling_is_bitwise_identical).
+// ---------------------------------------------------------------------------------------------
+constexpr int NT8 = 2 * NTHREADS;
+
+// LayerNorm of the three tiles by 512 threads: tiles 0 / 1 by the two halves of the workgroup, the tail tile by the first half
+__device__ __forceinline__ void layernorm_planes_3x8(const float* src, xhalf* P, int p_stride, const float* __restrict__ g,
+                                                     const float* __restrict__ b, int tid) {
+    const int t = tid >> 8, t16 = tid & 255;
+    layernorm_planes<false>(src + t * TM * LDT, LDT, P + t * p_stride, g, b, t16);
+    if (tid < NTHREADS) layernorm_planes<false>(src + 2 * TM * LDT, LDT, P + 2 * p_stride, g, b, t16);
+}
+
+__global__ __launch_bounds__(NT8) void k_polyline_fused8(XBlockPX p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* X = smem;                                                   // [3][16][LDT]
+    xhalf* P1 = reinterpret_cast<xhalf*>(X + 3 * TM * LDT);            // [3] plane sets
+    xhalf* P2 = P1 + 3 * NPL * PLANE;                                  // [3] plane sets
+    xhalf* KL = P2 + 3 * NPL * PLANE;                                  // K blocks of the two polylines
+    xhalf* VL = KL + 2 * KV_BLOCK_HALFS;                               // V blocks
+    float* kb = reinterpret_cast<float*>(VL + 2 * KV_BLOCK_HALFS);     // [2][32] additive key mask
+    uint8_t* rowvalid = reinterpret_cast<uint8_t*>(kb + 64);           // [48]
+    uint8_t* novalid_s = rowvalid + 48;                                // [48]
+    float* S = NPL == 2 ? reinterpret_cast<float*>(P2) : reinterpret_cast<float*>(novalid_s + 80);  // fp32 staging [3][16][LDT]
+    const int tid = threadIdx.x, wave = wave_of(tid), lane = tid & 63, kq = lane >> 4, m = lane & 15;
+    const int head = wave >> 1, half = wave & 1;  // attention head of this wave's output tile / which of the head's two feature tiles
+    const int g0 = blockIdx.x * 2;
+    const int po = m * LDP + kq * 8;
+    constexpr int PS = NPL * PLANE;
+
+    // rows of the three tiles: tile 0 / 1 = nodes 0 .. 15 of polyline g0 / g0 + 1, tile 2 rows 0 .. 3 / 4 .. 7 = their nodes 16 .. 19
+    auto load3 = [&](float* D) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int idx = tid + i * NT8;
+            const int t = idx >> 9, row = (idx >> 5) & 15, c4 = (idx & 31) * 4;
+            f32x4 v;
+            if (t < 2) v = ldg4(p.src + ((size_t)(g0 + t) * PL_NODES + row) * H + c4);
+            else v = row < 8 ? ldg4(p.src + ((size_t)(g0 + (row >> 2)) * PL_NODES + 16 + (row & 3)) * H + c4) : splat(0.f);
+            st4(D + t * TM * LDT + row * LDT + c4, v);
+        }
+    };
+    WUnit1X u, u2;
+    WUnitX uq;
+    wload1x(u, wnext1x(p.W, p.LX[0].wkv, p.W + p.L[0].bkv, wave), lane);
+    load3(X);
+    if (tid < 48) {
+        const int t = tid >> 4, r = tid & 15;
+        rowvalid[tid] = t < 2 ? p.src_valid[(size_t)(g0 + t) * PL_NODES + r] : (r < 8 ? p.src_valid[(size_t)(g0 + (r >> 2)) * PL_NODES + 16 + (r & 3)] : 0);
+    } else if (tid >= 64 && tid < 128) {
+        const int pl = (tid - 64) >> 5, k = (tid - 64) & 31;
+        kb[tid - 64] = (k < PL_NODES && p.src_valid[(size_t)(g0 + pl) * PL_NODES + k]) ? 0.f : -INFINITY;
+    }
+    {   // key slots 20 .. 31 stay zero for the whole kernel (masked keys must hold finite data)
+        const xh8 z = {};
+        xh8* kv8 = reinterpret_cast<xh8*>(KL);
+        for (int i = tid; i < 4 * KV_BLOCK_HALFS / 8; i += NT8) kv8[i] = z;
+    }
+    __syncthreads();
+
+    // this wave's output tile of a Linear over the three row tiles; the next unit is requested first (ua != ub)
+    auto gemm3 = [&](const WUnit1X& ua, WUnit1X& ub, const WNext1X& next, const xhalf* P, f32x4 (&a)[3]) {
+#pragma unroll
+        for (int t = 0; t < 3; ++t) a[t] = ua.b;
+        wmma1x_pf(a[0], ua, P + po, PLANE, ub, next, lane);
+        wmma1x(a[1], ua, P + PS + po, PLANE);
+        wmma1x(a[2], ua, P + 2 * PS + po, PLANE);
+    };
+
+#pragma unroll 1
+    for (int l = 0; l < p.n_layer; ++l) {
+        const XLayerW& L = p.L[l];
+        const XLayerX& LX = p.LX[l];
+        const float* lnblk = p.W + L.ln1_g;
+        // ---- K / V of the layer from the block input
+        if (l > 0) {  // (layer 0: X still holds the block input)
+            load3(S);
+            __syncthreads();
+        }
+        layernorm_planes_3x8(l > 0 ? S : X, P1, PS, lnblk + 256, lnblk + 384, tid);
+        __syncthreads();
+        {
+            f32x4 ak[3], av[3];
+            gemm3(u, u2, wnext1x(p.W, LX.wkv, p.W + L.bkv, 8 + wave), P1, ak);
+            // K: lane (kq, m) = token m, features 4 kq + r of this wave's feature tile -> its 8-byte half of the key's K granule
+            auto k_store = [&](xhalf* kblk, int kt, int krow, const f32x4& a) {
+                xhalf* pk = kblk + head * (NPL * 1024) + (kt * 64 + kq * 16 + krow) * 8 + half * 4;
+                xh4 h, lo;
+                split2(a, h, lo);
+                *reinterpret_cast<xh4*>(pk) = h;
+                if (NPL == 2) *reinterpret_cast<xh4*>(pk + 1024) = lo;
+            };
+            k_store(KL, 0, m, ak[0]);
+            k_store(KL + KV_BLOCK_HALFS, 0, m, ak[1]);
+            if (m < 8) k_store(KL + (m >> 2) * KV_BLOCK_HALFS, 1, m & 3, ak[2]);
+            // V with the MFMA operands swapped (k_polyline_fused): lane (kq, m) holds tokens 4 kq + r of feature m of this wave's d tile
+            {
+                const float* bv = p.W + L.bkv + (8 + wave) * 16 + m;
+                const f32x4 ba = splat(bv[0]);
+#pragma unroll
+                for (int t = 0; t < 3; ++t) av[t] = ba;
+                wmma1x_pf2<true>(av[0], u2, P1 + po, PLANE, uq, xlayer_first_x(p.W, L, LX, head), lane);
+                wmma1x<true>(av[1], u2, P1 + PS + po, PLANE);
+                wmma1x<true>(av[2], u2, P1 + 2 * PS + po, PLANE);
+                auto v_store = [&](xhalf* pv, const f32x4& a) {
+                    xh4 h, lo;
+                    split2(a, h, lo);
+                    *reinterpret_cast<xh4*>(pv) = h;
+                    if (NPL == 2) *reinterpret_cast<xh4*>(pv + 1024) = lo;
+                };
+                v_store(VL + head * (NPL * 1024) + (kq * 16 + m) * 8 + half * 512, av[0]);
+                v_store(VL + KV_BLOCK_HALFS + head * (NPL * 1024) + (kq * 16 + m) * 8 + half * 512, av[1]);
+                // tail tile: lane group kq = 0 / 1 holds nodes 16 .. 19 of polyline 0 / 1 = keys 16 .. 19 = elements 4 .. 7 of key quad 0
+                if (kq < 2) v_store(VL + kq * KV_BLOCK_HALFS + head * (NPL * 1024) + m * 8 + 4 + half * 512, av[2]);
+            }
+        }
+        __syncthreads();  // (the projections have read P1: LayerNorm 1 may overwrite it; K / V are in place)
+        // ---- the layer on the three tiles
+        layernorm_planes_3x8(X, P1, PS, lnblk, lnblk + 128, tid);
+        __syncthreads();
+        {
+            // Q of this wave's head for its own rows: head tile `half` (polyline `half`) and the tail tile
+            f32x4 qo[2] = {uq.b[0], uq.b[1]}, qt[2] = {uq.b[0], uq.b[1]};
+            wload1x(u2, wnext1x(p.W, LX.wo, p.W + L.bo, wave), lane);
+            wmmax(qo[0], qo[1], uq, P1 + half * PS + po, PLANE);
+            wmmax(qt[0], qt[1], uq, P1 + 2 * PS + po, PLANE);
+            f32x4 oo[2], ot[2];
+            const xhalf* Kp = KL + half * KV_BLOCK_HALFS;
+            const xhalf* Vp = VL + half * KV_BLOCK_HALFS;
+            const bool no = attention_oneblock_x(qo, Kp, Vp, kb + half * KEYPAD, head, lane, oo);
+            const bool nt = attention_oneblock_x(qt, Kp, Vp, kb + half * KEYPAD, head, lane, ot);
+            planes_store_c<false>(P2 + half * PS, 2 * head, lane, oo[0]);
+            planes_store_c<false>(P2 + half * PS, 2 * head + 1, lane, oo[1]);
+            const int grp = m >> 2;  // tail rows 0 .. 3 / 4 .. 7 belong to polyline 0 / 1, rows 8 .. 15 are padding (written by the wave of polyline 0)
+            const bool mine = grp == half, pad = half == 0 && grp >= 2;
+            if (mine || pad) {
+                const f32x4 z = splat(0.f);
+                planes_store_c<false>(P2 + 2 * PS, 2 * head, lane, mine ? ot[0] : z);
+                planes_store_c<false>(P2 + 2 * PS, 2 * head + 1, lane, mine ? ot[1] : z);
+            }
+            if (head == 0 && kq == 0) {
+                novalid_s[half * TM + m] = no ? 1 : 0;
+                if (mine || pad) novalid_s[2 * TM + m] = (mine ? nt : true) ? 1 : 0;
+            }
+        }
+        __syncthreads();
+        {
+            f32x4 a[3];
+            gemm3(u2, u, wnext1x(p.W, LX.w1, p.W + L.b1, wave), P2, a);
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                const bool nv = novalid_s[t * TM + m] != 0;
+                float* px = cptr(X + t * TM * LDT, LDT, wave, lane);
+                const f32x4 xo = lds4(px);
+                st4(px, nv ? xo : xo + a[t]);
+            }
+        }
+        __syncthreads();
+        layernorm_planes_3x8(X, P1, PS, lnblk + 512, lnblk + 640, tid);
+        __syncthreads();
+        {
+            f32x4 a[3];
+            gemm3(u, u2, wnext1x(p.W, LX.w2, p.W + L.b2, wave), P1, a);
+#pragma unroll
+            for (int t = 0; t < 3; ++t) planes_store_c(P2 + t * PS, wave, lane, relu4(a[t]));
+        }
+        __syncthreads();
+        {
+            f32x4 a[3];
+            const int ln = l + 1 < p.n_layer ? l + 1 : l;
+            gemm3(u2, u, wnext1x(p.W, p.LX[ln].wkv, p.W + p.L[ln].bkv, wave), P2, a);
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                const bool rv = rowvalid[t * TM + m] != 0;
+                float* px = cptr(X + t * TM * LDT, LDT, wave, lane);
+                st4(px, rv ? lds4(px) + a[t] : splat(0.f));
+            }
+        }
+        __syncthreads();
+    }
+    if (tid < NTHREADS) {  // MapEncoder: max over the valid nodes of the polyline, one (polyline, feature) per thread (k_polyline_fused)
+        const int pl = tid >> 7, f = tid & 127;
+        float mx = -INFINITY;
+        bool any = false;
+#pragma unroll
+        for (int k = 0; k < PL_NODES; ++k) {
+            const int t = k < TM ? pl : 2, r = k < TM ? k : pl * 4 + (k - TM);
+            if (rowvalid[t * TM + r]) {
+                any = true;
+                mx = fmaxf(mx, X[(t * TM + r) * LDT + f]);
+            }
+        }
+        p.pool_out[(size_t)(g0 + pl) * H + f] = any ? mx : 0.f;
+        if (f == 0) p.pool_valid[g0 + pl] = any;
+    }
+}
+
+void launch_polyline_fused_x(const XBlockPX& p, int G, hipStream_t s, bool eight_waves) {
     const size_t lds = PLF_LDS_BYTES + (NPL == 1 ? 3 * TM * LDT * 4 : 0);
-    hipLaunchKernelGGL(k_polyline_fused, dim3(G / 2), dim3(NTHREADS), lds, s, p);
+    if (eight_waves) hipLaunchKernelGGL(k_polyline_fused8, dim3(G / 2), dim3(NT8), lds, s, p);
+    else hipLaunchKernelGGL(k_polyline_fused, dim3(G / 2), dim3(NTHREADS), lds, s, p);
 }
 
 // hoist + block of the polyline encoder on the packed tiling; `p` as for launch_xblock_x (n_rows = 20, n_pad = 32, tgt = src)
@@ -764,6 +971,9 @@ hipError_t configure_encodex_kernels() {
     const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_polyline_fused), hipFuncAttributeMaxDynamicSharedMemorySize,
                                              PLF_LDS_BYTES + (NPL == 1 ? 3 * TM * LDT * 4 : 0));
     if (e != hipSuccess) return e;
+    const hipError_t e8 = hipFuncSetAttribute(reinterpret_cast<const void*>(k_polyline_fused8), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                              PLF_LDS_BYTES + (NPL == 1 ? 3 * TM * LDT * 4 : 0));
+    if (e8 != hipSuccess) return e8;
     return hipFuncSetAttribute(reinterpret_cast<const void*>(k_gru_scan_x), hipFuncAttributeMaxDynamicSharedMemorySize, SCANX_LDS_BYTES);
 }
 

@@ -97,7 +97,8 @@ struct CInputs {
 template <int NT, int NSRC = 6, bool DG_LDS = true>
 __device__ __forceinline__ void c_inputs_issue(const RolloutP& p, int n, int row0, int tid, CInputs<NT>& c) {
     const size_t base_row = (size_t)n * p.a_pad + row0;
-    const float* src[6] = {p.x_mid + base_row * H,
+    const size_t x_row = p.pre_shared ? (size_t)(n - n % p.k_rep) * p.a_pad + row0 : base_row;  // (RolloutP::pre_shared)
+    const float* src[6] = {p.x_mid + x_row * H,
                            p.hidden + (((size_t)0 * p.n_inst + n) * p.a_pad + row0) * H,
                            p.hidden + (((size_t)1 * p.n_inst + n) * p.a_pad + row0) * H,
                            p.hidden + (((size_t)2 * p.n_inst + n) * p.a_pad + row0) * H,

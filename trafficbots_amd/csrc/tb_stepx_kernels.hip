@@ -263,7 +263,7 @@ __global__ __launch_bounds__(AWB ? 2 * NTHREADS : NTHREADS, LEAN ? (W3 ? 3 : 2) 
     step_tile_map(n, rt);
     if (PRE) t = p.pre_t0 + (int)blockIdx.z;  // batched warm start: A(t + 1) of step t from the ground truth of step t
     // (the K futures of a scene share the ground truth: the batched launch runs once per SCENE, in the slot of future 0, and
-    // k_pre_replicate copies the slices to the other futures)
+    // the C halves of the other futures read that slot: RolloutP::pre_shared)
     const int b = PRE ? n : n / p.k_rep;
     if (PRE) n = b * p.k_rep;
     const int row0 = rt * TM;
@@ -287,9 +287,11 @@ __global__ __launch_bounds__(AWB ? 2 * NTHREADS : NTHREADS, LEAN ? (W3 ? 3 : 2) 
         }
         {
             const size_t ls = (size_t)p.a_pad * H;
-            xhalf* K0 = reinterpret_cast<xhalf*>(p.kin + ((size_t)n * 3) * ls);
-            xhalf* V0 = reinterpret_cast<xhalf*>(p.vtin + ((size_t)n * 3) * ls);
-            kv_helper_x(W, px.inter_kvf, px.inter_bkvf, p.x_mid + base_row * H, X, PD, reinterpret_cast<xhalf*>(Hs), K0, V0, ls, row0,
+            // (pre_shared: the helpers of the K futures of a scene write the same values into the scene's one slice)
+            const int ns = p.pre_shared ? b * p.k_rep : n;
+            xhalf* K0 = reinterpret_cast<xhalf*>(p.kin + ((size_t)ns * 3) * ls);
+            xhalf* V0 = reinterpret_cast<xhalf*>(p.vtin + ((size_t)ns * 3) * ls);
+            kv_helper_x(W, px.inter_kvf, px.inter_bkvf, p.x_mid + ((size_t)ns * p.a_pad + row0) * H, X, PD, reinterpret_cast<xhalf*>(Hs), K0, V0, ls, row0,
                         p.kv_flag + (size_t)tile_id * 2, (unsigned int)t + 1u, tid, uh, wnextx(W, px.gru[0].whh, nullptr, 2 * wave, 2 * wave + 1),
                         hmax);
         }
@@ -391,8 +393,9 @@ __global__ __launch_bounds__(AWB ? 2 * NTHREADS : NTHREADS, LEAN ? (W3 ? 3 : 2) 
         if (!bypass) {
             const float* kvd = p.vbias + (size_t)n * p.a_pad;
             const size_t ls = (size_t)p.a_pad * H;
-            const xhalf* K0 = reinterpret_cast<const xhalf*>(p.kin + ((size_t)n * 3) * ls);
-            const xhalf* V0 = reinterpret_cast<const xhalf*>(p.vtin + ((size_t)n * 3) * ls);
+            const int ns = p.pre_shared ? b * p.k_rep : n;  // (a slice of the batched warm start exists once per scene)
+            const xhalf* K0 = reinterpret_cast<const xhalf*>(p.kin + ((size_t)ns * 3) * ls);
+            const xhalf* V0 = reinterpret_cast<const xhalf*>(p.vtin + ((size_t)ns * 3) * ls);
             const unsigned int* kvf = p.kv_flag + (size_t)n * n_rt * 2;
             const unsigned int tok = (unsigned int)t + 1u;
             unsigned int seen = helpers ? kv_peek_x(kvf, n_rt, 1, tid) : 0u;
@@ -786,32 +789,6 @@ void launch_step_x(const RolloutP& p0, int t, int do_c, int do_a, hipStream_t s)
 #endif  // TB_XDL_W3
 
 #ifndef TB_XDL_AW
-// slices of future 0 of every scene -> futures 1 .. K-1 (x_mid rows, K and V of the three layers).  grid (n_pre * n_scene * (K - 1))
-__global__ __launch_bounds__(256) void k_pre_replicate(RolloutP p, int n_pre) {
-    const int km1 = p.k_rep - 1;
-    const int k = 1 + (int)(blockIdx.x % km1), b = (int)((blockIdx.x / km1) % p.n_scene), z = (int)(blockIdx.x / (km1 * p.n_scene));
-    if (z >= n_pre) return;
-    const size_t rowf = (size_t)p.a_pad * H;                         // floats of one instance's x_mid
-    const size_t zx = (size_t)z * p.n_inst * rowf;
-    const size_t src = (size_t)b * p.k_rep, dst = src + k;
-    const f32x4* s0 = reinterpret_cast<const f32x4*>(p.x_mid_pre + zx + src * rowf);
-    f32x4* d0 = reinterpret_cast<f32x4*>(p.x_mid_pre + zx + dst * rowf);
-    const f32x4* s1 = reinterpret_cast<const f32x4*>(p.kin_pre + 3 * zx + src * 3 * rowf);
-    f32x4* d1 = reinterpret_cast<f32x4*>(p.kin_pre + 3 * zx + dst * 3 * rowf);
-    const f32x4* s2 = reinterpret_cast<const f32x4*>(p.vtin_pre + 3 * zx + src * 3 * rowf);
-    f32x4* d2 = reinterpret_cast<f32x4*>(p.vtin_pre + 3 * zx + dst * 3 * rowf);
-    const size_t n4 = rowf / 4;
-    for (size_t i = threadIdx.x; i < n4; i += 256) d0[i] = s0[i];
-    for (size_t i = threadIdx.x; i < 3 * n4; i += 256) {
-        d1[i] = s1[i];
-        d2[i] = s2[i];
-    }
-}
-
-void launch_pre_replicate(const RolloutP& p, int n, hipStream_t s) {
-    hipLaunchKernelGGL(k_pre_replicate, dim3((unsigned)(n * p.n_scene * (p.k_rep - 1))), dim3(256), 0, s, p, n);
-}
-
 // A halves of steps t0 + 1 .. t0 + n from the ground truth of steps t0 .. t0 + n - 1, one launch (RolloutP::pre_mode)
 void launch_step_pre_x(const RolloutP& p0, int t0, int n, hipStream_t s) {
     RolloutP p = p0;
@@ -820,19 +797,16 @@ void launch_step_pre_x(const RolloutP& p0, int t0, int n, hipStream_t s) {
     dim3 grid(p.a_pad / TM, p.n_scene, n);
 #ifdef TB_XDL_W3
     hipLaunchKernelGGL((k_step_x<true, true>), grid, dim3(NTHREADS), STEPX_LEAN_LDS_FLOATS * sizeof(float), s, p, t0, 0, 1);
-    if (p.k_rep > 1) launch_pre_replicate(p, n, s);
 #else
     {
         // n x tiles workgroups: the LEAN carve (two workgroups per CU) whenever that is more than the chip has CUs
         const char* e = getenv("TB_STEP_LEAN");
         if ((size_t)grid.x * grid.y * grid.z > 256 && !(e && e[0] == '0')) {
             hipLaunchKernelGGL((k_step_x<true, true>), grid, dim3(NTHREADS), STEPX_LEAN_LDS_FLOATS * sizeof(float), s, p, t0, 0, 1);
-            if (p.k_rep > 1) launch_pre_replicate(p, n, s);
             return;
         }
     }
     hipLaunchKernelGGL(k_step_x<true>, grid, dim3(NTHREADS), STEPX_LDS_FLOATS * sizeof(float), s, p, t0, 0, 1);
-    if (p.k_rep > 1) launch_pre_replicate(p, n, s);
 #endif
 }
 
