@@ -88,6 +88,28 @@ def load_path(k_us, n_agent, n_pl, n_tl_keys, wbytes=4):
             "peak_B_per_clk_per_CU": 64.0, "frac": per_clk / 64.0}
 
 
+def structural_floor(k_us, n_agent, n_pl, n_tl_keys, wbytes=4, flops=None):
+    """What a fused launch CANNOT go below at 16 rows per workgroup, as numbers (VERDICT r04 task 6): every workgroup pulls its
+    weights + K / V through ONE CU's vector-load path -- at the 64 B/clk an L1 can fill, and at the 42 B/clk four waves sustain on an
+    L2-resident stream (tools/microtests, profiles/r01_microbench_*) -- in series with the cold start of the launch (the C half's
+    tile inputs come back from HBM / MALL behind a kernel boundary: 13 k cycles in profiles/r03_stage_profile_k_step_x.txt).  The
+    latency chains of attention / LayerNorm overlap with the stream only where a weight request is in flight beside them, so the
+    measured launch sits above this floor; `frac_of_nominal_roof_at_floor` is the SURVEY 8(d) fraction the launch would show AT it."""
+    lp = load_path(k_us, n_agent, n_pl, n_tl_keys, wbytes)
+    by = lp["bytes_per_workgroup_launch"]
+    peak_us = by / 64.0 / SHADER_CLK * 1e6
+    sust_us = by / 42.0 / SHADER_CLK * 1e6
+    cold_us = 13000.0 / SHADER_CLK * 1e6
+    floor = sust_us + cold_us
+    r = {"weight_and_kv_bytes_per_workgroup": by, "stream_us_at_64B_per_clk": peak_us, "stream_us_at_42B_per_clk_sustained": sust_us,
+         "cold_start_us": cold_us, "floor_us": floor, "avg_launch_us": k_us, "launch_over_floor": k_us / floor,
+         "serial_chains_us_measured": {"attention_walks": 35000.0 / SHADER_CLK * 1e6, "layernorms_21": 27000.0 / SHADER_CLK * 1e6,
+                                       "source": "profiles/r03_stage_profile_k_step_x.txt (cycles at 2.33 GHz; they overlap the stream only in part)"}}
+    if flops:
+        r["frac_of_nominal_roof_at_floor"] = flops / (floor * 1e-6) / 1e12 / PEAK_FP32_MFMA_TFLOPS
+    return r
+
+
 def mfma_issue(n_agent, n_pl_keys, n_tl_keys, planes):
     """XDL MFMAs (v_mfma_f32_16x16x32_{f16,bf16}) one WAVE issues per fused launch, from the kernel's structure: 67 weight units of
     [32 outputs x 16 agents x 128 k] = 8 MFMAs per product plane-pair (3 products with fp16 pairs, 1 with bf16) minus the 2 hoisted
@@ -688,6 +710,8 @@ def run_rank(args, rank: int, local_rank: int, world: int) -> None:
                              "measured_how": (pmc or {}).get("mfma_busy_how"),
                          },
                          "load_path": load_path(k_us, N_AGENT, N_PL, tl_keys_eff, 4 if prec == "fp32" else 2),
+                         "floor": structural_floor(k_us, N_AGENT, N_PL, tl_keys_eff, 4 if prec == "fp32" else 2, fl),
+                         "floor_us": structural_floor(k_us, N_AGENT, N_PL, tl_keys_eff, 4 if prec == "fp32" else 2, fl)["floor_us"],
                          "hbm": ({"achieved": traffic / (k_us * 1e-6) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                   "frac": traffic / (k_us * 1e-6) / 1e9 / PEAK_HBM_GBS,
                                   "algorithmic_bytes_per_launch": bytes_step(N_AGENT, N_PL, N_TL, 4) * n_inst,

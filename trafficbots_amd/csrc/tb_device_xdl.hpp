@@ -755,6 +755,9 @@ __device__ __forceinline__ bool attention_head_x(const f32x4 (&q)[2], AttnPreX& 
 constexpr int AW_WORDS = 16;                                   // control words (floats of LDS)
 constexpr int AW_PART_LD = 12;                                 // floats per lane of a partial state: o[2] (8), max, sum, pad
 constexpr int AW_PREFIX = AW_WORDS + 4 * 64 * AW_PART_LD;      // floats in front of the step kernel's carve
+// commands to the assist waves: 0 .. 2 = the odd key blocks of map-attention layer l; 255 = leave.  (Splitting the GEMM chains the same
+// way -- W_hh h of a GRU layer / the V halves of the interaction K / V projection on the assist waves -- was built, bit-identical,
+// and lost 1 %: those chains run at the rate one CU's L1 fills, which a second wave does not raise; profiles/r05_experiments.txt.)
 constexpr unsigned AW_OP_EXIT = 255u;
 #else
 constexpr int AW_PREFIX = 0;
@@ -1144,6 +1147,7 @@ __device__ __forceinline__ float* aw_part(int wave, int lane) {
     extern __shared__ __attribute__((aligned(16))) float smem_all[];
     return smem_all + AW_WORDS + (wave * 64 + lane) * AW_PART_LD;
 }
+
 // main waves, thread 0: "at the NEXT barrier: op" (the count of barriers so far is this thread's own word 0)
 __device__ __forceinline__ void aw_post(unsigned int op) {
     unsigned int* w = aw_words();

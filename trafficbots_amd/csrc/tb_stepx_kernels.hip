@@ -163,15 +163,13 @@ void launch_fuse_hoist_x(const RolloutP& p, hipStream_t s) {
 #ifdef TB_XDL_AW
 // The assist waves of a step workgroup (threads 256 .. 511; tb_device_xdl.hpp "Assist waves"): loop on the workgroup barrier, count,
 // and when the main waves' posted barrier number comes up take the odd key blocks of that map-attention layer.
-__device__ __forceinline__ void aw_assist_waves(const RolloutP& p, int do_a, const xhalf* PA) {
+__device__ __forceinline__ void aw_assist_waves(const RolloutP& p, int do_c, int do_a, const xhalf* PA) {
     const int tid = (int)threadIdx.x - NTHREADS, wave = wave_of(tid), lane = tid & 63;
     int n, rt;
     step_tile_map(n, rt);
     const int b = n / p.k_rep, n_rt = gridDim.x;
     const float* W = p.W;
     const volatile unsigned int* aw = aw_words();
-    WUnitX u;
-    if (do_a) wloadx(u, xlayer_first_x(W, p.pw.as2pl[0], p.px.as2pl[0], wave), lane);  // (held while the C half runs)
     const int nkw_p = do_a ? p.nkey_pl[b] : 0;
     const int nk_p = max(32, nkey_walk(nkw_p)), nv_p = nkey_valid(nkw_p);
     const int ks_p = ((rt * (nk_p >> 5)) / n_rt) << 5;
@@ -179,38 +177,49 @@ __device__ __forceinline__ void aw_assist_waves(const RolloutP& p, int do_a, con
     const size_t ls = (size_t)p.p_pad * H;
     const xhalf* K0 = reinterpret_cast<const xhalf*>(p.kpl + ((size_t)b * 3) * ls);
     const xhalf* V0 = reinterpret_cast<const xhalf*>(p.vtpl + ((size_t)b * 3) * ls);
-    // what the wave needs first in a layer -- its copy of the Q unit, the K / V fragments of its first two blocks -- is requested
-    // while it waits for that layer (layer 0: while the C half runs), so that behind the barrier it only reads LDS and computes
 #ifdef TB_AW_DEBUG  // timing experiments (wrong results): TB_DEBUG_HELPER_DELAY bit 0 = no priority, bit 1 = the assist waves skip their blocks
     const LeanSeq sq = lean_seq((p.dbg_helper_delay & 2) ? 32 : nk_p, (p.dbg_helper_delay & 2) ? 32 : nv_p, ks_p, 2);
 #else
     const LeanSeq sq = lean_seq(nk_p, nv_p, ks_p, 2);
 #endif
-    AttnPreX apre;
-    if (do_a) attention_prefetch_lean_x<2>(apre, K0, V0, kvd, sq, wave, lane);
+    // The commands of a launch come in a fixed order -- the three map-attention layers of the A half, then "leave" -- so the wave's
+    // code is linear (what it prefetches is live from the request to its use and not
+    // through a loop) and only the NUMBER of barriers in front of each command is data: `wait` loops on the workgroup barrier until
+    // the main waves' posted barrier number comes up.  An unexpected command ends the wave (wrong numbers, never a hang).
     unsigned int n_seen = 0u;
-    for (;;) {
-        aw_bare_sync();
-        // (a step has ~200 barriers: the bound turns any mismatch between the two counts into wrong numbers instead of four waves
-        // that spin on the barrier among themselves after the main waves have left)
-        if (++n_seen > 8192u) return;
-        if (aw[1] != n_seen) continue;
-        const unsigned int op = aw[2];
-        if (op > 2u) return;
-#ifdef TB_AW_DEBUG
-        if (!(p.dbg_helper_delay & 1))
-#endif
-        __builtin_amdgcn_s_setprio(1);
-        aw_assist_layer_x(u, apre, PA, K0 + 2 * op * ls, V0 + 2 * op * ls, kvd, sq, wave, lane);
-        __builtin_amdgcn_s_setprio(0);
-        if (op < 2u) {
-            if (op == 0u) wloadx(u, xlayer_first_x(W, p.pw.as2pl[1], p.px.as2pl[1], wave), lane);
-            else wloadx(u, xlayer_first_x(W, p.pw.as2pl[2], p.px.as2pl[2], wave), lane);
-            attention_prefetch_lean_x<2>(apre, K0 + 2 * (op + 1) * ls, V0 + 2 * (op + 1) * ls, kvd, sq, wave, lane);
+    auto wait = [&]() -> unsigned int {
+        for (;;) {
+            aw_bare_sync();
+            // (a step has ~200 barriers: the bound turns any mismatch between the two counts into wrong numbers instead of four
+            // waves that spin on the barrier among themselves after the main waves have left)
+            if (++n_seen > 8192u) return AW_OP_EXIT;
+            if (aw[1] == n_seen) return aw[2];
         }
-        aw_bare_sync();  // publishes the state (the main waves' merge barrier)
-        ++n_seen;
+    };
+    if (do_a) {
+        // what the wave needs first in a layer -- its copy of the Q unit, the K / V fragments of its first two blocks -- is requested
+        // while it waits for that layer, so that behind the barrier it only reads LDS and computes
+        WUnitX u;
+        AttnPreX apre;
+        wloadx(u, xlayer_first_x(W, p.pw.as2pl[0], p.px.as2pl[0], wave), lane);
+        attention_prefetch_lean_x<2>(apre, K0, V0, kvd, sq, wave, lane);
+#pragma unroll
+        for (int l = 0; l < 3; ++l) {
+            if (wait() != (unsigned int)l) return;
+#ifdef TB_AW_DEBUG
+            if (!(p.dbg_helper_delay & 1))
+#endif
+            __builtin_amdgcn_s_setprio(1);
+            aw_assist_layer_x(u, apre, PA, K0 + 2 * l * ls, V0 + 2 * l * ls, kvd, sq, wave, lane);
+            __builtin_amdgcn_s_setprio(0);
+            if (l < 2) {
+                wloadx(u, xlayer_first_x(W, p.pw.as2pl[l + 1], p.px.as2pl[l + 1], wave), lane);
+                attention_prefetch_lean_x<2>(apre, K0 + 2 * (l + 1) * ls, V0 + 2 * (l + 1) * ls, kvd, sq, wave, lane);
+            }
+            // (the next barrier publishes the state: the main waves' merge barrier)
+        }
     }
+    (void)wait();  // "leave"
 }
 #endif
 
@@ -232,7 +241,7 @@ __global__ __launch_bounds__(AWB ? 2 * NTHREADS : NTHREADS, LEAN ? (W3 ? 3 : 2) 
         w[2] = AW_OP_EXIT;
     }
     if (threadIdx.x >= NTHREADS) {
-        aw_assist_waves(p, do_a, reinterpret_cast<const xhalf*>(smem + XO_PL));
+        aw_assist_waves(p, do_c, do_a, reinterpret_cast<const xhalf*>(smem + XO_PL));
         return;
     }
 #endif
