@@ -27,6 +27,7 @@ hipError_t configure_rollout_kernels();
     hipError_t configure_stepx_kernel();                                                                                          \
     void launch_fuse_hoist_x(const RolloutP& p, hipStream_t s);                                                                   \
     void launch_step_pre_x(const RolloutP& p, int t0, int n, hipStream_t s);                                                      \
+    void launch_inter_pre_x(const RolloutP& p, int t0, int n, hipStream_t s);                                                     \
     void launch_kv_hoist_x(const float* W, const XLayerW* L3, const XLayerX* X3, const float* feat, const uint8_t* fvalid, int G, \
                            int n_tok, int n_pad, float* K, float* VT, float* kbias, int* nkey, hipStream_t s);                    \
     }
@@ -39,6 +40,7 @@ namespace xb3 {     // bf16, three workgroups per CU (tb_stepx_bf16w3_kernels.hi
 void launch_step_x(const RolloutP& p, int t, int do_c, int do_a, hipStream_t s);
 hipError_t configure_stepx_kernel();
 void launch_step_pre_x(const RolloutP& p, int t0, int n, hipStream_t s);
+void launch_inter_pre_x(const RolloutP& p, int t0, int n, hipStream_t s);
 }
 namespace xba {     // bf16, eight-wave workgroups with assist waves (tb_stepx_bf16aw_kernels.hip): one workgroup per CU over >= 512 polylines
 void launch_step_x(const RolloutP& p, int t, int do_c, int do_a, hipStream_t s);
@@ -802,6 +804,8 @@ static void carve_rollout(tb::RolloutP& p, Carver& c, bool with_gh) {
         p.x_mid_pre = c.take<float>(n_pre * N * p.a_pad * 128);
         p.kin_pre = c.take<float>(n_pre * N * 3 * p.a_pad * 128);
         p.vtin_pre = c.take<float>(n_pre * N * 3 * 128 * p.a_pad);
+        p.x_int_pre = c.take<float>(n_pre * N * p.a_pad * 128);
+        p.vbias_pre = c.take<float>(n_pre * N * p.a_pad);
     }
     for (int k = 0; k < 2; ++k) {
         p.kin_b[k] = c.take<float>(N * 3 * p.a_pad * 128);
@@ -960,7 +964,7 @@ static void rollout_prologue(const tb_ctx* ctx, const tb::RolloutP& p, const tb_
 static int rollout_enqueue(tb_ctx* ctx, const tb_rollout_io* io, const tb::RolloutP& p, hipStream_t s);
 
 // every launch-shaping development switch read below this call (step_launch, rollout_prologue): part of the graph key
-static const char* const kGraphEnv[] = {"TB_STEP_W3", "TB_STEP_AW", "TB_STEP_LEAN", "TB_STEP_HELPERS", "TB_GRU_HELPER", "TB_DEBUG_HELPER_DELAY", "TB_STEP_KERNEL"};
+static const char* const kGraphEnv[] = {"TB_STEP_W3", "TB_STEP_AW", "TB_STEP_PRE_INTER", "TB_STEP_LEAN", "TB_STEP_HELPERS", "TB_GRU_HELPER", "TB_DEBUG_HELPER_DELAY", "TB_STEP_KERNEL"};
 
 static void key_append(std::vector<unsigned char>& k, const void* data, size_t n) {
     const unsigned char* b = static_cast<const unsigned char*>(data);
@@ -1034,6 +1038,11 @@ extern "C" int tb_rollout(tb_ctx* ctx, const tb_rollout_io* io, tb_stream stream
     return 0;
 }
 
+static bool pre_inter() {
+    const char* e = getenv("TB_STEP_PRE_INTER");
+    return !(e && e[0] == '0');
+}
+
 static int rollout_enqueue(tb_ctx* ctx, const tb_rollout_io* io, const tb::RolloutP& p, hipStream_t s) {
     const int step_start = p.step_start;
     const int n_steps = p.n_step_out;
@@ -1056,6 +1065,13 @@ static int rollout_enqueue(tb_ctx* ctx, const tb_rollout_io* io, const tb::Rollo
         if (ctx->step_kernel == 3 && w3_launch((size_t)(p.a_pad / tb::TM) * p.n_scene * n_pre)) tb::xb3::launch_step_pre_x(p, t_pre0, n_pre, s);
         else if (ctx->step_kernel == 3) tb::xb::launch_step_pre_x(p, t_pre0, n_pre, s);
         else tb::xh::launch_step_pre_x(p, t_pre0, n_pre, s);
+        // ... and behind it the interaction blocks of the same steps, once per scene (RolloutP::x_int_pre; TB_STEP_PRE_INTER=0 keeps
+        // them in the step-by-step launches: development / A-B switch)
+        if (pre_inter()) {
+            if (ctx->step_kernel == 3 && w3_launch((size_t)(p.a_pad / tb::TM) * p.n_scene * n_pre)) tb::xb3::launch_inter_pre_x(p, t_pre0, n_pre, s);
+            else if (ctx->step_kernel == 3) tb::xb::launch_inter_pre_x(p, t_pre0, n_pre, s);
+            else tb::xh::launch_inter_pre_x(p, t_pre0, n_pre, s);
+        }
     }
     // ---- the sequential loop (waymo_motion.py:269): launch i runs C(start+i-1) then A(start+i); no host sync
     ctx->launch_kind.assign(n_launch, 0);
@@ -1066,7 +1082,8 @@ static int rollout_enqueue(tb_ctx* ctx, const tb_rollout_io* io, const tb::Rollo
         if (t - t_pre0 < n_pre) do_a = 0;                  // A(t+1) came out of the batched launch
         if (do_c && t - 1 - t_pre0 < n_pre && t - 1 >= t_pre0) {  // C(t) consumes slice t-1-t_pre0 of the batched results
             const size_t z = (size_t)(t - 1 - t_pre0) * p.n_inst * p.a_pad * 128;
-            q.x_mid = p.x_mid_pre + z;
+            q.x_mid = (pre_inter() ? p.x_int_pre : p.x_mid_pre) + z;
+            q.skip_inter = pre_inter();
             q.pre_shared = p.k_rep > 1;  // (the slices exist once per scene, in the slot of future 0: no replication)
             q.kin_b[0] = q.kin_b[1] = p.kin_pre + 3 * z;     // (read side only: step_launch picks by parity, the write side is restored below)
             q.vtin_b[0] = q.vtin_b[1] = p.vtin_pre + 3 * z;

@@ -136,6 +136,13 @@ struct RolloutP {
     float* x_mid_pre;             // [n_pre][N,a_pad,128]
     float* kin_pre;               // [n_pre][N,3,a_pad,128]
     float* vtin_pre;              // [n_pre][N,3,128,a_pad]
+    // round 5: the INTERACTION of the warm-start steps is batched as well (pre_mode = 2, one more launch of n x tiles workgroups behind
+    // the first): C(t + 1)'s three interaction layers read only what the batched A halves wrote (x_mid, the interaction K / V of every
+    // row tile of the scene) and the ground-truth validity of step t, so slice z of x_int_pre takes the residual stream behind them,
+    // once per scene; the C launches of those steps start at the GRU (skip_inter) with x_mid pointed at that slice
+    float* x_int_pre;             // [n_pre][N,a_pad,128]
+    float* vbias_pre;             // [n_pre][N,a_pad]   key bias of the interaction from the ground-truth validity (written by pre_mode 1)
+    int skip_inter;
     float* kin;                   // [N,3,a_pad,128]
     float* vtin;                  // [N,3,128,a_pad]
     float* goal_pre;              // [N,a_pad,128]

@@ -283,6 +283,44 @@ __global__ __launch_bounds__(AWB ? 2 * NTHREADS : NTHREADS, LEAN ? (W3 ? 3 : 2) 
     const size_t base_row = (size_t)n * p.a_pad + row0;
     // staggered start of the key walks of the row tiles of one instance (attention_prefetch_x)
     const int n_rt = gridDim.x;
+    if (PRE && p.pre_mode == 2) {
+        // ---- batched warm start, second launch: the three interaction layers of C(t + 1) for this scene tile (RolloutP::x_int_pre).
+        // The code of the C half below with its inputs redirected: x_mid / K / V from slice z of the first launch, validity and key
+        // bias from the ground truth of step t.  Same functions, same key order, same bits as the step-by-step launches.
+        const size_t zslice = (size_t)blockIdx.z * p.n_inst * p.a_pad * H;
+        WUnitX u;
+        RangeMax amax;
+        wloadx(u, xlayer_first_x(W, pw.inter[0], px.inter[0], wave), lane);
+        const uint8_t* hv = p.hist_valid + ((size_t)b * p.n_hist + t) * p.n_agent;
+        int n_valid = 0, hi_valid = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = i * 64 + lane;
+            const unsigned long long vm = __ballot(idx < p.n_agent && hv[min(idx, p.n_agent - 1)] != 0);
+            n_valid += __popcll(vm);
+            if (vm) hi_valid = i * 64 + 64 - __clzll(vm);
+        }
+        load_tile(X, LDT, p.x_mid_pre + zslice + base_row * H, TM, tid);
+        if (tid < TM) rowvalid[tid] = tid < n_real ? hv[row0 + tid] : (uint8_t)0;
+        __syncthreads();
+        if (n_valid != 1) {  // (agent_interaction.py:61: a single valid agent skips the block)
+            const int nk_a = min(p.a_pad, max(32, (hi_valid + 31) & ~31));
+            const int ks_a = ((rt * (nk_a >> 5)) / n_rt) << 5;
+            const float* kvd = p.vbias_pre + ((size_t)blockIdx.z * p.n_inst + n) * p.a_pad;
+            const size_t ls = (size_t)p.a_pad * H;
+            const xhalf* K0 = reinterpret_cast<const xhalf*>(p.kin_pre + 3 * zslice + ((size_t)n * 3) * ls);
+            const xhalf* V0 = reinterpret_cast<const xhalf*>(p.vtin_pre + 3 * zslice + ((size_t)n * 3) * ls);
+            xattn_layer_x<false, true>(W, pw.inter[0], px.inter[0], X, PA, PB, K0, V0, kvd, nk_a, ks_a, row0, rowvalid, novalid_s, tid, u,
+                                       xlayer_first_x(W, pw.inter[1], px.inter[1], wave), nullptr, nullptr, amax);
+            xattn_layer_x<false, true>(W, pw.inter[1], px.inter[1], X, PA, PB, K0 + 2 * ls, V0 + 2 * ls, kvd, nk_a, ks_a, row0, rowvalid, novalid_s, tid,
+                                       u, xlayer_first_x(W, pw.inter[2], px.inter[2], wave), nullptr, nullptr, amax);
+            xattn_layer_x<false, true>(W, pw.inter[2], px.inter[2], X, PA, PB, K0 + 4 * ls, V0 + 4 * ls, kvd, nk_a, ks_a, row0, rowvalid, novalid_s, tid,
+                                       u, xlayer_first_x(W, pw.inter[2], px.inter[2], wave), nullptr, nullptr, amax);
+        }
+        store_tile(p.x_int_pre + zslice + base_row * H, X, LDT, TM, tid);
+        range_flush(amax);
+        return;
+    }
     const int tile_id = n * n_rt + rt;
     const bool helpers = !W3 && !AWB && !PRE && gridDim.z == 2;
     if (helpers && blockIdx.z == 0) {
@@ -294,7 +332,7 @@ __global__ __launch_bounds__(AWB ? 2 * NTHREADS : NTHREADS, LEAN ? (W3 ? 3 : 2) 
             const long long t0 = clock64();
             while (clock64() - t0 < p.dbg_helper_delay) __builtin_amdgcn_s_sleep(32);
         }
-        {
+        if (!p.skip_inter) {  // (skip_inter: the interaction of this step came out of the batched warm start)
             const size_t ls = (size_t)p.a_pad * H;
             // (pre_shared: the helpers of the K futures of a scene write the same values into the scene's one slice)
             const int ns = p.pre_shared ? b * p.k_rep : n;
@@ -306,7 +344,7 @@ __global__ __launch_bounds__(AWB ? 2 * NTHREADS : NTHREADS, LEAN ? (W3 ? 3 : 2) 
         }
         gru_hh_helper(W, px.gru, p.hidden + (((size_t)0 * p.n_inst + n) * p.a_pad + row0) * H,
                       p.hidden + (((size_t)1 * p.n_inst + n) * p.a_pad + row0) * H, p.hidden + (((size_t)2 * p.n_inst + n) * p.a_pad + row0) * H,
-                      p.gh + (size_t)tile_id * GH_TILE_FLOATS, p.gh_flag + tile_id, (unsigned int)t + 1u, PA, tid, uh, true);
+                      p.gh + (size_t)tile_id * GH_TILE_FLOATS, p.gh_flag + tile_id, (unsigned int)t + 1u, PA, tid, uh, !p.skip_inter);
         range_flush(hmax);
         return;
     }
@@ -332,7 +370,8 @@ __global__ __launch_bounds__(AWB ? 2 * NTHREADS : NTHREADS, LEAN ? (W3 ? 3 : 2) 
     EncWRegs encw;
     EpiRegs epi;
     TB_SCHED_FENCE();
-    wloadx(u, do_c ? xlayer_first_x(W, pw.inter[0], px.inter[0], wave) : xlayer_first_x(W, pw.as2pl[0], px.as2pl[0], wave), lane);
+    wloadx(u, do_c ? (p.skip_inter ? gru_first_x(W, pw.gru[0], px.gru[0], wave) : xlayer_first_x(W, pw.inter[0], px.inter[0], wave))
+                   : xlayer_first_x(W, pw.as2pl[0], px.as2pl[0], wave), lane);
     if (tid < TM) {
         const size_t si = base_row + tid;
         rs_ty = (tid < n_real) ? p.agent_type[(size_t)b * p.n_agent + row0 + tid] : -1;
@@ -384,7 +423,9 @@ __global__ __launch_bounds__(AWB ? 2 * NTHREADS : NTHREADS, LEAN ? (W3 ? 3 : 2) 
             n_valid += __popcll(vm);
             if (vm) hi_valid = i * 64 + 64 - __clzll(vm);
         }
-        const bool bypass = n_valid == 1;  // agent_interaction.py:61
+        const bool bypass1 = n_valid == 1;  // agent_interaction.py:61
+        // (skip_inter: x_mid points at the residual stream BEHIND the interaction block, RolloutP::x_int_pre)
+        const bool bypass = bypass1 || p.skip_inter != 0;
         // keys past the last valid agent are all masked: the interaction walks only the key blocks in front of it (exact; real
         // scenes keep their valid agents in the leading slots)
         const int nk_a = min(p.a_pad, max(32, (hi_valid + 31) & ~31));
@@ -395,7 +436,7 @@ __global__ __launch_bounds__(AWB ? 2 * NTHREADS : NTHREADS, LEAN ? (W3 ? 3 : 2) 
             for (int sl = 0; sl < 9; ++sl)
                 if (tid < 192) st4(LN + sl * 768 + tid * 4, lnv[sl]);
         }
-        if (bypass) wloadx(u, gru_first_x(W, pw.gru[0], px.gru[0], wave), lane);
+        if (bypass1 && !p.skip_inter) wloadx(u, gru_first_x(W, pw.gru[0], px.gru[0], wave), lane);
         __syncthreads();
         TB_STAMP(1);
         unsigned int gh_seen = 0u;  // the GRU helper's flag, requested one interaction layer early (thread 0)
@@ -627,6 +668,8 @@ __global__ __launch_bounds__(AWB ? 2 * NTHREADS : NTHREADS, LEAN ? (W3 ? 3 : 2) 
     TB_STAMP(10);
     const size_t zslice = PRE ? (size_t)blockIdx.z * p.n_inst * p.a_pad * H : 0;  // floats per x_mid slice; K / V slices are 3x
     store_tile((PRE ? p.x_mid_pre + zslice : p.x_mid_w) + base_row * H, X, LDT, TM, tid);
+    if (PRE && tid < TM)  // the interaction's key bias of C(t + 1) from the ground-truth validity of step t (pre_mode 2 reads it)
+        p.vbias_pre[((size_t)blockIdx.z * p.n_inst + n) * p.a_pad + row0 + tid] = rowvalid[tid] ? 0.f : -INFINITY;
     {
         const size_t ls = (size_t)p.a_pad * H;
         xhalf* K0 = reinterpret_cast<xhalf*>((PRE ? p.kin_pre + 3 * zslice : p.kin_w) + ((size_t)n * 3) * ls);
@@ -809,6 +852,26 @@ void launch_step_pre_x(const RolloutP& p0, int t0, int n, hipStream_t s) {
 #else
     {
         // n x tiles workgroups: the LEAN carve (two workgroups per CU) whenever that is more than the chip has CUs
+        const char* e = getenv("TB_STEP_LEAN");
+        if ((size_t)grid.x * grid.y * grid.z > 256 && !(e && e[0] == '0')) {
+            hipLaunchKernelGGL((k_step_x<true, true>), grid, dim3(NTHREADS), STEPX_LEAN_LDS_FLOATS * sizeof(float), s, p, t0, 0, 1);
+            return;
+        }
+    }
+    hipLaunchKernelGGL(k_step_x<true>, grid, dim3(NTHREADS), STEPX_LDS_FLOATS * sizeof(float), s, p, t0, 0, 1);
+#endif
+}
+
+// the interaction blocks of C(t0 + 1) .. C(t0 + n) from the slices of launch_step_pre_x, one launch (RolloutP::pre_mode = 2)
+void launch_inter_pre_x(const RolloutP& p0, int t0, int n, hipStream_t s) {
+    RolloutP p = p0;
+    p.pre_mode = 2;
+    p.pre_t0 = t0;
+    dim3 grid(p.a_pad / TM, p.n_scene, n);
+#ifdef TB_XDL_W3
+    hipLaunchKernelGGL((k_step_x<true, true>), grid, dim3(NTHREADS), STEPX_LEAN_LDS_FLOATS * sizeof(float), s, p, t0, 0, 1);
+#else
+    {
         const char* e = getenv("TB_STEP_LEAN");
         if ((size_t)grid.x * grid.y * grid.z > 256 && !(e && e[0] == '0')) {
             hipLaunchKernelGGL((k_step_x<true, true>), grid, dim3(NTHREADS), STEPX_LEAN_LDS_FLOATS * sizeof(float), s, p, t0, 0, 1);
