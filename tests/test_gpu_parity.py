@@ -1126,6 +1126,9 @@ def test_helper_handoff_timeout_fails_loudly(monkeypatch):
     eps = torch.from_numpy(synth.make_latent_noise(3, 3, 20)).cuda()
     monkeypatch.setenv("TB_STEP_HELPERS", "1")
     monkeypatch.setenv("TB_DEBUG_HELPER_DELAY", "1200000000")
+    # (round 5: the interaction of the teacher-forced steps comes out of the batched warm start, where no hand-off exists; the two
+    # steps of this case are such steps, so the batching is switched off to keep the helper -> tile hand-off under test)
+    monkeypatch.setenv("TB_STEP_PRE_INTER", "0")
     wm = _engine({"time_step_end": 2, "n_joint_future": 1}, sd)
     wm.check_range = False
     buf = wm.test_step(batch, latent_eps=eps)["rollout_buffer"]

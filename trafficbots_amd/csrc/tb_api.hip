@@ -449,6 +449,7 @@ void tb_destroy(tb_ctx* ctx) {
     if (ctx->d_ws) (void)hipFree(ctx->d_ws);
     if (ctx->d_rule_ws) (void)hipFree(ctx->d_rule_ws);
     if (ctx->d_status) (void)hipFree(ctx->d_status);
+    if (ctx->d_warm_tab) (void)hipFree(ctx->d_warm_tab);
     if (ctx->d_raw) (void)hipFree(ctx->d_raw);
     if (ctx->d_fw) (void)hipFree(ctx->d_fw);
     for (auto e : ctx->ev) (void)hipEventDestroy(e);
@@ -648,6 +649,7 @@ int tb_finalize_weights(tb_ctx* ctx, tb_stream stream) {
     // overflow under it -- gets the XDL kernels back with in-range weights; an open stepwise rollout belongs to the old weights)
     ctx->step_kernel = ctx->step_kernel0;
     ctx->encode_kernel = ctx->encode_kernel0;
+    ctx->warm_key = -1;  // (the L2 warmers' table holds arena offsets)
     ctx->precision_reason = 0;
     ctx->precision_note.clear();
     ctx->step_active = false;
@@ -923,6 +925,47 @@ static int rollout_setup(tb_ctx* ctx, const tb_rollout_io* io, tb::RolloutP& p) 
         TB_HIP(ctx, hipMemset(ctx->d_status, 0, 2 * sizeof(unsigned int)));
     }
     p.sync_err = ctx->d_status + 1;
+    if (with_gh && ctx->step_kernel >= 2) {
+        // L2 warmers (tb_stepx_kernels.hip): request times of the weight units of a fused launch, cycles since launch start, from the
+        // stage profiles (profiles/r03_stage_profile_k_step_x.txt, fp16 pairs: prologue 13 k, an interaction layer 9.2 k + 2.2 k per
+        // key block, GRU 23 k, fusion 9 k, head 9 k, epilogue + front 10 k, a map layer 9.2 k + 1.12 k per key block, a
+        // traffic-light layer 11.3 k; bf16 operands: x 0.7).  Only what follows the helpers' own work is listed.  TB_STEP_WARM=0: off.
+        const char* we = getenv("TB_STEP_WARM");
+        const long long key = ((long long)p.p_pad << 32) | ((long long)p.a_pad << 8) | ctx->step_kernel;
+        if (we && we[0] == '0') {
+            p.warm_tab = nullptr;
+        } else {
+            if (key != ctx->warm_key) {
+                const tb::PolicyWX& x = ctx->step_kernel == 3 ? ctx->pxb : ctx->px;
+                const double sc = ctx->step_kernel == 3 ? 0.7 : 1.0;
+                const uint32_t gate = ctx->step_kernel == 3 ? 8192u : 16384u;  // floats of one 128 x 128 unit in the arena (bf16: one plane)
+                std::vector<int> tab;
+                auto add = [&](uint32_t off, double t) { tab.push_back((int)off); tab.push_back((int)(t * sc)); };
+                const double t_inter = 9200.0 + 2240.0 * (p.a_pad / 32), t_pl = 9200.0 + 1120.0 * (p.p_pad / 32), t_tl = 11300.0;
+                double t = 13000.0 + 3 * t_inter;  // the GRU
+                for (int l = 0; l < 3; ++l)
+                    for (int g = 0; g < 3; ++g) add(x.gru[l].wih + (uint32_t)g * gate, t + (l * 3 + g) * 2500.0 - 1700.0);
+                t += 23000.0;
+                add(x.goal_out_w1, t - 1700.0); add(x.goal_out_w2, t); add(x.lat_out_w1, t + 2500.0); add(x.lat_out_w2, t + 4800.0);
+                t += 9000.0;
+                for (int ty = 0; ty < 3; ++ty) add(x.head_w1[ty], t - 2000.0 + ty * 2000.0);
+                t += 9000.0 + 10000.0;  // head, epilogue, the A half's front end
+                for (int l = 0; l < 3; ++l, t += t_pl) {
+                    add(x.as2pl[l].wq, t - 1700.0); add(x.as2pl[l].wo, t + 2000.0); add(x.as2pl[l].w1, t + t_pl - 5000.0); add(x.as2pl[l].w2, t + t_pl - 2700.0);
+                }
+                for (int l = 0; l < 3; ++l, t += t_tl) {
+                    add(x.as2tl[l].wq, t - 1700.0); add(x.as2tl[l].wo, t + 2000.0); add(x.as2tl[l].w1, t + 5700.0); add(x.as2tl[l].w2, t + 8300.0);
+                }
+                add(x.inter_kvf[0], t - 2000.0);
+                if (!ctx->d_warm_tab) TB_HIP(ctx, hipMalloc((void**)&ctx->d_warm_tab, 128 * sizeof(int)));
+                TB_HIP(ctx, hipMemcpy(ctx->d_warm_tab, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice));
+                ctx->warm_key = key;
+                ctx->warm_n = (int)tab.size() / 2;
+            }
+            p.warm_tab = ctx->d_warm_tab;
+            p.warm_n = ctx->warm_n;
+        }
+    }
     {
         const char* e = getenv("TB_DEBUG_HELPER_DELAY");
         p.dbg_helper_delay = e ? atoi(e) : 0;
@@ -964,7 +1007,7 @@ static void rollout_prologue(const tb_ctx* ctx, const tb::RolloutP& p, const tb_
 static int rollout_enqueue(tb_ctx* ctx, const tb_rollout_io* io, const tb::RolloutP& p, hipStream_t s);
 
 // every launch-shaping development switch read below this call (step_launch, rollout_prologue): part of the graph key
-static const char* const kGraphEnv[] = {"TB_STEP_W3", "TB_STEP_AW", "TB_STEP_PRE_INTER", "TB_STEP_LEAN", "TB_STEP_HELPERS", "TB_GRU_HELPER", "TB_DEBUG_HELPER_DELAY", "TB_STEP_KERNEL"};
+static const char* const kGraphEnv[] = {"TB_STEP_W3", "TB_STEP_AW", "TB_STEP_PRE_INTER", "TB_STEP_WARM", "TB_STEP_LEAN", "TB_STEP_HELPERS", "TB_GRU_HELPER", "TB_DEBUG_HELPER_DELAY", "TB_STEP_KERNEL"};
 
 static void key_append(std::vector<unsigned char>& k, const void* data, size_t n) {
     const unsigned char* b = static_cast<const unsigned char*>(data);

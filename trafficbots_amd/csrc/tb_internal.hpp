@@ -37,6 +37,9 @@ struct tb_ctx {
     size_t rule_ws_bytes = 0;
     long long* last_prof = nullptr;
     unsigned int* d_status = nullptr;  // device word of tb_check_status
+    int* d_warm_tab = nullptr;         // L2 warmers (tb_stepx_kernels.hip): [64][2] {arena offset, request time} of the weight units a launch streams
+    long long warm_key = -1;           // (p_pad, a_pad, step kernel) the table was made for
+    int warm_n = 0;
     // stepwise rollout (tb_rollout_begin / _step / _state)
     tb::RolloutP step_p;
     int step_next = 0, step_end = -1;

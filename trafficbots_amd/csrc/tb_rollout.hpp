@@ -158,6 +158,8 @@ struct RolloutP {
     unsigned int* gh_flag;        // [N * tiles]  = step + 1 once the tile's gh of that step is complete (zeroed per rollout)
     unsigned int* kv_flag;        // [N * tiles][2] = step + 1 once the tile's K / V of layer 1 / 2 of that step are stored
     unsigned int* sync_err;       // one sticky word of the context: a tile workgroup gave up waiting for a helper (tb_check_status)
+    const int* warm_tab;          // L2 warmers (the helper workgroups, tb_stepx_kernels.hip): [warm_n][2] {arena offset, request time in cycles}, or nullptr
+    int warm_n;
     int pre_shared;               // 1: this launch's C half reads a slice of the batched warm start, which exists once per SCENE (in the slot of
                                   // future 0: the K futures share the ground truth) -- x_mid and the interaction K / V come from instance b * K
     int dbg_helper_delay;         // test knob (env TB_DEBUG_HELPER_DELAY, clock64 ticks): the helpers start late, the hand-off runs uneven
