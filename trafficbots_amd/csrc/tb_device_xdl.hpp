@@ -208,11 +208,19 @@ __device__ __forceinline__ void layernorm_planes(const float* src, int lds_, xha
     } else {
         g0 = ldg4(g + c0); g1 = ldg4(g + c0 + 4); b0 = ldg4(b + c0); b1 = ldg4(b + c0 + 4);
     }
+#ifdef TB_DBG_LN_ORDER  // (diagnosis builds only, VERDICT r04 task 4 (d): another association of the two row sums)
+    const float s = row16_sum(((((((a.x + a.y) + a.z) + a.w) + c.x) + c.y) + c.z) + c.w);
+#else
     const float s = row16_sum((a.x + a.y) + (a.z + a.w) + (c.x + c.y) + (c.z + c.w));
+#endif
     const float mean = s * (1.0f / 128.0f);
     const f32x4 da = a - splat(mean), dc = c - splat(mean);
+#ifdef TB_DBG_LN_ORDER
+    const float v = row16_sum(((((((da.x * da.x + da.y * da.y) + da.z * da.z) + da.w * da.w) + dc.x * dc.x) + dc.y * dc.y) + dc.z * dc.z) + dc.w * dc.w);
+#else
     const float v = row16_sum((da.x * da.x + da.y * da.y) + (da.z * da.z + da.w * da.w) + (dc.x * dc.x + dc.y * dc.y) +
                               (dc.z * dc.z + dc.w * dc.w));
+#endif
     const float rstd = 1.0f / sqrtf(v * (1.0f / 128.0f) + LN_EPS);
     planes_store4<false>(P, PLANE, LDP, row, c0, da * splat(rstd) * g0 + b0);  // (bounded by the parameters: checked at load time)
     planes_store4<false>(P, PLANE, LDP, row, c0 + 4, dc * splat(rstd) * g1 + b1);
@@ -603,7 +611,15 @@ __device__ __forceinline__ void attn_qk_x(const KFragX& f, const xh8& qh, const 
 // -inf - finite = -inf -> 0, and the correction factor of a row whose first valid key arrives is 2^(-3e38 - m) = 0 (times an
 // accumulator that is still 0).  Same bits as the earlier form, which clamped every argument at -160 instead (one v_max_f32 per key).
 constexpr float RUN_MAX_NONE = -3.0e38f;
+// (-DTB_DBG_EXPF, diagnosis builds only -- VERDICT r04 task 4 (d): the softmax in natural units with the library's expf, the form the
+// reference's softmax has, instead of log2 units + v_exp_f32; tools/gpu_bias_probe.sh)
+#ifdef TB_DBG_EXPF
+__device__ __forceinline__ float exp2_neg(float x) { return expf(x); }
+constexpr float SOFTMAX_UNIT = 1.0f;
+#else
 __device__ __forceinline__ float exp2_neg(float x) { return __builtin_amdgcn_exp2f(x); }
+constexpr float SOFTMAX_UNIT = 1.44269504088896340736f;
+#endif
 
 template <bool SELFMASK>
 __device__ __forceinline__ void attn_stats_x(const f32x4 (&s)[2], const f32x4 (&c)[2], const f32x4 (&kb)[2], int kb0, int self_key,
@@ -618,7 +634,7 @@ __device__ __forceinline__ void attn_stats_x(const f32x4 (&s)[2], const f32x4 (&
         // ~2^-24 |x| <= 1e-6 relative in p -- the same order as the rounding of logit x scale in the reference's own softmax;
         // closed-loop parity is unchanged within its noise (headline golden: 1.6e-4 vs fp32, 8.8e-5 vs fp64).
         // (crs * 2^-11 is exact, so the explicit fma has the bits of multiply-then-add; -ffp-contract=off would not form it)
-        const float v = fmaf(NPL == 2 ? fmaf(crs[r], SPLIT_INV, raw[r]) : raw[r], ATTN_SCALE * 1.44269504088896340736f, bias[r]);
+        const float v = fmaf(NPL == 2 ? fmaf(crs[r], SPLIT_INV, raw[r]) : raw[r], ATTN_SCALE * SOFTMAX_UNIT, bias[r]);
         sv[r] = (SELFMASK && kb0 + 16 * (r >> 2) + (r & 3) == self_key) ? -INFINITY : v;  // eye mask of MultiAgentTF only
     }
     float tmax = fmaxf(fmaxf(fmaxf(sv[0], sv[1]), fmaxf(sv[2], sv[3])), fmaxf(fmaxf(sv[4], sv[5]), fmaxf(sv[6], sv[7])));

@@ -751,7 +751,11 @@ __device__ __forceinline__ void step_encode_inputs_lds(const RolloutP& p, int b,
                 arg = pyaw * ENCW[ENCW_FYAW + j - 24]; c_cos = 48 + (j - 24); c_sin = 72 + (j - 24);
             }
             float sv, cv;
+#ifdef TB_DBG_SINCOSF  // (diagnosis builds only, VERDICT r04 task 4 (d): the library's fp32 sincos instead of the fp64 polynomial)
+            sincosf(arg, &sv, &cv);
+#else
             sincos_pe(arg, sv, cv);
+#endif
             xr[c_cos] = cv;
             xr[c_sin] = sv;
         }
