@@ -925,6 +925,43 @@ def test_training_step_train_mode_masks_against_reference_golden():
     assert torch.equal(a, b) and not torch.equal(a, c)
 
 
+def test_training_step_perturbed_latent_inputs_against_reference_golden():
+    """`pre_processing.latent.perturb_input_to_latent` (round 5; `sc_latent.py:115-152`): in train mode both personality encoders see the
+    episode re-centred in a frame drawn per scene.  Golden `train_perturb` = the body of the reference's training_step with its two
+    `torch.rand` draws replaced by synth.make_latent_perturb: posterior / prior personalities, the replay they drive, the losses."""
+    from trafficbots_amd import synth
+
+    g, meta = load_golden("train_perturb")
+    over = {"time_step_end": meta["time_step_end"], "n_joint_future": 1}
+    over.update(meta["overrides"])
+    sc = meta["scene"]
+    batch = synth.make_val_batch(meta["base_seed"], meta["n_scene"], **sc)
+    eps = torch.from_numpy(synth.make_latent_noise(meta["base_seed"] + 99, meta["n_scene"], sc["n_agent"])).cuda()
+    lp = {k: torch.from_numpy(v).cuda() for k, v in synth.make_latent_perturb(meta["perturb_seed"], meta["n_scene"]).items()}
+    wm = _engine(over, synth.make_state_dict(meta["weight_seed"]))
+    out = wm.training_step(batch, latent_eps=eps, latent_perturb=lp)
+    torch.cuda.synchronize()
+    buf = out["rollout_buffer"]
+    assert (out["latent_post"].valid.cpu().numpy() == g["post_valid"]).all() and (out["latent_prior"].valid.cpu().numpy() == g["prior_valid"]).all()
+    e_post = float(np.abs(out["latent_post"].mean.cpu().numpy() - g["post_mean"]).max())
+    e_prior = float(np.abs(out["latent_prior"].mean.cpu().numpy() - g["prior_mean"]).max())
+    REPORT["train_perturb"] = {"post_mean": e_post, "prior_mean": e_prior}
+    assert e_post <= ONE_SHOT_TOL and e_prior <= ONE_SHOT_TOL, (e_post, e_prior)
+    assert (buf.valid.cpu().numpy() == g["valid"]).all() and (buf.override_masks.cpu().numpy() == g["override_masks"]).all()
+    d = np.abs(buf.preds.cpu().numpy() - g["preds"]) * g["valid"][..., None]
+    assert d[..., :2].max() <= 1e-4, d[..., :2].max()
+    ref = json.loads(bytes(g["metrics_json"]).decode())
+    got = out["metrics_dict"]
+    assert set(got) == set(ref) and all(abs(got[k] - ref[k]) <= 2e-4 * max(1.0, abs(ref[k])) for k in ref), (got, ref)
+    # the frame matters (the personalities of the unperturbed episode are different ones) and the zero frame is the identity
+    wm0 = _engine({k: v for k, v in over.items() if "perturb" not in k}, synth.make_state_dict(meta["weight_seed"]))
+    plain = wm0.training_step(batch, latent_eps=eps)
+    assert float((plain["latent_post"].mean - out["latent_post"].mean).abs().max()) > 1e-3
+    half = {"yaw": torch.full_like(lp["yaw"], 0.5), "pos": torch.full_like(lp["pos"], 0.5)}  # u = 0.5 -> yaw 0, position 0
+    ident = wm.training_step(batch, latent_eps=eps, latent_perturb=half)
+    assert torch.equal(ident["latent_post"].mean, plain["latent_post"].mean) and torch.equal(ident["rollout_buffer"].preds, plain["rollout_buffer"].preds)
+
+
 @pytest.mark.parametrize("shape", [dict(n_agent=64, n_pl=256, n_tl=40), dict(n_agent=20, n_pl=33, n_tl=5, p_late_spawn=0.4, p_invalid_agent=0.2)])
 def test_batched_warm_start_is_bit_identical(shape):
     """tb_rollout_io.warm_start_steps: the map / traffic-light attention halves of the teacher-forced steps run as one batched launch

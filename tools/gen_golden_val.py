@@ -184,6 +184,16 @@ TRAIN_CASE = dict(
 )
 
 
+# `pre_processing.latent.perturb_input_to_latent` (sc_latent.py:115-152): both personality encoders see the episode in a frame drawn per
+# scene; the two torch.rand draws are synth.make_latent_perturb(perturb_seed); no Bernoulli masks in this case
+TRAIN_PERTURB_CASE = dict(
+    base_seed=17000, n_scene=3, weight_seed=9, time_step_end=40, draws_seed=17001, perturb_seed=17002,
+    overrides={"pre_processing.input.dropout_p_history": -1, "pre_processing.latent.dropout_p_history": -1, "p_drop_hidden": -1.0,
+               "pre_processing.latent.perturb_input_to_latent": True},
+    scene=dict(n_agent=10, n_pl=24, n_tl=12, p_invalid_agent=0.2, p_late_spawn=0.3, p_future_spawn=0.5, p_future_exit=0.3, pos_range=70.0),
+)
+
+
 def run_reference_training(case: dict = TRAIN_CASE) -> dict:
     """The body of the reference's `training_step` (`waymo_motion.py:356-418`) with ONLY the train-mode switches of the pre-processing
     modules and of `rollout` turned on (the network itself stays in eval mode: no nn.Dropout), `torch.bernoulli` / `torch.rand(1)` /
@@ -219,7 +229,17 @@ def run_reference_training(case: dict = TRAIN_CASE) -> dict:
         assert tuple(d.shape) == tuple(probs.shape), (key, tuple(d.shape), tuple(probs.shape))
         return d.to(probs.dtype)
 
+    perturb = synth.make_latent_perturb(case["perturb_seed"], case["n_scene"]) if case.get("perturb_seed") else None
+
     def fake_rand(*size, **k_):
+        if len(size) == 1 and isinstance(size[0], (list, tuple)):
+            size = tuple(size[0])
+        if perturb is not None and tuple(size) == (case["n_scene"],):       # sc_latent.py:119: the frame's yaw
+            calls["perturb"] = calls.get("perturb", 0) + 1
+            return torch.from_numpy(perturb["yaw"].copy())
+        if perturb is not None and tuple(size) == (case["n_scene"], 2):     # sc_latent.py:121: the frame's position
+            calls["perturb"] = calls.get("perturb", 0) + 1
+            return torch.from_numpy(perturb["pos"].copy())
         if tuple(size) == (1,):
             i = calls["rand"]
             calls["rand"] += 1
@@ -233,8 +253,10 @@ def run_reference_training(case: dict = TRAIN_CASE) -> dict:
         torch.bernoulli = fake_bernoulli
         tdn._standard_normal = lambda shape, dtype, device: eps.to(dtype)
         with torch.no_grad():
+            if perturb is not None:
+                torch.rand = fake_rand
             batch = model.pre_processing(batch)
-            assert calls["bern"] == 5, calls
+            assert calls["bern"] == (0 if perturb is not None else 5) and calls.get("perturb", 0) == (2 if perturb is not None else 0), calls
             pick = lambda pre: {k.split(pre)[-1]: v for k, v in batch.items() if pre in k}  # noqa: E731
             input_dict, post_dict, prior_dict = pick("input/"), pick("latent_post/"), pick("latent_prior/")
             feats = model.model.encode_input_features(**input_dict)
@@ -250,7 +272,7 @@ def run_reference_training(case: dict = TRAIN_CASE) -> dict:
                 batch=batch, input_feature_dict=feats, mask_teacher_forcing=model.teacher_forcing_training.get(batch["gt/valid"], 0),
                 latent=latent_post, goal=goal_gt, goal_valid=goal_valid, deterministic_latent=False,
                 deterministic_action=True, require_vis_dict=False)
-            assert calls["rand"] == n_step, calls
+            assert calls["rand"] == (n_step if ov["p_drop_hidden"] > 0 else 0), calls
             # (taken BEFORE the metric update: `pred_valid[:, :, :step_training_start] &= False` edits the buffer in place, training.py:93)
             raw_valid = buf.valid.clone()
             tm = model.train_metrics_train  # (torchmetrics' forward = update + compute; the Metric stand-in of tools/ref_shim.py has neither)
@@ -283,6 +305,11 @@ def main() -> None:
         np.savez_compressed(path, **r)
         print(f"[train_dropout] wrote {path} ({os.path.getsize(path) / 1024:.0f} KiB); hidden dropped after steps {r['hidden_drop_steps'] + 1}; "
               f"{json.loads(r['metrics_json'].tobytes())}")
+    if not only or "train_perturb" in only:
+        r = run_reference_training(TRAIN_PERTURB_CASE)
+        path = os.path.join(GOLDEN_DIR, "train_perturb.npz")
+        np.savez_compressed(path, **r)
+        print(f"[train_perturb] wrote {path} ({os.path.getsize(path) / 1024:.0f} KiB); {json.loads(r['metrics_json'].tobytes())}")
     for name, case in CASES.items():
         if only and name not in only:
             continue

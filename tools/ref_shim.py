@@ -191,7 +191,7 @@ def build_reference(cfg: dict, n_agent: int, n_pl: int, n_tl: int = 40) -> nn.Mo
                 _target_="data_modules.sc_latent.SceneCentricLatent",
                 pe_dim=c.pre_processing.input.pe_dim,
                 pose_pe=c.pre_processing.input.pose_pe,
-                perturb_input_to_latent=False,
+                perturb_input_to_latent=bool(cfg.get("pre_processing", {}).get("latent", {}).get("perturb_input_to_latent", False)),
                 dropout_p_history=cfg.get("pre_processing", {}).get("latent", {}).get("dropout_p_history", -1),
                 max_meter=50.0,
                 max_rad=3.14,

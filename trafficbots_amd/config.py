@@ -37,8 +37,8 @@ DEFAULT_MODEL_CONFIG: Dict[str, Any] = {
             "pose_pe": {"map": "pe_xy_yaw", "tl": "pe_xy_yaw", "agent": "pe_xy_yaw"},
         },
         # SceneCentricLatent (sc_latent.py): only the posterior-side history dropout is read (train mode, explicit draws);
-        # perturb_input_to_latent is an un-built augmentation
-        "latent": {"perturb_input_to_latent": False, "dropout_p_history": -1},
+        # (perturb_input_to_latent: built since round 5 for training_step, WaymoMotion._perturb_latent_inputs)
+        "latent": {"perturb_input_to_latent": False, "dropout_p_history": -1, "max_meter": 50.0, "max_rad": 3.14},
     },
     "p_drop_hidden": -1.0,
     "model": {

@@ -575,3 +575,10 @@ def case_state_dict(case: dict) -> "OrderedDict[str, np.ndarray]":
         z = np.load(path)
         return OrderedDict((k, np.ascontiguousarray(z[k])) for k in z.files)
     return make_state_dict(case["weight_seed"], mode=case.get("weight_mode"))
+
+
+def make_latent_perturb(seed: int, n_scene: int) -> Dict[str, np.ndarray]:
+    """Uniform draws in [0, 1) for `pre_processing.latent.perturb_input_to_latent` (`sc_latent.py:119-121`: one yaw and one position
+    per scene, in the order the reference draws them)."""
+    rs = RawStream(seed)
+    return {"yaw": rs.u01((n_scene,)).astype(np.float32), "pos": rs.u01((n_scene, 2)).astype(np.float32)}

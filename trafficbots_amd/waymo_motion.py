@@ -733,8 +733,10 @@ class WaymoMotion:
     def training_step(self, batch: Dict[str, Tensor], batch_idx: int = 0, latent_eps: Optional[Tensor] = None,
                       rollout_prior: bool = False, current_epoch: int = 0, action_eps: Optional[Tensor] = None,
                       generator=None, irrelevant_draw: Optional[Tensor] = None, history_keep: Optional[Dict[str, Tensor]] = None,
-                      hidden_drop=None) -> Dict[str, object]:
-        """Train-mode Bernoulli masks (explicit draws, the `irrelevant_draw` pattern; drawn here with `generator` when the config asks
+                      hidden_drop=None, latent_perturb: Optional[Dict[str, Tensor]] = None) -> Dict[str, object]:
+        """`latent_perturb` = {"yaw": [B], "pos": [B,2]} uniform draws in [0, 1) for `pre_processing.latent.perturb_input_to_latent`
+        (:meth:`_perturb_latent_inputs`; drawn here with `generator` when the config asks for it and none are given).
+        Train-mode Bernoulli masks (explicit draws, the `irrelevant_draw` pattern; drawn here with `generator` when the config asks
         for them and none are given):
           * `history_keep` -- KEEP masks of `pre_processing.input.dropout_p_history` ("input_agent" [B,10,A]: the agent history but its
             last step, "input_tl" [B,11,T], "input_map" [B,P,20]; `sc_input.py:100-106`) and of `pre_processing.latent.dropout_p_history`
@@ -765,8 +767,20 @@ class WaymoMotion:
         input_feature_dict = self.model.encode_input_features(scene)
         goal_gt, goal_valid = self.model.goal_manager.get_gt_goal(scene["agent_valid"], gt.get("gt_goal"), gt["gt_dest"])
         goal_pred = self.model.goal_manager.pred_goal()
-        latent_post = self.model.latent_encoder(posterior=True, gt=gt)
-        latent_prior = self.model.latent_encoder()
+        if hp["pre_processing"].get("latent", {}).get("perturb_input_to_latent", False):
+            # both personality encoders see the episode in a frame drawn per scene (their own encode of the re-centred inputs; the
+            # policy's features, the destination predictor and the replay stay in the scene frame)
+            b_ = scene["agent_valid"].shape[0]
+            lp = latent_perturb if latent_perturb is not None else {
+                "yaw": torch.rand(b_, device=self.device, generator=generator), "pos": torch.rand(b_, 2, device=self.device, generator=generator)}
+            scene_l, gt_l = self._perturb_latent_inputs(scene, gt, lp["yaw"], lp["pos"])
+            enc_l = self.engine.encode_scene(scene_l)
+            post = self.engine.encode_posterior(gt_l, enc_l)
+            latent_post = DiagGaussian(post["latent_mean"], self.model._log_std_post, valid=post["latent_valid"].bool(), engine=self.engine)
+            latent_prior = DiagGaussian(enc_l["latent_mean"], self.model._log_std, valid=enc_l["latent_valid"].bool(), engine=self.engine)
+        else:
+            latent_post = self.model.latent_encoder(posterior=True, gt=gt)
+            latent_prior = self.model.latent_encoder()
         latent = latent_prior if rollout_prior else latent_post
         mask_tf = teacher_forcing_mask(gt["agent_valid"].bool(), tf.get("step_spawn_agent", 10), tf.get("step_warm_start", 10))
         buf = self.reactive_replay(scene, input_feature_dict, mask_tf, latent, goal_gt, goal_valid,
@@ -786,6 +800,44 @@ class WaymoMotion:
         return {"loss": out["training/loss"], "metrics_dict": out, "train_states": states, "rollout_buffer": buf,
                 "latent_post": latent_post, "latent_prior": latent_prior}
 
+    def _perturb_latent_inputs(self, scene: Dict[str, Tensor], gt: Dict[str, Tensor], yaw_u: Tensor, pos_u: Tensor):
+        """`pre_processing.latent.perturb_input_to_latent` (train mode; `sc_latent.py:115-124` and the `torch_*2local` calls below it):
+        the inputs of BOTH personality encoders -- map, traffic lights, agents; history and 91-step ground truth -- are moved into a
+        frame drawn per scene, yaw = u * 2 max_rad - max_rad, position = u * 2 max_meter - max_meter (`yaw_u` [B], `pos_u` [B,2]:
+        the uniform draws, explicit as everywhere in this mirror): p' = (p - t) R, d' = d R, yaw' = yaw - yaw_0 (not wrapped),
+        R = [[cos, -sin], [sin, cos]] (`transform_utils.py:121-131,146-157,174-184,200-213`).  Returns copies of (scene, gt)."""
+        lat = self.hparams["pre_processing"].get("latent", {})
+        max_meter, max_rad = float(lat.get("max_meter", 50.0)), float(lat.get("max_rad", 3.14))
+        dev, f32 = self.device, torch.float32
+        yaw = yaw_u.to(dev, f32) * 2 * max_rad - max_rad          # [B]
+        pos = pos_u.to(dev, f32) * 2 * max_meter - max_meter      # [B,2]
+        c, s_ = torch.cos(yaw), torch.sin(yaw)
+        rot = torch.stack([torch.stack([c, -s_], -1), torch.stack([s_, c], -1)], -2)  # [B,2,2]
+
+        def pos2local(x):   # [B, ..., 2]
+            sh = x.shape
+            return torch.matmul(x.reshape(sh[0], -1, 2) - pos[:, None, :], rot).reshape(sh).contiguous()
+
+        def dir2local(x):
+            sh = x.shape
+            return torch.matmul(x.reshape(sh[0], -1, 2), rot).reshape(sh).contiguous()
+
+        def agents(d):
+            o = dict(d)
+            o["agent_pos"] = pos2local(d["agent_pos"])
+            o["agent_vel"] = dir2local(d["agent_vel"])
+            o["agent_yaw"] = (d["agent_yaw"] - yaw.reshape(-1, *([1] * (d["agent_yaw"].dim() - 1)))).contiguous()
+            o["agent_state"] = torch.cat([o["agent_pos"], o["agent_yaw"].unsqueeze(-1), d["agent_spd"].unsqueeze(-1)], -1).contiguous()
+            o["tl_pos"] = pos2local(d["tl_pos"])
+            o["tl_dir"] = dir2local(d["tl_dir"])
+            return o
+
+        scene_l = agents(scene)
+        scene_l["map_pos"] = pos2local(scene["map_pos"])
+        scene_l["map_dir"] = dir2local(scene["map_dir"])
+        scene_l.pop("gt", None)
+        return scene_l, agents(gt)
+
     def _train_mode_masks(self, scene: Dict[str, Tensor], gt: Dict[str, Tensor], history_keep, hidden_drop, generator):
         """Applies / draws the train-mode Bernoulli masks of :meth:`training_step`; returns (scene, gt, hidden_drop) -- copies of the
         dicts with the masked validity tensors (the caller's batch is not edited)."""
@@ -793,8 +845,9 @@ class WaymoMotion:
         p_in = float(hp["pre_processing"]["input"].get("dropout_p_history", -1))
         p_lat = float(hp["pre_processing"].get("latent", {}).get("dropout_p_history", -1))
         p_hid = float(hp.get("p_drop_hidden", -1.0))
-        if hp["pre_processing"].get("latent", {}).get("perturb_input_to_latent", False):
-            raise NotImplementedError("pre_processing.latent.perturb_input_to_latent (random re-centring of the latent encoders' inputs) is not built")
+        if hp["pre_processing"].get("latent", {}).get("perturb_input_to_latent", False) and 0 < p_lat <= 1.0:
+            raise NotImplementedError("pre_processing.latent.perturb_input_to_latent together with pre_processing.latent.dropout_p_history: "
+                                      "the prior-side history masks of the re-centred inputs (sc_latent.py:158-160,190-192) are not built")
         dev = self.device
         keep = dict(history_keep) if history_keep is not None else {}
 
