@@ -349,7 +349,8 @@ __global__ __launch_bounds__(AWB ? 2 * NTHREADS : NTHREADS, LEAN ? (W3 ? 3 : 2) 
         range_flush(hmax);
         // L2 WARMERS (round 5; VERDICT r04 task 6): the helper workgroups of an XCD, done with their own work ~25 k cycles into the launch,
         // touch the weight units the tile workgroups of THEIR XCD are about to request -- one 4-byte load per 128-byte line, unit i by
-        // the helper with (index in XCD) == i mod 16, ~3 k cycles ahead of the request -- so that the first tile to ask finds the line
+        // helper i mod 2 of the XCD's first TWO helpers (the other fourteen leave: a second stream's launch can have their CUs; with
+        // all sixteen waiting `two_batches_in_flight` fell from 600 k to 421 k), ~3 k cycles ahead of the request -- so that the first tile to ask finds the line
         // in the XCD's L2 instead of paying the miss for its 15 siblings (the 4.3 MB weight set is re-fetched into eight invalidated
         // L2s every launch).  The table (arena offset, estimated request time in cycles since launch start) is made by the host from the
         // stage profile of the launch (tb_api.hip: warm_table); measured insensitive to +-3 k cycles of lead.  Results are untouched.
@@ -357,7 +358,7 @@ __global__ __launch_bounds__(AWB ? 2 * NTHREADS : NTHREADS, LEAN ? (W3 ? 3 : 2) 
             const int me = (int)((blockIdx.y * gridDim.x + blockIdx.x) >> 3) & 15;
             const int lead = 3000;
             float sink = 0.f;
-            for (int i = me; i < p.warm_n; i += 16) {
+            for (int i = me; i < p.warm_n && me < 2; i += 2) {
                 const long long due = t_launch + p.warm_tab[2 * i + 1] - lead;
                 while (clock64() < due) __builtin_amdgcn_s_sleep(16);
                 const float* base = W + (uint32_t)p.warm_tab[2 * i];  // one 128 x 128 unit = 64 KB (fp16 pairs) = 512 lines: two loads per thread
