@@ -60,6 +60,14 @@ for i in range(3):
 v = st[:, 8] - st[:, 30]
 print(f"  {NAMES[7]:32s} {np.median(v):9.0f}  [{v.min():8.0f} .. {v.max():8.0f}]   (k_step_x only)")
 print(f"  sum of medians (without A front-end) {tot:9.0f}")
+if os.environ.get("TB_STEP_KERNEL") != "fp32":  # k_step_x: stamps inside the one-burst prologue (round 5)
+    seqx = [31, 0, 12, 13, 14, 15, 1]
+    labx = ["kernel entry -> tile map, first kernarg use", "first weight unit issued (addresses from kernarg)", "all prologue loads issued",
+            "encoder weights + epilogue record in LDS (first waits)", "C tiles + LN blocks in LDS (all loads back)", "barrier"]
+    for i in range(6):
+        v = st[:, seqx[i + 1]] - st[:, seqx[i]]
+        print(f"    C-start/{labx[i]:52s} {np.median(v):8.0f}  [{v.min():7.0f} .. {v.max():7.0f}]")
+    print(f"    (last launch, C half only) first entry -> last workgroup's stamp 7 {st[:, 7].max() - st[:, 31].min():8.0f}; entry skew {st[:, 31].max() - st[:, 31].min():8.0f}; stamp-7 skew {st[:, 7].max() - st[:, 7].min():8.0f}")
 seq = [0, 12, 13, 14, 15, 1]
 lab = ["LN params -> LDS (issue+store)", "row state loads (16 thr)", "valid ballots", "wload + 6 tile loads + geometry issue", "barrier (wait for all)"]
 if os.environ.get("TB_STEP_KERNEL") == "fp32":  # (k_step_x keeps no stamps inside its one-round-trip prologue)

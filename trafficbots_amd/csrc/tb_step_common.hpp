@@ -33,6 +33,27 @@ constexpr int STEP_LDS_FLOATS = OFF_SMALL + SMALL_FLOATS;
     } while (0)
 #endif
 
+// Kernel entry (round 5): the step kernels take ~2 KB of arguments, and the compiler loads each field where it is first used -- a
+// chain of `s_load; s_waitcnt lgkmcnt(0)` pairs, each one a miss of the (cold) scalar cache, ~600 cycles apiece, seven of them in
+// series in front of the first weight request alone.  One scalar load per 64-byte line of the argument segment, all in flight
+// together, turns the chain into one miss followed by hits.
+template <int BYTES>
+__device__ __forceinline__ void kernarg_warm() {
+    typedef const __attribute__((address_space(4))) unsigned int* kptr_t;
+    kptr_t ka = (kptr_t)__builtin_amdgcn_kernarg_segment_ptr();
+    unsigned int acc = 0u;
+#pragma unroll
+    for (int o = 0; o < BYTES / 4; o += 16) acc |= ka[o];
+    asm volatile("" ::"s"(acc));
+}
+// a zero the compiler cannot see through: `ptr[i + vzero()]` is a VECTOR load (issued with the burst, waited for with it) where
+// `ptr[i]` with a wave-uniform i would be a scalar load that stalls the wave on a cold line at its first use
+__device__ __forceinline__ int vzero() {
+    int z;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(z));
+    return z;
+}
+
 __device__ __forceinline__ float fmul_(float a, float b) { return __fmul_rn(a, b); }
 __device__ __forceinline__ float fadd_(float a, float b) { return __fadd_rn(a, b); }
 
@@ -111,12 +132,16 @@ __device__ __forceinline__ void c_inputs_issue(const RolloutP& p, int n, int row
             const int idx = tid + i * NT;
             c.v[s][i] = ldg4(src[s] + (size_t)(idx >> 5) * H + (idx & 31) * 4);
         }
+    // (unconditional loads at clamped indices: a conditional load merges with a constant behind the branch, and the compiler
+    // settles that merge with `s_waitcnt vmcnt` + a register copy IN the burst -- a full cold round trip per merge, round 5)
+    if (DG_LDS) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int idx = tid + i * NT;
-        c.g[i] = (DG_LDS && idx < TM * 20) ? ldg4(p.dest_geo + (base_row * 20 + idx) * 4) : splat(0.f);
+        for (int i = 0; i < 2; ++i) {
+            const int idx = min(tid + i * NT, TM * 20 - 1);
+            c.g[i] = ldg4(p.dest_geo + (base_row * 20 + idx) * 4);
+        }
     }
-    c.df = tid < TM ? p.dest_flag[base_row + tid] : 0;
+    c.df = p.dest_flag[base_row + (tid & (TM - 1))];
 }
 
 template <int NT, int NSRC = 6, bool DG_LDS = true>
@@ -277,10 +302,10 @@ __device__ __forceinline__ void step_epilogue(const RolloutP& p, int t, int n, i
 // stage (agent size) that do not depend on the step's own work: requested in the launch prologue's burst by threads 16 .. 48 and
 // parked in the LDS regions those stages only write later (attr: the epilogue's per-agent record, ench: sizes + tile constants),
 // so neither stage opens with a dependent round trip to memory.  (k_step_x; the fp32-MFMA twin keeps its own loads.)
-struct EpiRegs {
-    f32x4 hst, hax, sz, bd;
-    float ls[6], ae[2], ao[2];
-    int flags;
+struct EpiRegs {  // raw load results (wave 0 only; nothing is computed from them before epi_commit)
+    f32x4 hst;
+    float vel[2], acc, yr, ae[2], ao[2], sz[3], ls[3], bd;
+    unsigned int k0, o0, d0, m0, g0, am0;  // bytes
 };
 constexpr int EPI_FLAG_KILLED = 1, EPI_FLAG_OUTSIDE = 2, EPI_FLAG_DREACHED = 4, EPI_FLAG_OVR = 8, EPI_FLAG_GTV = 16, EPI_FLAG_AOVR = 32;
 constexpr int EPI_POISON_WORD = 17;  // StepSmall::dflag[17]: a helper hand-off timed out in this launch (kv_wait_x) -> NaN out
@@ -312,66 +337,77 @@ __device__ __forceinline__ TfSource tf_source(const RolloutP& p, int t, int n, i
     return f;
 }
 
-// threads 16 .. 31: the epilogue record of agent tid - 16; threads 32 .. 47: the size of agent tid - 32; thread 48: tile constants
-__device__ __forceinline__ void epi_issue(const RolloutP& p, int t, int n, int b, int row0, int n_real, int tid, bool do_c, EpiRegs& e) {
-    e.flags = 0;
-    e.ae[0] = e.ae[1] = e.ao[0] = e.ao[1] = 0.f;
-    e.hst = e.hax = e.sz = e.bd = splat(0.f);
-#pragma unroll
-    for (int i = 0; i < 6; ++i) e.ls[i] = 0.f;
-    if (do_c && tid >= 16 && tid < 32) {
-        const int a = tid - 16, row = row0 + a, rowc = min(row, p.n_agent - 1);
-        const size_t si = (size_t)n * p.a_pad + row;
-        const TfSource f = tf_source(p, t, n, b, rowc);
-        const uint8_t k0 = p.killed[si], o0 = p.outside[si], d0 = p.dest_reached[si], m0 = f.mask[f.hi], g0 = f.gtv ? f.gtv[f.hi] : (uint8_t)0;
-        e.hst = ldg4(f.state + f.hi * 4);
-        e.hax = f32x4{f.vel[f.hi * 2], f.vel[f.hi * 2 + 1], f.acc[f.hi], f.yr[f.hi]};
-        if (p.action_eps) {
-            const float* ap = p.action_eps + (((size_t)n * p.n_agent + rowc) * p.n_step_out + (t - p.step_start)) * 2;
-            e.ae[0] = ap[0];
-            e.ae[1] = ap[1];
-        }
-        uint8_t am0 = 0;
-        if (p.ovr_action_mask) {  // per-call action override (tb_step_override.action / action_mask; dynamics.py:96-100)
-            const size_t ai = (size_t)n * p.n_agent + rowc;
-            am0 = p.ovr_action_mask[ai];
-            e.ao[0] = p.ovr_action[ai * 2];
-            e.ao[1] = p.ovr_action[ai * 2 + 1];
-        }
-        e.flags = (k0 ? EPI_FLAG_KILLED : 0) | (o0 ? EPI_FLAG_OUTSIDE : 0) | (d0 ? EPI_FLAG_DREACHED : 0) | (m0 ? EPI_FLAG_OVR : 0) |
-                  (g0 ? EPI_FLAG_GTV : 0) | (am0 ? EPI_FLAG_AOVR : 0);
-    } else if (tid >= 32 && tid < 48) {
-        const int a = tid - 32;
-        if (a < n_real) {
-            const float* sp = p.agent_size + ((size_t)b * p.n_agent + row0 + a) * 3;
-            e.sz = f32x4{sp[0], sp[1], sp[2], 0.f};
-        }
-    } else if (do_c && tid == 48) {
-        e.bd = ldg4(p.map_boundary + (size_t)b * 4);
-#pragma unroll
-        for (int ty = 0; ty < 3; ++ty) {
-            e.ls[ty * 2] = p.W[p.pw.head_log_std[ty]];
-            e.ls[ty * 2 + 1] = p.W[p.pw.head_log_std[ty] + 1];
-        }
+// wave 0 -- lanes 16 .. 31: the epilogue record of agent lane - 16; lanes 32 .. 47: the size of agent lane - 32; lanes 48 .. 53: the six
+// action log-stds; lanes 56 .. 59: the map boundary.  EVERY lane of the wave executes EVERY load at a clamped address of its own
+// (a = lane & 15), so the burst holds no branch, no merge with a constant and no scalar load from a cold line (a wave-uniform
+// address -- the boundary, a log-std -- would become an s_load and stall the wave at its first use); optional arrays that are
+// absent are replaced by a buffer that holds the index, their values dropped in epi_commit.
+__device__ __forceinline__ void epi_issue(const RolloutP& p, int t, int n, int b, int row0, int tid, bool do_c, EpiRegs& e) {
+    const int a = tid & 15, rowc = min(row0 + a, p.n_agent - 1);
+    {
+        const float* sp = p.agent_size + ((size_t)b * p.n_agent + rowc) * 3;
+        e.sz[0] = sp[0]; e.sz[1] = sp[1]; e.sz[2] = sp[2];
     }
+    const size_t si = (size_t)n * p.a_pad + row0 + a;
+    const TfSource f = tf_source(p, t, n, b, rowc);
+    e.hst = ldg4(f.state + f.hi * 4);
+    e.vel[0] = f.vel[f.hi * 2]; e.vel[1] = f.vel[f.hi * 2 + 1]; e.acc = f.acc[f.hi]; e.yr = f.yr[f.hi];
+    {   // [N,A,S,2] draws; absent: `preds` ([N,A,S,4]) holds the index
+        const float* ap = (p.action_eps ? p.action_eps : p.preds) + (((size_t)n * p.n_agent + rowc) * p.n_step_out + (t - p.step_start)) * 2;
+        e.ae[0] = ap[0]; e.ae[1] = ap[1];
+    }
+    const size_t ai = (size_t)n * p.n_agent + rowc;
+    {   // per-call action override; absent: `state` ([N,a_pad,4]) holds the index
+        const float* ao = (p.ovr_action_mask ? p.ovr_action : p.state) + ai * 2;
+        e.ao[0] = ao[0]; e.ao[1] = ao[1];
+    }
+    // (three loads, one per type, picked by lane in epi_commit: an offset table indexed by lane would be read from the argument
+    // segment with a vector load, and the log-std would hang on it)
+#pragma unroll
+    for (int ty = 0; ty < 3; ++ty) e.ls[ty] = p.W[p.pw.head_log_std[ty] + (tid & 1)];
+    e.bd = p.map_boundary[(size_t)b * 4 + (tid & 3)];
+    // the byte loads LAST: the compiler moves their zero-extension up to the load -- behind a wait for it, which at the end of the
+    // burst costs nothing
+    e.k0 = p.killed[si]; e.o0 = p.outside[si]; e.d0 = p.dest_reached[si]; e.m0 = f.mask[f.hi];
+    e.g0 = (f.gtv ? f.gtv : f.mask)[f.hi];
+    e.am0 = (p.ovr_action_mask ? p.ovr_action_mask : p.valid)[ai];  // (absent: `valid`, [N,a_pad] bytes, holds the index)
 }
-__device__ __forceinline__ void epi_commit(int tid, bool do_c, const EpiRegs& e, const StepSmall& sm) {
+// the value as the compiler may not look through it: a compare or a mask that is the ONLY use of a loaded value is otherwise moved up
+// to the load -- into the burst, behind a wait for it
+__device__ __forceinline__ unsigned int pin_v(unsigned int x) {
+    asm volatile("" : "+v"(x));
+    return x;
+}
+__device__ __forceinline__ float pin_f(float x) {
+    asm volatile("" : "+v"(x));
+    return x;
+}
+__device__ __forceinline__ void epi_commit(const RolloutP& p, int n_real, int tid, bool do_c, const EpiRegs& e, const StepSmall& sm) {
     if (do_c && tid >= 16 && tid < 32) {
         float* r = sm.attr + (tid - 16) * 16;
+        const bool no_gtv = p.ovr_mask != nullptr && p.ovr_gt_valid == nullptr;  // (tf_source: f.gtv == nullptr)
+        const bool has_ae = p.action_eps != nullptr, has_ao = p.ovr_action_mask != nullptr;
         st4(r, e.hst);
-        st4(r + 4, e.hax);
-        reinterpret_cast<int*>(r)[8] = e.flags;
-        r[9] = e.ae[0];
-        r[10] = e.ae[1];
-        r[11] = e.ao[0];
-        r[12] = e.ao[1];
+        st4(r + 4, f32x4{e.vel[0], e.vel[1], e.acc, e.yr});
+        reinterpret_cast<int*>(r)[8] = (pin_v(e.k0) ? EPI_FLAG_KILLED : 0) | (pin_v(e.o0) ? EPI_FLAG_OUTSIDE : 0) |
+                                       (pin_v(e.d0) ? EPI_FLAG_DREACHED : 0) | (pin_v(e.m0) ? EPI_FLAG_OVR : 0) |
+                                       ((!no_gtv && pin_v(e.g0)) ? EPI_FLAG_GTV : 0) | ((has_ao && pin_v(e.am0)) ? EPI_FLAG_AOVR : 0);
+        r[9] = has_ae ? e.ae[0] : 0.f;
+        r[10] = has_ae ? e.ae[1] : 0.f;
+        r[11] = has_ao ? e.ao[0] : 0.f;
+        r[12] = has_ao ? e.ao[1] : 0.f;
     } else if (tid >= 32 && tid < 48) {
         float* r = sm.ench + EPI_ENCH_SIZE + (tid - 32) * 3;
-        r[0] = e.sz.x; r[1] = e.sz.y; r[2] = e.sz.z;
-    } else if (do_c && tid == 48) {
-        st4(sm.ench + EPI_ENCH_BD, e.bd);
-#pragma unroll
-        for (int i = 0; i < 6; ++i) sm.ench[EPI_ENCH_LS + i] = e.ls[i];
+        const bool real = tid - 32 < n_real;  // (rows past n_real: zeros)
+        r[0] = real ? e.sz[0] : 0.f; r[1] = real ? e.sz[1] : 0.f; r[2] = real ? e.sz[2] : 0.f;
+    } else if (do_c && tid >= 48 && tid < 54) {  // (lane parity = the component the lane loaded)
+        // (pinned: a select among the members of one object is otherwise rewritten as an indexed read of the object, which then lives
+        // in scratch memory)
+        const int ty = (tid - 48) >> 1;
+        const float l0 = pin_f(e.ls[0]), l1 = pin_f(e.ls[1]), l2 = pin_f(e.ls[2]);
+        sm.ench[EPI_ENCH_LS + (tid - 48)] = ty == 0 ? l0 : (ty == 1 ? l1 : l2);
+    } else if (do_c && tid >= 56 && tid < 60) {
+        sm.ench[EPI_ENCH_BD + (tid - 56)] = e.bd;
     }
 }
 
@@ -662,15 +698,22 @@ struct EncWRegs {
 };
 
 // region table of the 369 float4 the encoder needs: (first float4 index, arena offset)
+// (compile-time constants in a select chain: a local array indexed by `region` lands in constant MEMORY, and `local` then hangs on a
+// dependent load from a cold line in the middle of the launch prologue's burst)
 __device__ __forceinline__ const float* encw_src(const PolicyW& pw, const float* W, int q, int& region, int& local) {
-    const int first[7] = {0, 88, 96, 352, 360, 363, 369};
+    constexpr int first[7] = {0, 88, 96, 352, 360, 363, 369};
     const uint32_t off[6] = {pw.enc_w1, pw.enc_b1, pw.enc_w2, pw.enc_b2, pw.pe_fxy, pw.pe_fyaw};
     region = 0;
+    local = q;
+    uint32_t o = off[0];
 #pragma unroll
     for (int r = 1; r < 6; ++r)
-        if (q >= first[r]) region = r;
-    local = q - first[region];
-    return W + off[region] + local * 4;
+        if (q >= first[r]) {
+            region = r;
+            local = q - first[r];
+            o = off[r];
+        }
+    return W + o + local * 4;
 }
 
 __device__ __forceinline__ void encw_issue(const PolicyW& pw, const float* W, int tid, EncWRegs& r) {
@@ -688,12 +731,14 @@ __device__ __forceinline__ void encw_commit(int tid, const EncWRegs& r, float* E
     for (int i = 0; i < 2; ++i) {
         const int q = tid + i * 256;
         if (q >= 369) continue;
-        const int first[7] = {0, 88, 96, 352, 360, 363, 369};
-        int region = 0;
+        constexpr int first[7] = {0, 88, 96, 352, 360, 363, 369};
+        int region = 0, local = q;
 #pragma unroll
         for (int rr = 1; rr < 6; ++rr)
-            if (q >= first[rr]) region = rr;
-        const int local = q - first[region];
+            if (q >= first[rr]) {
+                region = rr;
+                local = q - first[rr];
+            }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int idx = local * 4 + e;

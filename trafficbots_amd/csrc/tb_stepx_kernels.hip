@@ -233,6 +233,10 @@ __global__ __launch_bounds__(AWB ? 2 * NTHREADS : NTHREADS, LEAN ? (W3 ? 3 : 2) 
     }
     extern __shared__ __attribute__((aligned(16))) float smem_all[];
     float* const smem = smem_all + AW_PREFIX;
+#ifdef TB_PROFILE
+    const long long t_entry = clock64();
+#endif
+    kernarg_warm<(int)sizeof(RolloutP) + 12 + 32>();  // (+ the dispatch's block counts behind the explicit arguments)
 #ifdef TB_XDL_AW
     if (threadIdx.x == 0) {  // barrier count and "no command"
         unsigned int* w = aw_words();
@@ -378,30 +382,42 @@ __global__ __launch_bounds__(AWB ? 2 * NTHREADS : NTHREADS, LEAN ? (W3 ? 3 : 2) 
     }
 #endif
     TB_STAMP(0);
+#ifdef TB_PROFILE
+    if (threadIdx.x == 0) p.prof[(size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 32 + 31] = t_entry;
+#endif
     // ---- launch start: EVERY load of the prologue is issued before the first result is consumed (one cold round trip
     // instead of four): first weight unit, LayerNorm parameter blocks, row state, validity bytes, the C-half tile inputs.
     // The first unit assumes the common case (no interaction bypass); the rare single-agent scene reloads it below.
     const uint32_t lnbase[9] = {pw.inter[0].ln1_g, pw.inter[1].ln1_g, pw.inter[2].ln1_g, pw.as2pl[0].ln1_g, pw.as2pl[1].ln1_g,
                                 pw.as2pl[2].ln1_g, pw.as2tl[0].ln1_g, pw.as2tl[1].ln1_g, pw.as2tl[2].ln1_g};
-    f32x4 lnv[9], rs_st = splat(0.f), rs_ax = splat(0.f);
-    int rs_ty = -1;
-    uint8_t rs_v = 0, rs_g = 0, vb[4] = {0, 0, 0, 0};
+    // Round 5: the burst holds NO branch around a load, no arithmetic on a loaded value and no wave-uniform global address -- every
+    // one of those made the compiler wait inside the burst (a conditional load merges with a constant behind its branch: `s_waitcnt
+    // vmcnt` + a copy; a uniform address becomes a scalar load that stalls at its first use), and the "one round trip" was five in
+    // series (13.5 k cycles at the headline shape, 19 k at the stress shape).  Loads run at clamped indices for every thread; what a
+    // thread is not responsible for is dropped when the values are committed below.
+    f32x4 lnv[9], rs_st, rs_ax;
+    float rs_hv[2] = {0.f, 0.f}, rs_ha = 0.f, rs_hy = 0.f;
+    int rs_ty, nkw_p_v = 0, nkw_t_v = 0;
+    uint8_t rs_v, rs_g = 0;
+    unsigned int vb[4] = {0u, 0u, 0u, 0u};
     CInputs<NTHREADS> cin;
     EncWRegs encw;
     EpiRegs epi;
+    const int vz = vzero();
     TB_SCHED_FENCE();
     wloadx(u, do_c ? (p.skip_inter ? gru_first_x(W, pw.gru[0], px.gru[0], wave) : xlayer_first_x(W, pw.inter[0], px.inter[0], wave))
                    : xlayer_first_x(W, pw.as2pl[0], px.as2pl[0], wave), lane);
-    if (tid < TM) {
-        const size_t si = base_row + tid;
-        rs_ty = (tid < n_real) ? p.agent_type[(size_t)b * p.n_agent + row0 + tid] : -1;
+    TB_STAMP(12);
+    {
+        const int tr = tid & (TM - 1);
+        const int rowc = min(row0 + tr, p.n_agent - 1);
+        const size_t si = base_row + tr;
+        rs_ty = p.agent_type[(size_t)b * p.n_agent + rowc];
         if (PRE) {  // the post-override simulator state of step t is the ground truth of step t (RolloutP::pre_mode)
-            if (tid < n_real) {
-                const size_t hi = ((size_t)b * p.n_hist + t) * p.n_agent + row0 + tid;
-                rs_st = ldg4(p.hist_state + hi * 4);
-                rs_ax = f32x4{p.hist_vel[hi * 2], p.hist_vel[hi * 2 + 1], p.hist_acc[hi], p.hist_yaw_rate[hi]};
-                rs_v = p.hist_valid[hi];
-            }
+            const size_t hi = ((size_t)b * p.n_hist + t) * p.n_agent + rowc;
+            rs_st = ldg4(p.hist_state + hi * 4);
+            rs_hv[0] = p.hist_vel[hi * 2]; rs_hv[1] = p.hist_vel[hi * 2 + 1]; rs_ha = p.hist_acc[hi]; rs_hy = p.hist_yaw_rate[hi];
+            rs_v = p.hist_valid[hi];
         } else {
             rs_st = ldg4(p.state + si * 4);
             rs_ax = ldg4(p.aux + si * 4);
@@ -409,25 +425,39 @@ __global__ __launch_bounds__(AWB ? 2 * NTHREADS : NTHREADS, LEAN ? (W3 ? 3 : 2) 
             rs_g = p.goal_valid[si];
         }
     }
-    if (do_c) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-            if (i * 64 + lane < p.a_pad) vb[i] = p.valid[(size_t)n * p.a_pad + i * 64 + lane];  // (a_pad <= 256)
-        c_inputs_issue<NTHREADS, W3 ? 1 : (LEAN ? 4 : 6), !(LEAN && XL_DG_GLOBAL)>(p, n, row0, tid, cin);
-    }
+    if (do_c) c_inputs_issue<NTHREADS, W3 ? 1 : (LEAN ? 4 : 6), !(LEAN && XL_DG_GLOBAL)>(p, n, row0, tid, cin);
     if (!LEAN) {
 #pragma unroll
-        for (int sl = 0; sl < 9; ++sl)
-            if (tid < 192) lnv[sl] = ldg4(W + lnbase[sl] + tid * 4);
+        for (int sl = 0; sl < 9; ++sl) lnv[sl] = ldg4(W + lnbase[sl] + min(tid, 191) * 4);
     }
-    if (do_a) encw_issue(pw, W, tid, encw);
-    if (!PRE) epi_issue(p, t, n, b, row0, n_real, tid, do_c != 0, epi);
+    if (do_a) {
+        encw_issue(pw, W, tid, encw);
+        // the key counts of the A half's walks (vector loads: see vzero)
+        nkw_p_v = p.nkey_pl[b + vz];
+        nkw_t_v = p.nkey_tl[b * p.n_tl_hist + min(t, p.n_tl_hist - 1) + vz];
+    }
+    if (do_c) {  // (byte loads at the end of the burst: see epi_issue)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) vb[i] = p.valid[(size_t)n * p.a_pad + min(i * 64 + lane, p.a_pad - 1)];  // (a_pad <= 256)
+    }
+    if (!PRE && wave == 0) epi_issue(p, t, n, b, row0, tid, do_c != 0, epi);
     TB_SCHED_FENCE();
+    TB_STAMP(13);
     if (do_a) encw_commit(tid, encw, ENCW);
-    if (!PRE) epi_commit(tid, do_c != 0, epi, sm);
+    if (!PRE) epi_commit(p, n_real, tid, do_c != 0, epi, sm);
+    TB_STAMP(14);
     if (tid == TM) dflag[EPI_POISON_WORD] = 0;
     if (tid < TM) {
-        rtype[tid] = rs_ty;
+        const bool real = tid < n_real;
+        if (PRE) {
+            rs_ax = f32x4{rs_hv[0], rs_hv[1], rs_ha, rs_hy};
+            if (!real) {
+                rs_st = splat(0.f);
+                rs_ax = splat(0.f);
+                rs_v = 0;
+            }
+        }
+        rtype[tid] = real ? rs_ty : -1;
         rst[tid].st[0] = rs_st.x; rst[tid].st[1] = rs_st.y; rst[tid].st[2] = rs_st.z; rst[tid].st[3] = rs_st.w;
         rst[tid].aux[0] = rs_ax.x; rst[tid].aux[1] = rs_ax.y; rst[tid].aux[2] = rs_ax.z; rst[tid].aux[3] = rs_ax.w;
         rowvalid[tid] = rs_v;
@@ -439,7 +469,7 @@ __global__ __launch_bounds__(AWB ? 2 * NTHREADS : NTHREADS, LEAN ? (W3 ? 3 : 2) 
         int n_valid = 0, hi_valid = 0;  // number of valid agents of the instance / one past the last valid one
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const unsigned long long vm = __ballot(vb[i] != 0);
+            const unsigned long long vm = __ballot(pin_v(vb[i]) != 0u && i * 64 + lane < p.a_pad);
             n_valid += __popcll(vm);
             if (vm) hi_valid = i * 64 + 64 - __clzll(vm);
         }
@@ -457,6 +487,7 @@ __global__ __launch_bounds__(AWB ? 2 * NTHREADS : NTHREADS, LEAN ? (W3 ? 3 : 2) 
                 if (tid < 192) st4(LN + sl * 768 + tid * 4, lnv[sl]);
         }
         if (bypass1 && !p.skip_inter) wloadx(u, gru_first_x(W, pw.gru[0], px.gru[0], wave), lane);
+        TB_STAMP(15);
         __syncthreads();
         TB_STAMP(1);
         unsigned int gh_seen = 0u;  // the GRU helper's flag, requested one interaction layer early (thread 0)
@@ -641,12 +672,12 @@ __global__ __launch_bounds__(AWB ? 2 * NTHREADS : NTHREADS, LEAN ? (W3 ? 3 : 2) 
     TB_STAMP(8);
     const int g_tl = b * p.n_tl_hist + min(t1 - 1, p.n_tl_hist - 1);
     // no lit traffic light at this step (the hoist counted the valid keys): as2tl keeps only its FFN halves
-    const int nkw_t = p.nkey_tl[g_tl];
+    const int nkw_t = __builtin_amdgcn_readfirstlane(nkw_t_v);  // (= p.nkey_tl[g_tl], requested in the launch prologue)
     const int nk_t_raw = nkey_walk(nkw_t), nv_t = nkey_valid(nkw_t);
     const bool tl_empty = nk_t_raw == 0;
     {
         const float* kvd = p.kbias_pl + (size_t)b * p.p_pad;
-        const int nkw_p = p.nkey_pl[b];
+        const int nkw_p = __builtin_amdgcn_readfirstlane(nkw_p_v);  // (= p.nkey_pl[b], requested in the launch prologue)
         const int nk_p = max(32, nkey_walk(nkw_p)), nv_p = nkey_valid(nkw_p);  // valid polylines, compacted to the front by the hoist, rounded up to whole key blocks
         const int ks_p = ((rt * (nk_p >> 5)) / n_rt) << 5;
         const size_t ls = (size_t)p.p_pad * H;
