@@ -1,10 +1,10 @@
 #!/bin/bash
 # GPU box: A/B of libtrafficbots_hip.so against libtrafficbots_hip_base.so on the headline and the sub-record shapes, back to back.
-# usage: bash tools/gpu_ab_cfg.sh [reps] [configs...]
+# usage: [LIBS="_base _mid"] bash tools/gpu_ab_cfg.sh [reps] [configs...]
 reps=${1:-2}; shift
 cfgs=${@:-"stress_bf16 k6_bf16"}
 for rep in $(seq 1 $reps); do
-for lib in "" _base; do
+for lib in "" ${LIBS:-_base}; do
   L=""; [ -n "$lib" ] && L="TB_HIP_LIB=trafficbots_amd/lib/libtrafficbots_hip$lib.so"
   env $L python bench.py --steps 30 --warmup 5 --no-cpu-baseline --lean 2>/dev/null | python -c "
 import sys, json

@@ -927,7 +927,7 @@ static int rollout_setup(tb_ctx* ctx, const tb_rollout_io* io, tb::RolloutP& p) 
     p.sync_err = ctx->d_status + 1;
     if (with_gh && ctx->step_kernel >= 2) {
         // L2 warmers (tb_stepx_kernels.hip): request times of the weight units of a fused launch, cycles since launch start, from the
-        // stage profiles (profiles/r03_stage_profile_k_step_x.txt, fp16 pairs: prologue 13 k, an interaction layer 9.2 k + 2.2 k per
+        // stage profiles (profiles/r03_stage_profile_k_step_x.txt, fp16 pairs: prologue 13 k -- 9.5 k since round 5's burst --, an interaction layer 9.2 k + 2.2 k per
         // key block, GRU 23 k, fusion 9 k, head 9 k, epilogue + front 10 k, a map layer 9.2 k + 1.12 k per key block, a
         // traffic-light layer 11.3 k; bf16 operands: x 0.7).  Only what follows the helpers' own work is listed.  TB_STEP_WARM=0: off.
         const char* we = getenv("TB_STEP_WARM");
@@ -942,7 +942,7 @@ static int rollout_setup(tb_ctx* ctx, const tb_rollout_io* io, tb::RolloutP& p) 
                 std::vector<int> tab;
                 auto add = [&](uint32_t off, double t) { tab.push_back((int)off); tab.push_back((int)(t * sc)); };
                 const double t_inter = 9200.0 + 2240.0 * (p.a_pad / 32), t_pl = 9200.0 + 1120.0 * (p.p_pad / 32), t_tl = 11300.0;
-                double t = 13000.0 + 3 * t_inter;  // the GRU
+                double t = 9500.0 + 3 * t_inter;  // the GRU
                 for (int l = 0; l < 3; ++l)
                     for (int g = 0; g < 3; ++g) add(x.gru[l].wih + (uint32_t)g * gate, t + (l * 3 + g) * 2500.0 - 1700.0);
                 t += 23000.0;

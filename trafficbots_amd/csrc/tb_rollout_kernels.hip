@@ -274,6 +274,7 @@ __device__ __forceinline__ void fuse_latent_goal(const float* __restrict__ W, ui
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(NTHREADS) void k_step(RolloutP p, int t, int do_c, int do_a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    kernarg_warm<(int)sizeof(RolloutP) + 12 + 32>();  // (tb_step_common.hpp: one miss of the cold scalar cache instead of a chain)
     float* X = smem + OFF_X;
     float* S1 = smem + OFF_S1;
     float* S2 = smem + OFF_S2;

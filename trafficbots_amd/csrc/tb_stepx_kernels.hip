@@ -91,11 +91,16 @@ __device__ __forceinline__ void fuse_latent_goal_x(const float* __restrict__ W, 
     {
         const int ta = 2 * wave, tb_ = 2 * wave + 1;
         f32x4 acc[2] = {uw.b[0], uw.b[1]};
+        f32x4 pre_a, pre_b;
+        if (PRE_GLOBAL) {  // PRE = the tile's rows in the rollout workspace ([16][128] fp32): requested in front of the GEMM that hides them
+            pre_a = ldg4(PRE + (size_t)m * H + ta * 16 + kq * 4);
+            pre_b = ldg4(PRE + (size_t)m * H + tb_ * 16 + kq * 4);
+        }
         wmmax_pf(acc[0], acc[1], uw, CP + m * LDPC + kq * 8, PLANEC, u2, wstdx(W, w2x, W + b2, wave), lane);
         if (zv) {
-            if (PRE_GLOBAL) {  // PRE = the tile's rows in the rollout workspace ([16][128] fp32)
-                acc[0] += ldg4(PRE + (size_t)m * H + ta * 16 + kq * 4);
-                acc[1] += ldg4(PRE + (size_t)m * H + tb_ * 16 + kq * 4);
+            if (PRE_GLOBAL) {
+                acc[0] += pre_a;
+                acc[1] += pre_b;
             } else {
                 acc[0] += lds4(cptr(const_cast<float*>(PRE), LDT, ta, lane));
                 acc[1] += lds4(cptr(const_cast<float*>(PRE), LDT, tb_, lane));
@@ -425,7 +430,7 @@ __global__ __launch_bounds__(AWB ? 2 * NTHREADS : NTHREADS, LEAN ? (W3 ? 3 : 2) 
             rs_g = p.goal_valid[si];
         }
     }
-    if (do_c) c_inputs_issue<NTHREADS, W3 ? 1 : (LEAN ? 4 : 6), !(LEAN && XL_DG_GLOBAL)>(p, n, row0, tid, cin);
+    if (do_c) c_inputs_issue<NTHREADS, W3 ? 1 : 4, !(LEAN && XL_DG_GLOBAL)>(p, n, row0, tid, cin);
     if (!LEAN) {
 #pragma unroll
         for (int sl = 0; sl < 9; ++sl) lnv[sl] = ldg4(W + lnbase[sl] + min(tid, 191) * 4);
@@ -480,7 +485,7 @@ __global__ __launch_bounds__(AWB ? 2 * NTHREADS : NTHREADS, LEAN ? (W3 ? 3 : 2) 
         // scenes keep their valid agents in the leading slots)
         const int nk_a = min(p.a_pad, max(32, (hi_valid + 31) & ~31));
         const int ks_a = ((rt * (nk_a >> 5)) / n_rt) << 5;
-        c_inputs_commit<NTHREADS, W3 ? 1 : (LEAN ? 4 : 6), !(LEAN && XL_DG_GLOBAL)>(tid, cin, X, Hs, H1, H2, GP, LP, DG, dflag);
+        c_inputs_commit<NTHREADS, W3 ? 1 : 4, !(LEAN && XL_DG_GLOBAL)>(tid, cin, X, Hs, H1, H2, GP, LP, DG, dflag);
         if (!LEAN) {
 #pragma unroll
             for (int sl = 0; sl < 9; ++sl)
@@ -568,7 +573,7 @@ __global__ __launch_bounds__(AWB ? 2 * NTHREADS : NTHREADS, LEAN ? (W3 ? 3 : 2) 
         }
         TB_STAMP(3);
         // ---- add_goal, add_latent (traffic_bots.py:240-241); concat planes = PC..PD, hidden = PB
-        fuse_latent_goal_x<LEAN>(W, px.goal_out_w2, pw.goal_out_b2, X, PC, PB, LEAN ? p.goal_pre + base_row * H : GP, gvalid, rowvalid, tid, u,
+        fuse_latent_goal_x<true>(W, px.goal_out_w2, pw.goal_out_b2, X, PC, PB, p.goal_pre + base_row * H, gvalid, rowvalid, tid, u,
                            wnextx(W, px.lat_out_w1, W + pw.lat_out_b1, 2 * wave, 2 * wave + 1, 8, 0), amax);
         const int my_ty = (lane < TM && rowvalid[lane]) ? rtype[lane] : -1;
         const bool has0 = __ballot(my_ty == 0) != 0, has1 = __ballot(my_ty == 1) != 0, has2 = __ballot(my_ty == 2) != 0;
@@ -577,7 +582,7 @@ __global__ __launch_bounds__(AWB ? 2 * NTHREADS : NTHREADS, LEAN ? (W3 ? 3 : 2) 
         const WNextX h1 = has1 ? wstdx(W, px.head_w1[1], W + pw.head_b1[1], wave) : h2;
         const WNextX h0 = has0 ? wstdx(W, px.head_w1[0], W + pw.head_b1[0], wave) : h1;
         TB_STAMP(4);
-        fuse_latent_goal_x<LEAN>(W, px.lat_out_w2, pw.lat_out_b2, X, PC, PB, LEAN ? p.lat_pre + base_row * H : LP, rowvalid, rowvalid, tid, u, h0, amax);
+        fuse_latent_goal_x<true>(W, px.lat_out_w2, pw.lat_out_b2, X, PC, PB, p.lat_pre + base_row * H, rowvalid, rowvalid, tid, u, h0, amax);
         TB_STAMP(5);
         if ((t == p.tap_step || p.tap_step == -2) && p.tap_policy_feature)
             store_tile(p.tap_policy_feature + ((size_t)n * p.n_agent + row0) * H, X, LDT, n_real, tid);
