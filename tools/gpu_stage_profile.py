@@ -67,7 +67,13 @@ if os.environ.get("TB_STEP_KERNEL") != "fp32":  # k_step_x: stamps inside the on
     for i in range(6):
         v = st[:, seqx[i + 1]] - st[:, seqx[i]]
         print(f"    C-start/{labx[i]:52s} {np.median(v):8.0f}  [{v.min():7.0f} .. {v.max():7.0f}]")
-    print(f"    (last launch, C half only) first entry -> last workgroup's stamp 7 {st[:, 7].max() - st[:, 31].min():8.0f}; entry skew {st[:, 31].max() - st[:, 31].min():8.0f}; stamp-7 skew {st[:, 7].max() - st[:, 7].min():8.0f}")
+    if a * b * k // 16 <= 128:  # helper workgroups (slots 28 / 29: their entry / end of their own work; the last launch is C only: same grid)
+        e_t, e_h, d_h, c_end = st[:, 27], st[:, 28], st[:, 29], st[:, 26]  # s_memrealtime ticks (10 ns)
+        t0 = min(e_t.min(), e_h.min())
+        us = lambda v: 0.01 * float(v)
+        print(f"    dispatch (us since the first workgroup's entry): helper entries {us(e_h.min() - t0):.2f} .. {us(e_h.max() - t0):.2f}, tile entries "
+              f"{us(e_t.min() - t0):.2f} .. {us(e_t.max() - t0):.2f} (median {us(np.median(e_t) - t0):.2f}); helpers done {us(np.median(d_h) - t0):.2f} (median) "
+              f"{us(d_h.max() - t0):.2f} (last); tiles' C half done {us(np.median(c_end) - t0):.2f} (median) {us(c_end.max() - t0):.2f} (last)")
 seq = [0, 12, 13, 14, 15, 1]
 lab = ["LN params -> LDS (issue+store)", "row state loads (16 thr)", "valid ballots", "wload + 6 tile loads + geometry issue", "barrier (wait for all)"]
 if os.environ.get("TB_STEP_KERNEL") == "fp32":  # (k_step_x keeps no stamps inside its one-round-trip prologue)

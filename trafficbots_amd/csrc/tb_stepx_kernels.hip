@@ -239,7 +239,7 @@ __global__ __launch_bounds__(AWB ? 2 * NTHREADS : NTHREADS, LEAN ? (W3 ? 3 : 2) 
     extern __shared__ __attribute__((aligned(16))) float smem_all[];
     float* const smem = smem_all + AW_PREFIX;
 #ifdef TB_PROFILE
-    const long long t_entry = clock64();
+    const long long t_entry = clock64(), t_entry_wall = wall_clock64();  // (s_memtime counts per XCD; s_memrealtime, 100 MHz, is one clock)
 #endif
     kernarg_warm<(int)sizeof(RolloutP) + 12 + 32>();  // (+ the dispatch's block counts behind the explicit arguments)
 #ifdef TB_XDL_AW
@@ -334,6 +334,9 @@ __global__ __launch_bounds__(AWB ? 2 * NTHREADS : NTHREADS, LEAN ? (W3 ? 3 : 2) 
     const bool helpers = !W3 && !AWB && !PRE && gridDim.z == 2;
     if (helpers && blockIdx.z == 0) {
         const long long t_launch = clock64();
+#ifdef TB_PROFILE  // (slots 28 / 29 of the tile's record: the helper workgroup's entry and the end of its own work)
+        if (threadIdx.x == 0) p.prof[(size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 32 + 28] = t_entry_wall;
+#endif
         // ---- helper of tile (n, rt) (RolloutP::gh): interaction K / V of layers 1, 2 of THIS step from the stored x_mid, then
         // W_hh h_{t-1} of the three GRU layers; handed to the tile workgroups (blockIdx.z = 1) through L2
         WUnitX uh;
@@ -356,6 +359,9 @@ __global__ __launch_bounds__(AWB ? 2 * NTHREADS : NTHREADS, LEAN ? (W3 ? 3 : 2) 
                       p.hidden + (((size_t)1 * p.n_inst + n) * p.a_pad + row0) * H, p.hidden + (((size_t)2 * p.n_inst + n) * p.a_pad + row0) * H,
                       p.gh + (size_t)tile_id * GH_TILE_FLOATS, p.gh_flag + tile_id, (unsigned int)t + 1u, PA, tid, uh, !p.skip_inter);
         range_flush(hmax);
+#ifdef TB_PROFILE
+        if (threadIdx.x == 0) p.prof[(size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 32 + 29] = wall_clock64();
+#endif
         // L2 WARMERS (round 5; VERDICT r04 task 6): the helper workgroups of an XCD, done with their own work ~25 k cycles into the launch,
         // touch the weight units the tile workgroups of THEIR XCD are about to request -- one 4-byte load per 128-byte line, unit i by
         // helper i mod 2 of the XCD's first TWO helpers (the other fourteen leave: a second stream's launch can have their CUs; with
@@ -389,6 +395,7 @@ __global__ __launch_bounds__(AWB ? 2 * NTHREADS : NTHREADS, LEAN ? (W3 ? 3 : 2) 
     TB_STAMP(0);
 #ifdef TB_PROFILE
     if (threadIdx.x == 0) p.prof[(size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 32 + 31] = t_entry;
+    if (threadIdx.x == 0) p.prof[(size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 32 + 27] = t_entry_wall;
 #endif
     // ---- launch start: EVERY load of the prologue is issued before the first result is consumed (one cold round trip
     // instead of four): first weight unit, LayerNorm parameter blocks, row state, validity bytes, the C-half tile inputs.
@@ -658,6 +665,9 @@ __global__ __launch_bounds__(AWB ? 2 * NTHREADS : NTHREADS, LEAN ? (W3 ? 3 : 2) 
         __syncthreads();
     }
     TB_STAMP(7);
+#ifdef TB_PROFILE
+    if (threadIdx.x == 0) p.prof[(size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 32 + 26] = wall_clock64();
+#endif
     if (!do_a) {
 #ifdef TB_XDL_AW
         if (tid == 0) aw_post(AW_OP_EXIT);
