@@ -445,6 +445,8 @@ void tb_destroy(tb_ctx* ctx) {
     if (!ctx) return;
     if (ctx->enc_fork) (void)hipEventDestroy(ctx->enc_fork);
     if (ctx->enc_join) (void)hipEventDestroy(ctx->enc_join);
+    if (ctx->enc_map) (void)hipEventDestroy(ctx->enc_map);
+    if (ctx->enc_join2) (void)hipEventDestroy(ctx->enc_join2);
     if (ctx->d_arena) (void)hipFree(ctx->d_arena);
     if (ctx->d_ws) (void)hipFree(ctx->d_ws);
     if (ctx->d_rule_ws) (void)hipFree(ctx->d_rule_ws);

@@ -485,7 +485,9 @@ static void launch_xblock(const XBlockP& p, int G, hipStream_t s) {
 // Returns true when the block also did the node pooling asked for with pool_out / pool_valid (the fused polyline kernel).
 static bool run_block(bool xdl, const float* W, const XLayerW* L, const XLayerX* LX, int n_layer, const float* tgt, const uint8_t* tgt_valid,
                       int G, int n_tgt, int n_pad, float* K, float* VT, float* kbias, const float* src, const uint8_t* src_valid, float* dst,
-                      int n_rows, int eye, hipStream_t s, float* pool_out = nullptr, uint8_t* pool_valid = nullptr) {
+                      int n_rows, int eye, hipStream_t s, float* pool_out = nullptr, uint8_t* pool_valid = nullptr, int part = 0) {
+    // part: 0 = K / V hoist + block, 1 = the hoist only, 2 = the block only (the hoist needs the targets alone: it may run on another
+    // stream before the block's sources exist; the generic hoist + block pair only)
     if (xdl) {
         XBlockPX x{};
         x.W = W; x.n_layer = n_layer;
@@ -506,11 +508,12 @@ static bool run_block(bool xdl, const float* W, const XLayerW* L, const XLayerX*
             xh::launch_polyline_block_x(x, G, K, VT, kbias, s);
             return false;
         }
-        xh::launch_kv_hoist_nx(W, L, LX, n_layer, tgt, tgt_valid, G, n_tgt, n_pad, K, VT, kbias, s);
-        xh::launch_xblock_x(x, G, s);
+        if (part != 2) xh::launch_kv_hoist_nx(W, L, LX, n_layer, tgt, tgt_valid, G, n_tgt, n_pad, K, VT, kbias, s);
+        if (part != 1) xh::launch_xblock_x(x, G, s);
         return false;
     }
-    launch_kv_hoist_n(W, L, n_layer, tgt, tgt_valid, G, n_tgt, n_pad, K, VT, kbias, s);
+    if (part != 2) launch_kv_hoist_n(W, L, n_layer, tgt, tgt_valid, G, n_tgt, n_pad, K, VT, kbias, s);
+    if (part == 1) return false;
     XBlockP x{};
     x.W = W; x.n_layer = n_layer;
     for (int l = 0; l < n_layer; ++l) x.L[l] = L[l];
@@ -546,14 +549,12 @@ static void carve_latent(Carver& c, LatentWs& w, size_t B, size_t S3, size_t A, 
 
 // Prior (which = 0) or posterior (which = 1) personality over the steps {0, 5, 10, ...} of NS encoded steps: agent -> map,
 // agent -> traffic lights (shared as2pl / as2tl weights), interaction, GRU over time, max over valid steps, DistEncoder mean.
-static void launch_latent_branch(bool xdl, const float* W, const EncoderW& ew, int which, int B, int NS, int A, int P, int T,
-                                 const float* agent_feature, const uint8_t* agent_valid, const float* tl_feature,
-                                 const uint8_t* tl_valid, const float* map_feature, const uint8_t* map_fvalid, const LatentWs& w,
-                                 float* out_mean, uint8_t* out_valid, hipStream_t s) {
-    const int a_pad = padk(A), p_pad = padk(P), t_pad = padk(T);
+// The part of it that needs neither the map feature nor anything computed on the main stream -- the gathers of the down-sampled steps
+// and the K / V hoist of the traffic-light targets -- is launch_latent_pre: run_encode puts it on the side stream, under the map encoder.
+static void launch_latent_pre(bool xdl, const float* W, const EncoderW& ew, int B, int NS, int A, int T, const float* agent_feature,
+                              const uint8_t* agent_valid, const float* tl_feature, const uint8_t* tl_valid, const LatentWs& w, hipStream_t s) {
+    const int t_pad = padk(T);
     const int S3 = (NS - 1) / 5 + 1;  // latent_encoder.py:98-103
-    const XLayerW* inter = which ? ew.inter_post : ew.inter_prior;
-    const GruLayerW* gru = which ? ew.gru_post : ew.gru_prior;
     const int RC4 = A * 32;
     size_t total = (size_t)B * S3 * RC4;
     hipLaunchKernelGGL(k_gather_steps_f, dim3((total + 255) / 256), dim3(256), 0, s, agent_feature, w.x0, B, NS, S3, 5, RC4);
@@ -563,10 +564,21 @@ static void launch_latent_branch(bool xdl, const float* W, const EncoderW& ew, i
     hipLaunchKernelGGL(k_gather_steps_f, dim3((total + 255) / 256), dim3(256), 0, s, tl_feature, w.tl3, B, NS, S3, 5, T * 32);
     total = (size_t)B * S3 * T;
     hipLaunchKernelGGL(k_gather_steps_u8, dim3((total + 255) / 256), dim3(256), 0, s, tl_valid, w.tlv3, B, NS, S3, 5, T);
+    // K / V of the traffic-light targets of agent -> traffic lights (its block runs in launch_latent_branch)
+    run_block(xdl, W, ew.as2tl, ew.as2tl_x, 3, w.tl3, w.tlv3, B * S3, T, t_pad, w.ktl, w.vttl, w.kvtl, w.x1, w.v0, w.x2, A, 0, s, nullptr, nullptr, 1);
+}
+
+static void launch_latent_branch(bool xdl, const float* W, const EncoderW& ew, int which, int B, int NS, int A, int P, int T,
+                                 const float* map_feature, const uint8_t* map_fvalid, const LatentWs& w,
+                                 float* out_mean, uint8_t* out_valid, hipStream_t s) {
+    const int a_pad = padk(A), p_pad = padk(P), t_pad = padk(T);
+    const int S3 = (NS - 1) / 5 + 1;  // latent_encoder.py:98-103
+    const XLayerW* inter = which ? ew.inter_post : ew.inter_prior;
+    const GruLayerW* gru = which ? ew.gru_post : ew.gru_prior;
     // agent -> map over the S3*A tokens of each scene (shared as2pl weights)
     run_block(xdl, W, ew.as2pl, ew.as2pl_x, 3, map_feature, map_fvalid, B, P, p_pad, w.kpl, w.vtpl, w.kvpl, w.x0, w.v0, w.x1, S3 * A, 0, s);
-    // agent -> traffic lights, per step
-    run_block(xdl, W, ew.as2tl, ew.as2tl_x, 3, w.tl3, w.tlv3, B * S3, T, t_pad, w.ktl, w.vttl, w.kvtl, w.x1, w.v0, w.x2, A, 0, s);
+    // agent -> traffic lights, per step (K / V hoisted by launch_latent_pre)
+    run_block(xdl, W, ew.as2tl, ew.as2tl_x, 3, w.tl3, w.tlv3, B * S3, T, t_pad, w.ktl, w.vttl, w.kvtl, w.x1, w.v0, w.x2, A, 0, s, nullptr, nullptr, 2);
     // interaction (own weights), tgt = block input
     run_block(xdl, W, inter, which ? ew.inter_post_x : ew.inter_prior_x, 3, w.x2, w.v0, B * S3, A, a_pad, w.kin, w.vtin, w.kvin, w.x2, w.v0,
               w.x3, A, 1, s);
@@ -652,6 +664,8 @@ int run_encode(struct ::tb_ctx* ctx, const tb_encode_io* io, hipStream_t s) {
             if (!ctx->enc_fork) {
                 TB_HIP(ctx, hipEventCreateWithFlags(&ctx->enc_fork, hipEventDisableTiming));
                 TB_HIP(ctx, hipEventCreateWithFlags(&ctx->enc_join, hipEventDisableTiming));
+                TB_HIP(ctx, hipEventCreateWithFlags(&ctx->enc_map, hipEventDisableTiming));
+                TB_HIP(ctx, hipEventCreateWithFlags(&ctx->enc_join2, hipEventDisableTiming));
             }
             s2 = ctx->cap_stream;
             TB_HIP(ctx, hipEventRecord(ctx->enc_fork, s));
@@ -691,6 +705,7 @@ int run_encode(struct ::tb_ctx* ctx, const tb_encode_io* io, hipStream_t s) {
         hipLaunchKernelGGL(k_encode_tokens, dim3((l.n_tok + TM * TOK_GROUPS - 1) / (TM * TOK_GROUPS)), dim3(NTHREADS), 0, s2, l);
         if (s2 != s) {
             dest_scan(s2);
+            launch_latent_pre(ctx->encode_kernel == 1, W, ew, B, NH, A, T, io->agent_feature, io->agent_valid, io->tl_feature, io->tl_valid, lws, s2);
             TB_HIP(ctx, hipEventRecord(ctx->enc_join, s2));
         }
     }
@@ -711,24 +726,41 @@ int run_encode(struct ::tb_ctx* ctx, const tb_encode_io* io, hipStream_t s) {
         run_block(ctx->encode_kernel == 1, W, &ew.map_self, &ew.map_self_x, 1, plf, io->map_feature_valid, B, P, p_pad, kps, vtps, kvps, plf,
                   io->map_feature_valid, io->map_feature, P, 0, s);
     }
-    // ---- personality prior
-    if (s2 != s) TB_HIP(ctx, hipStreamWaitEvent(s, ctx->enc_join, 0));
-    launch_latent_branch(ctx->encode_kernel == 1, W, ew, 0, B, NH, A, P, T, io->agent_feature, io->agent_valid, io->tl_feature, io->tl_valid, io->map_feature,
-                         io->map_feature_valid, lws, io->latent_mean, io->latent_valid, s);
-    // ---- destination predictor
-    {
-        if (s2 == s) dest_scan(s);
-        hipLaunchKernelGGL(k_linear_rows, dim3((B * P + TM - 1) / TM), dim3(NTHREADS), 0, s, W, ew.dest_w0_map, ew.dest_b0, 1,
+    // ---- personality prior on `s`, destination predictor beside it on the side stream: both start from the map feature and share
+    // nothing else (the predictor's agent half, the GRU scan over the history, ran on the side stream already)
+    auto dest_predictor = [&](hipStream_t st) {
+        hipLaunchKernelGGL(k_linear_rows, dim3((B * P + TM - 1) / TM), dim3(NTHREADS), 0, st, W, ew.dest_w0_map, ew.dest_b0, 1,
                            io->map_feature, B * P, U);
-        hipLaunchKernelGGL(k_linear_rows, dim3((B * A + TM - 1) / TM), dim3(NTHREADS), 0, s, W, ew.dest_w0_agent, 0u, 0, tgt, B * A, V);
+        hipLaunchKernelGGL(k_linear_rows, dim3((B * A + TM - 1) / TM), dim3(NTHREADS), 0, st, W, ew.dest_w0_agent, 0u, 0, tgt, B * A, V);
         DestP d{};
         d.W = W; d.ln0_g = ew.dest_ln0_g; d.ln0_b = ew.dest_ln0_b; d.w1 = ew.dest_w1; d.b1 = ew.dest_b1; d.ln1_g = ew.dest_ln1_g;
         d.ln1_b = ew.dest_ln1_b; d.w2 = ew.dest_w2; d.b2 = ew.dest_b2;
         d.B = B; d.A = A; d.P = P; d.U = U; d.V = V; d.map_fvalid = io->map_feature_valid; d.map_type = io->map_type;
         d.agent_type = io->agent_type; d.dist_valid = tgtv; d.logits = io->dest_logits;
         d.w1x = ew.dest_w1_x;
-        if (ctx->encode_kernel == 1) xh::launch_dest_pairs_x(d, s);
-        else hipLaunchKernelGGL(k_dest_pairs, dim3((P + TM - 1) / TM, A, B), dim3(NTHREADS), 0, s, d);
+        if (ctx->encode_kernel == 1) xh::launch_dest_pairs_x(d, st);
+        else hipLaunchKernelGGL(k_dest_pairs, dim3((P + TM - 1) / TM, A, B), dim3(NTHREADS), 0, st, d);
+    };
+    const char* ed = getenv("TB_ENCODE_DEST_SIDE");
+    const bool dest_side = s2 != s && !(ed && ed[0] == '0');
+    if (s2 != s) {
+        if (dest_side) {
+            TB_HIP(ctx, hipEventRecord(ctx->enc_map, s));
+            TB_HIP(ctx, hipStreamWaitEvent(s2, ctx->enc_map, 0));
+            dest_predictor(s2);
+            TB_HIP(ctx, hipEventRecord(ctx->enc_join2, s2));
+        }
+        TB_HIP(ctx, hipStreamWaitEvent(s, ctx->enc_join, 0));
+    } else {
+        launch_latent_pre(ctx->encode_kernel == 1, W, ew, B, NH, A, T, io->agent_feature, io->agent_valid, io->tl_feature, io->tl_valid, lws, s);
+    }
+    launch_latent_branch(ctx->encode_kernel == 1, W, ew, 0, B, NH, A, P, T, io->map_feature, io->map_feature_valid, lws, io->latent_mean,
+                         io->latent_valid, s);
+    if (dest_side) {
+        TB_HIP(ctx, hipStreamWaitEvent(s, ctx->enc_join2, 0));
+    } else {
+        if (s2 == s) dest_scan(s);
+        dest_predictor(s);
     }
     TB_HIP(ctx, hipGetLastError());
     return 0;
@@ -777,8 +809,9 @@ int run_encode_posterior(struct ::tb_ctx* ctx, const tb_posterior_io* io, hipStr
     l.kind = 1; l.mlp = ew.tl_enc; l.n_tok = B * NS * T; l.per_scene = NS * T; l.inner = T;
     l.valid = io->tl_valid; l.pos = io->tl_pos; l.dir = io->tl_dir; l.cls = io->tl_state; l.out = tf;
     hipLaunchKernelGGL(k_encode_tokens, dim3((l.n_tok + TM * TOK_GROUPS - 1) / (TM * TOK_GROUPS)), dim3(NTHREADS), 0, s, l);
-    launch_latent_branch(ctx->encode_kernel == 1, W, ew, 1, B, NS, A, P, T, af, io->agent_valid, tf, io->tl_valid, io->map_feature, io->map_feature_valid, lws,
-                         io->latent_mean, io->latent_valid, s);
+    launch_latent_pre(ctx->encode_kernel == 1, W, ew, B, NS, A, T, af, io->agent_valid, tf, io->tl_valid, lws, s);
+    launch_latent_branch(ctx->encode_kernel == 1, W, ew, 1, B, NS, A, P, T, io->map_feature, io->map_feature_valid, lws, io->latent_mean,
+                         io->latent_valid, s);
     TB_HIP(ctx, hipGetLastError());
     return 0;
 }

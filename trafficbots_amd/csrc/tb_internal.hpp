@@ -69,7 +69,7 @@ struct tb_ctx {
     // chip, and independent of the map) run on a side stream beside the map encoder's chip-filling launches; forked from and joined
     // back into the caller's stream with events (TB_ENCODE_SIDE=0: everything on the caller's stream).  2.60 -> 2.40 ms per 32 scenes.
     // (A second fork -- the destination logits beside the personality branch -- gained nothing: 2.42 .. 2.51 ms.)
-    hipEvent_t enc_fork = nullptr, enc_join = nullptr;
+    hipEvent_t enc_fork = nullptr, enc_join = nullptr, enc_map = nullptr, enc_join2 = nullptr;
 };
 
 

@@ -352,8 +352,10 @@ __device__ __forceinline__ void epi_issue(const RolloutP& p, int t, int n, int b
     const TfSource f = tf_source(p, t, n, b, rowc);
     e.hst = ldg4(f.state + f.hi * 4);
     e.vel[0] = f.vel[f.hi * 2]; e.vel[1] = f.vel[f.hi * 2 + 1]; e.acc = f.acc[f.hi]; e.yr = f.yr[f.hi];
-    {   // [N,A,S,2] draws; absent: `preds` ([N,A,S,4]) holds the index
-        const float* ap = (p.action_eps ? p.action_eps : p.preds) + (((size_t)n * p.n_agent + rowc) * p.n_step_out + (t - p.step_start)) * 2;
+    {   // [N,A,S,2] draws; absent: `preds` ([N,A,S,4]) holds the index.  The A-only launch of tb_rollout_begin runs at t = step_start - 1
+        // (its record is dropped, do_c = false): without the clamp lane 0 of instance 0 read 8 bytes in FRONT of the array -- a memory
+        // fault whenever the array opens an allocation (found in round 5 when a freed workspace moved torch's segments)
+        const float* ap = (p.action_eps ? p.action_eps : p.preds) + (((size_t)n * p.n_agent + rowc) * p.n_step_out + max(t - p.step_start, 0)) * 2;
         e.ae[0] = ap[0]; e.ae[1] = ap[1];
     }
     const size_t ai = (size_t)n * p.n_agent + rowc;
