@@ -514,7 +514,7 @@ def test_packed_polyline_tiling_is_bitwise_identical(monkeypatch):
         batch = synth.make_batch(seed, n_scene, n_agent=48, n_pl=n_pl, n_tl=20, **masks)
         scene = scene_from_batch(batch, torch.device("cuda", 0))
         got = {}
-        for mode in ("3", "2", "1", "0"):  # ("3", the default since round 5: the fused kernel on eight waves, `k_polyline_fused8`)
+        for mode in ("4", "3", "2", "1", "0"):  # ("4", the default: eight waves with merged phases, `k_polyline_fused8<true>`; "3": `<false>`)
             monkeypatch.setenv("TB_ENCODE_PACK", mode)
             enc = eng.encode_scene(scene)
             torch.cuda.synchronize()
@@ -527,6 +527,7 @@ def test_packed_polyline_tiling_is_bitwise_identical(monkeypatch):
             assert torch.equal(v, got["1"][k_]), (n_pl, k_, "packed")
             assert torch.equal(v, got["2"][k_]), (n_pl, k_, "fused")
             assert torch.equal(v, got["3"][k_]), (n_pl, k_, "fused, eight waves")
+            assert torch.equal(v, got["4"][k_]), (n_pl, k_, "fused, eight waves, merged phases")
 
 def test_bench_sub_records_and_traj_err():
     """the default single-GPU command carries the configs[3] / configs[4] sub-records and the golden trajectory error"""

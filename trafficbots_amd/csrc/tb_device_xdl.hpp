@@ -226,6 +226,23 @@ __device__ __forceinline__ void layernorm_planes(const float* src, int lds_, xha
     planes_store4<false>(P, PLANE, LDP, row, c0 + 4, dc * splat(rstd) * g1 + b1);
 }
 
+// The same LayerNorm of one row segment whose eight values are already in registers (a = columns c0 .. c0 + 3, c = c0 + 4 .. c0 + 7 of
+// row tid >> 4; k_polyline_fused8<true> keeps the block input of LN_tgt there for the whole kernel): the arithmetic and its order are
+// those of layernorm_planes -- same bits.
+__device__ __forceinline__ void layernorm_planes_regs(const f32x4& a, const f32x4& c, xhalf* P, const float* __restrict__ g,
+                                                      const float* __restrict__ b, int tid) {
+    const int row = tid >> 4, c0 = (tid & 15) * 8;
+    const f32x4 g0 = ldg4(g + c0), g1 = ldg4(g + c0 + 4), b0 = ldg4(b + c0), b1 = ldg4(b + c0 + 4);
+    const float s = row16_sum((a.x + a.y) + (a.z + a.w) + (c.x + c.y) + (c.z + c.w));
+    const float mean = s * (1.0f / 128.0f);
+    const f32x4 da = a - splat(mean), dc = c - splat(mean);
+    const float v = row16_sum((da.x * da.x + da.y * da.y) + (da.z * da.z + da.w * da.w) + (dc.x * dc.x + dc.y * dc.y) +
+                              (dc.z * dc.z + dc.w * dc.w));
+    const float rstd = 1.0f / sqrtf(v * (1.0f / 128.0f) + LN_EPS);
+    planes_store4<false>(P, PLANE, LDP, row, c0, da * splat(rstd) * g0 + b0);
+    planes_store4<false>(P, PLANE, LDP, row, c0 + 4, dc * splat(rstd) * g1 + b1);
+}
+
 // The same LayerNorm for N tiles at once (tile t at src + t * src_stride floats, its planes at P + t * p_stride fp16): the N
 // independent latency chains (LDS read -> two 16-lane reductions -> rsqrt -> pair split -> LDS write) are written side by side so
 // that they overlap in one wave's instruction stream; per tile the arithmetic and its order are those of layernorm_planes.

@@ -84,7 +84,7 @@ void launch_kv_hoist_nx(const float* W, const XLayerW* L, const XLayerX* X, int 
                         int n_tok, int n_pad, float* K, float* VT, float* kbias, hipStream_t s);
 void launch_xblock_x(const XBlockPX& p, int G, hipStream_t s);
 void launch_polyline_block_x(const XBlockPX& p, int G, float* K, float* VT, float* kbias, hipStream_t s);
-void launch_polyline_fused_x(const XBlockPX& p, int G, hipStream_t s, bool eight_waves);
+void launch_polyline_fused_x(const XBlockPX& p, int G, hipStream_t s, int eight_waves);  // 0: four waves, 1: eight, 2: eight with merged phases
 }  // namespace xh
 
 }  // namespace tb

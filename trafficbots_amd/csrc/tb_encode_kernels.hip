@@ -496,12 +496,13 @@ static bool run_block(bool xdl, const float* W, const XLayerW* L, const XLayerX*
         // the map encoder's polyline block (20 nodes, self-attention inside the polyline) runs on the packed tiling: no padding rows
         const char* pe = getenv("TB_ENCODE_PACK");  // (read per call: the tests flip it inside one process)
         const bool pack = !(pe && pe[0] == '0');
-        // '3' (default since round 5): the fused kernel on eight waves (k_polyline_fused8); '2': the fused kernel, K / V in LDS, four
-        // waves; '1': packed tiling with the K / V hoist through HBM; '0': padded tiling
-        const int pmode = pe ? pe[0] - '0' : 3;
+        // '4' (default): the fused kernel on eight waves with merged phases (k_polyline_fused8<true>); '3': eight waves, the four-wave
+        // kernel's phases (k_polyline_fused8<false>); '2': the fused kernel, K / V in LDS, four waves; '1': packed tiling with the K / V
+        // hoist through HBM; '0': padded tiling
+        const int pmode = pe ? pe[0] - '0' : 4;
         if (pmode >= 2 && pool_out && n_tgt == 20 && n_rows == 20 && n_pad == 32 && tgt == src && tgt_valid == src_valid && !eye && G % 2 == 0) {
             x.pool_out = pool_out; x.pool_valid = pool_valid;
-            xh::launch_polyline_fused_x(x, G, s, pmode == 3);
+            xh::launch_polyline_fused_x(x, G, s, pmode == 4 ? 2 : (pmode == 3 ? 1 : 0));
             return true;
         }
         if (pack && n_tgt == 20 && n_rows == 20 && n_pad == 32 && tgt == src && tgt_valid == src_valid && !eye && G % 4 == 0) {
@@ -622,7 +623,7 @@ int run_encode(struct ::tb_ctx* ctx, const tb_encode_io* io, hipStream_t s) {
     // map-encoder chunking bounds the per-polyline K/V scratch (3 layers x 32 keys x 128 x 2 x 4 B = 96 KiB / polyline)
     // (the fused polyline kernel keeps K / V in LDS: no scratch, one launch over all polylines)
     const char* pe_ = getenv("TB_ENCODE_PACK");
-    const bool fused_pl = ctx->encode_kernel == 1 && (pe_ ? (pe_[0] == '2' || pe_[0] == '3') : true) && P % 2 == 0;
+    const bool fused_pl = ctx->encode_kernel == 1 && (pe_ ? (pe_[0] >= '2' && pe_[0] <= '4') : true) && P % 2 == 0;
     const int scenes_per_chunk = fused_pl ? B : std::max(1, std::min(B, (int)(((size_t)512 << 20) / ((size_t)P * 98304))));
     const size_t kv_scenes = fused_pl ? 0 : (size_t)scenes_per_chunk;
 

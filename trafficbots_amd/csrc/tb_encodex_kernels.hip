@@ -553,6 +553,11 @@ __device__ __forceinline__ void layernorm_planes_3x8(const float* src, xhalf* P,
     if (tid < NTHREADS) layernorm_planes<false>(src + 2 * TM * LDT, LDT, P + 2 * p_stride, g, b, t16);
 }
 
+// MERGE (round 5, second form): LN_tgt and LN1 in ONE phase and the K, V and Q projections in ONE phase.  The block input of LN_tgt
+// (fixed over the layers) stays in 16 VGPRs of the thread that normalises it -- no staging copy per layer, no barrier behind it -- and
+// LN1 writes the second plane set, so the Q projection no longer waits for the K / V projections to release the first: seven
+// barriers per layer instead of ten, two LayerNorm latency chains side by side.  Per element the same instruction sequence: same bits.
+template <bool MERGE>
 __global__ __launch_bounds__(NT8) void k_polyline_fused8(XBlockPX p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* X = smem;                                                   // [3][16][LDT]
@@ -585,6 +590,18 @@ __global__ __launch_bounds__(NT8) void k_polyline_fused8(XBlockPX p) {
     WUnit1X u, u2;
     WUnitX uq;
     wload1x(u, wnext1x(p.W, p.LX[0].wkv, p.W + p.L[0].bkv, wave), lane);
+    // MERGE: this thread's segments of the block input for LN_tgt (layernorm_planes_3x8's assignment: row (tid & 255) >> 4, columns
+    // (tid & 15) * 8 .. + 7 of head tile tid >> 8; the first half of the workgroup also of the tail tile, whose rows 8 .. 15 are zeros)
+    f32x4 tg_a, tg_c, tt_a = splat(0.f), tt_c = splat(0.f);
+    if (MERGE) {
+        const int t = tid >> 8, r = (tid & 255) >> 4, c0 = (tid & 15) * 8;
+        const float* ph = p.src + ((size_t)(g0 + t) * PL_NODES + r) * H + c0;
+        tg_a = ldg4(ph); tg_c = ldg4(ph + 4);
+        if (tid < NTHREADS && r < 8) {
+            const float* pt = p.src + ((size_t)(g0 + (r >> 2)) * PL_NODES + 16 + (r & 3)) * H + c0;
+            tt_a = ldg4(pt); tt_c = ldg4(pt + 4);
+        }
+    }
     load3(X);
     if (tid < 48) {
         const int t = tid >> 4, r = tid & 15;
@@ -599,6 +616,8 @@ __global__ __launch_bounds__(NT8) void k_polyline_fused8(XBlockPX p) {
         for (int i = tid; i < 4 * KV_BLOCK_HALFS / 8; i += NT8) kv8[i] = z;
     }
     __syncthreads();
+    // the plane set the Q projection reads LN1's output from
+    xhalf* const PQ = MERGE ? P2 : P1;
 
     // this wave's output tile of a Linear over the three row tiles; the next unit is requested first (ua != ub)
     auto gemm3 = [&](const WUnit1X& ua, WUnit1X& ub, const WNext1X& next, const xhalf* P, f32x4 (&a)[3]) {
@@ -615,11 +634,17 @@ __global__ __launch_bounds__(NT8) void k_polyline_fused8(XBlockPX p) {
         const XLayerX& LX = p.LX[l];
         const float* lnblk = p.W + L.ln1_g;
         // ---- K / V of the layer from the block input
-        if (l > 0) {  // (layer 0: X still holds the block input)
-            load3(S);
-            __syncthreads();
+        if (MERGE) {
+            layernorm_planes_regs(tg_a, tg_c, P1 + (tid >> 8) * PS, lnblk + 256, lnblk + 384, tid & 255);
+            if (tid < NTHREADS) layernorm_planes_regs(tt_a, tt_c, P1 + 2 * PS, lnblk + 256, lnblk + 384, tid);
+            layernorm_planes_3x8(X, P2, PS, lnblk, lnblk + 128, tid);
+        } else {
+            if (l > 0) {  // (layer 0: X still holds the block input)
+                load3(S);
+                __syncthreads();
+            }
+            layernorm_planes_3x8(l > 0 ? S : X, P1, PS, lnblk + 256, lnblk + 384, tid);
         }
-        layernorm_planes_3x8(l > 0 ? S : X, P1, PS, lnblk + 256, lnblk + 384, tid);
         __syncthreads();
         {
             f32x4 ak[3], av[3];
@@ -656,16 +681,19 @@ __global__ __launch_bounds__(NT8) void k_polyline_fused8(XBlockPX p) {
                 if (kq < 2) v_store(VL + kq * KV_BLOCK_HALFS + head * (NPL * 1024) + m * 8 + 4 + half * 512, av[2]);
             }
         }
-        __syncthreads();  // (the projections have read P1: LayerNorm 1 may overwrite it; K / V are in place)
-        // ---- the layer on the three tiles
-        layernorm_planes_3x8(X, P1, PS, lnblk, lnblk + 128, tid);
-        __syncthreads();
+        if (!MERGE) {
+            __syncthreads();  // (the projections have read P1: LayerNorm 1 may overwrite it; K / V are in place)
+            // ---- the layer on the three tiles
+            layernorm_planes_3x8(X, P1, PS, lnblk, lnblk + 128, tid);
+            __syncthreads();
+        }
         {
             // Q of this wave's head for its own rows: head tile `half` (polyline `half`) and the tail tile
             f32x4 qo[2] = {uq.b[0], uq.b[1]}, qt[2] = {uq.b[0], uq.b[1]};
             wload1x(u2, wnext1x(p.W, LX.wo, p.W + L.bo, wave), lane);
-            wmmax(qo[0], qo[1], uq, P1 + half * PS + po, PLANE);
-            wmmax(qt[0], qt[1], uq, P1 + 2 * PS + po, PLANE);
+            wmmax(qo[0], qo[1], uq, PQ + half * PS + po, PLANE);
+            wmmax(qt[0], qt[1], uq, PQ + 2 * PS + po, PLANE);
+            if (MERGE) __syncthreads();  // (K / V of every head are in place; every wave has read its Q rows from the second plane set)
             f32x4 oo[2], ot[2];
             const xhalf* Kp = KL + half * KV_BLOCK_HALFS;
             const xhalf* Vp = VL + half * KV_BLOCK_HALFS;
@@ -737,9 +765,10 @@ __global__ __launch_bounds__(NT8) void k_polyline_fused8(XBlockPX p) {
     }
 }
 
-void launch_polyline_fused_x(const XBlockPX& p, int G, hipStream_t s, bool eight_waves) {
+void launch_polyline_fused_x(const XBlockPX& p, int G, hipStream_t s, int eight_waves) {
     const size_t lds = PLF_LDS_BYTES + (NPL == 1 ? 3 * TM * LDT * 4 : 0);
-    if (eight_waves) hipLaunchKernelGGL(k_polyline_fused8, dim3(G / 2), dim3(NT8), lds, s, p);
+    if (eight_waves == 2) hipLaunchKernelGGL(k_polyline_fused8<true>, dim3(G / 2), dim3(NT8), lds, s, p);
+    else if (eight_waves) hipLaunchKernelGGL(k_polyline_fused8<false>, dim3(G / 2), dim3(NT8), lds, s, p);
     else hipLaunchKernelGGL(k_polyline_fused, dim3(G / 2), dim3(NTHREADS), lds, s, p);
 }
 
@@ -971,9 +1000,12 @@ hipError_t configure_encodex_kernels() {
     const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_polyline_fused), hipFuncAttributeMaxDynamicSharedMemorySize,
                                              PLF_LDS_BYTES + (NPL == 1 ? 3 * TM * LDT * 4 : 0));
     if (e != hipSuccess) return e;
-    const hipError_t e8 = hipFuncSetAttribute(reinterpret_cast<const void*>(k_polyline_fused8), hipFuncAttributeMaxDynamicSharedMemorySize,
+    const hipError_t e8 = hipFuncSetAttribute(reinterpret_cast<const void*>(k_polyline_fused8<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                               PLF_LDS_BYTES + (NPL == 1 ? 3 * TM * LDT * 4 : 0));
     if (e8 != hipSuccess) return e8;
+    const hipError_t e8m = hipFuncSetAttribute(reinterpret_cast<const void*>(k_polyline_fused8<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               PLF_LDS_BYTES + (NPL == 1 ? 3 * TM * LDT * 4 : 0));
+    if (e8m != hipSuccess) return e8m;
     return hipFuncSetAttribute(reinterpret_cast<const void*>(k_gru_scan_x), hipFuncAttributeMaxDynamicSharedMemorySize, SCANX_LDS_BYTES);
 }
 
