@@ -541,6 +541,13 @@ def run_rank(args, rank: int, local_rank: int, world: int) -> None:
         enc_g.append(e0.elapsed_time(e1))
     encode_ms = sorted(enc_t)[1]      # median of three: wall clock of one synchronous call (host enqueue + GPU + synchronize)
     encode_gpu_ms = sorted(enc_g)[1]  # the same calls between two events on the caller's stream (the side stream is joined before the second)
+    # the same call ten times back to back (a data loader feeding batch after batch: clocks up, nothing idles between the calls)
+    torch.cuda.synchronize()
+    t0 = time.time()
+    for _ in range(10):
+        eng.encode_scene(scene)
+    torch.cuda.synchronize()
+    encode_ms_back_to_back = (time.time() - t0) * 1e2
 
     # a generation-2 collection of the interpreter (tens of ms with the weight / scene dicts alive) in the launching thread
     # starves the stream right after a synchronize, when nothing is queued ahead: collect now, keep the collector off while timing
@@ -695,6 +702,7 @@ def run_rank(args, rank: int, local_rank: int, world: int) -> None:
             "src_sha256": __import__("__graft_entry__").build_fingerprint(),
             "encode_ms": encode_ms,
             "encode_gpu_ms": encode_gpu_ms,
+            "encode_ms_back_to_back": encode_ms_back_to_back,
             "pass_ms": {"min": pass_ms[0], "median": pass_ms[len(pass_ms) // 2], "max": pass_ms[-1]},
             "kernel_us": {"k_step_fused": k_us, "n_fused": tm["n_fused"], "edge_launches_ms": tm["edge_ms"], "prologue_ms": tm["prologue_ms"],
                           "note": "per rollout: n_fused fused launches; edge_launches_ms = the batched warm-start launch (A halves of the "

@@ -58,7 +58,10 @@ typedef xhalf xh8 __attribute__((ext_vector_type(8)));
 typedef xhalf xh4 __attribute__((ext_vector_type(4)));
 typedef xhalf xh2 __attribute__((ext_vector_type(2)));
 
-constexpr int LDP = 136;            // fp16 per plane row for 128-wide inputs (272 B: 16 rows x b128 reads hit 64 distinct banks)
+#ifndef TB_LDP
+#define TB_LDP 136
+#endif
+constexpr int LDP = TB_LDP;         // fp16 per plane row for 128-wide inputs (272 B: 16 rows x b128 reads hit 64 distinct banks)
 constexpr int PLANE = TM * LDP;     // fp16 per plane
 constexpr int PLANES_BYTES = NPL * PLANE * 2;  // 8704
 constexpr int LDPC = 264;           // row length of the 256-wide concat planes
