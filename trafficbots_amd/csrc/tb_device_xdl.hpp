@@ -229,21 +229,31 @@ __device__ __forceinline__ void layernorm_planes(const float* src, int lds_, xha
     planes_store4<false>(P, PLANE, LDP, row, c0 + 4, dc * splat(rstd) * g1 + b1);
 }
 
-// The same LayerNorm of one row segment whose eight values are already in registers (a = columns c0 .. c0 + 3, c = c0 + 4 .. c0 + 7 of
-// row tid >> 4; k_polyline_fused8<true> keeps the block input of LN_tgt there for the whole kernel): the arithmetic and its order are
-// those of layernorm_planes -- same bits.
-__device__ __forceinline__ void layernorm_planes_regs(const f32x4& a, const f32x4& c, xhalf* P, const float* __restrict__ g,
-                                                      const float* __restrict__ b, int tid) {
-    const int row = tid >> 4, c0 = (tid & 15) * 8;
-    const f32x4 g0 = ldg4(g + c0), g1 = ldg4(g + c0 + 4), b0 = ldg4(b + c0), b1 = ldg4(b + c0 + 4);
+// The same LayerNorm in two steps, for an input that is normalised more than once with different parameters (k_polyline_fused8<true>:
+// the block input of LN_tgt is fixed over the layers, and at layer 0 it is LN1's input as well): ln_stats takes the statistics of a
+// row segment held in registers (a = columns c0 .. c0 + 3, c = c0 + 4 .. c0 + 7 of row tid >> 4, c0 = (tid & 15) * 8) and leaves the
+// centred values and 1 / std; ln_apply scales, shifts, splits and stores.  The arithmetic and its order are those of
+// layernorm_planes -- same bits -- and the two 16-lane reductions and the division are paid once.
+struct LnSeg {
+    f32x4 da, dc;
+    float rstd;
+};
+__device__ __forceinline__ LnSeg ln_stats(const f32x4& a, const f32x4& c) {
     const float s = row16_sum((a.x + a.y) + (a.z + a.w) + (c.x + c.y) + (c.z + c.w));
     const float mean = s * (1.0f / 128.0f);
-    const f32x4 da = a - splat(mean), dc = c - splat(mean);
-    const float v = row16_sum((da.x * da.x + da.y * da.y) + (da.z * da.z + da.w * da.w) + (dc.x * dc.x + dc.y * dc.y) +
-                              (dc.z * dc.z + dc.w * dc.w));
-    const float rstd = 1.0f / sqrtf(v * (1.0f / 128.0f) + LN_EPS);
-    planes_store4<false>(P, PLANE, LDP, row, c0, da * splat(rstd) * g0 + b0);
-    planes_store4<false>(P, PLANE, LDP, row, c0 + 4, dc * splat(rstd) * g1 + b1);
+    LnSeg r;
+    r.da = a - splat(mean);
+    r.dc = c - splat(mean);
+    const float v = row16_sum((r.da.x * r.da.x + r.da.y * r.da.y) + (r.da.z * r.da.z + r.da.w * r.da.w) + (r.dc.x * r.dc.x + r.dc.y * r.dc.y) +
+                              (r.dc.z * r.dc.z + r.dc.w * r.dc.w));
+    r.rstd = 1.0f / sqrtf(v * (1.0f / 128.0f) + LN_EPS);
+    return r;
+}
+__device__ __forceinline__ void ln_apply(const LnSeg& r, xhalf* P, const float* __restrict__ g, const float* __restrict__ b, int tid) {
+    const int row = tid >> 4, c0 = (tid & 15) * 8;
+    const f32x4 g0 = ldg4(g + c0), g1 = ldg4(g + c0 + 4), b0 = ldg4(b + c0), b1 = ldg4(b + c0 + 4);
+    planes_store4<false>(P, PLANE, LDP, row, c0, r.da * splat(r.rstd) * g0 + b0);
+    planes_store4<false>(P, PLANE, LDP, row, c0 + 4, r.dc * splat(r.rstd) * g1 + b1);
 }
 
 // The same LayerNorm for N tiles at once (tile t at src + t * src_stride floats, its planes at P + t * p_stride fp16): the N

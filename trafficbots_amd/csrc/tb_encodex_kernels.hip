@@ -570,6 +570,14 @@ __global__ __launch_bounds__(NT8) void k_polyline_fused8(XBlockPX p) {
     uint8_t* novalid_s = rowvalid + 48;                                // [48]
     float* S = NPL == 2 ? reinterpret_cast<float*>(P2) : reinterpret_cast<float*>(novalid_s + 80);  // fp32 staging [3][16][LDT]
     const int tid = threadIdx.x, wave = wave_of(tid), lane = tid & 63, kq = lane >> 4, m = lane & 15;
+#ifdef TB_PROFILE_ENC  // (stage profile: clock64 stamps of thread 0 of one workgroup, printed from the device; tools/gpu_stage_profile_enc.sh)
+    __shared__ long long enc_prof[64];
+    int enc_np = 0;
+#define ENC_STAMP() do { if (tid == 0 && enc_np < 64) enc_prof[enc_np++] = clock64(); } while (0)
+#else
+#define ENC_STAMP() do { } while (0)
+#endif
+    ENC_STAMP();
     const int head = wave >> 1, half = wave & 1;  // attention head of this wave's output tile / which of the head's two feature tiles
     const int g0 = blockIdx.x * 2;
     const int po = m * LDP + kq * 8;
@@ -603,6 +611,13 @@ __global__ __launch_bounds__(NT8) void k_polyline_fused8(XBlockPX p) {
         }
     }
     load3(X);
+    // the statistics of the block input are taken ONCE: LN_tgt of the three layers and LN1 of layer 0 (X is the block input there,
+    // same thread assignment) differ in their parameters only
+    LnSeg sg{}, st{};
+    if (MERGE) {
+        sg = ln_stats(tg_a, tg_c);
+        st = ln_stats(tt_a, tt_c);
+    }
     if (tid < 48) {
         const int t = tid >> 4, r = tid & 15;
         rowvalid[tid] = t < 2 ? p.src_valid[(size_t)(g0 + t) * PL_NODES + r] : (r < 8 ? p.src_valid[(size_t)(g0 + (r >> 2)) * PL_NODES + 16 + (r & 3)] : 0);
@@ -616,6 +631,7 @@ __global__ __launch_bounds__(NT8) void k_polyline_fused8(XBlockPX p) {
         for (int i = tid; i < 4 * KV_BLOCK_HALFS / 8; i += NT8) kv8[i] = z;
     }
     __syncthreads();
+    ENC_STAMP();  // 1: prologue done
     // the plane set the Q projection reads LN1's output from
     xhalf* const PQ = MERGE ? P2 : P1;
 
@@ -635,9 +651,14 @@ __global__ __launch_bounds__(NT8) void k_polyline_fused8(XBlockPX p) {
         const float* lnblk = p.W + L.ln1_g;
         // ---- K / V of the layer from the block input
         if (MERGE) {
-            layernorm_planes_regs(tg_a, tg_c, P1 + (tid >> 8) * PS, lnblk + 256, lnblk + 384, tid & 255);
-            if (tid < NTHREADS) layernorm_planes_regs(tt_a, tt_c, P1 + 2 * PS, lnblk + 256, lnblk + 384, tid);
-            layernorm_planes_3x8(X, P2, PS, lnblk, lnblk + 128, tid);
+            ln_apply(sg, P1 + (tid >> 8) * PS, lnblk + 256, lnblk + 384, tid & 255);
+            if (tid < NTHREADS) ln_apply(st, P1 + 2 * PS, lnblk + 256, lnblk + 384, tid);
+            if (l == 0) {
+                ln_apply(sg, P2 + (tid >> 8) * PS, lnblk, lnblk + 128, tid & 255);
+                if (tid < NTHREADS) ln_apply(st, P2 + 2 * PS, lnblk, lnblk + 128, tid);
+            } else {
+                layernorm_planes_3x8(X, P2, PS, lnblk, lnblk + 128, tid);
+            }
         } else {
             if (l > 0) {  // (layer 0: X still holds the block input)
                 load3(S);
@@ -645,7 +666,9 @@ __global__ __launch_bounds__(NT8) void k_polyline_fused8(XBlockPX p) {
             }
             layernorm_planes_3x8(l > 0 ? S : X, P1, PS, lnblk + 256, lnblk + 384, tid);
         }
+        ENC_STAMP();  // LN_tgt (+ LN1)
         __syncthreads();
+        ENC_STAMP();  // barrier
         {
             f32x4 ak[3], av[3];
             gemm3(u, u2, wnext1x(p.W, LX.wkv, p.W + L.bkv, 8 + wave), P1, ak);
@@ -660,6 +683,7 @@ __global__ __launch_bounds__(NT8) void k_polyline_fused8(XBlockPX p) {
             k_store(KL, 0, m, ak[0]);
             k_store(KL + KV_BLOCK_HALFS, 0, m, ak[1]);
             if (m < 8) k_store(KL + (m >> 2) * KV_BLOCK_HALFS, 1, m & 3, ak[2]);
+            ENC_STAMP();  // K projection + stores
             // V with the MFMA operands swapped (k_polyline_fused): lane (kq, m) holds tokens 4 kq + r of feature m of this wave's d tile
             {
                 const float* bv = p.W + L.bkv + (8 + wave) * 16 + m;
@@ -681,6 +705,7 @@ __global__ __launch_bounds__(NT8) void k_polyline_fused8(XBlockPX p) {
                 if (kq < 2) v_store(VL + kq * KV_BLOCK_HALFS + head * (NPL * 1024) + m * 8 + 4 + half * 512, av[2]);
             }
         }
+        ENC_STAMP();  // V projection + stores
         if (!MERGE) {
             __syncthreads();  // (the projections have read P1: LayerNorm 1 may overwrite it; K / V are in place)
             // ---- the layer on the three tiles
@@ -693,7 +718,9 @@ __global__ __launch_bounds__(NT8) void k_polyline_fused8(XBlockPX p) {
             wload1x(u2, wnext1x(p.W, LX.wo, p.W + L.bo, wave), lane);
             wmmax(qo[0], qo[1], uq, PQ + half * PS + po, PLANE);
             wmmax(qt[0], qt[1], uq, PQ + 2 * PS + po, PLANE);
+            ENC_STAMP();  // Q projection
             if (MERGE) __syncthreads();  // (K / V of every head are in place; every wave has read its Q rows from the second plane set)
+            ENC_STAMP();  // barrier
             f32x4 oo[2], ot[2];
             const xhalf* Kp = KL + half * KV_BLOCK_HALFS;
             const xhalf* Vp = VL + half * KV_BLOCK_HALFS;
@@ -713,7 +740,9 @@ __global__ __launch_bounds__(NT8) void k_polyline_fused8(XBlockPX p) {
                 if (mine || pad) novalid_s[2 * TM + m] = (mine ? nt : true) ? 1 : 0;
             }
         }
+        ENC_STAMP();  // two one-block attentions + plane stores
         __syncthreads();
+        ENC_STAMP();  // barrier
         {
             f32x4 a[3];
             gemm3(u2, u, wnext1x(p.W, LX.w1, p.W + L.b1, wave), P2, a);
@@ -725,16 +754,22 @@ __global__ __launch_bounds__(NT8) void k_polyline_fused8(XBlockPX p) {
                 st4(px, nv ? xo : xo + a[t]);
             }
         }
+        ENC_STAMP();  // output projection + residual
         __syncthreads();
+        ENC_STAMP();  // barrier
         layernorm_planes_3x8(X, P1, PS, lnblk + 512, lnblk + 640, tid);
+        ENC_STAMP();  // LN2
         __syncthreads();
+        ENC_STAMP();  // barrier
         {
             f32x4 a[3];
             gemm3(u, u2, wnext1x(p.W, LX.w2, p.W + L.b2, wave), P1, a);
 #pragma unroll
             for (int t = 0; t < 3; ++t) planes_store_c(P2 + t * PS, wave, lane, relu4(a[t]));
         }
+        ENC_STAMP();  // FFN 1 + ReLU + plane stores
         __syncthreads();
+        ENC_STAMP();  // barrier
         {
             f32x4 a[3];
             const int ln = l + 1 < p.n_layer ? l + 1 : l;
@@ -746,8 +781,21 @@ __global__ __launch_bounds__(NT8) void k_polyline_fused8(XBlockPX p) {
                 st4(px, rv ? lds4(px) + a[t] : splat(0.f));
             }
         }
+        ENC_STAMP();  // FFN 2 + residual
         __syncthreads();
+        ENC_STAMP();  // barrier
     }
+#ifdef TB_PROFILE_ENC
+    if (MERGE && tid == 0 && blockIdx.x == 700) {
+        printf("ENCPROF8 entry->prologue %lld\n", enc_prof[1] - enc_prof[0]);
+        const char* nm[16] = {"LNtgt+LN1", "bar", "Kproj+store", "Vproj+store", "Qproj", "bar", "attn2+store", "bar", "Oproj+res", "bar", "LN2", "bar", "F1+relu+store", "bar", "F2+res", "bar"};
+        for (int l = 0; l < 3; ++l) {
+            printf("ENCPROF8 layer %d:", l);
+            for (int i = 0; i < 16; ++i) printf(" %s %lld", nm[i], enc_prof[2 + l * 16 + i] - enc_prof[1 + l * 16 + i]);
+            printf("\n");
+        }
+    }
+#endif
     if (tid < NTHREADS) {  // MapEncoder: max over the valid nodes of the polyline, one (polyline, feature) per thread (k_polyline_fused)
         const int pl = tid >> 7, f = tid & 127;
         float mx = -INFINITY;
