@@ -469,7 +469,9 @@ def test_encode_side_stream_is_bitwise_identical(monkeypatch):
     """tb_encode_scene runs the agent / traffic-light token encoders and the destination predictor's GRU scan on a side stream beside
     the map encoder (forked from / joined into the caller's stream with events); TB_ENCODE_SIDE=0 keeps everything on the caller's
     stream.  Same kernels, same arguments: every product of the encoder is bit-identical, call after call (the side stream is
-    joined before the personality branch, so a second call cannot overtake the first one's workspace)."""
+    joined before the personality branch, so a second call cannot overtake the first one's workspace).  Round 5: the side stream also
+    carries the latent branch's gathers + traffic-light K / V hoist and, behind the map feature, the destination predictor
+    (TB_ENCODE_DEST_SIDE=0 keeps the predictor on the caller's stream: mode "d"); the posterior encoder shares the split functions."""
     import bench
     from trafficbots_amd import synth
     from trafficbots_amd.config import load_model_config
@@ -477,8 +479,9 @@ def test_encode_side_stream_is_bitwise_identical(monkeypatch):
     sd = synth.make_state_dict(7)
     cfg = load_model_config(overrides={"time_step_end": 30, "n_joint_future": 1})
     got = {}
-    for mode in ("1", "0"):
-        monkeypatch.setenv("TB_ENCODE_SIDE", mode)
+    for mode in ("1", "d", "0"):
+        monkeypatch.setenv("TB_ENCODE_SIDE", "0" if mode == "0" else "1")
+        monkeypatch.setenv("TB_ENCODE_DEST_SIDE", "0" if mode == "d" else "1")
         c = bench.setup_case(cfg, sd, torch.device("cuda", 0), 0, 5, 48, 80, 1, seed=9900)
         eng, scene = c["eng"], c["scene"]
         encs = [eng.encode_scene(scene) for _ in range(3)]
@@ -489,9 +492,10 @@ def test_encode_side_stream_is_bitwise_identical(monkeypatch):
                 if torch.is_tensor(v):
                     assert torch.equal(v, e[k_]), (mode, k_)
         got[mode] = {k_: v.clone() for k_, v in encs[0].items() if torch.is_tensor(v)}
-    assert set(got["1"]) == set(got["0"]) and len(got["1"]) >= 5
+    assert set(got["1"]) == set(got["0"]) == set(got["d"]) and len(got["1"]) >= 5
     for k_, v in got["1"].items():
         assert torch.equal(v, got["0"][k_]), k_
+        assert torch.equal(v, got["d"][k_]), k_
 
 
 def test_packed_polyline_tiling_is_bitwise_identical(monkeypatch):
