@@ -8,11 +8,12 @@ rows=[(int(r['Start_Timestamp']),int(r['End_Timestamp']),r['Kernel_Name'].split(
 rows.sort()
 idx=[i for i,r in enumerate(rows) if 'polyline_fused' in r[2]]
 i0=idx[-1]
+if len(idx) > 1 and rows[idx[-1]][0] - rows[idx[-2]][1] < 50000: i0 = idx[-2]  # (two halves of one encode)
 j=i0
 for back in range(1,8):
     if 'k_encode_tokens' in rows[i0-back][2]: j=i0-back
 t0=rows[j][0]
-for r in rows[j:j+45]:
+for r in rows[j:j+48]:
+    if 'k_step' in r[2] or 'rollout' in r[2] or 'at::' in r[2]: break  # (the encode is over: rollout prologue / torch kernels)
     print(f"{(r[0]-t0)/1e3:8.1f} -> {(r[1]-t0)/1e3:8.1f}  dur {(r[1]-r[0])/1e3:7.1f}  q{r[3]} {r[2]}")
-    if 'dest_pairs' in r[2]: break
 PY
