@@ -475,6 +475,22 @@ def test_fp16_pair_operand_range(scale, expect):
             wr.engine.check_status()
         assert wr.engine.precision_state()["step"] == "fp32_exact"
         wr.engine.check_status()  # the flag is cleared by the check that reported it
+        # round 5: a step that draws from a `generator` and is re-run sees the SAME draws (the generator's state
+        # is restored for the re-run) -- the result equals, bit for bit, what the same context (now on the kernels it switched to)
+        # computes from a fresh generator with that seed (K = 2: the second future's personality and destination are sampled)
+        wg = WaymoMotion(time_step_end=step_end, n_joint_future=2)
+        wg.load_state_dict(sd)
+        with pytest.warns(RuntimeWarning, match="re-run on the exact-fp32 kernels"):
+            og = wg.test_step(batch, generator=torch.Generator(device="cuda").manual_seed(77))
+        og = {"preds": og["rollout_buffer"].preds.clone(), "goal_sample": og["goal_sample"].clone()}
+        import warnings as _w
+
+        with _w.catch_warnings():
+            _w.simplefilter("error", RuntimeWarning)  # (no second fallback)
+            o2 = wg.test_step(batch, generator=torch.Generator(device="cuda").manual_seed(77))
+        assert torch.equal(og["goal_sample"], o2["goal_sample"]) and torch.equal(og["preds"], o2["rollout_buffer"].preds)
+        o3 = wg.test_step(batch, generator=torch.Generator(device="cuda").manual_seed(78))
+        assert not torch.equal(og["preds"], o3["rollout_buffer"].preds)  # (the draws matter)
         with pytest.warns(RuntimeWarning, match=r"re-run on the exact-fp32 kernels: .* ms against"):
             out = wm.test_step(batch, latent_eps=torch.from_numpy(eps).cuda(), tap_step=1)
         st = wm.engine.precision_state()

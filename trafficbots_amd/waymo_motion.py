@@ -244,9 +244,9 @@ def _range_fallback(fn):
     instead of failing: `tb_check_status` reports the overflow, the context has then switched itself (fp32 MFMA kernels, fp32's range)
     and the step is issued again -- the reference has no range limit (`src/models/modules/mlp.py:20-85`), so a checkpoint that trips
     the guard still gets an fp32-accurate result, only slower (the warning states the measured slowdown).  Metric holders are restored
-    to their state before the invalid run; random numbers the step draws itself from a `generator` are drawn AGAIN for the re-run (pass
-    explicit draws -- `latent_eps`, `goal_sample`, `action_eps`, `irrelevant_draw`, `history_keep` -- where the run must be repeatable).
-    `check_range = False` skips the check (and the fallback)."""
+    to their state before the invalid run, and so is the state of a `generator` the step draws from: the re-run sees the SAME random
+    numbers as the invalid run did (round 5; before, it silently drew new ones).  `check_range = False` skips the check (and the
+    fallback)."""
     import copy
     import functools
     import time
@@ -257,6 +257,8 @@ def _range_fallback(fn):
         if not self.check_range:
             return fn(self, *args, **kwargs)
         snap = [copy.deepcopy(h.__dict__) for h in self._metric_holders()]
+        gen = kwargs.get("generator")
+        gen_state = gen.get_state() if gen is not None else None
         t0 = time.perf_counter()
         out = fn(self, *args, **kwargs)
         if not self.engine.check_status(raise_on_range=False):
@@ -264,6 +266,8 @@ def _range_fallback(fn):
         t1 = time.perf_counter()
         for h, d in zip(self._metric_holders(), snap):
             h.__dict__.update(d)
+        if gen_state is not None:
+            gen.set_state(gen_state)
         out = fn(self, *args, **kwargs)
         self.engine.check_status()  # (the exact kernels cannot raise the flag; anything else is a hard error)
         t2 = time.perf_counter()
@@ -681,7 +685,8 @@ class WaymoMotion:
             deterministic_latent=deterministic, deterministic_action=action_eps is None,  # (the reference passes True, :560)
             action_eps=action_eps,
             step_start=self.hparams["time_step_sim_start"], step_end=self.hparams["time_step_end"],
-            k_futures=k, latent_eps=latent_eps, tap_step=tap_step, gt=gt,
+            k_futures=k, latent_eps=latent_eps, tap_step=tap_step, gt=gt, generator=generator,  # (round 5: the personalities of the
+            # sampled futures were drawn from torch's GLOBAL generator whatever `generator` said: not repeatable per seed)
             warm_start_steps=self._warm_start_steps(tf, gt if gt is not None else batch), require_vis_dict=require_vis_dict,
         )
         buf.flatten_repeat(k)
