@@ -3,7 +3,7 @@
 # (copied to profiles/r03_fuzz_summary.txt by the builder).  Closed-loop cases beyond 1e-4 m are judged against an ensemble of the
 # oracle on re-ordered batches measured on the spot (tools/ensemble.py), as the test suite does.
 cd $GRAFT_REPO_ROOT
-O=gpurun_out/fuzz_r03.txt; : > $O
+O=gpurun_out/fuzz_${FUZZ_ROUND:-r05}.txt; : > $O
 run() { echo "### $*" >> $O; ( eval "$@" ) 2>&1 | grep -E "ensemble:|OUTSIDE|FAIL|all [0-9]+ cases|worst|Error|error|^ok$|first 11 steps [0-9.e-]+ collided" | tail -40 >> $O; }
 run FUZZ_SEED=424242 timeout 1500 python tests/probes/gpu_fuzz_shapes.py 120
 run FUZZ_SEED=11 FUZZ_KEEP_GOING=1 timeout 2400 python tests/probes/gpu_fuzz_validation.py 60
