@@ -618,3 +618,26 @@ def test_unfused_forward_cross_checks_the_fused_step_kernel():
     torch.cuda.synchronize()
     d = (fw["policy_feature"] - buf.taps["tap_policy_feature"]).abs() * agent_valid.unsqueeze(-1)
     assert float(d.max()) <= 5e-6 * max(1.0, float(buf.taps["tap_policy_feature"].abs().max())), float(d.max())
+
+
+@pytest.mark.parametrize("at_end", [0, 1])
+def test_no_access_outside_the_callers_buffers(at_end):
+    """Round 5 (profiles/r05_experiments.txt item 16: a kernel read 8 bytes in FRONT of `preds` -- silent until an allocation boundary
+    sat there).  tests/probes/gpu_guard_pages.py runs test_step (K = 1 .. 3, sampled actions), validation_step and a stepwise rollout
+    over three shapes with EVERY tensor handed to the C ABI replaced by a copy that has unmapped address space on both sides
+    (tests/guard/tb_guard.cpp: hipMemAddressReserve / hipMemMap; 4 KiB granules), at the start of its mapping (at_end = 0: an access in
+    front of an array is a GPU memory fault) or at its end (at_end = 1: an access behind it is).  A fault aborts the subprocess.  The
+    build with the bug put back (`tools/build_variant.sh _oobbug -DTB_DBG_OOB_STEP_INDEX`) dies here with "Memory access fault"."""
+    import subprocess
+    import sys
+
+    from conftest import ROOT
+
+    import __graft_entry__ as g
+
+    g.build_guard()
+    env = dict(os.environ, GUARD_AT_END=str(at_end))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "probes", "gpu_guard_pages.py")], env=env, capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode == 0 and "GUARD-OK" in r.stdout, (r.returncode, r.stdout[-400:], r.stderr[-1200:])
+

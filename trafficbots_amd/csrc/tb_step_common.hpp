@@ -355,7 +355,11 @@ __device__ __forceinline__ void epi_issue(const RolloutP& p, int t, int n, int b
     {   // [N,A,S,2] draws; absent: `preds` ([N,A,S,4]) holds the index.  The A-only launch of tb_rollout_begin runs at t = step_start - 1
         // (its record is dropped, do_c = false): without the clamp lane 0 of instance 0 read 8 bytes in FRONT of the array -- a memory
         // fault whenever the array opens an allocation (found in round 5 when a freed workspace moved torch's segments)
+#ifdef TB_DBG_OOB_STEP_INDEX  // (test builds only: the bug as it was, to show that tests/probes/gpu_guard_pages.py catches it)
+        const float* ap = (p.action_eps ? p.action_eps : p.preds) + (((size_t)n * p.n_agent + rowc) * p.n_step_out + (t - p.step_start)) * 2;
+#else
         const float* ap = (p.action_eps ? p.action_eps : p.preds) + (((size_t)n * p.n_agent + rowc) * p.n_step_out + max(t - p.step_start, 0)) * 2;
+#endif
         e.ae[0] = ap[0]; e.ae[1] = ap[1];
     }
     const size_t ai = (size_t)n * p.n_agent + rowc;

@@ -249,11 +249,19 @@ def load() -> C.CDLL:
     return lib
 
 
+# Test hook (tests/probes/gpu_guard_pages.py): an object with `shadow(tensor) -> int` and `writeback()`.  When set, every tensor handed
+# to the C ABI is replaced by a copy in a buffer with unmapped memory on both sides (tests/guard/tb_guard.cpp), and copied back after
+# the call -- an out-of-bounds access of a kernel becomes a GPU memory fault.  None in every product run.
+guard_hook = None
+
+
 def ptr(t, ctype):
     """Device pointer of a contiguous torch tensor (or NULL for None) as a ctypes pointer."""
     if t is None:
         return ctype()  # NULL
     assert t.is_contiguous(), "tensor handed to the C ABI must be contiguous"
+    if guard_hook is not None and t.is_cuda:
+        return C.cast(guard_hook.shadow(t), ctype)
     return C.cast(t.data_ptr(), ctype)
 
 
