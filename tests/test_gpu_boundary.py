@@ -636,8 +636,11 @@ def test_no_access_outside_the_callers_buffers(at_end):
     import __graft_entry__ as g
 
     g.build_guard()
-    env = dict(os.environ, GUARD_AT_END=str(at_end))
+    # ... and every carve of the library's OWN workspace in a mapping of its own between unmapped pages (TB_WS_GUARD: 1 = the buffer ends
+    # its mapping, 2 = it opens it): an overrun from one internal buffer into the next cannot hide inside the one allocation
+    env = dict(os.environ, GUARD_AT_END=str(at_end), TB_WS_GUARD="1" if at_end else "2")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "probes", "gpu_guard_pages.py")], env=env, capture_output=True, text=True,
                        timeout=900)
     assert r.returncode == 0 and "GUARD-OK" in r.stdout, (r.returncode, r.stdout[-400:], r.stderr[-1200:])
+    assert "TB_WS_GUARD=" in r.stderr and "every workspace carve" in r.stderr  # (the library's debug mode was on)
 

@@ -766,6 +766,45 @@ int tb_get_timing(tb_ctx* ctx, float* out4) {
 // ---------------------------------------------------------------------------------------------------
 // workspace
 // ---------------------------------------------------------------------------------------------------
+void* tb_ws_guard_take(size_t bytes) {
+    static const int mode = [] {
+        const char* e = getenv("TB_WS_GUARD");
+        return e ? atoi(e) : 0;
+    }();
+    if (mode != 1 && mode != 2) return nullptr;
+    static bool said = false;
+    if (!said) {
+        said = true;
+        fprintf(stderr, "TB_WS_GUARD=%d: every workspace carve is a mapping of its own between unmapped pages (debug mode)\n", mode);
+    }
+    static size_t gran = 0;
+    hipMemAllocationProp prop = {};
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    prop.location.id = dev;
+    if (!gran && hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityMinimum) != hipSuccess) return nullptr;
+    const size_t need = bytes ? bytes : 16, n = (need + gran - 1) / gran, total = (n + 2) * gran;
+    void* va = nullptr;
+    hipMemGenericAllocationHandle_t h;
+    hipMemAccessDesc acc = {};
+    acc.location = prop.location;
+    acc.flags = hipMemAccessFlagsProtReadWrite;
+    if (hipMemAddressReserve(&va, total, gran, nullptr, 0) != hipSuccess || hipMemCreate(&h, n * gran, &prop, 0) != hipSuccess) {
+        fprintf(stderr, "TB_WS_GUARD: reserve / create of %zu bytes failed\n", need);
+        abort();  // (a debug run that silently fell back to the plain workspace would prove nothing)
+    }
+    char* mid = static_cast<char*>(va) + gran;
+    if (hipMemMap(mid, n * gran, 0, h, 0) != hipSuccess || hipMemSetAccess(mid, n * gran, &acc, 1) != hipSuccess) {
+        fprintf(stderr, "TB_WS_GUARD: map of %zu bytes failed\n", need);
+        abort();
+    }
+    (void)hipMemRelease(h);
+    (void)hipMemset(mid, 0, n * gran);
+    return mode == 2 ? mid : mid + n * gran - ((need + 15) & ~(size_t)15);
+}
+
 int tb_ensure_workspace(tb_ctx* ctx, size_t bytes) {
     if (bytes <= ctx->ws_bytes) return 0;
     if (ctx->d_ws) {

@@ -89,6 +89,12 @@ inline int tb_fail(tb_ctx* ctx, const char* fmt, ...) {
         if (e_ != hipSuccess) return tb_fail(ctx, "%s failed: %s", #call, hipGetErrorString(e_)); \
     } while (0)
 
+// Debug facility (TB_WS_GUARD=1 | 2; tests/probes/gpu_guard_pages.py): every carve of the workspace becomes a mapping of its own with
+// UNMAPPED address space on both sides (HIP virtual-memory calls), the buffer at the end (1) or at the start (2) of its mapping -- a
+// kernel that runs over the end of one internal buffer into the next (invisible inside one allocation) takes a GPU memory fault.
+// The mappings live until the process ends; nothing for production.  Returns nullptr when the mode is off.
+void* tb_ws_guard_take(size_t bytes);
+
 // bump allocator over the context workspace (pass base = nullptr to size)
 struct Carver {
     char* base;
@@ -98,6 +104,8 @@ struct Carver {
         off = (off + 255) & ~(size_t)255;
         T* p = base ? reinterpret_cast<T*>(base + off) : nullptr;
         off += n * sizeof(T);
+        if (base)
+            if (void* g = tb_ws_guard_take(n * sizeof(T))) return reinterpret_cast<T*>(g);
         return p;
     }
 };
