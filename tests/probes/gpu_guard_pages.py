@@ -19,59 +19,11 @@ from trafficbots_amd import synth  # noqa: E402
 from trafficbots_amd.runtime import teacher_forcing_mask  # noqa: E402
 from trafficbots_amd.waymo_motion import WaymoMotion  # noqa: E402
 
-import ctypes as C  # noqa: E402
-
+sys.path.insert(0, os.path.join(ROOT, "tests", "guard"))
+import guard_pool  # noqa: E402
 from trafficbots_amd import hip  # noqa: E402
 
-
-class _Raw:
-    def __init__(self, p, n):
-        self.__cuda_array_interface__ = {"shape": (n,), "typestr": "|u1", "data": (p, False), "version": 2}
-
-
-class GuardPool:
-    """hip.guard_hook: shadow(tensor) -> address of a guarded copy; writeback() copies the shadows of the call back."""
-
-    def __init__(self, at_end: bool):
-        self.lib = C.CDLL(os.path.join(ROOT, "tests", "guard", "libtb_guard.so"))
-        self.lib.tbg_alloc.restype = C.c_void_p
-        self.lib.tbg_alloc.argtypes = [C.c_size_t, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
-        self.lib.tbg_free.argtypes = [C.c_void_p, C.c_size_t]
-        self.lib.tbg_granularity.restype = C.c_size_t
-        self.at_end, self.pending, self.live, self.n_shadow = int(at_end), {}, [], 0
-        assert self.lib.tbg_granularity() > 0, "hipMemGetAllocationGranularity failed"
-
-    def shadow(self, t):
-        key = (t.data_ptr(), t.numel() * t.element_size())
-        if key in self.pending:
-            return self.pending[key][0]
-        n = key[1]
-        base, span = C.c_void_p(), C.c_size_t()
-        p = self.lib.tbg_alloc(n, self.at_end, C.byref(base), C.byref(span))
-        assert p, "tbg_alloc failed"
-        self.live.append((base.value, span.value))
-        g = torch.as_tensor(_Raw(p, max(n, 1)), device="cuda")[:n] if n else None
-        if n:
-            g.copy_(t.reshape(-1).view(torch.uint8))
-        self.pending[key] = (p, g, t)
-        self.n_shadow += 1
-        return p
-
-    def writeback(self):
-        for p, g, t in self.pending.values():
-            if g is not None:
-                t.reshape(-1).view(torch.uint8).copy_(g)
-        self.pending = {}
-
-    def close(self):
-        torch.cuda.synchronize()
-        for base, span in self.live:
-            self.lib.tbg_free(base, span)
-        self.live = []
-
-
-pool = GuardPool(os.environ.get("GUARD_AT_END", "0") == "1")
-hip.guard_hook = pool
+pool = guard_pool.install(os.environ.get("GUARD_AT_END", "0") == "1")
 sd = synth.make_state_dict(7)
 for i, (b, a, p, t, k) in enumerate(((2, 16, 32, 8, 1), (1, 33, 48, 5, 3), (3, 64, 66, 40, 2))):
     batch = synth.make_batch(7700 + i, b, n_agent=a, n_pl=p, n_tl=t, p_invalid_agent=0.2, p_late_spawn=0.2, p_invalid_pl=0.2, p_invalid_node=0.3)
@@ -124,6 +76,5 @@ wb = WaymoMotion(time_step_end=14, n_joint_future=6, operand_precision="bf16")  
 wb.load_state_dict(sd)
 assert torch.isfinite(wb.test_step(big, generator=torch.Generator(device="cuda").manual_seed(10))["rollout_buffer"].preds).all()
 torch.cuda.synchronize()
-hip.guard_hook = None
-pool.close()
+guard_pool.uninstall(pool)
 print(f"GUARD-OK ({pool.n_shadow} guarded buffers, at_end={pool.at_end}, granule {pool.lib.tbg_granularity()} B)")
