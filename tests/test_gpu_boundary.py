@@ -620,6 +620,36 @@ def test_unfused_forward_cross_checks_the_fused_step_kernel():
     assert float(d.max()) <= 5e-6 * max(1.0, float(buf.taps["tap_policy_feature"].abs().max())), float(d.max())
 
 
+def test_range_flag_with_two_contexts_on_one_device():
+    """the fp16-pair range flag is one word per device and kernel family.  With two contexts on one device, the check of
+    context A used to take -- and clear -- an overflow raised by context B: A was downgraded for nothing and B got rc 0 for invalid
+    results.  Round 5: whoever takes the flag hands its bits to every other live context of the device; B's own check still reports
+    the overflow and switches B to the exact kernels (A's report is conservative: it cannot tell whose launch raised the flag)."""
+    from trafficbots_amd.waymo_motion import WaymoMotion
+
+    g, meta = load_golden("small_k1")
+    cfg, sd0, batch, eps = golden_inputs(meta)
+    wa = WaymoMotion(time_step_end=15, n_joint_future=1)
+    wa.load_state_dict(sd0)
+    wb = WaymoMotion(time_step_end=15, n_joint_future=1)
+    wb.load_state_dict(_scaled(sd0, 3e5))
+    wa.check_range = wb.check_range = False
+    e = torch.from_numpy(eps).cuda()
+    wa.test_step(batch, latent_eps=e)
+    wa.engine.check_status()  # clean
+    wb.test_step(batch, latent_eps=e)  # activations of ~1e5: raises the device's flag
+    with pytest.raises(RuntimeError, match="65504"):
+        wa.engine.check_status()  # A's check takes the flag ...
+    with pytest.raises(RuntimeError, match="65504"):
+        wb.engine.check_status()  # ... and B still hears of it
+    assert wb.engine.precision_state()["step"] == "fp32_exact" and wb.engine.precision_state()["activation_overflow"]
+    wa.engine.check_status()
+    wb.engine.check_status()  # both clean now
+    out = wb.test_step(batch, latent_eps=e)
+    wb.engine.check_status()
+    assert torch.isfinite(out["rollout_buffer"].preds).all()
+
+
 @pytest.mark.parametrize("at_end", [0, 1])
 def test_no_access_outside_the_callers_buffers(at_end):
     """Round 5 (profiles/r05_experiments.txt item 16: a kernel read 8 bytes in FRONT of `preds` -- silent until an allocation boundary

@@ -7,6 +7,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -385,6 +386,12 @@ static void step_launch(const tb_ctx* ctx, const tb::RolloutP& rd, const tb::Rol
         tb::launch_step(p, t, do_c, do_a, s);
 }
 
+// Live contexts of the process (tb_check_status: the fp16-pair range flag is one word per device and kernel family, so the context
+// whose check takes it hands the bits to every other context of that device -- ADVICE r04: with two contexts on one device A's check
+// used to clear an overflow raised by B, and B got rc 0 for invalid results)
+static std::mutex g_ctx_mutex;
+static std::vector<tb_ctx*> g_ctx_live;
+
 int tb_create(const tb_config* cfg, tb_ctx** out) {
     if (!cfg || !out) return 1;
     int ndev = 0;
@@ -435,6 +442,10 @@ int tb_create(const tb_config* cfg, tb_ctx** out) {
     }
     c->step_kernel0 = c->step_kernel;
     c->encode_kernel0 = c->encode_kernel;
+    {
+        std::lock_guard<std::mutex> lk(g_ctx_mutex);
+        g_ctx_live.push_back(c);
+    }
     *out = c;
     return 0;
 }
@@ -443,6 +454,14 @@ void tb_destroy(tb_ctx* ctx) {
     if (ctx && ctx->graph_exec) (void)hipGraphExecDestroy(ctx->graph_exec);
     if (ctx && ctx->cap_stream) (void)hipStreamDestroy(ctx->cap_stream);
     if (!ctx) return;
+    {
+        std::lock_guard<std::mutex> lk(g_ctx_mutex);
+        for (size_t i = 0; i < g_ctx_live.size(); ++i)
+            if (g_ctx_live[i] == ctx) {
+                g_ctx_live.erase(g_ctx_live.begin() + i);
+                break;
+            }
+    }
     if (ctx->enc_fork) (void)hipEventDestroy(ctx->enc_fork);
     if (ctx->enc_join) (void)hipEventDestroy(ctx->enc_join);
     if (ctx->enc_map) (void)hipEventDestroy(ctx->enc_map);
@@ -1346,7 +1365,17 @@ extern "C" int tb_check_status(tb_ctx* ctx, tb_stream stream_) {
     TB_HIP(ctx, hipMemcpyAsync(hw, ctx->d_status, 2 * sizeof(unsigned int), hipMemcpyDeviceToHost, s));
     TB_HIP(ctx, hipMemsetAsync(ctx->d_status + 1, 0, sizeof(unsigned int), s));
     TB_HIP(ctx, hipStreamSynchronize(s));
-    const unsigned int h = hw[0];
+    unsigned int h = hw[0];
+    {   // the flag word belongs to the device: what this check took is every context's news, and what another context's check took
+        // since this context's last one is this context's news too (conservative: a context may switch kernels for a neighbour's
+        // overflow; none returns 0 over invalid results)
+        std::lock_guard<std::mutex> lk(g_ctx_mutex);
+        if (h)
+            for (tb_ctx* o : g_ctx_live)
+                if (o != ctx && o->device == ctx->device) o->range_pending |= h;
+        h |= ctx->range_pending;
+        ctx->range_pending = 0;
+    }
     if (hw[1])
         return tb_fail(ctx, "step kernel: a tile workgroup gave up waiting for its helper workgroup (the helpers of a launch are expected to be "
                             "dispatched first); results since the last check are invalid -- set TB_STEP_HELPERS=0 and report");

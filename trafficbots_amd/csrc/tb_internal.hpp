@@ -28,6 +28,7 @@ struct tb_ctx {
     int step_kernel = 2;  // 2: k_step_x (fp16-pair XDL MFMA, default)  3: k_step_x, bf16 operands (tb_config.operand_precision = 1)  0: k_step (fp32 MFMA, the A/B twin); TB_STEP_KERNEL overrides
     int step_kernel0 = 2, encode_kernel0 = 1;  // the selection of tb_create (configuration + development switches): what tb_finalize_weights starts from
     int precision_reason = 0;    // bit 0: a loaded tensor is outside the fp16-pair range; bit 1: an activation overflowed at run time
+    unsigned int range_pending = 0;  // range-flag bits another context of this device took in ITS check (the flag is one word per device and kernel family): reported by this context's next check
     std::string precision_note;  // the sentence that goes with it (tb_precision_note)
     int encode_kernel = 1;  // 1: XDL attention blocks (tb_encodex_kernels.hip, default)  0: fp32-MFMA blocks; TB_ENCODE_KERNEL overrides
     // workspace
