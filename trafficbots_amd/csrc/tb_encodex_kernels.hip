@@ -572,6 +572,7 @@ __global__ __launch_bounds__(NT8) void k_polyline_fused8(XBlockPX p) {
     const int tid = threadIdx.x, wave = wave_of(tid), lane = tid & 63, kq = lane >> 4, m = lane & 15;
 #ifdef TB_PROFILE_ENC  // (stage profile: clock64 stamps of thread 0 of one workgroup, printed from the device; tools/gpu_stage_profile_enc.sh)
     __shared__ long long enc_prof[64];
+    __shared__ long long enc_wave[16];
     int enc_np = 0;
 #define ENC_STAMP() do { if (tid == 0 && enc_np < 64) enc_prof[enc_np++] = clock64(); } while (0)
 #else
@@ -719,6 +720,9 @@ __global__ __launch_bounds__(NT8) void k_polyline_fused8(XBlockPX p) {
             wmmax(qo[0], qo[1], uq, PQ + half * PS + po, PLANE);
             wmmax(qt[0], qt[1], uq, PQ + 2 * PS + po, PLANE);
             ENC_STAMP();  // Q projection
+#ifdef TB_PROFILE_ENC
+            if (lane == 0 && l == 1) enc_wave[wave] = clock64();  // (per-wave arrival at the barrier in front of the attention, layer 1)
+#endif
             if (MERGE) __syncthreads();  // (K / V of every head are in place; every wave has read its Q rows from the second plane set)
             ENC_STAMP();  // barrier
             f32x4 oo[2], ot[2];
@@ -741,6 +745,9 @@ __global__ __launch_bounds__(NT8) void k_polyline_fused8(XBlockPX p) {
             }
         }
         ENC_STAMP();  // two one-block attentions + plane stores
+#ifdef TB_PROFILE_ENC
+        if (lane == 0 && l == 1) enc_wave[8 + wave] = clock64();  // (... and at the barrier behind it)
+#endif
         __syncthreads();
         ENC_STAMP();  // barrier
         {
@@ -794,6 +801,13 @@ __global__ __launch_bounds__(NT8) void k_polyline_fused8(XBlockPX p) {
             for (int i = 0; i < 16; ++i) printf(" %s %lld", nm[i], enc_prof[2 + l * 16 + i] - enc_prof[1 + l * 16 + i]);
             printf("\n");
         }
+        printf("ENCPROF8 layer 1, arrival of waves 0 .. 7 at the barrier in front of the attention (cycles after the first):");
+        long long m0 = enc_wave[0], m1 = enc_wave[8];
+        for (int w = 1; w < 8; ++w) { m0 = enc_wave[w] < m0 ? enc_wave[w] : m0; m1 = enc_wave[8 + w] < m1 ? enc_wave[8 + w] : m1; }
+        for (int w = 0; w < 8; ++w) printf(" %lld", enc_wave[w] - m0);
+        printf("; behind it:");
+        for (int w = 0; w < 8; ++w) printf(" %lld", enc_wave[8 + w] - m1);
+        printf("\n");
     }
 #endif
     if (tid < NTHREADS) {  // MapEncoder: max over the valid nodes of the polyline, one (polyline, feature) per thread (k_polyline_fused)
