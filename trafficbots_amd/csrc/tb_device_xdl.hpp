@@ -556,6 +556,116 @@ __device__ __forceinline__ void wmma1x_pf2(f32x4& acc, const WUnit1X& u, const x
     wloadx(un, n, lane);
     wmma1x<SWAP>(acc, u, bp, plane_stride);
 }
+// The same unit applied to THREE row tiles at once (tile t at bp + t * tile_stride), software-pipelined by hand: the operand reads run one
+// k chunk (9 MFMAs) ahead of their use, the MFMAs of a chunk go round the three tiles, and the requests for the NEXT unit's fragments
+// are spread under the MFMAs -- one every three (one-tile unit) or two (two-tile unit) MFMAs -- instead of standing in front of the
+// phase.  Measured reason (profiles/r05_stage_profile_polyline_fused.txt): with eight waves per workgroup each issuing its eight
+// 1-KiB requests at the top of a phase, the CU's one vector-memory path (44 B/clk) takes ~1.5 k cycles to accept them all and every
+// wave sits in its own request burst before its first operand read; the favoured wave of a SIMD needed 2.65 k cycles for 36 MFMAs.
+// Per accumulator the MFMAs are those of wmma1x in the same order: same bits.
+__device__ __forceinline__ void wnext_issue(WUnit1X& un, const WNext1X& n, int lane) {
+    const xh8* pa = wfrag1x(n, lane);
+    un.b = ldg4(n.bias ? n.bias + n.tile * 16 + (lane >> 4) * 4 : reinterpret_cast<const float*>(n.wpk));
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int p = 0; p < NPL; ++p) un.w[c][p] = pa[(c * NPL + p) * 64];
+}
+__device__ __forceinline__ void wnext_issue(WUnitX& un, const WNextX& n, int lane) {
+    const xh8* pa = wfragx(n, n.tile_a, lane);
+    const xh8* pb = wfragx(n, n.tile_b, lane);
+    const int bo = (lane >> 4) * 4;
+    un.b[0] = ldg4(n.bias ? n.bias + n.tile_a * 16 + bo : reinterpret_cast<const float*>(n.wpk));
+    un.b[1] = ldg4(n.bias ? n.bias + n.tile_b * 16 + bo : reinterpret_cast<const float*>(n.wpk));
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int p = 0; p < NPL; ++p) {
+            un.w[0][c][p] = pa[(c * NPL + p) * 64];
+            un.w[1][c][p] = pb[(c * NPL + p) * 64];
+        }
+}
+__device__ __forceinline__ void wnext_fix_bias(WUnit1X& un, const WNext1X& n) {
+    if (!n.bias) un.b = splat(0.f);
+}
+__device__ __forceinline__ void wnext_fix_bias(WUnitX& un, const WNextX& n) {
+    if (!n.bias) {
+        un.b[0] = splat(0.f);
+        un.b[1] = splat(0.f);
+    }
+}
+template <class U>
+struct wnext_loads;  // VMEM instructions of a unit request
+template <>
+struct wnext_loads<WUnit1X> { static constexpr int n = 1 + 4 * NPL; };
+template <>
+struct wnext_loads<WUnitX> { static constexpr int n = 2 + 8 * NPL; };
+
+template <bool SWAP = false, class UN, class WN>
+__device__ __forceinline__ void wmma1x_3(f32x4 (&acc)[3], const WUnit1X& u, const xhalf* bp, int tile_stride, int plane_stride, UN& un,
+                                         const WN& next, int lane) {
+    TB_SCHED_FENCE();
+    xh8 x[4][3][NPL];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int p = 0; p < NPL; ++p) x[c][t][p] = ldsb8(bp + t * tile_stride + p * plane_stride + c * 32);
+    wnext_issue(un, next, lane);
+    f32x4 mid[3] = {splat(0.f), splat(0.f), splat(0.f)};
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        if (NPL == 2) {
+#pragma unroll
+            for (int t = 0; t < 3; ++t) mid[t] = mm_sw<SWAP>(u.w[c][0], x[c][t][P1], mid[t]);
+#pragma unroll
+            for (int t = 0; t < 3; ++t) mid[t] = mm_sw<SWAP>(u.w[c][P1], x[c][t][0], mid[t]);
+        }
+#pragma unroll
+        for (int t = 0; t < 3; ++t) acc[t] = mm_sw<SWAP>(u.w[c][0], x[c][t][0], acc[t]);
+    }
+    // pin: the reads of chunks 0 and 1; then per chunk the reads of chunk c + 2 (two chunks of operands in flight or in use: a third
+    // spills) and its MFMAs in groups with one request of the next unit behind each group
+    static_assert(NPL == 2, "the pinned schedule below is written out for fp16 pairs (6 reads, 9 MFMAs per chunk)");
+    constexpr bool TWO = wnext_loads<UN>::n > 12;    // a two-tile unit is requested (18 VMEM instructions; a one-tile unit: 9)
+    __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+        if (TWO) {  // 2 MFMA + 1 request, four times, then 1 MFMA + 1 request: 15 requests under chunks 0 .. 2
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        } else {    // 3 MFMA + 1 request, three times: 9 requests under chunks 0 .. 2
+#pragma unroll
+            for (int g = 0; g < 3; ++g) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            }
+        }
+    }
+    if (TWO) {      // the last three requests under chunk 3
+#pragma unroll
+        for (int g = 0; g < 3; ++g) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+    } else {
+        __builtin_amdgcn_sched_group_barrier(0x008, 9, 0);
+    }
+    TB_SCHED_FENCE();
+    wnext_fix_bias(un, next);
+    if (NPL == 2) {
+#pragma unroll
+        for (int t = 0; t < 3; ++t) acc[t] += mid[t] * splat(SPLIT_INV);
+    }
+}
 #endif  // !TB_XDL_W3
 #endif  // TB_XDL_W3
 

@@ -640,6 +640,10 @@ __global__ __launch_bounds__(NT8) void k_polyline_fused8(XBlockPX p) {
     auto gemm3 = [&](const WUnit1X& ua, WUnit1X& ub, const WNext1X& next, const xhalf* P, f32x4 (&a)[3]) {
 #pragma unroll
         for (int t = 0; t < 3; ++t) a[t] = ua.b;
+        if (MERGE) {  // (hand-pipelined: operand reads a chunk ahead, MFMAs round the three tiles, the next unit's requests under them)
+            wmma1x_3(a, ua, P + po, PS, PLANE, ub, next, lane);
+            return;
+        }
         wmma1x_pf(a[0], ua, P + po, PLANE, ub, next, lane);
         wmma1x(a[1], ua, P + PS + po, PLANE);
         wmma1x(a[2], ua, P + 2 * PS + po, PLANE);
@@ -691,9 +695,13 @@ __global__ __launch_bounds__(NT8) void k_polyline_fused8(XBlockPX p) {
                 const f32x4 ba = splat(bv[0]);
 #pragma unroll
                 for (int t = 0; t < 3; ++t) av[t] = ba;
-                wmma1x_pf2<true>(av[0], u2, P1 + po, PLANE, uq, xlayer_first_x(p.W, L, LX, head), lane);
-                wmma1x<true>(av[1], u2, P1 + PS + po, PLANE);
-                wmma1x<true>(av[2], u2, P1 + 2 * PS + po, PLANE);
+                if (MERGE) {
+                    wmma1x_3<true>(av, u2, P1 + po, PS, PLANE, uq, xlayer_first_x(p.W, L, LX, head), lane);
+                } else {
+                    wmma1x_pf2<true>(av[0], u2, P1 + po, PLANE, uq, xlayer_first_x(p.W, L, LX, head), lane);
+                    wmma1x<true>(av[1], u2, P1 + PS + po, PLANE);
+                    wmma1x<true>(av[2], u2, P1 + 2 * PS + po, PLANE);
+                }
                 auto v_store = [&](xhalf* pv, const f32x4& a) {
                     xh4 h, lo;
                     split2(a, h, lo);
