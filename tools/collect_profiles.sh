@@ -9,7 +9,7 @@ for n in fp32 bf16 k6_fp32 k6_bf16 stress_fp32 stress_bf16; do
 done
 cp gpurun_out/pmc_step/pmc_step_kernel.json profiles/pmc_step_kernel.json
 for n in fp32 bf16; do
-  f=$(find gpurun_out/pmc_step/$n/stats -name "*kernel_stats.csv" | head -1)
+  f=$(ls -t $(find gpurun_out/pmc_step/$n/stats -name "*kernel_stats.csv") | head -1)  # (the newest: earlier calls leave theirs behind)
   { echo "# rocprofv3 --kernel-trace --stats -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --lean --operand-precision $n  (tools/gpu_pmc_step.sh, round ${r})"; cat $f; } > profiles/${r}_rocprof_$n.txt
 done
 ls -la profiles/${r}_pmc profiles/${r}_rocprof_*.txt
