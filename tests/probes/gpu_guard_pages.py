@@ -76,5 +76,19 @@ wb = WaymoMotion(time_step_end=14, n_joint_future=6, operand_precision="bf16")  
 wb.load_state_dict(sd)
 assert torch.isfinite(wb.test_step(big, generator=torch.Generator(device="cuda").manual_seed(10))["rollout_buffer"].preds).all()
 torch.cuda.synchronize()
+# the headline shape (128 tiles: helper workgroups + L2 warmers on the idle CUs) in the fp32-accurate kernels, and a stress-shaped scene
+# (128 agents, 1024 polylines: the 32-block key walks; bf16 takes the assist-wave carve by itself at this polyline count)
+head = synth.make_batch(5000, 32, n_agent=64, n_pl=256, n_tl=40)
+wh = WaymoMotion(time_step_end=16, n_joint_future=1)
+wh.load_state_dict(sd)
+for _ in range(2):  # (the second call sees the same argument set again)
+    oh = wh.test_step(head, generator=torch.Generator(device="cuda").manual_seed(11))
+assert torch.isfinite(oh["rollout_buffer"].preds).all()
+stress = synth.make_batch(5100, 2, n_agent=128, n_pl=1024, n_tl=40, p_invalid_pl=0.2)
+for prec in ("fp32", "bf16"):
+    ws = WaymoMotion(time_step_end=14, n_joint_future=1, operand_precision=prec)
+    ws.load_state_dict(sd)
+    assert torch.isfinite(ws.test_step(stress, generator=torch.Generator(device="cuda").manual_seed(12))["rollout_buffer"].preds).all(), prec
+torch.cuda.synchronize()
 guard_pool.uninstall(pool)
 print(f"GUARD-OK ({pool.n_shadow} guarded buffers, at_end={pool.at_end}, granule {pool.lib.tbg_granularity()} B)")
