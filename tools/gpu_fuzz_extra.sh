@@ -1,5 +1,5 @@
 cd $GRAFT_REPO_ROOT
-O=gpurun_out/fuzz_r03_extra.txt; : > $O
+O=gpurun_out/fuzz_${FUZZ_ROUND:-r05}_extra.txt; : > $O
 run() { echo "### $*" >> $O; ( eval "$@" ) 2>&1 | grep -E "OUTSIDE|FAIL|all [0-9]+ cases|worst|Error|error|^ok$" | tail -12 >> $O; }
 run FUZZ_SEED=101 FUZZ_KEEP_GOING=1 timeout 1500 python tests/probes/gpu_fuzz_validation.py 100
 run FUZZ_SEED=102 FUZZ_KEEP_GOING=1 timeout 1500 python tests/probes/gpu_fuzz_validation.py 100
