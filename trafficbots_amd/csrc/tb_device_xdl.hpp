@@ -61,7 +61,7 @@ typedef xhalf xh2 __attribute__((ext_vector_type(2)));
 #ifndef TB_LDP
 #define TB_LDP 136
 #endif
-constexpr int LDP = TB_LDP;         // fp16 per plane row for 128-wide inputs (272 B: 16 rows x b128 reads hit 64 distinct banks)
+constexpr int LDP = TB_LDP;         // fp16 per plane row for 128-wide inputs (272 B; the scene encoders' translation unit: 288 B, see there)
 constexpr int PLANE = TM * LDP;     // fp16 per plane
 constexpr int PLANES_BYTES = NPL * PLANE * 2;  // 8704
 constexpr int LDPC = 264;           // row length of the 256-wide concat planes

@@ -7,6 +7,14 @@
 #include <hip/hip_runtime.h>
 
 #include "tb_rollout.hpp"
+// Plane rows of 288 bytes in THIS translation unit (the step kernels keep 272): a wave's ds_read_b128 is served in four groups of sixteen
+// lanes {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} ... (MI355X guide, LDS table), and with 272-byte rows every group of the B-operand reads
+// holds a 2-way bank conflict; a row stride of 2 (mod 16) 16-byte blocks puts the kq-even lanes of a group on the even blocks and the
+// kq-odd lanes on the odd ones.  Worth nothing while the reads were spread through a phase (profiles/r05_experiments.txt item 19); with
+// the polyline encoder's reads issued together at the head of each GEMM phase (item 23) the encoders gain 3 %.  LDS layout only: same bits.
+#ifndef TB_LDP
+#define TB_LDP 144
+#endif
 #include "tb_device_xdl.hpp"
 #include "tb_encode.hpp"
 
