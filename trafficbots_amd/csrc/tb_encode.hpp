@@ -76,7 +76,7 @@ struct DestP {
 };
 
 namespace xh {
-void launch_dest_pairs_x(const DestP& p, hipStream_t s);
+void launch_dest_pairs_x(const DestP& p, hipStream_t s, int lds_pad = 0);
 void launch_gru_scan_x(const ScanP& p, int a_pad, hipStream_t s);
 hipError_t configure_encodex_kernels();
 void launch_range_flag_take_encode(unsigned int* out, hipStream_t s);

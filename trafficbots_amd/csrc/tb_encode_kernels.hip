@@ -739,7 +739,12 @@ int run_encode(struct ::tb_ctx* ctx, const tb_encode_io* io, hipStream_t s) {
         d.B = B; d.A = A; d.P = P; d.U = U; d.V = V; d.map_fvalid = io->map_feature_valid; d.map_type = io->map_type;
         d.agent_type = io->agent_type; d.dist_valid = tgtv; d.logits = io->dest_logits;
         d.w1x = ew.dest_w1_x;
-        if (ctx->encode_kernel == 1) xh::launch_dest_pairs_x(d, st);
+        // (beside the latent branch: TWO workgroups per CU instead of three, see launch_dest_pairs_x -- measured: 30 KB of padding
+        // -1 % / -4 % of the encode at the headline / stress shape, 60 KB (one per CU) +3 %: the predictor becomes the long pole;
+        // TB_DEST_LDS_PAD = bytes, development switch)
+        const char* lp = getenv("TB_DEST_LDS_PAD");
+        const int lds_pad = st != s ? (lp ? atoi(lp) : 30000) : 0;
+        if (ctx->encode_kernel == 1) xh::launch_dest_pairs_x(d, st, lds_pad);
         else hipLaunchKernelGGL(k_dest_pairs, dim3((P + TM - 1) / TM, A, B), dim3(NTHREADS), 0, st, d);
     };
     const char* ed = getenv("TB_ENCODE_DEST_SIDE");

@@ -1057,9 +1057,12 @@ __global__ __launch_bounds__(NTHREADS) void k_dest_pairs_x(DestP p) {
     }
 }
 
-void launch_dest_pairs_x(const DestP& p, hipStream_t s) {
+// `lds_pad`: dynamic LDS the kernel does not use -- it only bounds how many of its workgroups a CU holds (26 KB of static LDS each:
+// three by registers).  Beside the latent branch (run_encode: the destination predictor on the side stream) the 32 768-workgroup
+// grid otherwise takes three of every SIMD's wave slots and the branch's small dependent kernels run at half speed.
+void launch_dest_pairs_x(const DestP& p, hipStream_t s, int lds_pad) {
     dim3 grid((p.P + TM - 1) / TM, (p.A + DEST_AGENTS - 1) / DEST_AGENTS, p.B);
-    hipLaunchKernelGGL(k_dest_pairs_x, grid, dim3(NTHREADS), 0, s, p);
+    hipLaunchKernelGGL(k_dest_pairs_x, grid, dim3(NTHREADS), (size_t)lds_pad, s, p);
 }
 
 void launch_gru_scan_x(const ScanP& p, int a_pad, hipStream_t s) {
@@ -1084,6 +1087,8 @@ hipError_t configure_encodex_kernels() {
     const hipError_t e8m = hipFuncSetAttribute(reinterpret_cast<const void*>(k_polyline_fused8<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                                PLF_LDS_BYTES + (NPL == 1 ? 3 * TM * LDT * 4 : 0));
     if (e8m != hipSuccess) return e8m;
+    const hipError_t ed = hipFuncSetAttribute(reinterpret_cast<const void*>(k_dest_pairs_x), hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024);
+    if (ed != hipSuccess) return ed;
     return hipFuncSetAttribute(reinterpret_cast<const void*>(k_gru_scan_x), hipFuncAttributeMaxDynamicSharedMemorySize, SCANX_LDS_BYTES);
 }
 
