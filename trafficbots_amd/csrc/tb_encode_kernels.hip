@@ -44,6 +44,16 @@ struct TokP {
 // in LDS once: the scalar weight loads of a 16-token workgroup were an L1-latency chain of ~130 dependent loads.
 constexpr int TOK_GROUPS = 16;
 
+template <int DIM>
+__device__ __forceinline__ void tok_mlp1(const float* __restrict__ a, const float* __restrict__ w, float& s0, float& s1) {
+#pragma unroll
+    for (int k = 0; k < DIM; ++k) {
+        const float av = a[k];
+        s0 = fmaf(av, w[k * 32], s0);
+        s1 = fmaf(av, w[k * 32 + 1], s1);
+    }
+}
+
 __global__ __launch_bounds__(NTHREADS) void k_encode_tokens(TokP p) {
     // attributes / pose / validity of ALL TOK_GROUPS * 16 tokens of the workgroup, gathered by one thread per token in front of the
     // loop: the per-group gather (16 threads, dependent global loads + the fp64 atan2, then a barrier) was a serial round trip per
@@ -140,11 +150,12 @@ __global__ __launch_bounds__(NTHREADS) void k_encode_tokens(TokP p) {
             }
             const int o0 = i * 2;
             float s0 = b1s[o0], s1 = b1s[o0 + 1];
-            for (int k = 0; k < attr_dim; ++k) {
-                const float av = attrg[row][k];
-                s0 = fmaf(av, w1t[k * 32 + o0], s0);
-                s1 = fmaf(av, w1t[k * 32 + o0 + 1], s1);
-            }
+            // (compile-time trip count per token kind: with the run-time bound the loop was not unrolled -- two LDS reads, a wait and two
+            // dependent FMAs per iteration, ~3 k cycles per 16-token group; unrolled, the reads are batched in front of the FMA chain.
+            // Same products in the same order: same bits)
+            if (p.kind == 2) tok_mlp1<31>(attrg[row], w1t + o0, s0, s1);
+            else if (p.kind == 0) tok_mlp1<11>(attrg[row], w1t + o0, s0, s1);
+            else tok_mlp1<5>(attrg[row], w1t + o0, s0, s1);
             hid[row][o0] = fmaxf(s0, 0.f);
             hid[row][o0 + 1] = fmaxf(s1, 0.f);
         }
