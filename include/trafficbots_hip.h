@@ -436,6 +436,10 @@ typedef struct tb_post_io {
     float* waymo_scores;        /* [B,A,K] normalised */
     uint8_t* waymo_valid;       /* [B,S,A] */
     int32_t* mode_idx;          /* [B,A,K] selected input modes, or NULL */
+    int64_t traj_strides[4];    /* element strides of `trajs` over (scene, agent, future, step), the D components adjacent; all 0 = the
+                                 * contiguous [B,A,NP,S,D] layout.  Lets the caller hand over a rollout buffer where it lies -- preds
+                                 * [B*K,A,S_all,4] as futures-of-a-scene, from the first future step on -- instead of a re-laid-out copy
+                                 * (the reference's `trajs=buffer.preds[:, :, :, step_future_start:]`, waymo_motion.py:931-937) */
 } tb_post_io;
 int tb_post_process(tb_ctx* ctx, const tb_post_io* io, tb_stream stream);
 
@@ -506,6 +510,11 @@ int tb_dest_sample(tb_ctx* ctx, const tb_dest_sample_io* io, tb_stream stream);
  * tb_rule_io, tb_post_io, tb_metric_io; out[6] = the pointer size; out[7..8] = tb_posterior_io, tb_train_io; out[9..10] = tb_step_override, tb_forward_io;
  * out[11..12] = tb_latent_sample_io, tb_dest_sample_io -- lets a binding check its mirror of the layouts before the first call (no GPU needed). */
 void tb_struct_sizes(int32_t out[13]);
+
+/* Host-side helper (no device work, no context): bool one-hot rows [n_rows][n_class] (host memory) -> int32 class index per row, the
+ * first set class, -1 where none is set -- the conversion SceneCentricPreProcessing does with `.argmax(-1)` on the device
+ * (src/data_modules/scene_centric.py:92-133), done while a host batch is staged into pinned memory (trafficbots_amd/staging.py). */
+void tb_host_onehot_index(const uint8_t* onehot, int64_t n_rows, int32_t n_class, int32_t* out);
 
 #ifdef __cplusplus
 }

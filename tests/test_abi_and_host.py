@@ -182,7 +182,7 @@ def test_training_split_batch_has_no_history_keys():
     b = scene_from_batch(train, "cpu", 11)
     assert set(a) == set(b)
     for k in a:
-        if k == "warm_ok":
+        if not torch.is_tensor(a[k]):  # "warm_ok", "_tf_params": host-side facts
             assert a[k] == b[k]
         else:
             assert torch.equal(a[k], b[k]), k

@@ -111,6 +111,59 @@ def test_bf16_rollout_against_the_bf16_oracle(shape, monkeypatch):
         assert r2["ok_vs_fp64"] and r2["ok_vs_fp32"], {k_: v_ for k_, v_ in r2.items() if k_ != "per_step"}
 
 
+def test_bf16_agent_alone_in_its_key_block():
+    """the lean interaction walk (bf16 step kernels, `attention_walk_leanm_x`) starts a row tile's walk at a
+    staggered key block; a row whose FIRST walked block holds no valid key but its own (hidden by MultiAgentTF's eye mask) kept the
+    stand-in reference exponent, the next block's logits were rounded away against it and every valid key got the same weight --
+    uniform attention, no error raised.  Here agents 0..31 and agent 40 are the valid ones (A = 64: agent 40's row tile starts at keys
+    32..63, where only its own key is valid) and the attention in-projections are x3 ("sharp": near one-hot rows, so uniform weights
+    are far from the softmax).  The step-1 policy feature of agent 40 must be as close to the bf16 oracle's fp64-accumulate twin as
+    the bf16 oracle's own fp32 run is -- the bound of test_bf16_rollout_against_the_bf16_oracle, per agent."""
+    from oracle.trafficbots_oracle import Oracle
+    from trafficbots_amd import synth
+    from trafficbots_amd.config import load_model_config
+
+    n_scene, a, k, step_end = 2, 64, 1, 14
+    sd = synth.make_state_dict(11, mode="sharp")
+    batch = synth.make_batch(4700, n_scene, n_agent=a, n_pl=48, n_tl=12)
+    keep = np.zeros(a, dtype=bool)
+    keep[:32] = True
+    keep[40] = True
+    for key in list(batch.keys()):
+        if key.endswith("agent/valid"):
+            v = np.asarray(batch[key]).copy()
+            ax = [i for i, n in enumerate(v.shape) if n == a][-1]
+            shp = [1] * v.ndim
+            shp[ax] = a
+            batch[key] = v & keep.reshape(shp)
+    eps = synth.make_latent_noise(4799, n_scene * k, a)
+    cfg = load_model_config(overrides={"time_step_end": step_end, "n_joint_future": k})
+    with torch.no_grad():
+        base = Oracle(sd, cfg, torch.float32, hoist=True, operand_round="bf16").joint_future_pred(batch, k, eps, step_end, tap_steps=(1,))
+        dest = np.asarray(base["goal_sample"]).reshape(n_scene * k, a)
+        twin = Oracle(sd, cfg, torch.float64, hoist=True, operand_round="bf16").joint_future_pred(batch, k, eps, step_end, dest_override=dest, tap_steps=(1,))
+    wm = _wm(time_step_end=step_end, n_joint_future=k, operand_precision="bf16")
+    wm.load_state_dict(sd)
+    gs = torch.from_numpy(dest.reshape(n_scene, k, a).copy())
+    buf = wm.test_step(batch, latent_eps=torch.from_numpy(eps).cuda(), goal_sample=gs, tap_step=1)["rollout_buffer"]
+    torch.cuda.synchronize()
+    valid1 = base["valid"].numpy()[:, :, 0, 0]
+    assert valid1[:, 40].all() and valid1[:, :32].all() and not valid1[:, 32:40].any() and not valid1[:, 41:].any(), "the case lost its shape"
+    tap = buf.taps["tap_policy_feature"].cpu().double()
+    e_hip = (tap - twin["tap1/policy_feature"]).abs().amax(-1)                       # [N, A]
+    e_orc = (base["tap1/policy_feature"].double() - twin["tap1/policy_feature"]).abs().amax(-1)
+    lone, rest = float(e_hip[:, 40].max()), float(e_hip[:, :32].max())
+    REPORT["bf16_lone_agent_in_key_block"] = {"hip_vs_twin_agent40": lone, "hip_vs_twin_agents0_31": rest,
+                                              "bf16_oracle_vs_twin_agent40": float(e_orc[:, 40].max()), "bf16_oracle_vs_twin_all": float(e_orc[:, keep].max())}
+    bound = 3.0 * float(e_orc[:, keep].max()) + 1e-5
+    assert lone <= bound and rest <= bound, REPORT["bf16_lone_agent_in_key_block"]
+    # closed loop a few steps past the teacher-forced ones: same bookkeeping, bf16-sized distance to the bf16 oracle
+    assert (buf.valid.cpu().numpy() == base["valid"].numpy()).all()
+    d = np.abs(buf.preds.cpu().numpy() - base["preds"].numpy())[..., :2][base["valid"].numpy()]
+    REPORT["bf16_lone_agent_in_key_block"]["xy_vs_bf16_oracle_step14"] = float(d.max())
+    assert d.max() <= 2e-2, d.max()
+
+
 def test_config3_k6_bf16_at_batch_32():
     """BASELINE configs[3] exactly: B = 32 scenes, K = 6 futures, A = 64, P = 256, 90 steps, operand_precision = "bf16", against
     the fp32-accurate run of the same inputs: teacher-forced bookkeeping equal (valid / override masks of the warm-up steps, the

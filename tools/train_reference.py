@@ -56,6 +56,10 @@ def main() -> None:
     ap.add_argument("--batch", type=int, default=4)
     ap.add_argument("--out", default=os.path.join(GOLDEN_DIR, "trained_state_dict"))
     ap.add_argument("--threads", type=int, default=0)
+    ap.add_argument("--lr", type=float, default=3e-4, help="Adam learning rate (the reference's default 3e-4)")
+    ap.add_argument("--init", default="", help="continue from a stored state_dict (.npz) instead of the reference's initialisation")
+    ap.add_argument("--step-offset", type=int, default=0, help="episode seeds continue after this many earlier steps")
+    ap.add_argument("--save-every", type=int, default=0, help="also store <out>_stepN.npz every N steps (a session may end early)")
     args = ap.parse_args()
     if args.threads:
         torch.set_num_threads(args.threads)
@@ -64,7 +68,10 @@ def main() -> None:
     model = ref_shim.build_reference(cfg, n_agent=SCENE["n_agent"], n_pl=SCENE["n_pl"], n_tl=SCENE["n_tl"])
     # the optimizer of the reference's own configure_optimizers (Adam 3e-4 + the goal predictor's group); the scheduler steps per
     # epoch and a few hundred steps are less than one
-    model.hparams["optimizer"] = ref_shim.to_attr({"_target_": "torch.optim.Adam", "lr": 3e-4})
+    if args.init:
+        with np.load(args.init) as z:
+            model.load_state_dict({k: torch.from_numpy(z[k].copy()) for k in z.files})
+    model.hparams["optimizer"] = ref_shim.to_attr({"_target_": "torch.optim.Adam", "lr": args.lr})
     model.hparams["lr_scheduler"] = ref_shim.to_attr({"_target_": "torch.optim.lr_scheduler.StepLR", "gamma": 0.5, "step_size": 7})
     model.trainer = types.SimpleNamespace(check_val_every_n_epoch=1)
     (opt,), _ = model.configure_optimizers()
@@ -72,7 +79,7 @@ def main() -> None:
     model.train()
     losses, t0 = [], time.time()
     for step in range(args.steps):
-        batch_np = synth.make_val_batch(SEED + 1000 * (step + 1), args.batch, **SCENE)
+        batch_np = synth.make_val_batch(SEED + 1000 * (step + 1 + args.step_offset), args.batch, **SCENE)
         batch = {k: torch.from_numpy(v.copy()) for k, v in batch_np.items()}
         loss = model.training_step(batch, step)
         opt.zero_grad(set_to_none=True)
@@ -84,11 +91,17 @@ def main() -> None:
             print(f"step {step:4d} loss {float(loss):10.4f} grad_norm {float(gn):9.3f}  ({time.time() - t0:6.0f} s)", flush=True)
         if not np.isfinite(losses[-1]):
             raise RuntimeError("training diverged")
+        if args.save_every and (step + 1) % args.save_every == 0 and step + 1 < args.steps:
+            snap = {k: v.detach().cpu().numpy().copy() for k, v in model.state_dict().items()}
+            np.savez_compressed(f"{args.out}_step{step + 1}.npz", **snap)
+            with open(f"{args.out}_step{step + 1}.json", "w") as f:
+                json.dump(dict(seed=SEED, steps=step + 1, lr=args.lr, init=args.init, step_offset=args.step_offset, loss=losses,
+                               stats_trained=stats(snap), seconds=time.time() - t0), f, indent=1)
     model.eval()
     sd = {k: v.detach().cpu().numpy().copy() for k, v in model.state_dict().items()}
     np.savez_compressed(args.out + ".npz", **sd)
     moved = {k: float(np.abs(sd[k].astype(np.float64) - sd0[k]).max()) for k in sd if sd[k].dtype.kind == "f"}
-    meta = dict(seed=SEED, steps=args.steps, batch=args.batch, scene=SCENE, torch=torch.__version__, loss=losses,
+    meta = dict(seed=SEED, steps=args.steps, lr=args.lr, init=args.init, step_offset=args.step_offset, batch=args.batch, scene=SCENE, torch=torch.__version__, loss=losses,
                 stats_init=stats(sd0), stats_trained=stats(sd), max_abs_change=max(moved.values()),
                 tensors_moved=int(sum(v > 0 for v in moved.values())), tensors=len(moved), seconds=time.time() - t0)
     with open(args.out + ".json", "w") as f:

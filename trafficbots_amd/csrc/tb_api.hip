@@ -338,6 +338,18 @@ void tb_struct_sizes(int32_t out[13]) {
     out[6] = (int32_t)sizeof(void*);
 }
 
+// Host-side helper of the staging layer (trafficbots_amd/staging.py): bool one-hot rows [n_rows][n_class] -> int32 class index, the
+// FIRST set class (what argmax gives on a 0/1 row), -1 where none is set.  Plain host code: numpy has no fast reduction over a short
+// last axis (0.6 ms for the three one-hot tensors of a 32-scene batch; this loop: < 0.1 ms) and ctypes releases the GIL around it.
+void tb_host_onehot_index(const uint8_t* onehot, int64_t n_rows, int32_t n_class, int32_t* out) {
+    for (int64_t r = 0; r < n_rows; ++r) {
+        const uint8_t* x = onehot + r * n_class;
+        int32_t idx = -1;
+        for (int32_t c = n_class - 1; c >= 0; --c) idx = x[c] ? c : idx;
+        out[r] = idx;
+    }
+}
+
 const char* tb_version(void) { return "trafficbots_hip 0.2 (gfx950, fp16-pair XDL MFMA 16x16x32 with fp32 accumulate; fp32 MFMA 16x16x4 kernels selectable)"; }
 
 // bf16 launches of more than 512 row tiles (two per CU would need more than one dispatch round) take the three-per-CU carve
@@ -468,6 +480,8 @@ void tb_destroy(tb_ctx* ctx) {
     if (ctx->enc_join2) (void)hipEventDestroy(ctx->enc_join2);
     if (ctx->d_arena) (void)hipFree(ctx->d_arena);
     if (ctx->d_ws) (void)hipFree(ctx->d_ws);
+    if (ctx->d_ws_enc) (void)hipFree(ctx->d_ws_enc);
+    if (ctx->h_status) (void)hipHostFree(ctx->h_status);
     if (ctx->d_rule_ws) (void)hipFree(ctx->d_rule_ws);
     if (ctx->d_status) (void)hipFree(ctx->d_status);
     if (ctx->d_warm_tab) (void)hipFree(ctx->d_warm_tab);
@@ -835,6 +849,20 @@ int tb_ensure_workspace(tb_ctx* ctx, size_t bytes) {
     bytes += bytes / 8;
     TB_HIP(ctx, hipMalloc((void**)&ctx->d_ws, bytes));
     ctx->ws_bytes = bytes;
+    return 0;
+}
+
+int tb_ensure_workspace_enc(tb_ctx* ctx, size_t bytes) {
+    if (bytes <= ctx->ws_enc_bytes) return 0;
+    if (ctx->d_ws_enc) {
+        TB_HIP(ctx, hipDeviceSynchronize());
+        TB_HIP(ctx, hipFree(ctx->d_ws_enc));
+        ctx->d_ws_enc = nullptr;
+        ctx->ws_enc_bytes = 0;
+    }
+    bytes += bytes / 8;
+    TB_HIP(ctx, hipMalloc((void**)&ctx->d_ws_enc, bytes));
+    ctx->ws_enc_bytes = bytes;
     return 0;
 }
 
@@ -1361,10 +1389,11 @@ extern "C" int tb_check_status(tb_ctx* ctx, tb_stream stream_) {
     TB_HIP(ctx, hipMemsetAsync(ctx->d_status, 0, sizeof(unsigned int), s));
     tb::xh::launch_range_flag_take_step(ctx->d_status, s);
     tb::xh::launch_range_flag_take_encode(ctx->d_status, s);
-    unsigned int hw[2] = {0, 0};
-    TB_HIP(ctx, hipMemcpyAsync(hw, ctx->d_status, 2 * sizeof(unsigned int), hipMemcpyDeviceToHost, s));
+    if (!ctx->h_status) TB_HIP(ctx, hipHostMalloc((void**)&ctx->h_status, 2 * sizeof(unsigned int), hipHostMallocDefault));
+    TB_HIP(ctx, hipMemcpyAsync(ctx->h_status, ctx->d_status, 2 * sizeof(unsigned int), hipMemcpyDeviceToHost, s));  // (pinned: truly asynchronous)
     TB_HIP(ctx, hipMemsetAsync(ctx->d_status + 1, 0, sizeof(unsigned int), s));
     TB_HIP(ctx, hipStreamSynchronize(s));
+    const unsigned int hw[2] = {ctx->h_status[0], ctx->h_status[1]};
     unsigned int h = hw[0];
     {   // the flag word belongs to the device: what this check took is every context's news, and what another context's check took
         // since this context's last one is this context's news too (conservative: a context may switch kernels for a neighbour's

@@ -1217,6 +1217,15 @@ __device__ __forceinline__ void lean_stats_m_x(const f32x4 (&s)[2], const f32x4 
 #pragma unroll
         for (int r = 0; r < 8; ++r) v[r] -= ref;
     } else {
+        // A row that has met no valid key so far (every key of its earlier blocks masked or its own) still carries the stand-in
+        // reference: adding +3e38 to real logits would round them away (every valid key of this block would come out with p = 1:
+        // uniform weights -- ADVICE r05 high).  Such a row takes its reference from THIS block's unshifted logits, as a first block
+        // does; its accumulators and sum are still zero, so nothing is rescaled.  Wave-uniform, rare branch.
+        const bool noref = st.nref == -RUN_MAX_NONE;
+        if (__builtin_amdgcn_ballot_w64(noref) != 0ull) {
+            const float ref = fmaxf(rows_max(max8_x(v)), RUN_MAX_NONE);
+            if (noref) st.nref = -ref;
+        }
 #pragma unroll
         for (int r = 0; r < 8; ++r) v[r] += st.nref;
         lean_ref_x(max8_x(v), v, st);

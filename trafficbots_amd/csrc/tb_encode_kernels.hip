@@ -659,8 +659,8 @@ int run_encode(struct ::tb_ctx* ctx, const tb_encode_io* io, hipStream_t s) {
     };
     Carver sz{nullptr};
     carve(sz);
-    if (tb_ensure_workspace(ctx, sz.off + 256)) return 1;
-    Carver c{ctx->d_ws};
+    if (tb_ensure_workspace_enc(ctx, sz.off + 256)) return 1;
+    Carver c{ctx->d_ws_enc};
     carve(c);
 
     // ---- what does not need the map runs beside the map encoder: agent / traffic-light tokens and the destination predictor's GRU
@@ -811,8 +811,8 @@ int run_encode_posterior(struct ::tb_ctx* ctx, const tb_posterior_io* io, hipStr
     };
     Carver sz{nullptr};
     carve(sz);
-    if (tb_ensure_workspace(ctx, sz.off + 256)) return 1;
-    Carver c{ctx->d_ws};
+    if (tb_ensure_workspace_enc(ctx, sz.off + 256)) return 1;
+    Carver c{ctx->d_ws_enc};
     carve(c);
     TokP t{};
     t.W = W; t.pe_fxy = ew.pe_fxy; t.pe_fyaw = ew.pe_fyaw;

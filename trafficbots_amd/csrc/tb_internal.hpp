@@ -32,12 +32,15 @@ struct tb_ctx {
     std::string precision_note;  // the sentence that goes with it (tb_precision_note)
     int encode_kernel = 1;  // 1: XDL attention blocks (tb_encodex_kernels.hip, default)  0: fp32-MFMA blocks; TB_ENCODE_KERNEL overrides
     // workspace
-    char* d_ws = nullptr;
+    char* d_ws = nullptr;      // the rollout's carves (tb_rollout / tb_rollout_begin)
     size_t ws_bytes = 0;
+    char* d_ws_enc = nullptr;  // the encoders' carves (tb_encode_scene / tb_encode_posterior): a workspace of their own, so that the
+    size_t ws_enc_bytes = 0;   // encoders of batch n + 1 may run on another stream beside the rollout of batch n (round 6)
     uint8_t* d_rule_ws = nullptr;  // per-step flags of tb_rule_checks
     size_t rule_ws_bytes = 0;
     long long* last_prof = nullptr;
     unsigned int* d_status = nullptr;  // device word of tb_check_status
+    unsigned int* h_status = nullptr;  // its pinned host mirror (hipHostMalloc): the check's read-back is an async copy + one stream synchronise
     int* d_warm_tab = nullptr;         // L2 warmers (tb_stepx_kernels.hip): [64][2] {arena offset, request time} of the weight units a launch streams
     long long warm_key = -1;           // (p_pad, a_pad, step kernel) the table was made for
     int warm_n = 0;
@@ -112,4 +115,5 @@ struct Carver {
 };
 
 int tb_ensure_workspace(tb_ctx* ctx, size_t bytes);
+int tb_ensure_workspace_enc(tb_ctx* ctx, size_t bytes);
 inline int padk(int x) { return (x + 31) / 32 * 32; }  // key counts / row counts are padded to 32 (tb::KEYPAD)

@@ -22,14 +22,19 @@ __global__ __launch_bounds__(64) void k_post_process(tb_post_io io) {
     const int a = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
     const int NP = io.n_pred, S = io.n_step, D = io.d_traj, A = io.n_agent;
     const int K = NP > io.k_pred ? io.k_pred : NP;
-    const float* tr = io.trajs + ((size_t)b * A + a) * NP * S * D;
+    // element strides of `trajs` over (scene, agent, future, step); all 0 = the contiguous [B,A,NP,S,D] layout.  A rollout buffer is
+    // handed over where it lies: [B*K, A, S_all, 4] viewed as [B, A, K, S_all - s0, 4] (tb_post_io.traj_strides)
+    const bool strided = io.traj_strides[0] | io.traj_strides[1] | io.traj_strides[2] | io.traj_strides[3];
+    const size_t sb = strided ? (size_t)io.traj_strides[0] : (size_t)A * NP * S * D, sa = strided ? (size_t)io.traj_strides[1] : (size_t)NP * S * D;
+    const size_t sp = strided ? (size_t)io.traj_strides[2] : (size_t)S * D, ss = strided ? (size_t)io.traj_strides[3] : (size_t)D;
+    const float* tr = io.trajs + (size_t)b * sb + (size_t)a * sa;
     const bool need_dist = (NP > io.k_pred && io.n_mtr > 0) || io.n_mpa > 0;
     if (need_dist && tid < NP) {
         for (int j = 0; j < NP; ++j) {
             float acc = 0.f, last = 0.f;
             for (int s = io.use_ade ? 0 : S - 1; s < S; ++s) {
-                const float dx = __fadd_rn(tr[((size_t)j * S + s) * D], -tr[((size_t)tid * S + s) * D]);
-                const float dy = __fadd_rn(tr[((size_t)j * S + s) * D + 1], -tr[((size_t)tid * S + s) * D + 1]);
+                const float dx = __fadd_rn(tr[j * sp + s * ss], -tr[tid * sp + s * ss]);
+                const float dy = __fadd_rn(tr[j * sp + s * ss + 1], -tr[tid * sp + s * ss + 1]);
                 last = sqrtf(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)));
                 acc = __fadd_rn(acc, last);
             }
@@ -127,7 +132,7 @@ __global__ __launch_bounds__(64) void k_post_process(tb_post_io io) {
     const uint8_t v = io.valid[(size_t)b * A + a];
     for (int i = tid; i < S * K; i += 64) {
         const int s = i / K, k = i - s * K;
-        const float* src = tr + ((size_t)sel[k] * S + s) * D;
+        const float* src = tr + sel[k] * sp + s * ss;
         const size_t o = (((size_t)b * S + s) * A + a) * K + k;
         io.waymo_trajs[o * 2] = src[0];
         io.waymo_trajs[o * 2 + 1] = src[1];

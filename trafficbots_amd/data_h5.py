@@ -98,6 +98,7 @@ def reference_kind(key: str) -> int:
 
 
 _TORCH_DTYPE = {F32: torch.float32, MASK_U8: torch.uint8, ONEHOT_I32: torch.int32, I64: torch.int64}
+_NP_DTYPE = {F32: np.float32, MASK_U8: np.uint8, ONEHOT_I32: np.int32, I64: np.int64}
 
 # packed name -> (key below the prefix, kind, drop the trailing singleton dim)
 PACKED_AGENT = {
@@ -161,18 +162,31 @@ class PackedH5File:
         _check(self.lib.tb_h5_dataset_shape(self._h, episode, key.encode(), C.byref(rank), dims, C.byref(esz)), f"tb_h5_dataset_shape({key})")
         return tuple(dims[: rank.value])
 
-    def read_keys(self, episodes: Sequence[int], specs: Sequence[Tuple], pin: bool = False, n_threads: Optional[int] = None) -> List[torch.Tensor]:
+    @staticmethod
+    def decoded_shape(n_episode: int, size: Sequence[int], kind: int, n_lead: int) -> List[int]:
+        """Shape of what tb_h5_read_batch writes for one key (before the optional squeeze of a trailing singleton)."""
+        shape = list(size)
+        if n_lead:
+            shape[0] = n_lead
+        if kind == ONEHOT_I32:
+            shape = shape[:-1]
+        return [n_episode] + shape
+
+    def read_keys(self, episodes: Sequence[int], specs: Sequence[Tuple], pin: bool = False, n_threads: Optional[int] = None,
+                  into: Optional[Sequence[torch.Tensor]] = None) -> List[torch.Tensor]:
         """One tb_h5_read_batch call.  specs: (key, stored size, kind, n_lead, squeeze) per tensor; returns the [len(episodes), *decoded
-        shape] host tensors (pinned on request) in the same order."""
+        shape] host tensors (pinned on request) in the same order.  `into`: decode straight into these caller-made contiguous tensors
+        (views of one pinned slab: `read_packed_batch`) instead of allocating one per key."""
         outs, keep = [], []
         arr = (TbH5KeySpec * max(len(specs), 1))()
         for i, (key, size, kind, n_lead, squeeze) in enumerate(specs):
-            shape = list(size)
-            if n_lead:
-                shape[0] = n_lead
-            if kind == ONEHOT_I32:
-                shape = shape[:-1]
-            out = torch.empty([len(episodes)] + shape, dtype=_TORCH_DTYPE[kind], pin_memory=pin)
+            shape = self.decoded_shape(len(episodes), size, kind, n_lead)
+            if into is not None:
+                out = into[i]
+                assert out.is_contiguous() and out.dtype == _TORCH_DTYPE[kind] and out.numel() == int(np.prod(shape)), key
+                out = out.view(shape)
+            else:
+                out = torch.empty(shape, dtype=_TORCH_DTYPE[kind], pin_memory=pin)
             dims = (C.c_int64 * max(len(size), 1))(*size)
             kb = key.encode()
             keep += [dims, kb]
@@ -217,9 +231,15 @@ class PackedH5File:
                 "with_map": torch.from_numpy(with_map.astype(np.bool_))}
 
     def read_packed_batch(self, episodes: Sequence[int], tensor_size: Dict[str, Tuple[int, ...]], split: str, n_hist: int = 11,
-                          pin: bool = False) -> Dict:
+                          pin: bool = False, tf_params: Tuple[int, int] = (10, 10)) -> Dict:
         """split "test": scene from "history/*"; "val": scene from "history/*" + ground truth from "agent/*", "tl_stop/*";
-        "train": both from "agent/*", "tl_stop/*" (the history is their first `n_hist` steps, `scene_centric.py:103-133`)."""
+        "train": both from "agent/*", "tl_stop/*" (the history is their first `n_hist` steps, `scene_centric.py:103-133`).
+
+        Round 6: the whole batch is decoded into ONE (pinned) slab in the layout of `staging.HostStager` -- every "packed/<name>" entry
+        is a view of it -- together with what depends only on host data (`agent_state`, `goal_valid`, the default teacher-forcing
+        mask for `tf_params`, the one-hot copies behind "ref/*"): `scene_from_packed` then uploads the slab with one copy."""
+        from . import staging
+
         out: Dict = {"episode_idx": torch.tensor([int(e) for e in episodes], dtype=torch.int64)}
         if split != "train":
             out.update(self._collate_attrs(episodes))
@@ -227,16 +247,65 @@ class PackedH5File:
         names, specs = [], []
         for name, (key, kind, squeeze) in {**PACKED_AGENT, **PACKED_TL}.items():
             stepped = key.rsplit("/", 1)[-1] in _STEP_KEYS
-            names.append("packed/" + name)
+            names.append(name)
             specs.append((pre + key, tensor_size[pre + key], kind, lead if stepped else 0, squeeze))
         for name, (key, kind, squeeze) in PACKED_MAP.items():
-            names.append("packed/" + name)
+            names.append(name)
             specs.append((key, tensor_size[key], kind, 0, squeeze))
         if split != "test":
             for name, (key, kind, squeeze) in {**PACKED_AGENT, **PACKED_TL, **PACKED_GT_ONLY}.items():
-                names.append("packed/gt/" + name)
+                names.append("gt/" + name)
                 specs.append((key, tensor_size[key], kind, 0, squeeze))
-        out.update(zip(names, self.read_keys(episodes, specs, pin)))
+        nb = len(episodes)
+        plan = staging._Plan()
+        shapes = {}
+        for name, (key, size, kind, n_lead, squeeze) in zip(names, specs):
+            shp = self.decoded_shape(nb, size, kind, n_lead)
+            shapes[name] = shp[:-1] if squeeze else shp
+            if kind != I64:  # (int64 ids are decoded beside the slab and narrowed into it)
+                plan.add(name, _NP_DTYPE[kind], shapes[name])
+        b, nh, a = shapes["agent_valid"]
+        p, n_cls_map = shapes["map_type"][1], tensor_size["map/type"][-1]
+        plan.add("agent_state", np.float32, (b, nh, a, 4))
+        plan.add("goal_valid", np.uint8, (b, a))
+        plan.add("tf_mask", np.uint8, (b, nh, a))
+        plan.add("ref_agent_type", np.bool_, (b, a, 3))
+        plan.add("ref_map_type", np.bool_, (b, p, n_cls_map))
+        if split != "test":
+            s_gt = shapes["gt/agent_valid"][1]
+            plan.add("gt/agent_state", np.float32, (b, s_gt, a, 4))
+            plan.add("gt/gt_dest", np.int32, (b, a))
+            plan.add("gt/tf_mask", np.uint8, (b, s_gt, a))
+        slab = torch.empty(max(plan.nbytes, 1), dtype=torch.uint8, pin_memory=pin)
+        hv = plan.host_views(slab.numpy()[: plan.nbytes])
+        tv = plan.device_views(slab)  # (the same fields as torch views of the slab: what the batch hands out)
+        side = {}
+        into = []
+        for name, (key, size, kind, n_lead, squeeze) in zip(names, specs):
+            if kind == I64:
+                side[name] = torch.empty(shapes[name], dtype=torch.int64)
+                into.append(side[name])
+            else:
+                into.append(tv[name])
+        self.read_keys(episodes, specs, into=into)
+        # ---- what depends only on the decoded host data
+        def derive(pre_: str) -> None:
+            st = hv[pre_ + "agent_state"]
+            st[..., :2], st[..., 2], st[..., 3] = hv[pre_ + "agent_pos"], hv[pre_ + "agent_yaw"], hv[pre_ + "agent_spd"]
+            hv[pre_ + "tf_mask"][...] = staging.teacher_forcing_mask_np(hv[pre_ + "agent_valid"], *tf_params)
+
+        derive("")
+        hv["goal_valid"][...] = hv["agent_valid"].any(1)
+        hv["ref_agent_type"][...] = hv["agent_type"][..., None] == np.arange(3, dtype=np.int32)
+        hv["ref_map_type"][...] = hv["map_type"][..., None] == np.arange(n_cls_map, dtype=np.int32)
+        facts = {"warm_ok": staging.no_early_exit_np(hv["agent_valid"], n_hist)}
+        if split != "test":
+            derive("gt/")
+            hv["gt/gt_dest"][...] = side["gt/gt_dest"].numpy()
+            facts["gt_warm_ok"] = staging.no_early_exit_np(hv["gt/agent_valid"], n_hist)
+        for name, t in tv.items():
+            out["packed/" + name] = t
+        out["packed/_slab"], out["packed/_plan"], out["packed/_facts"], out["packed/_tf_params"] = slab, plan, facts, tuple(tf_params)
         return out
 
 
@@ -245,23 +314,25 @@ def _early_exit_free(valid_u8: torch.Tensor, n_steps: int) -> bool:
     return not bool((v[:, :-1] & ~v[:, 1:]).any())
 
 
-def scene_from_packed(batch: Dict, device, n_hist: int = 11) -> Dict:
+def scene_from_packed(batch: Dict, device, n_hist: int = 11, tf_params: Tuple[int, int] = (10, 10)) -> Dict:
     """Packed loader batch -> the dict `runtime.scene_from_batch` builds (plus `scene["gt"]` as `runtime.gt_from_batch` builds it
-    when the batch carries ground truth): uploads only; the one derived tensor is agent_state = [pos, yaw, spd]."""
+    when the batch carries ground truth): ONE upload of the batch's slab, every tensor a view of the device copy."""
+    from . import staging
 
-    def part(prefix: str) -> Dict:
-        names = [k[len(prefix):] for k in batch if k.startswith(prefix) and "/" not in k[len(prefix):]]
-        host = {n: batch[prefix + n] for n in names}
-        s = {n: t.to(device, non_blocking=True) for n, t in host.items()}
-        s["agent_state"] = torch.cat([s["agent_pos"], s["agent_yaw"][..., None], s["agent_spd"][..., None]], -1).contiguous()
-        if "gt_dest" in s:
-            s["gt_dest"] = s["gt_dest"].to(torch.int32)
-        s["warm_ok"] = _early_exit_free(host["agent_valid"], n_hist)
-        return s
-
-    scene = part("packed/")
-    if "packed/gt/agent_valid" in batch:
-        scene["gt"] = part("packed/gt/")
+    slab, plan = batch["packed/_slab"], batch["packed/_plan"]
+    device = torch.device(device)
+    if device.type == "cuda":
+        dev = torch.empty(plan.nbytes, dtype=torch.uint8, device=device)
+        dev.copy_(slab[: plan.nbytes], non_blocking=True)
+    else:
+        dev = slab[: plan.nbytes].clone()
+    views = plan.device_views(dev)
+    made_for = batch["packed/_tf_params"]
+    scene = staging.scene_from_views(views, batch["packed/_facts"], made_for)
+    if tuple(tf_params) != tuple(made_for):  # (the consumer asks for other teacher-forcing parameters: it makes its own mask)
+        for d in (scene, scene.get("gt", {})):
+            d.pop("_tf_mask", None)
+            d.pop("_tf_params", None)
     return scene
 
 
@@ -275,11 +346,13 @@ class PackedSceneLoader:
 
     def __init__(self, filepath: str, tensor_size: Dict[str, Tuple[int, ...]], split: str, batch_size: int, n_hist: int = 11,
                  prefetch: int = 2, pin: Optional[bool] = None, rank: int = 0, world_size: int = 1, seed: int = 0,
-                 limit_batches: Optional[int] = None, readers: int = 2, index_path: Optional[str] = None) -> None:
+                 limit_batches: Optional[int] = None, readers: int = 2, index_path: Optional[str] = None,
+                 tf_params: Tuple[int, int] = (10, 10)) -> None:
         assert split in ("train", "val", "test") and readers >= 1
         self.filepath, self.tensor_size, self.split, self.batch_size, self.n_hist = filepath, tensor_size, split, batch_size, n_hist
         self.prefetch, self.pin = prefetch, torch.cuda.is_available() if pin is None else pin
         self.rank, self.world_size, self.seed, self.limit_batches = rank, world_size, seed, limit_batches
+        self.tf_params = tuple(tf_params)  # the default teacher-forcing mask travels with the batch (teacher_forcing_joint_future_pred)
         # kept across epochs: a handle's chunk index makes every later visit of an episode metadata-free
         self._files = [PackedH5File(filepath) for _ in range(readers)]
         self._busy = threading.Lock()  # one iteration at a time uses them; a concurrent second one opens its own
@@ -317,7 +390,7 @@ class PackedSceneLoader:
                 for c in chunks[r::n]:
                     if stop.is_set():
                         break
-                    queues[r].put(files[r].read_packed_batch(c, self.tensor_size, self.split, self.n_hist, self.pin))
+                    queues[r].put(files[r].read_packed_batch(c, self.tensor_size, self.split, self.n_hist, self.pin, self.tf_params))
             except BaseException as e:  # surfaced in the consumer, in order
                 queues[r].put(e)
 

@@ -113,7 +113,7 @@ class TbPostIO(C.Structure):
         ("n_mtr", C.c_int32), ("mtr_nms_thresh", C.c_float * 3), ("use_ade", C.c_int32),
         ("valid", c_u8p), ("scores", c_f32p), ("trajs", c_f32p), ("agent_type", c_i32p),
         ("waymo_trajs", c_f32p), ("waymo_yaw_bbox", c_f32p), ("waymo_spd", c_f32p), ("waymo_scores", c_f32p),
-        ("waymo_valid", c_u8p), ("mode_idx", c_i32p),
+        ("waymo_valid", c_u8p), ("mode_idx", c_i32p), ("traj_strides", C.c_int64 * 4),
     ]
 
 
@@ -160,6 +160,7 @@ EXPORTS = (
     "tb_rollout", "tb_rollout_begin", "tb_rollout_step", "tb_rollout_step_ex", "tb_check_status", "tb_rollout_state", "tb_encode_scene", "tb_set_timing", "tb_get_timing",
     "tb_rule_checks", "tb_post_process", "tb_metric_partials", "tb_struct_sizes", "tb_encode_posterior", "tb_train_partials",
     "tb_forward", "tb_graph_stats", "tb_latent_sample", "tb_dest_sample", "tb_precision_state", "tb_precision_note",
+    "tb_host_onehot_index",
 )
 
 _lib: Optional[C.CDLL] = None
@@ -241,6 +242,8 @@ def load() -> C.CDLL:
     lib.tb_precision_state.restype = C.c_int
     lib.tb_precision_note.argtypes = [C.c_void_p]
     lib.tb_precision_note.restype = C.c_char_p
+    lib.tb_host_onehot_index.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]
+    lib.tb_host_onehot_index.restype = None
     lib.tb_set_timing.argtypes = [C.c_void_p, C.c_int]
     lib.tb_set_timing.restype = C.c_int
     lib.tb_get_timing.argtypes = [C.c_void_p, c_f32p]

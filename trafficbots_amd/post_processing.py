@@ -10,7 +10,7 @@ import torch
 from torch import Tensor
 
 from . import hip
-from .runtime import HipEngine
+from .runtime import HipEngine, as_bool, as_u8
 
 
 class WaymoPostProcessing:
@@ -42,9 +42,14 @@ class WaymoPostProcessing:
         b, a, n_pred, n_step, d = trajs.shape
         k = min(self.k_pred, n_pred)
         f32 = torch.float32
-        valid_u8 = valid.to(dev).to(torch.uint8).contiguous()
+        valid_u8 = as_u8(valid.to(dev))
         scores_c = scores.to(dev).to(f32).contiguous()
-        trajs_c = trajs.to(dev).to(f32).contiguous()
+        # the trajectories are read where they lie when the D components are adjacent (a rollout buffer's [B*K,A,S_all,4] viewed as
+        # [B,A,K,S,4] from the first future step on is such a view: tb_post_io.traj_strides) -- no re-laid-out copy
+        trajs_c = trajs.to(dev).to(f32)
+        strided = not trajs_c.is_contiguous()
+        if strided and trajs_c.stride(4) != 1:
+            trajs_c, strided = trajs_c.contiguous(), False
         ty = agent_type.to(dev)
         ty = (ty.to(torch.int32).argmax(-1) if ty.dim() == 3 else ty).to(torch.int32).contiguous()
         out = {
@@ -63,7 +68,14 @@ class WaymoPostProcessing:
             io.mpa_nms_thresh[i] = v
         for i, v in enumerate(self.mtr_nms_thresh):
             io.mtr_nms_thresh[i] = v
-        io.valid, io.scores, io.trajs = hip.ptr(valid_u8, hip.c_u8p), hip.ptr(scores_c, hip.c_f32p), hip.ptr(trajs_c, hip.c_f32p)
+        io.valid, io.scores = hip.ptr(valid_u8, hip.c_u8p), hip.ptr(scores_c, hip.c_f32p)
+        if strided:
+            for i in range(4):
+                io.traj_strides[i] = trajs_c.stride(i)
+            base = trajs_c.as_strided((trajs_c.untyped_storage().nbytes() // 4 - trajs_c.storage_offset(),), (1,))  # (first element .. end of the storage)
+            io.trajs = hip.ptr(base, hip.c_f32p)
+        else:
+            io.trajs = hip.ptr(trajs_c, hip.c_f32p)
         io.agent_type = hip.ptr(ty, hip.c_i32p)
         io.waymo_trajs = hip.ptr(out["waymo_trajs"], hip.c_f32p)
         io.waymo_yaw_bbox = hip.ptr(out["waymo_yaw_bbox"], hip.c_f32p)
@@ -72,6 +84,6 @@ class WaymoPostProcessing:
         io.waymo_valid = hip.ptr(out["waymo_valid"], hip.c_u8p)
         io.mode_idx = hip.ptr(out["mode_idx"], hip.c_i32p)
         eng._check(eng.lib.tb_post_process(eng._ctx, C.byref(io), eng._stream()), "tb_post_process")
-        out["waymo_valid"] = out["waymo_valid"].bool()
+        out["waymo_valid"] = as_bool(out["waymo_valid"])
         out["_keepalive"] = (valid_u8, scores_c, trajs_c, ty)
         return out

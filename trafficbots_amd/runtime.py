@@ -17,6 +17,20 @@ from . import hip
 N_PL_NODE = 20
 
 
+def as_bool(x: Tensor) -> Tensor:
+    """uint8 0/1 mask (what the kernels write and the staging makes) -> bool WITHOUT a conversion kernel: a reinterpreting view."""
+    return x.view(torch.bool) if x.dtype == torch.uint8 else x.bool()
+
+
+def as_u8(x: Tensor) -> Tensor:
+    """bool -> uint8 as a view (contiguous input), else a conversion."""
+    if x.dtype == torch.uint8:
+        return x.contiguous()
+    if x.dtype == torch.bool and x.is_contiguous():
+        return x.view(torch.uint8)
+    return x.to(torch.uint8).contiguous()
+
+
 def _onehot_to_index(x: Tensor) -> Tensor:
     """bool one-hot [..., C] -> int32 index, -1 where no class is set."""
     idx = x.to(torch.int32).argmax(-1).to(torch.int32)
@@ -70,12 +84,44 @@ def no_early_exit(valid, n_steps: int) -> bool:
     return not bool((v[:, :-1] & ~v[:, 1:]).any())
 
 
-def scene_from_batch(batch: Dict[str, Tensor], device, n_hist: int = 11) -> Dict[str, Tensor]:
+_STAGERS: Dict = {}
+
+
+def default_stager(device, n_hist: int = 11, tf_params: Tuple[int, int] = (10, 10)):
+    """The process-wide `staging.HostStager` of (device, n_hist, teacher-forcing parameters): pinned slabs are worth keeping."""
+    from .staging import HostStager
+
+    key = (str(torch.device(device)), int(n_hist), tuple(int(x) for x in tf_params))
+    if key not in _STAGERS:
+        _STAGERS[key] = HostStager(device, n_hist, tf_params)
+    return _STAGERS[key]
+
+
+def scene_from_batch(batch: Dict[str, Tensor], device, n_hist: int = 11, with_gt: bool = False) -> Dict[str, Tensor]:
     """Reference batch (`data_h5_womd.py:85-157`, bool tensors) -> the C ABI's device layout (uint8 masks, int32 class
     indices, yaw/spd/acc as [B,NH,A]).  Test / validation batches carry the history under "history/*"; a TRAINING-split batch
     has only "agent/*" / "tl_stop/*" over 91 steps, of which `SceneCentricPreProcessing` (prefix "" in training,
     `scene_centric.py:92-121`) takes the first `n_hist` steps -- same here.  `warm_ok` (a Python bool, not a tensor) records
-    that no agent leaves within the history, see :func:`no_early_exit`."""
+    that no agent leaves within the history, see :func:`no_early_exit`.
+
+    A batch that lives on the HOST (numpy arrays / CPU tensors -- what a DataLoader yields) takes the staged path (round 6,
+    `staging.HostStager`): the layout conversion happens on the host while the batch is copied into ONE pinned slab, one
+    host-to-device copy, every returned tensor a view of one device buffer, no device-side conversion kernels; `with_gt` keeps the
+    nested `scene["gt"]` of a validation / training batch (what :func:`gt_from_batch` builds).  A batch that is already on the
+    device is converted there with torch ops (:func:`scene_from_batch_torch`)."""
+    from .staging import is_host_batch
+
+    if is_host_batch(batch):
+        scene = default_stager(device, n_hist).stage(batch)
+        if not with_gt:
+            scene.pop("gt", None)
+        return scene
+    return scene_from_batch_torch(batch, device, n_hist)
+
+
+def scene_from_batch_torch(batch: Dict[str, Tensor], device, n_hist: int = 11) -> Dict[str, Tensor]:
+    """:func:`scene_from_batch` with torch ops on `device` (one copy per tensor + conversion kernels): the path of a batch that is
+    already device-resident, and the cross-check of the staged path in the CPU tests."""
     pre = "history/" if "history/agent/valid" in batch else ""
     if not pre and "agent/valid" not in batch:
         raise KeyError("batch carries neither 'history/agent/*' nor 'agent/*'")
@@ -193,6 +239,11 @@ class HipEngine:
 
     def _stream(self) -> C.c_void_p:
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def stager(self, tf_params: Tuple[int, int] = (10, 10)):
+        """The pinned-slab stager of this engine's device (`staging.HostStager`; shared per (device, n_hist, teacher-forcing
+        parameters) in the process)."""
+        return default_stager(self.device, self.n_hist, tf_params)
 
     # -------------------------------------------------------------------------------- weights
     def load_state_dict(self, state_dict: Dict) -> None:
@@ -411,10 +462,11 @@ class HipEngine:
             cached = out.get("_default_tf_mask") if out is not None else None
             if cached is not None and cached[2] is src and cached[0] == mkey:
                 mask_teacher_forcing = cached[1]
+            elif ag.get("_tf_params") == (tf.get("step_spawn_agent", 10), tf.get("step_warm_start", 10)):
+                mask_teacher_forcing = ag["_tf_mask"]  # made on the host when the batch was staged (staging.py)
             else:
-                mask_teacher_forcing = teacher_forcing_mask(
-                    ag["agent_valid"].bool(), tf.get("step_spawn_agent", 10), tf.get("step_warm_start", 10)
-                ).to(u8).contiguous()
+                mask_teacher_forcing = as_u8(teacher_forcing_mask(
+                    as_bool(ag["agent_valid"]), tf.get("step_spawn_agent", 10), tf.get("step_warm_start", 10)))
             default_mask = (mkey, mask_teacher_forcing, src)
         else:
             default_mask = None
@@ -462,7 +514,7 @@ class HipEngine:
         io.map_dir = hip.ptr(s["map_dir"], hip.c_f32p)
         latent_mean = latent_mean.to(f32).contiguous()
         dest = dest.to(torch.int32).contiguous()
-        goal_valid = goal_valid.to(u8).contiguous()
+        goal_valid = as_u8(goal_valid)
         assert dest.shape == (n, a) and goal_valid.shape == (n, a)
         assert latent_mean.shape == (b, a, 16)
         if latent_sample is None:  # drawn on the device by the prologue

@@ -19,13 +19,16 @@ from torch import Tensor
 from .config import config_from_hydra_kwargs, load_model_config
 from .distributions import DestCategorical, DiagGaussian
 from .metrics import ErrorMetrics, TrafficRuleMetrics, TrainingMetrics
-from .runtime import HipEngine, gt_from_batch, scene_from_batch, teacher_forcing_mask, warm_start_promise_holds
+from .runtime import HipEngine, as_bool, as_u8, gt_from_batch, scene_from_batch_torch, teacher_forcing_mask, warm_start_promise_holds
 
 _VIOLATION_KEYS = (
     "outside_map", "outside_map_this_step", "collided", "collided_this_step", "run_road_edge",
     "run_road_edge_this_step", "run_red_light", "run_red_light_this_step", "passive", "passive_this_step",
     "goal_reached", "goal_reached_this_step", "dest_reached", "dest_reached_this_step",
 )
+
+
+_STAND_IN: Dict = {}  # device -> the one-element tensor behind the shape-only attr / pe stand-ins
 
 
 def _with_reference_keys(scene: Dict[str, Tensor]) -> Dict[str, Tensor]:
@@ -38,7 +41,9 @@ def _with_reference_keys(scene: Dict[str, Tensor]) -> Dict[str, Tensor]:
     b, nh, a = scene["agent_valid"].shape
     p, t = scene["map_valid"].shape[1], scene["tl_valid"].shape[2]
     dev = scene["agent_valid"].device
-    z = torch.zeros(1, device=dev, dtype=torch.float32)
+    z = _STAND_IN.get(dev)
+    if z is None:
+        z = _STAND_IN[dev] = torch.zeros(1, device=dev, dtype=torch.float32)
 
     def stand_in(*shape):
         x = z.expand(*shape)
@@ -46,18 +51,21 @@ def _with_reference_keys(scene: Dict[str, Tensor]) -> Dict[str, Tensor]:
         return x
 
     ref = {
-        "agent_valid": scene["agent_valid"].bool(), "agent_attr": stand_in(b, nh, a, 11), "agent_pe": stand_in(b, nh, a, 96),
+        "agent_valid": as_bool(scene["agent_valid"]), "agent_attr": stand_in(b, nh, a, 11), "agent_pe": stand_in(b, nh, a, 96),
         "agent_pos": scene["agent_pos"],
-        "map_valid": scene["map_valid"].bool(), "map_attr": stand_in(b, p, 20, 31), "map_pe": stand_in(b, p, 20, 96),
+        "map_valid": as_bool(scene["map_valid"]), "map_attr": stand_in(b, p, 20, 31), "map_pe": stand_in(b, p, 20, 96),
         "map_pos": scene["map_pos"][:, :, 0],
-        "tl_valid": scene["tl_valid"].bool(), "tl_attr": stand_in(b, nh, t, 5), "tl_pe": stand_in(b, nh, t, 96), "tl_pos": scene["tl_pos"],
+        "tl_valid": as_bool(scene["tl_valid"]), "tl_attr": stand_in(b, nh, t, 5), "tl_pe": stand_in(b, nh, t, 96), "tl_pos": scene["tl_pos"],
     }
     for k, v in ref.items():
         scene["input/" + k] = v
         scene["latent_prior/" + k] = v
-    idx = torch.arange(11, device=dev)
-    scene["ref/agent_type"] = scene["agent_type"].unsqueeze(-1) == idx[:3]
-    scene["ref/map_type"] = scene["map_type"].unsqueeze(-1) == idx
+    if "_ref_agent_type" in scene:  # a staged scene carries the batch's own one-hots (staging.py): nothing to rebuild on the device
+        scene["ref/agent_type"], scene["ref/map_type"] = scene["_ref_agent_type"], scene["_ref_map_type"]
+    else:
+        idx = torch.arange(11, device=dev)
+        scene["ref/agent_type"] = scene["agent_type"].unsqueeze(-1) == idx[:3]
+        scene["ref/map_type"] = scene["map_type"].unsqueeze(-1) == idx
     scene["ref/agent_state"] = scene["agent_state"]
     return scene
 
@@ -139,11 +147,14 @@ class _GoalManager:
     def pred_goal(self, **kwargs) -> DestCategorical:
         """`GoalManager.pred_goal` -> `DestPredictor.forward` (`goal_manager.py:78-82,202-333`).  The logits
         were produced together with the features by `encode_input_features`."""
-        return DestCategorical(logits=self._o._enc["dest_logits"], valid=self._o._scene["agent_valid"].bool().any(1), engine=self._o.engine)
+        return DestCategorical(logits=self._o._enc["dest_logits"], valid=self._o._goal_valid(), engine=self._o.engine)
 
     def get_gt_goal(self, agent_valid: Tensor, gt_goal: Optional[Tensor], gt_dest: Tensor) -> Tuple[Tensor, Tensor]:
         """`GoalManager.get_gt_goal`, goal_attr_mode "dest" (`goal_manager.py:50-75`)."""
-        return gt_dest, agent_valid.bool().any(1)
+        sc = self._o._scene
+        if agent_valid is sc.get("agent_valid") or agent_valid is sc.get("input/agent_valid"):
+            return gt_dest, self._o._goal_valid()
+        return gt_dest, as_bool(agent_valid).any(1)
 
 
 class TrafficBots:
@@ -190,10 +201,15 @@ class TrafficBots:
             self._scene = scene
         e = self._enc
         return {
-            "agent_feature": e["agent_feature"], "agent_feature_valid": scene["agent_valid"].bool(),
-            "map_feature": e["map_feature"], "map_feature_valid": e["map_feature_valid"].bool(),
-            "tl_feature": e["tl_feature"], "tl_feature_valid": scene["tl_valid"].bool(),
+            "agent_feature": e["agent_feature"], "agent_feature_valid": as_bool(scene["agent_valid"]),
+            "map_feature": e["map_feature"], "map_feature_valid": as_bool(e["map_feature_valid"]),
+            "tl_feature": e["tl_feature"], "tl_feature_valid": as_bool(scene["tl_valid"]),
         }
+
+    def _goal_valid(self) -> Tensor:
+        """agent_valid.any(1) of the encoded scene [B, A] bool: made on the host for a staged scene (staging.py)."""
+        sc = self._scene
+        return as_bool(sc["_goal_valid"]) if "_goal_valid" in sc else as_bool(sc["agent_valid"]).any(1)
 
     def init(self, latent: DiagGaussian, deterministic: Union[bool, Tensor], eps: Optional[Tensor] = None) -> None:
         """`TrafficBots.init` (`traffic_bots.py:153-161`): binds the personality distribution for the next rollout and clears the
@@ -235,8 +251,8 @@ class TrafficBots:
             if gt is None:
                 raise ValueError("latent_encoder(posterior=True) needs the ground truth (pre_processing(batch)['gt'])")
             post = self.engine.encode_posterior(gt, self._enc)
-            return DiagGaussian(post["latent_mean"], self._log_std_post, valid=post["latent_valid"].bool(), engine=self.engine)
-        return DiagGaussian(self._enc["latent_mean"], self._log_std, valid=self._enc["latent_valid"].bool(), engine=self.engine)
+            return DiagGaussian(post["latent_mean"], self._log_std_post, valid=as_bool(post["latent_valid"]), engine=self.engine)
+        return DiagGaussian(self._enc["latent_mean"], self._log_std, valid=as_bool(self._enc["latent_valid"]), engine=self.engine)
 
 
 def _range_fallback(fn):
@@ -256,7 +272,8 @@ def _range_fallback(fn):
     def step(self, *args, **kwargs):
         if not self.check_range:
             return fn(self, *args, **kwargs)
-        snap = [copy.deepcopy(h.__dict__) for h in self._metric_holders()]
+        # (the holders' states are replaced, never modified in place -- metrics._PackedSumMetric.update: a shallow copy restores them)
+        snap = [copy.copy(h.__dict__) for h in self._metric_holders()] if fn.__name__ != "test_step" else []
         gen = kwargs.get("generator")
         gen_state = gen.get_state() if gen is not None else None
         t0 = time.perf_counter()
@@ -265,6 +282,7 @@ def _range_fallback(fn):
             return out
         t1 = time.perf_counter()
         for h, d in zip(self._metric_holders(), snap):
+            h.__dict__.clear()
             h.__dict__.update(d)
         if gen_state is not None:
             gen.set_state(gen_state)
@@ -291,6 +309,8 @@ class WaymoMotion:
         else:
             self.hparams = load_model_config(config_path, overrides or None)
         self.check_range = True  # tb_check_status at the end of test_step / validation_step / training_step (one stream sync each)
+        self._det_cache: Dict = {}
+        self._zeros_cache: Dict = {}
         self.device = torch.device(device)
         self.engine = HipEngine(self.hparams, device)
         self.model = TrafficBots(self.engine)
@@ -320,14 +340,36 @@ class WaymoMotion:
         (`scene_centric.py:103-133`, `sc_input.py:100-140`); attr/PE/MLP run inside `tb_encode_scene`.  A validation /
         training batch (one that carries "agent/valid") also yields the full ground truth as the nested dict `scene["gt"]`
         (`scene_centric.py:103-110`, `sc_latent.py:150-163,196-217`)."""
+        from .staging import StagedBatch, is_host_batch
+
+        if isinstance(batch, StagedBatch):  # staged (and possibly encoded) ahead of time by `prefetch`: this stream waits for it
+            batch.wait(torch.cuda.current_stream(self.device))
+            if batch.enc is not None:
+                self.model._enc, self.model._scene = batch.enc, batch
+            return batch
         if "packed/agent_valid" in batch:  # a `data_h5.PackedSceneLoader` batch: decoded by the reader, upload only
             from .data_h5 import scene_from_packed
 
-            return _with_reference_keys(scene_from_packed(batch, self.device, self.n_hist))
-        scene = scene_from_batch(batch, self.device, self.n_hist)
+            return _with_reference_keys(scene_from_packed(batch, self.device, self.n_hist, self._tf_params))
+        if is_host_batch(batch):  # what a DataLoader yields: ONE pinned slab, one copy, no conversion kernels (staging.py)
+            return _with_reference_keys(self.engine.stager(self._tf_params).stage(batch))
+        scene = scene_from_batch_torch(batch, self.device, self.n_hist)  # (a batch somebody moved to the device already)
         if "agent/valid" in batch:
             scene["gt"] = gt_from_batch(batch, self.device, self.n_hist)
         return _with_reference_keys(scene)
+
+    def prefetch(self, loader, encode: bool = True):
+        """`for staged in wm.prefetch(loader): out = wm.test_step(staged)` (also validation_step): batch n + 1 is staged -- host packing,
+        ONE upload -- and, with `encode`, run through the scene encoders on a side stream while batch n's rollout occupies the main
+        one (`staging.BatchPrefetcher`).  Same results as `test_step(batch)`, bit for bit."""
+        from .staging import BatchPrefetcher
+
+        return BatchPrefetcher(self, loader, encode=encode)
+
+    @property
+    def _tf_params(self) -> Tuple[int, int]:
+        tf = self.hparams["teacher_forcing_joint_future_pred"]
+        return int(tf.get("step_spawn_agent", 10)), int(tf.get("step_warm_start", 10))
 
     # ------------------------------------------------------------------ rollout
     def rollout(
@@ -400,7 +442,7 @@ class WaymoMotion:
         want_checks = any(bool(v) for k, v in flags.items() if k.startswith("enable_check_")) or agent_goal is not None
         out = self.engine.rollout(
             features, features, None, mean_scene, goal, goal_valid, k_futures, step_end, latent_eps=z_eps, latent_deterministic=z_det,
-            mask_teacher_forcing=mask_teacher_forcing.to(torch.uint8).contiguous(), tap_step=-2 if require_vis_dict else tap_step,
+            mask_teacher_forcing=as_u8(mask_teacher_forcing), tap_step=-2 if require_vis_dict else tap_step,
             stepwise=stepwise or per_step,
             record_check_states=want_checks, gt=gt, latent_posterior=latent_posterior, warm_start_steps=warm_start_steps,
             action_eps=action_eps, hidden_drop=hidden_drop, record_actions=require_vis_dict,
@@ -436,11 +478,17 @@ class WaymoMotion:
     def _buffer_from(self, out: Dict[str, Tensor]) -> RolloutBuffer:
         step_start, step_end, z = self._rollout_meta
         buf = RolloutBuffer(step_start, step_end, self.hparams["time_step_current"])
-        buf.valid = out["valid"].bool()
+        buf.valid = as_bool(out["valid"])  # (the kernels write 0 / 1: a reinterpreting view, not a conversion)
         buf.preds = out["preds"]
-        buf.override_masks = out["override_masks"].bool()
-        zeros = torch.zeros_like(buf.valid)
-        buf.violations = {k: (out[k].bool() if k in out else zeros) for k in _VIOLATION_KEYS}
+        buf.override_masks = as_bool(out["override_masks"])
+        zeros = None
+        if any(k not in out for k in _VIOLATION_KEYS):  # (checks that did not run: all-False, one shared tensor)
+            zk = (tuple(buf.valid.shape), buf.valid.device)
+            zeros = self._zeros_cache.get(zk)
+            if zeros is None:
+                self._zeros_cache.clear()
+                zeros = self._zeros_cache[zk] = torch.zeros_like(buf.valid)
+        buf.violations = {k: (as_bool(out[k]) if k in out else zeros) for k in _VIOLATION_KEYS}
         n_step = buf.valid.shape[2]
         buf.latent_log_probs = out["latent_log_prob"].unsqueeze(-1).expand(-1, -1, n_step)
         buf.action_log_probs = out["action_log_probs"]
@@ -451,7 +499,7 @@ class WaymoMotion:
         if vis is not None and vis["collected"]:  # `RolloutBuffer.finish`: torch.stack(..., dim=2) (`buffer.py:89-90`)
             buf.vis_dicts = {k_: torch.stack([d[k_] for d in vis["collected"]], dim=2) for k_ in vis["collected"][0]}
         if "diffbar_rewards" in out:
-            buf.diffbar_rewards, buf.diffbar_rewards_valid = out["diffbar_rewards"], out["diffbar_rewards_valid"].bool()
+            buf.diffbar_rewards, buf.diffbar_rewards_valid = out["diffbar_rewards"], as_bool(out["diffbar_rewards_valid"])
         return buf
 
     def _warm_start_steps(self, tf: Dict, src: Dict[str, Tensor]) -> int:
@@ -479,7 +527,7 @@ class WaymoMotion:
         `deterministic_latent=False` draws the personality as mean + std * `latent_eps` (training_step's rsample, `:397`)."""
         features = {k: v for k, v in batch.items() if k != "gt"}
         features["map_feature"] = input_feature_dict["map_feature"]
-        features["map_feature_valid"] = input_feature_dict["map_feature_valid"].to(torch.uint8).contiguous()
+        features["map_feature_valid"] = as_u8(input_feature_dict["map_feature_valid"])
         features["tl_feature"] = input_feature_dict["tl_feature"]
         # (the masks of validation / training force every valid agent up to step_warm_start = time_step_current; a mask the
         # caller made itself is checked against that promise, and the warm start is not batched when it does not hold)
@@ -656,8 +704,11 @@ class WaymoMotion:
         with repeat_interleave; here only the per-instance tensors are."""
         k = self.hparams["n_joint_future"]
         b, _, a = batch["agent_valid"].shape
-        deterministic = torch.zeros(b * k, a, dtype=torch.bool, device=self.device)
-        deterministic[::k] = True
+        deterministic = self._det_cache.get((b, k, a))  # (a constant of the shape: sample 0 of every scene takes the mean)
+        if deterministic is None:
+            deterministic = torch.zeros(b * k, a, dtype=torch.bool, device=self.device)
+            deterministic[::k] = True
+            self._det_cache[(b, k, a)] = deterministic
         latent.repeat_interleave_(k, 0)
         goal.repeat_interleave_(k, 0)
         if goal_sample is None:
@@ -669,17 +720,21 @@ class WaymoMotion:
                     raise IndexError(f"goal_sample holds a polyline index outside [0, {n_pl})")
             goal_sample = goal_sample.to(self.device).reshape(b * k, a)
         goal_log_probs = goal.log_prob(goal_sample)
-        goal_valid = goal_valid.repeat_interleave(k, 0)
+        if k > 1:
+            goal_valid = goal_valid.repeat_interleave(k, 0)
         features = {k_: v for k_, v in batch.items() if k_ != "gt"}
         features["map_feature"] = input_feature_dict["map_feature"]
-        features["map_feature_valid"] = input_feature_dict["map_feature_valid"].to(torch.uint8).contiguous()
+        features["map_feature_valid"] = as_u8(input_feature_dict["map_feature_valid"])
         features["tl_feature"] = input_feature_dict["tl_feature"]
         tf = self.hparams["teacher_forcing_joint_future_pred"]
         # validation: features["agent_valid"] etc. are the 91-step ground truth (waymo_motion.py:538-545 with batch["agent/*"]
         # left untouched), which only matters for the kill rule; test_step overwrites them with the history (:925-926)
         gt = batch.get("gt")
-        src_valid = (gt if gt is not None else batch)["agent_valid"].bool()
-        mask_tf = teacher_forcing_mask(src_valid, tf.get("step_spawn_agent", 10), tf.get("step_warm_start", 10))
+        src = gt if gt is not None else batch
+        if src.get("_tf_params") == (tf.get("step_spawn_agent", 10), tf.get("step_warm_start", 10)):
+            mask_tf = src["_tf_mask"]  # made on the host while the batch was staged (staging.teacher_forcing_mask_np)
+        else:
+            mask_tf = teacher_forcing_mask(as_bool(src["agent_valid"]), tf.get("step_spawn_agent", 10), tf.get("step_warm_start", 10))
         buf = self.rollout(
             features, latent=latent, goal=goal_sample, goal_valid=goal_valid, mask_teacher_forcing=mask_tf,
             deterministic_latent=deterministic, deterministic_action=action_eps is None,  # (the reference passes True, :560)
@@ -703,7 +758,7 @@ class WaymoMotion:
         scene = self.pre_processing(batch)
         scene.pop("gt", None)  # batch["agent/*"] = batch["history/agent/*"] (waymo_motion.py:925-926)
         input_feature_dict = self.model.encode_input_features(scene)
-        goal_valid = scene["agent_valid"].bool().any(1)
+        goal_valid = as_bool(scene["_goal_valid"]) if "_goal_valid" in scene else as_bool(scene["agent_valid"]).any(1)
         goal_pred = self.model.goal_manager.pred_goal()
         latent_prior = self.model.latent_encoder()
         latent_mean, latent_valid = latent_prior.mean, latent_prior.valid  # (repeat_interleave_ below rebinds them)
@@ -718,11 +773,20 @@ class WaymoMotion:
                 valid=buf.valid[:, :, 0].any(-1), scores=scores, trajs=buf.preds[:, :, :, buf.step_future_start:],
                 agent_type=scene["agent_type"],
             )
+        self._after_enqueue(batch)
         return {
             "rollout_buffer": buf, "goal_sample": gs, "goal_log_probs": glp, "input_feature_dict": input_feature_dict,
             "latent_mean": latent_mean, "latent_valid": latent_valid, "dest_logits": self.model._enc["dest_logits"],
             "scores": scores, "pred_dict": pred_dict,
         }
+
+    @staticmethod
+    def _after_enqueue(batch) -> None:
+        """Called by the harness steps once their GPU work is enqueued and before they synchronise: a batch that came out of
+        `prefetch` lets its prefetcher stage (and encode) the NEXT batch now, under this batch's rollout."""
+        pf = getattr(batch, "prefetcher", None)
+        if pf is not None:
+            pf.advance()
 
     def _check_range(self) -> None:
         """`tb_check_status` (one stream synchronisation; `self.check_range = False` skips it): raises if an fp16-pair operand of the
@@ -781,8 +845,8 @@ class WaymoMotion:
             scene_l, gt_l = self._perturb_latent_inputs(scene, gt, lp["yaw"], lp["pos"])
             enc_l = self.engine.encode_scene(scene_l)
             post = self.engine.encode_posterior(gt_l, enc_l)
-            latent_post = DiagGaussian(post["latent_mean"], self.model._log_std_post, valid=post["latent_valid"].bool(), engine=self.engine)
-            latent_prior = DiagGaussian(enc_l["latent_mean"], self.model._log_std, valid=enc_l["latent_valid"].bool(), engine=self.engine)
+            latent_post = DiagGaussian(post["latent_mean"], self.model._log_std_post, valid=as_bool(post["latent_valid"]), engine=self.engine)
+            latent_prior = DiagGaussian(enc_l["latent_mean"], self.model._log_std, valid=as_bool(enc_l["latent_valid"]), engine=self.engine)
         else:
             latent_post = self.model.latent_encoder(posterior=True, gt=gt)
             latent_prior = self.model.latent_encoder()
@@ -903,7 +967,10 @@ class WaymoMotion:
         prior_mean, prior_valid = latent_prior.mean, latent_prior.valid
         # ---- reactive replay
         tf = hp["teacher_forcing_reactive_replay"]
-        mask_tf = teacher_forcing_mask(gt["agent_valid"].bool(), tf.get("step_spawn_agent", 10), tf.get("step_warm_start", 10))
+        if gt.get("_tf_params") == (tf.get("step_spawn_agent", 10), tf.get("step_warm_start", 10)):
+            mask_tf = gt["_tf_mask"]  # (the same parameters as joint_future_pred's: the mask the staging made on the host)
+        else:
+            mask_tf = teacher_forcing_mask(as_bool(gt["agent_valid"]), tf.get("step_spawn_agent", 10), tf.get("step_warm_start", 10))
         buf = self.reactive_replay(scene, input_feature_dict, mask_tf, latent_post, goal_gt, goal_valid,
                                    deterministic_latent=True, deterministic_action=True)
         gv, gs = self._gt_slices(gt, s0, s1)
@@ -941,6 +1008,7 @@ class WaymoMotion:
         pred_dict_j = self.waymo_post_processing(
             valid=buf_j.valid[:, :, 0].any(-1), scores=scores, trajs=buf_j.preds[:, :, :, buf_j.step_future_start:],
             agent_type=scene["agent_type"])
+        self._after_enqueue(batch)
         return {
             "reactive_replay": {"rollout_buffer": buf, "train_states": train_states, "metric_states": states, "pred_dict": pred_dict_rr},
             "joint_future_pred": {"rollout_buffer": buf_j, "goal_sample": gsamp, "goal_log_probs": glp, "metric_states": states_j,
