@@ -75,17 +75,57 @@ def flops_encode(a, p):
     return f_map + f_dest + f_lat
 
 
-def load_path(k_us, n_agent, n_pl, n_tl_keys, wbytes=4):
-    """Bytes every workgroup pulls through its CU's vector-memory path per fused launch (weights are streamed once per
-    16-agent tile, K/V once per head) against the ~64 B/clk/CU the L1 can fill (MI355X_MICROARCH.md: L2 34.5 TB/s / 256 CUs)."""
+N_CU = 256
+
+
+def flops_encode_executed(a, p):
+    """What the encoders EXECUTE on the XDL pipe: the hoisted form of SURVEY 8(d)'s count -- the destination predictor's first Linear
+    runs once per agent and once per polyline (k_linear_rows), not once per (agent, polyline) pair -- times the 3 fp16 MFMAs the
+    fp16-pair kernels issue per algorithmic product."""
+    f_map = 2 * p * 20 * 2016 + 3 * (12 * (20 * p) * H * H + 4 * (20 * p) * 20 * H) + 12 * p * H * H + 4 * p * p * H
+    f_dest = 11 * 36 * a * H * H + 2 * (a + p) * 2 * H * H + 2 * a * p * (H * H + H)
+    f_lat = 0.51e9 * (a / 64.0)
+    return 3.0 * (f_map + f_dest + f_lat)
+
+
+def load_path(k_us, n_agent, n_pl, n_tl_keys, wbytes=4, n_workgroup=None):
+    """Bytes that pass through ONE CU's vector-memory path per fused launch against the ~64 B/clk/CU the L1 can fill
+    (MI355X_MICROARCH.md: L2 34.5 TB/s / 256 CUs) and the 42 B/clk four waves sustain on an L2-resident stream (tools/microtests,
+    profiles/r01_microbench_*).  Every workgroup streams the weights once per 16-agent tile and K / V once per head; a launch of more
+    than 256 workgroups puts n_workgroup / 256 of them through each CU (co-resident or in rounds: K = 6 has 768 tiles, three per CU),
+    so the per-CU figure is the per-workgroup bytes TIMES that factor (the line used to print one workgroup's
+    bytes over the launch time, 0.145 for K = 6 where the CU's path carries 0.44 of its fill peak)."""
     w_bytes = 65 * H * H * wbytes     # 67 H^2 weights of the path minus the two constant half-Linears of add_goal / add_latent
                                       # that the rollout prologue hoists (k_fuse_hoist_x); 4 B each as an fp16 pair, 2 B as bf16
     pad = lambda n: (n + 31) // 32 * 32  # noqa: E731
     kv_bytes = 3 * 2 * (pad(n_pl) + n_tl_keys + pad(n_agent)) * H * wbytes
     clk = SHADER_CLK                  # shader clock under this kernel (SQ_BUSY_CYCLES / 32 shader engines / kernel-trace duration)
-    per_clk = (w_bytes + kv_bytes) / (k_us * 1e-6 * clk)
-    return {"bytes_per_workgroup_launch": w_bytes + kv_bytes, "weights": w_bytes, "kv": kv_bytes, "achieved_B_per_clk_per_CU": per_clk,
-            "peak_B_per_clk_per_CU": 64.0, "frac": per_clk / 64.0}
+    wg_per_cu = max(1.0, (n_workgroup or 0) / float(N_CU))
+    per_clk = (w_bytes + kv_bytes) * wg_per_cu / (k_us * 1e-6 * clk)
+    return {"bytes_per_workgroup_launch": w_bytes + kv_bytes, "weights": w_bytes, "kv": kv_bytes,
+            "workgroups_per_launch": n_workgroup, "workgroups_per_cu": wg_per_cu, "bytes_per_cu_launch": (w_bytes + kv_bytes) * wg_per_cu,
+            "achieved_B_per_clk_per_CU": per_clk, "peak_B_per_clk_per_CU": 64.0, "frac": per_clk / 64.0,
+            "sustained_B_per_clk_per_CU_microbench": 42.0, "frac_of_sustained": per_clk / 42.0}
+
+
+_STAGE_CACHE = None
+
+
+def stage_constants():
+    """profiles/stage_constants.json (tools/gpu_stage_profile.py on the -DTB_PROFILE build of THIS round's sources): cold start of a
+    launch and the serial chains, in shader cycles; falls back to the round-3 figures (marked) when the file is missing."""
+    global _STAGE_CACHE
+    if _STAGE_CACHE is None:
+        path = os.path.join(ROOT, "profiles", "stage_constants.json")
+        try:
+            r = json.load(open(path))
+            _STAGE_CACHE = {"cold_cycles": r["cold_start_cycles"], "attention_walks": r["serial_chains_cycles"]["attention_walks"],
+                            "layernorms_21": r["serial_chains_cycles"]["layernorms_21"],
+                            "source": "profiles/stage_constants.json (this round's -DTB_PROFILE build, src_sha256 " + r["src_sha256"][:12] + ")"}
+        except Exception:
+            _STAGE_CACHE = {"cold_cycles": 13000.0, "attention_walks": 35000.0, "layernorms_21": 27000.0,
+                            "source": "profiles/r03_stage_profile_k_step_x.txt (ROUND 3 constants: no stage profile of this build found)"}
+    return _STAGE_CACHE
 
 
 def structural_floor(k_us, n_agent, n_pl, n_tl_keys, wbytes=4, flops=None):
@@ -97,14 +137,16 @@ def structural_floor(k_us, n_agent, n_pl, n_tl_keys, wbytes=4, flops=None):
     measured launch sits above this floor; `frac_of_nominal_roof_at_floor` is the SURVEY 8(d) fraction the launch would show AT it."""
     lp = load_path(k_us, n_agent, n_pl, n_tl_keys, wbytes)
     by = lp["bytes_per_workgroup_launch"]
+    sc = stage_constants()
     peak_us = by / 64.0 / SHADER_CLK * 1e6
     sust_us = by / 42.0 / SHADER_CLK * 1e6
-    cold_us = 13000.0 / SHADER_CLK * 1e6
+    cold_us = sc["cold_cycles"] / SHADER_CLK * 1e6
     floor = sust_us + cold_us
     r = {"weight_and_kv_bytes_per_workgroup": by, "stream_us_at_64B_per_clk": peak_us, "stream_us_at_42B_per_clk_sustained": sust_us,
          "cold_start_us": cold_us, "floor_us": floor, "avg_launch_us": k_us, "launch_over_floor": k_us / floor,
-         "serial_chains_us_measured": {"attention_walks": 35000.0 / SHADER_CLK * 1e6, "layernorms_21": 27000.0 / SHADER_CLK * 1e6,
-                                       "source": "profiles/r03_stage_profile_k_step_x.txt (cycles at 2.33 GHz; they overlap the stream only in part)"}}
+         "serial_chains_us_measured": {"attention_walks": sc["attention_walks"] / SHADER_CLK * 1e6, "layernorms_21": sc["layernorms_21"] / SHADER_CLK * 1e6,
+                                       "source": sc["source"] + " (cycles at 2.33 GHz; they overlap the stream only in part)"},
+         "weight_stationary_floor": weight_stationary_floor()}
     if flops:
         r["frac_of_nominal_roof_at_floor"] = flops / (floor * 1e-6) / 1e12 / PEAK_FP32_MFMA_TFLOPS
     return r
@@ -129,16 +171,29 @@ def xdl_pipe(n_mfma_per_wave, n_workgroup, k_us):
             "frac": fl / (k_us * 1e-6) / 1e12 / PEAK_BF16_MFMA_TFLOPS}
 
 
+def weight_stationary_floor():
+    """Second floor line (VERDICT r05 task 5): a weight-stationary variant of the GEMM chain -- the otherwise idle CUs keep the weight
+    units resident in LDS and serve [16 x 128] activation tiles handed over through L2 -- priced by tools/microtests/ws_hop.hip
+    (profiles/r06_microbench_ws_hop.txt -> profiles/ws_hop.json).  None until that micro-benchmark has run on this build's box."""
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", "ws_hop.json")))
+    except Exception:
+        return None
+
+
 def what_binds(mfma_busy, hbm_frac, xdl_frac, load_frac):
-    """`roofline.bound` from measurement, not from the formulation: "hbm" / "mfma" only when that resource is actually busy; below
-    30 % of both (matrix pipe busy share of the wave-resident SIMD time, or the executed share of the XDL peak when no PMC pass
-    matches this build; HBM-side bytes over the launch time) the launch is bound by its dependent-instruction chains in series with
-    the per-CU vector-load path (`load_path`)."""
+    """`roofline.bound` from measurement, not from the formulation: "hbm" / "mfma" / "load-path" only when that resource is actually
+    busy -- at least 30 % of its peak (matrix pipe busy share of the wave-resident SIMD time, or the executed share of the XDL peak
+    when no PMC pass matches this build; HBM-side bytes over the launch time; the per-CU vector-load path against the 64 B/clk an L1
+    can fill, workgroups per CU counted: `load_path`).  Below 30 % of all three the launch is bound by its dependent-instruction
+    chains in series with the per-CU vector-load path."""
     busy = mfma_busy if mfma_busy is not None else xdl_frac
     hbm = hbm_frac if hbm_frac is not None else 0.0
-    if busy < 0.30 and hbm < 0.30:
+    load = load_frac or 0.0
+    if busy < 0.30 and hbm < 0.30 and load < 0.30:
         return "latency/load-path"
-    return "hbm" if hbm >= busy else "mfma"
+    top = max(busy, hbm, load)
+    return "load-path" if top == load else ("hbm" if top == hbm else "mfma")
 
 
 def usable_cpus() -> int:
@@ -435,7 +490,7 @@ def sub_roofline(spec, c, fl, by, tf, gbs, k_us, n_inst, pmc):
     fp32 = spec["prec"] == "fp32"
     n_wg = n_inst * ((spec["a"] + 15) // 16)
     xdl = xdl_pipe(mfma_issue(spec["a"], spec["p"], c["tl_keys_eff"], 2 if fp32 else 1), n_wg, k_us)
-    lp = load_path(k_us, spec["a"], spec["p"], c["tl_keys_eff"], 4 if fp32 else 2)
+    lp = load_path(k_us, spec["a"], spec["p"], c["tl_keys_eff"], 4 if fp32 else 2, n_wg)
     traffic = (pmc or {}).get("fetch_bytes_per_launch")
     hbm_frac = (traffic / (k_us * 1e-6) / 1e9 / PEAK_HBM_GBS) if traffic else gbs / PEAK_HBM_GBS
     r = {"bound": what_binds((pmc or {}).get("mfma_busy"), hbm_frac, xdl["frac"], lp["frac"]),
@@ -600,22 +655,14 @@ def run_rank(args, rank: int, local_rank: int, world: int) -> None:
             torch.cuda.synchronize()
             return time.perf_counter() - t1
 
-        # The L2 warmers (round 5) keep two helper workgroups per XCD waiting on otherwise idle CUs for the whole launch -- +1.4 % for ONE
-        # rollout in flight, the headline; with a second rollout on another stream those CUs are wanted: this leg runs with the
-        # switch a two-stream caller sets (TB_STEP_WARM=0) and reports the default as well.
-        dt_on = pairs()
-        warm_env = os.environ.get("TB_STEP_WARM")
-        os.environ["TB_STEP_WARM"] = "0"
+        # The L2 warmers keep two helper workgroups per XCD waiting on otherwise idle CUs for the whole launch -- +1.4 % for ONE rollout
+        # in flight, a 15 % loss with a second one.  Since round 6 the library switches them off by itself while another context of
+        # the device is launching (tb_switches.step_l2_warmers = 0: automatic): no environment variable in this leg any more.
         dt2 = pairs()
-        if warm_env is None:
-            os.environ.pop("TB_STEP_WARM")
-        else:
-            os.environ["TB_STEP_WARM"] = warm_env
         two_stream = {"value": 2 * n_pairs * B_PER_GPU * STEP_END / dt2, "unit": "scene-steps/s", "passes": 2 * n_pairs,
                       "identical_results": bool(torch.equal(out["preds"], out2["preds"])),
-                      "value_with_l2_warmers_left_on": 2 * n_pairs * B_PER_GPU * STEP_END / dt_on,
-                      "note": "two independent batches of 32 scenes overlapped on two streams (64 scenes in flight), TB_STEP_WARM=0 (the L2 "
-                              "warmers hold CUs a second stream wants); not the headline value"}
+                      "note": "two independent batches of 32 scenes overlapped on two streams / two contexts (64 scenes in flight); the L2 "
+                              "warmers switch themselves off while a second context is active; not the headline value"}
         del eng2
 
     # ---- metric partials + the one collective of the path (torchmetrics dist_reduce_fx="sum" states in the reference)
@@ -666,6 +713,7 @@ def run_rank(args, rank: int, local_rank: int, world: int) -> None:
         planes = 2 if prec == "fp32" else 1
         # matrix-pipe occupancy from the kernel's structure and the measured launch time: MFMAs per wave x issue interval / launch cycles
         n_mfma = mfma_issue(N_AGENT, N_PL, tl_keys_eff, planes)
+        n_wg_head = B_PER_GPU * ((N_AGENT + 15) // 16)
         clk = SHADER_CLK
         mfma_busy_est = n_mfma * 16.0 / (k_us * 1e-6 * clk)
         pmc = _pmc_records().get(prec) if _pmc_records().get("_matches_build") else None
@@ -713,14 +761,15 @@ def run_rank(args, rank: int, local_rank: int, world: int) -> None:
                           "note": "per rollout: n_fused fused launches; edge_launches_ms = the batched warm-start launch (A halves of the "
                                   "teacher-forced steps, k_step_x<true>), their C-only launches and the last step's"},
             "roofline": {"bound": what_binds((pmc or {}).get("mfma_busy"), (traffic / (k_us * 1e-6) / 1e9 / PEAK_HBM_GBS) if traffic else None,
-                                             xdl_pipe(n_mfma, B_PER_GPU * ((N_AGENT + 15) // 16), k_us)["frac"], 0.0),
+                                             xdl_pipe(n_mfma, B_PER_GPU * ((N_AGENT + 15) // 16), k_us)["frac"],
+                                             load_path(k_us, N_AGENT, N_PL, tl_keys_eff, 4 if prec == "fp32" else 2, n_wg_head)["frac"]),
                          "bound_how": "from measurement (bench.py::what_binds): matrix pipe busy share and HBM share both below 30 % -> the "
                                       "launch is bound by dependent-instruction chains in series with the per-CU vector-load path; `frac` "
                                       "below stays the SURVEY 8(d) figure (algorithmic fp32 flops over the fp32-MFMA peak of the fp32 "
                                       "formulation), `xdl_pipe_frac` / `load_path_frac` / `hbm` are the fractions of what executes",
                          "xdl_pipe": xdl_pipe(n_mfma, B_PER_GPU * ((N_AGENT + 15) // 16), k_us),
                          "xdl_pipe_frac": xdl_pipe(n_mfma, B_PER_GPU * ((N_AGENT + 15) // 16), k_us)["frac"],
-                         "load_path_frac": load_path(k_us, N_AGENT, N_PL, tl_keys_eff, 4 if prec == "fp32" else 2)["frac"],
+                         "load_path_frac": load_path(k_us, N_AGENT, N_PL, tl_keys_eff, 4 if prec == "fp32" else 2, n_wg_head)["frac"],
                          "kernel": "tb::xh::k_step_x<false, false> (PRE = LEAN = false: the fused C(t)+A(t+1) launch of a simulation step)", "achieved": achieved,
                          "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
                          "traffic": traffic,
@@ -742,7 +791,7 @@ def run_rank(args, rank: int, local_rank: int, world: int) -> None:
                              "measured": (pmc or {}).get("mfma_busy"),
                              "measured_how": (pmc or {}).get("mfma_busy_how"),
                          },
-                         "load_path": load_path(k_us, N_AGENT, N_PL, tl_keys_eff, 4 if prec == "fp32" else 2),
+                         "load_path": load_path(k_us, N_AGENT, N_PL, tl_keys_eff, 4 if prec == "fp32" else 2, n_wg_head),
                          "floor": structural_floor(k_us, N_AGENT, N_PL, tl_keys_eff, 4 if prec == "fp32" else 2, fl),
                          "floor_us": structural_floor(k_us, N_AGENT, N_PL, tl_keys_eff, 4 if prec == "fp32" else 2, fl)["floor_us"],
                          "hbm": ({"achieved": traffic / (k_us * 1e-6) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
@@ -751,13 +800,19 @@ def run_rank(args, rank: int, local_rank: int, world: int) -> None:
                                   "note": "measured FETCH bytes per launch / launch time: the launch is not HBM-bound"}
                                  if traffic else None)},
             "encode_roofline": {
-                "flops_per_scene": flops_encode(N_AGENT, N_PL), "flops_per_call": flops_encode(N_AGENT, N_PL) * B_PER_GPU,
-                "encode_ms": encode_ms, "achieved": flops_encode(N_AGENT, N_PL) * B_PER_GPU / (encode_ms * 1e-3) / 1e12,
-                "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": flops_encode(N_AGENT, N_PL) * B_PER_GPU / (encode_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
-                "dominant_kernel": (pmc or {}).get("encode_dominant_kernel", "tb::xh::k_polyline_fused (map densetnt block + node pooling, two polylines per workgroup)"),
-                "note": "SURVEY 8(d): F_map + F_dest + F_latent_prior per scene x 32 scenes / host-timed tb_encode_scene (all its launches, "
-                        "one synchronize); one-time per batch, not part of `value`"},
+                "pipe": "XDL MFMA 16x16x32 f16 (fp16-pair operands: 3 MFMAs per algorithmic product), dense peak 2.5 PFLOP/s",
+                "executed_flops_per_call": flops_encode_executed(N_AGENT, N_PL) * B_PER_GPU,
+                "encode_ms": encode_ms, "achieved": flops_encode_executed(N_AGENT, N_PL) * B_PER_GPU / (encode_ms * 1e-3) / 1e12,
+                "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
+                "frac": flops_encode_executed(N_AGENT, N_PL) * B_PER_GPU / (encode_ms * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS,
+                "frac_how": "hoisted flops (the destination predictor's first Linear once per agent and per polyline) x 3 fp16 MFMAs per "
+                            "product, over the host-timed synchronous call, against the pipe these kernels run on",
+                "frac_nominal": flops_encode(N_AGENT, N_PL) * B_PER_GPU / (encode_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+                "frac_nominal_how": "SURVEY 8(d)'s UN-hoisted algorithmic flops over the fp32-MFMA peak of the fp32 formulation (a pipe "
+                                    "these kernels do not run on): kept for continuity with earlier rounds, NOT a utilisation figure",
+                "flops_per_scene_nominal": flops_encode(N_AGENT, N_PL),
+                "dominant_kernel": (pmc or {}).get("encode_dominant_kernel", "tb::xh::k_polyline_fused8<true> (map densetnt block + node pooling, two polylines per workgroup)"),
+                "note": "one-time per batch, not part of `value`; host-timed tb_encode_scene (all its launches, one synchronize)"},
             "max_abs_traj_err": None,
             "checks": dict(finite=finite, **red),
             "reference_metric_states": dict(ref_metrics, note="sum-states of the reference's TrafficRuleMetrics / ErrorMetrics over all ranks "
@@ -766,6 +821,24 @@ def run_rank(args, rank: int, local_rank: int, world: int) -> None:
             "two_batches_in_flight": two_stream,
             "configs": configs,
         }
+        if isinstance(configs.get("fp32_exact"), dict) and configs["fp32_exact"].get("value"):
+            # the strict-IEEE-fp32-arithmetic number of the same workload, next to `dtype` (VERDICT r05 task 3)
+            line["value_fp32_exact"] = configs["fp32_exact"]["value"]
+            line["value_fp32_exact_note"] = "the headline workload on the exact-fp32 kernels (fp32 MFMA 16x16x4 operands): configs.fp32_exact"
+        if world == 1 and not args.lean and not args.no_e2e:
+            try:
+                from tools import e2e_bench
+
+                line["e2e"] = e2e_bench.measure(sd, dev)
+                e = line["e2e"]["headline_k1"]
+                budget = 1.10 * (line["ms_per_step"] + encode_ms)
+                line["e2e"]["target"] = {"rule": "test_step at the headline shape <= 1.10 x (ms_per_step + encode_ms) per batch (VERDICT r05 task 1)",
+                                         "budget_ms": budget, "plain_ms": e["plain"]["ms_per_batch"], "met_by_plain_calls": e["plain"]["ms_per_batch"] <= budget,
+                                         "prefetch_ms": e["prefetch"]["ms_per_batch"], "pipeline_2_lanes_ms": e["pipeline_2_lanes"]["ms_per_batch"],
+                                         "best_over_kernel_only": value / max(e["plain"]["scene_steps_per_s"], e["prefetch"]["scene_steps_per_s"],
+                                                                              e["pipeline_2_lanes"]["scene_steps_per_s"])}
+            except Exception as e_:
+                line["e2e"] = {"error": f"{type(e_).__name__}: {e_}"[:300]}
         if not args.lean:
             try:
                 line["max_abs_traj_err"] = golden_traj_err(sd, dev)
@@ -814,6 +887,7 @@ def parse_args(argv=None):
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end test_step block (`e2e`)")
     ap.add_argument("--sustain-seconds", type=float, default=None,
                     help="back-to-back rollouts after the timed region, outside `value` (default 12 s; 0 with --lean)")
     ap.add_argument("--lean", action="store_true", help="headline only: no sub-records, no golden error, no two-stream leg, no 1-thread CPU leg")

@@ -27,6 +27,32 @@ extern "C" {
 typedef struct tb_ctx tb_ctx;
 typedef void* tb_stream; /* hipStream_t */
 
+/* Launch-shaping switches of the library (round 6: these used to be environment variables only).  Every field: 0 = automatic, the
+ * default and the validated choice; the other values are A/B and debugging aids -- results are bit-identical across every setting
+ * except where noted.  The environment variable named beside a field still works as a DEBUGGING OVERRIDE and wins when set. */
+typedef struct tb_switches {
+    int32_t step_helpers;     /* helper workgroups on the idle CUs of launches of <= 128 tiles (interaction K / V, W_hh h): 1 = off
+                               *   [TB_STEP_HELPERS=0] */
+    int32_t step_l2_warmers;  /* L2 warmers on the helper CUs (+1.4 % for ONE rollout in flight, a loss when another context's work
+                               *   wants those CUs): 0 = on while no other context of this device has launched work in the last
+                               *   100 ms, 1 = off, 2 = on regardless   [TB_STEP_WARM=0 | 1] */
+    int32_t step_pre_inter;   /* interaction blocks of the teacher-forced steps as one batched launch: 1 = off   [TB_STEP_PRE_INTER=0] */
+    int32_t step_w3;          /* bf16: three-workgroups-per-CU carve for launches of > 512 tiles: 1 = off   [TB_STEP_W3=0] */
+    int32_t step_aw;          /* bf16: assist-wave carve for 129..256-tile launches over >= 512 polylines (another summation order
+                               *   of the same softmax: deterministic, not bit-equal to the four-wave kernel): 1 = off, 2 = forced for
+                               *   launches of any size up to 256 tiles (test switch)   [TB_STEP_AW=0 | 2] */
+    int32_t step_lean;        /* two-workgroups-per-CU carve for launches of > 256 tiles: 1 = off   [TB_STEP_LEAN=0] */
+    int32_t rollout_graph;    /* one hipGraph per repeated rollout argument set: 1 = off (plain launches)   [TB_ROLLOUT_GRAPH=0] */
+    int32_t encode_pack;      /* map encoder's polyline block: 0 = the eight-wave fused kernel with merged phases; 1..5 = the older
+                               *   tilings TB_ENCODE_PACK = 0..4 (value - 1)   [TB_ENCODE_PACK] */
+    int32_t encode_side;      /* agent / traffic-light tokens and the destination GRU on the library's side stream: 1 = off
+                               *   [TB_ENCODE_SIDE=0] */
+    int32_t encode_dest_side; /* destination predictor beside the personality branch: 1 = off   [TB_ENCODE_DEST_SIDE=0] */
+    int32_t dest_lds_pad;     /* LDS padding (bytes) of the destination-pair kernel when it runs beside the personality branch:
+                               *   0 = 30000, -1 = none   [TB_DEST_LDS_PAD] */
+    int32_t reserved[5];      /* must be 0 */
+} tb_switches;
+
 /* Scalar config the kernels need (defaults = configs/model/traffic_bots.yaml of the reference). */
 typedef struct tb_config {
     int32_t time_step_current;   /* 10  (traffic_bots.yaml:5)  */
@@ -41,6 +67,7 @@ typedef struct tb_config {
                                   *    (|x| < 65504): tb_finalize_weights / tb_check_status / tb_precision_state;
                                   * 1: bf16 MFMA operands, fp32 accumulate -- BASELINE.json configs 4/5, no fp32-parity claim;
                                   * 2: exact fp32 from the start (fp32 MFMA kernels: fp32's range, about 2x slower per step) */
+    tb_switches sw;              /* launch-shaping switches; all zero = automatic */
 } tb_config;
 
 /* -- lifecycle ----------------------------------------------------------------------------------- */

@@ -753,3 +753,50 @@ def test_staged_and_prefetched_steps_equal_the_device_side_conversion():
                     assert torch.equal(v, y[part]["pred_dict"][k_]), (part, k_)
         assert torch.equal(x["reactive_replay"]["train_states"], y["reactive_replay"]["train_states"])
         assert torch.equal(x["latent_post"].mean, y["latent_post"].mean)
+
+
+def test_two_lane_pipeline_equals_plain_steps_and_reruns_an_overflowing_batch():
+    """`wm.pipeline(loader, lanes=2)`: consecutive batches on two contexts / streams, results in order.  (1) Bit-identical to plain
+    `test_step` calls over a stream of distinct batches (K = 2, drawn destinations; the L2 warmers switch themselves off while the
+    second context is active -- hints, no numerical effect).  (2) Nothing unchecked leaves the iterator: with weights scaled so that
+    an activation leaves the fp16-pair range, every batch comes out re-run on the exact-fp32 kernels (finite, equal to a plain
+    checked call) and the pipeline counts the re-runs."""
+    import warnings
+
+    from trafficbots_amd import synth
+
+    sd = synth.make_state_dict(5)
+    scene = dict(n_agent=20, n_pl=50, n_tl=12, p_late_spawn=0.3, p_invalid_agent=0.2, pos_range=140.0)
+    batches = [synth.make_batch(8800 + i, 3, **scene) for i in range(7)]
+    k, step_end = 2, 30
+    eps = torch.from_numpy(synth.make_latent_noise(5, 3 * k, 20)).cuda()
+    wm = _engine({"time_step_end": step_end, "n_joint_future": k}, sd)
+    kw = lambda i: dict(latent_eps=eps, generator=torch.Generator(device="cuda").manual_seed(300 + i))  # noqa: E731
+    ref = [wm.test_step(b, **kw(i)) for i, b in enumerate(batches)]
+    pipe = wm.pipeline(batches, lanes=2, kwargs_fn=kw)
+    got = list(pipe)
+    torch.cuda.synchronize()
+    assert len(got) == len(batches) and pipe.n_reruns == 0
+    for i in range(len(batches)):
+        _same_step_outputs(ref[i], got[i], f"lane pipeline {i}")
+    got3 = list(wm.pipeline(batches, lanes=3, kwargs_fn=kw))
+    torch.cuda.synchronize()
+    for i in range(len(batches)):
+        _same_step_outputs(ref[i], got3[i], f"three lanes {i}")
+    # ---- (2) an overflow inside the pipeline
+    big = _scaled(sd, 3e5)  # (the as2pl FFN hidden activations leave the fp16-pair range: test_fp16_pair_operand_range's "flag" case)
+    probe = _engine({"time_step_end": 12, "n_joint_future": 1}, big)
+    with warnings.catch_warnings(record=True) as wlist:
+        warnings.simplefilter("always")
+        plain = probe.test_step(batches[0])
+    if not any("exact-fp32" in str(w.message) for w in wlist):
+        pytest.skip("the scaled weights did not trip the range guard on this build")
+    wm2 = _engine({"time_step_end": 12, "n_joint_future": 1}, big)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        pipe2 = wm2.pipeline(batches[:4], lanes=2)
+        outs = list(pipe2)
+    torch.cuda.synchronize()
+    assert pipe2.n_reruns >= 1
+    assert all(torch.isfinite(o["rollout_buffer"].preds).all() for o in outs)
+    assert torch.equal(outs[0]["rollout_buffer"].preds, plain["rollout_buffer"].preds)

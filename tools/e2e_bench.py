@@ -37,6 +37,20 @@ def _loop(wm, batches: List, n: int, prefetch: bool) -> float:
     return (time.perf_counter() - t0) / n * 1e3
 
 
+def _loop_lanes(wm, batches: List, n: int, lanes: int) -> float:
+    """ms per batch through `wm.pipeline(stream, lanes)` (results consumed in order, each range-checked before it is handed out)."""
+    stream = [batches[i % len(batches)] for i in range(n + 2 * lanes)]
+    it = iter(wm.pipeline(stream, lanes=lanes))
+    for _ in range(2 * lanes):
+        next(it)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in it:
+        pass
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n * 1e3
+
+
 def _stages(wm, batches: List, n: int = 10) -> Dict[str, Dict[str, float]]:
     """Per-stage time of `test_step`, each stage run n times on rotating batches: `host_ms` = until the call returns (enqueue cost),
     `ms` = until the GPU has finished it (stage run alone, back to back)."""
@@ -108,6 +122,9 @@ def _case(sd, dev, k: int, batches: List, n: int, scenes: int, step_end: int = 9
         ms = _loop(wm, batches, n, pre)
         rec[name] = {"ms_per_batch": ms, "scene_steps_per_s": scenes * step_end * k / (ms * 1e-3)}
     wm.check_range = True
+    for lanes in (2, 3):
+        ms = _loop_lanes(wm, batches, 2 * n, lanes)
+        rec[f"pipeline_{lanes}_lanes"] = {"ms_per_batch": ms, "scene_steps_per_s": scenes * step_end * k / (ms * 1e-3)}
     rec["range_check_cost_ms"] = rec["plain"]["ms_per_batch"] - rec["plain_no_range_check"]["ms_per_batch"]
     if stages:
         wm.check_range = False
@@ -135,7 +152,9 @@ def measure(sd, dev, n: int = 12, womd: bool = True) -> Dict:
     t_all = time.perf_counter()
     out: Dict = {"what": "WaymoMotion.test_step(batch) end to end, fresh host batch per call (4 distinct numpy batches in rotation); "
                          "plain = one call after the other, prefetch = `for sb in wm.prefetch(loader): wm.test_step(sb)` (next batch "
-                         "staged + encoded on a side stream under the current rollout); ms per 32-scene batch",
+                         "staged + encoded on a side stream under the current rollout), pipeline_N_lanes = `for out in "
+                         "wm.pipeline(loader, lanes=N)` (consecutive batches on N contexts / streams, results in order and "
+                         "range-checked); ms per 32-scene batch",
                  "unit": "ms per batch; scene-steps/s"}
     batches = [synth.make_batch(5000 + 37 * i, 32, n_agent=64, n_pl=256, n_tl=40) for i in range(4)]
     out["headline_k1"] = _case(sd, dev, 1, batches, n, 32, stages=True)
@@ -182,6 +201,15 @@ def measure(sd, dev, n: int = 12, womd: bool = True) -> Dict:
                     torch.cuda.synchronize()
                     ms = (time.perf_counter() - t0) / nb * 1e3
                     rec[name] = {"ms_per_batch": ms, "scene_steps_per_s": 32 * 90 / (ms * 1e-3), "batches": nb}
+                it = iter(wm.pipeline(Epochs(loader, n_ep + 2), lanes=2))
+                for _ in range(4):
+                    next(it)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                nb = sum(1 for _ in it)
+                torch.cuda.synchronize()
+                ms = (time.perf_counter() - t0) / nb * 1e3
+                rec["pipeline_2_lanes"] = {"ms_per_batch": ms, "scene_steps_per_s": 32 * 90 / (ms * 1e-3), "batches": nb}
                 t0 = time.perf_counter()
                 nb = sum(1 for _ in Epochs(loader, 2))
                 rec["loader_alone_ms_per_batch"] = (time.perf_counter() - t0) / nb * 1e3

@@ -93,3 +93,32 @@ if os.environ.get("TB_STEP_AW", "1") != "0" and a * b // 16 > 128 and p >= 512 a
     # the assist carve (tb::xba): stamp 25 = the main wave's own half of the walk is done (in front of the merge barrier)
     v, w = st[:, 25] - st[:, 18], st[:, 19] - st[:, 25]
     print(f"    as2pl[0]/assist carve: main wave 0's own blocks {np.median(v):8.0f} [{v.min():7.0f} .. {v.max():7.0f}]; merge barrier + merge {np.median(w):8.0f} [{w.min():7.0f} .. {w.max():7.0f}]")
+
+# ---- machine-readable constants for bench.py::structural_floor (the floor used round-3 numbers)
+if os.environ.get("TB_STAGE_JSON"):
+    import json
+
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as ge
+
+    med = lambda v: float(np.median(v))  # noqa: E731
+    rec = {
+        "what": "s_memtime cycles of one fused k_step_x launch, -DTB_PROFILE build of the sources with this fingerprint (medians over workgroups)",
+        "src_sha256": ge.build_fingerprint(), "precision": os.environ.get("TB_PRECISION", "fp32"), "shape": {"B": b, "K": k, "A": a, "P": p, "T": t},
+        "workgroups": int(n_blocks),
+        "c_half": {NAMES[i]: med(d_c[:, i]) for i in range(7)},
+        "a_half": {NAMES[8 + i]: med(d_a[:, i]) for i in range(3)},
+        "a_front_end": med(st[:, 8] - st[:, 30]),
+        "cold_start_cycles": med(d_c[:, 0]),
+        "as2pl0": {lab[i]: med(st[:, 17 + i] - st[:, 16 + i]) for i in range(8)},
+        "sum_of_medians": float(tot),
+    }
+    # the serial chains the weight stream cannot hide: the attention walks (as2pl layer 0's walk x 3 layers, scaled by keys for the
+    # traffic-light and interaction walks) and the 21 LayerNorms (as2pl layer 0's two)
+    walk = rec["as2pl0"]["attention 256 keys (8 x 32 MFMA)"]
+    rec["serial_chains_cycles"] = {"attention_walks": 3 * walk + 3 * walk * (32.0 / p) * 2 + 3 * walk * (a / p),
+                                   "layernorms_21": 21 * 0.5 * (rec["as2pl0"]["LN1 + barrier"] + rec["as2pl0"]["LN2 + barrier"]),
+                                   "how": "3 map walks measured on as2pl[0]; traffic-light / interaction walks scaled by their key counts; 21 LayerNorms at the mean of as2pl[0]'s two"}
+    with open(os.environ["TB_STAGE_JSON"], "w") as f:
+        json.dump(rec, f, indent=1)
+    print("wrote", os.environ["TB_STAGE_JSON"])

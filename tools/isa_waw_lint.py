@@ -1,0 +1,289 @@
+"""Static hazard lint of the gfx950 machine code of the library (toolchain canary; VERDICT r05 task 2).
+
+Background (profiles/r05_experiments.txt item 24): built with the default machine scheduler, `k_step_x<false, false>` dies with a GPU
+memory fault -- a VGPR that is the destination of a weight-fragment `global_load` still IN FLIGHT is overwritten by a later VALU
+instruction without an `s_waitcnt vmcnt` in between (the load's data then lands on top of the new value: the lane offset of the next
+requests turns into weight bits).  That is a wait-count insertion bug of the compiler under that schedule, not an address the source
+computes; the shipped flag set (`-amdgpu-sched-strategy=max-ilp`) does not trigger it.  Whether a given toolchain + flag set does is
+visible in the machine code WITHOUT running it:
+
+  on gfx9-family hardware vector-memory operations complete in issue order and `s_waitcnt vmcnt(N)` waits until at most N are
+  outstanding; so, walking a kernel's instructions along its control-flow graph with the queue of outstanding vector-memory operations
+  (destination registers per entry), an instruction that WRITES or READS a register some still-outstanding load will write is a hazard.
+
+This script disassembles the device code of every object (or of the built library), runs that dataflow per kernel (fixed point over
+basic blocks, queues merged from the most recent entry backwards), and reports hazards.  `__graft_entry__.build()` runs it on the step
+and encoder kernels and refuses to ship a library with a hazard; tests/test_abi_and_host.py checks that the lint FINDS the planted
+hazard of the default-scheduler build of the fragment in tools/microtests/waw_case.s and passes the fixed form.
+
+usage: python tools/isa_waw_lint.py [objects or .so ...]      (default: trafficbots_amd/csrc/build/*.o)
+"""
+from __future__ import annotations
+
+import glob
+import os
+import re
+import subprocess
+import sys
+import tempfile
+from typing import Dict, List, Optional, Set, Tuple
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LLVM = os.environ.get("TB_LLVM_BIN", "/opt/rocm/lib/llvm/bin")
+TARGET = "hipv4-amdgcn-amd-amdhsa--gfx950"
+MAX_Q = 96  # queue entries kept per state (vmcnt is a 6-bit counter: 63 outstanding at most)
+
+_REG = re.compile(r"\b([va])(\d+)\b|\b([va])\[(\d+):(\d+)\]")
+_VMEM_LOAD = re.compile(r"^(global_load|buffer_load|flat_load|scratch_load|tbuffer_load|global_atomic|buffer_atomic|flat_atomic|image_load|image_sample)")
+_VMEM_STORE = re.compile(r"^(global_store|buffer_store|flat_store|scratch_store|tbuffer_store|image_store)")
+_BRANCH = re.compile(r"^s_c?branch")
+
+
+def regs(text: str) -> Set[Tuple[str, int]]:
+    out: Set[Tuple[str, int]] = set()
+    for m in _REG.finditer(text):
+        if m.group(1):
+            out.add((m.group(1), int(m.group(2))))
+        else:
+            out.update((m.group(3), i) for i in range(int(m.group(4)), int(m.group(5)) + 1))
+    return out
+
+
+class Ins:
+    __slots__ = ("addr", "op", "dst", "src", "kind", "vmcnt", "target", "text")
+
+    def __init__(self, addr: int, text: str) -> None:
+        self.addr, self.text = addr, text
+        parts = text.split(None, 1)
+        self.op = parts[0]
+        ops = [o.strip() for o in parts[1].split(",")] if len(parts) > 1 else []
+        self.kind, self.vmcnt, self.target = "other", None, None
+        self.dst: Set[Tuple[str, int]] = set()
+        self.src: Set[Tuple[str, int]] = set()
+        if self.op == "s_waitcnt":
+            m = re.search(r"vmcnt\((\d+)\)", text)
+            self.kind = "wait"
+            self.vmcnt = int(m.group(1)) if m else None  # None: the vmcnt field is at its maximum (no wait on it)
+            return
+        if _BRANCH.match(self.op) or self.op in ("s_endpgm", "s_setpc_b64", "s_swappc_b64"):
+            self.kind = "branch"
+            return
+        if _VMEM_LOAD.match(self.op):
+            self.kind = "vmem"
+            to_lds = " lds" in (" " + text)
+            returns = not self.op.startswith(("global_atomic", "buffer_atomic", "flat_atomic")) or " glc" in text or " sc0" in text
+            if ops and not to_lds and returns:
+                self.dst = regs(ops[0])
+                self.src = set().union(*[regs(o) for o in ops[1:]]) if len(ops) > 1 else set()
+            else:
+                self.src = set().union(*[regs(o) for o in ops]) if ops else set()
+            return
+        if _VMEM_STORE.match(self.op):
+            self.kind = "vmem"
+            self.src = set().union(*[regs(o) for o in ops]) if ops else set()
+            return
+        # everything else: the first operand is the destination when it is a vector register (VALU, MFMA, ds_read, v_readlane -> SGPR ...);
+        # instructions without a vector destination (ds_write, v_cmp to vcc / SGPRs, s_*) only read
+        no_dst = self.op.startswith(("ds_write", "ds_store", "v_cmp_", "v_cmpx_", "s_", "ds_append", "ds_gws", "buffer_wbl2", "buffer_inv"))
+        if ops and not no_dst:
+            self.dst = regs(ops[0])
+            self.src = set().union(*[regs(o) for o in ops[1:]]) if len(ops) > 1 else set()
+            if self.op.startswith(("v_mac_", "v_fmac_", "v_dot", "v_pk_fmac")) or "mfma" in self.op and len(ops) >= 4:
+                self.src |= regs(ops[-1]) if "mfma" in self.op else self.dst  # accumulating forms read their destination
+        else:
+            self.src = set().union(*[regs(o) for o in ops]) if ops else set()
+
+
+def device_code(path: str, workdir: str) -> List[str]:
+    """Extract the gfx950 code object(s) of a host object / shared library and return their disassembly lines."""
+    fat = os.path.join(workdir, os.path.basename(path) + ".fat")
+    r = subprocess.run([f"{LLVM}/llvm-objcopy", "--dump-section", f".hip_fatbin={fat}", path, os.path.join(workdir, "unused.o")],
+                       capture_output=True, text=True)
+    if r.returncode != 0 or not os.path.exists(fat) or os.path.getsize(fat) == 0:
+        return []
+    lines: List[str] = []
+    data = open(fat, "rb").read()
+    magic = b"__CLANG_OFFLOAD_BUNDLE__"
+    starts = [m.start() for m in re.finditer(re.escape(magic), data)]
+    for n, s in enumerate(starts):  # a linked library holds one bundle per translation unit, back to back
+        e = starts[n + 1] if n + 1 < len(starts) else len(data)
+        one = f"{fat}.{n}"
+        open(one, "wb").write(data[s:e])
+        co = f"{one}.co"
+        r = subprocess.run([f"{LLVM}/clang-offload-bundler", "--unbundle", "--type=o", f"--input={one}", f"--targets={TARGET}", f"--output={co}"],
+                           capture_output=True, text=True)
+        if r.returncode != 0 or not os.path.exists(co):
+            continue
+        d = subprocess.run([f"{LLVM}/llvm-objdump", "-d", "--no-show-raw-insn", co], capture_output=True, text=True)
+        lines += d.stdout.splitlines()
+    return lines
+
+
+def parse_asm_text(lines: List[str]) -> Dict[str, List[Ins]]:
+    """Kernels of a `clang -S` assembly listing (labels instead of addresses): label -> pseudo address = instruction index."""
+    fn: Dict[str, List[Tuple[str, Optional[str]]]] = {}
+    cur, pending = None, []
+    labels: Dict[str, Dict[str, int]] = {}
+    for ln in lines:
+        t = ln.split(";")[0].split("//")[0].rstrip()
+        if not t.strip():
+            continue
+        m = re.match(r"^([A-Za-z_.$][\w.$]*):\s*$", t)
+        if m:
+            name = m.group(1)
+            if not name.startswith(".L"):
+                cur = name
+                fn[cur], labels[cur] = [], {}
+            elif cur is not None:
+                labels[cur][name] = len(fn[cur])
+            continue
+        if cur is None or t.lstrip().startswith("."):
+            continue
+        fn[cur].append(t.strip())
+    out: Dict[str, List[Ins]] = {}
+    for name, body in fn.items():
+        if not body:
+            continue
+        ins = []
+        for i, t in enumerate(body):
+            x = Ins(i, t)
+            if x.kind == "branch":
+                m = re.search(r"(\.L[\w.$]+)", t)
+                if m and m.group(1) in labels[name]:
+                    x.target = labels[name][m.group(1)]
+            ins.append(x)
+        out[name] = ins
+    return out
+
+
+def parse_objdump(lines: List[str]) -> Dict[str, List[Ins]]:
+    out: Dict[str, List[Ins]] = {}
+    cur = None
+    for ln in lines:
+        m = re.match(r"^[0-9a-f]+ <(.+)>:$", ln.strip())
+        if m:
+            cur = m.group(1)
+            out[cur] = []
+            continue
+        m = re.match(r"^\s+(\S.*?)\s*//\s*([0-9A-Fa-f]+):", ln)
+        if m and cur is not None:
+            x = Ins(int(m.group(2), 16), m.group(1).strip())
+            if x.kind == "branch":
+                t = re.search(r"<.+\+0x([0-9a-fA-F]+)>", ln)
+                base = out[cur][0].addr if out[cur] else x.addr
+                if t:
+                    x.target = base + int(t.group(1), 16)
+                elif re.search(r"<[^+>]+>\s*$", ln):
+                    x.target = base
+            out[cur].append(x)
+    return {k: v for k, v in out.items() if v}
+
+
+def lint_kernel(ins: List[Ins]) -> List[str]:
+    """Fixed point over basic blocks; state = tuple of frozensets (outstanding vector-memory destinations, oldest first)."""
+    index = {x.addr: i for i, x in enumerate(ins)}
+    leaders = {0}
+    for i, x in enumerate(ins):
+        if x.kind == "branch":
+            if x.target is not None and x.target in index:
+                leaders.add(index[x.target])
+            if i + 1 < len(ins):
+                leaders.add(i + 1)
+    order = sorted(leaders)
+    block_end = {b: (order[n + 1] if n + 1 < len(order) else len(ins)) for n, b in enumerate(order)}
+    state_in: Dict[int, Optional[Tuple[frozenset, ...]]] = {b: None for b in order}
+    state_in[0] = ()
+    hazards: Dict[int, str] = {}
+
+    def merge(a, b):
+        if a is None:
+            return b
+        n = max(len(a), len(b))
+        pa, pb = (frozenset(),) * (n - len(a)) + a, (frozenset(),) * (n - len(b)) + b
+        return tuple(x | y for x, y in zip(pa, pb))
+
+    work = [0]
+    rounds = 0
+    while work and rounds < 20000:
+        rounds += 1
+        b = work.pop()
+        q = list(state_in[b])
+        i = b
+        succ = []
+        while i < block_end[b]:
+            x = ins[i]
+            if x.kind == "wait":
+                if x.vmcnt is not None:
+                    q = q[len(q) - x.vmcnt:] if x.vmcnt < len(q) else q
+                    if x.vmcnt == 0:
+                        q = []
+            else:
+                pend = frozenset().union(*q) if q else frozenset()
+                if pend:
+                    # (a LOAD into a register an earlier, still outstanding load will write is not a hazard: vector-memory loads return
+                    # in order, the later data lands last -- the compiler re-uses dead load destinations that way)
+                    w = (x.dst & pend) if x.kind != "vmem" else frozenset()
+                    r = x.src & pend
+                    if w or r:
+                        what = ("WRITES " + _fmt(w) if w else "") + (" READS " + _fmt(r) if r else "")
+                        hazards.setdefault(x.addr, f"  @{x.addr:#x}: `{x.text}`{what} -- destination of a vector-memory load still outstanding "
+                                                   f"({len(q)} in flight)")
+                if x.kind == "vmem":
+                    q.append(frozenset(x.dst))
+                    if len(q) > 63:  # the counter saturates: the hardware stalls the issue until an entry retires
+                        q = q[-63:]
+            if x.kind == "branch":
+                if x.target is not None and x.target in index:
+                    succ.append(index[x.target])
+                if x.op not in ("s_branch", "s_endpgm", "s_setpc_b64") and i + 1 < len(ins):
+                    succ.append(i + 1)
+                break
+            i += 1
+        else:
+            if block_end[b] < len(ins):
+                succ.append(block_end[b])
+        out = tuple(q[-MAX_Q:])
+        for s_ in succ:
+            if s_ not in state_in:
+                continue
+            m = merge(state_in[s_], out)
+            if m != state_in[s_]:
+                state_in[s_] = m
+                work.append(s_)
+    return [hazards[a] for a in sorted(hazards)]
+
+
+def _fmt(rs) -> str:
+    return ",".join(f"{k}{i}" for k, i in sorted(rs))
+
+
+def lint_paths(paths: List[str], only: Optional[str] = None) -> Tuple[int, int, List[str]]:
+    n_kernel, report = 0, []
+    with tempfile.TemporaryDirectory() as wd:
+        for path in paths:
+            if path.endswith(".s"):
+                kernels = parse_asm_text(open(path).read().splitlines())
+            else:
+                kernels = parse_objdump(device_code(path, wd))
+            for name, ins in kernels.items():
+                if only and only not in name:
+                    continue
+                n_kernel += 1
+                hz = lint_kernel(ins)
+                if hz:
+                    report.append(f"{os.path.basename(path)}: {name[:100]}: {len(hz)} hazard(s)")
+                    report += hz[:8]
+    return n_kernel, sum(1 for r in report if not r.startswith("  ")), report
+
+
+def main() -> int:
+    paths = sys.argv[1:] or sorted(glob.glob(os.path.join(ROOT, "trafficbots_amd", "csrc", "build", "*.o")))
+    n_kernel, n_bad, report = lint_paths(paths)
+    print(f"isa_waw_lint: {n_kernel} kernels in {len(paths)} file(s), {n_bad} with a write/read of an in-flight vector-memory destination")
+    for r in report:
+        print(r)
+    return 1 if n_bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

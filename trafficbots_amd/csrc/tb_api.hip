@@ -1,6 +1,8 @@
 // C ABI (include/trafficbots_hip.h): context, weight staging + MFMA-fragment packing, workspace, rollout driver.
 #include <hip/hip_runtime.h>
 
+#include <chrono>
+
 #include <cstdarg>
 #include <cstdio>
 #include <cmath>
@@ -352,12 +354,41 @@ void tb_host_onehot_index(const uint8_t* onehot, int64_t n_rows, int32_t n_class
 
 const char* tb_version(void) { return "trafficbots_hip 0.2 (gfx950, fp16-pair XDL MFMA 16x16x32 with fp32 accumulate; fp32 MFMA 16x16x4 kernels selectable)"; }
 
-// bf16 launches of more than 512 row tiles (two per CU would need more than one dispatch round) take the three-per-CU carve
-// (tb::xb3, same results); TB_STEP_W3=0 keeps them on the two-per-CU carve (development / A-B switch)
-static bool w3_launch(size_t n_tiles) {
-    const char* e = getenv("TB_STEP_W3");  // (read per launch: the tests flip it inside one process)
-    return !(e && e[0] == '0') && n_tiles > 512;
+// tb_config.sw with the debugging environment variables laid over it (read per API call: the tests flip them inside one process).
+// The variable of a switch, when set, wins over the configuration field.
+extern "C++" TbSw tb_switches_now(const tb_ctx* ctx) {
+    const tb_switches& c = ctx->cfg.sw;
+    auto env = [](const char* name) -> const char* { return getenv(name); };
+    auto off = [&](int32_t field, const char* name) {  // 1 = off; variable "0" = off, anything else = on
+        if (const char* e = env(name)) return e[0] == '0' ? 1 : 0;
+        return field == 1 ? 1 : 0;
+    };
+    TbSw s{};
+    {
+        const char* e = env("TB_STEP_HELPERS");
+        if (!e) e = env("TB_GRU_HELPER");  // (the switch's first name)
+        s.helpers_off = e ? (e[0] == '0') : (c.step_helpers == 1);
+    }
+    if (const char* e = env("TB_STEP_WARM")) s.warm = e[0] == '0' ? 1 : 2;
+    else s.warm = c.step_l2_warmers;
+    s.pre_inter_off = off(c.step_pre_inter, "TB_STEP_PRE_INTER");
+    s.w3_off = off(c.step_w3, "TB_STEP_W3");
+    if (const char* e = env("TB_STEP_AW")) s.aw = e[0] == '0' ? 1 : (e[0] == '2' ? 2 : 0);
+    else s.aw = c.step_aw;
+    s.lean_off = off(c.step_lean, "TB_STEP_LEAN");
+    s.graph_off = off(c.rollout_graph, "TB_ROLLOUT_GRAPH");
+    if (const char* e = env("TB_ENCODE_PACK")) s.enc_pack = (e[0] >= '0' && e[0] <= '4') ? e[0] - '0' : 4;
+    else s.enc_pack = (c.encode_pack >= 1 && c.encode_pack <= 5) ? c.encode_pack - 1 : 4;
+    s.enc_side_off = off(c.encode_side, "TB_ENCODE_SIDE");
+    s.enc_dest_side_off = off(c.encode_dest_side, "TB_ENCODE_DEST_SIDE");
+    if (const char* e = env("TB_DEST_LDS_PAD")) s.dest_lds_pad = atoi(e);
+    else s.dest_lds_pad = c.dest_lds_pad == 0 ? 30000 : (c.dest_lds_pad < 0 ? 0 : c.dest_lds_pad);
+    return s;
 }
+
+// bf16 launches of more than 512 row tiles (two per CU would need more than one dispatch round) take the three-per-CU carve
+// (tb::xb3, same results); tb_switches.step_w3 = 1 keeps them on the two-per-CU carve (development / A-B switch)
+static bool w3_launch(const TbSw& sw, size_t n_tiles) { return !sw.w3_off && n_tiles > 512; }
 
 // bf16 launches of one workgroup per CU (129 .. 256 row tiles: too many for helper workgroups, too few for a second dispatch round)
 // whose A half walks >= 512 map polylines run eight-wave workgroups: four assist waves take every other key block of the
@@ -366,14 +397,10 @@ static bool w3_launch(size_t n_tiles) {
 // TB_STEP_AW=0 keeps such launches on the four-wave kernel (development / A-B switch).
 // TB_STEP_AW=2 (test switch): such launches of ANY size up to 256 tiles take the assist carve -- the rollout then runs without helper
 // workgroups (aw_forced, rollout_setup) -- so that a one-scene case the CPU oracle can follow exercises it.
-static bool aw_forced() {
-    const char* e = getenv("TB_STEP_AW");
-    return e && e[0] == '2';
-}
-static bool aw_launch(const tb::RolloutP& p, int do_a) {
-    const char* e = getenv("TB_STEP_AW");
+static bool aw_forced(const TbSw& sw) { return sw.aw == 2; }
+static bool aw_launch(const TbSw& sw, const tb::RolloutP& p, int do_a) {
     const size_t n_tiles = (size_t)(p.a_pad / tb::TM) * p.n_inst;
-    return !(e && e[0] == '0') && do_a && (n_tiles > 128 || aw_forced()) && n_tiles <= 256 && p.p_pad >= 512;
+    return sw.aw != 1 && do_a && (n_tiles > 128 || aw_forced(sw)) && n_tiles <= 256 && p.p_pad >= 512;
 }
 
 // `rd` supplies what C(t) reads (normally the same struct as `wr`; the batched warm start substitutes its slices), `wr` what
@@ -386,9 +413,10 @@ static void step_launch(const tb_ctx* ctx, const tb::RolloutP& rd, const tb::Rol
         tb::set_parity(w, t);
         p.valid_w = w.valid_w; p.vbias_w = w.vbias_w; p.kin_w = w.kin_w; p.vtin_w = w.vtin_w; p.x_mid_w = w.x_mid_w;
     }
-    if (ctx->step_kernel == 3 && w3_launch((size_t)(p.a_pad / tb::TM) * p.n_inst))
+    const TbSw sw = tb_switches_now(ctx);
+    if (ctx->step_kernel == 3 && w3_launch(sw, (size_t)(p.a_pad / tb::TM) * p.n_inst))
         tb::xb3::launch_step_x(p, t, do_c, do_a, s);
-    else if (ctx->step_kernel == 3 && aw_launch(p, do_a))
+    else if (ctx->step_kernel == 3 && aw_launch(sw, p, do_a))
         tb::xba::launch_step_x(p, t, do_c, do_a, s);
     else if (ctx->step_kernel == 3)
         tb::xb::launch_step_x(p, t, do_c, do_a, s);
@@ -484,7 +512,8 @@ void tb_destroy(tb_ctx* ctx) {
     if (ctx->h_status) (void)hipHostFree(ctx->h_status);
     if (ctx->d_rule_ws) (void)hipFree(ctx->d_rule_ws);
     if (ctx->d_status) (void)hipFree(ctx->d_status);
-    if (ctx->d_warm_tab) (void)hipFree(ctx->d_warm_tab);
+    for (auto& kv : ctx->warm_tabs)
+        if (kv.second.d) (void)hipFree(kv.second.d);
     if (ctx->d_raw) (void)hipFree(ctx->d_raw);
     if (ctx->d_fw) (void)hipFree(ctx->d_fw);
     for (auto e : ctx->ev) (void)hipEventDestroy(e);
@@ -684,7 +713,12 @@ int tb_finalize_weights(tb_ctx* ctx, tb_stream stream) {
     // overflow under it -- gets the XDL kernels back with in-range weights; an open stepwise rollout belongs to the old weights)
     ctx->step_kernel = ctx->step_kernel0;
     ctx->encode_kernel = ctx->encode_kernel0;
-    ctx->warm_key = -1;  // (the L2 warmers' table holds arena offsets)
+    if (!ctx->warm_tabs.empty()) {  // (the L2 warmers' tables hold arena offsets of the previous weights)
+        (void)hipDeviceSynchronize();
+        for (auto& kv : ctx->warm_tabs)
+            if (kv.second.d) (void)hipFree(kv.second.d);
+        ctx->warm_tabs.clear();
+    }
     ctx->precision_reason = 0;
     ctx->precision_note.clear();
     ctx->step_active = false;
@@ -917,7 +951,7 @@ static void carve_rollout(tb::RolloutP& p, Carver& c, bool with_gh) {
     }
 }
 
-static int rollout_setup(tb_ctx* ctx, const tb_rollout_io* io, tb::RolloutP& p) {
+static int rollout_setup(tb_ctx* ctx, const tb_rollout_io* io, tb::RolloutP& p, tb_stream upload_stream) {
     if (!ctx || !io) return 1;
     if (!ctx->finalized) return tb_fail(ctx, "tb_rollout: weights not finalized");
     TB_HIP(ctx, hipSetDevice(ctx->device));  // the context is bound to the device that was current at tb_create
@@ -1001,12 +1035,12 @@ static int rollout_setup(tb_ctx* ctx, const tb_rollout_io* io, tb::RolloutP& p) 
     }
     p.pre_t0 = n_pre;  // (carve_rollout reads the slice count here)
     // helper workgroups: a launch of at most 128 tiles leaves at least half of the 256 CUs idle (tb_rollout.hpp)
+    const TbSw sw = tb_switches_now(ctx);
+    p.sw_lean_off = sw.lean_off;
     bool with_gh = false;
     {
-        const char* e = getenv("TB_STEP_HELPERS");
-        if (!e) e = getenv("TB_GRU_HELPER");  // (the switch's first name)
-        with_gh = ctx->step_kernel >= 2 && (size_t)p.n_inst * (p.a_pad / 16) <= 128 && !(e && e[0] == '0');
-        if (ctx->step_kernel == 3 && aw_forced() && p.p_pad >= 512) with_gh = false;  // (test switch: the assist carve has no helpers)
+        with_gh = ctx->step_kernel >= 2 && (size_t)p.n_inst * (p.a_pad / 16) <= 128 && !sw.helpers_off;
+        if (ctx->step_kernel == 3 && aw_forced(sw) && p.p_pad >= 512) with_gh = false;  // (test switch: the assist carve has no helpers)
     }
     if (!ctx->d_status) {
         TB_HIP(ctx, hipMalloc((void**)&ctx->d_status, 2 * sizeof(unsigned int)));
@@ -1018,16 +1052,28 @@ static int rollout_setup(tb_ctx* ctx, const tb_rollout_io* io, tb::RolloutP& p) 
         // stage profiles (profiles/r03_stage_profile_k_step_x.txt, fp16 pairs: prologue 13 k -- 9.5 k since round 5's burst --, an interaction layer 9.2 k + 2.2 k per
         // key block, GRU 23 k, fusion 9 k, head 9 k, epilogue + front 10 k, a map layer 9.2 k + 1.12 k per key block, a
         // traffic-light layer 11.3 k; bf16 operands: x 0.7).  Only what follows the helpers' own work is listed.  TB_STEP_WARM=0: off.
-        const char* we = getenv("TB_STEP_WARM");
+        // On while this context has the device to itself: the warmers hold two helper workgroups per XCD for the whole launch, +1.4 %
+        // for ONE rollout in flight and a 15 % loss when another context's launches want those CUs (bench.py two_batches_in_flight).
+        // tb_switches.step_l2_warmers = 0: automatic (off when another live context of this device launched work within the last
+        // 100 ms), 1: off, 2: on regardless.
+        bool warm_on = sw.warm != 1;
+        if (sw.warm == 0) {
+            const long long now = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+            std::lock_guard<std::mutex> lk(g_ctx_mutex);
+            for (tb_ctx* o : g_ctx_live)
+                if (o != ctx && o->device == ctx->device && o->last_launch_ns && now - o->last_launch_ns < 100000000LL) warm_on = false;
+        }
         const long long key = ((long long)p.p_pad << 32) | ((long long)p.a_pad << 8) | ctx->step_kernel;
-        if (we && we[0] == '0') {
+        if (!warm_on) {
             p.warm_tab = nullptr;
         } else {
-            if (key != ctx->warm_key) {
+            tb_ctx::WarmTab& wt = ctx->warm_tabs[key];
+            if (!wt.d) {
                 const tb::PolicyWX& x = ctx->step_kernel == 3 ? ctx->pxb : ctx->px;
                 const double sc = ctx->step_kernel == 3 ? 0.7 : 1.0;
                 const uint32_t gate = ctx->step_kernel == 3 ? 8192u : 16384u;  // floats of one 128 x 128 unit in the arena (bf16: one plane)
-                std::vector<int> tab;
+                std::vector<int>& tab = wt.host;
+                tab.clear();
                 auto add = [&](uint32_t off, double t) { tab.push_back((int)off); tab.push_back((int)(t * sc)); };
                 const double t_inter = 9200.0 + 2240.0 * (p.a_pad / 32), t_pl = 9200.0 + 1120.0 * (p.p_pad / 32), t_tl = 11300.0;
                 double t = 9500.0 + 3 * t_inter;  // the GRU
@@ -1045,13 +1091,14 @@ static int rollout_setup(tb_ctx* ctx, const tb_rollout_io* io, tb::RolloutP& p) 
                     add(x.as2tl[l].wq, t - 1700.0); add(x.as2tl[l].wo, t + 2000.0); add(x.as2tl[l].w1, t + 5700.0); add(x.as2tl[l].w2, t + 8300.0);
                 }
                 add(x.inter_kvf[0], t - 2000.0);
-                if (!ctx->d_warm_tab) TB_HIP(ctx, hipMalloc((void**)&ctx->d_warm_tab, 128 * sizeof(int)));
-                TB_HIP(ctx, hipMemcpy(ctx->d_warm_tab, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice));
-                ctx->warm_key = key;
-                ctx->warm_n = (int)tab.size() / 2;
+                // one table per key, written once (never rewritten: launches in flight / captured graphs keep theirs), uploaded on the
+                // caller's stream in front of the launches that read it -- no blocking copy inside tb_rollout
+                TB_HIP(ctx, hipMalloc((void**)&wt.d, 128 * sizeof(int)));
+                TB_HIP(ctx, hipMemcpyAsync(wt.d, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice, (hipStream_t)upload_stream));
+                wt.n = (int)tab.size() / 2;
             }
-            p.warm_tab = ctx->d_warm_tab;
-            p.warm_n = ctx->warm_n;
+            p.warm_tab = wt.d;
+            p.warm_n = wt.n;
         }
     }
     {
@@ -1095,7 +1142,8 @@ static void rollout_prologue(const tb_ctx* ctx, const tb::RolloutP& p, const tb_
 static int rollout_enqueue(tb_ctx* ctx, const tb_rollout_io* io, const tb::RolloutP& p, hipStream_t s);
 
 // every launch-shaping development switch read below this call (step_launch, rollout_prologue): part of the graph key
-static const char* const kGraphEnv[] = {"TB_STEP_W3", "TB_STEP_AW", "TB_STEP_PRE_INTER", "TB_STEP_WARM", "TB_STEP_LEAN", "TB_STEP_HELPERS", "TB_GRU_HELPER", "TB_DEBUG_HELPER_DELAY", "TB_STEP_KERNEL"};
+// (development-only variables that are not tb_switches fields)
+static const char* const kGraphEnv[] = {"TB_DEBUG_HELPER_DELAY", "TB_STEP_KERNEL"};
 
 static void key_append(std::vector<unsigned char>& k, const void* data, size_t n) {
     const unsigned char* b = static_cast<const unsigned char*>(data);
@@ -1104,19 +1152,21 @@ static void key_append(std::vector<unsigned char>& k, const void* data, size_t n
 
 extern "C" int tb_rollout(tb_ctx* ctx, const tb_rollout_io* io, tb_stream stream_) {
     tb::RolloutP p;
-    if (rollout_setup(ctx, io, p)) return 1;
+    if (rollout_setup(ctx, io, p, stream_)) return 1;
     hipStream_t s = (hipStream_t)stream_;
     ctx->step_active = false;
     // ---- one hipGraph per rollout: every kernel argument of the launch sequence is a function of (p, io, the development switches),
     // so a rollout with the same argument bytes replays the captured graph (bench loops, a serving loop over fixed buffers)
-    const char* ge = getenv("TB_ROLLOUT_GRAPH");
-    const bool use_graph = !(ge && ge[0] == '0') && !ctx->timing && ctx->step_kernel >= 2;
+    tb_note_launch(ctx);
+    const TbSw sw = tb_switches_now(ctx);
+    const bool use_graph = !sw.graph_off && !ctx->timing && ctx->step_kernel >= 2;
     if (!use_graph) return rollout_enqueue(ctx, io, p, s);
     std::vector<unsigned char> key;
     key.reserve(sizeof(p) + sizeof(*io) + 256);
     key_append(key, &p, sizeof(p));
     key_append(key, io, sizeof(*io));
     if (io->hidden_drop) key_append(key, io->hidden_drop, (size_t)p.n_step_out);  // (host data that shapes the launch sequence)
+    key_append(key, &sw, sizeof(sw));  // every launch-shaping switch read below this call (step_launch, rollout_prologue)
     for (const char* name : kGraphEnv) {
         const char* v = getenv(name);
         key_append(key, v ? v : "-", v ? strlen(v) + 1 : 2);
@@ -1169,9 +1219,10 @@ extern "C" int tb_rollout(tb_ctx* ctx, const tb_rollout_io* io, tb_stream stream
     return 0;
 }
 
-static bool pre_inter() {
-    const char* e = getenv("TB_STEP_PRE_INTER");
-    return !(e && e[0] == '0');
+static bool pre_inter(const tb_ctx* ctx) { return !tb_switches_now(ctx).pre_inter_off; }
+
+extern "C++" void tb_note_launch(tb_ctx* ctx) {
+    ctx->last_launch_ns = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
 static int rollout_enqueue(tb_ctx* ctx, const tb_rollout_io* io, const tb::RolloutP& p, hipStream_t s) {
@@ -1193,13 +1244,13 @@ static int rollout_enqueue(tb_ctx* ctx, const tb_rollout_io* io, const tb::Rollo
     const int n_pre = ctx->n_pre;
     const int t_pre0 = step_start - 1;
     if (n_pre > 0) {
-        if (ctx->step_kernel == 3 && w3_launch((size_t)(p.a_pad / tb::TM) * p.n_scene * n_pre)) tb::xb3::launch_step_pre_x(p, t_pre0, n_pre, s);
+        if (ctx->step_kernel == 3 && w3_launch(tb_switches_now(ctx), (size_t)(p.a_pad / tb::TM) * p.n_scene * n_pre)) tb::xb3::launch_step_pre_x(p, t_pre0, n_pre, s);
         else if (ctx->step_kernel == 3) tb::xb::launch_step_pre_x(p, t_pre0, n_pre, s);
         else tb::xh::launch_step_pre_x(p, t_pre0, n_pre, s);
         // ... and behind it the interaction blocks of the same steps, once per scene (RolloutP::x_int_pre; TB_STEP_PRE_INTER=0 keeps
         // them in the step-by-step launches: development / A-B switch)
-        if (pre_inter()) {
-            if (ctx->step_kernel == 3 && w3_launch((size_t)(p.a_pad / tb::TM) * p.n_scene * n_pre)) tb::xb3::launch_inter_pre_x(p, t_pre0, n_pre, s);
+        if (pre_inter(ctx)) {
+            if (ctx->step_kernel == 3 && w3_launch(tb_switches_now(ctx), (size_t)(p.a_pad / tb::TM) * p.n_scene * n_pre)) tb::xb3::launch_inter_pre_x(p, t_pre0, n_pre, s);
             else if (ctx->step_kernel == 3) tb::xb::launch_inter_pre_x(p, t_pre0, n_pre, s);
             else tb::xh::launch_inter_pre_x(p, t_pre0, n_pre, s);
         }
@@ -1213,8 +1264,8 @@ static int rollout_enqueue(tb_ctx* ctx, const tb_rollout_io* io, const tb::Rollo
         if (t - t_pre0 < n_pre) do_a = 0;                  // A(t+1) came out of the batched launch
         if (do_c && t - 1 - t_pre0 < n_pre && t - 1 >= t_pre0) {  // C(t) consumes slice t-1-t_pre0 of the batched results
             const size_t z = (size_t)(t - 1 - t_pre0) * p.n_inst * p.a_pad * 128;
-            q.x_mid = (pre_inter() ? p.x_int_pre : p.x_mid_pre) + z;
-            q.skip_inter = pre_inter();
+            q.x_mid = (pre_inter(ctx) ? p.x_int_pre : p.x_mid_pre) + z;
+            q.skip_inter = pre_inter(ctx);
             q.pre_shared = p.k_rep > 1;  // (the slices exist once per scene, in the slot of future 0: no replication)
             q.kin_b[0] = q.kin_b[1] = p.kin_pre + 3 * z;     // (read side only: step_launch picks by parity, the write side is restored below)
             q.vtin_b[0] = q.vtin_b[1] = p.vtin_pre + 3 * z;
@@ -1330,7 +1381,7 @@ extern "C" int tb_dest_sample(tb_ctx* ctx, const tb_dest_sample_io* io, tb_strea
 // ---- stepwise driving (the reference's stateful WaymoMotion.forward, waymo_motion.py:108-203) ------------------------
 extern "C" int tb_rollout_begin(tb_ctx* ctx, const tb_rollout_io* io, tb_stream stream_) {
     tb::RolloutP p;
-    if (rollout_setup(ctx, io, p)) return 1;
+    if (rollout_setup(ctx, io, p, stream_)) return 1;
     // (tb_rollout-only fields: refused here rather than silently ignored -- ADVICE r03)
     if (io->hidden_drop) return tb_fail(ctx, "tb_rollout_begin: hidden_drop is honoured by tb_rollout only (zero the hidden state between tb_rollout_step calls yourself)");
     hipStream_t s = (hipStream_t)stream_;

@@ -496,7 +496,7 @@ static void launch_xblock(const XBlockP& p, int G, hipStream_t s) {
 // Returns true when the block also did the node pooling asked for with pool_out / pool_valid (the fused polyline kernel).
 static bool run_block(bool xdl, const float* W, const XLayerW* L, const XLayerX* LX, int n_layer, const float* tgt, const uint8_t* tgt_valid,
                       int G, int n_tgt, int n_pad, float* K, float* VT, float* kbias, const float* src, const uint8_t* src_valid, float* dst,
-                      int n_rows, int eye, hipStream_t s, float* pool_out = nullptr, uint8_t* pool_valid = nullptr, int part = 0) {
+                      int n_rows, int eye, hipStream_t s, float* pool_out = nullptr, uint8_t* pool_valid = nullptr, int part = 0, int enc_pack = 4) {
     // part: 0 = K / V hoist + block, 1 = the hoist only, 2 = the block only (the hoist needs the targets alone: it may run on another
     // stream before the block's sources exist; the generic hoist + block pair only)
     if (xdl) {
@@ -505,12 +505,11 @@ static bool run_block(bool xdl, const float* W, const XLayerW* L, const XLayerX*
         for (int l = 0; l < n_layer; ++l) { x.L[l] = L[l]; x.LX[l] = LX[l]; }
         x.src = src; x.src_valid = src_valid; x.dst = dst; x.K = K; x.VT = VT; x.kbias = kbias; x.n_rows = n_rows; x.n_pad = n_pad; x.eye = eye;
         // the map encoder's polyline block (20 nodes, self-attention inside the polyline) runs on the packed tiling: no padding rows
-        const char* pe = getenv("TB_ENCODE_PACK");  // (read per call: the tests flip it inside one process)
-        const bool pack = !(pe && pe[0] == '0');
+        const int pmode = enc_pack;  // tb_switches.encode_pack resolved by the caller (tb_switches_now)
+        const bool pack = pmode != 0;
         // '4' (default): the fused kernel on eight waves with merged phases (k_polyline_fused8<true>); '3': eight waves, the four-wave
         // kernel's phases (k_polyline_fused8<false>); '2': the fused kernel, K / V in LDS, four waves; '1': packed tiling with the K / V
         // hoist through HBM; '0': padded tiling
-        const int pmode = pe ? pe[0] - '0' : 4;
         if (pmode >= 2 && pool_out && n_tgt == 20 && n_rows == 20 && n_pad == 32 && tgt == src && tgt_valid == src_valid && !eye && G % 2 == 0) {
             x.pool_out = pool_out; x.pool_valid = pool_valid;
             xh::launch_polyline_fused_x(x, G, s, pmode == 4 ? 2 : (pmode == 3 ? 1 : 0));
@@ -633,8 +632,9 @@ int run_encode(struct ::tb_ctx* ctx, const tb_encode_io* io, hipStream_t s) {
     const int S3 = (NH - 1) / 5 + 1;  // steps {0,5,10} (latent_encoder.py:98-103)
     // map-encoder chunking bounds the per-polyline K/V scratch (3 layers x 32 keys x 128 x 2 x 4 B = 96 KiB / polyline)
     // (the fused polyline kernel keeps K / V in LDS: no scratch, one launch over all polylines)
-    const char* pe_ = getenv("TB_ENCODE_PACK");
-    const bool fused_pl = ctx->encode_kernel == 1 && (pe_ ? (pe_[0] >= '2' && pe_[0] <= '4') : true) && P % 2 == 0;
+    tb_note_launch(ctx);
+    const TbSw sw = tb_switches_now(ctx);
+    const bool fused_pl = ctx->encode_kernel == 1 && sw.enc_pack >= 2 && P % 2 == 0;
     const int scenes_per_chunk = fused_pl ? B : std::max(1, std::min(B, (int)(((size_t)512 << 20) / ((size_t)P * 98304))));
     const size_t kv_scenes = fused_pl ? 0 : (size_t)scenes_per_chunk;
 
@@ -667,8 +667,7 @@ int run_encode(struct ::tb_ctx* ctx, const tb_encode_io* io, hipStream_t s) {
     // scan (128 workgroups) go to a side stream that forks from `s` here and joins it in front of the personality branch
     hipStream_t s2 = s;
     {
-        const char* e = getenv("TB_ENCODE_SIDE");
-        if (!(e && e[0] == '0')) {
+        if (!sw.enc_side_off) {
             // (the context's ONE private stream, shared with the rollout's graph capture: a further stream per context shifted the
             // runtime's stream -> hardware-queue assignment so that two rollouts on two caller streams no longer overlapped --
             // bench.py's two_batches_in_flight fell from 597 k to 369 k scene-steps/s)
@@ -728,7 +727,7 @@ int run_encode(struct ::tb_ctx* ctx, const tb_encode_io* io, hipStream_t s) {
         const float* src = nodef + (size_t)b0 * P * 20 * 128;
         const uint8_t* sv = io->map_valid + (size_t)b0 * P * 20;
         if (run_block(ctx->encode_kernel == 1, W, ew.densetnt, ew.densetnt_x, 3, src, sv, G, 20, 32, kn, vtn, kvn, src, sv, nodeo, 20, 0, s,
-                      plf + (size_t)b0 * P * 128, io->map_feature_valid + (size_t)b0 * P))
+                      plf + (size_t)b0 * P * 128, io->map_feature_valid + (size_t)b0 * P, 0, sw.enc_pack))
             continue;
         const int nthr = G * 32;
         hipLaunchKernelGGL(k_pool_nodes, dim3((nthr + 255) / 256), dim3(256), 0, s, nodeo, sv, G, plf + (size_t)b0 * P * 128,
@@ -753,13 +752,11 @@ int run_encode(struct ::tb_ctx* ctx, const tb_encode_io* io, hipStream_t s) {
         // (beside the latent branch: TWO workgroups per CU instead of three, see launch_dest_pairs_x -- measured: 30 KB of padding
         // -1 % / -4 % of the encode at the headline / stress shape, 60 KB (one per CU) +3 %: the predictor becomes the long pole;
         // TB_DEST_LDS_PAD = bytes, development switch)
-        const char* lp = getenv("TB_DEST_LDS_PAD");
-        const int lds_pad = st != s ? (lp ? atoi(lp) : 30000) : 0;
+        const int lds_pad = st != s ? sw.dest_lds_pad : 0;
         if (ctx->encode_kernel == 1) xh::launch_dest_pairs_x(d, st, lds_pad);
         else hipLaunchKernelGGL(k_dest_pairs, dim3((P + TM - 1) / TM, A, B), dim3(NTHREADS), 0, st, d);
     };
-    const char* ed = getenv("TB_ENCODE_DEST_SIDE");
-    const bool dest_side = s2 != s && !(ed && ed[0] == '0');
+    const bool dest_side = s2 != s && !sw.enc_dest_side_off;
     if (s2 != s) {
         if (dest_side) {
             TB_HIP(ctx, hipEventRecord(ctx->enc_map, s));

@@ -13,6 +13,12 @@
 #include "tb_encode.hpp"
 #include "tb_rollout.hpp"
 
+// The launch-shaping switches as the code reads them: tb_config.sw with the debugging environment variables laid over it
+// (tb_switches_now, tb_api.hip).  Resolved once per API call; part of the hipGraph key.
+struct TbSw {
+    int helpers_off, warm, pre_inter_off, w3_off, aw, lean_off, graph_off, enc_pack, enc_side_off, enc_dest_side_off, dest_lds_pad;
+};
+
 struct tb_ctx {
     tb_config cfg;
     int device = 0;  // HIP device the context is bound to
@@ -41,9 +47,12 @@ struct tb_ctx {
     long long* last_prof = nullptr;
     unsigned int* d_status = nullptr;  // device word of tb_check_status
     unsigned int* h_status = nullptr;  // its pinned host mirror (hipHostMalloc): the check's read-back is an async copy + one stream synchronise
-    int* d_warm_tab = nullptr;         // L2 warmers (tb_stepx_kernels.hip): [64][2] {arena offset, request time} of the weight units a launch streams
-    long long warm_key = -1;           // (p_pad, a_pad, step kernel) the table was made for
-    int warm_n = 0;
+    // L2 warmers (tb_stepx_kernels.hip): [64][2] {arena offset, request time} of the weight units a launch streams -- one device
+    // table per (p_pad, a_pad, step kernel), uploaded once on the caller's stream and never rewritten (launches in flight and
+    // captured graphs keep reading theirs: ADVICE r05)
+    struct WarmTab { int* d = nullptr; int n = 0; std::vector<int> host; };
+    std::map<long long, WarmTab> warm_tabs;
+    long long last_launch_ns = 0;      // steady-clock time of this context's last rollout / encode call (the warmers' auto-off)
     // stepwise rollout (tb_rollout_begin / _step / _state)
     tb::RolloutP step_p;
     int step_next = 0, step_end = -1;
@@ -114,6 +123,8 @@ struct Carver {
     }
 };
 
+TbSw tb_switches_now(const tb_ctx* ctx);
+void tb_note_launch(tb_ctx* ctx);
 int tb_ensure_workspace(tb_ctx* ctx, size_t bytes);
 int tb_ensure_workspace_enc(tb_ctx* ctx, size_t bytes);
 inline int padk(int x) { return (x + 31) / 32 * 32; }  // key counts / row counts are padded to 32 (tb::KEYPAD)

@@ -133,6 +133,7 @@ struct RolloutP {
     // state the A half of step t+1 starts from IS the ground truth of step t, so those A halves do not depend on the rollout and run
     // as ONE launch of n x tiles workgroups (the chip is half empty at 32 scenes); slice z of the *_pre buffers takes A(pre_t0 + z + 1)
     int pre_mode, pre_t0;
+    int sw_lean_off;  // (host side only: tb_switches.step_lean resolved for this call -- the launchers pick the carve)
     float* x_mid_pre;             // [n_pre][N,a_pad,128]
     float* kin_pre;               // [n_pre][N,3,a_pad,128]
     float* vtin_pre;              // [n_pre][N,3,128,a_pad]

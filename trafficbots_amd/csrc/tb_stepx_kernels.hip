@@ -895,8 +895,7 @@ void launch_step_x(const RolloutP& p0, int t, int do_c, int do_a, hipStream_t s)
     dim3 grid(p.a_pad / TM, p.n_inst, p.gh_flag ? 2 : 1);
     {
         // more tiles than CUs: the LEAN carve lets two workgroups share a CU (same arithmetic, same results)
-        const char* e = getenv("TB_STEP_LEAN");  // development switch: 0 = always the full carve
-        if ((size_t)grid.x * grid.y > 256 && !(e && e[0] == '0')) {
+        if ((size_t)grid.x * grid.y > 256 && !p.sw_lean_off) {  // (tb_switches.step_lean = 1: always the full carve)
             hipLaunchKernelGGL((k_step_x<false, true>), grid, dim3(NTHREADS), STEPX_LEAN_LDS_FLOATS * sizeof(float), s, p, t, do_c, do_a);
             return;
         }
@@ -918,8 +917,7 @@ void launch_step_pre_x(const RolloutP& p0, int t0, int n, hipStream_t s) {
 #else
     {
         // n x tiles workgroups: the LEAN carve (two workgroups per CU) whenever that is more than the chip has CUs
-        const char* e = getenv("TB_STEP_LEAN");
-        if ((size_t)grid.x * grid.y * grid.z > 256 && !(e && e[0] == '0')) {
+        if ((size_t)grid.x * grid.y * grid.z > 256 && !p.sw_lean_off) {
             hipLaunchKernelGGL((k_step_x<true, true>), grid, dim3(NTHREADS), STEPX_LEAN_LDS_FLOATS * sizeof(float), s, p, t0, 0, 1);
             return;
         }
@@ -938,8 +936,7 @@ void launch_inter_pre_x(const RolloutP& p0, int t0, int n, hipStream_t s) {
     hipLaunchKernelGGL((k_step_x<true, true>), grid, dim3(NTHREADS), STEPX_LEAN_LDS_FLOATS * sizeof(float), s, p, t0, 0, 1);
 #else
     {
-        const char* e = getenv("TB_STEP_LEAN");
-        if ((size_t)grid.x * grid.y * grid.z > 256 && !(e && e[0] == '0')) {
+        if ((size_t)grid.x * grid.y * grid.z > 256 && !p.sw_lean_off) {
             hipLaunchKernelGGL((k_step_x<true, true>), grid, dim3(NTHREADS), STEPX_LEAN_LDS_FLOATS * sizeof(float), s, p, t0, 0, 1);
             return;
         }

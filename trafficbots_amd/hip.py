@@ -17,6 +17,15 @@ c_u8p = C.POINTER(C.c_uint8)
 c_i32p = C.POINTER(C.c_int32)
 
 
+SWITCH_FIELDS = ("step_helpers", "step_l2_warmers", "step_pre_inter", "step_w3", "step_aw", "step_lean", "rollout_graph", "encode_pack",
+                 "encode_side", "encode_dest_side", "dest_lds_pad")
+
+
+class TbSwitches(C.Structure):
+    """`tb_switches` (include/trafficbots_hip.h): launch-shaping switches, every field 0 = automatic."""
+    _fields_ = [(n, C.c_int32) for n in SWITCH_FIELDS] + [("reserved", C.c_int32 * 5)]
+
+
 class TbConfig(C.Structure):
     _fields_ = [
         ("time_step_current", C.c_int32),
@@ -27,6 +36,7 @@ class TbConfig(C.Structure):
         ("action_log_std", C.c_float),
         ("latent_log_std", C.c_float),
         ("operand_precision", C.c_int32),
+        ("sw", TbSwitches),
     ]
 
 
@@ -285,4 +295,10 @@ def make_config(cfg: Dict) -> TbConfig:
     if prec not in ("fp32", "bf16", "fp32_exact"):
         raise ValueError(f"operand_precision must be 'fp32', 'bf16' or 'fp32_exact', got {prec!r}")
     c.operand_precision = {"fp32": 0, "bf16": 1, "fp32_exact": 2}[prec]
+    # not keys of the reference either: `library_switches: {step_l2_warmers: 1, ...}` -> tb_config.sw (include/trafficbots_hip.h;
+    # every field 0 = automatic, the default)
+    for name, value in dict(cfg.get("library_switches") or {}).items():
+        if name not in SWITCH_FIELDS:
+            raise ValueError(f"library_switches: unknown switch {name!r} (known: {', '.join(SWITCH_FIELDS)})")
+        setattr(c.sw, name, int(value))
     return c

@@ -384,3 +384,89 @@ class BatchPrefetcher:
 
     def __len__(self) -> int:
         return len(self.loader)
+
+
+def _record_stream(obj, stream, _depth: int = 0) -> None:
+    """`record_stream(stream)` on every CUDA tensor reachable from a step's result (dicts, sequences, RolloutBuffer-like objects)."""
+    if torch.is_tensor(obj):
+        if obj.is_cuda:
+            obj.record_stream(stream)
+    elif isinstance(obj, dict):
+        for v in obj.values():
+            _record_stream(v, stream, _depth + 1)
+    elif isinstance(obj, (list, tuple)):
+        for v in obj:
+            _record_stream(v, stream, _depth + 1)
+    elif _depth < 4 and hasattr(obj, "__dict__") and not isinstance(obj, type):
+        for v in vars(obj).values():
+            _record_stream(v, stream, _depth + 1)
+
+
+class LanePipeline:
+    """`for out in wm.pipeline(loader, lanes=2): ...` -- the harness step (`test_step` by default) of consecutive batches on `lanes`
+    independent contexts, each with its own stream: batch n + 1 is staged, encoded and rolled out on lane (n + 1) % lanes while batch n
+    still runs on its lane.  At 32 scenes a rollout launch has 128 tiles for 256 CUs and is bound by per-CU latency chains, so two
+    rollouts in flight nearly double the chip's throughput (bench.py `two_batches_in_flight`); the one-batch-at-a-time call sequence of
+    the reference's harness (`src/pl_modules/waymo_motion.py:902-949`) cannot show that, this iterator can.
+
+    Results come out IN ORDER and only after their lane's range check (`tb_check_status`): an fp16-pair overflow re-runs that batch
+    on the exact-fp32 kernels before it is handed out, exactly as a plain `test_step` does -- nothing unchecked leaves the iterator.
+    Bit-identical to plain calls (the lanes run the same kernels on the same inputs; the L2 warmers, prefetch hints without a
+    numerical effect, switch themselves off while a second context is active).  `kwargs_fn(i)` supplies per-batch keyword arguments
+    (`latent_eps`, `generator`, ...)."""
+
+    def __init__(self, wm, loader: Iterable[Dict], lanes: int = 2, step: str = "test_step", kwargs_fn=None) -> None:
+        assert lanes >= 1
+        self.loader, self.step, self.kwargs_fn = loader, step, kwargs_fn
+        self.wms = [wm] + [wm.clone() for _ in range(lanes - 1)]
+        self.streams = [torch.cuda.Stream(device=wm.device) for _ in range(lanes)]
+        self.n_reruns = 0
+
+    def __len__(self) -> int:
+        return len(self.loader)
+
+    def __iter__(self):
+        from collections import deque
+
+        inflight = deque()
+        it = enumerate(iter(self.loader))
+        raw = [getattr(type(w), self.step).__wrapped__ for w in self.wms]  # (the step without its own synchronising range check)
+        main = torch.cuda.current_stream(self.wms[0].device)
+
+        def launch() -> bool:
+            try:
+                i, batch = next(it)
+            except StopIteration:
+                return False
+            lane = i % len(self.wms)
+            kw = self.kwargs_fn(i) if self.kwargs_fn else {}
+            s = self.streams[lane]
+            s.wait_stream(main)  # (whatever the caller queued before -- e.g. tensors in kw -- is visible to the lane)
+            with torch.cuda.stream(s):
+                out = raw[lane](self.wms[lane], batch, **kw)
+                ev = torch.cuda.Event()
+                ev.record(s)
+            inflight.append((lane, batch, kw, out, ev))
+            return True
+
+        try:
+            for _ in self.wms:
+                if not launch():
+                    break
+            while inflight:
+                lane, batch, kw, out, ev = inflight.popleft()
+                ev.synchronize()
+                w = self.wms[lane]
+                if w.check_range:
+                    with torch.cuda.stream(self.streams[lane]):
+                        if w.engine.check_status(raise_on_range=False):  # overflowed: the lane's context is on the exact kernels now
+                            self.n_reruns += 1
+                            out = getattr(w, self.step)(batch, **kw)     # (the checked step: re-run + its own check)
+                            torch.cuda.current_stream().synchronize()
+                main.wait_stream(self.streams[lane])  # the consumer's stream sees the finished results
+                _record_stream(out, main)             # (they were allocated on the lane's stream: allocator bookkeeping)
+                launch()  # refill the lane before handing the result out: the GPU stays fed while the consumer works
+                yield out
+        finally:
+            for s in self.streams:
+                s.synchronize()

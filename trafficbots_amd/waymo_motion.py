@@ -304,6 +304,8 @@ class WaymoMotion:
         `hydra.utils.instantiate` passes for `configs/model/traffic_bots.yaml` (`waymo_motion.py:28-62`); nested groups as plain
         dicts (or anything dict-like), `_target_` keys and the training-only groups (optimizer, lr_scheduler, sub_womd_*, data_size,
         wb_artifact ...) accepted and not used.  See also :func:`trafficbots_amd.instantiate`."""
+        self._ctor = (config_path, device, dict(overrides))  # (for `clone`: a second context with the same configuration)
+        self._state_dict = None
         if isinstance(overrides.get("model"), dict) or hasattr(overrides.get("model"), "items"):
             self.hparams = config_from_hydra_kwargs(overrides)
         else:
@@ -328,6 +330,7 @@ class WaymoMotion:
 
     # ------------------------------------------------------------------ weights
     def load_state_dict(self, state_dict: Dict) -> None:
+        self._state_dict = state_dict
         self.engine.load_state_dict(state_dict)
         ls = state_dict["model.latent_encoder.latent_prior_dist.log_std"]
         self.model._log_std = torch.as_tensor(ls, dtype=torch.float32).to(self.device)
@@ -357,6 +360,23 @@ class WaymoMotion:
         if "agent/valid" in batch:
             scene["gt"] = gt_from_batch(batch, self.device, self.n_hist)
         return _with_reference_keys(scene)
+
+    def clone(self) -> "WaymoMotion":
+        """A second, independent context (own `tb_ctx`: weights arena, workspaces, status word) with this object's configuration and
+        weights -- what `pipeline` runs its other lanes on."""
+        config_path, device, overrides = self._ctor
+        w = WaymoMotion(config_path, device, **overrides)
+        if self._state_dict is not None:
+            w.load_state_dict(self._state_dict)
+        w.check_range = self.check_range
+        return w
+
+    def pipeline(self, loader, lanes: int = 2, step: str = "test_step", kwargs_fn=None):
+        """`for out in wm.pipeline(loader): ...`: the harness step of consecutive batches on `lanes` contexts / streams, results in
+        order and range-checked (`staging.LanePipeline`): two 32-scene rollouts in flight fill the chip that one leaves half empty."""
+        from .staging import LanePipeline
+
+        return LanePipeline(self, loader, lanes=lanes, step=step, kwargs_fn=kwargs_fn)
 
     def prefetch(self, loader, encode: bool = True):
         """`for staged in wm.prefetch(loader): out = wm.test_step(staged)` (also validation_step): batch n + 1 is staged -- host packing,
