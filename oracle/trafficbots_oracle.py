@@ -40,7 +40,8 @@ def _t(x, dtype):
 
 class Oracle:
     def __init__(self, state_dict: Dict[str, np.ndarray], cfg: dict, dtype=torch.float32, hoist: bool = False,
-                 exact_math: bool = False, gemm_order_seed: Optional[int] = None, operand_round: Optional[str] = None):
+                 exact_math: bool = False, gemm_order_seed: Optional[int] = None, operand_round: Optional[str] = None,
+                 ln_alt: bool = False):
         """`operand_round="bf16"` (VERDICT r03 task 1 (d)): the arithmetic of the library's `operand_precision = "bf16"` mode -- inside the
         ROLLOUT every matrix-product operand of the per-step policy (both operands of the transformer / GRU / fusion / action-head
         Linears that run on the matrix pipe, Q, K, V and the un-normalised softmax weights exp(logit - max)) is rounded to bf16
@@ -53,6 +54,9 @@ class Oracle:
         rounding of the matrix products too, not only that of the attention sums (tools/ensemble.py).
         `exact_math=True` (noise studies only, tests/probes): cos / sin / softmax / sigmoid / tanh of the rollout are evaluated in
         fp64 and rounded once to `dtype` -- another correct implementation of the same fp32 arithmetic, with a different libm.
+        `ln_alt=True` (noise studies only, tools/parity_control.py): LayerNorm from explicitly ordered sums -- mean and variance as
+        sums over a fixed random channel order, the variance from the centred values -- instead of `F.layer_norm`'s kernel: the same
+        function, another association of its two reductions.
         `hoist=False` recomputes the loop-invariant map/TL K,V projections and the goal/latent
         `mlp_in` every step exactly as the reference does; `hoist=True` computes them
         once (same values) -- used where only the result matters."""
@@ -61,6 +65,8 @@ class Oracle:
         self.w = {k: _t(v, dtype) for k, v in state_dict.items()}
         self.hoist = hoist
         self.exact_math = exact_math and dtype != torch.float64
+        self.ln_alt = ln_alt
+        self._ln_perm: Dict[int, Tensor] = {}
         self._kperm: Dict[int, Tensor] = {}
         self._wperm: Dict[tuple, Tensor] = {}
         self._kgen = None if gemm_order_seed is None else torch.Generator().manual_seed(int(gemm_order_seed))
@@ -106,6 +112,15 @@ class Oracle:
         return F.linear(x, w, b)
 
     def _ln(self, x: Tensor, prefix: str) -> Tensor:
+        if self.ln_alt:
+            n = x.shape[-1]
+            if n not in self._ln_perm:
+                self._ln_perm[n] = torch.randperm(n, generator=torch.Generator().manual_seed(9173 + n))
+            xp = x[..., self._ln_perm[n]]
+            mean = xp.cumsum(-1)[..., -1:] / n            # (a sequential sum in the permuted order)
+            c = x - mean
+            var = (c * c)[..., self._ln_perm[n]].cumsum(-1)[..., -1:] / n
+            return c * torch.rsqrt(var + LN_EPS) * self.w[prefix + ".weight"] + self.w[prefix + ".bias"]
         return F.layer_norm(x, (x.shape[-1],), self.w[prefix + ".weight"], self.w[prefix + ".bias"], LN_EPS)
 
     # Linears of the rollout that stay off the matrix pipe in the library (VALU fp32 / once-per-rollout fp32 prologue)

@@ -612,3 +612,24 @@ def teardown_module(module):
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     with open(os.path.join(ROOT, "gpurun_out", "configs_report.json"), "w") as f:
         json.dump(REPORT, f, indent=1)
+
+
+@pytest.mark.parametrize("seed,case", [
+    pytest.param(7, 4, marks=pytest.mark.xfail(strict=True, reason="known-outside fuzz draw (profiles/r05_fuzz_summary.txt: 1.7e-4 m vs the oracle's fp32 "
+                                                                     "run at an intermediate step, inside at step 90; the exact-fp32 kernels land in the same place)")),
+    pytest.param(7, 13, marks=pytest.mark.xfail(strict=True, reason="known-outside fuzz draw (profiles/r03_fuzz_case13.txt: steps 65-84 outside the oracle ensemble's "
+                                                                      "1e-3 prediction limit, rank 0/33, the fp32-MFMA twin likewise)")),
+])
+def test_known_outside_fuzz_draws(seed, case):
+    """VERDICT r05 task 4 (b): the two validation draws of the fuzz campaign (FUZZ_SEED=7, cases 4 and 13) that sit OUTSIDE the
+    closed-loop rule against an oracle ensemble measured on the spot -- the same two draws with the same digits in rounds 3, 4 and 5
+    -- lived only in a probe's log.  They are promoted here as strict expected failures: they cannot be forgotten, and they turn into
+    XPASS (= a red suite, strict) the day a change of the arithmetic moves them inside, which then has to be looked at and recorded.
+    Runs the probe itself (tests/probes/gpu_fuzz_validation.py, FUZZ_ONLY: the case is the same case as in a full campaign)."""
+    env = dict(os.environ, FUZZ_SEED=str(seed), FUZZ_ONLY=str(case))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "probes", "gpu_fuzz_validation.py"), str(case + 1)], capture_output=True, text=True,
+                       env=env, timeout=900, cwd=ROOT)
+    tail = "\n".join(r.stdout.strip().splitlines()[-4:])
+    REPORT[f"known_outside_fuzz_draw/seed{seed}_case{case}"] = tail
+    assert f"case {case:2d}" in r.stdout, r.stdout[-500:] + r.stderr[-500:]   # (the draw ran)
+    assert "OUTSIDE" not in r.stdout and r.returncode == 0, tail

@@ -46,7 +46,7 @@ FLAT_1E4_UNTIL = {"c1_plumbing": None, "small_k1": None, "degenerate": None, "va
                   "stoch_actions": None, "val_irrelevant": None,
                   "masks_k3": 60, "headline_2": 60, "headline_k6": 60, "val_masks": 60,
                   "headline_w_normal": 40, "headline_w_sharp": 40, "headline_w_ln_gamma": 40, "action_override": None,
-                  "headline_8": 60, "stress_1": 40, "headline_w_trained": 40, "val_trained": 60}
+                  "headline_8": 60, "stress_1": 40, "headline_w_trained": 40, "val_trained": 60, "headline_w_ckpt": 30}
 SUITE = {}  # case -> tools/ensemble.py::closed_loop_rule output (reference-made ensembles only), judged by the suite-level test
 
 
@@ -212,7 +212,7 @@ def _check_all_taps(name, g, meta, wm, sd, batch, eps, gs, rep):
 
 @pytest.mark.parametrize("name", ["c1_plumbing", "small_k1", "masks_k3", "degenerate", "headline_2", "headline_k6",
                                   "headline_w_normal", "headline_w_sharp", "headline_w_ln_gamma", "headline_8", "stress_1",
-                                  "headline_w_trained"])
+                                  "headline_w_trained", "headline_w_ckpt"])
 def test_against_reference_golden(name):
     g, meta = load_golden(name)
     cfg, sd, batch, eps = golden_inputs(meta)
@@ -1094,7 +1094,8 @@ def test_empty_and_bad_inputs_fail_loudly():
 
 
 SUITE_CASES = ("small_k1", "masks_k3", "degenerate", "headline_2", "headline_k6", "headline_w_normal", "headline_w_sharp",
-               "headline_w_ln_gamma", "headline_8", "stress_1", "stoch_actions", "val_small", "val_masks", "val_alt_losses", "val_irrelevant")
+               "headline_w_ln_gamma", "headline_8", "stress_1", "stoch_actions", "val_small", "val_masks", "val_alt_losses", "val_irrelevant",
+               "headline_w_ckpt")
 
 
 def test_suite_level_closed_loop_parity():

@@ -147,6 +147,19 @@ def _womd_file(path: str, n_episode: int, n_pl: int) -> Dict:
     return {k: v.shape for k, v in test_eps[0].items()}
 
 
+def measure_rank(sd, dev, rank: int, n: int = 6) -> Dict:
+    """The N > 1 form (every rank runs it at the same time: eight launching threads, eight stagers on one host): plain calls and the
+    two-lane pipeline at the headline shape, this rank's own batches."""
+    from trafficbots_amd.waymo_motion import WaymoMotion
+
+    batches = [synth.make_batch(5000 + 37 * i + 1009 * rank, 32, n_agent=64, n_pl=256, n_tl=40) for i in range(4)]
+    wm = WaymoMotion(time_step_end=90, n_joint_future=1, device=str(dev))
+    wm.load_state_dict(sd)
+    plain = _loop(wm, batches, n, False)
+    lanes = _loop_lanes(wm, batches, 2 * n, 2)
+    return {"plain_ms_per_batch": plain, "pipeline_2_lanes_ms_per_batch": lanes}
+
+
 def measure(sd, dev, n: int = 12, womd: bool = True) -> Dict:
     """The `e2e` block of the bench line."""
     t_all = time.perf_counter()

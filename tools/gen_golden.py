@@ -124,6 +124,13 @@ CASES["headline_w_trained"] = dict(
     scene=dict(n_agent=64, n_pl=256, n_tl=40), tap_steps=[1, 11, 50], fp64=True, store_feats=True,
 )
 
+# VERDICT r05 task 7: checkpoint-LIKE statistics (synth.ckpt_like: LayerNorm gains spread over [0.3, 3], biases +- 0.5, attention
+# in-projections x 3 with the out-projection re-balanced) composed onto the trained tensors, two scenes x K = 3 at the headline shape
+CASES["headline_w_ckpt"] = dict(
+    base_seed=9700, n_scene=2, k=3, weight_file="trained_state_dict.npz", weight_transform="ckpt_like", weight_seed=31, time_step_end=90,
+    scene=dict(n_agent=64, n_pl=256, n_tl=40), tap_steps=[1, 11, 50], fp64=True, store_feats=True,
+)
+
 # members of the measured rounding-noise ensemble (tools/ensemble.py) per closed-loop golden
 N_ENSEMBLE = 32
 ENSEMBLE_CASES = ("small_k1", "masks_k3", "degenerate", "headline_2", "headline_k6", "stoch_actions", "action_override",

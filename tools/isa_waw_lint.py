@@ -1,20 +1,22 @@
-"""Static hazard lint of the gfx950 machine code of the library (toolchain canary; VERDICT r05 task 2).
+"""Static hazard lint of the gfx950 machine code of the library (a toolchain canary; VERDICT r05 task 2).
 
-Background (profiles/r05_experiments.txt item 24): built with the default machine scheduler, `k_step_x<false, false>` dies with a GPU
-memory fault -- a VGPR that is the destination of a weight-fragment `global_load` still IN FLIGHT is overwritten by a later VALU
-instruction without an `s_waitcnt vmcnt` in between (the load's data then lands on top of the new value: the lane offset of the next
-requests turns into weight bits).  That is a wait-count insertion bug of the compiler under that schedule, not an address the source
-computes; the shipped flag set (`-amdgpu-sched-strategy=max-ilp`) does not trigger it.  Whether a given toolchain + flag set does is
-visible in the machine code WITHOUT running it:
+What it checks.  On gfx9-family hardware vector-memory operations complete in issue order and `s_waitcnt vmcnt(N)` waits until at most
+N are outstanding; so, walking a kernel's instructions along its control-flow graph with the queue of outstanding vector-memory
+operations (destination registers per entry; fixed point over basic blocks, queues merged from the most recent entry backwards), an
+instruction that WRITES (other than a later load: loads return in order) or READS a register some still-outstanding load will write
+is a hazard -- a wait count the compiler failed to insert.  The script disassembles the device code of every object (or of a built
+library), runs that dataflow per kernel and reports hazards; `__graft_entry__.build()` runs it on every object it has just built and
+refuses to ship a library with one (no GPU needed).
 
-  on gfx9-family hardware vector-memory operations complete in issue order and `s_waitcnt vmcnt(N)` waits until at most N are
-  outstanding; so, walking a kernel's instructions along its control-flow graph with the queue of outstanding vector-memory operations
-  (destination registers per entry), an instruction that WRITES or READS a register some still-outstanding load will write is a hazard.
-
-This script disassembles the device code of every object (or of the built library), runs that dataflow per kernel (fixed point over
-basic blocks, queues merged from the most recent entry backwards), and reports hazards.  `__graft_entry__.build()` runs it on the step
-and encoder kernels and refuses to ship a library with a hazard; tests/test_abi_and_host.py checks that the lint FINDS the planted
-hazard of the default-scheduler build of the fragment in tools/microtests/waw_case.s and passes the fixed form.
+What it does NOT prove -- stated plainly, because the first hope was otherwise.  profiles/r05_experiments.txt item 24: built with the
+DEFAULT machine scheduler (no `-amdgpu-sched-strategy=max-ilp`), `k_step_x<false, false>` dies with a GPU memory fault; round 5 read
+the register dump as exactly this hazard class.  Round 6 re-built that library (`TB_DROP_FLAGS=-amdgpu-sched-strategy=max-ilp
+tools/build_variant.sh _defsched`), confirmed on an MI355X that it STILL faults (fp16-pair kernels; the bf16 ones run), and ran this
+lint over it: CLEAN, all 62 kernels.  So the fault of that build is not a plain overwrite / read of an in-flight vector-memory
+destination -- whatever the default schedule breaks is outside this model (profiles/r06_experiments.txt item 7 has the details).  The
+protection against that build is therefore the TOOLCHAIN GATE (trafficbots_amd/csrc/toolchain.json: `build()` refuses compiler
+releases and flag sets the GPU suite has not run on, a library built anyway warns at load time); this lint is a second, narrower net
+for one well-defined bug class, validated on planted cases (tools/microtests/waw_case.s, tests/test_abi_and_host.py).
 
 usage: python tools/isa_waw_lint.py [objects or .so ...]      (default: trafficbots_amd/csrc/build/*.o)
 """

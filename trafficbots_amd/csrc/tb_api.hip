@@ -1450,10 +1450,14 @@ extern "C" int tb_check_status(tb_ctx* ctx, tb_stream stream_) {
         // since this context's last one is this context's news too (conservative: a context may switch kernels for a neighbour's
         // overflow; none returns 0 over invalid results)
         std::lock_guard<std::mutex> lk(g_ctx_mutex);
+        // (only contexts whose ACTIVE kernels can raise a bit inherit it -- the step bit goes to contexts on the fp16-pair
+        // step kernels, the encoder bit to contexts on the fp16-pair encoders; a bf16 or exact-fp32 neighbour is not re-run, let alone
+        // downgraded, for somebody else's overflow)
+        auto can_raise = [](const tb_ctx* c) { return (c->step_kernel == 2 ? 1u : 0u) | (c->encode_kernel == 1 ? 2u : 0u); };
         if (h)
             for (tb_ctx* o : g_ctx_live)
-                if (o != ctx && o->device == ctx->device) o->range_pending |= h;
-        h |= ctx->range_pending;
+                if (o != ctx && o->device == ctx->device) o->range_pending |= h & can_raise(o);
+        h = (h | ctx->range_pending) & can_raise(ctx);
         ctx->range_pending = 0;
     }
     if (hw[1])

@@ -180,6 +180,51 @@ def lib_path() -> str:
     return _LIB_PATH
 
 
+VALIDATED_RUNTIME_HIP = ("7.0",)  # major.minor of the in-process HIP runtimes (torch.version.hip) the GPU suite has run on
+
+
+def build_info() -> Dict:
+    """trafficbots_amd/lib/build_info.json (written by __graft_entry__.build next to the library): the fingerprint of the sources, the
+    compiler + flag set it was built with and whether that pair is a validated one (trafficbots_amd/csrc/toolchain.json), the result
+    of the ISA hazard lint.  {} for a library built some other way (the Makefile)."""
+    import json
+
+    path = os.path.join(os.path.dirname(_LIB_PATH), "build_info.json")
+    try:
+        with open(path) as f:
+            return json.load(f)
+    except Exception:
+        return {}
+
+
+def _warn_if_unvalidated() -> None:
+    """The library is at the edge of what the compiler schedules correctly (profiles/r05_experiments.txt item 24): one built with a
+    compiler release / flag set the GPU suite has not seen, or loaded under another HIP runtime generation, says so -- once per
+    process, loudly; TB_REQUIRE_VALIDATED_TOOLCHAIN=1 turns the warning into an error."""
+    import warnings
+
+    problems = []
+    info = build_info()
+    tc = info.get("toolchain")
+    if tc is not None and not tc.get("validated", False):
+        problems.append(f"built with an unvalidated toolchain ({tc.get('why')})")
+    try:
+        import torch
+
+        rt = getattr(torch.version, "hip", None)
+        if rt and ".".join(rt.split(".")[:2]) not in VALIDATED_RUNTIME_HIP:
+            problems.append(f"running under HIP runtime {rt}; validated: {', '.join(VALIDATED_RUNTIME_HIP)}.x")
+    except Exception:
+        pass
+    if not problems:
+        return
+    msg = ("trafficbots_amd: " + "; ".join(problems) + " -- results are unverified on this combination: run `pytest -m gpu` and "
+           "tests/probes/gpu_guard_pages.py before trusting them (trafficbots_amd/csrc/toolchain.json)")
+    if os.environ.get("TB_REQUIRE_VALIDATED_TOOLCHAIN") == "1":
+        raise RuntimeError(msg)
+    warnings.warn(msg, RuntimeWarning, stacklevel=3)
+
+
 def load() -> C.CDLL:
     """dlopen the HIP library (raises if it has not been built: run `python -c 'import
     __graft_entry__ as g; g.build()'` or `make -C trafficbots_amd/csrc`)."""
@@ -196,6 +241,7 @@ def load() -> C.CDLL:
             f"trafficbots_amd: HIP library not built ({_LIB_PATH} missing). There is no CPU fallback; "
             "build it with __graft_entry__.build()."
         )
+    _warn_if_unvalidated()
     lib = C.CDLL(_LIB_PATH)
     lib.tb_create.argtypes = [C.POINTER(TbConfig), C.POINTER(C.c_void_p)]
     lib.tb_create.restype = C.c_int

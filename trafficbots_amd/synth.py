@@ -573,8 +573,43 @@ def case_state_dict(case: dict) -> "OrderedDict[str, np.ndarray]":
 
         path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", case["weight_file"])
         z = np.load(path)
-        return OrderedDict((k, np.ascontiguousarray(z[k])) for k in z.files)
+        sd = OrderedDict((k, np.ascontiguousarray(z[k])) for k in z.files)
+        if case.get("weight_transform") == "ckpt_like":
+            sd = ckpt_like(sd, int(case.get("weight_seed", 0)))
+        elif case.get("weight_transform"):
+            raise ValueError(case["weight_transform"])
+        return sd
     return make_state_dict(case["weight_seed"], mode=case.get("weight_mode"))
+
+
+def ckpt_like(sd: "OrderedDict[str, np.ndarray]", seed: int) -> "OrderedDict[str, np.ndarray]":
+    """Checkpoint-like statistics composed onto a stored `state_dict` (VERDICT r05 task 7; round 6 trained the reference for 1 150
+    more optimizer steps at lr 1e-3 and its LayerNorm gains still sat in [0.95, 1.05] -- synthetic episodes carry too little signal to
+    move them -- so the statistics long training produces are imposed instead, deterministically from `seed`):
+      * every LayerNorm gain x a per-channel factor log-uniform in [0.3, 3], every LayerNorm bias + U(-0.5, 0.5);
+      * every attention in-projection (weight and bias: Q, K and V rows) x 3 -- logits x 9, near one-hot softmax rows -- with the
+        out-projection's columns / 3, so that the value path and the residual stream keep their scale (activations stay O(1..100)).
+    Not the same function as the input weights: another network, with non-initial statistics everywhere."""
+    rs = RawStream(seed)
+    out: "OrderedDict[str, np.ndarray]" = OrderedDict()
+    for name in sd:
+        v = np.asarray(sd[name])
+        is_ln = (".norm" in name
+                 or (".mlp_in.fc_layers." in name and name.split(".")[-2] in ("1", "5", "9") and "add_goal" in name)
+                 or ("goal_predictor.mlp.fc_layers." in name and name.split(".")[-2] in ("1", "4")))
+        if is_ln and v.ndim == 1 and v.dtype.kind == "f":
+            u = rs.uniform(-1.0, 1.0, v.shape)
+            v = (v * np.exp(u * math.log(3.0 / 0.3) * 0.5 + 0.5 * math.log(3.0 * 0.3))) if name.endswith("weight") else (v + 0.5 * u)
+        elif "in_proj_weight" in name or "in_proj_bias" in name:
+            v = v * 3.0
+        elif "out_proj.weight" in name:
+            v = v / 3.0
+        out[name] = np.ascontiguousarray(v.astype(sd[name].dtype))
+    for a, tgt in ALIASES.items():  # (aliased tensors stay aliases of their transformed targets)
+        for name in out:
+            if name.startswith(a) and tgt + name[len(a):] in out:
+                out[name] = out[tgt + name[len(a):]]
+    return out
 
 
 def make_latent_perturb(seed: int, n_scene: int) -> Dict[str, np.ndarray]:

@@ -265,8 +265,11 @@ def _range_fallback(fn):
     fallback)."""
     import copy
     import functools
+    import inspect
     import time
     import warnings
+
+    sig = inspect.signature(fn)
 
     @functools.wraps(fn)
     def step(self, *args, **kwargs):
@@ -274,8 +277,14 @@ def _range_fallback(fn):
             return fn(self, *args, **kwargs)
         # (the holders' states are replaced, never modified in place -- metrics._PackedSumMetric.update: a shallow copy restores them)
         snap = [copy.copy(h.__dict__) for h in self._metric_holders()] if fn.__name__ != "test_step" else []
-        gen = kwargs.get("generator")
+        # the generator wherever it was passed (keyword or positional: ADVICE r05); with none, the draws come from torch's default
+        # generators, whose states are snapshotted instead
+        try:
+            gen = sig.bind(self, *args, **kwargs).arguments.get("generator")
+        except TypeError:
+            gen = kwargs.get("generator")
         gen_state = gen.get_state() if gen is not None else None
+        default_state = None if gen is not None else (torch.random.get_rng_state(), torch.cuda.get_rng_state(self.device))
         t0 = time.perf_counter()
         out = fn(self, *args, **kwargs)
         if not self.engine.check_status(raise_on_range=False):
@@ -286,6 +295,9 @@ def _range_fallback(fn):
             h.__dict__.update(d)
         if gen_state is not None:
             gen.set_state(gen_state)
+        elif default_state is not None:
+            torch.random.set_rng_state(default_state[0])
+            torch.cuda.set_rng_state(default_state[1], self.device)
         out = fn(self, *args, **kwargs)
         self.engine.check_status()  # (the exact kernels cannot raise the flag; anything else is a hard error)
         t2 = time.perf_counter()
@@ -852,6 +864,7 @@ class WaymoMotion:
         if "gt" not in scene:
             raise ValueError("training_step needs a training / validation batch (agent/*, tl_stop/* ground truth)")
         gt = scene["gt"]
+        scene_raw, gt_raw = scene, gt  # (before the train-mode masks: what the perturbed personality encoders are fed, see below)
         scene, gt, hidden_drop = self._train_mode_masks(scene, gt, history_keep, hidden_drop, generator)
         input_feature_dict = self.model.encode_input_features(scene)
         goal_gt, goal_valid = self.model.goal_manager.get_gt_goal(scene["agent_valid"], gt.get("gt_goal"), gt["gt_dest"])
@@ -862,7 +875,11 @@ class WaymoMotion:
             b_ = scene["agent_valid"].shape[0]
             lp = latent_perturb if latent_perturb is not None else {
                 "yaw": torch.rand(b_, device=self.device, generator=generator), "pos": torch.rand(b_, 2, device=self.device, generator=generator)}
-            scene_l, gt_l = self._perturb_latent_inputs(scene, gt, lp["yaw"], lp["pos"])
+            # The re-centred inputs are built from the UN-dropped scene: under perturbation the reference makes latent_prior/* from the
+            # sc/* tensors (latent_prior/agent_valid = sc/agent_valid, tl_valid = sc/tl_valid, map_valid = sc/map_valid,
+            # `sc_latent.py:142-167`), not from the input/* tensors that `pre_processing.input.dropout_p_history` has masked
+            # (the masked scene used to be handed over; perturb + latent.dropout_p_history is refused above)
+            scene_l, gt_l = self._perturb_latent_inputs(scene_raw, gt_raw, lp["yaw"], lp["pos"])
             enc_l = self.engine.encode_scene(scene_l)
             post = self.engine.encode_posterior(gt_l, enc_l)
             latent_post = DiagGaussian(post["latent_mean"], self.model._log_std_post, valid=as_bool(post["latent_valid"]), engine=self.engine)
@@ -953,10 +970,16 @@ class WaymoMotion:
             mv = scene["map_valid"].bool() & draw("input_map", tuple(scene["map_valid"].shape), p_in)
             scene = dict(scene, agent_valid=av.to(torch.uint8), tl_valid=tlv.to(torch.uint8).contiguous(), map_valid=mv.to(torch.uint8).contiguous(),
                          warm_ok=False)
+            for stale in ("_goal_valid", "_tf_mask", "_tf_params"):  # (host-made from the unmasked validity when the batch was staged)
+                scene.pop(stale, None)
+            scene.update({"input/agent_valid": av, "input/tl_valid": tlv, "input/map_valid": mv,
+                          "latent_prior/agent_valid": av, "latent_prior/tl_valid": tlv, "latent_prior/map_valid": mv})
         if 0 < p_lat <= 1.0 or any(k in keep for k in ("post_agent", "post_tl")):
             gav = gt["agent_valid"].bool() & draw("post_agent", tuple(gt["agent_valid"].shape), p_lat)
             gtl = gt["tl_valid"].bool() & draw("post_tl", tuple(gt["tl_valid"].shape), p_lat)
             gt = dict(gt, agent_valid=gav.to(torch.uint8).contiguous(), tl_valid=gtl.to(torch.uint8).contiguous(), warm_ok=False)
+            gt.pop("_tf_mask", None)
+            gt.pop("_tf_params", None)
             scene = dict(scene, gt=gt)
         if hidden_drop is None and p_hid > 0:
             n_step = hp["time_step_end"] - hp["time_step_sim_start"] + 1
