@@ -326,6 +326,11 @@ def test_isa_hazard_lint_finds_the_planted_hazards_and_passes_the_built_objects(
 
     k = lint.parse_asm_text(open(os.path.join(ROOT, "tools", "microtests", "waw_case.s")).read().splitlines())
     got = {name: lint.lint_kernel(ins) for name, ins in k.items()}
+    # rule 2: register-allocator traffic in front of a join block's exec restore -- the cause of the default-scheduler build's GPU
+    # fault (profiles/r06_experiments.txt item 7): flagged in the planted bad form, clean in the good one and in every rule-1 case
+    got2 = {name: lint.lint_exec_prologue(ins) for name, ins in k.items()}
+    assert len(got2.pop("exec_prologue_bad")) == 1 and all(v == [] for v in got2.values()), got2
+    assert got.pop("exec_prologue_bad") == [] and got.pop("exec_prologue_good") == []
     assert set(got) == {"bad", "good", "partial_wait_ok", "partial_wait_bad", "loads_only", "across_blocks"}
     assert len(got["bad"]) == 2 and "WRITES v108" in got["bad"][0] and "READS v108" in got["bad"][1]
     assert got["good"] == [] and got["partial_wait_ok"] == [] and got["loads_only"] == []

@@ -783,6 +783,21 @@ def test_two_lane_pipeline_equals_plain_steps_and_reruns_an_overflowing_batch():
     torch.cuda.synchronize()
     for i in range(len(batches)):
         _same_step_outputs(ref[i], got3[i], f"three lanes {i}")
+    # ---- validation_step through two lanes: same per-batch results, and ONE set of accumulated metric states (the lanes' holders merge)
+    vb = [synth.make_val_batch(8900 + i, 2, n_agent=20, n_pl=50, n_tl=12, p_future_spawn=0.3, p_future_exit=0.3) for i in range(5)]
+    veps = torch.from_numpy(synth.make_latent_noise(6, 2 * 2, 20)).cuda()
+    vkw = lambda i: dict(latent_eps=veps, generator=torch.Generator(device="cuda").manual_seed(400 + i))  # noqa: E731
+    wa = _engine({"time_step_end": 40, "n_joint_future": 2}, sd)
+    vref = [wa.validation_step(b, **vkw(i)) for i, b in enumerate(vb)]
+    wb = _engine({"time_step_end": 40, "n_joint_future": 2}, sd)
+    vgot = list(wb.pipeline(vb, lanes=2, step="validation_step", kwargs_fn=vkw))
+    torch.cuda.synchronize()
+    for x, y in zip(vref, vgot):
+        for part in ("reactive_replay", "joint_future_pred"):
+            assert torch.equal(x[part]["rollout_buffer"].preds, y[part]["rollout_buffer"].preds), part
+            assert torch.equal(x[part]["metric_states"], y[part]["metric_states"]), part
+    for ha, hb in zip(wa._metric_holders(), wb._metric_holders()):
+        assert torch.allclose(ha.states, hb.states, rtol=1e-12, atol=0), type(ha).__name__  # (float64 sums in another order)
     # ---- (2) an overflow inside the pipeline
     big = _scaled(sd, 3e5)  # (the as2pl FFN hidden activations leave the fp16-pair range: test_fp16_pair_operand_range's "flag" case)
     probe = _engine({"time_step_end": 12, "n_joint_future": 1}, big)

@@ -182,8 +182,13 @@ def test_config3_k6_bf16_at_batch_32():
     wm = _wm(time_step_end=90, n_joint_future=6)
     wm.load_state_dict(sd)
     o = wm.test_step(batch, latent_eps=eps_t, generator=torch.Generator(device="cuda").manual_seed(5))
-    goal = o["goal_sample"]                       # [B,A,K]; both precisions follow the same sampled destinations
+    goal = o["goal_sample"].clone()               # [B,A,K]; both precisions follow the same sampled destinations ...
+    # ... and scene 0 follows the GOLDEN's destinations (round 6, VERDICT r05 weak #10: with the HIP sampler's own draws only 18 % of
+    # scene 0's (agent, future) pairs had the golden's destination and the others perturbed everyone through the interaction block:
+    # the reported 0.2 m "distance to the reference" at step 90 read like a parity failure and was none)
+    goal[:1] = torch.from_numpy(g["goal_sample"]).to(goal)
     gs = goal.transpose(1, 2).contiguous().cpu()  # [B,K,A]
+    o = wm.test_step(batch, latent_eps=eps_t, goal_sample=gs)
     outs["fp32"] = o["rollout_buffer"]
     wm = _wm(time_step_end=90, n_joint_future=6, operand_precision="bf16")
     wm.load_state_dict(sd)
@@ -208,17 +213,24 @@ def test_config3_k6_bf16_at_batch_32():
            "dest_reached_mismatch_frac": float((a.violations["dest_reached"] != b.violations["dest_reached"]).float().mean())}
     # scene 0 against the reference golden (fp32 HIP run: the closed-loop envelope; bf16: reported)
     gp, gv = torch.from_numpy(g["preds"]).cuda(), torch.from_numpy(g["valid"]).cuda()
-    # (the destinations of scene 0 are the HIP sampler's draws, not the golden's: compare the futures where they agree --
-    # future 0, the argmax, always does unless two logits nearly tie)
-    same = torch.from_numpy(g["goal_sample"]).cuda() == goal[:1]            # [1,A,K]
-    m = (gv & same.unsqueeze(-1))
-    rep["scene0_dest_agree_frac"] = float(same.float().mean())
+    # (scene 0 ran with the golden's destinations and latent draws: the whole trajectory is comparable, and the fp32-accurate run is
+    # held to the closed-loop rule of the parity tests on it -- scene 0 inside a 32-scene, 1152-tile LEAN launch)
+    from tools import ensemble
+
     for t in (11, 30, 60, 90):
-        mt = m[..., t - 1, None]
+        mt = gv[..., t - 1, None]
         rep[f"scene0_fp32_vs_reference_xy_step{t}"] = float(((a.preds[:1] - gp)[..., t - 1, :2].abs() * mt).max())
         rep[f"scene0_bf16_vs_reference_xy_step{t}"] = float(((b.preds[:1] - gp)[..., t - 1, :2].abs() * mt).max())
+    p0 = a.preds[:1].cpu().numpy()
+    both = (g["valid"] & g["valid_fp64"])[..., None]
+    d32 = (np.abs(p0 - g["preds"]) * g["valid"][..., None])[..., :2].max(axis=(0, 1, 2, 4))
+    d64 = (np.abs(p0.astype(np.float64) - g["preds_fp64"]) * both)[..., :2].max(axis=(0, 1, 2, 4))
+    e = np.load(os.path.join(ROOT, "tests", "golden", "ensg", "headline_k6.npz"))
+    r = ensemble.closed_loop_rule(d32, d64, e["ensg_d32"], e["ensg_d64"], 60)
+    rep["scene0_fp32_rule"] = {k_: v_ for k_, v_ in r.items() if k_ != "per_step"}
     REPORT["config3_k6_bf16"] = rep
     assert rep["scene0_fp32_vs_reference_xy_step11"] <= 1e-4
+    assert r["ok"], rep["scene0_fp32_rule"]
 
 
 @pytest.mark.parametrize("prec", ["bf16", "fp32"])
@@ -633,3 +645,23 @@ def test_known_outside_fuzz_draws(seed, case):
     REPORT[f"known_outside_fuzz_draw/seed{seed}_case{case}"] = tail
     assert f"case {case:2d}" in r.stdout, r.stdout[-500:] + r.stderr[-500:]   # (the draw ran)
     assert "OUTSIDE" not in r.stdout and r.returncode == 0, tail
+
+
+def test_default_scheduler_build_runs():
+    """VERDICT r05 task 2 (b) / (c): the library built WITHOUT `-amdgpu-sched-strategy=max-ilp` (`__graft_entry__.build_defsched`: same
+    sources, the compiler's default machine scheduler) used to die with a GPU memory fault in `k_step_x<false, false>` -- the register
+    allocator parked a whole-wave VGPR in an AGPR in front of the exec restore of the divergent `if (tid == 0)` poll of the GRU
+    helper's flag (profiles/r06_experiments.txt item 7; tools/isa_waw_lint.py rule 2 flags that placement).  The poll is wave-uniform
+    now.  In a SUBPROCESS (a fault would take the process down): two closed-loop goldens against the reference and the guard-page test
+    (every caller buffer and every workspace carve between unmapped pages) on that build."""
+    lib = os.path.join(ROOT, "trafficbots_amd", "lib", "libtrafficbots_hip_defsched.so")
+    if not os.path.exists(lib):
+        pytest.skip("no default-scheduler build in this checkout (python -c 'import __graft_entry__ as g; g.build()' makes it)")
+    env = dict(os.environ, TB_HIP_LIB=lib)
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_parity.py"), os.path.join(ROOT, "tests", "test_gpu_boundary.py"),
+                        "-q", "-m", "gpu", "-p", "no:cacheprovider", "-x",
+                        "-k", "(against_reference_golden and (headline_2 or small_k1 or headline_k6)) or no_access_outside"],
+                       capture_output=True, text=True, env=env, timeout=1500, cwd=ROOT)
+    tail = "\n".join(r.stdout.strip().splitlines()[-6:])
+    REPORT["default_scheduler_build"] = tail
+    assert r.returncode == 0 and " passed" in tail and "failed" not in tail, tail + r.stderr[-1500:]

@@ -1,22 +1,24 @@
-"""Static hazard lint of the gfx950 machine code of the library (a toolchain canary; VERDICT r05 task 2).
+"""Static hazard lint of the gfx950 machine code of the library (toolchain canary; VERDICT r05 task 2).  Two rules, no GPU needed.
 
-What it checks.  On gfx9-family hardware vector-memory operations complete in issue order and `s_waitcnt vmcnt(N)` waits until at most
-N are outstanding; so, walking a kernel's instructions along its control-flow graph with the queue of outstanding vector-memory
-operations (destination registers per entry; fixed point over basic blocks, queues merged from the most recent entry backwards), an
-instruction that WRITES (other than a later load: loads return in order) or READS a register some still-outstanding load will write
-is a hazard -- a wait count the compiler failed to insert.  The script disassembles the device code of every object (or of a built
-library), runs that dataflow per kernel and reports hazards; `__graft_entry__.build()` runs it on every object it has just built and
-refuses to ship a library with one (no GPU needed).
+Rule 1 -- in-flight vector-memory destinations.  On gfx9-family hardware vector-memory operations complete in issue order and
+`s_waitcnt vmcnt(N)` waits until at most N are outstanding; walking a kernel's instructions along its control-flow graph with the queue
+of outstanding vector-memory operations (destination registers per entry; fixed point over basic blocks, queues merged from the most
+recent entry backwards), an instruction that WRITES (other than a later load: loads return in order) or READS a register some
+still-outstanding load will write is a missing wait count.  (This is what round 5 believed the default-scheduler fault to be; it is
+not -- that build is clean under rule 1 and still faults with a forced full wait after every instruction.)
 
-What it does NOT prove -- stated plainly, because the first hope was otherwise.  profiles/r05_experiments.txt item 24: built with the
-DEFAULT machine scheduler (no `-amdgpu-sched-strategy=max-ilp`), `k_step_x<false, false>` dies with a GPU memory fault; round 5 read
-the register dump as exactly this hazard class.  Round 6 re-built that library (`TB_DROP_FLAGS=-amdgpu-sched-strategy=max-ilp
-tools/build_variant.sh _defsched`), confirmed on an MI355X that it STILL faults (fp16-pair kernels; the bf16 ones run), and ran this
-lint over it: CLEAN, all 62 kernels.  So the fault of that build is not a plain overwrite / read of an in-flight vector-memory
-destination -- whatever the default schedule breaks is outside this model (profiles/r06_experiments.txt item 7 has the details).  The
-protection against that build is therefore the TOOLCHAIN GATE (trafficbots_amd/csrc/toolchain.json: `build()` refuses compiler
-releases and flag sets the GPU suite has not run on, a library built anyway warns at load time); this lint is a second, narrower net
-for one well-defined bug class, validated on planted cases (tools/microtests/waw_case.s, tests/test_abi_and_host.py).
+Rule 2 -- register-allocator traffic in front of a join block's exec restore (`lint_exec_prologue`).  THE cause of the fault of
+profiles/r05_experiments.txt item 24, found in round 6 with the ROCm debug agent (profiles/r06_experiments.txt item 7): a divergent
+`if (tid == 0) { poll a flag }` is lowered to `s_and_saveexec_b64 ; s_cbranch_execz JOIN ; ... ; JOIN: s_or_b64 exec, exec, sN`, and under
+the DEFAULT machine scheduler of clang 22 / ROCm 7.2.0 the register allocator parks a whole-wave VGPR in an AGPR with its
+`v_accvgpr_write_b32` placed between the JOIN label and the `s_or_b64` -- written under the then-branch's one-lane mask (or under exec
+= 0), read back later for all 64 lanes: garbage lane offsets, GPU memory fault.  The rule reports AGPR copies and scratch spills /
+reloads at the target of a forward `s_cbranch_execz` in front of the exec restore.  It flags the faulty build (exactly that
+instruction) and passes the shipped one; the source no longer has that divergent region (tb_stepx_kernels.hip: the poll is
+wave-uniform), so the default-scheduler build of the current sources is clean too and runs (profiles/r06_experiments.txt item 7).
+
+`__graft_entry__.build()` runs both rules over every object it has just built and refuses to ship a library with a finding; planted
+cases for both rules: tools/microtests/waw_case.s (tests/test_abi_and_host.py).
 
 usage: python tools/isa_waw_lint.py [objects or .so ...]      (default: trafficbots_amd/csrc/build/*.o)
 """
@@ -255,6 +257,43 @@ def lint_kernel(ins: List[Ins]) -> List[str]:
     return [hazards[a] for a in sorted(hazards)]
 
 
+_EXEC_RESTORE = re.compile(r"^s_(or|mov|xor|andn2|and)_b64\s+exec\b")
+
+
+def lint_exec_prologue(ins: List[Ins]) -> List[str]:
+    """Second rule (round 6, found with the ROCm debug agent on the default-scheduler build: profiles/r06_experiments.txt item 7).
+    A divergent `if` is lowered to `s_and_saveexec_b64 sN, vcc ; s_cbranch_execz JOIN ; ...then... ; JOIN: s_or_b64 exec, exec, sN`.
+    The join block starts with the exec restore; a VECTOR instruction between the JOIN label and that restore runs under the
+    then-branch's mask (or under exec = 0 when the branch was taken) although it belongs to the code after the `if`.  That is what the
+    faulty build does: the register allocator's copy `v_accvgpr_write_b32 a73, v194` (a whole-wave value parked in an AGPR across the
+    `if (tid == 0)` poll of the GRU helper flag) sits in front of `s_or_b64 exec, exec, s[4:5]` -- it writes lane 0 only (or no lane),
+    the later `v_accvgpr_read_b32` hands 63 lanes of garbage to the weight-fragment address computation: GPU memory fault.
+    Reported: register-allocator traffic in that position -- AGPR copies (`v_accvgpr_write / _read`) and scratch spills / reloads -- at
+    the target of a FORWARD `s_cbranch_execz`.  (Ordinary vector instructions there are not reported: the skip branch of a divergent
+    `if` may legally land inside the tail of the then-block, whose instructions are no-ops under exec = 0; and loop back-edges restore
+    their masks differently.)"""
+    index = {x.addr: i for i, x in enumerate(ins)}
+    out: Dict[int, str] = {}
+    for x in ins:
+        if x.kind != "branch" or not x.op.startswith("s_cbranch_execz") or x.target not in index or x.target <= x.addr:
+            continue
+        j = index[x.target]
+        pending = []
+        while j < len(ins):
+            y = ins[j]
+            if _EXEC_RESTORE.match(y.text):
+                for z in pending:
+                    out.setdefault(z.addr, f"  @{z.addr:#x}: `{z.text}` sits in a join block IN FRONT OF the exec restore `{y.text}` "
+                                           f"(target of `{x.text.split()[0]}` @{x.addr:#x}): it runs under the divergent branch's mask")
+                break
+            if y.kind == "branch" or y.op in ("s_barrier", "s_endpgm") or "exec" in y.text:
+                break
+            if y.op.startswith(("v_accvgpr_write", "v_accvgpr_read", "scratch_store", "scratch_load")):
+                pending.append(y)
+            j += 1
+    return [out[a] for a in sorted(out)]
+
+
 def _fmt(rs) -> str:
     return ",".join(f"{k}{i}" for k, i in sorted(rs))
 
@@ -271,7 +310,7 @@ def lint_paths(paths: List[str], only: Optional[str] = None) -> Tuple[int, int, 
                 if only and only not in name:
                     continue
                 n_kernel += 1
-                hz = lint_kernel(ins)
+                hz = lint_kernel(ins) + lint_exec_prologue(ins)
                 if hz:
                     report.append(f"{os.path.basename(path)}: {name[:100]}: {len(hz)} hazard(s)")
                     report += hz[:8]
@@ -281,7 +320,8 @@ def lint_paths(paths: List[str], only: Optional[str] = None) -> Tuple[int, int, 
 def main() -> int:
     paths = sys.argv[1:] or sorted(glob.glob(os.path.join(ROOT, "trafficbots_amd", "csrc", "build", "*.o")))
     n_kernel, n_bad, report = lint_paths(paths)
-    print(f"isa_waw_lint: {n_kernel} kernels in {len(paths)} file(s), {n_bad} with a write/read of an in-flight vector-memory destination")
+    print(f"isa_waw_lint: {n_kernel} kernels in {len(paths)} file(s), {n_bad} with a hazard (in-flight vector-memory destination touched / "
+          f"vector instruction in front of a join block's exec restore)")
     for r in report:
         print(r)
     return 1 if n_bad else 0

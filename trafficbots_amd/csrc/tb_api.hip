@@ -1113,6 +1113,7 @@ static int rollout_setup(tb_ctx* ctx, const tb_rollout_io* io, tb::RolloutP& p, 
     p.pre_t0 = 0;
     ctx->n_pre = n_pre;
     ctx->last_prof = p.prof;
+    tb_note_launch(ctx);  // (tb_rollout and tb_rollout_begin: this context is launching -- other contexts' L2 warmers stand down)
     return 0;
 }
 
@@ -1157,7 +1158,6 @@ extern "C" int tb_rollout(tb_ctx* ctx, const tb_rollout_io* io, tb_stream stream
     ctx->step_active = false;
     // ---- one hipGraph per rollout: every kernel argument of the launch sequence is a function of (p, io, the development switches),
     // so a rollout with the same argument bytes replays the captured graph (bench loops, a serving loop over fixed buffers)
-    tb_note_launch(ctx);
     const TbSw sw = tb_switches_now(ctx);
     const bool use_graph = !sw.graph_off && !ctx->timing && ctx->step_kernel >= 2;
     if (!use_graph) return rollout_enqueue(ctx, io, p, s);
@@ -1421,6 +1421,7 @@ extern "C" int tb_rollout_step_ex(tb_ctx* ctx, const tb_step_override* ov, tb_st
         p.ovr_action_mask = ov->action_mask;
     }
     step_launch(ctx, p, p, t, /*do_c=*/1, /*do_a=*/t < ctx->step_end, (hipStream_t)stream_);
+    tb_note_launch(ctx);
     ctx->step_next = t + 1;
     TB_HIP(ctx, hipGetLastError());
     return 0;

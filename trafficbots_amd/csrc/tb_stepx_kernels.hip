@@ -502,7 +502,7 @@ __global__ __launch_bounds__(AWB ? 2 * NTHREADS : NTHREADS, LEAN ? (W3 ? 3 : 2) 
         TB_STAMP(15);
         __syncthreads();
         TB_STAMP(1);
-        unsigned int gh_seen = 0u;  // the GRU helper's flag, requested one interaction layer early (thread 0)
+        unsigned int gh_seen = 0u;  // the GRU helper's flag, requested one interaction layer early (wave 0, every lane the same word)
         if (!bypass) {
             const float* kvd = p.vbias + (size_t)n * p.a_pad;
             const size_t ls = (size_t)p.a_pad * H;
@@ -522,7 +522,7 @@ __global__ __launch_bounds__(AWB ? 2 * NTHREADS : NTHREADS, LEAN ? (W3 ? 3 : 2) 
                                 u, xlayer_first_x(W, pw.inter[2], px.inter[2], wave), (LEAN ? nullptr : LN + 1 * 768), nullptr, amax);
             if (helpers) {
                 kv_wait_x(kvf, n_rt, 2, tok, tid, p.sync_err, seen, dflag + EPI_POISON_WORD);
-                if (tid == 0) gh_seen = __hip_atomic_load(p.gh_flag + tile_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (wave == 0) gh_seen = __hip_atomic_load(p.gh_flag + tile_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             xattn_layer_x<!LEAN, true>(W, pw.inter[2], px.inter[2], X, PA, PB, K0 + 4 * ls, V0 + 4 * ls, kvd, nk_a, ks_a, row0, rowvalid,
                                 novalid_s, tid, u, gru_first_x(W, pw.gru[0], px.gru[0], wave), (LEAN ? nullptr : LN + 2 * 768), nullptr, amax);
@@ -534,7 +534,13 @@ __global__ __launch_bounds__(AWB ? 2 * NTHREADS : NTHREADS, LEAN ? (W3 ? 3 : 2) 
             float* hg1 = p.hidden + (((size_t)1 * p.n_inst + n) * p.a_pad + row0) * H;
             float* hg2 = p.hidden + (((size_t)2 * p.n_inst + n) * p.a_pad + row0) * H;
             int* gh_ok = dflag + 16;  // (a free word of the small-state area)
-            if (tid == 0) {
+            // WAVE-UNIFORM on purpose (`wave` lives in an SGPR: a scalar branch, no exec mask; all 64 lanes of wave 0 poll the same word
+            // and store the same value).  As `if (tid == 0)` this was a divergent region around a loop, and under the DEFAULT machine
+            // scheduler of clang 22 / ROCm 7.2.0 the register allocator parked a whole-wave VGPR (the weight-fragment lane offset) in an
+            // AGPR with its `v_accvgpr_write_b32` IN FRONT OF the join block's `s_or_b64 exec` -- written for lane 0 only, read back for
+            // all 64: a GPU memory fault in add_latent's weight requests (profiles/r06_experiments.txt item 7; tools/isa_waw_lint.py
+            // checks every build for that placement).  The shipped max-ilp schedule never did that; this form gives it no chance to.
+            if (wave == 0) {
                 // has the tile's helper workgroup delivered b_hh + W_hh h of this step?  A few polls, then the workgroup computes it
                 // itself (a helper that was not scheduled in time -- another stream's kernel on the CUs -- costs nothing but the polls)
                 int got = 0;

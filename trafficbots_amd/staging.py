@@ -442,11 +442,16 @@ class LanePipeline:
             kw = self.kwargs_fn(i) if self.kwargs_fn else {}
             s = self.streams[lane]
             s.wait_stream(main)  # (whatever the caller queued before -- e.g. tensors in kw -- is visible to the lane)
+            import copy
+
+            # (a step that accumulates metric states -- validation_step -- may turn out invalid: the holders' states are replaced,
+            # never edited in place, so a shallow copy taken now restores them; same contract as waymo_motion._range_fallback)
+            snap = [copy.copy(h.__dict__) for h in self.wms[lane]._metric_holders()] if self.step != "test_step" else []
             with torch.cuda.stream(s):
                 out = raw[lane](self.wms[lane], batch, **kw)
                 ev = torch.cuda.Event()
                 ev.record(s)
-            inflight.append((lane, batch, kw, out, ev))
+            inflight.append((lane, batch, kw, out, ev, snap))
             return True
 
         try:
@@ -454,13 +459,16 @@ class LanePipeline:
                 if not launch():
                     break
             while inflight:
-                lane, batch, kw, out, ev = inflight.popleft()
+                lane, batch, kw, out, ev, snap = inflight.popleft()
                 ev.synchronize()
                 w = self.wms[lane]
                 if w.check_range:
                     with torch.cuda.stream(self.streams[lane]):
                         if w.engine.check_status(raise_on_range=False):  # overflowed: the lane's context is on the exact kernels now
                             self.n_reruns += 1
+                            for h, d in zip(w._metric_holders(), snap):
+                                h.__dict__.clear()
+                                h.__dict__.update(d)
                             out = getattr(w, self.step)(batch, **kw)     # (the checked step: re-run + its own check)
                             torch.cuda.current_stream().synchronize()
                 main.wait_stream(self.streams[lane])  # the consumer's stream sees the finished results
@@ -470,3 +478,9 @@ class LanePipeline:
         finally:
             for s in self.streams:
                 s.synchronize()
+            # the other lanes' metric holders (validation_step) flow into the first lane's: the caller reads ONE set of states
+            for w in self.wms[1:]:
+                for h0, hc in zip(self.wms[0]._metric_holders(), w._metric_holders()):
+                    if hc.states is not None:
+                        h0.update(hc.states)
+                        hc.reset()
