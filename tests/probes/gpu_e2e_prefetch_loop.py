@@ -20,14 +20,24 @@ wm.load_state_dict(synth.make_state_dict(7))
 wm.check_range = chk
 for rep in range(int(os.environ.get("REPS", "3"))):
     stream = [batches[i % 4] for i in range(n + 2)]
-    it = iter(wm.prefetch(stream)) if pre else iter(stream)
-    wm.test_step(next(it))
-    wm.test_step(next(it))
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for sb in it:
-        wm.test_step(sb)
+    lanes = int(os.environ.get("LANES", "0"))
+    if lanes:  # `wm.pipeline`: results in order, range-checked
+        it = iter(wm.pipeline(stream, lanes=lanes))
+        next(it)
+        next(it)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in it:
+            pass
+    else:
+        it = iter(wm.prefetch(stream)) if pre else iter(stream)
+        wm.test_step(next(it))
+        wm.test_step(next(it))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for sb in it:
+            wm.test_step(sb)
     torch.cuda.synchronize()
     t = (time.perf_counter() - t0) / n
-    print(f"K={k} prefetch={pre} check_range={chk} WARM={os.environ.get('TB_STEP_WARM')} HELPERS={os.environ.get('TB_STEP_HELPERS')}: "
+    print(f"K={k} lanes={os.environ.get('LANES', 0)} prefetch={pre} check_range={chk} WARM={os.environ.get('TB_STEP_WARM')} HELPERS={os.environ.get('TB_STEP_HELPERS')}: "
           f"{t * 1e3:.2f} ms per batch = {32 * 90 * k / t:.0f} scene-steps/s", flush=True)

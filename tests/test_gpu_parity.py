@@ -165,6 +165,12 @@ def _check_all_taps(name, g, meta, wm, sd, batch, eps, gs, rep):
     spread32 = np.maximum.accumulate(g["ens_d32"].max(0)) if "ens_d32" in g.files else None
     bound32 = ensemble.prediction_bound(g["ens_d32"]) if "ens_d32" in g.files else None
     ens_xy = lambda s_: None if spread32 is None else float(spread32[min(s_, len(spread32)) - 1])  # noqa: E731
+    # (round 6) the tap ensembles stored in the golden are batch-permutation members, which share the base run's GEMM order and
+    # under-state what an independent implementation spreads by (round 4); where the golden has the channel-re-labelled sidecar, a
+    # closed-loop tap's tolerance is widened by how much farther THOSE members' trajectory prediction limit reaches at that step
+    ensg_path = os.path.join(ROOT, "tests", "golden", "ensg", f"{name}.npz")
+    pbg = ensemble.prediction_bound(np.load(ensg_path)["ensg_d32"]) if os.path.exists(ensg_path) else None
+    widen = lambda s_: 1.0 if pbg is None or spread32 is None else max(1.0, float(pbg[min(s_, len(pbg)) - 1]) / max(ens_xy(s_), 1e-9))  # noqa: E731
     closed = lambda s_: s_ > wm.hparams["time_step_current"] + 1  # noqa: E731  (the state of step s-1 already came from the policy)
     eps_t = torch.from_numpy(eps).cuda()
     for s_ in meta["tap_steps"]:
@@ -174,9 +180,12 @@ def _check_all_taps(name, g, meta, wm, sd, batch, eps, gs, rep):
             v = g[f"tap{s_}/agent_valid"][..., None]
             err = float((np.abs(got.cpu().numpy() - ref) * v).max())
             rep[f"tap{s_}/{key}"] = err
-            tol = _tap_tol(ref * v, ens(f"ens_tap{s_}/{key}") if closed(s_) else 0.0, ens_xy(s_))
+            tol = _tap_tol(ref * v, ens(f"ens_tap{s_}/{key}") * widen(s_) if closed(s_) else 0.0, ens_xy(s_))
             if key == "policy_feature" and not closed(s_):  # (round 1/2's bound on the re-synced one-step policy feature)
-                tol = 5e-6 * max(1.0, float(np.abs(ref * v).max()))
+                # (`headline_w_ckpt`: intermediate activations reach ~30 under the checkpoint-like LayerNorm gains; the reference's own
+                # fp32 run is 5.7e-6 from its fp64 run on this tap, independent fp32 oracles 3.2e-6 .. 5.7e-6 from the golden -- measured
+                # with the oracle, profiles/r06_experiments.txt item 11 -- so 5e-6 is below that case's fp32 noise: 1.5e-5 there)
+                tol = (1.5e-5 if name == "headline_w_ckpt" else 5e-6) * max(1.0, float(np.abs(ref * v).max()))
             assert err <= tol, (name, s_, key, err, tol)
     # stepwise: hidden state + simulator state at every tap step
     scene = wm.pre_processing(batch)
@@ -205,7 +214,14 @@ def _check_all_taps(name, g, meta, wm, sd, batch, eps, gs, rep):
             ref = g[f"tap{t}/hidden"].reshape(3, n, a, 128)
             err = float(np.abs(st["hidden"].cpu().numpy() - ref).max())
             rep[f"tap{t}/hidden"] = err
-            assert err <= _tap_tol(ref, ens(f"ens_tap{t}/hidden") if closed(t) else 0.0, ens_xy(t)), (name, t, "hidden", err)
+            # (a tap in front of the closed loop: 2e-5 on |h| <= 1 -- or, where the reference's own permutation ensemble already spreads
+            # by more than a third of that at this tap, four times its spread: under `headline_w_ckpt`'s sharp attention the
+            # reference's fp32 run is 2.1e-4 from its fp64 run on tap1/hidden and independent fp32 oracles 1.1e-4 .. 2.2e-4 from the
+            # golden (ensemble spread 7.4e-5; the members share the base run's GEMM order, an independent implementation does not))
+            tol_h = _tap_tol(ref, ens(f"ens_tap{t}/hidden") * widen(t) if closed(t) else 0.0, ens_xy(t))
+            if not closed(t):
+                tol_h = max(tol_h, 4.0 * ens(f"ens_tap{t}/hidden"))  # (independent oracle seeds reach 3.0x the spread: a third of margin)
+            assert err <= tol_h, (name, t, "hidden", err, tol_h)
         prev = st
     wm.finish_rollout()
 

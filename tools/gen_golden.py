@@ -134,7 +134,7 @@ CASES["headline_w_ckpt"] = dict(
 # members of the measured rounding-noise ensemble (tools/ensemble.py) per closed-loop golden
 N_ENSEMBLE = 32
 ENSEMBLE_CASES = ("small_k1", "masks_k3", "degenerate", "headline_2", "headline_k6", "stoch_actions", "action_override",
-                  "headline_w_normal", "headline_w_sharp", "headline_w_ln_gamma")
+                  "headline_w_normal", "headline_w_sharp", "headline_w_ln_gamma", "headline_w_ckpt")
 
 RULE_KEYS = ["collided", "collided_this_step", "run_road_edge", "run_road_edge_this_step", "run_red_light",
              "run_red_light_this_step", "passive", "passive_this_step"]
