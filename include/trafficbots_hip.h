@@ -89,6 +89,13 @@ int tb_check_status(tb_ctx* ctx, tb_stream stream);
  * bit 1: a run-time activation overflow, seen by tb_check_status).  tb_precision_note: the sentence naming the tensor / stage. */
 int tb_precision_state(tb_ctx* ctx, int32_t out[3]);
 const char* tb_precision_note(tb_ctx* ctx);
+/* Back to the kernels tb_finalize_weights selected after a RUN-TIME fallback (tb_check_status returned 3; reason bit 1): both
+ * operand packings of every weight live in the arena, so this is a state change, no upload and no synchronisation.  For the caller
+ * whose overflow was ONE outlier batch: re-issue that batch on the exact-fp32 kernels, then call this and continue at full speed (the
+ * host mirror does it: WaymoMotion.fallback_policy).  A context whose LOADED tensors are outside the range (reason bit 0) stays on
+ * the exact kernels; a context that has not fallen back is left alone.  Closes an open stepwise rollout (tb_rollout_begin again).
+ * Returns 0; out_changed (may be NULL) = 1 when the kernel selection changed. */
+int tb_precision_restore(tb_ctx* ctx, int32_t* out_changed);
 /* Version / build info string (static storage). */
 const char* tb_version(void);
 

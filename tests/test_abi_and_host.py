@@ -381,3 +381,28 @@ def test_toolchain_gate_refuses_unvalidated_compilers_and_flags(monkeypatch):
     monkeypatch.setenv("TB_REQUIRE_VALIDATED_TOOLCHAIN", "1")
     with pytest.raises(RuntimeError, match="unvalidated toolchain"):
         hip._warn_if_unvalidated()
+
+
+def test_warm_schedule_is_generated_from_the_committed_stage_profile():
+    """VERDICT r05 task 6: the L2 warmers' timetable is not a set of hand-copied cycle counts any more -- `tools/gen_warm_schedule.py`
+    derives it from `profiles/stage_constants.json` (the stage profile `tools/gpu_stage_profile.py` measures on the GPU) into
+    `csrc/tb_warm_schedule.inc`, which `tb_api.hip` includes.  The committed .inc must be what the script makes of the committed
+    profile, the constants must be plausible (positive, ordered), and the source must not carry literal cycle counts beside them."""
+    import json
+
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import gen_warm_schedule as g
+
+    sc = json.load(open(g.SRC))
+    assert open(g.DST).read() == g.render(sc), "stale: run tools/gen_warm_schedule.py"
+    s = g.schedule(sc)
+    assert all(v > 0 for v in s.values())
+    assert s["LAYER_W2_BEFORE_END"] < s["LAYER_W1_BEFORE_END"] < s["PL_BASE"] + s["PL_PER_BLOCK"] * (sc["shape"]["P"] // 32)
+    assert abs(s["INTER_BASE"] + s["INTER_PER_BLOCK"] * (sc["shape"]["A"] // 32) - sc["c_half"]["C: interaction x3"] / 3) < 1e-6
+    api = open(os.path.join(ROOT, "trafficbots_amd", "csrc", "tb_api.hip")).read()
+    a = api.index("tb_ctx::WarmTab& wt = ctx->warm_tabs[key];")
+    body = api[a:api.index("one table per key, written once", a)]
+    import re
+
+    assert "WS_PROLOGUE" in body and "WS_TL_LAYER" in body
+    assert not re.search(r"\b\d{4,}\.0\b", body), "a literal cycle count in the warm table"

@@ -461,6 +461,7 @@ def test_fp16_pair_operand_range(scale, expect):
         # as2pl weights (latent encoder) and DO overflow -- the encoders alone fall back, the message names the stage
         wb = WaymoMotion(time_step_end=step_end, n_joint_future=1, operand_precision="bf16")
         wb.load_state_dict(sd)
+        wb.fallback_policy = wm.fallback_policy = "sticky"  # (what follows is about the switch itself; the default policy: below)
         with pytest.warns(RuntimeWarning, match="scene encoders"):
             o = wb.test_step(batch, latent_eps=torch.from_numpy(eps).cuda())
         assert torch.isfinite(o["rollout_buffer"].preds).all()
@@ -480,6 +481,7 @@ def test_fp16_pair_operand_range(scale, expect):
         # computes from a fresh generator with that seed (K = 2: the second future's personality and destination are sampled)
         wg = WaymoMotion(time_step_end=step_end, n_joint_future=2)
         wg.load_state_dict(sd)
+        wg.fallback_policy = "sticky"
         with pytest.warns(RuntimeWarning, match="re-run on the exact-fp32 kernels"):
             og = wg.test_step(batch, generator=torch.Generator(device="cuda").manual_seed(77))
         og = {"preds": og["rollout_buffer"].preds.clone(), "goal_sample": og["goal_sample"].clone()}
@@ -495,6 +497,26 @@ def test_fp16_pair_operand_range(scale, expect):
             out = wm.test_step(batch, latent_eps=torch.from_numpy(eps).cuda(), tap_step=1)
         st = wm.engine.precision_state()
         assert st["step"] == "fp32_exact" and st["activation_overflow"]
+        # round 6, the DEFAULT policy ("adaptive") with weights that overflow on every batch: the first two re-runs go back to the fast
+        # kernels, the third overflow of the window keeps the context on the exact ones -- no fourth re-run; every result is the exact
+        # kernels' (bit-identical to the sticky context's)
+        wa = WaymoMotion(time_step_end=step_end, n_joint_future=1)
+        wa.load_state_dict(sd)
+        assert wa.fallback_policy == "adaptive" and wa.fallback_sticky_after == 3
+        e_ = torch.from_numpy(eps).cuda()
+        for i in range(2):
+            with pytest.warns(RuntimeWarning, match="back on the fp16-pair kernels"):
+                oa = wa.test_step(batch, latent_eps=e_, tap_step=1)
+            assert torch.equal(oa["rollout_buffer"].preds, out["rollout_buffer"].preds)
+            sa = wa.engine.precision_state()
+            assert sa["step"] == "fp16_pair" and sa["encode"] == "fp16_pair" and not sa["activation_overflow"] and sa["note"] == ""
+        with pytest.warns(RuntimeWarning, match=r"stays on them \(3 of the last 3 checked steps overflowed\)"):
+            oa = wa.test_step(batch, latent_eps=e_, tap_step=1)
+        assert wa.engine.precision_state()["step"] == "fp32_exact" and wa.n_fallbacks == 3
+        with _w.catch_warnings():
+            _w.simplefilter("error", RuntimeWarning)
+            oa = wa.test_step(batch, latent_eps=e_, tap_step=1)
+        assert torch.equal(oa["rollout_buffer"].preds, out["rollout_buffer"].preds)
     else:
         import warnings
 
@@ -815,3 +837,96 @@ def test_two_lane_pipeline_equals_plain_steps_and_reruns_an_overflowing_batch():
     assert pipe2.n_reruns >= 1
     assert all(torch.isfinite(o["rollout_buffer"].preds).all() for o in outs)
     assert torch.equal(outs[0]["rollout_buffer"].preds, plain["rollout_buffer"].preds)
+
+
+def test_one_outlier_batch_costs_one_rerun_not_the_context():
+    """Round 6 ("a checkpoint that trips the range guard halves throughput").  With in-range weights and ONE batch
+    that leaves the fp16-pair range -- here a corrupt record: an agent of 3e8 m length, the first encoder layer's output is then a
+    GEMM operand of ~1e7 -- the default `fallback_policy` re-runs THAT batch on the exact-fp32 kernels (bit-identical to a context
+    created with operand_precision="fp32_exact") and returns to the fp16-pair kernels (`tb_precision_restore`): the batches after it
+    are bit-identical to an undisturbed context's and raise nothing.  "sticky" keeps the old behaviour.  Through `wm.pipeline` the
+    outlier is re-run too; a neighbour lane's batch in flight at that moment may be re-run conservatively (the flag word belongs to
+    the device): its result then comes from the exact kernels -- valid, not bit-identical -- and every lane ends on the fast kernels."""
+    import warnings
+
+    from trafficbots_amd import synth
+
+    sd = synth.make_state_dict(5)
+    scene = dict(n_agent=20, n_pl=50, n_tl=12, p_late_spawn=0.3, p_invalid_agent=0.2, pos_range=140.0)
+    batches = [synth.make_batch(9100 + i, 3, **scene) for i in range(5)]
+    bad = dict(batches[1])
+    size = np.array(bad["history/agent/size"], copy=True)
+    first_valid = int(np.argmax(np.asarray(bad["history/agent/valid"])[0].all(0)))
+    size[0, first_valid, 0] = 3e8
+    bad["history/agent/size"] = size
+    seq = [batches[0], bad, batches[2], batches[3], batches[4]]
+    cfg = {"time_step_end": 25, "n_joint_future": 1}
+    eps = torch.from_numpy(synth.make_latent_noise(5, 3, 20)).cuda()
+    fast = _engine(cfg, sd)
+    exact = _engine(dict(cfg, operand_precision="fp32_exact"), sd)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error", RuntimeWarning)
+        ref_fast = {i: fast.test_step(seq[i], latent_eps=eps) for i in (0, 2, 3, 4)}
+        ref_exact = {i: exact.test_step(seq[i], latent_eps=eps) for i in range(5)}
+    assert torch.isfinite(ref_exact[1]["rollout_buffer"].preds).all()
+
+    wm = _engine(cfg, sd)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error", RuntimeWarning)
+        _same_step_outputs(ref_fast[0], wm.test_step(seq[0], latent_eps=eps), "before the outlier")
+    with pytest.warns(RuntimeWarning, match="back on the fp16-pair kernels for the next batch") as rec:
+        o1 = wm.test_step(bad, latent_eps=eps)
+    # (only the kernel family that overflowed switches: bit-identical to the all-exact context when both did, else as close as the
+    # two precisions are to each other)
+    both = any("step kernels and the scene encoders" in str(r.message) for r in rec)
+    _same_or_close(ref_exact[1], o1, both, "the outlier, re-run")
+    st = wm.engine.precision_state()
+    assert st["step"] == "fp16_pair" and st["encode"] == "fp16_pair" and not st["activation_overflow"] and wm.n_fallbacks == 1
+    with warnings.catch_warnings():
+        warnings.simplefilter("error", RuntimeWarning)
+        for i in (2, 3, 4):
+            _same_step_outputs(ref_fast[i], wm.test_step(seq[i], latent_eps=eps), f"after the outlier {i}")
+    assert wm.n_fallbacks == 1
+
+    ws = _engine(cfg, sd)
+    ws.fallback_policy = "sticky"
+    with pytest.warns(RuntimeWarning, match="this context stays on them"):
+        _same_or_close(ref_exact[1], ws.test_step(bad, latent_eps=eps), both, "sticky: the outlier")
+    sts = ws.engine.precision_state()
+    assert sts["activation_overflow"] and "fp32_exact" in (sts["step"], sts["encode"])
+    _same_or_close(ref_exact[2], ws.test_step(seq[2], latent_eps=eps), both, "sticky: after the outlier")
+
+    # the C call by itself: nothing to restore on a context that never fell back / one created on the exact kernels
+    assert fast.engine.precision_restore() is False and exact.engine.precision_restore() is False
+    assert ws.engine.precision_restore() is True
+    sts = ws.engine.precision_state()
+    assert sts["step"] == "fp16_pair" and sts["encode"] == "fp16_pair" and not sts["activation_overflow"]
+
+    wp = _engine(cfg, sd)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        pipe = wp.pipeline(seq, lanes=2, kwargs_fn=lambda i: dict(latent_eps=eps))
+        outs = list(pipe)
+    torch.cuda.synchronize()
+    assert 1 <= pipe.n_reruns <= 3 and len(pipe.notes) == pipe.n_reruns and all("back on the fp16-pair" in n for n in pipe.notes)
+    _same_or_close(ref_exact[1], outs[1], both, "pipeline: the outlier")
+    n_fast = 0
+    for i in (0, 2, 3, 4):
+        is_fast = torch.equal(outs[i]["rollout_buffer"].preds, ref_fast[i]["rollout_buffer"].preds)
+        n_fast += int(is_fast)
+        if is_fast:
+            _same_step_outputs(ref_fast[i], outs[i], f"pipeline {i}")
+        else:
+            _same_or_close(ref_exact[i], outs[i], False, f"pipeline {i} (re-run beside the outlier)")
+    assert n_fast >= 4 - (pipe.n_reruns - 1) and n_fast >= 2
+    assert all(w.engine.precision_state()["step"] == "fp16_pair" and w.engine.precision_state()["encode"] == "fp16_pair" for w in pipe.wms)
+
+
+def _same_or_close(ref, got, bitwise, what):
+    if bitwise:
+        return _same_step_outputs(ref, got, what)
+    ra, rb = ref["rollout_buffer"], got["rollout_buffer"]
+    assert torch.equal(ra.valid, rb.valid), what
+    assert torch.isfinite(rb.preds).all(), what
+    d = float(((ra.preds - rb.preds).abs() * ra.valid.unsqueeze(-1)).max())
+    assert d <= 2e-3, (what, d)  # (25 steps: fp16-pair vs exact fp32 is ~1e-5 there; the bound only says "the same rollout")

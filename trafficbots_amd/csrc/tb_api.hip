@@ -15,6 +15,7 @@
 
 #include "../../include/trafficbots_hip.h"
 #include "tb_internal.hpp"
+#include "tb_warm_schedule.inc"  // WS_*: generated from profiles/stage_constants.json (tools/gen_warm_schedule.py)
 
 namespace tb {
 size_t step_lds_bytes();
@@ -1048,10 +1049,10 @@ static int rollout_setup(tb_ctx* ctx, const tb_rollout_io* io, tb::RolloutP& p, 
     }
     p.sync_err = ctx->d_status + 1;
     if (with_gh && ctx->step_kernel >= 2) {
-        // L2 warmers (tb_stepx_kernels.hip): request times of the weight units of a fused launch, cycles since launch start, from the
-        // stage profiles (profiles/r03_stage_profile_k_step_x.txt, fp16 pairs: prologue 13 k -- 9.5 k since round 5's burst --, an interaction layer 9.2 k + 2.2 k per
-        // key block, GRU 23 k, fusion 9 k, head 9 k, epilogue + front 10 k, a map layer 9.2 k + 1.12 k per key block, a
-        // traffic-light layer 11.3 k; bf16 operands: x 0.7).  Only what follows the helpers' own work is listed.  TB_STEP_WARM=0: off.
+        // L2 warmers (tb_stepx_kernels.hip): request times of the weight units of a fused launch, cycles since launch start.  The
+        // stage durations come from the stage profile of the -DTB_PROFILE build (profiles/stage_constants.json -> tools/
+        // gen_warm_schedule.py -> tb_warm_schedule.inc: WS_*; fp16 pairs, headline shape; the key-block slopes extend it to other
+        // shapes; bf16 operands: x 0.7).  Only what follows the helpers' own work is listed.  TB_STEP_WARM=0: off.
         // On while this context has the device to itself: the warmers hold two helper workgroups per XCD for the whole launch, +1.4 %
         // for ONE rollout in flight and a 15 % loss when another context's launches want those CUs (bench.py two_batches_in_flight).
         // tb_switches.step_l2_warmers = 0: automatic (off when another live context of this device launched work within the last
@@ -1075,22 +1076,26 @@ static int rollout_setup(tb_ctx* ctx, const tb_rollout_io* io, tb::RolloutP& p, 
                 std::vector<int>& tab = wt.host;
                 tab.clear();
                 auto add = [&](uint32_t off, double t) { tab.push_back((int)off); tab.push_back((int)(t * sc)); };
-                const double t_inter = 9200.0 + 2240.0 * (p.a_pad / 32), t_pl = 9200.0 + 1120.0 * (p.p_pad / 32), t_tl = 11300.0;
-                double t = 9500.0 + 3 * t_inter;  // the GRU
+                const double t_inter = WS_INTER_BASE + WS_INTER_PER_BLOCK * (p.a_pad / 32), t_pl = WS_PL_BASE + WS_PL_PER_BLOCK * (p.p_pad / 32),
+                             t_tl = WS_TL_LAYER;
+                double t = WS_PROLOGUE + 3 * t_inter;  // the GRU: a unit is requested one unit ahead of its use
                 for (int l = 0; l < 3; ++l)
-                    for (int g = 0; g < 3; ++g) add(x.gru[l].wih + (uint32_t)g * gate, t + (l * 3 + g) * 2500.0 - 1700.0);
-                t += 23000.0;
-                add(x.goal_out_w1, t - 1700.0); add(x.goal_out_w2, t); add(x.lat_out_w1, t + 2500.0); add(x.lat_out_w2, t + 4800.0);
-                t += 9000.0;
-                for (int ty = 0; ty < 3; ++ty) add(x.head_w1[ty], t - 2000.0 + ty * 2000.0);
-                t += 9000.0 + 10000.0;  // head, epilogue, the A half's front end
+                    for (int g = 0; g < 3; ++g) add(x.gru[l].wih + (uint32_t)g * gate, t + (l * 3 + g - 1) * WS_GRU_UNIT);
+                t += WS_GRU;
+                add(x.goal_out_w1, t - WS_GRU_UNIT); add(x.goal_out_w2, t); add(x.lat_out_w1, t + 0.5 * WS_ADD_GOAL);
+                add(x.lat_out_w2, t + WS_ADD_GOAL);
+                t += WS_ADD_GOAL + WS_ADD_LATENT;
+                for (int ty = 0; ty < 3; ++ty) add(x.head_w1[ty], t + (ty - 1) * WS_HEAD / 4.0);
+                t += WS_HEAD + WS_EPILOGUE_AND_FRONT;  // head, epilogue, the A half's front end
                 for (int l = 0; l < 3; ++l, t += t_pl) {
-                    add(x.as2pl[l].wq, t - 1700.0); add(x.as2pl[l].wo, t + 2000.0); add(x.as2pl[l].w1, t + t_pl - 5000.0); add(x.as2pl[l].w2, t + t_pl - 2700.0);
+                    add(x.as2pl[l].wq, t - WS_LAYER_WQ_LEAD); add(x.as2pl[l].wo, t + WS_LAYER_WO_AT);
+                    add(x.as2pl[l].w1, t + t_pl - WS_LAYER_W1_BEFORE_END); add(x.as2pl[l].w2, t + t_pl - WS_LAYER_W2_BEFORE_END);
                 }
                 for (int l = 0; l < 3; ++l, t += t_tl) {
-                    add(x.as2tl[l].wq, t - 1700.0); add(x.as2tl[l].wo, t + 2000.0); add(x.as2tl[l].w1, t + 5700.0); add(x.as2tl[l].w2, t + 8300.0);
+                    add(x.as2tl[l].wq, t - WS_LAYER_WQ_LEAD); add(x.as2tl[l].wo, t + WS_LAYER_WO_AT);
+                    add(x.as2tl[l].w1, t + t_tl - WS_LAYER_W1_BEFORE_END); add(x.as2tl[l].w2, t + t_tl - WS_LAYER_W2_BEFORE_END);
                 }
-                add(x.inter_kvf[0], t - 2000.0);
+                add(x.inter_kvf[0], t - WS_LAYER_WQ_LEAD);
                 // one table per key, written once (never rewritten: launches in flight / captured graphs keep theirs), uploaded on the
                 // caller's stream in front of the launches that read it -- no blocking copy inside tb_rollout
                 TB_HIP(ctx, hipMalloc((void**)&wt.d, 128 * sizeof(int)));
@@ -1505,6 +1510,21 @@ extern "C" int tb_precision_state(tb_ctx* ctx, int32_t* out3) {
     return 0;
 }
 extern "C" const char* tb_precision_note(tb_ctx* ctx) { return ctx ? ctx->precision_note.c_str() : ""; }
+
+// back to the configured kernels after a run-time fallback (header): the arena holds both operand packings of every weight
+extern "C" int tb_precision_restore(tb_ctx* ctx, int32_t* out_changed) {
+    if (!ctx) return 1;
+    if (out_changed) *out_changed = 0;
+    if (!(ctx->precision_reason & 2) || (ctx->precision_reason & 1)) return 0;  // (never fell back / the weights themselves are out of range)
+    const bool changed = ctx->step_kernel != ctx->step_kernel0 || ctx->encode_kernel != ctx->encode_kernel0;
+    ctx->step_kernel = ctx->step_kernel0;
+    ctx->encode_kernel = ctx->encode_kernel0;
+    ctx->precision_reason &= ~2;
+    ctx->precision_note.clear();
+    if (changed) ctx->step_active = false;  // (an open stepwise rollout was begun by the other kernels' prologue: operand order differs)
+    if (out_changed) *out_changed = changed ? 1 : 0;
+    return 0;
+}
 
 // development aid (not in the public header): copy the stage time stamps of the last launch of a -DTB_PROFILE build
 // hipGraph statistics of the context: out[0] = rollouts captured, out[1] = rollouts replayed from a captured graph

@@ -169,7 +169,7 @@ EXPORTS = (
     "tb_create", "tb_destroy", "tb_last_error", "tb_version", "tb_load_weight", "tb_finalize_weights",
     "tb_rollout", "tb_rollout_begin", "tb_rollout_step", "tb_rollout_step_ex", "tb_check_status", "tb_rollout_state", "tb_encode_scene", "tb_set_timing", "tb_get_timing",
     "tb_rule_checks", "tb_post_process", "tb_metric_partials", "tb_struct_sizes", "tb_encode_posterior", "tb_train_partials",
-    "tb_forward", "tb_graph_stats", "tb_latent_sample", "tb_dest_sample", "tb_precision_state", "tb_precision_note",
+    "tb_forward", "tb_graph_stats", "tb_latent_sample", "tb_dest_sample", "tb_precision_state", "tb_precision_note", "tb_precision_restore",
     "tb_host_onehot_index",
 )
 
@@ -298,6 +298,8 @@ def load() -> C.CDLL:
     lib.tb_precision_state.restype = C.c_int
     lib.tb_precision_note.argtypes = [C.c_void_p]
     lib.tb_precision_note.restype = C.c_char_p
+    lib.tb_precision_restore.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
+    lib.tb_precision_restore.restype = C.c_int
     lib.tb_host_onehot_index.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]
     lib.tb_host_onehot_index.restype = None
     lib.tb_set_timing.argtypes = [C.c_void_p, C.c_int]

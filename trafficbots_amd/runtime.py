@@ -822,6 +822,15 @@ class HipEngine:
         return {"step": names[int(o[0])], "encode": names[int(o[1])], "weight_out_of_range": bool(o[2] & 1),
                 "activation_overflow": bool(o[2] & 2), "note": (self.lib.tb_precision_note(self._ctx) or b"").decode()}
 
+    def precision_restore(self) -> bool:
+        """`tb_precision_restore`: after a RUN-TIME fallback, back to the kernels `tb_finalize_weights` selected (no upload, no
+        synchronisation); True when the selection changed.  A context whose loaded tensors are out of range stays where it is."""
+        ch = C.c_int32(0)
+        self._check(self.lib.tb_precision_restore(self._ctx, C.byref(ch)), "tb_precision_restore")
+        if ch.value:
+            self._step_open = False
+        return bool(ch.value)
+
     def rollout_state(self) -> Dict[str, Tensor]:
         """Current simulator state of the stepwise rollout: `Dynamics.agent_state / agent_valid`, `TrafficBots.hidden`."""
         o = self._step_out

@@ -410,7 +410,8 @@ class LanePipeline:
     the reference's harness (`src/pl_modules/waymo_motion.py:902-949`) cannot show that, this iterator can.
 
     Results come out IN ORDER and only after their lane's range check (`tb_check_status`): an fp16-pair overflow re-runs that batch
-    on the exact-fp32 kernels before it is handed out, exactly as a plain `test_step` does -- nothing unchecked leaves the iterator.
+    on the exact-fp32 kernels before it is handed out, exactly as a plain `test_step` does (same draws, same `fallback_policy`: the
+    lane goes back to the fast kernels afterwards unless overflows keep coming) -- nothing unchecked leaves the iterator.
     Bit-identical to plain calls (the lanes run the same kernels on the same inputs; the L2 warmers, prefetch hints without a
     numerical effect, switch themselves off while a second context is active).  `kwargs_fn(i)` supplies per-batch keyword arguments
     (`latent_eps`, `generator`, ...)."""
@@ -421,6 +422,7 @@ class LanePipeline:
         self.wms = [wm] + [wm.clone() for _ in range(lanes - 1)]
         self.streams = [torch.cuda.Stream(device=wm.device) for _ in range(lanes)]
         self.n_reruns = 0
+        self.notes = []  # what each re-run's context did afterwards (WaymoMotion._after_fallback)
 
     def __len__(self) -> int:
         return len(self.loader)
@@ -447,11 +449,16 @@ class LanePipeline:
             # (a step that accumulates metric states -- validation_step -- may turn out invalid: the holders' states are replaced,
             # never edited in place, so a shallow copy taken now restores them; same contract as waymo_motion._range_fallback)
             snap = [copy.copy(h.__dict__) for h in self.wms[lane]._metric_holders()] if self.step != "test_step" else []
+            # (and the random draws: a re-run sees the SAME numbers as the invalid run -- the state of the batch's generator, or of
+            # torch's default generators, as it is now)
+            gen = kw.get("generator")
+            rng = ("gen", gen.get_state()) if gen is not None else \
+                  ("default", torch.random.get_rng_state(), torch.cuda.get_rng_state(self.wms[lane].device))
             with torch.cuda.stream(s):
                 out = raw[lane](self.wms[lane], batch, **kw)
                 ev = torch.cuda.Event()
                 ev.record(s)
-            inflight.append((lane, batch, kw, out, ev, snap))
+            inflight.append((lane, batch, kw, out, ev, snap, rng))
             return True
 
         try:
@@ -459,7 +466,7 @@ class LanePipeline:
                 if not launch():
                     break
             while inflight:
-                lane, batch, kw, out, ev, snap = inflight.popleft()
+                lane, batch, kw, out, ev, snap, rng = inflight.popleft()
                 ev.synchronize()
                 w = self.wms[lane]
                 if w.check_range:
@@ -469,8 +476,25 @@ class LanePipeline:
                             for h, d in zip(w._metric_holders(), snap):
                                 h.__dict__.clear()
                                 h.__dict__.update(d)
+                            # the draws of the invalid run again; afterwards the default generators continue where the batches
+                            # launched since have left them
+                            if rng[0] == "gen":
+                                kw["generator"].set_state(rng[1])
+                            else:
+                                later = (torch.random.get_rng_state(), torch.cuda.get_rng_state(w.device))
+                                torch.random.set_rng_state(rng[1])
+                                torch.cuda.set_rng_state(rng[2], w.device)
+                            n_before = w.n_fallbacks
                             out = getattr(w, self.step)(batch, **kw)     # (the checked step: re-run + its own check)
+                            if rng[0] == "default":
+                                torch.random.set_rng_state(later[0])
+                                torch.cuda.set_rng_state(later[1], w.device)
                             torch.cuda.current_stream().synchronize()
+                            # fallback_policy: back to the fast kernels, or stay (the checked step has done it itself if the
+                            # re-run overflowed in the other kernel family and ran a second time)
+                            self.notes.append(w._after_fallback() if w.n_fallbacks == n_before else "re-run twice; see the warning")
+                        else:
+                            w._fallback_hist.append(0)
                 main.wait_stream(self.streams[lane])  # the consumer's stream sees the finished results
                 _record_stream(out, main)             # (they were allocated on the lane's stream: allocator bookkeeping)
                 launch()  # refill the lane before handing the result out: the GPU stays fed while the consumer works

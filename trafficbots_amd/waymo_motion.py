@@ -11,6 +11,7 @@ object that can be wrapped by a LightningModule in the reference harness (INTEGR
 """
 from __future__ import annotations
 
+import collections
 from typing import Dict, Optional, Tuple, Union
 
 import torch
@@ -288,6 +289,7 @@ def _range_fallback(fn):
         t0 = time.perf_counter()
         out = fn(self, *args, **kwargs)
         if not self.engine.check_status(raise_on_range=False):
+            self._fallback_hist.append(0)
             return out
         t1 = time.perf_counter()
         for h, d in zip(self._metric_holders(), snap):
@@ -299,11 +301,24 @@ def _range_fallback(fn):
             torch.random.set_rng_state(default_state[0])
             torch.cuda.set_rng_state(default_state[1], self.device)
         out = fn(self, *args, **kwargs)
-        self.engine.check_status()  # (the exact kernels cannot raise the flag; anything else is a hard error)
+        if self.engine.check_status(raise_on_range=False):
+            # only the kernel family that overflowed had switched (say the scene encoders), and with its results now finite the other
+            # one overflowed in turn: one more run, everything that can raise the flag is on its exact twin by now
+            for h, d in zip(self._metric_holders(), snap):
+                h.__dict__.clear()
+                h.__dict__.update(d)
+            if gen_state is not None:
+                gen.set_state(gen_state)
+            elif default_state is not None:
+                torch.random.set_rng_state(default_state[0])
+                torch.cuda.set_rng_state(default_state[1], self.device)
+            out = fn(self, *args, **kwargs)
+            self.engine.check_status()  # (the exact kernels cannot raise the flag; anything else is a hard error)
         t2 = time.perf_counter()
-        warnings.warn(f"trafficbots_amd: {self.engine.precision_state()['note']} -- {fn.__name__} was re-run on the exact-fp32 kernels: "
+        note = self.engine.precision_state()["note"]
+        warnings.warn(f"trafficbots_amd: {note} -- {fn.__name__} was re-run on the exact-fp32 kernels: "
                       f"{(t2 - t1) * 1e3:.1f} ms against {(t1 - t0) * 1e3:.1f} ms for the invalid fp16-pair run ({(t2 - t1) / max(t1 - t0, 1e-9):.2f}x); "
-                      "this context stays on them", RuntimeWarning, stacklevel=2)
+                      + self._after_fallback(), RuntimeWarning, stacklevel=2)
         return out
 
     return step
@@ -323,6 +338,15 @@ class WaymoMotion:
         else:
             self.hparams = load_model_config(config_path, overrides or None)
         self.check_range = True  # tb_check_status at the end of test_step / validation_step / training_step (one stream sync each)
+        # What a context does AFTER a batch overflowed the fp16-pair range and was re-run on the exact-fp32 kernels (`_range_fallback`):
+        # "adaptive" (default) goes back to the fast kernels for the next batch (`tb_precision_restore`: one outlier scene costs one
+        # re-run, not half the throughput of everything after it) unless `fallback_sticky_after` of the last `fallback_window` checked
+        # steps overflowed -- a checkpoint that overflows systematically stays on the exact kernels instead of paying both runs per
+        # batch; "sticky": stay after the first overflow (the behaviour up to round 5); "per_batch": always go back.
+        self.fallback_policy = "adaptive"
+        self.fallback_sticky_after, self.fallback_window = 3, 16
+        self._fallback_hist = collections.deque(maxlen=self.fallback_window)
+        self.n_fallbacks = 0
         self._det_cache: Dict = {}
         self._zeros_cache: Dict = {}
         self.device = torch.device(device)
@@ -381,7 +405,24 @@ class WaymoMotion:
         if self._state_dict is not None:
             w.load_state_dict(self._state_dict)
         w.check_range = self.check_range
+        w.fallback_policy, w.fallback_sticky_after, w.fallback_window = self.fallback_policy, self.fallback_sticky_after, self.fallback_window
         return w
+
+    def _after_fallback(self) -> str:
+        """Policy step after a batch was re-run on the exact-fp32 kernels (see `fallback_policy`); returns the clause for the warning."""
+        if self._fallback_hist.maxlen != self.fallback_window:
+            self._fallback_hist = collections.deque(self._fallback_hist, maxlen=self.fallback_window)
+        self._fallback_hist.append(1)
+        self.n_fallbacks += 1
+        if self.fallback_policy not in ("adaptive", "sticky", "per_batch"):
+            raise ValueError(f"fallback_policy = {self.fallback_policy!r}: expected 'adaptive', 'sticky' or 'per_batch'")
+        recent = sum(self._fallback_hist)
+        stay = self.fallback_policy == "sticky" or (self.fallback_policy == "adaptive" and recent >= self.fallback_sticky_after)
+        if not stay and self.engine.precision_restore():
+            return "the context is back on the fp16-pair kernels for the next batch (fallback_policy = %r)" % self.fallback_policy
+        if self.fallback_policy == "adaptive" and stay:
+            return f"this context stays on them ({recent} of the last {len(self._fallback_hist)} checked steps overflowed)"
+        return "this context stays on them"
 
     def pipeline(self, loader, lanes: int = 2, step: str = "test_step", kwargs_fn=None):
         """`for out in wm.pipeline(loader): ...`: the harness step of consecutive batches on `lanes` contexts / streams, results in
