@@ -276,7 +276,9 @@ def test_pre_processed_scene_carries_the_reference_keys():
         assert tuple(input_dict[k].shape) == shp, k
     assert input_dict["agent_valid"].dtype == torch.bool and input_dict["agent_valid"].any(1).shape == (2, 7)
     for k in ("agent_attr", "agent_pe", "map_attr", "map_pe", "tl_attr", "tl_pe"):
-        assert input_dict[k]._tb_scene is scene and input_dict[k].untyped_storage().nbytes() == 4
+        # (a WEAK reference since round 6: scene -> stand-in -> scene was a cycle that kept each batch's device slab alive until the
+        # cyclic collector ran)
+        assert input_dict[k]._tb_scene() is scene and input_dict[k].untyped_storage().nbytes() == 4
         assert scene["latent_prior/" + k] is input_dict[k]
     assert scene["ref/agent_type"].shape == (2, 7, 3) and scene["ref/agent_type"].sum(-1).max() == 1
     assert scene["ref/map_type"].shape == (2, 9, 11) and scene["ref/agent_state"].shape == (2, 11, 7, 4)
@@ -381,6 +383,36 @@ def test_toolchain_gate_refuses_unvalidated_compilers_and_flags(monkeypatch):
     monkeypatch.setenv("TB_REQUIRE_VALIDATED_TOOLCHAIN", "1")
     with pytest.raises(RuntimeError, match="unvalidated toolchain"):
         hip._warn_if_unvalidated()
+
+
+def test_pre_processed_scene_is_not_cyclic_garbage():
+    """Round 6 (tests/probes/gpu_soak.py): the stand-ins' back-reference to their scene is weak -- dropping the last reference to a
+    pre-processed scene frees it (and the device slab its tensors are views of) at once, by reference counting; the stand-ins of a
+    scene that is gone raise instead of being taken for caller-made attributes."""
+    import gc
+    import weakref
+
+    from trafficbots_amd import synth
+    from trafficbots_amd.runtime import scene_from_batch
+    from trafficbots_amd.waymo_motion import _scene_of_stand_ins, _with_reference_keys, retarget_stand_ins
+
+    gc.collect()
+    gc.disable()
+    try:
+        scene = _with_reference_keys(scene_from_batch(synth.make_batch(5, 2, n_agent=7, n_pl=9, n_tl=3), "cpu", 11))
+        probe = weakref.ref(scene)
+        attr = scene["input/agent_attr"]
+        assert _scene_of_stand_ins((attr,)) is scene and _scene_of_stand_ins((torch.zeros(2),)) is None
+        moved = type(scene)(scene)  # what staging.StagedBatch(scene) does: the entries live in another dict object now
+        retarget_stand_ins(moved)
+        del scene
+        assert probe() is None, "the scene survived its last reference: a cycle"
+        assert _scene_of_stand_ins((attr,)) is moved
+        del moved
+        with pytest.raises(RuntimeError, match="no longer exists"):
+            _scene_of_stand_ins((attr,))
+    finally:
+        gc.enable()
 
 
 def test_warm_schedule_is_generated_from_the_committed_stage_profile():

@@ -930,3 +930,44 @@ def _same_or_close(ref, got, bitwise, what):
     assert torch.isfinite(rb.preds).all(), what
     d = float(((ra.preds - rb.preds).abs() * ra.valid.unsqueeze(-1)).max())
     assert d <= 2e-3, (what, d)  # (25 steps: fp16-pair vs exact fp32 is ~1e-5 there; the bound only says "the same rollout")
+
+
+def test_steps_and_pipelines_hold_no_device_memory_between_batches():
+    """Round 6 (tests/probes/gpu_soak.py, profiles/r06_soak.txt).  (1) With the cyclic collector OFF, repeated `test_step` /
+    `validation_step` calls do not grow torch's allocated bytes: a batch's device slab and outputs die with their last reference (the
+    scene <-> stand-in cycle kept every slab alive until a collection happened to run).  (2) `wm.pipeline` makes its other lanes'
+    contexts once per `wm` and reuses them (a context is a weights arena + workspaces: one per call was a leak of hundreds of
+    megabytes and a second of host time each)."""
+    import gc
+
+    from trafficbots_amd import synth
+
+    sd = synth.make_state_dict(5)
+    scene = dict(n_agent=20, n_pl=50, n_tl=12, p_late_spawn=0.3, p_invalid_agent=0.2, pos_range=140.0)
+    batches = [synth.make_batch(9300 + i, 3, **scene) for i in range(3)]
+    vb = [synth.make_val_batch(9400 + i, 2, n_agent=20, n_pl=50, n_tl=12) for i in range(2)]
+    wm = _engine({"time_step_end": 30, "n_joint_future": 2}, sd)
+
+    def spin(n):
+        for i in range(n):
+            wm.test_step(batches[i % 3])
+            wm.validation_step(vb[i % 2])
+        for _ in wm.pipeline([batches[i % 3] for i in range(n)], lanes=2):
+            pass
+        torch.cuda.synchronize()
+
+    spin(4)
+    gc.collect()
+    gc.disable()
+    try:
+        m0 = torch.cuda.memory_allocated()
+        clones = [id(c) for c in wm._lane_clones]
+        free0 = torch.cuda.mem_get_info()[0]
+        spin(12)
+        m1 = torch.cuda.memory_allocated()
+        free1 = torch.cuda.mem_get_info()[0]
+    finally:
+        gc.enable()
+    assert m1 - m0 <= 64 * 1024, f"torch allocated grew by {(m1 - m0) / 2**20:.2f} MB over 36 steps with the cyclic collector off"
+    assert [id(c) for c in wm._lane_clones] == clones and len(clones) == 1
+    assert free0 - free1 <= 32 * 2**20, f"device memory in use grew by {(free0 - free1) / 2**20:.1f} MB"

@@ -351,9 +351,12 @@ class BatchPrefetcher:
         except StopIteration:
             self._done = True
             return None
+        from .waymo_motion import retarget_stand_ins
+
         with torch.cuda.stream(self._stream):
             scene = self.wm.pre_processing(batch)
             sb = StagedBatch(scene)
+            retarget_stand_ins(sb)  # (the attr / pe stand-ins of the scene refer to the dict they live in, weakly)
             sb.host = batch
             if self.encode:
                 gt = sb.get("gt")
@@ -419,8 +422,7 @@ class LanePipeline:
     def __init__(self, wm, loader: Iterable[Dict], lanes: int = 2, step: str = "test_step", kwargs_fn=None) -> None:
         assert lanes >= 1
         self.loader, self.step, self.kwargs_fn = loader, step, kwargs_fn
-        self.wms = [wm] + [wm.clone() for _ in range(lanes - 1)]
-        self.streams = [torch.cuda.Stream(device=wm.device) for _ in range(lanes)]
+        self.wms, self.streams = wm._lanes(lanes)  # (the other lanes' contexts are made once per `wm` and kept)
         self.n_reruns = 0
         self.notes = []  # what each re-run's context did afterwards (WaymoMotion._after_fallback)
 

@@ -12,6 +12,7 @@ object that can be wrapped by a LightningModule in the reference harness (INTEGR
 from __future__ import annotations
 
 import collections
+import weakref
 from typing import Dict, Optional, Tuple, Union
 
 import torch
@@ -32,6 +33,34 @@ _VIOLATION_KEYS = (
 _STAND_IN: Dict = {}  # device -> the one-element tensor behind the shape-only attr / pe stand-ins
 
 
+class SceneDict(dict):
+    """The pre-processed scene: a dict that can be weakly referenced (see `_with_reference_keys`)."""
+
+    __slots__ = ("__weakref__",)
+
+
+def _scene_of_stand_ins(tensors) -> Optional[Dict[str, Tensor]]:
+    """The scene behind the shape-only attr / pe stand-ins of `_with_reference_keys`, None when `tensors` are caller-made."""
+    for t in tensors:
+        r = getattr(t, "_tb_scene", None)
+        if r is not None:
+            scene = r()
+            if scene is None:
+                raise RuntimeError("encode_input_features: these attr / pe tensors are the shape-only stand-ins of a pre-processed scene that "
+                                   "no longer exists -- keep the dict `pre_processing` returned alive while its entries are in use")
+            return scene
+    return None
+
+
+def retarget_stand_ins(scene) -> None:
+    """After the entries of a pre-processed scene were moved into ANOTHER dict object (`staging.StagedBatch(scene)`): the stand-ins
+    point (weakly) at that one from now on."""
+    back = weakref.ref(scene)
+    for v in scene.values():
+        if torch.is_tensor(v) and getattr(v, "_tb_scene", None) is not None:
+            v._tb_scene = back
+
+
 def _with_reference_keys(scene: Dict[str, Tensor]) -> Dict[str, Tensor]:
     """Adds the entries the reference's harness reads off the pre-processed batch (`waymo_motion.py:902-921`): "input/*" and
     "latent_prior/*" (the twelve arguments of `encode_input_features`; in eval mode the second set aliases the first,
@@ -46,9 +75,15 @@ def _with_reference_keys(scene: Dict[str, Tensor]) -> Dict[str, Tensor]:
     if z is None:
         z = _STAND_IN[dev] = torch.zeros(1, device=dev, dtype=torch.float32)
 
+    if type(scene) is dict:
+        scene = SceneDict(scene)  # (a plain dict cannot be weakly referenced)
+    back = weakref.ref(scene)
+
     def stand_in(*shape):
         x = z.expand(*shape)
-        x._tb_scene = scene
+        # a WEAK reference: scene -> stand-in -> scene would be a cycle, and cyclic garbage keeps the batch's device slab alive until
+        # the cyclic collector happens to run -- its thresholds count objects, not bytes (tests/probes/gpu_soak.py: +0.3 MB per batch)
+        x._tb_scene = back
         return x
 
     ref = {
@@ -192,8 +227,7 @@ class TrafficBots:
             given = (agent_valid, agent_attr, agent_pe, agent_pos, map_valid, map_attr, map_pe, map_pos, tl_valid, tl_attr, tl_pe, tl_pos)
             if any(t is None for t in given):
                 raise TypeError("encode_input_features needs the pre-processed scene or all twelve tensors of the reference's signature")
-            scene = next((getattr(t, "_tb_scene", None) for t in (agent_attr, agent_pe, map_attr, map_pe, tl_attr, tl_pe)
-                          if getattr(t, "_tb_scene", None) is not None), None)
+            scene = _scene_of_stand_ins((agent_attr, agent_pe, map_attr, map_pe, tl_attr, tl_pe))
             if scene is None:
                 scene = _scene_from_reference_inputs(agent_valid, agent_attr, agent_pe, agent_pos, map_valid, map_attr, map_pe, map_pos,
                                                      tl_valid, tl_attr, tl_pe, tl_pos, self.engine.device)
@@ -333,6 +367,8 @@ class WaymoMotion:
         wb_artifact ...) accepted and not used.  See also :func:`trafficbots_amd.instantiate`."""
         self._ctor = (config_path, device, dict(overrides))  # (for `clone`: a second context with the same configuration)
         self._state_dict = None
+        self._lane_clones: list = []   # the other contexts `pipeline` runs on: made once, kept (a context is an arena + workspaces)
+        self._lane_streams: list = []
         if isinstance(overrides.get("model"), dict) or hasattr(overrides.get("model"), "items"):
             self.hparams = config_from_hydra_kwargs(overrides)
         else:
@@ -368,6 +404,8 @@ class WaymoMotion:
     def load_state_dict(self, state_dict: Dict) -> None:
         self._state_dict = state_dict
         self.engine.load_state_dict(state_dict)
+        for c in getattr(self, "_lane_clones", []):  # (the other lanes of `pipeline` follow: same weights on every context)
+            c.load_state_dict(state_dict)
         ls = state_dict["model.latent_encoder.latent_prior_dist.log_std"]
         self.model._log_std = torch.as_tensor(ls, dtype=torch.float32).to(self.device)
         lp = state_dict["model.latent_encoder.latent_post_dist.log_std"]
@@ -430,6 +468,19 @@ class WaymoMotion:
         from .staging import LanePipeline
 
         return LanePipeline(self, loader, lanes=lanes, step=step, kwargs_fn=kwargs_fn)
+
+    def _lanes(self, n: int):
+        """The `n` contexts and streams `pipeline` uses: this object + clones that are made ONCE and kept (a clone is a weights arena,
+        two workspaces and a host-side packing of every tensor -- hundreds of megabytes and a second of host time: a pipeline per
+        epoch must not pay, or leak, that each time; tests/probes/gpu_soak.py).  Policy attributes follow this object at every call."""
+        while len(self._lane_clones) < n - 1:
+            self._lane_clones.append(self.clone())
+        while len(self._lane_streams) < n:
+            self._lane_streams.append(torch.cuda.Stream(device=self.device))
+        for c in self._lane_clones:
+            c.check_range = self.check_range
+            c.fallback_policy, c.fallback_sticky_after, c.fallback_window = self.fallback_policy, self.fallback_sticky_after, self.fallback_window
+        return [self] + self._lane_clones[: n - 1], self._lane_streams[:n]
 
     def prefetch(self, loader, encode: bool = True):
         """`for staged in wm.prefetch(loader): out = wm.test_step(staged)` (also validation_step): batch n + 1 is staged -- host packing,
