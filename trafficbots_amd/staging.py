@@ -19,6 +19,7 @@ the HIP entry points.
 """
 from __future__ import annotations
 
+import weakref
 from math import prod
 from typing import Dict, Iterable, Iterator, List, Optional, Sequence, Tuple
 
@@ -301,7 +302,11 @@ class StagedBatch(dict):
     ready: Optional[torch.cuda.Event] = None
     enc: Optional[Dict[str, Tensor]] = None
     host: Optional[Dict] = None
-    prefetcher: Optional["BatchPrefetcher"] = None
+    _prefetcher_ref = None  # weak: the prefetcher holds the batch it staged ahead (a cycle otherwise; tests/probes/gpu_soak2.py)
+
+    @property
+    def prefetcher(self) -> Optional["BatchPrefetcher"]:
+        return self._prefetcher_ref() if self._prefetcher_ref is not None else None
 
     def wait(self, stream: Optional[torch.cuda.Stream] = None) -> None:
         """Make `stream` (default: the current one) wait for the staging work; the tensors allocated on the side stream are marked
@@ -337,7 +342,11 @@ class BatchPrefetcher:
 
     def __init__(self, wm, loader: Iterable[Dict], encode: bool = True) -> None:
         self.wm, self.loader, self.encode = wm, loader, encode
-        self._stream = torch.cuda.Stream(device=wm.device)
+        # one side stream per `wm`, kept: every torch.cuda.Stream() takes the next of the runtime's pooled streams, each of which costs a
+        # hardware queue (~5 MB of device memory) the first time it is used -- a prefetcher per epoch would walk through the pool
+        if getattr(wm, "_prefetch_stream", None) is None:
+            wm._prefetch_stream = torch.cuda.Stream(device=wm.device)
+        self._stream = wm._prefetch_stream
         self._it: Optional[Iterator[Dict]] = None
         self._ahead: Optional[StagedBatch] = None
         self._done = False
@@ -366,7 +375,7 @@ class BatchPrefetcher:
             ev = torch.cuda.Event()
             ev.record()
             sb.ready = ev
-        sb.prefetcher = self
+        sb._prefetcher_ref = weakref.ref(self)
         self.n_staged += 1
         return sb
 
