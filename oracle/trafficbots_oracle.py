@@ -569,7 +569,6 @@ class Oracle:
         dest_reached = torch.zeros_like(valid)
         goal_pose = rep(gt["gt_goal"]) if (gt is not None and "gt_goal" in gt) else None  # traffic_rule_checker.py:473-479
         goal_reached = torch.zeros_like(valid)
-        act_std_logp = 2 * (2.0 - math.log(math.sqrt(2 * math.pi)))  # Normal(mu, e^-2).log_prob(mu), 2 dims
         atype_idx = a_type.to(torch.int64).argmax(-1)
         max_acc = self.max_acc[atype_idx]
         max_yr = self.max_yr[atype_idx]
@@ -597,12 +596,14 @@ class Oracle:
                 taps[f"tap{t}/policy_feature"] = x.clone()
                 taps[f"tap{t}/hidden"] = h.clone()
             u = self.action_mean(x, valid, a_type)
+            # action_head.py:81-87: per-type log_std (a PARAMETER of the state_dict) under (type & valid), 0 elsewhere -- an agent
+            # without a type is scored with log_std = 0 (golden `edge_scenes`); distributions.py:49
+            tmask = a_type & valid.unsqueeze(-1)
+            ls = sum(self.w[f"action_head.log_std.{i}"].to(d)[None, None, :] * tmask[:, :, [i]].to(d) for i in range(3))
+            dist = torch.distributions.Independent(torch.distributions.Normal(u, ls.exp()), 1)
             if action_eps is None:
-                alp = torch.full_like(state[:, :, 0], act_std_logp).masked_fill(~valid, 0)
-            else:  # action_head.py:81-87: per-type log_std under (type & valid), 0 elsewhere; distributions.py:49
-                tmask = a_type & valid.unsqueeze(-1)
-                ls = sum(self.w[f"action_head.log_std.{i}"].to(d)[None, None, :] * tmask[:, :, [i]].to(d) for i in range(3))
-                dist = torch.distributions.Independent(torch.distributions.Normal(u, ls.exp()), 1)
+                alp = dist.log_prob(u).masked_fill(~valid, 0)  # (Normal(mu, sigma).log_prob(mu): no dependence on mu)
+            else:
                 u = u + _t(action_eps, d)[:, :, t - self.cfg["time_step_sim_start"]] * ls.exp()
                 alp = dist.log_prob(u).masked_fill(~valid, 0)
             act = self._m(torch.tanh, u)

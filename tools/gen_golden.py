@@ -55,6 +55,13 @@ CASES = {
         scene=dict(n_agent=16, n_pl=16, n_tl=40, p_invalid_agent=0.97, p_tl_valid=0.0, p_invalid_pl=0.5),
         tap_steps=[1, 11], fp64=True, store_feats=True,
     ),
+    # scenes at the edge of the layout (synth.EDGE_KINDS: no valid agent / polyline / traffic light, nothing valid at all, one agent
+    # that is valid at the current step only, agents without a type), one of each kind in one batch
+    "edge_scenes": dict(
+        base_seed=9800, n_scene=6, k=2, weight_seed=8, time_step_end=40,
+        scene=dict(n_agent=12, n_pl=24, n_tl=8, p_tl_valid=0.6, p_late_spawn=0.2, edge="v1"),
+        tap_steps=[1, 11], fp64=True, store_feats=True,
+    ),
     # BASELINE.json configs[1] shape (headline), 2 scenes of it
     "headline_2": dict(
         base_seed=5000, n_scene=2, k=1, weight_seed=7, time_step_end=90,

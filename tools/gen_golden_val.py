@@ -63,6 +63,12 @@ CASES = {
     ),
 }
 
+# the validation step over scenes at the edge of the layout (synth.EDGE_KINDS), one of each kind in one batch
+CASES["val_edge"] = dict(
+    base_seed=17000, n_scene=6, weight_seed=8, time_step_end=50, overrides={},
+    scene=dict(n_agent=12, n_pl=24, n_tl=8, p_tl_valid=0.6, p_late_spawn=0.2, p_future_spawn=0.4, p_future_exit=0.3, edge="v1"), fp64=True,
+)
+
 # the validation step on the trained-statistics weights (tools/train_reference.py; trained on episodes of this kind)
 CASES["val_trained"] = dict(
     base_seed=16000, n_scene=3, weight_file="trained_state_dict.npz", time_step_end=90, overrides={},

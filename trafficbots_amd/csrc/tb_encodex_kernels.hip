@@ -985,14 +985,17 @@ __global__ __launch_bounds__(NTHREADS) void k_dest_pairs_x(DestP p) {
     WUnitX u;
     wloadx(u, wstdx(p.W, p.w1x, p.W + p.b1, wave), lane);
     // which agent classes have any candidate polyline in this scene (rows that are all -inf become 0, :331-332)
-    bool mine[3] = {false, false, false};
+    // (an agent WITHOUT a type -- all-false one-hot, class index -1 -- has no exclusion: every valid lane polyline is a candidate,
+    // goal_manager.py:237-244 with agent_type all False; golden `edge_scenes`)
+    bool mine[4] = {false, false, false, false};
     for (int q = tid; q < p.P; q += NTHREADS) {
         const int mt = p.map_type[(size_t)b * p.P + q];
         const bool mv = p.map_fvalid[(size_t)b * p.P + q] != 0;
 #pragma unroll
-        for (int c = 0; c < 3; ++c) mine[c] |= dest_candidate_x(mt, mv, c);
+        for (int c = 0; c < 4; ++c) mine[c] |= dest_candidate_x(mt, mv, c == 3 ? -1 : c);
     }
-    const bool any0 = __syncthreads_or(mine[0]), any1 = __syncthreads_or(mine[1]), any2 = __syncthreads_or(mine[2]);
+    const bool any0 = __syncthreads_or(mine[0]), any1 = __syncthreads_or(mine[1]), any2 = __syncthreads_or(mine[2]),
+               anyn = __syncthreads_or(mine[3]);
     for (int i = tid; i < TM * 32; i += NTHREADS) {
         const int r = i >> 5, c4 = (i & 31) * 4;
         st4(Ut + r * LDT + c4, r < n_real ? ldg4(p.U + ((size_t)b * p.P + p0 + r) * H + c4) : splat(0.f));
@@ -1011,7 +1014,7 @@ __global__ __launch_bounds__(NTHREADS) void k_dest_pairs_x(DestP p) {
     for (int a = a0; a < min(a0 + DEST_AGENTS, p.A); ++a) {
         const int atype = p.agent_type[(size_t)b * p.A + a];
         const bool dvalid = p.dist_valid[(size_t)b * p.A + a] != 0;
-        const bool any_cand = atype == 0 ? any0 : (atype == 1 ? any1 : (atype == 2 ? any2 : false));
+        const bool any_cand = atype == 0 ? any0 : (atype == 1 ? any1 : (atype == 2 ? any2 : anyn));
         {   // relu(LN0(U + V[a])) -> planes
             const float* v = p.V + ((size_t)b * p.A + a) * H + c0;
             const f32x4 xa = lds4(Ut + row * LDT + c0) + ldg4(v), xc = lds4(Ut + row * LDT + c0 + 4) + ldg4(v + 4);

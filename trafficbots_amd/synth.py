@@ -170,8 +170,48 @@ def make_scene(
 def make_batch(base_seed: int, n_scene: int, scene_offset: int = 0, **kw) -> Dict[str, np.ndarray]:
     """Batch-stacked scenes; scene i uses seed base_seed + scene_offset + i (so a rank's shard
     of a global batch is `make_batch(base, n_local, scene_offset=rank * n_local)`)."""
+    edge = kw.pop("edge", None)
     scenes = [make_scene(base_seed + scene_offset + i, **kw) for i in range(n_scene)]
+    if edge is not None:
+        scenes = [edge_scene(s, (scene_offset + i) % len(EDGE_KINDS)) if edge == "v1" else s for i, s in enumerate(scenes)]
     return {k: np.stack([s[k] for s in scenes], 0) for k in scenes[0].keys()}
+
+
+# Scenes at the edge of what the reference's fixed-size, mask-carrying layout can hold (golden `edge_scenes`): scene i of a batch made
+# with edge="v1" is of kind i % 6.
+EDGE_KINDS = ("no valid agent", "no valid polyline", "no valid traffic light and no valid polyline", "nothing valid at all",
+              "one agent, valid at the current step only", "agents without a type")
+
+
+def edge_scene(s: Dict[str, np.ndarray], kind: int) -> Dict[str, np.ndarray]:
+    """Test-split or validation-split scene -> the edge scene of that kind (the validation split's 91-step `agent/*` / `tl_stop/*`
+    entries follow their `history/*` twins)."""
+    s = {k: np.array(v, copy=True) for k, v in s.items()}
+    both = lambda k: [x for x in ("history/" + k, k) if x in s]  # noqa: E731
+    if kind in (0, 3):
+        for k in both("agent/valid"):
+            s[k][...] = False
+    if kind in (1, 2, 3):
+        s["map/valid"][...] = False
+    if kind in (2, 3):
+        for k in both("tl_stop/valid"):
+            s[k][...] = False
+    if kind == 3:
+        s["history/agent_no_sim/valid"][...] = False
+    if kind == 4:
+        hv = s["history/agent/valid"]
+        n_hist = hv.shape[0]
+        keep = int(np.argmax(hv[-1])) if hv[-1].any() else 0
+        for k in both("agent/valid"):
+            v = s[k]
+            fut = v[n_hist:, keep].copy()
+            v[...] = False
+            v[n_hist - 1, keep] = True
+            v[n_hist:, keep] = fut
+    if kind == 5:
+        for k in both("agent/type"):
+            s[k][...] = False
+    return s
 
 
 N_STEP_GT = 91
@@ -257,7 +297,10 @@ def make_val_scene(seed: int, p_future_spawn: float = 0.15, p_future_exit: float
 
 def make_val_batch(base_seed: int, n_scene: int, scene_offset: int = 0, **kw) -> Dict[str, np.ndarray]:
     """Batch-stacked :func:`make_val_scene` (same seeding rule as :func:`make_batch`)."""
+    edge = kw.pop("edge", None)
     scenes = [make_val_scene(base_seed + scene_offset + i, **kw) for i in range(n_scene)]
+    if edge == "v1":
+        scenes = [edge_scene(s, (scene_offset + i) % len(EDGE_KINDS)) for i, s in enumerate(scenes)]
     return {k: np.stack([s[k] for s in scenes], 0) for k in scenes[0].keys()}
 
 
