@@ -42,7 +42,7 @@ REPORT = {}
 
 
 # simulation step up to which |hip - reference fp32| <= 1e-4 m is asserted flat (None = the whole horizon)
-FLAT_1E4_UNTIL = {"c1_plumbing": None, "small_k1": None, "degenerate": None, "edge_scenes": None, "val_edge": None, "val_small": None, "val_alt_losses": None,
+FLAT_1E4_UNTIL = {"c1_plumbing": None, "small_k1": None, "degenerate": None, "edge_scenes": None, "val_edge": None, "edge_scenes2": None, "val_edge2": None, "val_small": None, "val_alt_losses": None,
                   "stoch_actions": None, "val_irrelevant": None,
                   "masks_k3": 60, "headline_2": 60, "headline_k6": 60, "val_masks": 60,
                   "headline_w_normal": 40, "headline_w_sharp": 40, "headline_w_ln_gamma": 40, "action_override": None,
@@ -71,7 +71,7 @@ def _closed_loop_check(name, preds, g, step_axis, rep, step_start=1):
     if not os.path.exists(ensg_path):  # a horizon that ends inside the teacher-forced steps (c1_plumbing): nothing chaotic to measure
         # (no ensemble: only cases that meet north_star's flat 1e-4 m over their WHOLE horizon against both reference runs -- c1_plumbing
         # ends inside the teacher-forced steps, edge_scenes / val_edge run 40 / 50 steps)
-        assert name in ("c1_plumbing", "edge_scenes", "val_edge") and until is None and d32.max() <= 1e-4 and d64.max() <= 1e-4, \
+        assert name in ("c1_plumbing", "edge_scenes", "val_edge", "edge_scenes2", "val_edge2") and until is None and d32.max() <= 1e-4 and d64.max() <= 1e-4, \
             f"{name}: {d32.max():.3e} / {d64.max():.3e}"
         return
     from tools import ensemble
@@ -231,7 +231,7 @@ def _check_all_taps(name, g, meta, wm, sd, batch, eps, gs, rep):
 
 @pytest.mark.parametrize("name", ["c1_plumbing", "small_k1", "masks_k3", "degenerate", "headline_2", "headline_k6",
                                   "headline_w_normal", "headline_w_sharp", "headline_w_ln_gamma", "headline_8", "stress_1",
-                                  "headline_w_trained", "headline_w_ckpt", "edge_scenes"])
+                                  "headline_w_trained", "headline_w_ckpt", "edge_scenes", "edge_scenes2"])
 def test_against_reference_golden(name):
     g, meta = load_golden(name)
     cfg, sd, batch, eps = golden_inputs(meta)
@@ -307,7 +307,7 @@ def test_against_reference_golden(name):
     _closed_loop_check(name, preds, g, 3, rep)
 
 
-@pytest.mark.parametrize("name", ["small_k1", "masks_k3", "headline_2", "edge_scenes"])
+@pytest.mark.parametrize("name", ["small_k1", "masks_k3", "headline_2", "edge_scenes", "edge_scenes2"])
 def test_exact_fp32_kernels_against_reference_golden(name):
     """`operand_precision="fp32_exact"` -- the fp32 MFMA step kernel and the fp32-MFMA encoder blocks that a context falls back to when a
     tensor or an activation leaves the fp16-pair range (round 4: a product path, not a development switch) -- against the same reference
@@ -718,7 +718,7 @@ def test_metric_partials_kernel():
 TRAIN_FIELDS = ("vae_kl_counter", "vae_kl", "diffbar_reward_counter", "diffbar_reward", "goal_loss", "goal_counter")
 
 
-@pytest.mark.parametrize("name", ["val_small", "val_masks", "val_alt_losses", "val_irrelevant", "val_trained", "val_edge"])
+@pytest.mark.parametrize("name", ["val_small", "val_masks", "val_alt_losses", "val_irrelevant", "val_trained", "val_edge", "val_edge2"])
 def test_validation_step_against_reference_golden(name):
     """SURVEY 8(f)-3 through the C ABI (tb_encode_posterior, tb_rollout driven by the 91-step ground truth, tb_train_partials,
     tb_rule_checks' goal_reached, tb_metric_partials) against what the imported reference's validation_step produced."""

@@ -62,6 +62,13 @@ CASES = {
         scene=dict(n_agent=12, n_pl=24, n_tl=8, p_tl_valid=0.6, p_late_spawn=0.2, edge="v1"),
         tap_steps=[1, 11], fp64=True, store_feats=True,
     ),
+    # second set (synth.EDGE_SETS["v2"]): polylines without a type, traffic lights without a state, +-1e4 noise / zeros in every invalid slot
+    "edge_scenes2": dict(
+        base_seed=9900, n_scene=4, k=2, weight_seed=8, time_step_end=40,
+        scene=dict(n_agent=12, n_pl=24, n_tl=8, p_tl_valid=0.6, p_late_spawn=0.3, p_early_exit=0.2, p_invalid_agent=0.2, p_invalid_pl=0.2,
+                   p_invalid_node=0.5, edge="v2"),
+        tap_steps=[1, 11], fp64=True, store_feats=True,
+    ),
     # BASELINE.json configs[1] shape (headline), 2 scenes of it
     "headline_2": dict(
         base_seed=5000, n_scene=2, k=1, weight_seed=7, time_step_end=90,

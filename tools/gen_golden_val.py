@@ -69,6 +69,12 @@ CASES["val_edge"] = dict(
     scene=dict(n_agent=12, n_pl=24, n_tl=8, p_tl_valid=0.6, p_late_spawn=0.2, p_future_spawn=0.4, p_future_exit=0.3, edge="v1"), fp64=True,
 )
 
+CASES["val_edge2"] = dict(
+    base_seed=17100, n_scene=4, weight_seed=8, time_step_end=50, overrides={},
+    scene=dict(n_agent=12, n_pl=24, n_tl=8, p_tl_valid=0.6, p_late_spawn=0.3, p_early_exit=0.2, p_invalid_agent=0.2, p_invalid_pl=0.2,
+               p_invalid_node=0.5, p_future_spawn=0.4, p_future_exit=0.3, edge="v2"), fp64=True,
+)
+
 # the validation step on the trained-statistics weights (tools/train_reference.py; trained on episodes of this kind)
 CASES["val_trained"] = dict(
     base_seed=16000, n_scene=3, weight_file="trained_state_dict.npz", time_step_end=90, overrides={},

@@ -173,17 +173,21 @@ def make_batch(base_seed: int, n_scene: int, scene_offset: int = 0, **kw) -> Dic
     edge = kw.pop("edge", None)
     scenes = [make_scene(base_seed + scene_offset + i, **kw) for i in range(n_scene)]
     if edge is not None:
-        scenes = [edge_scene(s, (scene_offset + i) % len(EDGE_KINDS)) if edge == "v1" else s for i, s in enumerate(scenes)]
+        kinds = EDGE_SETS[edge]
+        scenes = [edge_scene(s, kinds[(scene_offset + i) % len(kinds)], base_seed + scene_offset + i) for i, s in enumerate(scenes)]
     return {k: np.stack([s[k] for s in scenes], 0) for k in scenes[0].keys()}
 
 
 # Scenes at the edge of what the reference's fixed-size, mask-carrying layout can hold (golden `edge_scenes`): scene i of a batch made
-# with edge="v1" is of kind i % 6.
+# with edge="v1" is of kind i % 6 (golden `edge_scenes`, `val_edge`), with edge="v2" of kind 6 + i % 4 (`edge_scenes2`, `val_edge2`).
 EDGE_KINDS = ("no valid agent", "no valid polyline", "no valid traffic light and no valid polyline", "nothing valid at all",
-              "one agent, valid at the current step only", "agents without a type")
+              "one agent, valid at the current step only", "agents without a type",
+              "polylines without a type", "traffic lights without a state", "large garbage in every invalid slot",
+              "zeros in every invalid slot")
+EDGE_SETS = {"v1": (0, 1, 2, 3, 4, 5), "v2": (6, 7, 8, 9)}
 
 
-def edge_scene(s: Dict[str, np.ndarray], kind: int) -> Dict[str, np.ndarray]:
+def edge_scene(s: Dict[str, np.ndarray], kind: int, seed: int = 0) -> Dict[str, np.ndarray]:
     """Test-split or validation-split scene -> the edge scene of that kind (the validation split's 91-step `agent/*` / `tl_stop/*`
     entries follow their `history/*` twins)."""
     s = {k: np.array(v, copy=True) for k, v in s.items()}
@@ -211,6 +215,31 @@ def edge_scene(s: Dict[str, np.ndarray], kind: int) -> Dict[str, np.ndarray]:
     if kind == 5:
         for k in both("agent/type"):
             s[k][...] = False
+    if kind == 6:
+        s["map/type"][...] = False
+    if kind == 7:
+        for k in both("tl_stop/state"):
+            s[k][...] = False
+    if kind in (8, 9):  # what an invalid slot holds must not matter: +-1e4 noise, or zeros (what a packed WOMD file holds there)
+        rs = RawStream(seed + 0x0ED6E000)
+
+        def fill(key, valid):
+            x = s[key]
+            inv = ~np.broadcast_to(valid.reshape(valid.shape + (1,) * (x.ndim - valid.ndim)), x.shape)
+            junk = rs.uniform(-1.0e4, 1.0e4, x.shape).astype(x.dtype) if kind == 8 else np.zeros_like(x)
+            x[inv] = junk[inv]
+
+        for pre in ("history/", ""):
+            if pre + "agent/valid" not in s:
+                continue
+            av = s[pre + "agent/valid"]
+            for k in ("pos", "vel", "spd", "acc", "yaw_bbox", "yaw_rate"):
+                fill(f"{pre}agent/{k}", av)
+            tv = s[pre + "tl_stop/valid"]
+            for k in ("pos", "dir"):
+                fill(f"{pre}tl_stop/{k}", tv)
+        for k in ("pos", "dir"):
+            fill("map/" + k, s["map/valid"])
     return s
 
 
@@ -299,8 +328,9 @@ def make_val_batch(base_seed: int, n_scene: int, scene_offset: int = 0, **kw) ->
     """Batch-stacked :func:`make_val_scene` (same seeding rule as :func:`make_batch`)."""
     edge = kw.pop("edge", None)
     scenes = [make_val_scene(base_seed + scene_offset + i, **kw) for i in range(n_scene)]
-    if edge == "v1":
-        scenes = [edge_scene(s, (scene_offset + i) % len(EDGE_KINDS)) for i, s in enumerate(scenes)]
+    if edge is not None:
+        kinds = EDGE_SETS[edge]
+        scenes = [edge_scene(s, kinds[(scene_offset + i) % len(kinds)], base_seed + scene_offset + i) for i, s in enumerate(scenes)]
     return {k: np.stack([s[k] for s in scenes], 0) for k in scenes[0].keys()}
 
 
