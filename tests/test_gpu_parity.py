@@ -46,7 +46,10 @@ FLAT_1E4_UNTIL = {"c1_plumbing": None, "small_k1": None, "degenerate": None, "ed
                   "stoch_actions": None, "val_irrelevant": None,
                   "masks_k3": 60, "headline_2": 60, "headline_k6": 60, "val_masks": 60,
                   "headline_w_normal": 40, "headline_w_sharp": 40, "headline_w_ln_gamma": 40, "action_override": None,
-                  "headline_8": 60, "stress_1": 40, "headline_w_trained": 40, "val_trained": 60, "headline_w_ckpt": 30}
+                  "headline_8": 60, "stress_1": 40, "headline_w_trained": 40, "val_trained": 60, "headline_w_ckpt": 30,
+                  # far_scene: positions of ~3 km carry an fp32 ulp of 2.4e-4 m -- one differently rounded state update is already beyond
+                  # 1e-4 m; flat over the teacher-forced steps only, the ensemble rule after them
+                  "far_scene": 11}
 SUITE = {}  # case -> tools/ensemble.py::closed_loop_rule output (reference-made ensembles only), judged by the suite-level test
 
 
@@ -231,7 +234,7 @@ def _check_all_taps(name, g, meta, wm, sd, batch, eps, gs, rep):
 
 @pytest.mark.parametrize("name", ["c1_plumbing", "small_k1", "masks_k3", "degenerate", "headline_2", "headline_k6",
                                   "headline_w_normal", "headline_w_sharp", "headline_w_ln_gamma", "headline_8", "stress_1",
-                                  "headline_w_trained", "headline_w_ckpt", "edge_scenes", "edge_scenes2"])
+                                  "headline_w_trained", "headline_w_ckpt", "edge_scenes", "edge_scenes2", "far_scene"])
 def test_against_reference_golden(name):
     g, meta = load_golden(name)
     cfg, sd, batch, eps = golden_inputs(meta)
@@ -303,7 +306,11 @@ def test_against_reference_golden(name):
     rep["traj_spd_max"] = float(d[..., 3].max())
     n_open = min(10, per_step.shape[0])
     rep["traj_xy_open_loop_max"] = float(per_step[:n_open].max())
-    assert rep["traj_xy_open_loop_max"] <= 1e-5
+    # (teacher-forced steps: one state update from the reference's own states.  1e-5 m for scenes of WOMD's extent; a scene kilometres
+    # across -- `far_scene` -- cannot be held below the fp32 spacing of its coordinates: two ulps of the largest one)
+    reach = float(np.abs(g["preds"][..., :2]).max())
+    open_tol = 1e-5 if reach < 1000.0 else 2.0 * float(np.spacing(np.float32(reach)))
+    assert rep["traj_xy_open_loop_max"] <= open_tol, (rep["traj_xy_open_loop_max"], open_tol)
     _closed_loop_check(name, preds, g, 3, rep)
 
 

@@ -69,6 +69,13 @@ CASES = {
                    p_invalid_node=0.5, edge="v2"),
         tap_steps=[1, 11], fp64=True, store_feats=True,
     ),
+    # a scene 6 km across (WOMD scenes reach a few hundred metres; this is the range of the pose-PE arguments, of the map-boundary
+    # test and of the fp32 position arithmetic stretched 20x)
+    "far_scene": dict(
+        base_seed=9950, n_scene=2, k=2, weight_seed=7, time_step_end=60,
+        scene=dict(n_agent=12, n_pl=24, n_tl=8, p_tl_valid=0.6, pos_range=3000.0, boundary=2500.0, spd_max=40.0),
+        tap_steps=[1, 11], fp64=True, store_feats=True,
+    ),
     # BASELINE.json configs[1] shape (headline), 2 scenes of it
     "headline_2": dict(
         base_seed=5000, n_scene=2, k=1, weight_seed=7, time_step_end=90,
@@ -148,7 +155,7 @@ CASES["headline_w_ckpt"] = dict(
 # members of the measured rounding-noise ensemble (tools/ensemble.py) per closed-loop golden
 N_ENSEMBLE = 32
 ENSEMBLE_CASES = ("small_k1", "masks_k3", "degenerate", "headline_2", "headline_k6", "stoch_actions", "action_override",
-                  "headline_w_normal", "headline_w_sharp", "headline_w_ln_gamma", "headline_w_ckpt")
+                  "headline_w_normal", "headline_w_sharp", "headline_w_ln_gamma", "headline_w_ckpt", "far_scene")
 
 RULE_KEYS = ["collided", "collided_this_step", "run_road_edge", "run_road_edge_this_step", "run_red_light",
              "run_red_light_this_step", "passive", "passive_this_step"]

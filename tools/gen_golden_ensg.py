@@ -35,7 +35,7 @@ N_MEMBER = 32
 
 ROLLOUT_CASES = ("small_k1", "masks_k3", "degenerate", "headline_2", "headline_k6", "stoch_actions", "action_override",
                  "headline_w_normal", "headline_w_sharp", "headline_w_ln_gamma", "headline_8", "stress_1", "headline_w_trained",
-                 "headline_w_ckpt")
+                 "headline_w_ckpt", "far_scene")
 VAL_CASES = ("val_small", "val_masks", "val_alt_losses", "val_irrelevant", "val_trained")
 
 
