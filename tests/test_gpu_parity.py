@@ -42,7 +42,7 @@ REPORT = {}
 
 
 # simulation step up to which |hip - reference fp32| <= 1e-4 m is asserted flat (None = the whole horizon)
-FLAT_1E4_UNTIL = {"c1_plumbing": None, "small_k1": None, "degenerate": None, "edge_scenes": None, "val_edge": None, "edge_scenes2": None, "val_edge2": None, "val_small": None, "val_alt_losses": None,
+FLAT_1E4_UNTIL = {"c1_plumbing": None, "small_k1": None, "degenerate": None, "edge_scenes": None, "val_edge": None, "edge_scenes2": None, "val_edge2": None, "cfg_variant": None, "val_small": None, "val_alt_losses": None,
                   "stoch_actions": None, "val_irrelevant": None,
                   "masks_k3": 60, "headline_2": 60, "headline_k6": 60, "val_masks": 60,
                   "headline_w_normal": 40, "headline_w_sharp": 40, "headline_w_ln_gamma": 40, "action_override": None,
@@ -74,7 +74,7 @@ def _closed_loop_check(name, preds, g, step_axis, rep, step_start=1):
     if not os.path.exists(ensg_path):  # a horizon that ends inside the teacher-forced steps (c1_plumbing): nothing chaotic to measure
         # (no ensemble: only cases that meet north_star's flat 1e-4 m over their WHOLE horizon against both reference runs -- c1_plumbing
         # ends inside the teacher-forced steps, edge_scenes / val_edge run 40 / 50 steps)
-        assert name in ("c1_plumbing", "edge_scenes", "val_edge", "edge_scenes2", "val_edge2") and until is None and d32.max() <= 1e-4 and d64.max() <= 1e-4, \
+        assert name in ("c1_plumbing", "edge_scenes", "val_edge", "edge_scenes2", "val_edge2", "cfg_variant") and until is None and d32.max() <= 1e-4 and d64.max() <= 1e-4, \
             f"{name}: {d32.max():.3e} / {d64.max():.3e}"
         return
     from tools import ensemble
@@ -142,7 +142,7 @@ def _engine(cfg_overrides, sd):
 
 
 def _run(meta, sd, batch, eps, goal_sample=None, tap_step=-1):
-    wm = _engine({"time_step_end": meta["time_step_end"], "n_joint_future": meta["k"]}, sd)
+    wm = _engine({"time_step_end": meta["time_step_end"], "n_joint_future": meta["k"], **meta.get("overrides", {})}, sd)
     out = wm.test_step(batch, latent_eps=torch.from_numpy(eps).cuda(), goal_sample=goal_sample, tap_step=tap_step)
     torch.cuda.synchronize()
     return wm, out
@@ -234,7 +234,7 @@ def _check_all_taps(name, g, meta, wm, sd, batch, eps, gs, rep):
 
 @pytest.mark.parametrize("name", ["c1_plumbing", "small_k1", "masks_k3", "degenerate", "headline_2", "headline_k6",
                                   "headline_w_normal", "headline_w_sharp", "headline_w_ln_gamma", "headline_8", "stress_1",
-                                  "headline_w_trained", "headline_w_ckpt", "edge_scenes", "edge_scenes2", "far_scene"])
+                                  "headline_w_trained", "headline_w_ckpt", "edge_scenes", "edge_scenes2", "far_scene", "cfg_variant"])
 def test_against_reference_golden(name):
     g, meta = load_golden(name)
     cfg, sd, batch, eps = golden_inputs(meta)
@@ -314,7 +314,7 @@ def test_against_reference_golden(name):
     _closed_loop_check(name, preds, g, 3, rep)
 
 
-@pytest.mark.parametrize("name", ["small_k1", "masks_k3", "headline_2", "edge_scenes", "edge_scenes2"])
+@pytest.mark.parametrize("name", ["small_k1", "masks_k3", "headline_2", "edge_scenes", "edge_scenes2", "cfg_variant"])
 def test_exact_fp32_kernels_against_reference_golden(name):
     """`operand_precision="fp32_exact"` -- the fp32 MFMA step kernel and the fp32-MFMA encoder blocks that a context falls back to when a
     tensor or an activation leaves the fp16-pair range (round 4: a product path, not a development switch) -- against the same reference
@@ -322,7 +322,7 @@ def test_exact_fp32_kernels_against_reference_golden(name):
     g, meta = load_golden(name)
     cfg, sd, batch, eps = golden_inputs(meta)
     gs = torch.from_numpy(np.transpose(g["goal_sample"], (0, 2, 1)).copy())
-    wm = _engine({"time_step_end": meta["time_step_end"], "n_joint_future": meta["k"], "operand_precision": "fp32_exact"}, sd)
+    wm = _engine({"time_step_end": meta["time_step_end"], "n_joint_future": meta["k"], "operand_precision": "fp32_exact", **meta.get("overrides", {})}, sd)
     st = wm.engine.precision_state()
     assert st["step"] == "fp32_exact" and st["encode"] == "fp32_exact" and not st["weight_out_of_range"]
     out = wm.test_step(batch, latent_eps=torch.from_numpy(eps).cuda(), goal_sample=gs)

@@ -76,6 +76,17 @@ CASES = {
         scene=dict(n_agent=12, n_pl=24, n_tl=8, p_tl_valid=0.6, pos_range=3000.0, boundary=2500.0, spd_max=40.0),
         tap_steps=[1, 11], fp64=True, store_feats=True,
     ),
+    # the scalar config surface off its defaults: a shorter history (time_step_current 5: the batch still carries 11 steps), a warm
+    # start that ends BEFORE the current step, spawning allowed two steps longer than that, other action bounds for every agent class
+    "cfg_variant": dict(
+        base_seed=9960, n_scene=3, k=2, weight_seed=8, time_step_end=45,
+        overrides={"time_step_current": 5, "teacher_forcing_joint_future_pred.step_warm_start": 3,
+                   "teacher_forcing_joint_future_pred.step_spawn_agent": 4,
+                   "dynamics.veh.max_acc": 3.5, "dynamics.veh.max_yaw_rate": 0.9, "dynamics.cyc.max_acc": 4.5,
+                   "dynamics.cyc.max_yaw_rate": 2.2, "dynamics.ped.max_acc": 5.5, "dynamics.ped.max_yaw_rate": 5.0},
+        scene=dict(n_agent=14, n_pl=32, n_tl=8, p_tl_valid=0.6, p_late_spawn=0.5, p_early_exit=0.2),
+        tap_steps=[], fp64=True, store_feats=True,
+    ),
     # BASELINE.json configs[1] shape (headline), 2 scenes of it
     "headline_2": dict(
         base_seed=5000, n_scene=2, k=1, weight_seed=7, time_step_end=90,
@@ -173,6 +184,7 @@ def run_reference(case: dict, dtype=torch.float32, force_goal_sample=None, pertu
     if case.get("rule_flags"):
         over["traffic_rule_checker"] = {"enable_check_collided": True, "enable_check_run_road_edge": True,
                                         "enable_check_run_red_light": True, "enable_check_passive": True}
+    over.update(case.get("overrides", {}))  # (golden `cfg_variant`: scalars of the config surface off their defaults)
     cfg = load_model_config(overrides=over)
     sc = case["scene"]
     torch.set_default_dtype(torch.float32)
