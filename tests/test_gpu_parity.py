@@ -582,7 +582,7 @@ def test_fp32_mfma_step_kernels_match_default(monkeypatch):
         assert err <= 1e-4, (kern, err)
 
 
-@pytest.mark.parametrize("name", ["rules_k2", "rules_passive"])
+@pytest.mark.parametrize("name", ["rules_k2", "rules_passive", "rules_edge"])
 def test_rule_checks_kernel(name):
     """SURVEY 8(f)-1, `tb_rule_checks`: (1) on the (valid, state) pairs the REFERENCE handed to TrafficRuleChecker.check the
     HIP kernels must return the reference's flags exactly (compare work only, same operand order); (2) end to end -- flags

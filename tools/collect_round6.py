@@ -40,7 +40,13 @@ def main():
     d, raw = bench_line(src)
     open(os.path.join(P, "r06_bench_final.json"), "w").write(raw)
     # ---- stage profile
-    shutil.copy(os.path.join(G, "stage_constants.json"), os.path.join(P, "stage_constants.json"))
+    # profiles/stage_constants.json is an INPUT of the build (tools/gen_warm_schedule.py -> csrc/tb_warm_schedule.inc, part of the source
+    # fingerprint): adopting a new stage profile changes the sources the PMC / bench evidence of this very batch was taken on.  The
+    # profile of the final sources is therefore kept beside it; `--adopt-stage-profile` replaces the build input (then regenerate the
+    # schedule, rebuild, and collect again).
+    shutil.copy(os.path.join(G, "stage_constants.json"), os.path.join(P, "r06_stage_constants_final.json"))
+    if "--adopt-stage-profile" in sys.argv:
+        shutil.copy(os.path.join(G, "stage_constants.json"), os.path.join(P, "stage_constants.json"))
     txt = open(os.path.join(G, "stage_profile_k_step_x.txt")).read()
     head = ("# Round 6, shipped sources + -DTB_PROFILE (tools/gpu_stage_profile.py), headline shape, fp16-pair operands; machine-readable twin: "
             "profiles/stage_constants.json (read by bench.py::structural_floor and tools/gen_warm_schedule.py)\n")

@@ -121,6 +121,16 @@ CASES["rules_passive"] = dict(
     tap_steps=[], fp64=False, store_feats=False, rule_flags=True,
 )
 
+# the four rule checks over dense scenes at the edge of the layout (synth.EDGE_SETS["v3"]: agents without a type, polylines without a
+# type -- the road-edge check reads it --, traffic lights without a state -- the red-light check reads it --, noise / zeros in invalid
+# slots, one agent valid at the current step only)
+CASES["rules_edge"] = dict(
+    base_seed=7700, n_scene=6, k=1, weight_seed=9, time_step_end=50,
+    scene=dict(n_agent=16, n_pl=40, n_tl=16, p_tl_valid=0.6, pos_range=25.0, p_invalid_agent=0.2, p_late_spawn=0.2, p_invalid_pl=0.2,
+               p_invalid_node=0.4, edge="v3"),
+    tap_steps=[], fp64=False, store_feats=False, rule_flags=True,
+)
+
 # `forward(action_override=, mask_action_override=)` (waymo_motion.py:116-117,174-175 -> dynamics.py:96-100): the reference's rollout()
 # never passes them, so its forward is wrapped to add step s of synth.make_action_override(base_seed + 55, ...) to every call
 CASES["action_override"] = dict(

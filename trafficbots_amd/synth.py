@@ -184,7 +184,7 @@ EDGE_KINDS = ("no valid agent", "no valid polyline", "no valid traffic light and
               "one agent, valid at the current step only", "agents without a type",
               "polylines without a type", "traffic lights without a state", "large garbage in every invalid slot",
               "zeros in every invalid slot")
-EDGE_SETS = {"v1": (0, 1, 2, 3, 4, 5), "v2": (6, 7, 8, 9)}
+EDGE_SETS = {"v1": (0, 1, 2, 3, 4, 5), "v2": (6, 7, 8, 9), "v3": (5, 6, 7, 8, 9, 4)}  # (v3: golden `rules_edge`, the rule checks switched on)
 
 
 def edge_scene(s: Dict[str, np.ndarray], kind: int, seed: int = 0) -> Dict[str, np.ndarray]:
