@@ -31,8 +31,9 @@ typedef void* tb_stream; /* hipStream_t */
  * default and the validated choice; the other values are A/B and debugging aids -- results are bit-identical across every setting
  * except where noted.  The environment variable named beside a field still works as a DEBUGGING OVERRIDE and wins when set. */
 typedef struct tb_switches {
-    int32_t step_helpers;     /* helper workgroups on the idle CUs of launches of <= 128 tiles (interaction K / V, W_hh h): 1 = off
-                               *   [TB_STEP_HELPERS=0] */
+    int32_t step_helpers;     /* helper workgroups on the idle CUs of launches of <= 128 tiles (interaction K / V, W_hh h): 0 = on while
+                               *   no other context of this device has launched work in the last 100 ms (two rollouts in flight fill
+                               *   the chip by themselves), 1 = off, 2 = on regardless   [TB_STEP_HELPERS=0 | 1] */
     int32_t step_l2_warmers;  /* L2 warmers on the helper CUs (+1.4 % for ONE rollout in flight, a loss when another context's work
                                *   wants those CUs): 0 = on while no other context of this device has launched work in the last
                                *   100 ms, 1 = off, 2 = on regardless   [TB_STEP_WARM=0 | 1] */

@@ -368,7 +368,9 @@ extern "C++" TbSw tb_switches_now(const tb_ctx* ctx) {
     {
         const char* e = env("TB_STEP_HELPERS");
         if (!e) e = env("TB_GRU_HELPER");  // (the switch's first name)
-        s.helpers_off = e ? (e[0] == '0') : (c.step_helpers == 1);
+        // 0: automatic (on, unless another context of the device is launching: two rollouts in flight fill the chip by themselves),
+        // 1: off, 2: on regardless
+        s.helpers_off = e ? (e[0] == '0' ? 1 : 2) : (c.step_helpers == 1 ? 1 : (c.step_helpers == 2 ? 2 : 0));
     }
     if (const char* e = env("TB_STEP_WARM")) s.warm = e[0] == '0' ? 1 : 2;
     else s.warm = c.step_l2_warmers;
@@ -1038,9 +1040,21 @@ static int rollout_setup(tb_ctx* ctx, const tb_rollout_io* io, tb::RolloutP& p, 
     // helper workgroups: a launch of at most 128 tiles leaves at least half of the 256 CUs idle (tb_rollout.hpp)
     const TbSw sw = tb_switches_now(ctx);
     p.sw_lean_off = sw.lean_off;
+    // another live context of this device launched work within the last 100 ms: its kernels want the CUs a 128-tile launch leaves idle
+    bool neighbour_active = false;
+    if (sw.warm == 0 || sw.helpers_off == 0) {
+        const long long now = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+        std::lock_guard<std::mutex> lk(g_ctx_mutex);
+        for (tb_ctx* o : g_ctx_live)
+            if (o != ctx && o->device == ctx->device && o->last_launch_ns && now - o->last_launch_ns < 100000000LL) neighbour_active = true;
+    }
     bool with_gh = false;
     {
-        with_gh = ctx->step_kernel >= 2 && (size_t)p.n_inst * (p.a_pad / 16) <= 128 && !sw.helpers_off;
+        // (helpers: tb_switches.step_helpers.  Automatic = on while this context has the device to itself; with a second rollout in
+        // flight the two launches' 2 x 128 tiles fill the 256 CUs and 2 x 128 helper workgroups only queue in front of them:
+        // wm.pipeline(lanes=2) 5.59 -> 5.35 ms per batch, profiles/r06_experiments.txt item 14.  Same results either way.)
+        const bool helpers_on = sw.helpers_off == 2 || (sw.helpers_off == 0 && !neighbour_active);
+        with_gh = ctx->step_kernel >= 2 && (size_t)p.n_inst * (p.a_pad / 16) <= 128 && helpers_on;
         if (ctx->step_kernel == 3 && aw_forced(sw) && p.p_pad >= 512) with_gh = false;  // (test switch: the assist carve has no helpers)
     }
     if (!ctx->d_status) {
@@ -1057,13 +1071,7 @@ static int rollout_setup(tb_ctx* ctx, const tb_rollout_io* io, tb::RolloutP& p, 
         // for ONE rollout in flight and a 15 % loss when another context's launches want those CUs (bench.py two_batches_in_flight).
         // tb_switches.step_l2_warmers = 0: automatic (off when another live context of this device launched work within the last
         // 100 ms), 1: off, 2: on regardless.
-        bool warm_on = sw.warm != 1;
-        if (sw.warm == 0) {
-            const long long now = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
-            std::lock_guard<std::mutex> lk(g_ctx_mutex);
-            for (tb_ctx* o : g_ctx_live)
-                if (o != ctx && o->device == ctx->device && o->last_launch_ns && now - o->last_launch_ns < 100000000LL) warm_on = false;
-        }
+        const bool warm_on = sw.warm == 2 || (sw.warm == 0 && !neighbour_active);
         const long long key = ((long long)p.p_pad << 32) | ((long long)p.a_pad << 8) | ctx->step_kernel;
         if (!warm_on) {
             p.warm_tab = nullptr;
