@@ -32,11 +32,11 @@ typedef void* tb_stream; /* hipStream_t */
  * except where noted.  The environment variable named beside a field still works as a DEBUGGING OVERRIDE and wins when set. */
 typedef struct tb_switches {
     int32_t step_helpers;     /* helper workgroups on the idle CUs of launches of <= 128 tiles (interaction K / V, W_hh h): 0 = on while
-                               *   no other context of this device has launched work in the last 100 ms (two rollouts in flight fill
+                               *   no other context of this device has launched work in the last 25 ms (two rollouts in flight fill
                                *   the chip by themselves), 1 = off, 2 = on regardless   [TB_STEP_HELPERS=0 | 1] */
     int32_t step_l2_warmers;  /* L2 warmers on the helper CUs (+1.4 % for ONE rollout in flight, a loss when another context's work
                                *   wants those CUs): 0 = on while no other context of this device has launched work in the last
-                               *   100 ms, 1 = off, 2 = on regardless   [TB_STEP_WARM=0 | 1] */
+                               *   25 ms, 1 = off, 2 = on regardless   [TB_STEP_WARM=0 | 1] */
     int32_t step_pre_inter;   /* interaction blocks of the teacher-forced steps as one batched launch: 1 = off   [TB_STEP_PRE_INTER=0] */
     int32_t step_w3;          /* bf16: three-workgroups-per-CU carve for launches of > 512 tiles: 1 = off   [TB_STEP_W3=0] */
     int32_t step_aw;          /* bf16: assist-wave carve for 129..256-tile launches over >= 512 polylines (another summation order

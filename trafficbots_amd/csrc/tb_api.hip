@@ -1040,13 +1040,16 @@ static int rollout_setup(tb_ctx* ctx, const tb_rollout_io* io, tb::RolloutP& p, 
     // helper workgroups: a launch of at most 128 tiles leaves at least half of the 256 CUs idle (tb_rollout.hpp)
     const TbSw sw = tb_switches_now(ctx);
     p.sw_lean_off = sw.lean_off;
-    // another live context of this device launched work within the last 100 ms: its kernels want the CUs a 128-tile launch leaves idle
+    // another live context of this device launched work within the last 25 ms: its kernels want the CUs a 128-tile launch leaves idle.
+    // (The window only has to span the gap between a pipelined neighbour's launches -- the rollouts this matters for, <= 128 tiles,
+    // last ~7 ms -- and should not outlive the neighbour by much: with the first choice, 100 ms, ten plain calls after the last
+    // pipelined one ran without helpers, 0.5 ms per rollout slower.)
     bool neighbour_active = false;
     if (sw.warm == 0 || sw.helpers_off == 0) {
         const long long now = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
         std::lock_guard<std::mutex> lk(g_ctx_mutex);
         for (tb_ctx* o : g_ctx_live)
-            if (o != ctx && o->device == ctx->device && o->last_launch_ns && now - o->last_launch_ns < 100000000LL) neighbour_active = true;
+            if (o != ctx && o->device == ctx->device && o->last_launch_ns && now - o->last_launch_ns < 25000000LL) neighbour_active = true;
     }
     bool with_gh = false;
     {
@@ -1070,7 +1073,7 @@ static int rollout_setup(tb_ctx* ctx, const tb_rollout_io* io, tb::RolloutP& p, 
         // On while this context has the device to itself: the warmers hold two helper workgroups per XCD for the whole launch, +1.4 %
         // for ONE rollout in flight and a 15 % loss when another context's launches want those CUs (bench.py two_batches_in_flight).
         // tb_switches.step_l2_warmers = 0: automatic (off when another live context of this device launched work within the last
-        // 100 ms), 1: off, 2: on regardless.
+        // 25 ms), 1: off, 2: on regardless.
         const bool warm_on = sw.warm == 2 || (sw.warm == 0 && !neighbour_active);
         const long long key = ((long long)p.p_pad << 32) | ((long long)p.a_pad << 8) | ctx->step_kernel;
         if (!warm_on) {

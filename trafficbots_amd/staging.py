@@ -415,7 +415,7 @@ def _record_stream(obj, stream, _depth: int = 0) -> None:
 
 
 class LanePipeline:
-    """`for out in wm.pipeline(loader, lanes=2): ...` -- the harness step (`test_step` by default) of consecutive batches on `lanes`
+    """`for out in wm.pipeline(loader): ...` (default: three lanes) -- the harness step (`test_step` by default) of consecutive batches on `lanes`
     independent contexts, each with its own stream: batch n + 1 is staged, encoded and rolled out on lane (n + 1) % lanes while batch n
     still runs on its lane.  At 32 scenes a rollout launch has 128 tiles for 256 CUs and is bound by per-CU latency chains, so two
     rollouts in flight nearly double the chip's throughput (bench.py `two_batches_in_flight`); the one-batch-at-a-time call sequence of
@@ -428,7 +428,7 @@ class LanePipeline:
     numerical effect, switch themselves off while a second context is active).  `kwargs_fn(i)` supplies per-batch keyword arguments
     (`latent_eps`, `generator`, ...)."""
 
-    def __init__(self, wm, loader: Iterable[Dict], lanes: int = 2, step: str = "test_step", kwargs_fn=None) -> None:
+    def __init__(self, wm, loader: Iterable[Dict], lanes: int = 3, step: str = "test_step", kwargs_fn=None) -> None:
         assert lanes >= 1
         self.loader, self.step, self.kwargs_fn = loader, step, kwargs_fn
         self.wms, self.streams = wm._lanes(lanes)  # (the other lanes' contexts are made once per `wm` and kept)
