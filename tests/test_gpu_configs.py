@@ -463,6 +463,19 @@ def test_bench_eight_ranks_share_the_device():
     REPORT["bench_gloo_eight_ranks_one_gpu"] = {"value": ln["value"], "elapsed_s": r["elapsed_s"]}
 
 
+def test_bench_n_ranks_carry_the_end_to_end_block():
+    """VERDICT r05 task 8: the N > 1 line also measures the DROP-IN path on every rank at once (`tools/e2e_bench.measure_rank`: plain
+    `test_step` calls and the lane pipeline, each rank its own host batches, its own stager and its own launching thread), gathered to
+    rank 0 -- host-side contention shows before a multi-GPU node exists.  Two ranks share the visible GPU here (gloo)."""
+    ln = _run_bench(["--gpus", "2", "--configs", "--sustain-seconds", "0"], {"TB_BENCH_BACKEND": "gloo"})
+    assert ln["n_gpus"] == 2 and ln["ranks"]["ranks_seen"] == 2 and ln["ranks"]["collectives_in_timed_passes"] == 0
+    e = ln["e2e"]
+    per = e["per_rank"]
+    assert len(per) == 2 and all("plain_ms_per_batch" in r and "pipeline_2_lanes_ms_per_batch" in r for r in per), e
+    assert all(0 < r["pipeline_2_lanes_ms_per_batch"] and 0 < r["plain_ms_per_batch"] < 100 for r in per)
+    REPORT["bench_gloo_two_ranks_e2e"] = per
+
+
 def test_bench_one_rank_through_rccl():
     """The driver's multi-GPU command line with ONE rank on the real backend: `python -m torch.distributed.run --nproc-per-node 1
     bench.py --gpus 1` with TB_BENCH_FORCE_DIST=1 initialises the RCCL process group (backend "nccl", device_id), runs the barriers
