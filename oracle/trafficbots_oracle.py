@@ -706,6 +706,15 @@ class Oracle:
         # validation_step leaves batch["agent/*"] = the 91-step ground truth in place (waymo_motion.py:538-545), which the kill
         # rule and goal_reached then see; test_step overwrites it with the history (:925-926)
         gt = self.preprocess_gt(batch) if use_gt else None
+        if gt is None and np.asarray(batch["history/agent/valid"]).shape[1] > self.n_hist:
+            # test_step hands the rollout batch["agent/*"] = batch["history/agent/*"] over ALL history steps of the batch
+            # (waymo_motion.py:925-926, 538-545) while the encoders see the first time_step_current + 1 of them (scene_centric.py:92-121):
+            # with time_step_current < 10 the teacher-forcing mask, the state overrides and the kill rule's ground-truth validity still
+            # reach to the end of the 11-step history (tools/fuzz_oracle_vs_reference.py cases 74, 118)
+            d_ = self.dtype
+            hg = lambda k_: _t(batch["history/agent/" + k_], d_)  # noqa: E731
+            gt = {"agent_valid": _t(batch["history/agent/valid"], d_), "agent_vel": hg("vel"), "agent_acc": hg("acc"),
+                  "agent_yaw_rate": hg("yaw_rate"), "agent_state": torch.cat([hg("pos"), hg("yaw_bbox"), hg("spd")], -1)}
         res = self.rollout(inp, f, z, mean, dest, goal_valid, k, step_end, tap_steps, gt=gt, action_eps=action_eps,
                            action_override=action_override)
         # RolloutBuffer.flatten_repeat (`buffer.py:92-123`): [N,A,S,..] -> [B,A,K,S,..]

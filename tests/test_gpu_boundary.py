@@ -971,3 +971,31 @@ def test_steps_and_pipelines_hold_no_device_memory_between_batches():
     assert m1 - m0 <= 64 * 1024, f"torch allocated grew by {(m1 - m0) / 2**20:.2f} MB over 36 steps with the cyclic collector off"
     assert [id(c) for c in wm._lane_clones] == clones and len(clones) == 1
     assert free0 - free1 <= 32 * 2**20, f"device memory in use grew by {(free0 - free1) / 2**20:.1f} MB"
+
+
+def test_shorter_time_step_current_rolls_out_on_the_whole_history_through_every_feeder():
+    """Round 6 (tools/fuzz_oracle_vs_reference.py): with time_step_current = 5 the reference's `test_step` still hands the rollout the
+    batch's 11-step history (teacher-forcing mask, state overrides, the validity the kill rule spares: `waymo_motion.py:925-926,
+    538-545`) while the encoders see six steps.  Golden `cfg_variant` pins the numbers (tests/test_gpu_parity.py); here: the same
+    result through plain calls with a host batch and a device batch, `wm.prefetch` and `wm.pipeline`, and the packed-h5 path refuses
+    the configuration instead of rolling out on a truncated history."""
+    g, meta = load_golden("cfg_variant")
+    cfg, sd, batch, eps = golden_inputs(meta)
+    over = {"time_step_end": meta["time_step_end"], "n_joint_future": meta["k"], **meta["overrides"]}
+    wm = _engine(over, sd)
+    assert wm.n_hist == 6
+    e = torch.from_numpy(eps).cuda()
+    gs = torch.from_numpy(np.transpose(g["goal_sample"], (0, 2, 1)).copy()).cuda()
+    kw = dict(latent_eps=e, goal_sample=gs)
+    ref = wm.test_step(batch, **kw)
+    # the rule at work: agents valid in the golden beyond step 5 although they sit outside the map (the history still holds them)
+    assert torch.equal(ref["rollout_buffer"].valid.cpu(), torch.from_numpy(g["valid"]))
+    assert float(g["outside_map"].mean()) > 0.1
+    _same_step_outputs(ref, wm.test_step(_dev_batch(batch), **kw), "device batch")
+    for i, sb in enumerate(wm.prefetch([batch, batch])):
+        assert "hist" in sb
+        _same_step_outputs(ref, wm.test_step(sb, **kw), f"prefetch {i}")
+    for i, o in enumerate(wm.pipeline([batch, batch, batch], lanes=2, kwargs_fn=lambda i: kw)):
+        _same_step_outputs(ref, o, f"pipeline {i}")
+    with pytest.raises(NotImplementedError, match="time_step_current = 10"):
+        wm.pre_processing({"packed/agent_valid": torch.zeros(1, 6, 2)})

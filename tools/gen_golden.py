@@ -77,14 +77,16 @@ CASES = {
         tap_steps=[1, 11], fp64=True, store_feats=True,
     ),
     # the scalar config surface off its defaults: a shorter history (time_step_current 5: the batch still carries 11 steps), a warm
-    # start that ends BEFORE the current step, spawning allowed two steps longer than that, other action bounds for every agent class
+    # start that ends BEFORE the current step, spawning allowed until step 8, other action bounds for every agent class
     "cfg_variant": dict(
         base_seed=9960, n_scene=3, k=2, weight_seed=8, time_step_end=45,
         overrides={"time_step_current": 5, "teacher_forcing_joint_future_pred.step_warm_start": 3,
-                   "teacher_forcing_joint_future_pred.step_spawn_agent": 4,
+                   "teacher_forcing_joint_future_pred.step_spawn_agent": 8,  # (beyond the current step: the rollout of test_step sees
+                   # the batch's WHOLE 11-step history -- spawns at steps 6 .. 8, and the kill rule spares agents the history still
+                   # holds valid: half the scene lies outside the map boundary)
                    "dynamics.veh.max_acc": 3.5, "dynamics.veh.max_yaw_rate": 0.9, "dynamics.cyc.max_acc": 4.5,
                    "dynamics.cyc.max_yaw_rate": 2.2, "dynamics.ped.max_acc": 5.5, "dynamics.ped.max_yaw_rate": 5.0},
-        scene=dict(n_agent=14, n_pl=32, n_tl=8, p_tl_valid=0.6, p_late_spawn=0.5, p_early_exit=0.2),
+        scene=dict(n_agent=14, n_pl=32, n_tl=8, p_tl_valid=0.6, p_late_spawn=0.5, p_early_exit=0.2, pos_range=260.0),
         tap_steps=[], fp64=True, store_feats=True,
     ),
     # BASELINE.json configs[1] shape (headline), 2 scenes of it

@@ -168,6 +168,41 @@ _CRITERIA = {"SmoothL1Loss": 0, "MSELoss": 1, "L1Loss": 2}
 _ANGULAR = {None: 0, "cast": 1, "cosine": 2, "vector": 3}
 
 
+def history_len(batch: Dict) -> int:
+    """Number of history steps a test-split / validation-split batch carries ("history/agent/valid" is [B, steps, A]); 0 without one."""
+    v = batch.get("history/agent/valid")
+    return int(v.shape[1]) if v is not None else 0
+
+
+def hist_from_batch(batch: Dict[str, Tensor], device, n_hist: int, tf_params: Tuple[int, int]) -> Dict[str, Tensor]:
+    """What `test_step` hands the ROLLOUT as `features["agent_valid" / "agent_state" / "vel" / "acc" / "yaw_rate"]`: the batch's
+    history over ALL of its steps (`waymo_motion.py:925-926`: batch["agent/*"] = batch["history/agent/*"]; `:538-545`) -- while the
+    encoders see the first time_step_current + 1 steps only (`scene_centric.py:92-121`).  With the default time_step_current = 10 the
+    two coincide and this is not built; with a shorter one the teacher-forcing mask, the state overrides and the ground-truth validity
+    the kill rule spares (`dynamics.py:161-167`) still reach to the end of the 11-step history (found by tools/
+    fuzz_oracle_vs_reference.py, round 6).  Same layout as the agent part of :func:`gt_from_batch`; plain torch copies (a config off
+    the default: not the staged fast path)."""
+
+    def g(k):
+        v = batch["history/agent/" + k]
+        if isinstance(v, np.ndarray):
+            v = torch.from_numpy(v)
+        return v.to(device)
+
+    f32, u8 = torch.float32, torch.uint8
+    pos, yaw, spd = g("pos").to(f32), g("yaw_bbox").to(f32), g("spd").to(f32)
+    valid = g("valid")
+    s: Dict[str, Tensor] = {
+        "warm_ok": no_early_exit(batch["history/agent/valid"], n_hist),
+        "agent_valid": valid.to(u8).contiguous(), "agent_state": torch.cat([pos, yaw, spd], -1).contiguous(),
+        "agent_vel": g("vel").to(f32).contiguous(), "agent_acc": g("acc")[..., 0].to(f32).contiguous(),
+        "agent_yaw_rate": g("yaw_rate")[..., 0].to(f32).contiguous(),
+    }
+    s["_tf_mask"] = as_u8(teacher_forcing_mask(valid.bool(), *tf_params))
+    s["_tf_params"] = tuple(tf_params)
+    return s
+
+
 def gt_from_batch(batch: Dict[str, Tensor], device, n_hist: int = 11) -> Dict[str, Tensor]:
     """Ground-truth part of a validation / training batch (`data_h5_womd.py:85-118`: "agent/*", "tl_stop/*" over all 91
     steps) -> the C ABI's device layout: what `SceneCentricPreProcessing` exposes as "gt/*" (`scene_centric.py:103-110`),
