@@ -1208,3 +1208,50 @@ def test_helper_handoff_timeout_fails_loudly(monkeypatch):
     monkeypatch.setenv("TB_DEBUG_HELPER_DELAY", "0")
     wm = _engine({"time_step_end": 2, "n_joint_future": 1}, sd)
     assert torch.isfinite(wm.test_step(batch, latent_eps=eps)["rollout_buffer"].preds).all()
+
+
+def test_training_step_perturbation_with_input_dropout_against_reference_golden():
+    """ADVICE r05 (medium), pinned by the reference itself in round 6: `perturb_input_to_latent` TOGETHER with
+    `pre_processing.input.dropout_p_history` (+ `p_drop_hidden`).  The perturbed personality encoders see the UN-dropped episode
+    (`sc_latent.py:115-152` builds latent_post / latent_prior from sc/* under perturbation) while the model inputs are dropped
+    (`sc_input.py:100-106`).  Golden `train_perturb_dropout` = the body of the reference's training_step with the Bernoulli masks, the
+    two frame draws, the hidden-state draws and the personality's rsample replaced by stored draws."""
+    from trafficbots_amd import synth
+    from trafficbots_amd.config import load_model_config
+
+    g, meta = load_golden("train_perturb_dropout")
+    over = {"time_step_end": meta["time_step_end"], "n_joint_future": 1}
+    over.update(meta["overrides"])
+    cfg = load_model_config(overrides=over)
+    sc, ov = meta["scene"], meta["overrides"]
+    n_step = meta["time_step_end"] - cfg["time_step_sim_start"] + 1
+    draws = synth.make_train_draws(meta["draws_seed"], meta["n_scene"], sc["n_agent"], sc["n_pl"], sc["n_tl"], n_step,
+                                   ov["pre_processing.input.dropout_p_history"], ov["pre_processing.latent.dropout_p_history"], ov["p_drop_hidden"])
+    assert (np.nonzero(draws["hidden_drop"])[0] == g["hidden_drop_steps"]).all() and not draws["input_agent"].all()
+    batch = synth.make_val_batch(meta["base_seed"], meta["n_scene"], **sc)
+    eps = torch.from_numpy(synth.make_latent_noise(meta["base_seed"] + 99, meta["n_scene"], sc["n_agent"])).cuda()
+    lp = {k: torch.from_numpy(v).cuda() for k, v in synth.make_latent_perturb(meta["perturb_seed"], meta["n_scene"]).items()}
+    keep = {k: torch.from_numpy(v) for k, v in draws.items() if k.startswith("input_")}
+    wm = _engine(over, synth.make_state_dict(meta["weight_seed"]))
+    out = wm.training_step(batch, latent_eps=eps, history_keep=keep, hidden_drop=draws["hidden_drop"], latent_perturb=lp)
+    torch.cuda.synchronize()
+    buf = out["rollout_buffer"]
+    assert (out["latent_post"].valid.cpu().numpy() == g["post_valid"]).all() and (out["latent_prior"].valid.cpu().numpy() == g["prior_valid"]).all()
+    e_post = float(np.abs(out["latent_post"].mean.cpu().numpy() - g["post_mean"]).max())
+    e_prior = float(np.abs(out["latent_prior"].mean.cpu().numpy() - g["prior_mean"]).max())
+    REPORT["train_perturb_dropout"] = {"post_mean": e_post, "prior_mean": e_prior}
+    assert e_post <= ONE_SHOT_TOL and e_prior <= ONE_SHOT_TOL, (e_post, e_prior)
+    assert np.abs(out["input_feature_dict"]["map_feature"].cpu().numpy() - g["map_feature"]).max() <= ONE_SHOT_TOL if "input_feature_dict" in out else True
+    assert (buf.valid.cpu().numpy() == g["valid"]).all() and (buf.override_masks.cpu().numpy() == g["override_masks"]).all()
+    d = np.abs(buf.preds.cpu().numpy() - g["preds"]) * g["valid"][..., None]
+    assert d[..., :2].max() <= 1e-4, d[..., :2].max()
+    ref = json.loads(bytes(g["metrics_json"]).decode())
+    got = out["metrics_dict"]
+    assert set(got) == set(ref) and all(abs(got[k] - ref[k]) <= 2e-4 * max(1.0, abs(ref[k])) for k in ref), (got, ref)
+    # each ingredient matters: without the frame draws / without the input masks the personalities or the rollout are different ones
+    no_pert = wm.training_step(batch, latent_eps=eps, history_keep=keep, hidden_drop=draws["hidden_drop"],
+                               latent_perturb={k: torch.zeros_like(v) for k, v in lp.items()})
+    no_keep = wm.training_step(batch, latent_eps=eps, hidden_drop=draws["hidden_drop"], latent_perturb=lp,
+                               history_keep={k: torch.ones_like(v) for k, v in keep.items()})
+    assert float((no_pert["latent_post"].mean - out["latent_post"].mean).abs().max()) > 1e-3
+    assert float((no_keep["rollout_buffer"].preds - buf.preds).abs().max()) > 1e-3

@@ -206,6 +206,16 @@ TRAIN_PERTURB_CASE = dict(
 )
 
 
+# perturbation TOGETHER with the input history dropout -- the perturbed personality encoders must see the UN-dropped
+# scene (sc_latent.py builds latent_prior/* from sc/* under perturbation) while the model inputs are dropped; plus the hidden-state drop
+TRAIN_PERTURB_DROPOUT_CASE = dict(
+    base_seed=17500, n_scene=3, weight_seed=9, time_step_end=40, draws_seed=17501, perturb_seed=17502,
+    overrides={"pre_processing.input.dropout_p_history": 0.25, "pre_processing.latent.dropout_p_history": -1, "p_drop_hidden": 0.1,
+               "pre_processing.latent.perturb_input_to_latent": True},
+    scene=dict(n_agent=10, n_pl=24, n_tl=12, p_invalid_agent=0.2, p_late_spawn=0.3, p_future_spawn=0.5, p_future_exit=0.3, pos_range=70.0),
+)
+
+
 def run_reference_training(case: dict = TRAIN_CASE) -> dict:
     """The body of the reference's `training_step` (`waymo_motion.py:356-418`) with ONLY the train-mode switches of the pre-processing
     modules and of `rollout` turned on (the network itself stays in eval mode: no nn.Dropout), `torch.bernoulli` / `torch.rand(1)` /
@@ -268,7 +278,8 @@ def run_reference_training(case: dict = TRAIN_CASE) -> dict:
             if perturb is not None:
                 torch.rand = fake_rand
             batch = model.pre_processing(batch)
-            assert calls["bern"] == (0 if perturb is not None else 5) and calls.get("perturb", 0) == (2 if perturb is not None else 0), calls
+            n_bern = 3 * int(ov["pre_processing.input.dropout_p_history"] > 0) + 2 * int(ov["pre_processing.latent.dropout_p_history"] > 0)
+            assert calls["bern"] == n_bern and calls.get("perturb", 0) == (2 if perturb is not None else 0), calls
             pick = lambda pre: {k.split(pre)[-1]: v for k, v in batch.items() if pre in k}  # noqa: E731
             input_dict, post_dict, prior_dict = pick("input/"), pick("latent_post/"), pick("latent_prior/")
             feats = model.model.encode_input_features(**input_dict)
@@ -322,6 +333,12 @@ def main() -> None:
         path = os.path.join(GOLDEN_DIR, "train_perturb.npz")
         np.savez_compressed(path, **r)
         print(f"[train_perturb] wrote {path} ({os.path.getsize(path) / 1024:.0f} KiB); {json.loads(r['metrics_json'].tobytes())}")
+    if not only or "train_perturb_dropout" in only:
+        r = run_reference_training(TRAIN_PERTURB_DROPOUT_CASE)
+        path = os.path.join(GOLDEN_DIR, "train_perturb_dropout.npz")
+        np.savez_compressed(path, **r)
+        print(f"[train_perturb_dropout] wrote {path} ({os.path.getsize(path) / 1024:.0f} KiB); hidden dropped after steps {r['hidden_drop_steps'] + 1}; "
+              f"{json.loads(r['metrics_json'].tobytes())}")
     for name, case in CASES.items():
         if only and name not in only:
             continue

@@ -979,7 +979,6 @@ class WaymoMotion:
         if "gt" not in scene:
             raise ValueError("training_step needs a training / validation batch (agent/*, tl_stop/* ground truth)")
         gt = scene["gt"]
-        scene_raw, gt_raw = scene, gt  # (before the train-mode masks: what the perturbed personality encoders are fed, see below)
         scene, gt, hidden_drop = self._train_mode_masks(scene, gt, history_keep, hidden_drop, generator)
         input_feature_dict = self.model.encode_input_features(scene)
         goal_gt, goal_valid = self.model.goal_manager.get_gt_goal(scene["agent_valid"], gt.get("gt_goal"), gt["gt_dest"])
@@ -990,11 +989,14 @@ class WaymoMotion:
             b_ = scene["agent_valid"].shape[0]
             lp = latent_perturb if latent_perturb is not None else {
                 "yaw": torch.rand(b_, device=self.device, generator=generator), "pos": torch.rand(b_, 2, device=self.device, generator=generator)}
-            # The re-centred inputs are built from the UN-dropped scene: under perturbation the reference makes latent_prior/* from the
-            # sc/* tensors (latent_prior/agent_valid = sc/agent_valid, tl_valid = sc/tl_valid, map_valid = sc/map_valid,
-            # `sc_latent.py:142-167`), not from the input/* tensors that `pre_processing.input.dropout_p_history` has masked
-            # (the masked scene used to be handed over; perturb + latent.dropout_p_history is refused above)
-            scene_l, gt_l = self._perturb_latent_inputs(scene_raw, gt_raw, lp["yaw"], lp["pos"])
+            # The re-centred inputs carry the INPUT-DROPPED validity: `SceneCentricInput` aliases input/agent_valid, input/tl_valid and
+            # input/map_valid to the sc/* tensors and masks them IN PLACE (`sc_input.py:103-113`: `batch["input/agent_valid"] =
+            # batch["sc/agent_valid"]` ... `&=`), so the sc/* validity `SceneCentricLatent` reads under perturbation
+            # (`sc_latent.py:142-167`) is the masked one -- and sc/map_valid IS batch["map/valid"], which the posterior's map shares.
+            # The posterior's agents / traffic lights come from agent/valid, tl_stop/valid (separate tensors: not masked by the input
+            # dropout).  Pinned by golden `train_perturb_dropout`, made by the reference (round 6; the advisor's reading of round 5 --
+            # "from the un-dropped sc/*" -- overlooked the aliasing, and the change it prompted is undone here).
+            scene_l, gt_l = self._perturb_latent_inputs(scene, gt, lp["yaw"], lp["pos"])
             enc_l = self.engine.encode_scene(scene_l)
             post = self.engine.encode_posterior(gt_l, enc_l)
             latent_post = DiagGaussian(post["latent_mean"], self.model._log_std_post, valid=as_bool(post["latent_valid"]), engine=self.engine)
