@@ -134,7 +134,58 @@ def compare_val(case: dict) -> dict:
     return rep
 
 
+def main_train() -> int:
+    """Train-mode Bernoulli masks (input / posterior history dropout, hidden-state drop) with explicit draws: the body of the reference's
+    training_step (tools/gen_golden_val.py::run_reference_training, fp32) against `Oracle.reactive_replay(history_keep=, hidden_drop=)`."""
+    import gen_golden_val
+
+    n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 20260932)
+    lines, bad, t0 = [], 0, time.time()
+    for i in range(n_cases):
+        a, p_, t = int(rng.integers(2, 14)), int(rng.integers(3, 30)), int(rng.integers(1, 12))
+        case = dict(base_seed=int(rng.integers(1, 2**30)), n_scene=int(rng.integers(2, 4)), weight_seed=int(rng.integers(1, 1000)),
+                    time_step_end=int(rng.integers(15, 41)), draws_seed=int(rng.integers(1, 2**30)),
+                    overrides={"pre_processing.input.dropout_p_history": float(rng.uniform(0.05, 0.5)),
+                               "pre_processing.latent.dropout_p_history": float(rng.uniform(0.05, 0.5)), "p_drop_hidden": float(rng.uniform(0.03, 0.3))},
+                    scene=dict(n_agent=a, n_pl=p_, n_tl=t, p_invalid_agent=float(rng.choice([0.0, 0.3])), p_late_spawn=float(rng.choice([0.0, 0.3])),
+                               p_future_spawn=float(rng.choice([0.0, 0.5])), p_future_exit=float(rng.choice([0.0, 0.3])), pos_range=float(rng.choice([40.0, 100.0]))))
+        tag = f"train case {i:3d} B={case['n_scene']} A={a:2d} P={p_:2d} T={t:2d} S={case['time_step_end']} p=({case['overrides']['pre_processing.input.dropout_p_history']:.2f}, {case['overrides']['pre_processing.latent.dropout_p_history']:.2f}, {case['overrides']['p_drop_hidden']:.2f})"
+        try:
+            g = gen_golden_val.run_reference_training(case)
+            over = {"time_step_end": case["time_step_end"], "n_joint_future": 1, **case["overrides"]}
+            cfg = load_model_config(overrides=over)
+            sc, ov = case["scene"], case["overrides"]
+            n_step = case["time_step_end"] - cfg["time_step_sim_start"] + 1
+            draws = synth.make_train_draws(case["draws_seed"], case["n_scene"], sc["n_agent"], sc["n_pl"], sc["n_tl"], n_step,
+                                           ov["pre_processing.input.dropout_p_history"], ov["pre_processing.latent.dropout_p_history"], ov["p_drop_hidden"])
+            batch = synth.make_val_batch(case["base_seed"], case["n_scene"], **sc)
+            eps = synth.make_latent_noise(case["base_seed"] + 99, case["n_scene"], sc["n_agent"])
+            with torch.no_grad():
+                r = Oracle(synth.make_state_dict(case["weight_seed"]), cfg, torch.float32).reactive_replay(
+                    batch, case["time_step_end"], tf_cfg_name="teacher_forcing_training", eps=eps, history_keep=draws, hidden_drop=draws["hidden_drop"])
+        except Exception as e:
+            lines.append(f"{tag}: NOT RUN ({type(e).__name__}: {str(e)[:120]})")
+            print(lines[-1], flush=True)
+            continue
+        masks = sum(int((r[k].numpy() != g[k]).sum()) for k in ("post_valid", "prior_valid", "valid", "override_masks"))
+        e_mean = max(float(np.abs(r["post_mean"].numpy() - g["post_mean"]).max()), float(np.abs(r["prior_mean"].numpy() - g["prior_mean"]).max()))
+        e_xy = float((np.abs(r["preds"].numpy() - g["preds"]) * g["valid"][..., None]).max())
+        ok = masks == 0 and e_mean <= 2e-6 and e_xy <= 1e-4
+        bad += int(not ok)
+        lines.append(f"{tag}: {'ok' if ok else 'DIFFERS'} masks {masks} means {e_mean:.1e} preds {e_xy:.1e}")
+        print(lines[-1], flush=True)
+    head = [f"# tools/fuzz_oracle_vs_reference.py --train: train-mode masks with explicit draws, the reference's training_step body (fp32) against the oracle (fp32);",
+            f"# masks equal, personality means <= 2e-6, trajectories <= 1e-4 m (<= 40 steps).  {n_cases - sum('NOT RUN' in l for l in lines)} cases run, {bad} differ; {time.time() - t0:.0f} s."]
+    open(os.path.join(ROOT, "profiles", "r06_oracle_vs_reference_fuzz_train.txt"), "w").write("\n".join(head + lines) + "\n")
+    print("\n".join(head))
+    return 1 if bad else 0
+
+
 def main() -> int:
+    if "--train" in sys.argv:
+        sys.argv.remove("--train")
+        return main_train()
     if "--val" in sys.argv:
         sys.argv.remove("--val")
         return main_val()
