@@ -17,4 +17,5 @@ run FUZZ_SEED=56 timeout 900 python tests/probes/gpu_fuzz_warm_start.py 64
 # round 6: the case generator the oracle is held to the reference with (tools/fuzz_cases.py): edge scenes, config overrides, weight modes
 run FUZZ_SEED=777 timeout 900 python tests/probes/gpu_fuzz_cases.py 120
 run FUZZ_SEED=778 timeout 900 python tests/probes/gpu_fuzz_cases.py 120
+run FUZZ_SEED=991 timeout 900 python tests/probes/gpu_fuzz_training.py 60
 cat $O
