@@ -756,6 +756,19 @@ class Oracle:
             av[:, :-1] &= kb("input_agent")
             inp_enc = dict(inp, agent_valid=av, tl_valid=inp["tl_valid"] & kb("input_tl"), map_valid=inp["map_valid"] & kb("input_map"))
             gt_enc = dict(gt, agent_valid=gt["agent_valid"] & kb("post_agent"), tl_valid=gt["tl_valid"] & kb("post_tl"))
+            if av.shape[0] == 1:
+                # A batch of ONE scene (found by tools/fuzz_oracle_vs_reference.py --train with n_scene = 1): `sc/agent_valid =
+                # batch["agent/valid"][:, :n_step_hist].contiguous()` (scene_centric.py:92-99; likewise tl) is a VIEW when the batch
+                # dimension is 1 -- the slice is already contiguous -- so the history tensors and the first steps of the ground truth share
+                # storage and every in-place `&=` (sc_input.py:105-113, sc_latent.py:171-173,216-218) lands on both: the history carries
+                # the posterior's masks, the ground truth's first steps the input's.  With two or more scenes the slice is a copy.
+                nh = av.shape[1]
+                av_all = inp_enc["agent_valid"] & gt_enc["agent_valid"][:, :nh]
+                tl_all = inp_enc["tl_valid"] & gt_enc["tl_valid"][:, :nh]
+                inp_enc = dict(inp_enc, agent_valid=av_all, tl_valid=tl_all)
+                ga, gtl = gt_enc["agent_valid"].clone(), gt_enc["tl_valid"].clone()
+                ga[:, :nh], gtl[:, :nh] = av_all, tl_all
+                gt_enc = dict(gt_enc, agent_valid=ga, tl_valid=gtl)
         f = self.encode_scene(inp_enc)
         post_mean, post_log_std, post_valid = self.latent_post(f, gt_enc)
         prior_mean, prior_log_std, prior_valid = self.latent_prior(f)

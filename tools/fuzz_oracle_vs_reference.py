@@ -144,7 +144,7 @@ def main_train() -> int:
     lines, bad, t0 = [], 0, time.time()
     for i in range(n_cases):
         a, p_, t = int(rng.integers(2, 14)), int(rng.integers(3, 30)), int(rng.integers(1, 12))
-        case = dict(base_seed=int(rng.integers(1, 2**30)), n_scene=int(rng.integers(2, 4)), weight_seed=int(rng.integers(1, 1000)),
+        case = dict(base_seed=int(rng.integers(1, 2**30)), n_scene=int(rng.integers(1, 4)), weight_seed=int(rng.integers(1, 1000)),
                     time_step_end=int(rng.integers(15, 41)), draws_seed=int(rng.integers(1, 2**30)),
                     overrides={"pre_processing.input.dropout_p_history": float(rng.uniform(0.05, 0.5)),
                                "pre_processing.latent.dropout_p_history": float(rng.uniform(0.05, 0.5)), "p_drop_hidden": float(rng.uniform(0.03, 0.3))},

@@ -1098,6 +1098,22 @@ class WaymoMotion:
             gt.pop("_tf_mask", None)
             gt.pop("_tf_params", None)
             scene = dict(scene, gt=gt)
+        if b == 1 and (scene.get("warm_ok") is False or gt.get("warm_ok") is False):
+            # A batch of ONE scene: in the reference `sc/agent_valid = batch["agent/valid"][:, :n_step_hist].contiguous()` (likewise the
+            # traffic lights; `scene_centric.py:92-99`) is a VIEW when the batch dimension is 1 -- the slice is contiguous already -- so
+            # the history and the first steps of the ground truth share storage, and every in-place `&=` of the two pre-processing
+            # modules lands on both (found by tools/fuzz_oracle_vs_reference.py --train at n_scene = 1; with >= 2 scenes it is a copy)
+            av_all = scene["agent_valid"].bool() & gt["agent_valid"][:, :nh].bool()
+            tl_all = scene["tl_valid"].bool() & gt["tl_valid"][:, :nh].bool()
+            ga, gtl = gt["agent_valid"].clone(), gt["tl_valid"].clone()
+            ga[:, :nh], gtl[:, :nh] = av_all.to(ga.dtype), tl_all.to(gtl.dtype)
+            gt = dict(gt, agent_valid=ga.contiguous(), tl_valid=gtl.contiguous(), warm_ok=False)
+            gt.pop("_tf_mask", None)
+            gt.pop("_tf_params", None)
+            scene = dict(scene, agent_valid=av_all.to(torch.uint8).contiguous(), tl_valid=tl_all.to(torch.uint8).contiguous(), warm_ok=False, gt=gt)
+            for stale in ("_goal_valid", "_tf_mask", "_tf_params"):
+                scene.pop(stale, None)
+            scene.update({"input/agent_valid": av_all, "input/tl_valid": tl_all, "latent_prior/agent_valid": av_all, "latent_prior/tl_valid": tl_all})
         if hidden_drop is None and p_hid > 0:
             n_step = hp["time_step_end"] - hp["time_step_sim_start"] + 1
             hidden_drop = (torch.rand(n_step, device=dev, generator=generator) < p_hid).cpu()
