@@ -27,6 +27,7 @@ fails = 0
 for ci in range(n_cases):
     case = draw_case(rng)
     case.pop("rule_flags", None)  # (flag-gated checks: tests/probes/gpu_fuzz_rules_post_metrics.py)
+    case.pop("action_override", None)  # (per-call action overrides belong to the stepwise API: tests/test_gpu_boundary.py)
     sc, k, n_scene, step_end = case["scene"], case["k"], case["n_scene"], case["time_step_end"]
     over = {"time_step_end": step_end, "n_joint_future": k, **case["overrides"]}
     cfg = load_model_config(overrides=over)

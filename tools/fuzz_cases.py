@@ -32,6 +32,8 @@ def draw_case(rng) -> dict:
         case["action_noise"] = True
     if rng.random() < 0.25:
         case["rule_flags"] = True
+    if rng.random() < 0.2:  # `forward(action_override=, mask_action_override=)` at every step (dynamics.py:96-100; the stepwise API of the mirror)
+        case["action_override"] = True
     return case
 
 

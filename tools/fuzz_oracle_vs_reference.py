@@ -49,8 +49,12 @@ def compare(case: dict) -> dict:
     act = None
     if case.get("action_noise"):
         act = synth.make_action_noise(case["base_seed"] + 77, n, sc["n_agent"], case["time_step_end"] - cfg["time_step_sim_start"] + 1)
+    act_ov = None
+    if case.get("action_override"):
+        act_ov = synth.make_action_override(case["base_seed"] + 55, n, sc["n_agent"], case["time_step_end"] - cfg["time_step_sim_start"] + 1)
     with torch.no_grad():
-        r = Oracle(sd, cfg, torch.float64).joint_future_pred(batch, case["k"], eps, case["time_step_end"], dest_override=dest, action_eps=act)
+        r = Oracle(sd, cfg, torch.float64).joint_future_pred(batch, case["k"], eps, case["time_step_end"], dest_override=dest, action_eps=act,
+                                                             action_override=act_ov)
     rep = {}
     for k in BOOL_KEYS:
         if k in ref and k in r:
@@ -199,7 +203,7 @@ def main() -> int:
         case = draw_case(rng)
         tag = (f"case {i:3d} B={case['n_scene']} K={case['k']} A={case['scene']['n_agent']:2d} P={case['scene']['n_pl']:2d} T={case['scene']['n_tl']:2d} "
                f"S={case['time_step_end']} edge={case['scene'].get('edge', '-')} w={case.get('weight_mode', 'default')} "
-               f"{'act-noise ' if case.get('action_noise') else ''}{'rules ' if case.get('rule_flags') else ''}over={sorted(k.split('.')[-1] for k in case['overrides'])}")
+               f"{'act-noise ' if case.get('action_noise') else ''}{'act-override ' if case.get('action_override') else ''}{'rules ' if case.get('rule_flags') else ''}over={sorted(k.split('.')[-1] for k in case['overrides'])}")
         try:
             rep = compare(case)
         except Exception as e:  # a case the reference itself cannot run is reported, not counted
