@@ -42,6 +42,8 @@ for ci in range(n_cases):
             "training_metrics.kl_balance_scale": float(rng.choice([-1.0, 0.8])),
             "training_metrics.kl_free_nats": float(rng.choice([-1.0, 0.01, 5.0])),
             "training_metrics.step_training_start": int(rng.choice([0, 10]))}
+    if os.environ.get("FUZZ_CUR"):  # (round 6: a shorter history for the encoders -- FUZZ_CUR=5 -- on top of the draws above, which stay the same)
+        over["time_step_current"] = int(os.environ["FUZZ_CUR"])
     seed = 30000 + ci
     if os.environ.get("FUZZ_ONLY") and ci != int(os.environ["FUZZ_ONLY"]):
         continue  # (after the draws, so that case ci is the same case as in a full run)

@@ -93,7 +93,7 @@ def draw_val_case(rng) -> dict:
     sc = c["scene"]
     sc.update(p_future_spawn=float(rng.choice([0.0, 0.4, 0.8])), p_future_exit=float(rng.choice([0.0, 0.3])))
     sc["n_pl"] = max(sc["n_pl"], 3)
-    over = {k: v for k, v in c["overrides"].items() if k.startswith("dynamics.")}
+    over = {k: v for k, v in c["overrides"].items() if k.startswith("dynamics.") or k == "time_step_current"}  # (the replay's warm start follows it)
     if rng.random() < 0.5:
         over.update({"differentiable_reward.w_collision": float(rng.choice([0.0, 0.5, 1.0])),
                      "differentiable_reward.reduce_collsion_with_max": bool(rng.random() < 0.5),
