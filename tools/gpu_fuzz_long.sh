@@ -18,4 +18,5 @@ run FUZZ_SEED=56 timeout 900 python tests/probes/gpu_fuzz_warm_start.py 64
 run FUZZ_SEED=777 timeout 900 python tests/probes/gpu_fuzz_cases.py 120
 run FUZZ_SEED=778 timeout 900 python tests/probes/gpu_fuzz_cases.py 120
 run FUZZ_SEED=991 timeout 900 python tests/probes/gpu_fuzz_training.py 60
+run FUZZ_SEED=313 timeout 900 python tests/probes/gpu_fuzz_stepwise.py 60
 cat $O
