@@ -26,6 +26,8 @@ worst = {"xy": 0.0, "one_shot": 0.0, "logp": 0.0}
 fails = 0
 for ci in range(n_cases):
     case = draw_case(rng)
+    if os.environ.get("FUZZ_ONLY") and ci != int(os.environ["FUZZ_ONLY"]):
+        continue  # (after the draw, so that case ci is the same case as in a full run)
     case.pop("rule_flags", None)  # (flag-gated checks: tests/probes/gpu_fuzz_rules_post_metrics.py)
     case.pop("action_override", None)  # (per-call action overrides belong to the stepwise API: tests/test_gpu_boundary.py)
     sc, k, n_scene, step_end = case["scene"], case["k"], case["n_scene"], case["time_step_end"]
@@ -38,7 +40,7 @@ for ci in range(n_cases):
     act = None
     if case.get("action_noise"):
         act = synth.make_action_noise(case["base_seed"] + 77, n, a, step_end - cfg["time_step_sim_start"] + 1)
-    wm = WaymoMotion(**over)
+    wm = WaymoMotion(**over, **({"operand_precision": os.environ["FUZZ_PRECISION"]} if os.environ.get("FUZZ_PRECISION") else {}))
     wm.load_state_dict(sd)
     out = wm.test_step(batch, latent_eps=torch.from_numpy(eps).cuda(), generator=torch.Generator(device="cuda").manual_seed(case["base_seed"] % 2**31),
                        action_eps=None if act is None else torch.from_numpy(act).cuda())
@@ -76,6 +78,15 @@ for ci in range(n_cases):
         msgs.append(f"one-shot tolerance (largest feature entry {scale:.3g})")
     if e_logp > 2e-4:
         msgs.append("log-prob tolerance")
+    if os.environ.get("FUZZ_VERBOSE"):
+        with torch.no_grad():
+            r64v = Oracle(sd, cfg, torch.float64).joint_future_pred(batch, k, eps, step_end, dest_override=dest, action_eps=act)
+        d32 = ((buf.preds.cpu() - r["preds"]).abs() * v.unsqueeze(-1))[..., :2].amax(dim=(0, 1, 2, 4))
+        d64 = ((buf.preds.cpu().double() - r64v["preds"]).abs() * v.unsqueeze(-1))[..., :2].amax(dim=(0, 1, 2, 4))
+        o64 = ((r["preds"].double() - r64v["preds"]).abs() * v.unsqueeze(-1))[..., :2].amax(dim=(0, 1, 2, 4))
+        print("   per step |hip - oracle32|:", " ".join(f"{x:.0e}" for x in d32.tolist()))
+        print("   per step |hip - oracle64|:", " ".join(f"{x:.0e}" for x in d64.tolist()))
+        print("   per step |o32 - oracle64|:", " ".join(f"{x:.0e}" for x in o64.tolist()))
     if e_xy > 1e-4:
         # beyond north_star's flat bound: the parity tests' ONE closed-loop rule (tools/ensemble.py::closed_loop_rule) against an ensemble
         # measured on the spot -- 16 fp32 oracle runs on re-ordered batches with re-ordered Linear sums -- as tests/probes/
