@@ -438,3 +438,22 @@ def test_warm_schedule_is_generated_from_the_committed_stage_profile():
 
     assert "WS_PROLOGUE" in body and "WS_TL_LAYER" in body
     assert not re.search(r"\b\d{4,}\.0\b", body), "a literal cycle count in the warm table"
+
+
+def test_rollout_source_of_test_step_is_the_whole_history_of_the_batch():
+    """Round 6 (tools/fuzz_oracle_vs_reference.py): `test_step` hands the rollout batch["agent/*"] = batch["history/agent/*"] over ALL
+    history steps of the batch (`waymo_motion.py:925-926, 538-545`), whatever time_step_current says; `runtime.hist_from_batch` builds
+    that source (layout of the agent part of `gt_from_batch`), the teacher-forcing mask over all of its steps included."""
+    from trafficbots_amd import synth
+    from trafficbots_amd.runtime import hist_from_batch, history_len, scene_from_batch, teacher_forcing_mask
+
+    batch = synth.make_batch(77, 2, n_agent=6, n_pl=8, n_tl=3, p_late_spawn=0.6)
+    assert history_len(batch) == 11 and history_len({"agent/valid": np.zeros((1, 91, 2))}) == 0
+    hist = hist_from_batch(batch, "cpu", n_hist=6, tf_params=(8, 3))
+    scene = scene_from_batch(batch, "cpu", 6)
+    assert tuple(scene["agent_valid"].shape) == (2, 6, 6) and tuple(hist["agent_valid"].shape) == (2, 11, 6)
+    assert torch.equal(hist["agent_valid"][:, :6], scene["agent_valid"]) and torch.equal(hist["agent_state"][:, :6], scene["agent_state"])
+    assert tuple(hist["agent_state"].shape) == (2, 11, 6, 4) and tuple(hist["agent_acc"].shape) == (2, 11, 6)
+    want = teacher_forcing_mask(torch.from_numpy(np.asarray(batch["history/agent/valid"])), 8, 3)
+    assert torch.equal(hist["_tf_mask"].bool(), want) and hist["_tf_params"] == (8, 3)
+    assert want[:, 6:9].any(), "the case should spawn agents beyond step 5: that is what a truncated history would lose"
