@@ -111,7 +111,7 @@ def compare_val(case: dict) -> dict:
     import gen_golden_val
     from oracle import training_oracle as TO
 
-    ref = gen_golden_val.run_reference(case, torch.float64)
+    ref = gen_golden_val.run_reference(case, torch.float64, with_jfp=True)
     over = {"time_step_end": case["time_step_end"], "n_joint_future": 1, **case["overrides"]}
     cfg = load_model_config(overrides=over)
     sd = synth.case_state_dict(case)
@@ -135,6 +135,18 @@ def compare_val(case: dict) -> dict:
                                    cfg["training_metrics"])
     got = np.array([st[k] for k in TRAIN_FIELDS], np.float64)
     rep["train_states_rel"] = float(np.max(np.abs(got - ref["train_states"]) / np.maximum(1.0, np.abs(ref["train_states"]))))
+    # second half of validation_step: joint_future_pred on the 91-step ground truth (`Oracle.joint_future_pred(use_gt=True)`)
+    dest = np.transpose(ref["jfp/goal_sample"], (0, 2, 1)).reshape(case["n_scene"], -1)
+    with torch.no_grad():
+        j = Oracle(sd, cfg, dtype=torch.float64).joint_future_pred(batch, 1, None, case["time_step_end"], dest_override=dest, use_gt=True)
+    own = j["dest_logits_raw"].argmax(-1).numpy()
+    rep["jfp/argmax_dest"] = int((own != ref["jfp/goal_sample"][:, :, 0]).sum())
+    for k in ("valid", "override_masks", "outside_map", "dest_reached", "goal_reached"):
+        rep["jfp/" + k] = int((j[k].numpy() != ref["jfp/" + k]).sum())
+    jv = ref["jfp/valid"][..., None]
+    rep["jfp/preds"] = float((np.abs(j["preds"].numpy() - ref["jfp/preds"]) * jv).max())
+    rep["jfp/action_log_probs"] = float((np.abs(j["action_log_probs"].numpy() - ref["jfp/action_log_probs"]) * ref["jfp/valid"]).max())
+    rep["jfp/latent_log_probs"] = float(np.abs(j["latent_log_probs"].numpy() - ref["jfp/latent_log_probs"]).max())
     return rep
 
 
@@ -255,7 +267,8 @@ def main_val() -> int:
         lines.append(f"{tag}: {'ok' if ok else 'DIFFERS'} preds {rep['preds']:.1e}" + ("" if ok else f"  {json.dumps({**ints, **{k: v for k, v in flts.items() if v > 1e-9}})}"))
         print(lines[-1], flush=True)
     head = [f"# tools/fuzz_oracle_vs_reference.py --val {n_cases} {seed}: the validation path (posterior / prior personalities, reactive replay from the ground truth,",
-            "# differentiable rewards, TrainingMetrics states) of the CPU oracles against the imported reference, both fp64, random cases; bound 1e-9",
+            "# differentiable rewards, TrainingMetrics states; then joint_future_pred on the 91-step ground truth -- kill rule, goal_reached -- as the second",
+            "# half of validation_step runs it) of the CPU oracles against the imported reference, both fp64, random cases; bound 1e-9",
             "# (TrainingMetrics states: 1e-6 relative, the reference accumulates them in float32).",
             f"# {n_cases - sum('NOT RUN' in l for l in lines)} cases run, {bad} differ; {time.time() - t0:.0f} s.",
             "# worst difference per quantity: " + ", ".join(f"{k} {v:.1e}" for k, v in sorted(worst.items()))]

@@ -91,7 +91,7 @@ RULE = ("counter_agent", "counter_veh", "outside_map", "collided", "run_road_edg
 N_ENSEMBLE = 32
 
 
-def run_reference(case: dict, dtype=torch.float32, perturb=None, channel_seed=None) -> dict:
+def run_reference(case: dict, dtype=torch.float32, perturb=None, channel_seed=None, with_jfp: bool = False) -> dict:
     """`channel_seed`: the member also runs on a channel-re-labelled copy of the weights (tools/channel_perm.py).
     `perturb` = seed of an ensemble member (tools/ensemble.py: agent slots, polylines, stop points permuted per scene); only the
     replayed trajectory comes back, in the original agent order."""
@@ -182,6 +182,16 @@ def run_reference(case: dict, dtype=torch.float32, perturb=None, channel_seed=No
             comp = tm.compute()
             out["train_compute_json"] = np.frombuffer(json.dumps({k: float(v) for k, v in comp.items()}).encode(), np.uint8)
             out["final_state"], out["final_valid"] = model.dynamics.agent_state.clone(), model.dynamics.agent_valid.clone()
+            if with_jfp:
+                # the second half of validation_step (`waymo_motion.py:683-690`): joint_future_pred with the PRIOR personality and the
+                # PREDICTED destinations while batch["agent/*"] is still the 91-step ground truth (kill rule, goal_reached); K = 1 here:
+                # the one future is the deterministic one (prior mean, argmax destination) -- tools/fuzz_oracle_vs_reference.py --val
+                jb, jgs, jglp = model.joint_future_pred(batch=batch, input_feature_dict=feats, latent=latent_prior, goal=goal_pred,
+                                                        goal_valid=goal_valid, require_vis_dict=False)
+                out.update({"jfp/preds": jb.preds.clone(), "jfp/valid": jb.valid.clone(), "jfp/override_masks": jb.override_masks.clone(),
+                            "jfp/outside_map": jb.violations["outside_map"].clone(), "jfp/dest_reached": jb.violations["dest_reached"].clone(),
+                            "jfp/goal_reached": jb.violations["goal_reached"].clone(), "jfp/goal_sample": jgs.clone(),
+                            "jfp/action_log_probs": jb.action_log_probs.clone(), "jfp/latent_log_probs": jb.latent_log_probs.clone()})
     finally:
         torch.set_default_dtype(torch.float32)
     return {k: (v.detach().cpu().numpy() if torch.is_tensor(v) else v) for k, v in out.items()}
