@@ -103,8 +103,12 @@ def draw_val_case(rng) -> dict:
                      "training_metrics.kl_for_unseen_agent": bool(rng.random() < 0.5),
                      "training_metrics.kl_balance_scale": float(rng.choice([-1.0, 0.8])),
                      "training_metrics.kl_free_nats": float(rng.choice([-1.0, 0.01]))})
+    extra = {}
+    if rng.random() < 0.3:  # training.py:85-89: agents without a role keep their loss terms only where a Bernoulli draw says so (stored draw)
+        over["training_metrics.p_loss_for_irrelevant"] = float(rng.choice([0.3, 0.6]))
+        extra["irrelevant_seed"] = int(rng.integers(1, 2**30))
     return dict(base_seed=c["base_seed"], n_scene=c["n_scene"], weight_seed=c["weight_seed"], time_step_end=int(rng.integers(15, 91)),
-                overrides=over, scene=sc, fp64=True, **({"weight_mode": c["weight_mode"]} if "weight_mode" in c else {}))
+                overrides=over, scene=sc, fp64=True, **extra, **({"weight_mode": c["weight_mode"]} if "weight_mode" in c else {}))
 
 
 def compare_val(case: dict) -> dict:
@@ -132,7 +136,8 @@ def compare_val(case: dict) -> dict:
     rep["diffbar_rewards"] = float(np.abs(np.where(both, rew.numpy() - ref["diffbar_rewards"], 0)).max())
     st = TO.training_metric_states(r["valid"], rv, rew, r["override_masks"], r["agent_role"], r["dest_logits_raw"], r["goal_valid"], r["gt_dest"],
                                    r["post_mean"], r["post_log_std"], r["post_valid"], r["prior_mean"], r["prior_log_std"], r["prior_valid"],
-                                   cfg["training_metrics"])
+                                   cfg["training_metrics"],
+                                   irrelevant_draw=torch.from_numpy(ref["irrelevant_draw"]) if "irrelevant_draw" in ref else None)
     got = np.array([st[k] for k in TRAIN_FIELDS], np.float64)
     rep["train_states_rel"] = float(np.max(np.abs(got - ref["train_states"]) / np.maximum(1.0, np.abs(ref["train_states"]))))
     # second half of validation_step: joint_future_pred on the 91-step ground truth (`Oracle.joint_future_pred(use_gt=True)`)
